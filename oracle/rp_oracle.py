@@ -1,0 +1,148 @@
+"""ctypes wrapper for the CPU oracle (TEST INFRASTRUCTURE — see rp_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module.  PARITY UNPINNED (no MuJoCo in the reference tree or image).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "librp_oracle.so")
+
+FIELDS = dict(
+    qpos=0, qvel=1, qacc=2, qacc_warmstart=3, ctrl=4, qfrc_applied=5,
+    actuator_force=6, actuator_velocity=7, actuator_length=8, xpos=9, xmat=10,
+    geom_xpos=11, geom_xmat=12, site_xpos=13, qM=14, qfrc_bias=15, qfrc_passive=16,
+    qfrc_actuator=17, qfrc_smooth=18, qacc_smooth=19, qfrc_constraint=20,
+    efc_force=21, efc_aref=22, efc_D=23, efc_pos=24, efc_J=25, contact=26, time=27,
+    body_pos=28,
+)
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "rp_oracle.c")
+    if (force or not os.path.exists(_LIB_PATH)
+            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "librp_oracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.rpo_model_load.restype = ctypes.c_void_p
+        L.rpo_model_load.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+        L.rpo_model_free.argtypes = [ctypes.c_void_p]
+        L.rpo_data_new.restype = ctypes.c_void_p
+        L.rpo_data_new.argtypes = [ctypes.c_void_p]
+        L.rpo_data_free.argtypes = [ctypes.c_void_p]
+        for f in ("rpo_reset", "rpo_forward", "rpo_step"):
+            getattr(L, f).argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.rpo_get_ptr.restype = ctypes.POINTER(ctypes.c_double)
+        L.rpo_get_ptr.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        for f in ("rpo_ncon", "rpo_nefc", "rpo_solver_iter", "rpo_warnings"):
+            getattr(L, f).argtypes = [ctypes.c_void_p]
+            getattr(L, f).restype = ctypes.c_int
+        L.rpo_bench.restype = ctypes.c_double
+        L.rpo_bench.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+class Oracle:
+    """One fp64 environment stepped by the CPU oracle."""
+
+    def __init__(self, model, blob: bytes):
+        self.m = model
+        self._L = lib()
+        self._blob = blob
+        self._model = self._L.rpo_model_load(blob, len(blob))
+        if not self._model:
+            raise RuntimeError("rpo_model_load failed (bad blob)")
+        self._data = self._L.rpo_data_new(self._model)
+        self.reset()
+
+    def __del__(self):
+        try:
+            self._L.rpo_data_free(self._data)
+            self._L.rpo_model_free(self._model)
+        except Exception:
+            pass
+
+    def _size(self, name):
+        m = self.m
+        return dict(
+            qpos=m.nv, qvel=m.nv, qacc=m.nv, qacc_warmstart=m.nv, ctrl=m.nu,
+            qfrc_applied=m.nv, actuator_force=m.nu, actuator_velocity=m.nu,
+            actuator_length=m.nu, xpos=3 * m.nbody, xmat=9 * m.nbody,
+            geom_xpos=3 * m.ngeom, geom_xmat=9 * m.ngeom, site_xpos=3 * m.nsite,
+            qM=m.nv * m.nv, qfrc_bias=m.nv, qfrc_passive=m.nv, qfrc_actuator=m.nv,
+            qfrc_smooth=m.nv, qacc_smooth=m.nv, qfrc_constraint=m.nv,
+            efc_force=self.nefc, efc_aref=self.nefc, efc_D=self.nefc,
+            efc_pos=self.nefc, efc_J=self.nefc * m.nv, contact=16 * self.ncon, time=1,
+            body_pos=3 * m.nbody,
+        )[name]
+
+    def view(self, name) -> np.ndarray:
+        """Writable numpy view of an oracle array."""
+        n = self._size(name)
+        p = self._L.rpo_get_ptr(self._model, self._data, FIELDS[name])
+        if n == 0:
+            return np.zeros(0)
+        return np.ctypeslib.as_array(p, shape=(n,))
+
+    def __getattr__(self, name):
+        if name in FIELDS:
+            return self.view(name)
+        raise AttributeError(name)
+
+    @property
+    def ncon(self):
+        return self._L.rpo_ncon(self._data)
+
+    @property
+    def nefc(self):
+        return self._L.rpo_nefc(self._data)
+
+    @property
+    def solver_iter(self):
+        return self._L.rpo_solver_iter(self._data)
+
+    @property
+    def warnings(self):
+        return self._L.rpo_warnings(self._data)
+
+    def reset(self):
+        self._L.rpo_reset(self._model, self._data)
+
+    def forward(self):
+        self._L.rpo_forward(self._model, self._data)
+
+    def step(self, n: int = 1):
+        for _ in range(n):
+            self._L.rpo_step(self._model, self._data)
+
+    def bench(self, nenv, nstep, ctrl=None, nthreads=0):
+        """Returns (seconds, qpos[nenv, nv])."""
+        out = np.zeros((nenv, self.m.nv))
+        c = None
+        if ctrl is not None:
+            c = np.ascontiguousarray(ctrl, np.float64)
+            assert c.shape == (nenv, self.m.nu)
+        t = self._L.rpo_bench(
+            self._model, nenv, nstep,
+            c.ctypes.data if c is not None else None, nthreads, out.ctypes.data)
+        return t, out

@@ -1,0 +1,471 @@
+"""Scene -> flat model arrays (the role `mj_compile` + `mj_setConst` play for the
+reference, reached there via dm_control: robopianist/suite/__init__.py:87-93).
+
+`compile_scene` returns a `Model`: a dict of numpy arrays with MuJoCo-style
+names (body_*, jnt_*, dof_*, geom_*, actuator_*, tendon_*, opt_*), plus name
+tables.  Quantities that MuJoCo derives at compile time are derived here at
+qpos0 with an independent numpy implementation (Jacobian-sum mass matrix):
+
+  dof_M0, dof_invweight0, body_invweight0, stat_meaninertia   [mj_setConst]
+  geom_rbound, static collision-pair list                      [mj_collision filters]
+
+The blob is the single source of model constants for BOTH the CPU oracle and
+the HIP engine, so neither can "agree by construction" on the dynamics — they
+only share inputs.
+"""
+
+from __future__ import annotations
+
+import io
+import struct
+from typing import Dict, List
+
+import numpy as np
+
+from robopianist_amd.model import spec
+
+MINVAL = 1e-15  # mjMINVAL
+
+BLOB_MAGIC = 0x52504D42  # 'RPMB'
+BLOB_VERSION = 3
+
+
+class Model(dict):
+    """dict of numpy arrays + name tables, attribute access for convenience."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def name2id(self, kind: str, name: str) -> int:
+        return self.names[kind].index(name)
+
+
+def _box_inertia(mass, size):
+    sx, sy, sz = size
+    return np.array([
+        mass * (sy * sy + sz * sz) / 3.0,
+        mass * (sx * sx + sz * sz) / 3.0,
+        mass * (sx * sx + sy * sy) / 3.0,
+    ])
+
+
+def _flatten(scene: spec.Scene):
+    bodies, parents = [], []
+
+    def rec(b, parent):
+        idx = len(bodies)
+        bodies.append(b)
+        parents.append(parent)
+        for c in b.children:
+            rec(c, idx)
+
+    rec(scene.world, 0)
+    return bodies, parents
+
+
+def kinematics(m: Model, qpos: np.ndarray):
+    """Forward kinematics (numpy, compile-time / test helper)."""
+    nb = m.nbody
+    xpos = np.zeros((nb, 3))
+    xquat = np.zeros((nb, 4))
+    xquat[0] = (1, 0, 0, 0)
+    xanchor = np.zeros((m.njnt, 3))
+    xaxis = np.zeros((m.njnt, 3))
+    for b in range(1, nb):
+        p = m.body_parentid[b]
+        pmat = spec.quat_to_mat(xquat[p])
+        pos = xpos[p] + pmat @ m.body_pos[b]
+        quat = spec.quat_mul(xquat[p], m.body_quat[b])
+        for j in range(m.body_jntadr[b], m.body_jntadr[b] + m.body_jntnum[b]):
+            mat = spec.quat_to_mat(quat)
+            axis = mat @ m.jnt_axis[j]
+            anchor = pos + mat @ m.jnt_pos[j]
+            q = qpos[j] - m.qpos0[j]
+            if m.jnt_type[j] == spec.JNT_SLIDE:
+                pos = pos + axis * q
+            else:
+                dq = spec.axis_angle_to_quat(m.jnt_axis[j], q)
+                quat = spec.quat_mul(quat, dq)
+                # keep the anchor fixed
+                pos = anchor - spec.quat_to_mat(quat) @ m.jnt_pos[j]
+            xanchor[j] = anchor
+            xaxis[j] = axis
+        xpos[b] = pos
+        xquat[b] = spec.quat_normalize(quat)
+    xmat = np.stack([spec.quat_to_mat(q) for q in xquat])
+    xipos = xpos + np.einsum("bij,bj->bi", xmat, m.body_ipos)
+    ximat = np.stack([xmat[b] @ spec.quat_to_mat(m.body_iquat[b]) for b in range(nb)])
+    return dict(xpos=xpos, xquat=xquat, xmat=xmat, xipos=xipos, ximat=ximat,
+                xanchor=xanchor, xaxis=xaxis)
+
+
+def jac(m: Model, kin, point, body):
+    """Translational / rotational Jacobian of `point` attached to `body`."""
+    jacp = np.zeros((3, m.nv))
+    jacr = np.zeros((3, m.nv))
+    b = body
+    while b > 0:
+        for j in range(m.body_jntadr[b], m.body_jntadr[b] + m.body_jntnum[b]):
+            ax = kin["xaxis"][j]
+            if m.jnt_type[j] == spec.JNT_SLIDE:
+                jacp[:, j] = ax
+            else:
+                jacr[:, j] = ax
+                jacp[:, j] = np.cross(ax, point - kin["xanchor"][j])
+        b = m.body_parentid[b]
+    return jacp, jacr
+
+
+def mass_matrix(m: Model, kin):
+    """Dense joint-space inertia via sum_b J_b^T diag(m, I_b) J_b + armature."""
+    M = np.zeros((m.nv, m.nv))
+    for b in range(1, m.nbody):
+        if m.body_mass[b] <= 0:
+            continue
+        jp, jr = jac(m, kin, kin["xipos"][b], b)
+        I = kin["ximat"][b] @ np.diag(m.body_inertia[b]) @ kin["ximat"][b].T
+        M += m.body_mass[b] * jp.T @ jp + jr.T @ I @ jr
+    M += np.diag(m.dof_armature)
+    return M
+
+
+def compile_scene(scene: spec.Scene) -> Model:
+    bodies, parents = _flatten(scene)
+    nb = len(bodies)
+    m = Model()
+    names: Dict[str, List[str]] = dict(body=[], joint=[], geom=[], site=[],
+                                       actuator=[], tendon=[])
+    m["names"] = names
+    m["nbody"] = nb
+
+    body_pos = np.zeros((nb, 3)); body_quat = np.zeros((nb, 4))
+    body_ipos = np.zeros((nb, 3)); body_iquat = np.zeros((nb, 4))
+    body_mass = np.zeros(nb); body_inertia = np.zeros((nb, 3))
+    body_gravcomp = np.zeros(nb)
+    body_jntadr = np.zeros(nb, np.int32); body_jntnum = np.zeros(nb, np.int32)
+    jnt = dict(type=[], bodyid=[], pos=[], axis=[], range=[], limited=[],
+               stiffness=[], springref=[], damping=[], armature=[], frictionloss=[],
+               solref=[], solimp=[], fsolref=[], fsolimp=[], margin=[])
+    geom = dict(type=[], bodyid=[], pos=[], quat=[], size=[], contype=[],
+                conaffinity=[], condim=[], friction=[], solref=[], solimp=[],
+                solmix=[], margin=[], gap=[], priority=[])
+    site_bodyid, site_pos = [], []
+
+    for i, b in enumerate(bodies):
+        names["body"].append(b.name)
+        body_pos[i] = b.pos
+        body_quat[i] = spec.quat_normalize(b.quat)
+        body_gravcomp[i] = b.gravcomp
+        if b.mass is not None:
+            body_mass[i] = b.mass
+            body_ipos[i] = b.ipos
+            body_iquat[i] = spec.quat_normalize(b.iquat)
+            body_inertia[i] = b.inertia
+        else:
+            massive = [g for g in b.geoms if g.mass is not None]
+            body_iquat[i] = (1, 0, 0, 0)
+            if massive:
+                # Only the single-box case is needed (piano keys).
+                assert len(massive) == 1 and massive[0].type == spec.GEOM_BOX
+                g = massive[0]
+                assert tuple(g.quat) == (1.0, 0.0, 0.0, 0.0)
+                body_mass[i] = g.mass
+                body_ipos[i] = g.pos
+                body_inertia[i] = _box_inertia(g.mass, g.size)
+        body_jntadr[i] = len(jnt["type"])
+        body_jntnum[i] = len(b.joints)
+        for j in b.joints:
+            names["joint"].append(j.name)
+            jnt["type"].append(j.type)
+            jnt["bodyid"].append(i)
+            jnt["pos"].append(j.pos)
+            ax = np.asarray(j.axis, float)
+            jnt["axis"].append(ax / np.linalg.norm(ax))
+            jnt["limited"].append(0 if j.range is None else 1)
+            jnt["range"].append((0.0, 0.0) if j.range is None else j.range)
+            jnt["stiffness"].append(j.stiffness)
+            jnt["springref"].append(j.springref)
+            jnt["damping"].append(j.damping)
+            jnt["armature"].append(j.armature)
+            jnt["frictionloss"].append(j.frictionloss)
+            jnt["solref"].append(j.solref_limit)
+            jnt["solimp"].append(j.solimp_limit)
+            jnt["fsolref"].append(j.solref_friction)
+            jnt["fsolimp"].append(j.solimp_friction)
+            jnt["margin"].append(j.margin)
+        for g in b.geoms:
+            names["geom"].append(g.name)
+            geom["type"].append(g.type)
+            geom["bodyid"].append(i)
+            geom["pos"].append(g.pos)
+            geom["quat"].append(spec.quat_normalize(g.quat))
+            size = list(g.size) + [0.0] * (3 - len(g.size))
+            geom["size"].append(size)
+            for k in ("contype", "conaffinity", "condim", "friction", "solref",
+                      "solimp", "solmix", "margin", "gap", "priority"):
+                geom[k].append(getattr(g, k))
+        for s in b.sites:
+            names["site"].append(s.name)
+            site_bodyid.append(i)
+            site_pos.append(s.pos)
+
+    njnt = len(jnt["type"])
+    m["njnt"] = njnt
+    m["nv"] = njnt
+    m["nq"] = njnt
+    m["body_parentid"] = np.asarray(parents, np.int32)
+    m["body_pos"] = body_pos; m["body_quat"] = body_quat
+    m["body_ipos"] = body_ipos; m["body_iquat"] = body_iquat
+    m["body_mass"] = body_mass; m["body_inertia"] = body_inertia
+    m["body_gravcomp"] = body_gravcomp
+    m["body_jntadr"] = body_jntadr; m["body_jntnum"] = body_jntnum
+    # weld id: bodies without joints are welded to their parent's weld body.
+    weld = np.zeros(nb, np.int32)
+    for i in range(1, nb):
+        weld[i] = i if body_jntnum[i] > 0 else weld[parents[i]]
+    m["body_weldid"] = weld
+
+    def arr(v, dt=np.float64, shape=None):
+        a = np.asarray(v, dt)
+        if shape is not None:
+            a = a.reshape(shape)
+        return a
+
+    m["jnt_type"] = arr(jnt["type"], np.int32)
+    m["jnt_bodyid"] = arr(jnt["bodyid"], np.int32)
+    m["jnt_pos"] = arr(jnt["pos"], shape=(njnt, 3))
+    m["jnt_axis"] = arr(jnt["axis"], shape=(njnt, 3))
+    m["jnt_limited"] = arr(jnt["limited"], np.int32)
+    m["jnt_range"] = arr(jnt["range"], shape=(njnt, 2))
+    m["jnt_stiffness"] = arr(jnt["stiffness"])
+    m["qpos_spring"] = arr(jnt["springref"])
+    m["qpos0"] = np.zeros(njnt)
+    m["jnt_solref"] = arr(jnt["solref"], shape=(njnt, 2))
+    m["jnt_solimp"] = arr(jnt["solimp"], shape=(njnt, 5))
+    m["jnt_margin"] = arr(jnt["margin"])
+    m["dof_solref"] = arr(jnt["fsolref"], shape=(njnt, 2))
+    m["dof_solimp"] = arr(jnt["fsolimp"], shape=(njnt, 5))
+    m["dof_bodyid"] = m["jnt_bodyid"].copy()
+    m["dof_armature"] = arr(jnt["armature"])
+    m["dof_damping"] = arr(jnt["damping"])
+    m["dof_frictionloss"] = arr(jnt["frictionloss"])
+    # dof_parentid: previous dof in the same body, else last dof of nearest
+    # ancestor body that has dofs.
+    dof_parent = np.full(njnt, -1, np.int32)
+    body_lastdof = np.full(nb, -1, np.int32)
+    for i in range(1, nb):
+        last = body_lastdof[parents[i]]
+        for j in range(body_jntadr[i], body_jntadr[i] + body_jntnum[i]):
+            dof_parent[j] = last
+            last = j
+        body_lastdof[i] = last
+    m["dof_parentid"] = dof_parent
+    m["body_lastdof"] = body_lastdof
+    # tree id per dof (root dof index of its kinematic tree).
+    dof_tree = np.zeros(njnt, np.int32)
+    ntree = 0
+    for j in range(njnt):
+        if dof_parent[j] < 0:
+            dof_tree[j] = ntree
+            ntree += 1
+        else:
+            dof_tree[j] = dof_tree[dof_parent[j]]
+    m["dof_treeid"] = dof_tree
+    m["ntree"] = ntree
+
+    ngeom = len(geom["type"])
+    m["ngeom"] = ngeom
+    m["geom_type"] = arr(geom["type"], np.int32)
+    m["geom_bodyid"] = arr(geom["bodyid"], np.int32)
+    m["geom_pos"] = arr(geom["pos"], shape=(ngeom, 3))
+    m["geom_quat"] = arr(geom["quat"], shape=(ngeom, 4))
+    m["geom_size"] = arr(geom["size"], shape=(ngeom, 3))
+    m["geom_contype"] = arr(geom["contype"], np.int32)
+    m["geom_conaffinity"] = arr(geom["conaffinity"], np.int32)
+    m["geom_condim"] = arr(geom["condim"], np.int32)
+    m["geom_friction"] = arr(geom["friction"], shape=(ngeom, 3))
+    m["geom_solref"] = arr(geom["solref"], shape=(ngeom, 2))
+    m["geom_solimp"] = arr(geom["solimp"], shape=(ngeom, 5))
+    m["geom_solmix"] = arr(geom["solmix"])
+    m["geom_margin"] = arr(geom["margin"])
+    m["geom_gap"] = arr(geom["gap"])
+    m["geom_priority"] = arr(geom["priority"], np.int32)
+    rb = np.zeros(ngeom)
+    for g in range(ngeom):
+        t, s = m.geom_type[g], m.geom_size[g]
+        if t == spec.GEOM_SPHERE:
+            rb[g] = s[0]
+        elif t == spec.GEOM_CAPSULE:
+            rb[g] = s[0] + s[1]
+        elif t == spec.GEOM_BOX:
+            rb[g] = np.linalg.norm(s)
+        else:
+            raise ValueError(f"unsupported geom type {t}")
+    m["geom_rbound"] = rb
+
+    m["nsite"] = len(site_bodyid)
+    m["site_bodyid"] = arr(site_bodyid, np.int32)
+    m["site_pos"] = arr(site_pos, shape=(len(site_bodyid), 3))
+
+    # Tendons (fixed).
+    ten_adr, ten_num, wrap_jnt, wrap_coef = [], [], [], []
+    for t in scene.tendons:
+        names["tendon"].append(t.name)
+        ten_adr.append(len(wrap_jnt))
+        ten_num.append(len(t.joints))
+        for jn, c in zip(t.joints, t.coefs):
+            wrap_jnt.append(names["joint"].index(jn))
+            wrap_coef.append(c)
+    m["ntendon"] = len(scene.tendons)
+    m["tendon_adr"] = arr(ten_adr, np.int32)
+    m["tendon_num"] = arr(ten_num, np.int32)
+    m["wrap_objid"] = arr(wrap_jnt, np.int32)
+    m["wrap_prm"] = arr(wrap_coef)
+
+    # Actuators.
+    nu = len(scene.actuators)
+    m["nu"] = nu
+    trntype = np.zeros(nu, np.int32); trnid = np.zeros(nu, np.int32)
+    gain = np.zeros(nu); bias = np.zeros((nu, 3)); gear = np.zeros(nu)
+    ctrllimited = np.zeros(nu, np.int32); ctrlrange = np.zeros((nu, 2))
+    forcelimited = np.zeros(nu, np.int32); forcerange = np.zeros((nu, 2))
+    for i, a in enumerate(scene.actuators):
+        names["actuator"].append(a.name)
+        if a.joint is not None:
+            trntype[i] = spec.TRN_JOINT
+            trnid[i] = names["joint"].index(a.joint)
+        else:
+            trntype[i] = spec.TRN_TENDON
+            trnid[i] = names["tendon"].index(a.tendon)
+        gain[i] = a.gain
+        bias[i] = a.bias
+        gear[i] = a.gear
+        if a.ctrlrange is not None:
+            ctrllimited[i] = 1
+            ctrlrange[i] = a.ctrlrange
+        if a.forcerange is not None:
+            forcelimited[i] = 1
+            forcerange[i] = a.forcerange
+    m["actuator_trntype"] = trntype; m["actuator_trnid"] = trnid
+    m["actuator_gainprm"] = gain; m["actuator_biasprm"] = bias
+    m["actuator_gear"] = gear
+    m["actuator_ctrllimited"] = ctrllimited; m["actuator_ctrlrange"] = ctrlrange
+    m["actuator_forcelimited"] = forcelimited; m["actuator_forcerange"] = forcerange
+
+    o = scene.options
+    m["opt_timestep"] = float(o.timestep)
+    m["opt_gravity"] = np.asarray(o.gravity, float)
+    m["opt_tolerance"] = float(o.tolerance)
+    m["opt_iterations"] = int(o.iterations)
+    m["opt_ls_iterations"] = int(o.ls_iterations)
+    m["opt_ls_tolerance"] = float(o.ls_tolerance)
+    m["opt_impratio"] = float(o.impratio)
+    m["opt_refsafe"] = int(o.refsafe)
+
+    # ---- derived constants at qpos0 (mj_setConst) --------------------------
+    kin = kinematics(m, m.qpos0)
+    M = mass_matrix(m, kin)
+    # Critical damping for joints flagged damping<0 (=-kp):
+    # mujoco_utils.physics_utils.get_critical_damping_from_stiffness = 2*sqrt(M0*kp)
+    # (called from shadow_hand.py:299-301).
+    for j in range(njnt):
+        if m.dof_damping[j] < 0:
+            kp = -m.dof_damping[j]
+            m.dof_damping[j] = 2.0 * np.sqrt(M[j, j] * kp)
+    m["dof_M0"] = np.diag(M).copy()
+    Minv = np.linalg.inv(M)
+    m["dof_invweight0"] = np.diag(Minv).copy()
+    biw = np.zeros((nb, 2))
+    for b in range(1, nb):
+        if weld[b] == 0:
+            continue  # static
+        jp, jr = jac(m, kin, kin["xipos"][b], b)
+        A = jp @ Minv @ jp.T
+        B = jr @ Minv @ jr.T
+        biw[b, 0] = max(MINVAL, np.trace(A) / 3.0)
+        biw[b, 1] = max(MINVAL, np.trace(B) / 3.0)
+    m["body_invweight0"] = biw
+    m["stat_meaninertia"] = float(np.mean(np.diag(M))) if njnt else 1.0
+
+    # ---- static collision-pair list ----------------------------------------
+    excl = set()
+    for a, b in scene.excludes:
+        ia, ib = names["body"].index(a), names["body"].index(b)
+        excl.add((min(ia, ib), max(ia, ib)))
+    pairs = []
+    dropped_boxbox = 0
+    for g1 in range(ngeom):
+        for g2 in range(g1 + 1, ngeom):
+            b1, b2 = m.geom_bodyid[g1], m.geom_bodyid[g2]
+            if b1 == b2:
+                continue
+            if not ((m.geom_contype[g1] & m.geom_conaffinity[g2])
+                    or (m.geom_contype[g2] & m.geom_conaffinity[g1])):
+                continue
+            w1, w2 = weld[b1], weld[b2]
+            if w1 == w2:
+                continue  # both static, or welded together
+            if w1 != 0 and w2 != 0 and (weld[parents[w1]] == w2 or weld[parents[w2]] == w1):
+                continue  # parent-child filter
+            if (min(b1, b2), max(b1, b2)) in excl:
+                continue
+            a, b = g1, g2
+            if m.geom_type[a] > m.geom_type[b]:
+                a, b = b, a
+            if m.geom_type[a] == spec.GEOM_BOX and m.geom_type[b] == spec.GEOM_BOX:
+                dropped_boxbox += 1
+                continue
+            pairs.append((min(b1, b2), max(b1, b2), a, b))
+    pairs.sort()
+    m["pair_geom"] = np.asarray([(p[2], p[3]) for p in pairs], np.int32).reshape(-1, 2)
+    m["npair"] = len(pairs)
+    m["npair_dropped_boxbox"] = dropped_boxbox
+    return m
+
+
+# ---------------------------------------------------------------------------
+# Blob serialisation: header + table of named arrays (float64 / int32).
+# ---------------------------------------------------------------------------
+
+_SCALARS_I = ["nbody", "njnt", "nv", "nq", "ngeom", "nsite", "ntendon", "nu",
+              "npair", "ntree", "opt_iterations", "opt_ls_iterations", "opt_refsafe"]
+_SCALARS_F = ["opt_timestep", "opt_tolerance", "opt_ls_tolerance", "opt_impratio",
+              "stat_meaninertia"]
+
+
+def to_blob(m: Model, extra: Dict[str, np.ndarray] | None = None) -> bytes:
+    """Serialise: [magic,u32 version,u32 n] + n*(char[40] name,i32 dtype,i32 ndim,
+    i64 count,i64 offset) + 8-byte aligned data.  dtype 0=f64, 1=i32."""
+    entries = []
+    for k in _SCALARS_I:
+        entries.append((k, np.asarray([m[k]], np.int32)))
+    for k in _SCALARS_F:
+        entries.append((k, np.asarray([m[k]], np.float64)))
+    for k, v in m.items():
+        if isinstance(v, np.ndarray):
+            entries.append((k, v))
+    for k, v in (extra or {}).items():
+        entries.append((k, np.asarray(v)))
+    head_size = 12 + len(entries) * (40 + 4 + 4 + 8 + 8)
+    head_size = (head_size + 7) // 8 * 8
+    data = io.BytesIO()
+    table = io.BytesIO()
+    table.write(struct.pack("<III", BLOB_MAGIC, BLOB_VERSION, len(entries)))
+    for name, a in entries:
+        if a.dtype.kind == "f":
+            a = np.ascontiguousarray(a, np.float64); dt = 0
+        else:
+            a = np.ascontiguousarray(a, np.int32); dt = 1
+        off = head_size + data.tell()
+        raw = a.tobytes()
+        data.write(raw)
+        data.write(b"\0" * ((-len(raw)) % 8))
+        nm = name.encode()[:39]
+        table.write(nm + b"\0" * (40 - len(nm)))
+        table.write(struct.pack("<iiqq", dt, a.ndim, a.size, off))
+    t = table.getvalue()
+    t += b"\0" * (head_size - len(t))
+    return t + data.getvalue()

@@ -1,0 +1,140 @@
+"""Scene assembly for the RoboPianist tasks.
+
+Mirrors what the reference does with composer entities:
+  PianoOnlyTask.__init__   robopianist/suite/tasks/base.py:45-70
+  PianoTask._add_hand      robopianist/suite/tasks/base.py:149-197
+  Stage (non-colliding floor) robopianist/models/arenas/stage.py:61-68
+Body order = world, piano base, 88 keys, right hand, left hand, which is the
+order `arena.attach` produces (piano first, then right, then left), hence
+dof order keys[0:88], right[88:114], left[114:140].
+"""
+
+from __future__ import annotations
+
+import dataclasses
+import warnings
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from robopianist_amd.model import compile as mcompile
+from robopianist_amd.model import piano as piano_model
+from robopianist_amd.model import shadow_hand, spec
+
+# suite/tasks/base.py:28-39
+PHYSICS_TIMESTEP = 0.005
+CONTROL_TIMESTEP = 0.05
+LEFT_HAND_POSITION = (0.4, -0.15, 0.13)
+LEFT_HAND_QUATERNION = (-1, -1, 1, 1)
+RIGHT_HAND_POSITION = (0.4, 0.15, 0.13)
+RIGHT_HAND_QUATERNION = (-1, -1, 1, 1)
+
+
+@dataclasses.dataclass
+class HandInfo:
+    side: str
+    name: str
+    joint_ids: np.ndarray  # Python-order joints (24 hand joints, then forearm)
+    actuator_ids: np.ndarray  # 20 hand actuators then forearm actuators
+    fingertip_site_ids: np.ndarray  # th, ff, mf, rf, lf
+    root_body_id: int
+    forearm_geom_ids: np.ndarray
+    n_forearm_dofs: int
+
+
+@dataclasses.dataclass
+class SceneInfo:
+    model: mcompile.Model
+    key_joint_ids: np.ndarray
+    key_geom_ids: np.ndarray
+    key_body_ids: np.ndarray
+    key_actuator_ids: Optional[np.ndarray]
+    hands: Dict[str, HandInfo]
+    piano_size: tuple
+
+
+def build_scene(
+    hands: Sequence[str] = ("right", "left"),
+    add_piano_actuators: bool = False,
+    gravity_compensation: bool = False,
+    primitive_fingertip_collisions: bool = False,
+    reduced_action_space: bool = False,
+    attachment_yaw: float = 0.0,
+    forearm_dofs: Sequence[str] = shadow_hand.DEFAULT_FOREARM_DOFS,
+    physics_timestep: float = PHYSICS_TIMESTEP,
+    disable_hand_collisions: bool = False,
+) -> SceneInfo:
+    if hands and not primitive_fingertip_collisions:
+        warnings.warn(
+            "Mesh fingertip colliders are unavailable (mujoco_menagerie is not "
+            "vendored in the reference checkout): using capsule fingertips, i.e. "
+            "primitive_fingertip_collisions=True semantics.",
+            stacklevel=2,
+        )
+    world = spec.Body(name="world")
+    base, keys, piano_acts = piano_model.build(add_piano_actuators, physics_timestep)
+    world.add(base)
+    for k in keys:
+        world.add(k)
+    scene = spec.Scene(world=world)
+    scene.options.timestep = physics_timestep
+    scene.actuators.extend(piano_acts)
+
+    builders = {}
+    for side in hands:
+        hb = shadow_hand.HandBuilder(
+            side=side, forearm_dofs=forearm_dofs,
+            reduced_action_space=reduced_action_space,
+        )
+        position = RIGHT_HAND_POSITION if side == "right" else LEFT_HAND_POSITION
+        quaternion = RIGHT_HAND_QUATERNION if side == "right" else LEFT_HAND_QUATERNION
+        # base.py:176-183: yaw about world z, sign flipped for the left hand.
+        sign = -1 if side == "left" else 1
+        rotate_by = spec.axis_angle_to_quat((0, 0, 1), np.radians(sign * attachment_yaw))
+        # mju_mulQuat does not normalise; normalisation happens at compile.
+        final_quat = spec.quat_mul(rotate_by, np.asarray(quaternion, float))
+        hb.set_pose(position, final_quat)
+        if gravity_compensation:
+            hb.compensate_gravity()
+        # base.py:160-163,189-194: forearm_tx range spans the keyboard.
+        joint_range = [-piano_model.BASE_SIZE[1] - position[1],
+                       piano_model.BASE_SIZE[1] - position[1]]
+        if "forearm_tx" in forearm_dofs:
+            hb.set_forearm_tx_range(joint_range)
+        if disable_hand_collisions:
+            hb.disable_hand_collisions()
+        world.add(hb.root)
+        scene.tendons.extend(hb.tendons)
+        scene.actuators.extend(hb.actuators)
+        # [MEM] menagerie <contact><exclude> pairs.
+        scene.excludes.append((hb._n("wrist"), hb._n("forearm")))
+        scene.excludes.append((hb._n("thproximal"), hb._n("thmiddle")))
+        builders[side] = hb
+
+    m = mcompile.compile_scene(scene)
+    n = m.names
+    key_joint_ids = np.array([n["joint"].index(k.joints[0].name) for k in keys], np.int32)
+    key_geom_ids = np.array([n["geom"].index(k.geoms[0].name) for k in keys], np.int32)
+    key_body_ids = np.array([n["body"].index(k.name) for k in keys], np.int32)
+    key_act_ids = None
+    if add_piano_actuators:
+        key_act_ids = np.array([n["actuator"].index(a.name) for a in piano_acts], np.int32)
+    infos = {}
+    for side, hb in builders.items():
+        root_id = n["body"].index(hb.root.name)
+        infos[side] = HandInfo(
+            side=side,
+            name=hb.model_name,
+            joint_ids=np.array([n["joint"].index(j) for j in hb.joint_names], np.int32),
+            actuator_ids=np.array([n["actuator"].index(a) for a in hb.actuator_names], np.int32),
+            fingertip_site_ids=np.array([n["site"].index(s) for s in hb.fingertip_sites], np.int32),
+            root_body_id=root_id,
+            forearm_geom_ids=np.array(
+                [g for g in range(m.ngeom) if m.geom_bodyid[g] == root_id], np.int32),
+            n_forearm_dofs=len(hb.forearm_dofs),
+        )
+    return SceneInfo(
+        model=m, key_joint_ids=key_joint_ids, key_geom_ids=key_geom_ids,
+        key_body_ids=key_body_ids, key_actuator_ids=key_act_ids, hands=infos,
+        piano_size=piano_model.BASE_SIZE,
+    )
