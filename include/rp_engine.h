@@ -1,0 +1,104 @@
+/*
+ * rp_engine.h — C ABI of the MI355X batched physics engine for RoboPianist.
+ *
+ * The reference has no FFI seam for physics: tasks/entities talk to a
+ * `dm_control.mjcf.Physics` Python object.  Each entry point
+ * below names the part of that object protocol it replaces, with the reference
+ * call sites that use it.  A maintainer binds this library with ctypes (see
+ * INTEGRATION.md); `robopianist_amd/engine.py` is that binding.
+ *
+ * Conventions
+ *   - All arrays are env-major `[n_envs][n]`, caller-owned, and may be device
+ *     pointers or host pointers (copied with hipMemcpyDefault on the engine
+ *     stream).  Element type is `float` for precision 32 and `double` for 64.
+ *   - Return value: 0 = OK, negative = error; message via rp_last_error().
+ *   - Physics divergence is not an error; it sets per-env RP_WARN_* bits
+ *     (mirrors mj_checkPos/Vel -> dm_control PhysicsError).
+ *   - Calls are asynchronous on the engine's HIP stream; rp_get() to host
+ *     memory and rp_sync() synchronise.  One host thread per engine.
+ */
+#ifndef RP_ENGINE_H
+#define RP_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rp_engine rp_engine;
+
+typedef enum {
+  RP_QPOS = 0,          /* [E][nv]    physics.bind(joints).qpos   piano.py:186, hands/base.py:78 */
+  RP_QVEL = 1,          /* [E][nv]    physics.bind(joints).qvel   hands/base.py:96 */
+  RP_QACC_WARMSTART = 2,/* [E][nv]    mjData.qacc_warmstart (checkpoint/resume) */
+  RP_CTRL = 3,          /* [E][nu]    physics.bind(actuators).ctrl shadow_hand.py:387, piano.py:181 */
+  RP_QFRC_APPLIED = 4,  /* [E][nv]    physics.bind(joints).qfrc_applied  piano_with_shadow_hands_test.py:235 */
+  RP_ACT_FORCE = 5,     /* [E][nu]    `actuatorfrc` sensors       shadow_hand.py:240-245,412 */
+  RP_ACT_VELOCITY = 6,  /* [E][nu]    `actuatorvel` sensors       shadow_hand.py:233-238,413 */
+  RP_SITE_XPOS = 7,     /* [E][nsite][3] physics.bind(sites).xpos piano_with_shadow_hands.py:309-310,336-337 */
+  RP_TIME = 8,          /* [E]        physics.data.time           midi_module.py:70 */
+  RP_NCON = 9,          /* [E] int32  physics.data.ncon */
+  RP_CONTACT_GEOMS = 10,/* [E][RP_MAX_CONTACTS][2] int32 model geom ids (-1 pad), for
+                           collision_utils.has_collision          piano_with_shadow_hands.py:253-257 */
+  RP_WARN_FLAGS = 11,   /* [E] int32 */
+  RP_SOLVER_ITER = 12,  /* [E] int32  Newton iterations of the last substep */
+  RP_CONTACT_DIST = 13, /* [E][RP_MAX_CONTACTS] */
+  RP_TREE_OFFSET = 14   /* [E][ntree][3] per-env root-body translation (hand.shift_pose,
+                           piano_with_shadow_hands.py:491-499) */
+} rp_field;
+
+#define RP_MAX_CONTACTS 32
+
+#define RP_WARN_BADSTATE 1     /* NaN / |q|>1e10 in qpos or qvel */
+#define RP_WARN_CONTACT_FULL 2 /* more than RP_MAX_CONTACTS contacts, extra dropped */
+#define RP_WARN_HESSIAN 4      /* non-positive pivot in the Newton Hessian */
+#define RP_WARN_KEYSLOT_FULL 8 /* more simultaneously touched keys than solver slots */
+#define RP_WARN_WORK_FULL 16   /* narrow-phase work list overflow */
+
+/* Builds an engine for `n_envs` copies of the model in `model_blob`
+ * (robopianist_amd.model.compile.to_blob + engine tables) on HIP device
+ * `device_id`.  precision: 32 or 64.  Replaces: mjcf.Physics.from_mjcf_model /
+ * composer.Environment construction (suite/__init__.py:87-93). */
+int rp_create(const void* model_blob, size_t blob_bytes, int n_envs, int device_id,
+              int precision, rp_engine** out);
+int rp_destroy(rp_engine* e);
+
+/* physics.reset(): qpos<-qpos0, qvel<-0, ctrl<-0, warmstart<-0, qfrc_applied<-0,
+ * time<-0 for envs with mask[e]!=0 (mask==NULL: all).  mask is a host or
+ * device uint8 array. */
+int rp_reset(rp_engine* e, const uint8_t* mask);
+
+/* Generic field write/read (RP_QPOS, RP_QVEL, RP_QACC_WARMSTART, RP_CTRL,
+ * RP_QFRC_APPLIED, RP_TREE_OFFSET, RP_TIME are writable). */
+int rp_set(rp_engine* e, rp_field f, const void* src);
+int rp_get(rp_engine* e, rp_field f, void* dst);
+
+/* `n_substeps` x physics.step() in dm_control legacy order (mj_step2; mj_step1),
+ * i.e. the body of composer.Environment.step's substep loop
+ * (suite/tasks/base.py:28,31,68-70).  If key_trace != NULL it receives, for
+ * every substep, the bitmask of activated keys (Piano._update_key_state,
+ * piano.py:178-192) as [E][n_substeps][4] uint32. */
+int rp_step(rp_engine* e, int n_substeps, uint32_t* key_trace);
+
+/* Recomputes position/velocity-stage outputs (site_xpos, act_velocity, contacts)
+ * for the current state without stepping: physics.forward(). */
+int rp_forward(rp_engine* e);
+
+/* Solver iteration caps (defaults: model opt.iterations / opt.ls_iterations). */
+int rp_set_solver_limits(rp_engine* e, int max_newton_iter, int max_ls_iter);
+
+int rp_sync(rp_engine* e);
+int rp_get_stream(rp_engine* e, void** hip_stream);
+int rp_n_envs(const rp_engine* e);
+int rp_dim(const rp_engine* e, const char* name); /* "nv","nu","nsite","ntree","nkey","nlink" */
+/* Average device time (ms) of the step kernel since the last call, measured
+ * with HIP events on the engine stream; also returns the launch count. */
+int rp_kernel_time(rp_engine* e, double* avg_ms, int* n_launches);
+const char* rp_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,436 @@
+// rp_engine.hip — host side of the C ABI declared in include/rp_engine.h.
+// Parses the model blob (robopianist_amd/model/compile.py:to_blob + engine
+// tables), uploads the fixed-topology tables, owns the env-major state arrays and
+// launches rp_step_kernel<T> (rp_kernels.hpp) on a private HIP stream.
+#include "rp_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rp_engine.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string& s) { g_err = s; return -1; }
+#define HIP_OK(x)                                                                  \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess)                                                          \
+      return fail(std::string(#x) + ": " + hipGetErrorString(e_));                 \
+  } while (0)
+
+struct BlobEntry { char name[40]; int32_t dtype, ndim; int64_t count, offset; };
+
+struct Blob {
+  std::vector<unsigned char> data;
+  int n = 0;
+  const BlobEntry* ent = nullptr;
+  bool init(const void* p, size_t nb) {
+    data.assign((const unsigned char*)p, (const unsigned char*)p + nb);
+    if (nb < 12) return false;
+    const uint32_t* h = (const uint32_t*)data.data();
+    if (h[0] != 0x52504D42u) return false;
+    n = (int)h[2];
+    ent = (const BlobEntry*)(data.data() + 12);
+    return true;
+  }
+  const BlobEntry* find(const char* name) const {
+    for (int i = 0; i < n; i++) if (!strncmp(ent[i].name, name, 40)) return &ent[i];
+    return nullptr;
+  }
+  bool has(const char* name) const { return find(name) != nullptr; }
+  std::vector<double> f(const char* name) const {
+    const BlobEntry* e = find(name);
+    if (!e) throw std::string("blob entry missing: ") + name;
+    std::vector<double> v((size_t)e->count);
+    if (e->dtype == 0) memcpy(v.data(), data.data() + e->offset, sizeof(double) * e->count);
+    else { const int32_t* s = (const int32_t*)(data.data() + e->offset); for (int64_t i = 0; i < e->count; i++) v[i] = s[i]; }
+    return v;
+  }
+  std::vector<int> i(const char* name) const {
+    const BlobEntry* e = find(name);
+    if (!e) throw std::string("blob entry missing: ") + name;
+    if (e->dtype != 1) throw std::string("blob entry not int: ") + name;
+    std::vector<int> v((size_t)e->count);
+    memcpy(v.data(), data.data() + e->offset, sizeof(int32_t) * e->count);
+    return v;
+  }
+  int i1(const char* name) const { return i(name).at(0); }
+  double f1(const char* name) const { return f(name).at(0); }
+};
+
+struct EngineBase {
+  virtual ~EngineBase() {}
+  int nenv = 0, device = 0, precision = 32;
+  int nv = 0, nu = 0, nsite = 0, ntree = 0, nkey = 0, nlink = 0;
+  hipStream_t stream = nullptr;
+  // ring of HIP event pairs bracketing every step-kernel launch on `stream`
+  static const int kRing = 128;
+  hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
+  bool ev_pending[kRing] = {};
+  int ev_next = 0;
+  double kernel_ms = 0; int kernel_launches = 0;
+  void harvest(int i, bool wait) {
+    if (!ev_pending[i]) return;
+    if (wait) hipEventSynchronize(ev1[i]);
+    else if (hipEventQuery(ev1[i]) != hipSuccess) return;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ev0[i], ev1[i]) == hipSuccess) { kernel_ms += ms; kernel_launches++; }
+    ev_pending[i] = false;
+  }
+  virtual int reset(const uint8_t* mask) = 0;
+  virtual int set(rp_field f, const void* src) = 0;
+  virtual int get(rp_field f, void* dst) = 0;
+  virtual int step(int nsub, uint32_t* trace, int mode) = 0;
+  virtual void limits(int newton, int ls) = 0;
+};
+
+template <typename T>
+struct Engine : EngineBase {
+  RpModel<T> M{};
+  RpState<T> S{};
+  std::vector<void*> allocs;
+  std::vector<T> qpos0;
+  uint32_t* d_trace = nullptr; size_t trace_cap = 0;
+  uint8_t* d_mask = nullptr;
+
+  ~Engine() override {
+    hipSetDevice(device);
+    for (void* p : allocs) hipFree(p);
+    if (d_trace) hipFree(d_trace);
+    if (d_mask) hipFree(d_mask);
+    for (int i = 0; i < kRing; i++) { if (ev0[i]) hipEventDestroy(ev0[i]); if (ev1[i]) hipEventDestroy(ev1[i]); }
+    if (stream) hipStreamDestroy(stream);
+  }
+  template <typename U> U* dalloc(size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, (n ? n : 1) * sizeof(U)) != hipSuccess) throw std::string("hipMalloc failed");
+    hipMemset(p, 0, (n ? n : 1) * sizeof(U));
+    allocs.push_back(p);
+    return (U*)p;
+  }
+  const T* upF(const std::vector<double>& v) {
+    std::vector<T> t(v.begin(), v.end());
+    T* d = dalloc<T>(t.size());
+    if (!t.empty()) hipMemcpy(d, t.data(), t.size() * sizeof(T), hipMemcpyHostToDevice);
+    return d;
+  }
+  const int* upI(const std::vector<int>& v) {
+    int* d = dalloc<int>(v.size());
+    if (!v.empty()) hipMemcpy(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice);
+    return d;
+  }
+
+  void build(const Blob& b, int n_envs) {
+    nenv = n_envs;
+    M.nlink = nlink = b.i1("eng_nlink"); M.ntree = ntree = b.i1("eng_ntree");
+    M.maxdepth = b.i1("eng_maxdepth"); M.nkey = nkey = b.i1("eng_nkey");
+    M.ngeom = b.i1("eng_ngeom"); M.npair = b.i1("eng_npair"); M.nkeycap = b.i1("eng_nkeycap");
+    M.nu = nu = b.i1("eng_nu"); M.nsite = nsite = b.i1("eng_nsite"); M.nv = nv = b.i1("nv");
+    if (M.nlink > RPK_NL) throw std::string("too many hand dofs for the engine (max 52)");
+    if (M.nkey > RPK_NKEYS) throw std::string("too many keys (max 128)");
+    if (M.ngeom > RPK_WAVE) throw std::string("too many collision geoms (max 64)");
+    if (M.nu > RPK_WAVE + M.nkey) throw std::string("too many actuators");
+    if (M.nsite > RPK_WAVE) throw std::string("too many sites (max 64)");
+    if (M.maxdepth > RPK_MAXD) throw std::string("tree too deep (max 9 levels)");
+    {
+      std::vector<int> kind = b.i("eng_act_kind");
+      for (int a = 0; a < nu; a++)
+        if (kind[a] == 0 && a >= RPK_WAVE) throw std::string("hand actuator index >= 64");
+    }
+    M.iterations = b.i1("opt_iterations"); M.ls_iterations = b.i1("opt_ls_iterations");
+    M.timestep = (T)b.f1("opt_timestep");
+    auto g = b.f("opt_gravity");
+    M.gx = (T)g[0]; M.gy = (T)g[1]; M.gz = (T)g[2];
+    M.tolerance = (T)b.f1("opt_tolerance"); M.ls_tolerance = (T)b.f1("opt_ls_tolerance");
+    M.meaninertia = (T)b.f1("stat_meaninertia");
+    M.link_parent = upI(b.i("eng_link_parent")); M.link_depth = upI(b.i("eng_link_depth"));
+    M.link_tree = upI(b.i("eng_link_tree")); M.link_jtype = upI(b.i("eng_link_jtype"));
+    M.link_dof = upI(b.i("eng_link_dof")); M.link_sibrank = upI(b.i("eng_link_sibrank"));
+    M.level_maxrank = upI(b.i("eng_level_maxrank")); M.link_anc = upI(b.i("eng_link_anc"));
+    M.link_limited = upI(b.i("eng_link_limited")); M.link_act = upI(b.i("eng_link_act"));
+    M.link_ancmask = (const unsigned*)upI(b.i("eng_link_ancmask"));
+    M.link_lpos = upF(b.f("eng_link_lpos"));
+    {
+      auto q = b.f("eng_link_lquat");
+      std::vector<double> m(9 * (size_t)M.nlink);
+      for (int i = 0; i < M.nlink; i++) {
+        double w = q[4 * i], x = q[4 * i + 1], y = q[4 * i + 2], z = q[4 * i + 3];
+        double* o = &m[9 * i];
+        o[0] = 1 - 2 * (y * y + z * z); o[1] = 2 * (x * y - w * z); o[2] = 2 * (x * z + w * y);
+        o[3] = 2 * (x * y + w * z); o[4] = 1 - 2 * (x * x + z * z); o[5] = 2 * (y * z - w * x);
+        o[6] = 2 * (x * z - w * y); o[7] = 2 * (y * z + w * x); o[8] = 1 - 2 * (x * x + y * y);
+      }
+      M.link_lmat = upF(m);
+    }
+    M.link_axis = upF(b.f("eng_link_axis")); M.link_anchor = upF(b.f("eng_link_anchor"));
+    M.link_mass = upF(b.f("eng_link_mass")); M.link_ipos = upF(b.f("eng_link_ipos"));
+    M.link_inertia = upF(b.f("eng_link_inertia")); M.link_invw_body = upF(b.f("eng_link_invw_body"));
+    M.link_armature = upF(b.f("eng_link_armature")); M.link_damping = upF(b.f("eng_link_damping"));
+    M.link_stiffness = upF(b.f("eng_link_stiffness")); M.link_springref = upF(b.f("eng_link_springref"));
+    M.link_floss = upF(b.f("eng_link_floss")); M.link_fl_R = upF(b.f("eng_link_fl_R"));
+    M.link_fl_B = upF(b.f("eng_link_fl_B")); M.link_range = upF(b.f("eng_link_range"));
+    M.link_lim_K = upF(b.f("eng_link_lim_K")); M.link_lim_B = upF(b.f("eng_link_lim_B"));
+    M.link_lim_solimp = upF(b.f("eng_link_lim_solimp")); M.link_invw_dof = upF(b.f("eng_link_invw_dof"));
+    M.link_act_coef = upF(b.f("eng_link_act_coef"));
+    M.tree_gscale = upF(b.f("eng_tree_gscale")); M.tree_ref = upF(b.f("eng_tree_ref"));
+    M.key_dof = upI(b.i("eng_key_dof")); M.key_act = upI(b.i("eng_key_act"));
+    M.key_geomid = upI(b.i("eng_key_geomid"));
+    auto kpos = b.f("eng_key_pos"), khalf = b.f("eng_key_half");
+    M.key_pos = upF(kpos); M.key_half = upF(khalf);
+    {
+      std::vector<double> rb((size_t)M.nkey);
+      double zmax = -1e30;
+      for (int k = 0; k < M.nkey; k++) {
+        rb[k] = std::sqrt(khalf[3 * k] * khalf[3 * k] + khalf[3 * k + 1] * khalf[3 * k + 1] +
+                          khalf[3 * k + 2] * khalf[3 * k + 2]);
+        // the key box centre moves on a circle of radius hx about the hinge
+        zmax = std::max(zmax, kpos[3 * k + 2] + khalf[3 * k] + rb[k]);
+      }
+      M.key_rbound = upF(rb);
+      M.key_zmax = (T)zmax;
+    }
+    M.key_mass = upF(b.f("eng_key_mass")); M.key_M = upF(b.f("eng_key_M"));
+    M.key_stiffness = upF(b.f("eng_key_stiffness")); M.key_springref = upF(b.f("eng_key_springref"));
+    M.key_damping = upF(b.f("eng_key_damping")); M.key_range = upF(b.f("eng_key_range"));
+    M.key_lim_K = upF(b.f("eng_key_lim_K")); M.key_lim_B = upF(b.f("eng_key_lim_B"));
+    M.key_lim_solimp = upF(b.f("eng_key_lim_solimp")); M.key_invw_dof = upF(b.f("eng_key_invw_dof"));
+    M.key_invw_body = upF(b.f("eng_key_invw_body")); M.key_cparam = upF(b.f("eng_key_cparam"));
+    M.geom_link = upI(b.i("eng_geom_link")); M.geom_type = upI(b.i("eng_geom_type"));
+    M.geom_modelid = upI(b.i("eng_geom_modelid")); M.pair = upI(b.i("eng_pair"));
+    M.keycap = upI(b.i("eng_keycap"));
+    M.geom_size = upF(b.f("eng_geom_size")); M.geom_pos = upF(b.f("eng_geom_pos"));
+    M.geom_mat = upF(b.f("eng_geom_mat")); M.geom_rbound = upF(b.f("eng_geom_rbound"));
+    M.geom_invw = upF(b.f("eng_geom_invw")); M.geom_cparam = upF(b.f("eng_geom_cparam"));
+    M.act_kind = upI(b.i("eng_act_kind")); M.act_lane = upI(b.i("eng_act_lane"));
+    M.act_ctrllimited = upI(b.i("eng_act_ctrllimited")); M.act_forcelimited = upI(b.i("eng_act_forcelimited"));
+    M.act_coef = upF(b.f("eng_act_coef")); M.act_gain = upF(b.f("eng_act_gain"));
+    M.act_bias = upF(b.f("eng_act_bias")); M.act_ctrlrange = upF(b.f("eng_act_ctrlrange"));
+    M.act_forcerange = upF(b.f("eng_act_forcerange"));
+    M.site_link = upI(b.i("eng_site_link")); M.site_pos = upF(b.f("eng_site_pos"));
+    {
+      auto q0 = b.f("qpos0");
+      qpos0.assign(q0.begin(), q0.end());
+    }
+    size_t E = (size_t)nenv;
+    S.nenv = nenv;
+    S.qpos = dalloc<T>(E * nv); S.qvel = dalloc<T>(E * nv); S.warm = dalloc<T>(E * nv);
+    S.ctrl = dalloc<T>(E * nu); S.qfrc_applied = dalloc<T>(E * nv); S.time = dalloc<T>(E);
+    S.tree_offset = dalloc<T>(E * (ntree ? ntree : 1) * 3);
+    S.act_force = dalloc<T>(E * nu); S.act_vel = dalloc<T>(E * nu);
+    S.site_xpos = dalloc<T>(E * (nsite ? nsite : 1) * 3);
+    S.contact_dist = dalloc<T>(E * RPK_NC);
+    S.ncon = dalloc<int>(E); S.contact_geoms = dalloc<int>(E * RPK_NC * 2);
+    S.warn = dalloc<int>(E); S.solver_iter = dalloc<int>(E);
+    S.key_trace = nullptr;
+    S.max_newton = M.iterations; S.max_ls = M.ls_iterations;
+  }
+
+  void limits(int newton, int ls) override {
+    if (newton > 0) S.max_newton = newton;
+    if (ls > 0) S.max_ls = ls;
+  }
+
+  int reset(const uint8_t* mask) override {
+    HIP_OK(hipSetDevice(device));
+    std::vector<uint8_t> hm((size_t)nenv, 1);
+    if (mask) HIP_OK(hipMemcpy(hm.data(), mask, nenv, hipMemcpyDefault));
+    bool all = true;
+    for (auto v : hm) if (!v) all = false;
+    size_t E = (size_t)nenv;
+    if (all) {
+      std::vector<T> q(E * nv);
+      for (size_t e = 0; e < E; e++) memcpy(&q[e * nv], qpos0.data(), sizeof(T) * nv);
+      HIP_OK(hipMemcpyAsync(S.qpos, q.data(), sizeof(T) * E * nv, hipMemcpyHostToDevice, stream));
+      HIP_OK(hipMemsetAsync(S.qvel, 0, sizeof(T) * E * nv, stream));
+      HIP_OK(hipMemsetAsync(S.warm, 0, sizeof(T) * E * nv, stream));
+      HIP_OK(hipMemsetAsync(S.ctrl, 0, sizeof(T) * E * nu, stream));
+      HIP_OK(hipMemsetAsync(S.qfrc_applied, 0, sizeof(T) * E * nv, stream));
+      HIP_OK(hipMemsetAsync(S.time, 0, sizeof(T) * E, stream));
+      HIP_OK(hipMemsetAsync(S.warn, 0, sizeof(int) * E, stream));
+      HIP_OK(hipStreamSynchronize(stream));
+    } else {
+      for (size_t e = 0; e < E; e++) {
+        if (!hm[e]) continue;
+        HIP_OK(hipMemcpyAsync(S.qpos + e * nv, qpos0.data(), sizeof(T) * nv, hipMemcpyHostToDevice, stream));
+        HIP_OK(hipMemsetAsync(S.qvel + e * nv, 0, sizeof(T) * nv, stream));
+        HIP_OK(hipMemsetAsync(S.warm + e * nv, 0, sizeof(T) * nv, stream));
+        HIP_OK(hipMemsetAsync(S.ctrl + e * nu, 0, sizeof(T) * nu, stream));
+        HIP_OK(hipMemsetAsync(S.qfrc_applied + e * nv, 0, sizeof(T) * nv, stream));
+        HIP_OK(hipMemsetAsync(S.time + e, 0, sizeof(T), stream));
+        HIP_OK(hipMemsetAsync(S.warn + e, 0, sizeof(int), stream));
+      }
+      HIP_OK(hipStreamSynchronize(stream));
+    }
+    return 0;
+  }
+
+  bool field(rp_field f, void** p, size_t* bytes, bool* writable) {
+    size_t E = (size_t)nenv;
+    *writable = false;
+    switch (f) {
+      case RP_QPOS: *p = S.qpos; *bytes = sizeof(T) * E * nv; *writable = true; return true;
+      case RP_QVEL: *p = S.qvel; *bytes = sizeof(T) * E * nv; *writable = true; return true;
+      case RP_QACC_WARMSTART: *p = S.warm; *bytes = sizeof(T) * E * nv; *writable = true; return true;
+      case RP_CTRL: *p = S.ctrl; *bytes = sizeof(T) * E * nu; *writable = true; return true;
+      case RP_QFRC_APPLIED: *p = S.qfrc_applied; *bytes = sizeof(T) * E * nv; *writable = true; return true;
+      case RP_ACT_FORCE: *p = S.act_force; *bytes = sizeof(T) * E * nu; return true;
+      case RP_ACT_VELOCITY: *p = S.act_vel; *bytes = sizeof(T) * E * nu; return true;
+      case RP_SITE_XPOS: *p = S.site_xpos; *bytes = sizeof(T) * E * nsite * 3; return true;
+      case RP_TIME: *p = S.time; *bytes = sizeof(T) * E; *writable = true; return true;
+      case RP_NCON: *p = S.ncon; *bytes = sizeof(int) * E; return true;
+      case RP_CONTACT_GEOMS: *p = S.contact_geoms; *bytes = sizeof(int) * E * RPK_NC * 2; return true;
+      case RP_WARN_FLAGS: *p = S.warn; *bytes = sizeof(int) * E; *writable = true; return true;
+      case RP_SOLVER_ITER: *p = S.solver_iter; *bytes = sizeof(int) * E; return true;
+      case RP_CONTACT_DIST: *p = S.contact_dist; *bytes = sizeof(T) * E * RPK_NC; return true;
+      case RP_TREE_OFFSET: *p = S.tree_offset; *bytes = sizeof(T) * E * ntree * 3; *writable = true; return true;
+    }
+    return false;
+  }
+  int set(rp_field f, const void* src) override {
+    void* p; size_t nb; bool w;
+    if (!field(f, &p, &nb, &w)) return fail("rp_set: unknown field");
+    if (!w) return fail("rp_set: field is read-only");
+    if (!src) return fail("rp_set: null source");
+    HIP_OK(hipSetDevice(device));
+    if (nb) HIP_OK(hipMemcpyAsync(p, src, nb, hipMemcpyDefault, stream));
+    return 0;
+  }
+  int get(rp_field f, void* dst) override {
+    void* p; size_t nb; bool w;
+    if (!field(f, &p, &nb, &w)) return fail("rp_get: unknown field");
+    if (!dst) return fail("rp_get: null destination");
+    HIP_OK(hipSetDevice(device));
+    if (nb) HIP_OK(hipMemcpyAsync(dst, p, nb, hipMemcpyDefault, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int step(int nsub, uint32_t* trace, int mode) override {
+    HIP_OK(hipSetDevice(device));
+    if (mode == 0 && nsub <= 0) return fail("rp_step: n_substeps must be positive");
+    RpState<T> s = S;
+    size_t need = (size_t)nenv * (nsub > 0 ? nsub : 1) * 4;
+    if (trace && mode == 0) {
+      if (need > trace_cap) {
+        if (d_trace) hipFree(d_trace);
+        HIP_OK(hipMalloc((void**)&d_trace, need * sizeof(uint32_t)));
+        trace_cap = need;
+      }
+      s.key_trace = d_trace;
+    }
+    const int slot = ev_next;
+    ev_next = (ev_next + 1) % kRing;
+    harvest(slot, true);
+    const bool timeit = (mode == 0);
+    if (timeit) HIP_OK(hipEventRecord(ev0[slot], stream));
+    hipLaunchKernelGGL(rp_step_kernel<T>, dim3(nenv), dim3(64), 0, stream, M, s, nsub, mode);
+    HIP_OK(hipGetLastError());
+    if (timeit) { HIP_OK(hipEventRecord(ev1[slot], stream)); ev_pending[slot] = true; }
+    if (trace && mode == 0)
+      HIP_OK(hipMemcpyAsync(trace, d_trace, need * sizeof(uint32_t), hipMemcpyDefault, stream));
+    return 0;
+  }
+};
+
+EngineBase* E(rp_engine* e) { return reinterpret_cast<EngineBase*>(e); }
+
+}  // namespace
+
+extern "C" {
+
+const char* rp_last_error(void) { return g_err.c_str(); }
+
+int rp_create(const void* model_blob, size_t blob_bytes, int n_envs, int device_id, int precision,
+              rp_engine** out) {
+  if (!out) return fail("rp_create: out is null");
+  *out = nullptr;
+  if (!model_blob || n_envs <= 0) return fail("rp_create: bad arguments");
+  if (precision != 32 && precision != 64) return fail("rp_create: precision must be 32 or 64");
+  Blob b;
+  if (!b.init(model_blob, blob_bytes)) return fail("rp_create: not a model blob (bad magic)");
+  if (!b.has("eng_nlink")) return fail("rp_create: blob lacks engine tables (eng_*)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail("rp_create: no HIP device available (the engine has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail("rp_create: bad device id");
+  HIP_OK(hipSetDevice(device_id));
+  EngineBase* e = nullptr;
+  try {
+    if (precision == 32) { auto* p = new Engine<float>(); e = p; p->device = device_id; p->precision = 32;
+      HIP_OK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking)); p->build(b, n_envs); }
+    else { auto* p = new Engine<double>(); e = p; p->device = device_id; p->precision = 64;
+      HIP_OK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking)); p->build(b, n_envs); }
+  } catch (const std::string& s) {
+    delete e;
+    return fail("rp_create: " + s);
+  }
+  for (int i = 0; i < EngineBase::kRing; i++) {
+    HIP_OK(hipEventCreate(&e->ev0[i]));
+    HIP_OK(hipEventCreate(&e->ev1[i]));
+  }
+  int r = e->reset(nullptr);
+  if (r) { delete e; return r; }
+  *out = reinterpret_cast<rp_engine*>(e);
+  return 0;
+}
+
+int rp_destroy(rp_engine* e) {
+  if (!e) return fail("rp_destroy: null engine");
+  delete E(e);
+  return 0;
+}
+int rp_reset(rp_engine* e, const uint8_t* mask) { return e ? E(e)->reset(mask) : fail("null engine"); }
+int rp_set(rp_engine* e, rp_field f, const void* src) { return e ? E(e)->set(f, src) : fail("null engine"); }
+int rp_get(rp_engine* e, rp_field f, void* dst) { return e ? E(e)->get(f, dst) : fail("null engine"); }
+int rp_step(rp_engine* e, int n_substeps, uint32_t* key_trace) {
+  return e ? E(e)->step(n_substeps, key_trace, 0) : fail("null engine");
+}
+int rp_forward(rp_engine* e) { return e ? E(e)->step(0, nullptr, 1) : fail("null engine"); }
+int rp_set_solver_limits(rp_engine* e, int max_newton_iter, int max_ls_iter) {
+  if (!e) return fail("null engine");
+  E(e)->limits(max_newton_iter, max_ls_iter);
+  return 0;
+}
+int rp_sync(rp_engine* e) {
+  if (!e) return fail("null engine");
+  HIP_OK(hipSetDevice(E(e)->device));
+  HIP_OK(hipStreamSynchronize(E(e)->stream));
+  return 0;
+}
+int rp_get_stream(rp_engine* e, void** hip_stream) {
+  if (!e || !hip_stream) return fail("null argument");
+  *hip_stream = (void*)E(e)->stream;
+  return 0;
+}
+int rp_n_envs(const rp_engine* e) { return e ? reinterpret_cast<const EngineBase*>(e)->nenv : -1; }
+int rp_dim(const rp_engine* e, const char* name) {
+  if (!e || !name) return -1;
+  const EngineBase* b = reinterpret_cast<const EngineBase*>(e);
+  if (!strcmp(name, "nv")) return b->nv;
+  if (!strcmp(name, "nu")) return b->nu;
+  if (!strcmp(name, "nsite")) return b->nsite;
+  if (!strcmp(name, "ntree")) return b->ntree;
+  if (!strcmp(name, "nkey")) return b->nkey;
+  if (!strcmp(name, "nlink")) return b->nlink;
+  if (!strcmp(name, "precision")) return b->precision;
+  return -1;
+}
+int rp_kernel_time(rp_engine* e, double* avg_ms, int* n_launches) {
+  if (!e) return fail("null engine");
+  EngineBase* b = E(e);
+  HIP_OK(hipSetDevice(b->device));
+  for (int i = 0; i < EngineBase::kRing; i++) b->harvest(i, true);
+  if (avg_ms) *avg_ms = b->kernel_launches ? b->kernel_ms / b->kernel_launches : 0.0;
+  if (n_launches) *n_launches = b->kernel_launches;
+  b->kernel_ms = 0; b->kernel_launches = 0;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,1467 @@
+// rp_kernels.hpp — fixed-topology batched rigid-body step for RoboPianist on gfx950.
+//
+// One environment per 64-lane wavefront (one workgroup = one wave).  Lane roles:
+//   lane i < nlink        : hand link i (= hand dof i; 2 trees x 26 links)
+//   lane k, k+64          : piano keys k and k+64 (closed-form 1-dof hinges)
+//   lane c < ncon         : contact c (4 pyramidal rows) during the solve
+//   lane a < nu           : actuator a during transmission/actuation
+//   lane nlink+s          : solver slot of the s-th key currently touched by a hand
+// Per-dof vectors live in registers of their owner lane; LDS holds link frames,
+// the packed joint-space matrices, contact Jacobians and small staging vectors.
+//
+// What the reference does here: `physics.step()` x n_substeps inside
+// dm_control's composer.Environment.step, configured by
+// /root/reference/robopianist/suite/tasks/base.py:28,31,68-70 and reached from
+// suite/__init__.py:87-93.  The arithmetic follows MuJoCo's documented
+// pipeline; the CPU restatement used as the parity
+// oracle is oracle/rp_oracle.c (a generic, sequential, dense-J formulation).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RPK_WAVE 64
+#define RPK_NC 32        // max contacts (== RP_MAX_CONTACTS)
+#define RPK_WORK 256     // narrow-phase work list
+#define RPK_MAXD 9       // tree depth levels
+#define RPK_NL 52        // max links
+#define RPK_NKEYS 128    // max keys (2 slots per lane)
+#define RPK_KEYBASE 1000 // work-list / contact encoding of "key k" = RPK_KEYBASE + k
+
+#define JNT_SLIDE_ 2
+#define JNT_HINGE_ 3
+#define GEOM_CAPSULE_ 3
+#define GEOM_BOX_ 6
+
+template <typename T>
+struct RpModel {
+  int nlink, ntree, maxdepth, nkey, ngeom, npair, nkeycap, nu, nsite, nv;
+  int iterations, ls_iterations;
+  T timestep, gx, gy, gz, tolerance, ls_tolerance, meaninertia, key_zmax;
+  // links
+  const int *link_parent, *link_depth, *link_tree, *link_jtype, *link_dof, *link_sibrank,
+      *level_maxrank, *link_anc, *link_limited, *link_act;
+  const unsigned* link_ancmask;
+  const T *link_lpos, *link_lmat, *link_axis, *link_anchor, *link_mass, *link_ipos,
+      *link_inertia, *link_invw_body, *link_armature, *link_damping, *link_stiffness,
+      *link_springref, *link_floss, *link_fl_R, *link_fl_B, *link_range, *link_lim_K,
+      *link_lim_B, *link_lim_solimp, *link_invw_dof, *link_act_coef, *tree_gscale, *tree_ref;
+  // keys
+  const int *key_dof, *key_act;
+  const T *key_pos, *key_half, *key_mass, *key_M, *key_stiffness, *key_springref,
+      *key_damping, *key_range, *key_lim_K, *key_lim_B, *key_lim_solimp, *key_invw_dof,
+      *key_invw_body, *key_cparam, *key_rbound;
+  // geoms
+  const int *geom_link, *geom_type, *geom_modelid, *pair, *keycap, *key_geomid;
+  const T *geom_size, *geom_pos, *geom_mat, *geom_rbound, *geom_invw, *geom_cparam;
+  // actuators
+  const int *act_kind, *act_lane, *act_ctrllimited, *act_forcelimited;
+  const T *act_coef, *act_gain, *act_bias, *act_ctrlrange, *act_forcerange;
+  // sites
+  const int* site_link;
+  const T* site_pos;
+};
+
+template <typename T>
+struct RpState {
+  int nenv;
+  T *qpos, *qvel, *warm, *ctrl, *qfrc_applied, *time, *tree_offset;
+  T *act_force, *act_vel, *site_xpos, *contact_dist;
+  int *ncon, *contact_geoms, *warn, *solver_iter;
+  uint32_t* key_trace;  // may be null
+  int max_newton, max_ls;
+};
+
+namespace rpk {
+
+template <typename T> struct Num;
+template <> struct Num<float> {
+  static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
+  static __device__ __forceinline__ float abs(float x) { return fabsf(x); }
+  static __device__ __forceinline__ float pow(float x, float y) { return powf(x, y); }
+  static __device__ __forceinline__ void sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+  static __device__ __forceinline__ float eps() { return 1.1920929e-7f; }
+};
+template <> struct Num<double> {
+  static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+  static __device__ __forceinline__ double abs(double x) { return fabs(x); }
+  static __device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }
+  static __device__ __forceinline__ void sincos(double x, double* s, double* c) { ::sincos(x, s, c); }
+  static __device__ __forceinline__ double eps() { return 2.220446049250313e-16; }
+};
+#define RPK_MINVAL ((T)1e-15)
+
+__device__ __forceinline__ float bcast(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v),
+                                                             __builtin_amdgcn_readfirstlane(l)));
+}
+__device__ __forceinline__ int bcast(int v, int l) {
+  return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l));
+}
+__device__ __forceinline__ double bcast(double v, int l) {
+  long long b = __builtin_bit_cast(long long, v);
+  int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+  int sl = __builtin_amdgcn_readfirstlane(l);
+  lo = __builtin_amdgcn_readlane(lo, sl);
+  hi = __builtin_amdgcn_readlane(hi, sl);
+  long long r = ((long long)hi << 32) | (unsigned int)lo;
+  return __builtin_bit_cast(double, r);
+}
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned long long lanemask_lt(int lane) {
+  return (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+}
+__device__ __forceinline__ int tri(int i, int j) { return (i * (i + 1) >> 1) + j; }
+
+template <typename T> __device__ __forceinline__ T dot3(const T* a, const T* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+template <typename T> __device__ __forceinline__ void cross3(T* r, const T* a, const T* b) {
+  T x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+template <typename T> __device__ __forceinline__ void mat_vec(T* r, const T* m, const T* v) {
+  T x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+  T y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
+  T z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+template <typename T> __device__ __forceinline__ void matT_vec(T* r, const T* m, const T* v) {
+  T x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2];
+  T y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2];
+  T z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+template <typename T> __device__ __forceinline__ void mat_mul(T* r, const T* a, const T* b) {
+  T t[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      t[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; i++) r[i] = t[i];
+}
+// spatial inertia (about the tree reference point) times motion vector
+// I = [Ixx Iyy Izz Ixy Ixz Iyz mdx mdy mdz m]
+template <typename T> __device__ __forceinline__ void mul_inert(T* res, const T* I, const T* v) {
+  T t[3];
+  res[0] = I[0] * v[0] + I[3] * v[1] + I[4] * v[2];
+  res[1] = I[3] * v[0] + I[1] * v[1] + I[5] * v[2];
+  res[2] = I[4] * v[0] + I[5] * v[1] + I[2] * v[2];
+  cross3(t, I + 6, v + 3);
+  res[0] += t[0]; res[1] += t[1]; res[2] += t[2];
+  cross3(t, I + 6, v);
+  res[3] = I[9] * v[3] - t[0]; res[4] = I[9] * v[4] - t[1]; res[5] = I[9] * v[5] - t[2];
+}
+template <typename T> __device__ __forceinline__ T dot6(const T* a, const T* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+template <typename T> __device__ __forceinline__ void make_frame(const T* n, T* t1, T* t2) {
+  if (Num<T>::abs(n[1]) < (T)0.5) { t1[0] = 0; t1[1] = 1; t1[2] = 0; }
+  else { t1[0] = 0; t1[1] = 0; t1[2] = 1; }
+  T dp = dot3(n, t1);
+  t1[0] -= dp * n[0]; t1[1] -= dp * n[1]; t1[2] -= dp * n[2];
+  T inv = (T)1 / Num<T>::sqrt(dot3(t1, t1));
+  t1[0] *= inv; t1[1] *= inv; t1[2] *= inv;
+  cross3(t2, n, t1);
+}
+template <typename T>
+__device__ __forceinline__ T impedance(const T* solimp, T pos) {  // margin == 0
+  T dmin = fmin((T)0.9999, fmax((T)0.0001, solimp[0]));
+  T dmax = fmin((T)0.9999, fmax((T)0.0001, solimp[1]));
+  T width = fmax(RPK_MINVAL, solimp[2]);
+  T mid = fmin((T)0.9999, fmax((T)0.0001, solimp[3]));
+  T power = fmax((T)1, solimp[4]);
+  if (dmin == dmax || width <= RPK_MINVAL) return (T)0.5 * (dmin + dmax);
+  T x = Num<T>::abs(pos) / width;
+  if (x >= (T)1) return dmax;
+  if (x == (T)0) return dmin;
+  T y;
+  if (x <= mid) y = Num<T>::pow(x, power) / Num<T>::pow(mid, power - 1);
+  else y = (T)1 - Num<T>::pow((T)1 - x, power) / Num<T>::pow((T)1 - mid, power - 1);
+  return dmin + y * (dmax - dmin);
+}
+
+// ----------------------------------------------------------------- narrow phase
+template <typename T> struct RawCon { T dist, pos[3], n[3]; };
+
+template <typename T>
+__device__ __forceinline__ int sphere_sphere(RawCon<T>* c, const T* c1, T r1, const T* c2, T r2) {
+  T v[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
+  T len = Num<T>::sqrt(dot3(v, v)), dist = len - r1 - r2;
+  if (dist > (T)0) return 0;
+  if (len < RPK_MINVAL) { v[0] = 1; v[1] = 0; v[2] = 0; }
+  else { T inv = (T)1 / len; v[0] *= inv; v[1] *= inv; v[2] *= inv; }
+  c->dist = dist;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { c->n[k] = v[k]; c->pos[k] = c1[k] + v[k] * (r1 + (T)0.5 * dist); }
+  return 1;
+}
+
+template <typename T>
+__device__ int capsule_capsule(RawCon<T>* out, const T* p1, const T* m1, const T* s1, const T* p2,
+                               const T* m2, const T* s2) {
+  T a1[3] = {m1[2], m1[5], m1[8]}, a2[3] = {m2[2], m2[5], m2[8]};
+  T r1 = s1[0], l1 = s1[1], r2 = s2[0], l2 = s2[1];
+  T dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+  T b = dot3(a1, a2), u = -dot3(a1, dif), v = dot3(a2, dif);
+  T det = (T)1 - b * b;
+  int n = 0;
+  T c1[3], c2[3];
+  if (det > (T)1e-10) {
+    T x1 = (u + b * v) / det, x2 = (v + b * u) / det;
+    if (x1 > l1) { x1 = l1; x2 = v + b * x1; } else if (x1 < -l1) { x1 = -l1; x2 = v + b * x1; }
+    if (x2 > l2) { x2 = l2; x1 = fmin(l1, fmax(-l1, u + b * x2)); }
+    else if (x2 < -l2) { x2 = -l2; x1 = fmin(l1, fmax(-l1, u + b * x2)); }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * x1; c2[k] = p2[k] + a2[k] * x2; }
+    n += sphere_sphere(out + n, c1, r1, c2, r2);
+  } else {
+    T sgn = b >= 0 ? (T)1 : (T)-1, mid = u;
+    T lo = fmax(-l1, mid - l2), hi = fmin(l1, mid + l2);
+    if (lo <= hi) {
+      int cnt = (hi - lo > (T)1e-12) ? 2 : 1;
+      for (int q = 0; q < cnt; q++) {
+        T x1 = q == 0 ? lo : hi, x2 = sgn * (x1 - mid);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * x1; c2[k] = p2[k] + a2[k] * x2; }
+        n += sphere_sphere(out + n, c1, r1, c2, r2);
+      }
+    } else {
+      T x1 = mid > 0 ? l1 : -l1;
+      T x2 = fmin(l2, fmax(-l2, sgn * (x1 - mid)));
+#pragma unroll
+      for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * x1; c2[k] = p2[k] + a2[k] * x2; }
+      n += sphere_sphere(out + n, c1, r1, c2, r2);
+    }
+  }
+  return n;
+}
+
+template <typename T>
+__device__ __forceinline__ T seg_box_g(const T* c, const T* a, const T* h, T t) {
+  T g = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    T p = c[k] + t * a[k];
+    if (p > h[k]) g += a[k] * (p - h[k]); else if (p < -h[k]) g += a[k] * (p + h[k]);
+  }
+  return g;
+}
+
+template <typename T>
+__device__ __forceinline__ int sphere_box_local(RawCon<T>* c, const T* p, T r, const T* h) {
+  T q[3], v[3], d2 = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    q[k] = p[k] > h[k] ? h[k] : (p[k] < -h[k] ? -h[k] : p[k]);
+    v[k] = p[k] - q[k]; d2 += v[k] * v[k];
+  }
+  T nbs[3], dist;
+  if (d2 > 0) {
+    T dd = Num<T>::sqrt(d2);
+    dist = dd - r;
+    T inv = (T)1 / dd;
+    nbs[0] = v[0] * inv; nbs[1] = v[1] * inv; nbs[2] = v[2] * inv;
+  } else {
+    int ax = 0; T best = (T)-1e30;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { T pen = Num<T>::abs(p[k]) - h[k]; if (pen > best) { best = pen; ax = k; } }
+    nbs[0] = nbs[1] = nbs[2] = 0;
+    T sg = p[ax] >= 0 ? (T)1 : (T)-1;
+    nbs[ax] = sg; q[ax] = sg * h[ax];
+    dist = best - r;
+  }
+  if (dist > 0) return 0;
+  c->dist = dist;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { c->pos[k] = q[k] + nbs[k] * (T)0.5 * dist; c->n[k] = -nbs[k]; }
+  return 1;
+}
+
+// capsule (geom1) vs box (geom2): closest axis point (exact root of the piecewise
+// linear distance derivative) plus both segment ends.
+template <typename T>
+__device__ int capsule_box(RawCon<T>* out, const T* cp, const T* cm, const T* cs, const T* bp,
+                           const T* bm, const T* bs) {
+  T r = cs[0], l = cs[1];
+  T ax[3] = {cm[2], cm[5], cm[8]}, rel[3] = {cp[0] - bp[0], cp[1] - bp[1], cp[2] - bp[2]};
+  T c[3], a[3];
+  matT_vec(c, bm, rel);
+  matT_vec(a, bm, ax);
+  a[0] *= l; a[1] *= l; a[2] *= l;
+  T tstar;
+  T gm = seg_box_g(c, a, bs, (T)-1), gp = seg_box_g(c, a, bs, (T)1);
+  if (gm >= 0) tstar = -1;
+  else if (gp <= 0) tstar = 1;
+  else {
+    T tl = -1, gl = gm, tr = 1, gr = gp;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (Num<T>::abs(a[k]) > RPK_MINVAL) {
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+          T tt = ((s == 0 ? bs[k] : -bs[k]) - c[k]) / a[k];
+          if (tt > -1 && tt < 1) {
+            T g = seg_box_g(c, a, bs, tt);
+            if (g <= 0 && tt > tl) { tl = tt; gl = g; }
+            if (g >= 0 && tt < tr) { tr = tt; gr = g; }
+          }
+        }
+      }
+    }
+    if (tr <= tl) tstar = tl;
+    else if (gr - gl > 0) tstar = tl + (tr - tl) * (-gl) / (gr - gl);
+    else tstar = tl;
+  }
+  int n = 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    T tc = i == 0 ? tstar : (i == 1 ? (T)-1 : (T)1);
+    if (i > 0 && Num<T>::abs(tc - tstar) < (T)1e-9) continue;
+    T p[3] = {c[0] + tc * a[0], c[1] + tc * a[1], c[2] + tc * a[2]};
+    RawCon<T> rc;
+    if (sphere_box_local(&rc, p, r, bs)) {
+      T w[3];
+      mat_vec(w, bm, rc.pos);
+      out[n].pos[0] = bp[0] + w[0]; out[n].pos[1] = bp[1] + w[1]; out[n].pos[2] = bp[2] + w[2];
+      mat_vec(out[n].n, bm, rc.n);
+      out[n].dist = rc.dist;
+      n++;
+    }
+  }
+  return n;
+}
+
+// ----------------------------------------------------------------- shared memory
+template <typename T>
+struct Smem {
+  T xpos[RPK_NL][3];
+  T xmat[RPK_NL][9];
+  T xaxis[RPK_NL][3];
+  T xanchor[RPK_NL][3];
+  T cdof[RPK_NL][6];
+  T vel[RPK_NL][6];
+  T Mh[RPK_NL * (RPK_NL + 1) / 2];
+  union {
+    T acc[RPK_NL][10];
+    T H[RPK_WAVE * (RPK_WAVE + 1) / 2];
+  };
+  T vec[2][RPK_WAVE];
+  T keyvec[2][RPK_NKEYS];
+  T kq[RPK_NKEYS];
+  T gpos[RPK_WAVE][3];
+  T actf[RPK_WAVE];
+  T cpos[RPK_NC][3];
+  T cn[RPK_NC][3];
+  T cdist[RPK_NC];
+  T cpar[RPK_NC][4];  // mu, kterm (K*imp*dist), B, D
+  int cA[RPK_NC], cB[RPK_NC], cgA[RPK_NC], cgB[RPK_NC];
+  T cJ[RPK_NC][2][RPK_MAXD][3];
+  int work[RPK_WORK][2];
+  int slotkey[RPK_WAVE];
+  int keyslot[RPK_NKEYS];
+};
+
+// rows owned by one lane: friction-loss row of its hand dof, one limit row per dof
+// slot (hand, key, key+64), four pyramidal rows of its contact.
+template <typename T> struct Rows { T fr, lim[3], con[4]; };
+
+// packed lower-triangular Cholesky, lane = row.  n uniform.
+template <typename T>
+__device__ void chol_packed(T* H, int n, int lane, int* warn) {
+  for (int j = 0; j < n; j++) {
+    T s = 0;
+    if (lane >= j && lane < n) {
+      s = H[tri(lane, j)];
+      const T* ri = H + tri(lane, 0);
+      const T* rj = H + tri(j, 0);
+      for (int p = 0; p < j; p++) s -= ri[p] * rj[p];
+    }
+    T sj = bcast(s, j);
+    if (sj < RPK_MINVAL) { sj = RPK_MINVAL; *warn |= 4; }
+    T ljj = Num<T>::sqrt(sj);
+    if (lane == j) H[tri(j, j)] = ljj;
+    else if (lane > j && lane < n) H[tri(lane, j)] = s / ljj;
+    __syncthreads();
+  }
+}
+// solves (L L^T) x = b, x/b in the register of lane i (< n).
+template <typename T>
+__device__ T solve_packed(const T* H, int n, int lane, T x) {
+  T invd = (lane < n) ? (T)1 / H[tri(lane, lane)] : (T)0;
+  for (int p = 0; p < n; p++) {
+    if (lane == p) x *= invd;
+    T xp = bcast(x, p);
+    if (lane > p && lane < n) x -= H[tri(lane, p)] * xp;
+  }
+  for (int p = n - 1; p >= 0; p--) {
+    if (lane == p) x *= invd;
+    T xp = bcast(x, p);
+    if (lane < p) x -= H[tri(p, lane)] * xp;
+  }
+  return x;
+}
+// y = M v, M symmetric packed (n rows), v staged in LDS
+template <typename T>
+__device__ T symv_packed(const T* M, int n, int lane, const T* v) {
+  T s = 0;
+  if (lane < n) {
+    const T* ri = M + tri(lane, 0);
+    for (int j = 0; j <= lane; j++) s += ri[j] * v[j];
+    for (int j = lane + 1; j < n; j++) s += M[tri(j, lane)] * v[j];
+  }
+  return s;
+}
+
+}  // namespace rpk
+
+// ============================================================================
+// The step kernel.  mode 0: n_sub x (acceleration stage, Euler, position/velocity
+// stage).  mode 1: position/velocity stage only (physics.forward()).
+// ============================================================================
+template <typename T>
+__global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S, int nsub, int mode) {
+  using namespace rpk;
+  using N = Num<T>;
+  const int env = blockIdx.x;
+  const int lane = threadIdx.x;
+  __shared__ Smem<T> sm;
+  int warn = 0;
+  const int nl = M.nlink, nk = M.nkey, nv = M.nv, nu = M.nu;
+  const T h = M.timestep;
+
+  // ------------------------------------------------------------ lane constants
+  const bool isl = lane < nl;
+  const int L = isl ? lane : 0;
+  const int parent = isl ? M.link_parent[L] : -1;
+  const int depth = isl ? M.link_depth[L] : -1;
+  const int jtype = M.link_jtype ? (isl ? M.link_jtype[L] : 0) : 0;
+  const int sibrank = isl ? M.link_sibrank[L] : 0;
+  const int ltree = isl ? M.link_tree[L] : 0;
+  const int ldof = isl ? M.link_dof[L] : 0;
+  int anc[RPK_MAXD];
+#pragma unroll
+  for (int k = 0; k < RPK_MAXD; k++) anc[k] = isl ? M.link_anc[L * RPK_MAXD + k] : -1;
+  T lpos[3], lmat[9], laxis[3], lanchor[3], lipos[3], linert[6], tref[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    lpos[k] = isl ? M.link_lpos[3 * L + k] : (T)0;
+    laxis[k] = isl ? M.link_axis[3 * L + k] : (T)0;
+    lanchor[k] = isl ? M.link_anchor[3 * L + k] : (T)0;
+    lipos[k] = isl ? M.link_ipos[3 * L + k] : (T)0;
+    tref[k] = isl ? M.tree_ref[3 * ltree + k] : (T)0;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) lmat[k] = isl ? M.link_lmat[9 * L + k] : (T)0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) linert[k] = isl ? M.link_inertia[6 * L + k] : (T)0;
+  const T lmass = isl ? M.link_mass[L] : (T)0;
+  const T larm = isl ? M.link_armature[L] : (T)0;
+  const T ldamp = isl ? M.link_damping[L] : (T)0;
+  const T lstiff = isl ? M.link_stiffness[L] : (T)0;
+  const T lsref = isl ? M.link_springref[L] : (T)0;
+  const T lfloss = isl ? M.link_floss[L] : (T)0;
+  const T lflR = isl ? M.link_fl_R[L] : (T)1;
+  const T lflB = isl ? M.link_fl_B[L] : (T)0;
+  const T lflD = (T)1 / lflR;
+  const int llimited = isl ? M.link_limited[L] : 0;
+  const int lact = isl ? M.link_act[L] : -1;
+  const T lactcoef = isl ? M.link_act_coef[L] : (T)0;
+  const T gscale = (isl && nl) ? M.tree_gscale[ltree] : (T)0;
+  if (isl && parent < 0 && S.tree_offset) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      T o = S.tree_offset[((size_t)env * M.ntree + ltree) * 3 + k];
+      lpos[k] += o;
+    }
+  }
+  // limit parameters of the three dof slots: 0 = hand link, 1 = key lane, 2 = key lane+64
+  T lo[3], hi[3], limK[3], limB[3], limW[3];
+  int hasdof[3];
+  hasdof[0] = isl && llimited; hasdof[1] = lane < nk; hasdof[2] = lane + 64 < nk;
+  const bool isk[2] = {lane < nk, lane + 64 < nk};
+  const int kid[2] = {lane, lane + 64};
+  lo[0] = isl ? M.link_range[2 * L] : (T)0; hi[0] = isl ? M.link_range[2 * L + 1] : (T)0;
+  limK[0] = isl ? M.link_lim_K[L] : (T)0; limB[0] = isl ? M.link_lim_B[L] : (T)0;
+  limW[0] = isl ? M.link_invw_dof[L] : (T)0;
+  T kM[2], kstiff[2], ksref[2], kdamp[2], kmass[2], kpos[2][3], khalf[2][3], krb[2], kinvwb[2];
+  int kdof[2], kact[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const int K = isk[s] ? kid[s] : 0;
+    const bool ok = isk[s];
+    lo[1 + s] = ok ? M.key_range[2 * K] : (T)0; hi[1 + s] = ok ? M.key_range[2 * K + 1] : (T)0;
+    limK[1 + s] = ok ? M.key_lim_K[K] : (T)0; limB[1 + s] = ok ? M.key_lim_B[K] : (T)0;
+    limW[1 + s] = ok ? M.key_invw_dof[K] : (T)0;
+    kM[s] = ok ? M.key_M[K] : (T)1; kstiff[s] = ok ? M.key_stiffness[K] : (T)0;
+    ksref[s] = ok ? M.key_springref[K] : (T)0; kdamp[s] = ok ? M.key_damping[K] : (T)0;
+    kmass[s] = ok ? M.key_mass[K] : (T)0; kdof[s] = ok ? M.key_dof[K] : 0;
+    kact[s] = ok ? M.key_act[K] : -1; krb[s] = ok ? M.key_rbound[K] : (T)0;
+    kinvwb[s] = ok ? M.key_invw_body[K] : (T)0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      kpos[s][k] = ok ? M.key_pos[3 * K + k] : (T)0;
+      khalf[s][k] = ok ? M.key_half[3 * K + k] : (T)0;
+    }
+  }
+  // actuator owned by this lane (hand actuators only; key actuators live with the key)
+  const bool isa = lane < nu && M.act_kind[lane < nu ? lane : 0] == 0;
+  const int A = lane < nu ? lane : 0;
+  const int alane0 = isa ? M.act_lane[2 * A] : -1, alane1 = isa ? M.act_lane[2 * A + 1] : -1;
+  const T acoef0 = isa ? M.act_coef[2 * A] : (T)0, acoef1 = isa ? M.act_coef[2 * A + 1] : (T)0;
+
+  // ------------------------------------------------------------------- state
+  const size_t eo = (size_t)env * nv;
+  T q[3], qd[3], qw[3], qapp[3];
+  q[0] = isl ? S.qpos[eo + ldof] : (T)0; qd[0] = isl ? S.qvel[eo + ldof] : (T)0;
+  qw[0] = isl ? S.warm[eo + ldof] : (T)0;
+  qapp[0] = (isl && S.qfrc_applied) ? S.qfrc_applied[eo + ldof] : (T)0;
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    q[1 + s] = isk[s] ? S.qpos[eo + kdof[s]] : (T)0;
+    qd[1 + s] = isk[s] ? S.qvel[eo + kdof[s]] : (T)0;
+    qw[1 + s] = isk[s] ? S.warm[eo + kdof[s]] : (T)0;
+    qapp[1 + s] = (isk[s] && S.qfrc_applied) ? S.qfrc_applied[eo + kdof[s]] : (T)0;
+  }
+  T ctrl = (lane < nu) ? S.ctrl[(size_t)env * nu + lane] : (T)0;
+  if (lane < nu && M.act_ctrllimited[A])
+    ctrl = fmin(M.act_ctrlrange[2 * A + 1], fmax(M.act_ctrlrange[2 * A], ctrl));
+  T kctrl[2] = {0, 0};
+#pragma unroll
+  for (int s = 0; s < 2; s++) if (isk[s] && kact[s] >= 0) {
+    T c = S.ctrl[(size_t)env * nu + kact[s]];
+    if (M.act_ctrllimited[kact[s]])
+      c = fmin(M.act_ctrlrange[2 * kact[s] + 1], fmax(M.act_ctrlrange[2 * kact[s]], c));
+    kctrl[s] = c;
+  }
+  T time = S.time[env];
+
+  // zero the structurally-zero part of the packed hand mass matrix once
+  for (int i = lane; i < RPK_NL * (RPK_NL + 1) / 2; i += 64) sm.Mh[i] = 0;
+  __syncthreads();
+
+  // values produced by the position/velocity stage and consumed by the next
+  // acceleration stage
+  T cdofr[6], qbias = 0, alen = 0, avel = 0;
+  T ksin[2] = {0, 0}, kcos[2] = {1, 1};
+  int ncon = 0, nkt = 0;
+  // rows
+  T fr_aref = 0;
+  int lim_sign[3] = {0, 0, 0};
+  T lim_D[3] = {0, 0, 0}, lim_aref[3] = {0, 0, 0};
+  T con_aref[4] = {0, 0, 0, 0}, con_D = 0, con_mu = 0, con_n[3] = {0, 0, 0}, con_t1[3] = {0, 0, 0},
+    con_t2[3] = {0, 0, 0};
+  int con_A = -1, con_B = -1, con_slot = -1;
+  unsigned long long con_maskA = 0, con_maskB = 0;
+  int niter_last = 0;
+
+  const int nstage = (mode == 1) ? 1 : nsub + 1;
+  for (int stage = 0; stage < nstage; stage++) {
+    // ======================================================================
+    // ACCELERATION STAGE + EULER (skipped on the first pass: state is fresh)
+    // ======================================================================
+    if (stage > 0) {
+      // ---- actuation [MJ: mj_fwdActuation]
+      T aforce = 0;
+      if (isa) {
+        aforce = M.act_gain[A] * ctrl + M.act_bias[3 * A] + M.act_bias[3 * A + 1] * alen +
+                 M.act_bias[3 * A + 2] * avel;
+        if (M.act_forcelimited[A])
+          aforce = fmin(M.act_forcerange[2 * A + 1], fmax(M.act_forcerange[2 * A], aforce));
+        sm.actf[lane] = aforce;
+        S.act_force[(size_t)env * nu + lane] = aforce;
+      }
+      __syncthreads();
+      T qfs[3], qs[3];
+      {
+        T qact = (isl && lact >= 0) ? lactcoef * sm.actf[lact] : (T)0;
+        T qpas = -lstiff * (q[0] - lsref) - ldamp * qd[0];
+        qfs[0] = isl ? (qpas - qbias + qapp[0] + qact) : (T)0;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+          T f = 0;
+          if (isk[s]) {
+            // passive spring/damper, gravity torque m*g*(hx)*cos(q) about +y, actuator
+            T grav = -kmass[s] * M.gz * khalf[s][0] * kcos[s] - kmass[s] * M.gx * khalf[s][0] * ksin[s];
+            f = -kstiff[s] * (q[1 + s] - ksref[s]) - kdamp[s] * qd[1 + s] + grav + qapp[1 + s];
+            if (kact[s] >= 0) {
+              T af = M.act_gain[kact[s]] * kctrl[s];
+              if (M.act_forcelimited[kact[s]])
+                af = fmin(M.act_forcerange[2 * kact[s] + 1], fmax(M.act_forcerange[2 * kact[s]], af));
+              f += M.act_coef[2 * kact[s]] * af;
+              S.act_force[(size_t)env * nu + kact[s]] = af;
+            }
+          }
+          qfs[1 + s] = f;
+          qs[1 + s] = f / kM[s];
+        }
+      }
+      // ---- qacc_smooth = M^-1 qfrc_smooth (hand: dense packed Cholesky)
+      for (int i = lane; i < tri(nl, 0); i += 64) sm.H[i] = sm.Mh[i];
+      __syncthreads();
+      chol_packed(sm.H, nl, lane, &warn);
+      qs[0] = solve_packed(sm.H, nl, lane, qfs[0]);
+      __syncthreads();
+
+      // ---- constraint solve [MJ: mj_solNewton]
+      const int nsys = nl + nkt;
+      const bool hascon = lane < ncon && con_D > 0;
+      const T scale = (T)1 / (M.meaninertia * (T)(nv > 1 ? nv : 1));
+      T qa[3], Ma[3], qfc[3];
+      Rows<T> jar, frc;
+      int fr_quad = 0, lim_act[3] = {0, 0, 0}, con_act[4] = {0, 0, 0, 0};
+
+      // y = J x for the rows owned by this lane (x in per-lane slot registers)
+      auto mulJ = [&](const T* x, Rows<T>& out) {
+        sm.vec[0][lane] = x[0];
+        if (isk[0]) sm.keyvec[0][kid[0]] = x[1];
+        if (isk[1]) sm.keyvec[0][kid[1]] = x[2];
+        __syncthreads();
+        out.fr = x[0];
+#pragma unroll
+        for (int s = 0; s < 3; s++) out.lim[s] = (T)lim_sign[s] * x[s];
+        T vc[3] = {0, 0, 0};
+        if (hascon) {
+#pragma unroll
+          for (int side = 0; side < 2; side++) {
+            int Lk = side ? con_B : con_A;
+            if (Lk >= RPK_KEYBASE) {
+              T xv = sm.keyvec[0][Lk - RPK_KEYBASE];
+              const T* jc = sm.cJ[lane][side][0];
+              vc[0] += jc[0] * xv; vc[1] += jc[1] * xv; vc[2] += jc[2] * xv;
+            } else if (Lk >= 0) {
+              int dL = M.link_depth[Lk];
+              for (int lv = 0; lv <= dL; lv++) {
+                T xv = sm.vec[0][M.link_anc[Lk * RPK_MAXD + lv]];
+                const T* jc = sm.cJ[lane][side][lv];
+                vc[0] += jc[0] * xv; vc[1] += jc[1] * xv; vc[2] += jc[2] * xv;
+              }
+            }
+          }
+        }
+        T vn = dot3(con_n, vc), v1 = con_mu * dot3(con_t1, vc), v2 = con_mu * dot3(con_t2, vc);
+        out.con[0] = vn + v1; out.con[1] = vn - v1; out.con[2] = vn + v2; out.con[3] = vn - v2;
+        __syncthreads();
+      };
+      // forces + active set from jar; returns this lane's share of the constraint cost
+      auto update = [&](const Rows<T>& ja, Rows<T>& f) -> T {
+        T cost = 0;
+        f.fr = 0; fr_quad = 0;
+        if (isl && lfloss > 0) {
+          T x = ja.fr, rf = lflR * lfloss;
+          if (x <= -rf) { f.fr = lfloss; cost += -(T)0.5 * rf * lfloss - lfloss * x; }
+          else if (x >= rf) { f.fr = -lfloss; cost += -(T)0.5 * rf * lfloss + lfloss * x; }
+          else { f.fr = -lflD * x; fr_quad = 1; cost += (T)0.5 * lflD * x * x; }
+        }
+#pragma unroll
+        for (int s = 0; s < 3; s++) {
+          f.lim[s] = 0; lim_act[s] = 0;
+          if (lim_sign[s] != 0 && ja.lim[s] < 0) {
+            f.lim[s] = -lim_D[s] * ja.lim[s]; lim_act[s] = 1;
+            cost += (T)0.5 * lim_D[s] * ja.lim[s] * ja.lim[s];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          f.con[r] = 0; con_act[r] = 0;
+          if (hascon && ja.con[r] < 0) {
+            f.con[r] = -con_D * ja.con[r]; con_act[r] = 1;
+            cost += (T)0.5 * con_D * ja.con[r] * ja.con[r];
+          }
+        }
+        return cost;
+      };
+      // out = J^T f
+      auto mulJT = [&](const Rows<T>& f, T* out) {
+        out[0] = f.fr + (T)lim_sign[0] * f.lim[0];
+        out[1] = (T)lim_sign[1] * f.lim[1];
+        out[2] = (T)lim_sign[2] * f.lim[2];
+        T fn = f.con[0] + f.con[1] + f.con[2] + f.con[3];
+        T f1 = con_mu * (f.con[0] - f.con[1]), f2 = con_mu * (f.con[2] - f.con[3]);
+        T fc[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) fc[k] = fn * con_n[k] + f1 * con_t1[k] + f2 * con_t2[k];
+        for (int c = 0; c < ncon; c++) {
+          T f0 = bcast(fc[0], c), f1c = bcast(fc[1], c), f2c = bcast(fc[2], c);
+          int cA = bcast(con_A, c), cB = bcast(con_B, c);
+          unsigned long long mA = ((unsigned long long)(unsigned)bcast((int)(con_maskA >> 32), c) << 32) |
+                                  (unsigned)bcast((int)(con_maskA & 0xffffffffu), c);
+          unsigned long long mB = ((unsigned long long)(unsigned)bcast((int)(con_maskB >> 32), c) << 32) |
+                                  (unsigned)bcast((int)(con_maskB & 0xffffffffu), c);
+          if (isl) {
+            if ((mA >> lane) & 1) {
+              const T* jc = sm.cJ[c][0][depth];
+              out[0] += jc[0] * f0 + jc[1] * f1c + jc[2] * f2c;
+            }
+            if ((mB >> lane) & 1) {
+              const T* jc = sm.cJ[c][1][depth];
+              out[0] += jc[0] * f0 + jc[1] * f1c + jc[2] * f2c;
+            }
+          }
+#pragma unroll
+          for (int side = 0; side < 2; side++) {
+            int Lk = side ? cB : cA;
+            if (Lk >= RPK_KEYBASE) {
+              int k = Lk - RPK_KEYBASE;
+              if ((k & 63) == lane) {
+                const T* jc = sm.cJ[c][side][0];
+                T v = jc[0] * f0 + jc[1] * f1c + jc[2] * f2c;
+                if (k < 64) out[1] += v; else out[2] += v;
+              }
+            }
+          }
+        }
+      };
+      auto gauss = [&](const T* qa_, const T* Ma_) -> T {
+        T g = 0;
+#pragma unroll
+        for (int s = 0; s < 3; s++) g += (Ma_[s] - qfs[s]) * (qa_[s] - qs[s]);
+        return (T)0.5 * g;
+      };
+      auto mulM = [&](const T* x, T* out) {
+        sm.vec[1][lane] = x[0];
+        __syncthreads();
+        out[0] = symv_packed(sm.Mh, nl, lane, sm.vec[1]);
+        out[1] = kM[0] * x[1];
+        out[2] = kM[1] * x[2];
+        __syncthreads();
+      };
+      auto sub_aref = [&](Rows<T>& r) {
+        r.fr -= fr_aref;
+#pragma unroll
+        for (int s = 0; s < 3; s++) r.lim[s] -= lim_aref[s];
+#pragma unroll
+        for (int k = 0; k < 4; k++) r.con[k] -= con_aref[k];
+      };
+
+      // any constraint rows at all?  (uniform)
+      int anyrow = (isl && lfloss > 0) || lim_sign[0] || lim_sign[1] || lim_sign[2] || hascon;
+      anyrow = __ballot(anyrow) != 0ull;
+      niter_last = 0;
+      if (!anyrow) {
+#pragma unroll
+        for (int s = 0; s < 3; s++) { qa[s] = qs[s]; qfc[s] = 0; }
+      } else {
+        // warmstart [MJ: warmstart()]
+        Rows<T> jtmp;
+        mulJ(qs, jtmp); sub_aref(jtmp);
+        T cost_smooth = wave_sum(update(jtmp, frc));
+#pragma unroll
+        for (int s = 0; s < 3; s++) qa[s] = qw[s];
+        mulM(qa, Ma);
+        mulJ(qa, jar); sub_aref(jar);
+        T cost = wave_sum(update(jar, frc) + gauss(qa, Ma));
+        if (cost > cost_smooth) {
+#pragma unroll
+          for (int s = 0; s < 3; s++) { qa[s] = qs[s]; Ma[s] = qfs[s]; }
+          jar = jtmp;
+          cost = wave_sum(update(jar, frc) + gauss(qa, Ma));
+        }
+        mulJT(frc, qfc);
+        T grad[3];
+#pragma unroll
+        for (int s = 0; s < 3; s++) grad[s] = Ma[s] - qfs[s] - qfc[s];
+
+        const int maxit = S.max_newton;
+        for (int iter = 0; iter < maxit; iter++) {
+          // ---- H = M + J^T D J on the coupled system (hand dofs + touched keys)
+          for (int i = lane; i < tri(nl, 0); i += 64) sm.H[i] = sm.Mh[i];
+          for (int i = tri(nl, 0) + lane; i < tri(nsys, 0); i += 64) sm.H[i] = 0;
+          // key diagonals and gradients to the solver slots
+#pragma unroll
+          for (int s = 0; s < 2; s++) if (isk[s]) {
+            sm.keyvec[0][kid[s]] = kM[s] + (lim_act[1 + s] ? lim_D[1 + s] : (T)0);
+            sm.keyvec[1][kid[s]] = grad[1 + s];
+          }
+          __syncthreads();
+          T rhs = grad[0];
+          if (isl) sm.H[tri(lane, lane)] += (fr_quad ? lflD : (T)0) + (lim_act[0] ? lim_D[0] : (T)0);
+          else if (lane < nsys) {
+            int k = sm.slotkey[lane - nl];
+            sm.H[tri(lane, lane)] = sm.keyvec[0][k];
+            rhs = sm.keyvec[1][k];
+          } else rhs = 0;
+          __syncthreads();
+          // contact blocks
+          {
+            T Dr[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) Dr[r] = con_act[r] ? con_D : (T)0;
+            // C = sum_r D_r w_r w_r^T with w = n +- mu t
+            T sn = Dr[0] + Dr[1] + Dr[2] + Dr[3];
+            T a1 = con_mu * (Dr[0] - Dr[1]), a2 = con_mu * (Dr[2] - Dr[3]);
+            T b1 = con_mu * con_mu * (Dr[0] + Dr[1]), b2 = con_mu * con_mu * (Dr[2] + Dr[3]);
+            T Cm[6];  // xx yy zz xy xz yz
+            const int ia[6] = {0, 1, 2, 0, 0, 1}, ib[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+            for (int e = 0; e < 6; e++) {
+              int a = ia[e], b = ib[e];
+              Cm[e] = sn * con_n[a] * con_n[b] + a1 * (con_n[a] * con_t1[b] + con_t1[a] * con_n[b]) +
+                      a2 * (con_n[a] * con_t2[b] + con_t2[a] * con_n[b]) + b1 * con_t1[a] * con_t1[b] +
+                      b2 * con_t2[a] * con_t2[b];
+            }
+            int anyact = hascon && (con_act[0] | con_act[1] | con_act[2] | con_act[3]);
+            for (int c = 0; c < ncon; c++) {
+              if (!bcast(anyact, c)) continue;
+              T C0 = bcast(Cm[0], c), C1 = bcast(Cm[1], c), C2 = bcast(Cm[2], c), C3 = bcast(Cm[3], c),
+                C4 = bcast(Cm[4], c), C5 = bcast(Cm[5], c);
+              int cA = bcast(con_A, c), cB = bcast(con_B, c), cslot = bcast(con_slot, c);
+              unsigned long long mA = ((unsigned long long)(unsigned)bcast((int)(con_maskA >> 32), c) << 32) |
+                                      (unsigned)bcast((int)(con_maskA & 0xffffffffu), c);
+              unsigned long long mB = ((unsigned long long)(unsigned)bcast((int)(con_maskB >> 32), c) << 32) |
+                                      (unsigned)bcast((int)(con_maskB & 0xffffffffu), c);
+              unsigned long long sup = mA | mB;
+              int keyside = cA >= RPK_KEYBASE ? 0 : (cB >= RPK_KEYBASE ? 1 : -1);
+              if (keyside >= 0 && cslot >= 0) sup |= 1ull << (nl + cslot);
+              // this lane's column of J_diff for contact c
+              T jc[3] = {0, 0, 0};
+              if (isl) {
+                if ((mA >> lane) & 1) { const T* p = sm.cJ[c][0][depth]; jc[0] += p[0]; jc[1] += p[1]; jc[2] += p[2]; }
+                if ((mB >> lane) & 1) { const T* p = sm.cJ[c][1][depth]; jc[0] += p[0]; jc[1] += p[1]; jc[2] += p[2]; }
+              } else if (keyside >= 0 && lane == nl + cslot) {
+                const T* p = sm.cJ[c][keyside][0]; jc[0] = p[0]; jc[1] = p[1]; jc[2] = p[2];
+              }
+              T u0 = C0 * jc[0] + C3 * jc[1] + C4 * jc[2];
+              T u1 = C3 * jc[0] + C1 * jc[1] + C5 * jc[2];
+              T u2 = C4 * jc[0] + C5 * jc[1] + C2 * jc[2];
+              bool insup = (sup >> lane) & 1;
+              unsigned long long rem = sup;
+              while (rem) {
+                int j = __ffsll((long long)rem) - 1;
+                rem &= rem - 1;
+                T j0 = bcast(jc[0], j), j1 = bcast(jc[1], j), j2 = bcast(jc[2], j);
+                if (insup && lane >= j) sm.H[tri(lane, j)] += u0 * j0 + u1 * j1 + u2 * j2;
+              }
+            }
+          }
+          __syncthreads();
+          chol_packed(sm.H, nsys, lane, &warn);
+          T x = solve_packed(sm.H, nsys, lane, rhs);
+          __syncthreads();
+          T search[3];
+          search[0] = isl ? -x : (T)0;
+          if (!isl && lane < nsys) sm.keyvec[0][sm.slotkey[lane - nl]] = -x;
+          __syncthreads();
+#pragma unroll
+          for (int s = 0; s < 2; s++) {
+            search[1 + s] = 0;
+            if (isk[s]) {
+              if (sm.keyslot[kid[s]] >= 0) search[1 + s] = sm.keyvec[0][kid[s]];
+              else search[1 + s] = -grad[1 + s] / (kM[s] + (lim_act[1 + s] ? lim_D[1 + s] : (T)0));
+            }
+          }
+          __syncthreads();
+          T snorm = N::sqrt(wave_sum(search[0] * search[0] + search[1] * search[1] + search[2] * search[2]));
+          if (!(snorm >= RPK_MINVAL)) break;
+          T Mv[3];
+          mulM(search, Mv);
+          Rows<T> jv;
+          mulJ(search, jv);
+          T g0 = 0, g1 = 0, g2 = 0;
+#pragma unroll
+          for (int s = 0; s < 3; s++) {
+            g0 += (Ma[s] - qfs[s]) * (qa[s] - qs[s]);
+            g1 += search[s] * (Ma[s] - qfs[s]);
+            g2 += search[s] * Mv[s];
+          }
+          g0 = (T)0.5 * wave_sum(g0); g1 = wave_sum(g1); g2 = (T)0.5 * wave_sum(g2);
+          // ---- exact line search: safeguarded Newton on phi'(alpha)
+          auto ls_eval = [&](T alpha, T& d1, T& d2) -> T {
+            T cst = 0, a = 0, b = 0;
+            if (isl && lfloss > 0) {
+              T xx = jar.fr + alpha * jv.fr, rf = lflR * lfloss;
+              if (xx <= -rf) { cst += -(T)0.5 * rf * lfloss - lfloss * xx; a += -lfloss * jv.fr; }
+              else if (xx >= rf) { cst += -(T)0.5 * rf * lfloss + lfloss * xx; a += lfloss * jv.fr; }
+              else { cst += (T)0.5 * lflD * xx * xx; a += lflD * xx * jv.fr; b += lflD * jv.fr * jv.fr; }
+            }
+#pragma unroll
+            for (int s = 0; s < 3; s++) if (lim_sign[s] != 0) {
+              T xx = jar.lim[s] + alpha * jv.lim[s];
+              if (xx < 0) { cst += (T)0.5 * lim_D[s] * xx * xx; a += lim_D[s] * xx * jv.lim[s]; b += lim_D[s] * jv.lim[s] * jv.lim[s]; }
+            }
+            if (hascon) {
+#pragma unroll
+              for (int r = 0; r < 4; r++) {
+                T xx = jar.con[r] + alpha * jv.con[r];
+                if (xx < 0) { cst += (T)0.5 * con_D * xx * xx; a += con_D * xx * jv.con[r]; b += con_D * jv.con[r] * jv.con[r]; }
+              }
+            }
+            cst = wave_sum(cst); a = wave_sum(a); b = wave_sum(b);
+            d1 = a + (T)2 * alpha * g2 + g1;
+            d2 = b + (T)2 * g2;
+            return cst + alpha * alpha * g2 + alpha * g1 + g0;
+          };
+          T gtol = M.tolerance * M.ls_tolerance * snorm / scale;
+          T f0, h0, f, hh;
+          T c0 = ls_eval((T)0, f0, h0);
+          T alpha = 0;
+          if (f0 < 0 && h0 > 0) {
+            T lo_ = 0, hi_ = (T)-1;  // hi_<0: unbounded
+            alpha = -f0 / h0;
+            for (int it = 0; it < S.max_ls; it++) {
+              ls_eval(alpha, f, hh);
+              if (N::abs(f) < gtol) break;
+              if (f < 0) lo_ = alpha; else hi_ = alpha;
+              T an = alpha - f / hh;
+              bool inside = an > lo_ && (hi_ < 0 || an < hi_);
+              if (!inside) an = hi_ < 0 ? (T)2 * alpha : (T)0.5 * (lo_ + hi_);
+              if (N::abs(an - alpha) <= (T)4 * N::eps() * N::abs(alpha)) { alpha = an; break; }
+              alpha = an;
+            }
+            T c1 = ls_eval(alpha, f, hh);
+            if (c1 > c0) alpha = 0;
+          }
+          if (!(alpha > 0)) break;
+#pragma unroll
+          for (int s = 0; s < 3; s++) { qa[s] += alpha * search[s]; Ma[s] += alpha * Mv[s]; }
+          jar.fr += alpha * jv.fr;
+#pragma unroll
+          for (int s = 0; s < 3; s++) jar.lim[s] += alpha * jv.lim[s];
+#pragma unroll
+          for (int r = 0; r < 4; r++) jar.con[r] += alpha * jv.con[r];
+          T oldcost = cost;
+          cost = wave_sum(update(jar, frc) + gauss(qa, Ma));
+          mulJT(frc, qfc);
+          niter_last = iter + 1;
+          T gn = 0;
+#pragma unroll
+          for (int s = 0; s < 3; s++) { grad[s] = Ma[s] - qfs[s] - qfc[s]; gn += grad[s] * grad[s]; }
+          gn = N::sqrt(wave_sum(gn));
+          if (scale * (oldcost - cost) < M.tolerance || scale * gn < M.tolerance) break;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 3; s++) qw[s] = qa[s];
+
+      // ---- Euler with implicit joint damping [MJ: mj_Euler, eulerdamp]
+      for (int i = lane; i < tri(nl, 0); i += 64) sm.H[i] = sm.Mh[i];
+      __syncthreads();
+      if (isl) sm.H[tri(lane, lane)] += h * ldamp;
+      __syncthreads();
+      chol_packed(sm.H, nl, lane, &warn);
+      T qe[3];
+      qe[0] = solve_packed(sm.H, nl, lane, qfs[0] + qfc[0]);
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < 2; s++) qe[1 + s] = (qfs[1 + s] + qfc[1 + s]) / (kM[s] + h * kdamp[s]);
+#pragma unroll
+      for (int s = 0; s < 3; s++) { qd[s] += h * qe[s]; q[s] += h * qd[s]; }
+      time += h;
+    }
+
+    // ======================================================================
+    // POSITION STAGE
+    // ======================================================================
+    {
+      bool bad = !(N::abs(q[0]) < (T)1e10) || !(N::abs(q[1]) < (T)1e10) || !(N::abs(q[2]) < (T)1e10) ||
+                 !(N::abs(qd[0]) < (T)1e10) || !(N::abs(qd[1]) < (T)1e10) || !(N::abs(qd[2]) < (T)1e10);
+      if (__ballot(bad)) warn |= 1;
+    }
+    // ---- forward kinematics by tree level [MJ: mj_kinematics]
+    T xp[3] = {0, 0, 0}, xm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, axw[3] = {0, 0, 0}, anw[3] = {0, 0, 0};
+    for (int d = 0; d < M.maxdepth; d++) {
+      if (isl && depth == d) {
+        T pp[3] = {0, 0, 0}, pm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (parent >= 0) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) pp[k] = sm.xpos[parent][k];
+#pragma unroll
+          for (int k = 0; k < 9; k++) pm[k] = sm.xmat[parent][k];
+        }
+        T t[3], m0[9];
+        mat_vec(t, pm, lpos);
+        T pos[3] = {pp[0] + t[0], pp[1] + t[1], pp[2] + t[2]};
+        mat_mul(m0, pm, lmat);
+        mat_vec(axw, m0, laxis);
+        mat_vec(t, m0, lanchor);
+        anw[0] = pos[0] + t[0]; anw[1] = pos[1] + t[1]; anw[2] = pos[2] + t[2];
+        if (jtype == JNT_SLIDE_) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) xp[k] = pos[k] + axw[k] * q[0];
+#pragma unroll
+          for (int k = 0; k < 9; k++) xm[k] = m0[k];
+        } else {
+          T s, c;
+          N::sincos(q[0], &s, &c);
+          T oc = (T)1 - c, ax = laxis[0], ay = laxis[1], az = laxis[2];
+          T R[9] = {c + oc * ax * ax, oc * ax * ay - s * az, oc * ax * az + s * ay,
+                    oc * ax * ay + s * az, c + oc * ay * ay, oc * ay * az - s * ax,
+                    oc * ax * az - s * ay, oc * ay * az + s * ax, c + oc * az * az};
+          mat_mul(xm, m0, R);
+          mat_vec(t, xm, lanchor);
+          xp[0] = anw[0] - t[0]; xp[1] = anw[1] - t[1]; xp[2] = anw[2] - t[2];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          sm.xpos[lane][k] = xp[k]; sm.xaxis[lane][k] = axw[k]; sm.xanchor[lane][k] = anw[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) sm.xmat[lane][k] = xm[k];
+      }
+      __syncthreads();
+    }
+    // ---- spatial inertia and motion axis about the tree reference point [MJ: mj_comPos]
+    T cin[10];
+    {
+      T t[3], A9[9], dd[3];
+      mat_vec(t, xm, lipos);
+#pragma unroll
+      for (int k = 0; k < 3; k++) dd[k] = xp[k] + t[k] - tref[k];
+      // A = xm * Iloc (Iloc symmetric)
+      const T I9[9] = {linert[0], linert[3], linert[4], linert[3], linert[1], linert[5],
+                       linert[4], linert[5], linert[2]};
+      mat_mul(A9, xm, I9);
+      T Iw[6];  // xx yy zz xy xz yz of A * xm^T
+      Iw[0] = A9[0] * xm[0] + A9[1] * xm[1] + A9[2] * xm[2];
+      Iw[1] = A9[3] * xm[3] + A9[4] * xm[4] + A9[5] * xm[5];
+      Iw[2] = A9[6] * xm[6] + A9[7] * xm[7] + A9[8] * xm[8];
+      Iw[3] = A9[0] * xm[3] + A9[1] * xm[4] + A9[2] * xm[5];
+      Iw[4] = A9[0] * xm[6] + A9[1] * xm[7] + A9[2] * xm[8];
+      Iw[5] = A9[3] * xm[6] + A9[4] * xm[7] + A9[5] * xm[8];
+      T d2 = dot3(dd, dd);
+      cin[0] = Iw[0] + lmass * (d2 - dd[0] * dd[0]);
+      cin[1] = Iw[1] + lmass * (d2 - dd[1] * dd[1]);
+      cin[2] = Iw[2] + lmass * (d2 - dd[2] * dd[2]);
+      cin[3] = Iw[3] - lmass * dd[0] * dd[1];
+      cin[4] = Iw[4] - lmass * dd[0] * dd[2];
+      cin[5] = Iw[5] - lmass * dd[1] * dd[2];
+      cin[6] = lmass * dd[0]; cin[7] = lmass * dd[1]; cin[8] = lmass * dd[2]; cin[9] = lmass;
+      if (jtype == JNT_SLIDE_) {
+        cdofr[0] = cdofr[1] = cdofr[2] = 0;
+        cdofr[3] = axw[0]; cdofr[4] = axw[1]; cdofr[5] = axw[2];
+      } else {
+        T off[3] = {tref[0] - anw[0], tref[1] - anw[1], tref[2] - anw[2]};
+        cdofr[0] = axw[0]; cdofr[1] = axw[1]; cdofr[2] = axw[2];
+        cross3(cdofr + 3, axw, off);
+      }
+      if (isl) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) sm.cdof[lane][k] = cdofr[k];
+#pragma unroll
+        for (int k = 0; k < 10; k++) sm.acc[lane][k] = cin[k];
+      }
+    }
+    __syncthreads();
+    // ---- composite inertias, children -> parent by level and sibling rank [MJ: mj_crb]
+    for (int d = M.maxdepth - 1; d >= 1; d--) {
+      int mr = M.level_maxrank[d];
+      for (int r = 0; r < mr; r++) {
+        if (isl && depth == d && sibrank == r) {
+#pragma unroll
+          for (int k = 0; k < 10; k++) sm.acc[parent][k] += sm.acc[lane][k];
+        }
+        __syncthreads();
+      }
+    }
+    if (isl) {
+      T crb[10], buf[6];
+#pragma unroll
+      for (int k = 0; k < 10; k++) crb[k] = sm.acc[lane][k];
+      mul_inert(buf, crb, cdofr);
+#pragma unroll
+      for (int k = 0; k < RPK_MAXD; k++) {
+        if (k <= depth) {
+          int a = anc[k];
+          T v = dot6(sm.cdof[a], buf);
+          if (a == lane) v += larm;
+          sm.Mh[tri(lane, a)] = v;
+        }
+      }
+    }
+    // ---- key poses, geom centres
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      if (isk[s]) {
+        N::sincos(q[1 + s], &ksin[s], &kcos[s]);
+        sm.kq[kid[s]] = q[1 + s];
+        sm.keyslot[kid[s]] = -1;
+      }
+    }
+    __syncthreads();
+    if (lane < M.ngeom) {
+      int gl = M.geom_link[lane];
+      T gp[3] = {M.geom_pos[3 * lane], M.geom_pos[3 * lane + 1], M.geom_pos[3 * lane + 2]};
+      if (gl >= 0) {
+        T t[3];
+        mat_vec(t, sm.xmat[gl], gp);
+        gp[0] = sm.xpos[gl][0] + t[0]; gp[1] = sm.xpos[gl][1] + t[1]; gp[2] = sm.xpos[gl][2] + t[2];
+      }
+      sm.gpos[lane][0] = gp[0]; sm.gpos[lane][1] = gp[1]; sm.gpos[lane][2] = gp[2];
+    }
+    __syncthreads();
+
+    // ---- broad phase: static pair list + (capsule x keys) family [MJ: mj_collision]
+    int nwork = 0;
+    for (int base = 0; base < M.npair; base += 64) {
+      int p = base + lane;
+      bool hit = false;
+      int ga = 0, gb = 0;
+      if (p < M.npair) {
+        ga = M.pair[2 * p]; gb = M.pair[2 * p + 1];
+        T dx = sm.gpos[ga][0] - sm.gpos[gb][0], dy = sm.gpos[ga][1] - sm.gpos[gb][1],
+          dz = sm.gpos[ga][2] - sm.gpos[gb][2];
+        T rr = M.geom_rbound[ga] + M.geom_rbound[gb];
+        hit = dx * dx + dy * dy + dz * dz <= rr * rr;
+      }
+      unsigned long long mk = __ballot(hit);
+      int idx = nwork + __popcll(mk & lanemask_lt(lane));
+      if (hit && idx < RPK_WORK) { sm.work[idx][0] = ga; sm.work[idx][1] = gb; }
+      nwork += __popcll(mk);
+    }
+    for (int base = 0; base < M.nkeycap; base += 64) {
+      int ci = base + lane;
+      bool near = false;
+      if (ci < M.nkeycap) {
+        int g = M.keycap[ci];
+        near = sm.gpos[g][2] - M.geom_rbound[g] <= M.key_zmax;
+      }
+      unsigned long long nm = __ballot(near);
+      while (nm) {
+        int cj = __ffsll((long long)nm) - 1;
+        nm &= nm - 1;
+        int g = M.keycap[base + cj];
+        T cx = sm.gpos[g][0], cy = sm.gpos[g][1], cz = sm.gpos[g][2], rb = M.geom_rbound[g];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+          bool hit = false;
+          if (isk[s]) {
+            // key box centre = anchor + R_y(q) (hx,0,0)
+            T kx = kpos[s][0] - khalf[s][0] + khalf[s][0] * kcos[s];
+            T kz = kpos[s][2] - khalf[s][0] * ksin[s];
+            T dx = kx - cx, dy = kpos[s][1] - cy, dz = kz - cz, rr = rb + krb[s];
+            // bounding spheres, then a conservative box test (the key only rotates
+            // about y, so its y-extent is exact; x/z get a 1 cm allowance)
+            hit = dx * dx + dy * dy + dz * dz <= rr * rr &&
+                  N::abs(dy) <= khalf[s][1] + rb &&
+                  N::abs(cx - kpos[s][0]) <= khalf[s][0] + rb + (T)0.01 &&
+                  cz - rb <= kpos[s][2] + khalf[s][2] + (T)0.01;
+          }
+          unsigned long long mk = __ballot(hit);
+          int idx = nwork + __popcll(mk & lanemask_lt(lane));
+          if (hit && idx < RPK_WORK) { sm.work[idx][0] = g; sm.work[idx][1] = RPK_KEYBASE + kid[s]; }
+          nwork += __popcll(mk);
+        }
+      }
+    }
+    if (nwork > RPK_WORK) { warn |= 16; nwork = RPK_WORK; }
+    __syncthreads();
+
+    // ---- narrow phase + contact parameters [MJ: mjc_* , mj_contactParam, mj_makeImpedance]
+    ncon = 0;
+    for (int base = 0; base < nwork; base += 64) {
+      int w = base + lane;
+      RawCon<T> rc[3];
+      int n = 0, ga = 0, gb = 0;
+      T pB[8], invw = 0;
+      if (w < nwork) {
+        ga = sm.work[w][0]; gb = sm.work[w][1];
+        int la = M.geom_link[ga];
+        T mA[9], posA[3] = {sm.gpos[ga][0], sm.gpos[ga][1], sm.gpos[ga][2]};
+        if (la >= 0) mat_mul(mA, sm.xmat[la], M.geom_mat + 9 * ga);
+        else {
+#pragma unroll
+          for (int k = 0; k < 9; k++) mA[k] = M.geom_mat[9 * ga + k];
+        }
+        invw = M.geom_invw[ga];
+        if (gb >= RPK_KEYBASE) {
+          int k = gb - RPK_KEYBASE;
+          T s, c;
+          N::sincos(sm.kq[k], &s, &c);
+          T hx = M.key_half[3 * k];
+          T bp[3] = {M.key_pos[3 * k] - hx + hx * c, M.key_pos[3 * k + 1], M.key_pos[3 * k + 2] - hx * s};
+          T bm[9] = {c, 0, s, 0, 1, 0, -s, 0, c};
+          n = capsule_box(rc, posA, mA, M.geom_size + 3 * ga, bp, bm, M.key_half + 3 * k);
+#pragma unroll
+          for (int e = 0; e < 8; e++) pB[e] = M.key_cparam[e];
+          invw += M.key_invw_body[k];
+        } else {
+          int lb = M.geom_link[gb];
+          T mB[9], posB[3] = {sm.gpos[gb][0], sm.gpos[gb][1], sm.gpos[gb][2]};
+          if (lb >= 0) mat_mul(mB, sm.xmat[lb], M.geom_mat + 9 * gb);
+          else {
+#pragma unroll
+            for (int k = 0; k < 9; k++) mB[k] = M.geom_mat[9 * gb + k];
+          }
+          if (M.geom_type[gb] == GEOM_CAPSULE_)
+            n = capsule_capsule(rc, posA, mA, M.geom_size + 3 * ga, posB, mB, M.geom_size + 3 * gb);
+          else
+            n = capsule_box(rc, posA, mA, M.geom_size + 3 * ga, posB, mB, M.geom_size + 3 * gb);
+#pragma unroll
+          for (int e = 0; e < 8; e++) pB[e] = M.geom_cparam[8 * gb + e];
+          invw += M.geom_invw[gb];
+        }
+      }
+#pragma unroll
+      for (int slot = 0; slot < 3; slot++) {
+        bool has = n > slot;
+        unsigned long long mk = __ballot(has);
+        int idx = ncon + __popcll(mk & lanemask_lt(lane));
+        if (has && idx < RPK_NC) {
+          const T* pA = M.geom_cparam + 8 * ga;
+          T solref0 = (T)0.5 * (pA[0] + pB[0]), solref1 = (T)0.5 * (pA[1] + pB[1]);
+          T solimp[5];
+#pragma unroll
+          for (int e = 0; e < 5; e++) solimp[e] = (T)0.5 * (pA[2 + e] + pB[2 + e]);
+          T mu = fmax(pA[7], pB[7]);
+          if (solref0 > 0) solref0 = fmax(solref0, (T)2 * h);
+          T dmax = fmin((T)0.9999, fmax((T)0.0001, solimp[1]));
+          T Kc = (T)1 / fmax(RPK_MINVAL, dmax * dmax * solref0 * solref0 * solref1 * solref1);
+          T Bc = (T)2 / fmax(RPK_MINVAL, dmax * solref0);
+          T dist = rc[slot].dist;
+          T imp = impedance(solimp, dist);
+          T Rn = fmax(RPK_MINVAL, ((T)1 - imp) * invw * ((T)1 + mu * mu) / imp);
+          T Rpy = fmax(RPK_MINVAL, (T)2 * mu * mu * Rn);
+#pragma unroll
+          for (int k = 0; k < 3; k++) { sm.cpos[idx][k] = rc[slot].pos[k]; sm.cn[idx][k] = rc[slot].n[k]; }
+          sm.cdist[idx] = dist;
+          sm.cpar[idx][0] = mu; sm.cpar[idx][1] = Kc * imp * dist; sm.cpar[idx][2] = Bc;
+          sm.cpar[idx][3] = (T)1 / Rpy;
+          int la = M.geom_link[ga];
+          sm.cA[idx] = la;
+          sm.cB[idx] = gb >= RPK_KEYBASE ? gb : M.geom_link[gb];
+          sm.cgA[idx] = M.geom_modelid[ga];
+          sm.cgB[idx] = gb >= RPK_KEYBASE ? M.key_geomid[gb - RPK_KEYBASE] : M.geom_modelid[gb];
+        }
+        ncon += __popcll(mk);
+      }
+    }
+    if (ncon > RPK_NC) { warn |= 2; ncon = RPK_NC; }
+    __syncthreads();
+
+    // ---- solver slots for touched keys
+    {
+      int kb = -1;
+      if (lane < ncon) {
+        if (sm.cB[lane] >= RPK_KEYBASE) kb = sm.cB[lane] - RPK_KEYBASE;
+        else if (sm.cA[lane] >= RPK_KEYBASE) kb = sm.cA[lane] - RPK_KEYBASE;
+      }
+      bool first = kb >= 0;
+      for (int c2 = 0; c2 < ncon; c2++) {
+        int k2 = bcast(kb, c2);
+        if (c2 < lane && k2 == kb) first = false;
+      }
+      unsigned long long fm = __ballot(first);
+      int slot = __popcll(fm & lanemask_lt(lane));
+      nkt = __popcll(fm);
+      int cap = 64 - nl;
+      if (first && slot < cap) { sm.slotkey[slot] = kb; sm.keyslot[kb] = slot; }
+      if (nkt > cap) { warn |= 8; nkt = cap; }
+      __syncthreads();
+      con_slot = kb >= 0 ? sm.keyslot[kb] : -1;
+      // per-contact registers
+      con_A = -1; con_B = -1; con_D = 0; con_mu = 0; con_maskA = 0; con_maskB = 0;
+      if (lane < ncon) {
+        con_A = sm.cA[lane]; con_B = sm.cB[lane];
+        con_mu = sm.cpar[lane][0];
+        con_D = sm.cpar[lane][3];
+        if (kb >= 0 && con_slot < 0) con_D = 0;  // dropped (slot overflow)
+#pragma unroll
+        for (int k = 0; k < 3; k++) con_n[k] = sm.cn[lane][k];
+        make_frame(con_n, con_t1, con_t2);
+        if (con_A >= 0 && con_A < RPK_KEYBASE)
+          con_maskA = ((unsigned long long)M.link_ancmask[2 * con_A + 1] << 32) | M.link_ancmask[2 * con_A];
+        if (con_B >= 0 && con_B < RPK_KEYBASE)
+          con_maskB = ((unsigned long long)M.link_ancmask[2 * con_B + 1] << 32) | M.link_ancmask[2 * con_B];
+      }
+    }
+    // ---- contact Jacobian columns (J_diff = J(body2) - J(body1)) [MJ: mj_jacDifPair]
+    for (int it = lane; it < ncon * 2 * RPK_MAXD; it += 64) {
+      int c = it / (2 * RPK_MAXD), rem = it - c * 2 * RPK_MAXD;
+      int side = rem / RPK_MAXD, lv = rem - side * RPK_MAXD;
+      int Lk = side ? sm.cB[c] : sm.cA[c];
+      T sg = side ? (T)1 : (T)-1;
+      T col[3] = {0, 0, 0};
+      if (Lk >= RPK_KEYBASE) {
+        if (lv == 0) {
+          int k = Lk - RPK_KEYBASE;
+          T rx = sm.cpos[c][0] - (M.key_pos[3 * k] - M.key_half[3 * k]);
+          T rz = sm.cpos[c][2] - M.key_pos[3 * k + 2];
+          col[0] = rz; col[1] = 0; col[2] = -rx;  // (0,1,0) x r
+        }
+      } else if (Lk >= 0 && lv <= M.link_depth[Lk]) {
+        int a = M.link_anc[Lk * RPK_MAXD + lv];
+        if (M.link_jtype[a] == JNT_SLIDE_) {
+          col[0] = sm.xaxis[a][0]; col[1] = sm.xaxis[a][1]; col[2] = sm.xaxis[a][2];
+        } else {
+          T r[3] = {sm.cpos[c][0] - sm.xanchor[a][0], sm.cpos[c][1] - sm.xanchor[a][1],
+                    sm.cpos[c][2] - sm.xanchor[a][2]};
+          cross3(col, sm.xaxis[a], r);
+        }
+      }
+      sm.cJ[c][side][lv][0] = sg * col[0]; sm.cJ[c][side][lv][1] = sg * col[1];
+      sm.cJ[c][side][lv][2] = sg * col[2];
+    }
+    __syncthreads();
+
+    // ======================================================================
+    // VELOCITY STAGE
+    // ======================================================================
+    // ---- spatial velocities, axis derivatives [MJ: mj_comVel]
+    T cv[6] = {0, 0, 0, 0, 0, 0}, cdd[6] = {0, 0, 0, 0, 0, 0};
+    for (int d = 0; d < M.maxdepth; d++) {
+      if (isl && depth == d) {
+        T pv[6] = {0, 0, 0, 0, 0, 0};
+        if (parent >= 0) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) pv[k] = sm.vel[parent][k];
+        }
+        T t1[3], t2[3];
+        cross3(cdd, pv, cdofr);
+        cross3(t1, pv, cdofr + 3); cross3(t2, pv + 3, cdofr);
+        cdd[3] = t1[0] + t2[0]; cdd[4] = t1[1] + t2[1]; cdd[5] = t1[2] + t2[2];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { cv[k] = pv[k] + cdofr[k] * qd[0]; sm.vel[lane][k] = cv[k]; }
+      }
+      __syncthreads();
+    }
+    // ---- bias forces: recursive Newton-Euler with gravity as base acceleration [MJ: mj_rne]
+    T ca[6] = {0, 0, 0, 0, 0, 0};
+    for (int d = 0; d < M.maxdepth; d++) {
+      if (isl && depth == d) {
+        T pa[6] = {0, 0, 0, -M.gx * gscale, -M.gy * gscale, -M.gz * gscale};
+        if (parent >= 0) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) pa[k] = sm.vel[parent][k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) ca[k] = pa[k] + cdd[k] * qd[0];
+      }
+      __syncthreads();  // all reads of this level's parents (cvel or cacc) are done
+      if (isl && depth == d) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) sm.vel[lane][k] = ca[k];
+      }
+      __syncthreads();
+    }
+    {
+      T f1[6], iv[6], f2[6], t1[3], t2[3];
+      mul_inert(f1, cin, ca);
+      mul_inert(iv, cin, cv);
+      cross3(t1, cv, iv); cross3(t2, cv + 3, iv + 3);
+      f2[0] = t1[0] + t2[0]; f2[1] = t1[1] + t2[1]; f2[2] = t1[2] + t2[2];
+      cross3(f2 + 3, cv, iv + 3);
+      if (isl) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) sm.acc[lane][k] = f1[k] + f2[k];
+      }
+    }
+    __syncthreads();
+    for (int d = M.maxdepth - 1; d >= 1; d--) {
+      int mr = M.level_maxrank[d];
+      for (int r = 0; r < mr; r++) {
+        if (isl && depth == d && sibrank == r) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) sm.acc[parent][k] += sm.acc[lane][k];
+        }
+        __syncthreads();
+      }
+    }
+    qbias = isl ? dot6(cdofr, sm.acc[lane]) : (T)0;
+    // ---- transmission [MJ: mj_transmission]: actuator length / velocity
+    sm.vec[0][lane] = q[0]; sm.vec[1][lane] = qd[0];
+    if (isk[0]) sm.keyvec[0][kid[0]] = qd[1];
+    if (isk[1]) sm.keyvec[0][kid[1]] = qd[2];
+    __syncthreads();
+    if (isa) {
+      alen = acoef0 * sm.vec[0][alane0] + (alane1 >= 0 ? acoef1 * sm.vec[0][alane1] : (T)0);
+      avel = acoef0 * sm.vec[1][alane0] + (alane1 >= 0 ? acoef1 * sm.vec[1][alane1] : (T)0);
+    }
+    // ---- constraint rows: reference accelerations [MJ: mj_makeConstraint, mj_referenceConstraint]
+    fr_aref = -lflB * qd[0];
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      lim_sign[s] = 0; lim_D[s] = 0; lim_aref[s] = 0;
+      if (hasdof[s]) {
+        T dl = q[s] - lo[s], du = hi[s] - q[s];
+        T dist = 0;
+        if (dl < 0) { lim_sign[s] = 1; dist = dl; }
+        else if (du < 0) { lim_sign[s] = -1; dist = du; }
+        if (lim_sign[s] != 0) {
+          const T* si = (s == 0) ? (M.link_lim_solimp + 5 * L) : (M.key_lim_solimp + 5 * kid[s - 1]);
+          T imp = impedance(si, dist);
+          T R = fmax(RPK_MINVAL, ((T)1 - imp) * limW[s] / imp);
+          lim_D[s] = (T)1 / R;
+          lim_aref[s] = -limB[s] * ((T)lim_sign[s] * qd[s]) - limK[s] * imp * dist;
+        }
+      }
+    }
+    {
+      T vc[3] = {0, 0, 0};
+      if (lane < ncon) {
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+          int Lk = side ? con_B : con_A;
+          if (Lk >= RPK_KEYBASE) {
+            T xv = sm.keyvec[0][Lk - RPK_KEYBASE];
+            const T* jc = sm.cJ[lane][side][0];
+            vc[0] += jc[0] * xv; vc[1] += jc[1] * xv; vc[2] += jc[2] * xv;
+          } else if (Lk >= 0) {
+            int dL = M.link_depth[Lk];
+            for (int lv = 0; lv <= dL; lv++) {
+              T xv = sm.vec[1][M.link_anc[Lk * RPK_MAXD + lv]];
+              const T* jc = sm.cJ[lane][side][lv];
+              vc[0] += jc[0] * xv; vc[1] += jc[1] * xv; vc[2] += jc[2] * xv;
+            }
+          }
+        }
+        T vn = dot3(con_n, vc), v1 = con_mu * dot3(con_t1, vc), v2 = con_mu * dot3(con_t2, vc);
+        T Bc = sm.cpar[lane][2], kt = sm.cpar[lane][1];
+        con_aref[0] = -Bc * (vn + v1) - kt; con_aref[1] = -Bc * (vn - v1) - kt;
+        con_aref[2] = -Bc * (vn + v2) - kt; con_aref[3] = -Bc * (vn - v2) - kt;
+      } else {
+        con_aref[0] = con_aref[1] = con_aref[2] = con_aref[3] = 0;
+      }
+    }
+    __syncthreads();
+
+    // ---- per-substep key activation trace (Piano._update_key_state, piano.py:178-192)
+    if (S.key_trace && stage > 0) {
+      unsigned long long b0 = __ballot(isk[0] && (fmin(hi[1], fmax(lo[1], q[1])) >= hi[1] - (T)0.00872665));
+      unsigned long long b1 = __ballot(isk[1] && (fmin(hi[2], fmax(lo[2], q[2])) >= hi[2] - (T)0.00872665));
+      if (lane == 0) {
+        uint32_t* o = S.key_trace + ((size_t)env * nsub + (stage - 1)) * 4;
+        o[0] = (uint32_t)b0; o[1] = (uint32_t)(b0 >> 32); o[2] = (uint32_t)b1; o[3] = (uint32_t)(b1 >> 32);
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ outputs
+  if (isl) { S.qpos[eo + ldof] = q[0]; S.qvel[eo + ldof] = qd[0]; S.warm[eo + ldof] = qw[0]; }
+#pragma unroll
+  for (int s = 0; s < 2; s++) if (isk[s]) {
+    S.qpos[eo + kdof[s]] = q[1 + s]; S.qvel[eo + kdof[s]] = qd[1 + s]; S.warm[eo + kdof[s]] = qw[1 + s];
+    if (kact[s] >= 0) S.act_vel[(size_t)env * nu + kact[s]] = M.act_coef[2 * kact[s]] * qd[1 + s];
+  }
+  if (isa) S.act_vel[(size_t)env * nu + lane] = avel;
+  if (lane < M.nsite) {
+    int sl = M.site_link[lane];
+    T t[3];
+    mat_vec(t, sm.xmat[sl], M.site_pos + 3 * lane);
+#pragma unroll
+    for (int k = 0; k < 3; k++) S.site_xpos[((size_t)env * M.nsite + lane) * 3 + k] = sm.xpos[sl][k] + t[k];
+  }
+  if (lane < RPK_NC) {
+    bool v = lane < ncon;
+    S.contact_geoms[((size_t)env * RPK_NC + lane) * 2] = v ? sm.cgA[lane] : -1;
+    S.contact_geoms[((size_t)env * RPK_NC + lane) * 2 + 1] = v ? sm.cgB[lane] : -1;
+    S.contact_dist[(size_t)env * RPK_NC + lane] = v ? sm.cdist[lane] : (T)0;
+  }
+  {
+    int w = warn;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) w |= __shfl_xor(w, off, 64);
+    if (lane == 0) {
+      S.warn[env] |= w;
+      S.ncon[env] = ncon;
+      S.solver_iter[env] = niter_last;
+      S.time[env] = time;
+    }
+  }
+}

@@ -1,0 +1,212 @@
+"""ctypes binding of the HIP engine's C ABI (include/rp_engine.h).
+
+`BatchedPhysics` plays the role `dm_control.mjcf.Physics` plays for the
+reference (call sites listed in SURVEY.md §8b): named, batched views of
+qpos/qvel/ctrl/sensors/site positions plus `step()`/`forward()`/`reset()`.
+There is NO CPU fallback: if the shared library is missing or no HIP device
+is present, construction raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import numpy as np
+
+from robopianist_amd.model import compile as mcompile
+from robopianist_amd.model import engine_tables
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librp_engine.so")
+
+# rp_field
+QPOS, QVEL, QACC_WARMSTART, CTRL, QFRC_APPLIED, ACT_FORCE, ACT_VELOCITY, SITE_XPOS, \
+    TIME, NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER, CONTACT_DIST, TREE_OFFSET = range(15)
+MAX_CONTACTS = 32
+
+WARN_BADSTATE = 1
+WARN_CONTACT_FULL = 2
+WARN_HESSIAN = 4
+WARN_KEYSLOT_FULL = 8
+WARN_WORK_FULL = 16
+
+EXPORTED_SYMBOLS = (
+    "rp_create", "rp_destroy", "rp_reset", "rp_set", "rp_get", "rp_step", "rp_forward",
+    "rp_set_solver_limits", "rp_sync", "rp_get_stream", "rp_n_envs", "rp_dim",
+    "rp_kernel_time", "rp_last_error",
+)
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load_library(path: str = LIB_PATH):
+    """Loads librp_engine.so; raises EngineError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise EngineError(
+            f"HIP engine library not found at {path}. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+            "There is no CPU fallback."
+        )
+    L = ctypes.CDLL(path)
+    L.rp_last_error.restype = ctypes.c_char_p
+    L.rp_create.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                            ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    L.rp_destroy.argtypes = [ctypes.c_void_p]
+    L.rp_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.rp_set.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.rp_get.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.rp_step.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.rp_forward.argtypes = [ctypes.c_void_p]
+    L.rp_set_solver_limits.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    L.rp_sync.argtypes = [ctypes.c_void_p]
+    L.rp_get_stream.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+    L.rp_n_envs.argtypes = [ctypes.c_void_p]
+    L.rp_dim.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    L.rp_kernel_time.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
+                                 ctypes.POINTER(ctypes.c_int)]
+    _lib = L
+    return L
+
+
+def make_blob(model: mcompile.Model, key_joint_ids: np.ndarray) -> bytes:
+    """Model blob including the engine tables (what rp_create expects)."""
+    tables = engine_tables.build_engine_tables(model, key_joint_ids)
+    return mcompile.to_blob(model, extra=tables)
+
+
+def _ptr(x):
+    """Raw address of a numpy array or a torch tensor (host or device)."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        assert x.flags["C_CONTIGUOUS"]
+        return x.ctypes.data
+    if hasattr(x, "data_ptr"):
+        assert x.is_contiguous()
+        return x.data_ptr()
+    raise TypeError(type(x))
+
+
+class BatchedPhysics:
+    """`n_envs` copies of one compiled scene stepped on one MI355X."""
+
+    def __init__(self, model: mcompile.Model, key_joint_ids: np.ndarray, n_envs: int,
+                 device_id: int = 0, precision: int = 32, blob: Optional[bytes] = None):
+        self._L = load_library()
+        self.model = model
+        self.n_envs = int(n_envs)
+        self.precision = int(precision)
+        self.dtype = np.float32 if precision == 32 else np.float64
+        self.blob = blob if blob is not None else make_blob(model, key_joint_ids)
+        self._h = ctypes.c_void_p()
+        rc = self._L.rp_create(self.blob, len(self.blob), self.n_envs, int(device_id),
+                               self.precision, ctypes.byref(self._h))
+        if rc != 0:
+            raise EngineError(self._L.rp_last_error().decode())
+        self.nv = self.dim("nv"); self.nu = self.dim("nu"); self.nsite = self.dim("nsite")
+        self.ntree = self.dim("ntree")
+        self._shapes = {
+            QPOS: (self.nv,), QVEL: (self.nv,), QACC_WARMSTART: (self.nv,), CTRL: (self.nu,),
+            QFRC_APPLIED: (self.nv,), ACT_FORCE: (self.nu,), ACT_VELOCITY: (self.nu,),
+            SITE_XPOS: (self.nsite, 3), TIME: (), NCON: (), CONTACT_GEOMS: (MAX_CONTACTS, 2),
+            WARN_FLAGS: (), SOLVER_ITER: (), CONTACT_DIST: (MAX_CONTACTS,),
+            TREE_OFFSET: (self.ntree, 3),
+        }
+        self._int_fields = {NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER}
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.rp_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(self._L.rp_last_error().decode())
+
+    def dim(self, name: str) -> int:
+        return self._L.rp_dim(self._h, name.encode())
+
+    def field_shape(self, f):
+        return (self.n_envs,) + self._shapes[f]
+
+    def field_dtype(self, f):
+        return np.int32 if f in self._int_fields else self.dtype
+
+    def reset(self, mask=None):
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, np.uint8)
+            assert mask.shape == (self.n_envs,)
+        self._check(self._L.rp_reset(self._h, _ptr(mask)))
+
+    def set(self, f, value):
+        """value: numpy array or torch tensor (host or device) of the field's shape."""
+        if isinstance(value, np.ndarray) or not hasattr(value, "data_ptr"):
+            value = np.ascontiguousarray(np.broadcast_to(
+                np.asarray(value, self.field_dtype(f)), self.field_shape(f)))
+        else:
+            assert tuple(value.shape) == self.field_shape(f), (value.shape, self.field_shape(f))
+        self._check(self._L.rp_set(self._h, f, _ptr(value)))
+        # host sources must stay alive until the async copy has been consumed
+        self._check(self._L.rp_sync(self._h)) if isinstance(value, np.ndarray) else None
+
+    def get(self, f, out=None):
+        if out is None:
+            out = np.empty(self.field_shape(f), self.field_dtype(f))
+        self._check(self._L.rp_get(self._h, f, _ptr(out)))
+        return out
+
+    def step(self, n_substeps: int = 1, key_trace=None):
+        """key_trace: optional uint32 array/tensor [n_envs, n_substeps, 4]."""
+        self._check(self._L.rp_step(self._h, int(n_substeps), _ptr(key_trace)))
+
+    def forward(self):
+        self._check(self._L.rp_forward(self._h))
+
+    def sync(self):
+        self._check(self._L.rp_sync(self._h))
+
+    def set_solver_limits(self, max_newton_iter=0, max_ls_iter=0):
+        self._check(self._L.rp_set_solver_limits(self._h, max_newton_iter, max_ls_iter))
+
+    def kernel_time(self):
+        """(average step-kernel ms since last call, number of launches)."""
+        ms = ctypes.c_double(); n = ctypes.c_int()
+        self._check(self._L.rp_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    @property
+    def stream(self) -> int:
+        s = ctypes.c_void_p()
+        self._check(self._L.rp_get_stream(self._h, ctypes.byref(s)))
+        return s.value or 0
+
+    # convenience accessors (host copies)
+    @property
+    def qpos(self): return self.get(QPOS)
+    @property
+    def qvel(self): return self.get(QVEL)
+    @property
+    def ctrl(self): return self.get(CTRL)
+    @property
+    def time(self): return self.get(TIME)
+    @property
+    def warn_flags(self): return self.get(WARN_FLAGS)
+
+
+def decode_key_trace(trace: np.ndarray, n_keys: int = 88) -> np.ndarray:
+    """[E, n_sub, 4] uint32 bit masks -> [E, n_sub, n_keys] bool."""
+    t = np.asarray(trace, np.uint32)
+    bits = (t[..., :, None] >> np.arange(32, dtype=np.uint32)) & 1
+    return bits.reshape(t.shape[:-1] + (128,))[..., :n_keys].astype(bool)

@@ -1,0 +1,353 @@
+"""Model -> fixed-topology tables for the HIP engine (`robopianist_amd/csrc`).
+
+The HIP engine does not consume the generic MuJoCo-style arrays the oracle
+uses.  It consumes a *specialised* view in which
+
+  * every hand dof is one "link" (a body with several joints becomes a chain
+    of massless virtual links, the last of which carries the body's inertia),
+    and link `i` lives on wavefront lane `i` (<= 52 links);
+  * the 88 piano keys are independent closed-form 1-dof hinges about world y
+    (this is asserted here from the compiled model, not assumed);
+  * collision candidates are split into a static (hand x hand, hand x base)
+    pair list and the (hand capsule x key) family, which the engine
+    enumerates itself.
+
+Everything here is derived from the `Model` arrays, so the two views cannot
+disagree about constants; they are independent only in how the *dynamics* is
+evaluated.
+"""
+
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+
+from robopianist_amd.model import spec
+from robopianist_amd.model.compile import MINVAL, Model
+
+MAX_LINKS = 52
+MAX_DEPTH = 9  # levels 0..8
+
+
+def _imp0(solimp):
+    dmin = min(0.9999, max(0.0001, solimp[0]))
+    return dmin
+
+
+def _kb(m: Model, solref, solimp):
+    tc = solref[0]
+    if m.opt_refsafe and tc > 0:
+        tc = max(tc, 2 * m.opt_timestep)
+    dmax = min(0.9999, max(0.0001, solimp[1]))
+    K = 1.0 / max(MINVAL, dmax * dmax * tc * tc * solref[1] * solref[1])
+    B = 2.0 / max(MINVAL, dmax * tc)
+    return K, B
+
+
+def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.ndarray]:
+    nv = m.nv
+    key_dofs = [int(j) for j in key_joint_ids]
+    key_set = set(key_dofs)
+    t: Dict[str, np.ndarray] = {}
+
+    # ---- links: every non-key dof, in dof order ---------------------------
+    link_dofs = [j for j in range(nv) if j not in key_set]
+    nl = len(link_dofs)
+    assert nl <= MAX_LINKS, f"{nl} hand dofs > {MAX_LINKS}"
+    lane_of_dof = {j: i for i, j in enumerate(link_dofs)}
+    parent = np.full(nl, -1, np.int32)
+    depth = np.zeros(nl, np.int32)
+    for i, j in enumerate(link_dofs):
+        p = m.dof_parentid[j]
+        if p >= 0:
+            parent[i] = lane_of_dof[int(p)]
+            depth[i] = depth[parent[i]] + 1
+    assert depth.max(initial=0) < MAX_DEPTH
+    tree = m.dof_treeid[link_dofs] if nl else np.zeros(0, np.int32)
+    tree_ids = sorted(set(int(x) for x in tree))
+    tree_local = np.array([tree_ids.index(int(x)) for x in tree], np.int32)
+    ntree = len(tree_ids)
+
+    lpos = np.zeros((nl, 3)); lquat = np.tile([1.0, 0, 0, 0], (nl, 1))
+    axis = np.zeros((nl, 3)); anchor = np.zeros((nl, 3))
+    mass = np.zeros(nl); ipos = np.zeros((nl, 3)); inertia = np.zeros((nl, 6))
+    invw_body = np.zeros(nl)
+    link_body = np.full(nl, -1, np.int32)
+    body_lane = {}
+    for i, j in enumerate(link_dofs):
+        b = int(m.jnt_bodyid[j])
+        first = j == m.body_jntadr[b]
+        last = j == m.body_jntadr[b] + m.body_jntnum[b] - 1
+        if first:
+            # pose of this body in its parent BODY frame; the parent link is the
+            # last link of the parent body, whose frame is that body's frame.
+            pb = int(m.body_parentid[b])
+            assert m.body_jntnum[pb] > 0 or pb == 0 or m.body_weldid[pb] == 0, \
+                "jointless intermediate bodies are not supported by the engine tables"
+            # accumulate static transforms of jointless ancestors (attachment frames)
+            pos = m.body_pos[b].copy(); quat = m.body_quat[b].copy()
+            while pb != 0 and m.body_jntnum[pb] == 0:
+                R = spec.quat_to_mat(m.body_quat[pb])
+                pos = m.body_pos[pb] + R @ pos
+                quat = spec.quat_mul(m.body_quat[pb], quat)
+                pb = int(m.body_parentid[pb])
+            lpos[i] = pos; lquat[i] = spec.quat_normalize(quat)
+        axis[i] = m.jnt_axis[j]; anchor[i] = m.jnt_pos[j]
+        if last:
+            mass[i] = m.body_mass[b]; ipos[i] = m.body_ipos[b]
+            R = spec.quat_to_mat(m.body_iquat[b])
+            I = R @ np.diag(m.body_inertia[b]) @ R.T
+            inertia[i] = [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
+            link_body[i] = b
+            body_lane[b] = i
+        invw_body[i] = m.body_invweight0[b, 0]
+    # ancestor tables
+    anc = np.full((nl, MAX_DEPTH), -1, np.int32)
+    ancmask = np.zeros((nl, 2), np.uint32)
+    for i in range(nl):
+        a = i
+        mask = 0
+        while a >= 0:
+            anc[i, depth[a]] = a
+            mask |= 1 << int(a)
+            a = int(parent[a])
+        ancmask[i] = (mask & 0xFFFFFFFF, (mask >> 32) & 0xFFFFFFFF)
+    # sibling rank (for deterministic child->parent accumulation)
+    sibrank = np.zeros(nl, np.int32)
+    cnt = {}
+    for i in range(nl):
+        p = int(parent[i])
+        sibrank[i] = cnt.get(p, 0) if p >= 0 else 0
+        if p >= 0:
+            cnt[p] = cnt.get(p, 0) + 1
+    maxrank = np.zeros(MAX_DEPTH, np.int32)
+    for i in range(nl):
+        maxrank[depth[i]] = max(maxrank[depth[i]], sibrank[i] + 1)
+
+    # per-dof constants
+    ld = np.array(link_dofs, np.int64)
+    fl = m.dof_frictionloss[ld] if nl else np.zeros(0)
+    fl_R = np.zeros(nl); fl_B = np.zeros(nl)
+    lim_K = np.zeros(nl); lim_B = np.zeros(nl)
+    for i, j in enumerate(link_dofs):
+        imp = _imp0(m.dof_solimp[j])
+        fl_R[i] = max(MINVAL, (1 - imp) * m.dof_invweight0[j] / imp)
+        _, fl_B[i] = _kb(m, m.dof_solref[j], m.dof_solimp[j])
+        lim_K[i], lim_B[i] = _kb(m, m.jnt_solref[j], m.jnt_solimp[j])
+    # gravity compensation: uniform per tree -> effective gravity scale
+    tree_gscale = np.ones(max(ntree, 1))
+    for ti in range(ntree):
+        lanes = [i for i in range(nl) if tree_local[i] == ti and link_body[i] >= 0]
+        gcs = set(float(m.body_gravcomp[link_body[i]]) for i in lanes)
+        assert len(gcs) == 1, "engine requires uniform gravcomp per hand tree"
+        tree_gscale[ti] = 1.0 - gcs.pop()
+    tree_ref = np.zeros((max(ntree, 1), 3))
+    for ti in range(ntree):
+        root = [i for i in range(nl) if tree_local[i] == ti and parent[i] < 0][0]
+        tree_ref[ti] = lpos[root]
+
+    t["eng_nlink"] = np.array([nl], np.int32)
+    t["eng_ntree"] = np.array([ntree], np.int32)
+    t["eng_maxdepth"] = np.array([int(depth.max(initial=-1)) + 1], np.int32)
+    t["eng_link_parent"] = parent
+    t["eng_link_depth"] = depth
+    t["eng_link_tree"] = tree_local
+    t["eng_link_jtype"] = m.jnt_type[ld].astype(np.int32) if nl else np.zeros(0, np.int32)
+    t["eng_link_dof"] = np.array(link_dofs, np.int32)
+    t["eng_link_sibrank"] = sibrank
+    t["eng_level_maxrank"] = maxrank
+    t["eng_link_anc"] = anc
+    t["eng_link_ancmask"] = ancmask.view(np.int32)
+    t["eng_link_lpos"] = lpos; t["eng_link_lquat"] = lquat
+    t["eng_link_axis"] = axis; t["eng_link_anchor"] = anchor
+    t["eng_link_mass"] = mass; t["eng_link_ipos"] = ipos; t["eng_link_inertia"] = inertia
+    t["eng_link_invw_body"] = invw_body
+    sel = lambda a: (a[ld] if nl else np.zeros((0,) + a.shape[1:]))
+    t["eng_link_armature"] = sel(m.dof_armature)
+    t["eng_link_damping"] = sel(m.dof_damping)
+    t["eng_link_stiffness"] = sel(m.jnt_stiffness)
+    t["eng_link_springref"] = sel(m.qpos_spring)
+    t["eng_link_floss"] = fl
+    t["eng_link_fl_R"] = fl_R; t["eng_link_fl_B"] = fl_B
+    t["eng_link_limited"] = sel(m.jnt_limited).astype(np.int32)
+    t["eng_link_range"] = sel(m.jnt_range)
+    t["eng_link_lim_K"] = lim_K; t["eng_link_lim_B"] = lim_B
+    t["eng_link_lim_solimp"] = sel(m.jnt_solimp)
+    t["eng_link_invw_dof"] = sel(m.dof_invweight0)
+    t["eng_tree_gscale"] = tree_gscale
+    t["eng_tree_ref"] = tree_ref
+
+    # ---- keys ----------------------------------------------------------------
+    nk = len(key_dofs)
+    kd = np.array(key_dofs, np.int64)
+    key_body = m.jnt_bodyid[kd]
+    key_geom = np.zeros(nk, np.int32)
+    for k in range(nk):
+        b = int(key_body[k])
+        gs = [g for g in range(m.ngeom) if m.geom_bodyid[g] == b]
+        assert len(gs) == 1 and m.geom_type[gs[0]] == spec.GEOM_BOX
+        g = gs[0]
+        key_geom[k] = g
+        # closed-form assumptions the engine makes about a key
+        assert m.body_parentid[b] == 0 and m.body_jntnum[b] == 1
+        assert np.allclose(m.body_quat[b], (1, 0, 0, 0))
+        assert np.allclose(m.jnt_axis[kd[k]], (0, 1, 0))
+        assert m.jnt_type[kd[k]] == spec.JNT_HINGE and m.jnt_limited[kd[k]]
+        assert np.allclose(m.geom_pos[g], 0) and np.allclose(m.geom_quat[g], (1, 0, 0, 0))
+        assert np.allclose(m.body_ipos[b], 0)
+        assert np.allclose(m.jnt_pos[kd[k]], (-m.geom_size[g, 0], 0, 0))
+        assert m.dof_frictionloss[kd[k]] == 0 and m.body_gravcomp[b] == 0
+        assert m.geom_margin[g] == 0 and m.geom_gap[g] == 0
+    t["eng_nkey"] = np.array([nk], np.int32)
+    t["eng_key_dof"] = kd.astype(np.int32)
+    t["eng_key_geomid"] = key_geom.astype(np.int32)
+    t["eng_key_pos"] = m.body_pos[key_body]
+    t["eng_key_half"] = m.geom_size[key_geom]
+    t["eng_key_mass"] = m.body_mass[key_body]
+    t["eng_key_M"] = m.dof_M0[kd]
+    t["eng_key_stiffness"] = m.jnt_stiffness[kd]
+    t["eng_key_springref"] = m.qpos_spring[kd]
+    t["eng_key_damping"] = m.dof_damping[kd]
+    t["eng_key_range"] = m.jnt_range[kd]
+    kK = np.zeros(nk); kB = np.zeros(nk)
+    for k in range(nk):
+        kK[k], kB[k] = _kb(m, m.jnt_solref[kd[k]], m.jnt_solimp[kd[k]])
+    t["eng_key_lim_K"] = kK; t["eng_key_lim_B"] = kB
+    t["eng_key_lim_solimp"] = m.jnt_solimp[kd]
+    t["eng_key_invw_dof"] = m.dof_invweight0[kd]
+    t["eng_key_invw_body"] = m.body_invweight0[key_body, 0]
+    # contact parameters shared by all key geoms (asserted)
+    for arr in (m.geom_solref, m.geom_solimp, m.geom_friction):
+        assert np.allclose(arr[key_geom], arr[key_geom[0]])
+    g0 = int(key_geom[0])
+    t["eng_key_cparam"] = np.concatenate(
+        [m.geom_solref[g0], m.geom_solimp[g0], m.geom_friction[g0, :1]])
+
+    # ---- collision geoms other than keys --------------------------------------
+    key_geom_set = set(int(g) for g in key_geom)
+    egeoms = [g for g in range(m.ngeom) if g not in key_geom_set
+              and (m.geom_contype[g] or m.geom_conaffinity[g])]
+    eidx = {g: i for i, g in enumerate(egeoms)}
+    ng = len(egeoms)
+    g_link = np.full(ng, -1, np.int32)
+    g_mat = np.zeros((ng, 9))
+    g_invw = np.zeros(ng)
+    for i, g in enumerate(egeoms):
+        b = int(m.geom_bodyid[g])
+        assert m.geom_margin[g] == 0 and m.geom_gap[g] == 0
+        assert m.geom_condim[g] == 3 and m.geom_priority[g] == 0 and m.geom_solmix[g] == 1
+        if m.body_weldid[b] == 0:
+            # static geom: bake world pose (parent chain is static)
+            pos = m.geom_pos[g].copy(); R = spec.quat_to_mat(m.geom_quat[g])
+            bb = b
+            while bb != 0:
+                Rb = spec.quat_to_mat(m.body_quat[bb])
+                pos = m.body_pos[bb] + Rb @ pos
+                R = Rb @ R
+                bb = int(m.body_parentid[bb])
+            g_mat[i] = R.reshape(-1)
+            t.setdefault("_static_pos", {})[i] = pos
+        else:
+            g_link[i] = body_lane[b]
+            g_mat[i] = spec.quat_to_mat(m.geom_quat[g]).reshape(-1)
+        g_invw[i] = m.body_invweight0[b, 0]
+    g_pos = m.geom_pos[egeoms].copy() if ng else np.zeros((0, 3))
+    for i, pos in t.pop("_static_pos", {}).items():
+        g_pos[i] = pos
+    t["eng_ngeom"] = np.array([ng], np.int32)
+    t["eng_geom_link"] = g_link
+    t["eng_geom_type"] = m.geom_type[egeoms].astype(np.int32) if ng else np.zeros(0, np.int32)
+    t["eng_geom_size"] = m.geom_size[egeoms] if ng else np.zeros((0, 3))
+    t["eng_geom_pos"] = g_pos
+    t["eng_geom_mat"] = g_mat
+    t["eng_geom_rbound"] = m.geom_rbound[egeoms] if ng else np.zeros(0)
+    t["eng_geom_invw"] = g_invw
+    t["eng_geom_cparam"] = (np.concatenate(
+        [m.geom_solref[egeoms], m.geom_solimp[egeoms], m.geom_friction[egeoms][:, :1]],
+        axis=1) if ng else np.zeros((0, 8)))
+    t["eng_geom_modelid"] = np.array(egeoms, np.int32)
+
+    # static pairs (neither geom is a key) and the capsule-x-all-keys family
+    spairs = []
+    keycount = {}
+    for a, b in m.pair_geom:
+        a, b = int(a), int(b)
+        ka, kb = a in key_geom_set, b in key_geom_set
+        assert not (ka and kb)
+        if ka or kb:
+            h = b if ka else a
+            assert m.geom_type[h] == spec.GEOM_CAPSULE, "only capsule-vs-key pairs supported"
+            keycount[h] = keycount.get(h, 0) + 1
+        else:
+            spairs.append((eidx[a], eidx[b]))
+    for h, c in keycount.items():
+        assert c == nk, "engine expects each colliding capsule paired with every key"
+    t["eng_npair"] = np.array([len(spairs)], np.int32)
+    t["eng_pair"] = np.array(spairs, np.int32).reshape(-1, 2)
+    kcaps = sorted(eidx[h] for h in keycount)
+    t["eng_nkeycap"] = np.array([len(kcaps)], np.int32)
+    t["eng_keycap"] = np.array(kcaps, np.int32)
+
+    # ---- actuators -------------------------------------------------------------
+    nu = m.nu
+    a_kind = np.zeros(nu, np.int32)  # 0: hand joint/tendon, 2: key
+    a_lane = np.full((nu, 2), -1, np.int32)
+    a_coef = np.zeros((nu, 2))
+    key_index = {d: k for k, d in enumerate(key_dofs)}
+    key_act = np.full(nk, -1, np.int32)
+    dof_act = np.full(nl, -1, np.int32)
+    dof_act_coef = np.zeros(nl)
+    for i in range(nu):
+        gear = m.actuator_gear[i]
+        if m.actuator_trntype[i] == spec.TRN_JOINT:
+            j = int(m.actuator_trnid[i])
+            if j in key_set:
+                a_kind[i] = 2
+                a_lane[i, 0] = key_index[j]
+                a_coef[i, 0] = gear
+                assert key_act[key_index[j]] < 0
+                key_act[key_index[j]] = i
+                assert np.allclose(m.actuator_biasprm[i], 0)
+            else:
+                a_lane[i, 0] = lane_of_dof[j]
+                a_coef[i, 0] = gear
+        else:
+            tid = int(m.actuator_trnid[i])
+            assert m.tendon_num[tid] <= 2
+            for w in range(m.tendon_num[tid]):
+                j = int(m.wrap_objid[m.tendon_adr[tid] + w])
+                a_lane[i, w] = lane_of_dof[j]
+                a_coef[i, w] = gear * m.wrap_prm[m.tendon_adr[tid] + w]
+        if a_kind[i] == 0:
+            for w in range(2):
+                if a_lane[i, w] >= 0:
+                    assert dof_act[a_lane[i, w]] < 0, "one actuator per hand dof expected"
+                    dof_act[a_lane[i, w]] = i
+                    dof_act_coef[a_lane[i, w]] = a_coef[i, w]
+    t["eng_nu"] = np.array([nu], np.int32)
+    t["eng_act_kind"] = a_kind
+    t["eng_act_lane"] = a_lane
+    t["eng_act_coef"] = a_coef
+    t["eng_act_gain"] = m.actuator_gainprm.copy()
+    t["eng_act_bias"] = m.actuator_biasprm.copy()
+    t["eng_act_ctrllimited"] = m.actuator_ctrllimited.copy()
+    t["eng_act_ctrlrange"] = m.actuator_ctrlrange.copy()
+    t["eng_act_forcelimited"] = m.actuator_forcelimited.copy()
+    t["eng_act_forcerange"] = m.actuator_forcerange.copy()
+    t["eng_link_act"] = dof_act
+    t["eng_link_act_coef"] = dof_act_coef
+    t["eng_key_act"] = key_act
+
+    # ---- sites ------------------------------------------------------------------
+    s_link = np.full(m.nsite, -1, np.int32)
+    for s in range(m.nsite):
+        b = int(m.site_bodyid[s])
+        if b in body_lane:
+            s_link[s] = body_lane[b]
+    hs = [s for s in range(m.nsite) if s_link[s] >= 0]
+    t["eng_nsite"] = np.array([len(hs)], np.int32)
+    t["eng_site_link"] = s_link[hs] if hs else np.zeros(0, np.int32)
+    t["eng_site_pos"] = m.site_pos[hs] if hs else np.zeros((0, 3))
+    t["eng_site_modelid"] = np.array(hs, np.int32)
+    return t
