@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path (BASELINE.json: env-steps/sec at 4096 envs/GPU).
+
+One "step" = one control step (= 10 physics substeps, base.py:28,31) of ALL envs
+on this rank.  Workload: BASELINE.json configs[1] — PianoWithShadowHands,
+TwinkleTwinkle scripted replay (tests/golden/twinkle_twinkle_actions.npy mapped
+canonical -> ctrlrange), 4096 envs per GPU, inputs resident in HBM.
+
+Prints ONE JSON line (rank 0).  See DESIGN.md §Measurement for the definitions
+of `roofline` (algorithmic bytes / step-kernel time from HIP events) and
+`cpu_baseline` (the fp64 C oracle timed on the host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_ENV_STEP = 4352  # 1856 in + 1680 out + 712 epilogue (fp32, fused)
+HBM_PEAK_GBS = 8000.0
+
+
+def load_actions(m):
+    a = np.load(os.path.join(ROOT, "tests", "golden", "twinkle_twinkle_actions.npy")).astype(np.float64)
+    hands = a[:, :-1]
+    assert hands.shape[1] == m.nu, (hands.shape, m.nu)
+    lo, hi = m.actuator_ctrlrange[:, 0], m.actuator_ctrlrange[:, 1]
+    # dm_env_wrappers.CanonicalSpecWrapper: ctrl = lo + (a+1)/2*(hi-lo), clipped
+    ctrl = lo + (np.clip(hands, -1, 1) + 1.0) * 0.5 * (hi - lo)
+    return ctrl, a[:, -1]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=158)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--precision", type=int, default=32, choices=(32, 64))
+    ap.add_argument("--substeps", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", type=int, default=1, help="all-gather trajectory slab when gpus>1")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = local_rank if torch.cuda.is_available() else 0
+
+    from robopianist_amd import engine
+    from robopianist_amd.model import scene
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # notebook cell 15 kwargs; capsule fingertips (no meshes available)
+        si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=True)
+    m = si.model
+    E = args.envs
+    phys = engine.BatchedPhysics(m, si.key_joint_ids, n_envs=E, device_id=dev, precision=args.precision)
+    ctrl_seq, _ = load_actions(m)
+    T = ctrl_seq.shape[0]
+    tdt = torch.float32 if args.precision == 32 else torch.float64
+    device = torch.device("cuda", dev)
+    # all envs replay the same action stream (config #2); rows pre-expanded on device
+    ctrl_dev = torch.as_tensor(ctrl_seq, dtype=tdt, device=device)
+    ctrl_buf = torch.empty((E, m.nu), dtype=tdt, device=device)
+    qpos_buf = torch.empty((E, m.nv), dtype=tdt, device=device)
+    gathered = torch.empty((world * E, m.nv), dtype=tdt, device=device) if world > 1 else None
+
+    def one_step(t):
+        ctrl_buf.copy_(ctrl_dev[t % T].expand(E, -1))
+        torch.cuda.current_stream().synchronize()  # ctrl_buf ready before the engine stream reads it
+        phys.set(engine.CTRL, ctrl_buf)
+        phys.step(args.substeps)
+        if (t + 1) % T == 0:
+            phys.sync()
+            phys.reset()
+        if world > 1 and args.gather:
+            phys.get(engine.QPOS, qpos_buf)  # D2D on the engine stream, synchronises
+            dist.all_gather_into_tensor(gathered, qpos_buf)
+
+    def barrier():
+        phys.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for t in range(args.warmup):
+        one_step(t)
+    barrier()
+    phys.kernel_time()  # reset kernel timer
+    t0 = time.perf_counter()
+    for t in range(args.steps):
+        one_step(args.warmup + t)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    kms, nl = phys.kernel_time()
+    warn = int(phys.warn_flags.max())
+    q = phys.qpos
+    finite = bool(np.isfinite(q).all())
+
+    if rank == 0:
+        value = world * E * args.steps / dt
+        achieved = ALGO_BYTES_PER_ENV_STEP * (2 if args.precision == 64 else 1) * E / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        out = {
+            "metric": "env-steps/sec (whole node) at 4096 envs/GPU",
+            "value": value,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if args.precision == 32 else "f64",
+            "data": "synthetic (scripted twinkle_twinkle_actions.npy replay on the stand-in hand model)",
+            "config": {
+                "workload": "PianoWithShadowHands-TwinkleTwinkle scripted replay (BASELINE configs[1]), engine-level rp_step",
+                "envs_per_gpu": E, "substeps_per_step": args.substeps, "nv": int(m.nv), "nu": int(m.nu),
+                "fingertips": "capsule (primitive) stand-in", "mj_steps_per_s": value * args.substeps,
+                "trajectory_gather": bool(world > 1 and args.gather),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "rp_step_kernel", "kernel_avg_ms": kms, "kernel_launches": nl,
+                "note": "path is latency/VALU bound by construction (BASELINE.md §2.3); HBM fraction reported as the north-star asks",
+            },
+            "sanity": {"warn_flags": warn, "finite": finite},
+        }
+        if not args.no_cpu_baseline:
+            from oracle.rp_oracle import Oracle
+            orc = Oracle(m, phys.blob)
+            cores = os.cpu_count() or 1
+            nenv_cpu = max(cores, 8)
+            nstep = 200
+            cc = np.tile(ctrl_seq[40], (nenv_cpu, 1))
+            secs, _ = orc.bench(nenv_cpu, nstep, cc, cores)
+            out["cpu_baseline"] = {
+                "value": nenv_cpu * nstep / args.substeps / secs, "unit": "env-steps/s",
+                "cores": cores, "kind": "port",
+                "sample": f"{nenv_cpu} envs x {nstep} mj_steps, fp64 C oracle (not MuJoCo), OpenMP {cores} threads, ctrl = action row 40 held",
+                "mj_steps_per_s": nenv_cpu * nstep / secs,
+            }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -96,6 +96,9 @@ int rp_dim(const rp_engine* e, const char* name); /* "nv","nu","nsite","ntree","
 /* Average device time (ms) of the step kernel since the last call, measured
  * with HIP events on the engine stream; also returns the launch count. */
 int rp_kernel_time(rp_engine* e, double* avg_ms, int* n_launches);
+/* Debug aid: per-phase shader-clock counters of env 0 (see rp_kernels.hpp PROF).
+ * Reads and clears the counters (out may be NULL), then enables/disables them. */
+int rp_profile(rp_engine* e, long long* out, int n, int enable);
 const char* rp_last_error(void);
 
 #ifdef __cplusplus

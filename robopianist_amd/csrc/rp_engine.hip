@@ -90,6 +90,7 @@ struct EngineBase {
   virtual int get(rp_field f, void* dst) = 0;
   virtual int step(int nsub, uint32_t* trace, int mode) = 0;
   virtual void limits(int newton, int ls) = 0;
+  virtual int profile(long long* out, int n, int enable) = 0;
 };
 
 template <typename T>
@@ -230,9 +231,24 @@ struct Engine : EngineBase {
     S.ncon = dalloc<int>(E); S.contact_geoms = dalloc<int>(E * RPK_NC * 2);
     S.warn = dalloc<int>(E); S.solver_iter = dalloc<int>(E);
     S.key_trace = nullptr;
+    S.prof = nullptr;
     S.max_newton = M.iterations; S.max_ls = M.ls_iterations;
   }
 
+  long long* d_prof = nullptr;
+  int profile(long long* out, int n, int enable) override {
+    HIP_OK(hipSetDevice(device));
+    if (!d_prof) { d_prof = dalloc<long long>(RPK_NPROF); }
+    HIP_OK(hipStreamSynchronize(stream));
+    if (out) {
+      long long h[RPK_NPROF];
+      HIP_OK(hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost));
+      for (int i = 0; i < n && i < RPK_NPROF; i++) out[i] = h[i];
+    }
+    HIP_OK(hipMemset(d_prof, 0, sizeof(long long) * RPK_NPROF));
+    S.prof = enable ? d_prof : nullptr;
+    return 0;
+  }
   void limits(int newton, int ls) override {
     if (newton > 0) S.max_newton = newton;
     if (ls > 0) S.max_ls = ls;
@@ -397,6 +413,9 @@ int rp_set_solver_limits(rp_engine* e, int max_newton_iter, int max_ls_iter) {
   if (!e) return fail("null engine");
   E(e)->limits(max_newton_iter, max_ls_iter);
   return 0;
+}
+int rp_profile(rp_engine* e, long long* out, int n, int enable) {
+  return e ? E(e)->profile(out, n, enable) : fail("null engine");
 }
 int rp_sync(rp_engine* e) {
   if (!e) return fail("null engine");

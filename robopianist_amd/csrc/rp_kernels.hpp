@@ -68,8 +68,19 @@ struct RpState {
   T *act_force, *act_vel, *site_xpos, *contact_dist;
   int *ncon, *contact_geoms, *warn, *solver_iter;
   uint32_t* key_trace;  // may be null
+  long long* prof;      // may be null: per-phase cycle counters (env 0)
   int max_newton, max_ls;
 };
+
+#define RPK_NPROF 24
+#define PROF(i)                                                         \
+  do {                                                                  \
+    if (S.prof && env == 0) {                                           \
+      long long t_ = (long long)__builtin_readcyclecounter();           \
+      if (lane == 0) S.prof[i] += t_ - prof_t;                          \
+      prof_t = t_;                                                      \
+    }                                                                   \
+  } while (0)
 
 namespace rpk {
 
@@ -373,49 +384,111 @@ struct Smem {
 // slot (hand, key, key+64), four pyramidal rows of its contact.
 template <typename T> struct Rows { T fr, lim[3], con[4]; };
 
-// packed lower-triangular Cholesky, lane = row.  n uniform.
+// packed lower-triangular Cholesky (left-looking), lane = row, n uniform.
+// Row j is loaded cooperatively (lane p holds L[j][p]) and broadcast with
+// v_readlane, so the inner product costs one LDS read per term; reads are issued
+// in batches of 8 ahead of the dependent FMA chain.
 template <typename T>
 __device__ void chol_packed(T* H, int n, int lane, int* warn) {
   for (int j = 0; j < n; j++) {
+    T rj = (lane < j) ? H[tri(j, 0) + lane] : (T)0;
     T s = 0;
-    if (lane >= j && lane < n) {
-      s = H[tri(lane, j)];
-      const T* ri = H + tri(lane, 0);
-      const T* rj = H + tri(j, 0);
-      for (int p = 0; p < j; p++) s -= ri[p] * rj[p];
+    const bool act = lane >= j && lane < n;
+    const T* ri = H + tri(act ? lane : 0, 0);
+    if (act) s = ri[j];
+    int p = 0;
+    for (; p + 8 <= j; p += 8) {
+      T a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+      if (act) { a0 = ri[p]; a1 = ri[p + 1]; a2 = ri[p + 2]; a3 = ri[p + 3];
+                 a4 = ri[p + 4]; a5 = ri[p + 5]; a6 = ri[p + 6]; a7 = ri[p + 7]; }
+      s -= a0 * bcast(rj, p); s -= a1 * bcast(rj, p + 1); s -= a2 * bcast(rj, p + 2);
+      s -= a3 * bcast(rj, p + 3); s -= a4 * bcast(rj, p + 4); s -= a5 * bcast(rj, p + 5);
+      s -= a6 * bcast(rj, p + 6); s -= a7 * bcast(rj, p + 7);
+    }
+    for (; p < j; p++) {
+      T a0 = act ? ri[p] : (T)0;
+      s -= a0 * bcast(rj, p);
     }
     T sj = bcast(s, j);
     if (sj < RPK_MINVAL) { sj = RPK_MINVAL; *warn |= 4; }
     T ljj = Num<T>::sqrt(sj);
     if (lane == j) H[tri(j, j)] = ljj;
-    else if (lane > j && lane < n) H[tri(lane, j)] = s / ljj;
+    else if (act) H[tri(lane, j)] = s / ljj;
     __syncthreads();
   }
 }
 // solves (L L^T) x = b, x/b in the register of lane i (< n).
 template <typename T>
 __device__ T solve_packed(const T* H, int n, int lane, T x) {
-  T invd = (lane < n) ? (T)1 / H[tri(lane, lane)] : (T)0;
-  for (int p = 0; p < n; p++) {
+  const bool in = lane < n;
+  T invd = in ? (T)1 / H[tri(lane, lane)] : (T)0;
+  if (!in) x = 0;
+  const T* ri = H + tri(in ? lane : 0, 0);
+  int p = 0;
+  for (; p + 4 <= n; p += 4) {
+    // lane i needs L[i][p..p+3] for p < i
+    T l0 = (in && lane > p) ? ri[p] : (T)0;
+    T l1 = (in && lane > p + 1) ? ri[p + 1] : (T)0;
+    T l2 = (in && lane > p + 2) ? ri[p + 2] : (T)0;
+    T l3 = (in && lane > p + 3) ? ri[p + 3] : (T)0;
     if (lane == p) x *= invd;
-    T xp = bcast(x, p);
-    if (lane > p && lane < n) x -= H[tri(lane, p)] * xp;
+    x -= l0 * bcast(x, p);
+    if (lane == p + 1) x *= invd;
+    x -= l1 * bcast(x, p + 1);
+    if (lane == p + 2) x *= invd;
+    x -= l2 * bcast(x, p + 2);
+    if (lane == p + 3) x *= invd;
+    x -= l3 * bcast(x, p + 3);
   }
-  for (int p = n - 1; p >= 0; p--) {
+  for (; p < n; p++) {
+    T l0 = (in && lane > p) ? ri[p] : (T)0;
     if (lane == p) x *= invd;
-    T xp = bcast(x, p);
-    if (lane < p) x -= H[tri(p, lane)] * xp;
+    x -= l0 * bcast(x, p);
+  }
+  p = n - 1;
+  for (; p - 3 >= 0; p -= 4) {
+    T l0 = (lane < p) ? H[tri(p, 0) + lane] : (T)0;
+    T l1 = (lane < p - 1) ? H[tri(p - 1, 0) + lane] : (T)0;
+    T l2 = (lane < p - 2) ? H[tri(p - 2, 0) + lane] : (T)0;
+    T l3 = (lane < p - 3) ? H[tri(p - 3, 0) + lane] : (T)0;
+    if (lane == p) x *= invd;
+    x -= l0 * bcast(x, p);
+    if (lane == p - 1) x *= invd;
+    x -= l1 * bcast(x, p - 1);
+    if (lane == p - 2) x *= invd;
+    x -= l2 * bcast(x, p - 2);
+    if (lane == p - 3) x *= invd;
+    x -= l3 * bcast(x, p - 3);
+  }
+  for (; p >= 0; p--) {
+    T l0 = (lane < p) ? H[tri(p, 0) + lane] : (T)0;
+    if (lane == p) x *= invd;
+    x -= l0 * bcast(x, p);
   }
   return x;
 }
-// y = M v, M symmetric packed (n rows), v staged in LDS
+// y = M x, M symmetric packed (n rows), x in the register of lane j
 template <typename T>
-__device__ T symv_packed(const T* M, int n, int lane, const T* v) {
+__device__ T symv_packed(const T* M, int n, int lane, T x) {
   T s = 0;
-  if (lane < n) {
-    const T* ri = M + tri(lane, 0);
-    for (int j = 0; j <= lane; j++) s += ri[j] * v[j];
-    for (int j = lane + 1; j < n; j++) s += M[tri(j, lane)] * v[j];
+  const bool in = lane < n;
+  const T* ri = M + tri(in ? lane : 0, 0);
+  if (!in) x = 0;
+  int j = 0;
+  for (; j + 4 <= n; j += 4) {
+    T m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    if (in) {
+      m0 = (j <= lane) ? ri[j] : M[tri(j, 0) + lane];
+      m1 = (j + 1 <= lane) ? ri[j + 1] : M[tri(j + 1, 0) + lane];
+      m2 = (j + 2 <= lane) ? ri[j + 2] : M[tri(j + 2, 0) + lane];
+      m3 = (j + 3 <= lane) ? ri[j + 3] : M[tri(j + 3, 0) + lane];
+    }
+    s += m0 * bcast(x, j); s += m1 * bcast(x, j + 1); s += m2 * bcast(x, j + 2);
+    s += m3 * bcast(x, j + 3);
+  }
+  for (; j < n; j++) {
+    T m0 = in ? ((j <= lane) ? ri[j] : M[tri(j, 0) + lane]) : (T)0;
+    s += m0 * bcast(x, j);
   }
   return s;
 }
@@ -434,6 +507,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
   const int lane = threadIdx.x;
   __shared__ Smem<T> sm;
   int warn = 0;
+  long long prof_t = (long long)__builtin_readcyclecounter();
   const int nl = M.nlink, nk = M.nkey, nv = M.nv, nu = M.nu;
   const T h = M.timestep;
 
@@ -547,6 +621,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
   for (int i = lane; i < RPK_NL * (RPK_NL + 1) / 2; i += 64) sm.Mh[i] = 0;
   __syncthreads();
 
+  PROF(0);
   // values produced by the position/velocity stage and consumed by the next
   // acceleration stage
   T cdofr[6], qbias = 0, alen = 0, avel = 0;
@@ -603,6 +678,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
           qs[1 + s] = f / kM[s];
         }
       }
+      PROF(1);
       // ---- qacc_smooth = M^-1 qfrc_smooth (hand: dense packed Cholesky)
       for (int i = lane; i < tri(nl, 0); i += 64) sm.H[i] = sm.Mh[i];
       __syncthreads();
@@ -610,6 +686,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
       qs[0] = solve_packed(sm.H, nl, lane, qfs[0]);
       __syncthreads();
 
+      PROF(2);
       // ---- constraint solve [MJ: mj_solNewton]
       const int nsys = nl + nkt;
       const bool hascon = lane < ncon && con_D > 0;
@@ -726,12 +803,9 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
         return (T)0.5 * g;
       };
       auto mulM = [&](const T* x, T* out) {
-        sm.vec[1][lane] = x[0];
-        __syncthreads();
-        out[0] = symv_packed(sm.Mh, nl, lane, sm.vec[1]);
+        out[0] = symv_packed(sm.Mh, nl, lane, x[0]);
         out[1] = kM[0] * x[1];
         out[2] = kM[1] * x[2];
-        __syncthreads();
       };
       auto sub_aref = [&](Rows<T>& r) {
         r.fr -= fr_aref;
@@ -769,6 +843,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
 #pragma unroll
         for (int s = 0; s < 3; s++) grad[s] = Ma[s] - qfs[s] - qfc[s];
 
+        PROF(3);
         const int maxit = S.max_newton;
         for (int iter = 0; iter < maxit; iter++) {
           // ---- H = M + J^T D J on the coupled system (hand dofs + touched keys)
@@ -842,6 +917,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
             }
           }
           __syncthreads();
+          PROF(4);
           chol_packed(sm.H, nsys, lane, &warn);
           T x = solve_packed(sm.H, nsys, lane, rhs);
           __syncthreads();
@@ -858,6 +934,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
             }
           }
           __syncthreads();
+          PROF(5);
           T snorm = N::sqrt(wave_sum(search[0] * search[0] + search[1] * search[1] + search[2] * search[2]));
           if (!(snorm >= RPK_MINVAL)) break;
           T Mv[3];
@@ -872,6 +949,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
             g2 += search[s] * Mv[s];
           }
           g0 = (T)0.5 * wave_sum(g0); g1 = wave_sum(g1); g2 = (T)0.5 * wave_sum(g2);
+          PROF(6);
           // ---- exact line search: safeguarded Newton on phi'(alpha)
           auto ls_eval = [&](T alpha, T& d1, T& d2) -> T {
             T cst = 0, a = 0, b = 0;
@@ -918,6 +996,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
             T c1 = ls_eval(alpha, f, hh);
             if (c1 > c0) alpha = 0;
           }
+          PROF(7);
           if (!(alpha > 0)) break;
 #pragma unroll
           for (int s = 0; s < 3; s++) { qa[s] += alpha * search[s]; Ma[s] += alpha * Mv[s]; }
@@ -934,12 +1013,14 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
 #pragma unroll
           for (int s = 0; s < 3; s++) { grad[s] = Ma[s] - qfs[s] - qfc[s]; gn += grad[s] * grad[s]; }
           gn = N::sqrt(wave_sum(gn));
+          PROF(8);
           if (scale * (oldcost - cost) < M.tolerance || scale * gn < M.tolerance) break;
         }
       }
 #pragma unroll
       for (int s = 0; s < 3; s++) qw[s] = qa[s];
 
+      PROF(8);
       // ---- Euler with implicit joint damping [MJ: mj_Euler, eulerdamp]
       for (int i = lane; i < tri(nl, 0); i += 64) sm.H[i] = sm.Mh[i];
       __syncthreads();
@@ -957,6 +1038,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
     }
 
     // ======================================================================
+    if (stage > 0) PROF(9);
     // POSITION STAGE
     // ======================================================================
     {
@@ -1007,6 +1089,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
       }
       __syncthreads();
     }
+    PROF(10);
     // ---- spatial inertia and motion axis about the tree reference point [MJ: mj_comPos]
     T cin[10];
     {
@@ -1075,6 +1158,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
         }
       }
     }
+    PROF(11);
     // ---- key poses, geom centres
 #pragma unroll
     for (int s = 0; s < 2; s++) {
@@ -1097,6 +1181,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
     }
     __syncthreads();
 
+    PROF(18);
     // ---- broad phase: static pair list + (capsule x keys) family [MJ: mj_collision]
     int nwork = 0;
     for (int base = 0; base < M.npair; base += 64) {
@@ -1153,6 +1238,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
     if (nwork > RPK_WORK) { warn |= 16; nwork = RPK_WORK; }
     __syncthreads();
 
+    PROF(12);
     // ---- narrow phase + contact parameters [MJ: mjc_* , mj_contactParam, mj_makeImpedance]
     ncon = 0;
     for (int base = 0; base < nwork; base += 64) {
@@ -1235,6 +1321,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
     if (ncon > RPK_NC) { warn |= 2; ncon = RPK_NC; }
     __syncthreads();
 
+    PROF(13);
     // ---- solver slots for touched keys
     {
       int kb = -1;
@@ -1301,6 +1388,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
     __syncthreads();
 
     // ======================================================================
+    PROF(14);
     // VELOCITY STAGE
     // ======================================================================
     // ---- spatial velocities, axis derivatives [MJ: mj_comVel]
@@ -1364,6 +1452,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
       }
     }
     qbias = isl ? dot6(cdofr, sm.acc[lane]) : (T)0;
+    PROF(15);
     // ---- transmission [MJ: mj_transmission]: actuator length / velocity
     sm.vec[0][lane] = q[0]; sm.vec[1][lane] = qd[0];
     if (isk[0]) sm.keyvec[0][kid[0]] = qd[1];
@@ -1421,6 +1510,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
     }
     __syncthreads();
 
+    PROF(16);
     // ---- per-substep key activation trace (Piano._update_key_state, piano.py:178-192)
     if (S.key_trace && stage > 0) {
       unsigned long long b0 = __ballot(isk[0] && (fmin(hi[1], fmax(lo[1], q[1])) >= hi[1] - (T)0.00872665));
@@ -1432,6 +1522,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
     }
   }
 
+  PROF(17);
   // ------------------------------------------------------------------ outputs
   if (isl) { S.qpos[eo + ldof] = q[0]; S.qvel[eo + ldof] = qd[0]; S.warm[eo + ldof] = qw[0]; }
 #pragma unroll

@@ -35,7 +35,7 @@ WARN_WORK_FULL = 16
 EXPORTED_SYMBOLS = (
     "rp_create", "rp_destroy", "rp_reset", "rp_set", "rp_get", "rp_step", "rp_forward",
     "rp_set_solver_limits", "rp_sync", "rp_get_stream", "rp_n_envs", "rp_dim",
-    "rp_kernel_time", "rp_last_error",
+    "rp_kernel_time", "rp_profile", "rp_last_error",
 )
 
 _lib = None
@@ -73,6 +73,7 @@ def load_library(path: str = LIB_PATH):
     L.rp_dim.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
     L.rp_kernel_time.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                  ctypes.POINTER(ctypes.c_int)]
+    L.rp_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     _lib = L
     return L
 
@@ -185,6 +186,12 @@ class BatchedPhysics:
         ms = ctypes.c_double(); n = ctypes.c_int()
         self._check(self._L.rp_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
+
+    def profile(self, enable=True):
+        """Reads+clears the per-phase cycle counters of env 0, then (dis)enables them."""
+        out = np.zeros(24, np.int64)
+        self._check(self._L.rp_profile(self._h, out.ctypes.data, 24, int(bool(enable))))
+        return out
 
     @property
     def stream(self) -> int:

@@ -1,0 +1,26 @@
+import warnings; warnings.simplefilter('ignore')
+import sys; sys.path.insert(0,'.')
+import numpy as np, time
+from robopianist_amd import engine
+from robopianist_amd.model import scene
+from bench import load_actions
+prec = int(sys.argv[1]) if len(sys.argv)>1 else 32
+E = int(sys.argv[2]) if len(sys.argv)>2 else 4096
+si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=True)
+m = si.model
+phys = engine.BatchedPhysics(m, si.key_joint_ids, n_envs=E, precision=prec)
+ctrl,_ = load_actions(m)
+names = {0:'load',1:'actuation',2:'M chol+solve',3:'warmstart',4:'H assembly',5:'H chol+solve',6:'mulM/mulJ/quad',7:'linesearch',8:'update+JT',9:'euler',10:'FK',11:'inertia+CRB',18:'geom centres',12:'broadphase',13:'narrowphase',14:'slots+jac',15:'cvel+rne',16:'transm+rows',17:'trace'}
+for t in range(30):
+    phys.set(engine.CTRL, ctrl[t][None,:]); phys.step(10)
+phys.profile(True)
+n=40
+its=[]
+for t in range(30,30+n):
+    phys.set(engine.CTRL, ctrl[t][None,:]); phys.step(10)
+    its.append(phys.get(engine.SOLVER_ITER).mean())
+p = phys.profile(False)
+tot = p.sum()
+print('total cycles/env-step (env0): %.0f  -> per mj_step %.0f' % (tot/n, tot/n/10), 'mean newton iters', np.mean(its), 'ncon mean', phys.get(engine.NCON).mean())
+for i in sorted(names, key=lambda i:-p[i]):
+    print('%-16s %10.0f cyc/mj_step  %5.1f%%' % (names[i], p[i]/n/10, 100*p[i]/tot))
