@@ -43,7 +43,8 @@ typedef enum {
   RP_CONTACT_GEOMS = 10,/* [E][RP_MAX_CONTACTS][2] int32 model geom ids (-1 pad), for
                            collision_utils.has_collision          piano_with_shadow_hands.py:253-257 */
   RP_WARN_FLAGS = 11,   /* [E] int32 */
-  RP_SOLVER_ITER = 12,  /* [E] int32  Newton iterations of the last substep */
+  RP_SOLVER_ITER = 12,  /* [E] int32  last substep: bits 0-7 Newton iterations, 8-15 rows in the
+                           dense (cross-chain) block, 16-23 touched keys */
   RP_CONTACT_DIST = 13, /* [E][RP_MAX_CONTACTS] */
   RP_TREE_OFFSET = 14   /* [E][ntree][3] per-env root-body translation (hand.shift_pose,
                            piano_with_shadow_hands.py:491-499) */

@@ -157,6 +157,7 @@ struct Engine : EngineBase {
     M.link_dof = upI(b.i("eng_link_dof")); M.link_sibrank = upI(b.i("eng_link_sibrank"));
     M.level_maxrank = upI(b.i("eng_level_maxrank")); M.link_anc = upI(b.i("eng_link_anc"));
     M.link_limited = upI(b.i("eng_link_limited")); M.link_act = upI(b.i("eng_link_act"));
+    M.link_desc = upI(b.i("eng_link_desc"));
     M.link_ancmask = (const unsigned*)upI(b.i("eng_link_ancmask"));
     M.link_lpos = upF(b.f("eng_link_lpos"));
     {

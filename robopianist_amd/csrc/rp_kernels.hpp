@@ -39,7 +39,7 @@ struct RpModel {
   T timestep, gx, gy, gz, tolerance, ls_tolerance, meaninertia, key_zmax;
   // links
   const int *link_parent, *link_depth, *link_tree, *link_jtype, *link_dof, *link_sibrank,
-      *level_maxrank, *link_anc, *link_limited, *link_act;
+      *level_maxrank, *link_anc, *link_limited, *link_act, *link_desc;
   const unsigned* link_ancmask;
   const T *link_lpos, *link_lmat, *link_axis, *link_anchor, *link_mass, *link_ipos,
       *link_inertia, *link_invw_body, *link_armature, *link_damping, *link_stiffness,
@@ -72,6 +72,14 @@ struct RpState {
   int max_newton, max_ls;
 };
 
+// One workgroup == one wavefront, and a wave's LDS instructions execute in issue
+// order, so cross-lane LDS hand-offs need no s_barrier and no s_waitcnt drain: only
+// the compiler must be kept from reordering LDS accesses across the hand-off.
+#define WSYNC()                                              \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+  } while (0)
 #define RPK_NPROF 24
 #define PROF(i)                                                         \
   do {                                                                  \
@@ -359,7 +367,10 @@ struct Smem {
   T xanchor[RPK_NL][3];
   T cdof[RPK_NL][6];
   T vel[RPK_NL][6];
-  T Mh[RPK_NL * (RPK_NL + 1) / 2];
+  T RM[RPK_NL][RPK_MAXD + 1];   // mass-matrix rows: RM[i][e] = M[i][anc_e(i)]
+  T R[RPK_WAVE][RPK_MAXD + 1];  // tree factor rows (L), incl. key-leaf rows
+  T Dg[RPK_WAVE];               // tree factor diagonal
+  T xs[RPK_WAVE];               // solve staging
   union {
     T acc[RPK_NL][10];
     T H[RPK_WAVE * (RPK_WAVE + 1) / 2];
@@ -377,6 +388,9 @@ struct Smem {
   T cJ[RPK_NC][2][RPK_MAXD][3];
   int work[RPK_WORK][2];
   int slotkey[RPK_WAVE];
+  int slotlink[RPK_WAVE];
+  unsigned long long slotmask[16];
+  signed char desc[RPK_NL * RPK_MAXD * 5];
   int keyslot[RPK_NKEYS];
 };
 
@@ -414,7 +428,7 @@ __device__ void chol_packed(T* H, int n, int lane, int* warn) {
     T ljj = Num<T>::sqrt(sj);
     if (lane == j) H[tri(j, j)] = ljj;
     else if (act) H[tri(lane, j)] = s / ljj;
-    __syncthreads();
+    WSYNC();
   }
 }
 // solves (L L^T) x = b, x/b in the register of lane i (< n).
@@ -617,14 +631,21 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
   }
   T time = S.time[env];
 
-  // zero the structurally-zero part of the packed hand mass matrix once
-  for (int i = lane; i < RPK_NL * (RPK_NL + 1) / 2; i += 64) sm.Mh[i] = 0;
-  __syncthreads();
+  // descendant table (link, depth) -> <=5 lanes, used by the tree-sparse routines
+  for (int i = lane; i < nl * RPK_MAXD * 5; i += 64) sm.desc[i] = (signed char)M.link_desc[i];
+  WSYNC();
 
   PROF(0);
   // values produced by the position/velocity stage and consumed by the next
   // acceleration stage
   T cdofr[6], qbias = 0, alen = 0, avel = 0;
+  T Mr[RPK_MAXD + 1];  // this link's mass-matrix row over its ancestors (diag at [depth])
+#pragma unroll
+  for (int e = 0; e <= RPK_MAXD; e++) Mr[e] = 0;
+  int tree_ok = 1;     // all contacts lie on single root-to-leaf paths (uniform)
+  int sdepth = -1, sanc[RPK_MAXD];  // solver-slot lanes: anchor link depth / ancestors
+#pragma unroll
+  for (int e = 0; e < RPK_MAXD; e++) sanc[e] = 0;
   T ksin[2] = {0, 0}, kcos[2] = {1, 1};
   int ncon = 0, nkt = 0;
   // rows
@@ -633,7 +654,8 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
   T lim_D[3] = {0, 0, 0}, lim_aref[3] = {0, 0, 0};
   T con_aref[4] = {0, 0, 0, 0}, con_D = 0, con_mu = 0, con_n[3] = {0, 0, 0}, con_t1[3] = {0, 0, 0},
     con_t2[3] = {0, 0, 0};
-  int con_A = -1, con_B = -1, con_slot = -1;
+  int con_A = -1, con_B = -1, con_slot = -1, con_cross = 0;
+  unsigned long long dirty_mask = 0;  // rows that need the dense block (uniform)
   unsigned long long con_maskA = 0, con_maskB = 0;
   int niter_last = 0;
 
@@ -653,7 +675,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
         sm.actf[lane] = aforce;
         S.act_force[(size_t)env * nu + lane] = aforce;
       }
-      __syncthreads();
+      WSYNC();
       T qfs[3], qs[3];
       {
         T qact = (isl && lact >= 0) ? lactcoef * sm.actf[lact] : (T)0;
@@ -679,12 +701,155 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
         }
       }
       PROF(1);
-      // ---- qacc_smooth = M^-1 qfrc_smooth (hand: dense packed Cholesky)
-      for (int i = lane; i < tri(nl, 0); i += 64) sm.H[i] = sm.Mh[i];
-      __syncthreads();
-      chol_packed(sm.H, nl, lane, &warn);
-      qs[0] = solve_packed(sm.H, nl, lane, qfs[0]);
-      __syncthreads();
+      // ---- hybrid tree-sparse / dense factor + solve [MJ: mj_factorM / mj_solveLD by levels].
+      // Row r of the symmetric system is held by lane r as Rr[e] = A[r][anc_e(r)]
+      // (diag at e = depth).  Touched keys (nslots of them, lanes nl..nl+nslots-1)
+      // are extra leaves hanging under their anchor link.  Rows whose bit is clear in
+      // `dm` ("clean") only couple to their ancestors and are eliminated leaf-to-root
+      // with no fill-in.  The rows in `dm` ("dirty": supports of cross-chain contacts,
+      // an ancestor-closed set) receive the Schur complement and are solved with a
+      // small dense Cholesky; `cross_fn(cidx)` adds the cross-contact blocks to it.
+      auto tree_solve = [&](T* Rr, T rhs, int nslots, unsigned long long dm, auto&& cross_fn) -> T {
+        const bool isslot = !isl && lane < nl + nslots;
+        const bool dirty = (dm >> lane) & 1;
+        const int mydiag = isl ? depth : sdepth + 1;
+        T Dme = 1;
+        if (nslots > 0) {
+          if (isslot && !dirty) {
+            T Dk = 1;
+#pragma unroll
+            for (int e = 0; e <= RPK_MAXD; e++) if (e == mydiag) Dk = Rr[e];
+            if (!(Dk >= RPK_MINVAL)) { Dk = RPK_MINVAL; warn |= 4; }
+            Dme = Dk;
+            T inv = (T)1 / Dk;
+#pragma unroll
+            for (int e = 0; e < RPK_MAXD; e++) if (e < mydiag) { Rr[e] *= inv; sm.R[lane][e] = Rr[e]; }
+            sm.Dg[lane] = Dk;
+          }
+          WSYNC();
+          if (isl) {
+            for (int sidx = 0; sidx < nslots; sidx++) {
+              if (((sm.slotmask[sidx] >> lane) & 1) && !((dm >> (nl + sidx)) & 1)) {
+                const T* Lk = sm.R[nl + sidx];
+                T t = Lk[depth] * sm.Dg[nl + sidx];
+#pragma unroll
+                for (int e = 0; e < RPK_MAXD; e++) if (e <= depth) Rr[e] -= t * Lk[e];
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int d = RPK_MAXD - 1; d >= 0; d--) {
+          if (d < M.maxdepth) {
+            if (isl && depth == d && !dirty) {
+              T Dk = Rr[d];
+              if (!(Dk >= RPK_MINVAL)) { Dk = RPK_MINVAL; warn |= 4; }
+              Dme = Dk;
+              T inv = (T)1 / Dk;
+#pragma unroll
+              for (int e = 0; e < RPK_MAXD; e++) if (e < d) { Rr[e] *= inv; sm.R[lane][e] = Rr[e]; }
+              sm.Dg[lane] = Dk;
+            }
+            WSYNC();
+            if (isl && depth < d) {
+              for (int r = 0; r < 5; r++) {
+                int k = sm.desc[(lane * RPK_MAXD + d) * 5 + r];
+                if (k < 0) break;
+                if ((dm >> k) & 1) continue;
+                const T* Lk = sm.R[k];
+                T t = Lk[depth] * sm.Dg[k];
+#pragma unroll
+                for (int e = 0; e < RPK_MAXD; e++) if (e <= depth) Rr[e] -= t * Lk[e];
+              }
+            }
+          }
+        }
+        // ---- solve, part 1: x <- L^-T restricted to clean rows
+        T x = (isl || isslot) ? rhs : (T)0;
+        if (nslots > 0) {
+          if (isslot && !dirty) sm.xs[lane] = x;
+          WSYNC();
+          if (isl)
+            for (int sidx = 0; sidx < nslots; sidx++)
+              if (((sm.slotmask[sidx] >> lane) & 1) && !((dm >> (nl + sidx)) & 1))
+                x -= sm.R[nl + sidx][depth] * sm.xs[nl + sidx];
+        }
+        for (int d = M.maxdepth - 1; d >= 1; d--) {
+          if (isl && depth == d && !dirty) sm.xs[lane] = x;
+          WSYNC();
+          if (isl && depth < d) {
+            for (int r = 0; r < 5; r++) {
+              int k = sm.desc[(lane * RPK_MAXD + d) * 5 + r];
+              if (k < 0) break;
+              if ((dm >> k) & 1) continue;
+              x -= sm.R[k][depth] * sm.xs[k];
+            }
+          }
+        }
+        // ---- dense block on the dirty rows (Schur complement + cross-contact terms)
+        if (dm) {
+          WSYNC();
+          const int nD = __popcll(dm);
+          auto cidx = [&](int l) -> int { return __popcll(dm & lanemask_lt(l)); };
+          const int ci = cidx(lane);
+          for (int i = lane; i < tri(nD, 0); i += 64) sm.H[i] = 0;
+          WSYNC();
+          if (dirty) {
+            if (isl) {
+#pragma unroll
+              for (int e = 0; e < RPK_MAXD; e++) if (e <= depth) sm.H[tri(ci, cidx(anc[e]))] = Rr[e];
+            } else {
+              T Dk = 0;
+#pragma unroll
+              for (int e = 0; e <= RPK_MAXD; e++) if (e == mydiag) Dk = Rr[e];
+              sm.H[tri(ci, ci)] = Dk;
+#pragma unroll
+              for (int e = 0; e < RPK_MAXD; e++)
+                if (e <= sdepth && ((dm >> sanc[e]) & 1)) sm.H[tri(ci, cidx(sanc[e]))] = Rr[e];
+            }
+            sm.xs[ci] = x;
+          }
+          WSYNC();
+          cross_fn(cidx);
+          WSYNC();
+          T xr = lane < nD ? sm.xs[lane] : (T)0;
+          WSYNC();
+          chol_packed(sm.H, nD, lane, &warn);
+          xr = solve_packed(sm.H, nD, lane, xr);
+          if (lane < nD) sm.xs[lane] = xr;
+          WSYNC();
+          if (dirty) x = sm.xs[ci];
+          WSYNC();
+        }
+        if (!dirty) x /= Dme;
+        // ---- solve, part 2: forward substitution of the clean rows, root to leaves
+#pragma unroll
+        for (int d = 0; d < RPK_MAXD - 1; d++) {
+          if (d < M.maxdepth - 1) {
+            if (isl && depth == d) sm.xs[lane] = x;
+            WSYNC();
+            if (isl && depth > d && !dirty) x -= Rr[d] * sm.xs[anc[d]];
+          }
+        }
+        if (nslots > 0) {
+          if (isl && depth == M.maxdepth - 1) sm.xs[lane] = x;
+          WSYNC();
+          if (isslot && !dirty) {
+#pragma unroll
+            for (int e = 0; e < RPK_MAXD; e++) if (e <= sdepth) x -= Rr[e] * sm.xs[sanc[e]];
+          }
+        }
+        WSYNC();
+        return x;
+      };
+      auto no_cross = [&](auto&&) {};
+      // ---- qacc_smooth = M^-1 qfrc_smooth (M is always tree-sparse)
+      {
+        T Rr[RPK_MAXD + 1];
+#pragma unroll
+        for (int e = 0; e <= RPK_MAXD; e++) Rr[e] = Mr[e];
+        qs[0] = tree_solve(Rr, qfs[0], 0, 0ull, no_cross);
+      }
 
       PROF(2);
       // ---- constraint solve [MJ: mj_solNewton]
@@ -700,7 +865,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
         sm.vec[0][lane] = x[0];
         if (isk[0]) sm.keyvec[0][kid[0]] = x[1];
         if (isk[1]) sm.keyvec[0][kid[1]] = x[2];
-        __syncthreads();
+        WSYNC();
         out.fr = x[0];
 #pragma unroll
         for (int s = 0; s < 3; s++) out.lim[s] = (T)lim_sign[s] * x[s];
@@ -725,7 +890,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
         }
         T vn = dot3(con_n, vc), v1 = con_mu * dot3(con_t1, vc), v2 = con_mu * dot3(con_t2, vc);
         out.con[0] = vn + v1; out.con[1] = vn - v1; out.con[2] = vn + v2; out.con[3] = vn - v2;
-        __syncthreads();
+        WSYNC();
       };
       // forces + active set from jar; returns this lane's share of the constraint cost
       auto update = [&](const Rows<T>& ja, Rows<T>& f) -> T {
@@ -803,9 +968,24 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
         return (T)0.5 * g;
       };
       auto mulM = [&](const T* x, T* out) {
-        out[0] = symv_packed(sm.Mh, nl, lane, x[0]);
+        sm.xs[lane] = x[0];
+        WSYNC();
+        T y = 0;
+        if (isl) {
+#pragma unroll
+          for (int e = 0; e < RPK_MAXD; e++) if (e <= depth) y += Mr[e] * sm.xs[anc[e]];
+          for (int d = depth + 1; d < M.maxdepth; d++) {
+            for (int r = 0; r < 5; r++) {
+              int k = sm.desc[(lane * RPK_MAXD + d) * 5 + r];
+              if (k < 0) break;
+              y += sm.RM[k][depth] * sm.xs[k];
+            }
+          }
+        }
+        out[0] = y;
         out[1] = kM[0] * x[1];
         out[2] = kM[1] * x[2];
+        WSYNC();
       };
       auto sub_aref = [&](Rows<T>& r) {
         r.fr -= fr_aref;
@@ -847,33 +1027,30 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
         const int maxit = S.max_newton;
         for (int iter = 0; iter < maxit; iter++) {
           // ---- H = M + J^T D J on the coupled system (hand dofs + touched keys)
-          for (int i = lane; i < tri(nl, 0); i += 64) sm.H[i] = sm.Mh[i];
-          for (int i = tri(nl, 0) + lane; i < tri(nsys, 0); i += 64) sm.H[i] = 0;
           // key diagonals and gradients to the solver slots
 #pragma unroll
           for (int s = 0; s < 2; s++) if (isk[s]) {
             sm.keyvec[0][kid[s]] = kM[s] + (lim_act[1 + s] ? lim_D[1 + s] : (T)0);
             sm.keyvec[1][kid[s]] = grad[1 + s];
           }
-          __syncthreads();
-          T rhs = grad[0];
-          if (isl) sm.H[tri(lane, lane)] += (fr_quad ? lflD : (T)0) + (lim_act[0] ? lim_D[0] : (T)0);
-          else if (lane < nsys) {
+          WSYNC();
+          const bool isslot = !isl && lane < nsys;
+          T rhs = isl ? grad[0] : (T)0, slotdiag = 0;
+          if (isslot) {
             int k = sm.slotkey[lane - nl];
-            sm.H[tri(lane, lane)] = sm.keyvec[0][k];
+            slotdiag = sm.keyvec[0][k];
             rhs = sm.keyvec[1][k];
-          } else rhs = 0;
-          __syncthreads();
-          // contact blocks
+          }
+          const T mydiag_add = (fr_quad ? lflD : (T)0) + (lim_act[0] ? lim_D[0] : (T)0);
+          // per-contact 3x3 weight C = sum_r D_r w_r w_r^T with w = n +- mu t
+          T Cm[6];  // xx yy zz xy xz yz
           {
             T Dr[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) Dr[r] = con_act[r] ? con_D : (T)0;
-            // C = sum_r D_r w_r w_r^T with w = n +- mu t
             T sn = Dr[0] + Dr[1] + Dr[2] + Dr[3];
             T a1 = con_mu * (Dr[0] - Dr[1]), a2 = con_mu * (Dr[2] - Dr[3]);
             T b1 = con_mu * con_mu * (Dr[0] + Dr[1]), b2 = con_mu * con_mu * (Dr[2] + Dr[3]);
-            T Cm[6];  // xx yy zz xy xz yz
             const int ia[6] = {0, 1, 2, 0, 0, 1}, ib[6] = {0, 1, 2, 1, 2, 2};
 #pragma unroll
             for (int e = 0; e < 6; e++) {
@@ -882,49 +1059,95 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
                       a2 * (con_n[a] * con_t2[b] + con_t2[a] * con_n[b]) + b1 * con_t1[a] * con_t1[b] +
                       b2 * con_t2[a] * con_t2[b];
             }
-            int anyact = hascon && (con_act[0] | con_act[1] | con_act[2] | con_act[3]);
+          }
+          const int anyact = hascon && (con_act[0] | con_act[1] | con_act[2] | con_act[3]);
+          T x;
+          {
+            // rows: mass matrix + per-dof terms + every single-chain contact (+ its key leaf)
+            T Rr[RPK_MAXD + 1];
+#pragma unroll
+            for (int e = 0; e <= RPK_MAXD; e++) Rr[e] = isl ? Mr[e] : (T)0;
+            T diag_acc = isl ? mydiag_add : slotdiag;
             for (int c = 0; c < ncon; c++) {
-              if (!bcast(anyact, c)) continue;
+              if (!bcast(anyact, c) || bcast(con_cross, c)) continue;
               T C0 = bcast(Cm[0], c), C1 = bcast(Cm[1], c), C2 = bcast(Cm[2], c), C3 = bcast(Cm[3], c),
                 C4 = bcast(Cm[4], c), C5 = bcast(Cm[5], c);
               int cA = bcast(con_A, c), cB = bcast(con_B, c), cslot = bcast(con_slot, c);
-              unsigned long long mA = ((unsigned long long)(unsigned)bcast((int)(con_maskA >> 32), c) << 32) |
-                                      (unsigned)bcast((int)(con_maskA & 0xffffffffu), c);
-              unsigned long long mB = ((unsigned long long)(unsigned)bcast((int)(con_maskB >> 32), c) << 32) |
-                                      (unsigned)bcast((int)(con_maskB & 0xffffffffu), c);
-              unsigned long long sup = mA | mB;
+              // after the nested-contact merge at most one side is a link
+              int lside = (cA >= 0 && cA < RPK_KEYBASE) ? 0 : ((cB >= 0 && cB < RPK_KEYBASE) ? 1 : -1);
               int keyside = cA >= RPK_KEYBASE ? 0 : (cB >= RPK_KEYBASE ? 1 : -1);
-              if (keyside >= 0 && cslot >= 0) sup |= 1ull << (nl + cslot);
-              // this lane's column of J_diff for contact c
-              T jc[3] = {0, 0, 0};
-              if (isl) {
-                if ((mA >> lane) & 1) { const T* p = sm.cJ[c][0][depth]; jc[0] += p[0]; jc[1] += p[1]; jc[2] += p[2]; }
-                if ((mB >> lane) & 1) { const T* p = sm.cJ[c][1][depth]; jc[0] += p[0]; jc[1] += p[1]; jc[2] += p[2]; }
-              } else if (keyside >= 0 && lane == nl + cslot) {
-                const T* p = sm.cJ[c][keyside][0]; jc[0] = p[0]; jc[1] = p[1]; jc[2] = p[2];
-              }
-              T u0 = C0 * jc[0] + C3 * jc[1] + C4 * jc[2];
-              T u1 = C3 * jc[0] + C1 * jc[1] + C5 * jc[2];
-              T u2 = C4 * jc[0] + C5 * jc[1] + C2 * jc[2];
-              bool insup = (sup >> lane) & 1;
-              unsigned long long rem = sup;
-              while (rem) {
-                int j = __ffsll((long long)rem) - 1;
-                rem &= rem - 1;
-                T j0 = bcast(jc[0], j), j1 = bcast(jc[1], j), j2 = bcast(jc[2], j);
-                if (insup && lane >= j) sm.H[tri(lane, j)] += u0 * j0 + u1 * j1 + u2 * j2;
+              int lk = lside == 0 ? cA : cB;
+              unsigned long long mk = lside == 0
+                  ? (((unsigned long long)(unsigned)bcast((int)(con_maskA >> 32), c) << 32) | (unsigned)bcast((int)(con_maskA & 0xffffffffu), c))
+                  : (((unsigned long long)(unsigned)bcast((int)(con_maskB >> 32), c) << 32) | (unsigned)bcast((int)(con_maskB & 0xffffffffu), c));
+              if (lside < 0) mk = 0;
+              const bool mine = isl && ((mk >> lane) & 1);
+              const bool myslot = keyside >= 0 && cslot >= 0 && lane == nl + cslot;
+              if (mine || myslot) {
+                const T* jp = mine ? sm.cJ[c][lside][depth] : sm.cJ[c][keyside][0];
+                T u0 = C0 * jp[0] + C3 * jp[1] + C4 * jp[2];
+                T u1 = C3 * jp[0] + C1 * jp[1] + C5 * jp[2];
+                T u2 = C4 * jp[0] + C5 * jp[1] + C2 * jp[2];
+                if (myslot) diag_acc += u0 * jp[0] + u1 * jp[1] + u2 * jp[2];
+                if (lside >= 0) {
+                  int top = mine ? depth : M.link_depth[lk];
+#pragma unroll
+                  for (int e = 0; e < RPK_MAXD; e++) {
+                    if (e <= top) {
+                      const T* je = sm.cJ[c][lside][e];
+                      Rr[e] += u0 * je[0] + u1 * je[1] + u2 * je[2];
+                    }
+                  }
+                }
               }
             }
+            {
+              const int dg = isl ? depth : sdepth + 1;
+#pragma unroll
+              for (int e = 0; e <= RPK_MAXD; e++) if (e == dg && (isl || isslot)) Rr[e] += diag_acc;
+            }
+            // cross-chain contacts go into the dense block of the dirty rows
+            auto cross_fn = [&](auto&& cidx) {
+              for (int c = 0; c < ncon; c++) {
+                if (!bcast(anyact, c) || !bcast(con_cross, c)) continue;
+                T C0 = bcast(Cm[0], c), C1 = bcast(Cm[1], c), C2 = bcast(Cm[2], c), C3 = bcast(Cm[3], c),
+                  C4 = bcast(Cm[4], c), C5 = bcast(Cm[5], c);
+                int cA = bcast(con_A, c), cB = bcast(con_B, c), cslot = bcast(con_slot, c);
+                unsigned long long mA = ((unsigned long long)(unsigned)bcast((int)(con_maskA >> 32), c) << 32) |
+                                        (unsigned)bcast((int)(con_maskA & 0xffffffffu), c);
+                unsigned long long mB = ((unsigned long long)(unsigned)bcast((int)(con_maskB >> 32), c) << 32) |
+                                        (unsigned)bcast((int)(con_maskB & 0xffffffffu), c);
+                unsigned long long sup = mA | mB;
+                int keyside = cA >= RPK_KEYBASE ? 0 : (cB >= RPK_KEYBASE ? 1 : -1);
+                if (keyside >= 0 && cslot >= 0) sup |= 1ull << (nl + cslot);
+                T jc[3] = {0, 0, 0};
+                if (isl) {
+                  if ((mA >> lane) & 1) { const T* p = sm.cJ[c][0][depth]; jc[0] += p[0]; jc[1] += p[1]; jc[2] += p[2]; }
+                  if ((mB >> lane) & 1) { const T* p = sm.cJ[c][1][depth]; jc[0] += p[0]; jc[1] += p[1]; jc[2] += p[2]; }
+                } else if (keyside >= 0 && lane == nl + cslot) {
+                  const T* p = sm.cJ[c][keyside][0]; jc[0] = p[0]; jc[1] = p[1]; jc[2] = p[2];
+                }
+                T u0 = C0 * jc[0] + C3 * jc[1] + C4 * jc[2];
+                T u1 = C3 * jc[0] + C1 * jc[1] + C5 * jc[2];
+                T u2 = C4 * jc[0] + C5 * jc[1] + C2 * jc[2];
+                bool insup = (sup >> lane) & 1;
+                const int cme = cidx(lane);
+                unsigned long long rem = sup;
+                while (rem) {
+                  int j = __ffsll((long long)rem) - 1;
+                  rem &= rem - 1;
+                  T j0 = bcast(jc[0], j), j1 = bcast(jc[1], j), j2 = bcast(jc[2], j);
+                  if (insup && lane >= j) sm.H[tri(cme, cidx(j))] += u0 * j0 + u1 * j1 + u2 * j2;
+                }
+              }
+            };
+            PROF(4);
+            x = tree_solve(Rr, rhs, nkt, dirty_mask, cross_fn);
           }
-          __syncthreads();
-          PROF(4);
-          chol_packed(sm.H, nsys, lane, &warn);
-          T x = solve_packed(sm.H, nsys, lane, rhs);
-          __syncthreads();
           T search[3];
           search[0] = isl ? -x : (T)0;
           if (!isl && lane < nsys) sm.keyvec[0][sm.slotkey[lane - nl]] = -x;
-          __syncthreads();
+          WSYNC();
 #pragma unroll
           for (int s = 0; s < 2; s++) {
             search[1 + s] = 0;
@@ -933,7 +1156,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
               else search[1 + s] = -grad[1 + s] / (kM[s] + (lim_act[1 + s] ? lim_D[1 + s] : (T)0));
             }
           }
-          __syncthreads();
+          WSYNC();
           PROF(5);
           T snorm = N::sqrt(wave_sum(search[0] * search[0] + search[1] * search[1] + search[2] * search[2]));
           if (!(snorm >= RPK_MINVAL)) break;
@@ -1022,14 +1245,13 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
 
       PROF(8);
       // ---- Euler with implicit joint damping [MJ: mj_Euler, eulerdamp]
-      for (int i = lane; i < tri(nl, 0); i += 64) sm.H[i] = sm.Mh[i];
-      __syncthreads();
-      if (isl) sm.H[tri(lane, lane)] += h * ldamp;
-      __syncthreads();
-      chol_packed(sm.H, nl, lane, &warn);
       T qe[3];
-      qe[0] = solve_packed(sm.H, nl, lane, qfs[0] + qfc[0]);
-      __syncthreads();
+      {
+        T Rr[RPK_MAXD + 1];
+#pragma unroll
+        for (int e = 0; e <= RPK_MAXD; e++) Rr[e] = Mr[e] + ((isl && e == depth) ? h * ldamp : (T)0);
+        qe[0] = tree_solve(Rr, qfs[0] + qfc[0], 0, 0ull, no_cross);
+      }
 #pragma unroll
       for (int s = 0; s < 2; s++) qe[1 + s] = (qfs[1 + s] + qfc[1 + s]) / (kM[s] + h * kdamp[s]);
 #pragma unroll
@@ -1087,7 +1309,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
 #pragma unroll
         for (int k = 0; k < 9; k++) sm.xmat[lane][k] = xm[k];
       }
-      __syncthreads();
+      WSYNC();
     }
     PROF(10);
     // ---- spatial inertia and motion axis about the tree reference point [MJ: mj_comPos]
@@ -1131,7 +1353,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
         for (int k = 0; k < 10; k++) sm.acc[lane][k] = cin[k];
       }
     }
-    __syncthreads();
+    WSYNC();
     // ---- composite inertias, children -> parent by level and sibling rank [MJ: mj_crb]
     for (int d = M.maxdepth - 1; d >= 1; d--) {
       int mr = M.level_maxrank[d];
@@ -1140,7 +1362,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
 #pragma unroll
           for (int k = 0; k < 10; k++) sm.acc[parent][k] += sm.acc[lane][k];
         }
-        __syncthreads();
+        WSYNC();
       }
     }
     if (isl) {
@@ -1154,7 +1376,8 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
           int a = anc[k];
           T v = dot6(sm.cdof[a], buf);
           if (a == lane) v += larm;
-          sm.Mh[tri(lane, a)] = v;
+          Mr[k] = v;
+          sm.RM[lane][k] = v;
         }
       }
     }
@@ -1168,7 +1391,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
         sm.keyslot[kid[s]] = -1;
       }
     }
-    __syncthreads();
+    WSYNC();
     if (lane < M.ngeom) {
       int gl = M.geom_link[lane];
       T gp[3] = {M.geom_pos[3 * lane], M.geom_pos[3 * lane + 1], M.geom_pos[3 * lane + 2]};
@@ -1179,7 +1402,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
       }
       sm.gpos[lane][0] = gp[0]; sm.gpos[lane][1] = gp[1]; sm.gpos[lane][2] = gp[2];
     }
-    __syncthreads();
+    WSYNC();
 
     PROF(18);
     // ---- broad phase: static pair list + (capsule x keys) family [MJ: mj_collision]
@@ -1236,7 +1459,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
       }
     }
     if (nwork > RPK_WORK) { warn |= 16; nwork = RPK_WORK; }
-    __syncthreads();
+    WSYNC();
 
     PROF(12);
     // ---- narrow phase + contact parameters [MJ: mjc_* , mj_contactParam, mj_makeImpedance]
@@ -1319,7 +1542,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
       }
     }
     if (ncon > RPK_NC) { warn |= 2; ncon = RPK_NC; }
-    __syncthreads();
+    WSYNC();
 
     PROF(13);
     // ---- solver slots for touched keys
@@ -1340,7 +1563,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
       int cap = 64 - nl;
       if (first && slot < cap) { sm.slotkey[slot] = kb; sm.keyslot[kb] = slot; }
       if (nkt > cap) { warn |= 8; nkt = cap; }
-      __syncthreads();
+      WSYNC();
       con_slot = kb >= 0 ? sm.keyslot[kb] : -1;
       // per-contact registers
       con_A = -1; con_B = -1; con_D = 0; con_mu = 0; con_maskA = 0; con_maskB = 0;
@@ -1385,9 +1608,81 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
       sm.cJ[c][side][lv][0] = sg * col[0]; sm.cJ[c][side][lv][1] = sg * col[1];
       sm.cJ[c][side][lv][2] = sg * col[2];
     }
-    __syncthreads();
+    WSYNC();
 
     // ======================================================================
+    // ---- nested link-link contacts (one link an ancestor of the other) collapse to a
+    // single chain of columns; then decide whether the Hessian is tree-structured.
+    {
+      int cross = 0;
+      if (lane < ncon) {
+        const bool la = con_A >= 0 && con_A < RPK_KEYBASE, lb = con_B >= 0 && con_B < RPK_KEYBASE;
+        if (la && lb) {
+          int deep = -1;
+          if ((con_maskA & ~con_maskB) == 0) deep = 1;       // A's chain is a prefix of B's
+          else if ((con_maskB & ~con_maskA) == 0) deep = 0;
+          if (deep < 0) cross = 1;
+          else {
+            const int sh = 1 - deep;
+            const int dsh = M.link_depth[sh ? con_B : con_A];
+            for (int e = 0; e <= dsh; e++) {
+#pragma unroll
+              for (int k = 0; k < 3; k++) sm.cJ[lane][deep][e][k] += sm.cJ[lane][sh][e][k];
+            }
+            if (sh == 0) { con_A = -1; con_maskA = 0; sm.cA[lane] = -1; }
+            else { con_B = -1; con_maskB = 0; sm.cB[lane] = -1; }
+          }
+        }
+      }
+      // anchor link of every touched key = deepest link pressing it; all other links
+      // pressing the same key must lie on the anchor's chain
+      const int mylink = (con_A >= 0 && con_A < RPK_KEYBASE) ? con_A : ((con_B >= 0 && con_B < RPK_KEYBASE) ? con_B : -1);
+      const unsigned long long mymask = con_maskA | con_maskB;
+      const int mydepthc = (lane < ncon && mylink >= 0) ? M.link_depth[mylink] : -1;
+      for (int sidx = 0; sidx < nkt; sidx++) {
+        int cand = (lane < ncon && con_slot == sidx && mylink >= 0) ? ((mydepthc << 8) | lane) : -1;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cand = max(cand, __shfl_xor(cand, off, 64));
+        int cl = cand >= 0 ? (cand & 255) : 0;
+        unsigned long long am = ((unsigned long long)(unsigned)bcast((int)(mymask >> 32), cl) << 32) |
+                                (unsigned)bcast((int)(mymask & 0xffffffffu), cl);
+        int alink = bcast(mylink, cl);
+        if (cand < 0) { am = 0; alink = -1; }
+        if (lane < ncon && con_slot == sidx && (mymask & ~am) != 0) cross = 1;
+        if (lane == 0) { sm.slotmask[sidx] = am; sm.slotlink[sidx] = alink; }
+      }
+      // a key pressed from two different chains makes all of its contacts cross contacts
+      {
+        unsigned long long badslots = 0;
+        if (cross && lane < ncon && con_slot >= 0) badslots = 1ull << con_slot;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) badslots |= __shfl_xor(badslots, off, 64);
+        if (lane < ncon && con_slot >= 0 && ((badslots >> con_slot) & 1)) cross = 1;
+      }
+      con_cross = cross;
+      {
+        unsigned long long dmk = 0;
+        if (cross) {
+          dmk = con_maskA | con_maskB;
+          if (con_slot >= 0) dmk |= 1ull << (nl + con_slot);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) dmk |= __shfl_xor(dmk, off, 64);
+        dirty_mask = dmk;
+      }
+      tree_ok = dirty_mask == 0ull;
+      WSYNC();
+      sdepth = -1;
+      if (!isl && lane < nl + nkt) {
+        int al = sm.slotlink[lane - nl];
+        if (al >= 0) {
+          sdepth = M.link_depth[al];
+#pragma unroll
+          for (int e = 0; e < RPK_MAXD; e++) sanc[e] = M.link_anc[al * RPK_MAXD + e];
+        }
+      }
+    }
+    WSYNC();
     PROF(14);
     // VELOCITY STAGE
     // ======================================================================
@@ -1407,7 +1702,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
 #pragma unroll
         for (int k = 0; k < 6; k++) { cv[k] = pv[k] + cdofr[k] * qd[0]; sm.vel[lane][k] = cv[k]; }
       }
-      __syncthreads();
+      WSYNC();
     }
     // ---- bias forces: recursive Newton-Euler with gravity as base acceleration [MJ: mj_rne]
     T ca[6] = {0, 0, 0, 0, 0, 0};
@@ -1421,12 +1716,12 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
 #pragma unroll
         for (int k = 0; k < 6; k++) ca[k] = pa[k] + cdd[k] * qd[0];
       }
-      __syncthreads();  // all reads of this level's parents (cvel or cacc) are done
+      WSYNC();  // all reads of this level's parents (cvel or cacc) are done
       if (isl && depth == d) {
 #pragma unroll
         for (int k = 0; k < 6; k++) sm.vel[lane][k] = ca[k];
       }
-      __syncthreads();
+      WSYNC();
     }
     {
       T f1[6], iv[6], f2[6], t1[3], t2[3];
@@ -1440,7 +1735,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
         for (int k = 0; k < 6; k++) sm.acc[lane][k] = f1[k] + f2[k];
       }
     }
-    __syncthreads();
+    WSYNC();
     for (int d = M.maxdepth - 1; d >= 1; d--) {
       int mr = M.level_maxrank[d];
       for (int r = 0; r < mr; r++) {
@@ -1448,7 +1743,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
 #pragma unroll
           for (int k = 0; k < 6; k++) sm.acc[parent][k] += sm.acc[lane][k];
         }
-        __syncthreads();
+        WSYNC();
       }
     }
     qbias = isl ? dot6(cdofr, sm.acc[lane]) : (T)0;
@@ -1457,7 +1752,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
     sm.vec[0][lane] = q[0]; sm.vec[1][lane] = qd[0];
     if (isk[0]) sm.keyvec[0][kid[0]] = qd[1];
     if (isk[1]) sm.keyvec[0][kid[1]] = qd[2];
-    __syncthreads();
+    WSYNC();
     if (isa) {
       alen = acoef0 * sm.vec[0][alane0] + (alane1 >= 0 ? acoef1 * sm.vec[0][alane1] : (T)0);
       avel = acoef0 * sm.vec[1][alane0] + (alane1 >= 0 ? acoef1 * sm.vec[1][alane1] : (T)0);
@@ -1508,7 +1803,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
         con_aref[0] = con_aref[1] = con_aref[2] = con_aref[3] = 0;
       }
     }
-    __syncthreads();
+    WSYNC();
 
     PROF(16);
     // ---- per-substep key activation trace (Piano._update_key_state, piano.py:178-192)
@@ -1551,7 +1846,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
     if (lane == 0) {
       S.warn[env] |= w;
       S.ncon[env] = ncon;
-      S.solver_iter[env] = niter_last;
+      S.solver_iter[env] = (niter_last & 255) | ((__popcll(dirty_mask) & 255) << 8) | ((nkt & 255) << 16);
       S.time[env] = time;
     }
   }

@@ -113,6 +113,18 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
             mask |= 1 << int(a)
             a = int(parent[a])
         ancmask[i] = (mask & 0xFFFFFFFF, (mask >> 32) & 0xFFFFFFFF)
+    # descendants of each link at each depth (<=5 per level: one per finger chain)
+    MAXDESC = 5
+    desc = np.full((nl, MAX_DEPTH, MAXDESC), -1, np.int32)
+    dcount = np.zeros((nl, MAX_DEPTH), np.int32)
+    for k in range(nl):
+        a = int(parent[k])
+        while a >= 0:
+            c = dcount[a, depth[k]]
+            assert c < MAXDESC, "more than 5 descendants of one link at one depth"
+            desc[a, depth[k], c] = k
+            dcount[a, depth[k]] += 1
+            a = int(parent[a])
     # sibling rank (for deterministic child->parent accumulation)
     sibrank = np.zeros(nl, np.int32)
     cnt = {}
@@ -159,6 +171,7 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
     t["eng_level_maxrank"] = maxrank
     t["eng_link_anc"] = anc
     t["eng_link_ancmask"] = ancmask.view(np.int32)
+    t["eng_link_desc"] = desc
     t["eng_link_lpos"] = lpos; t["eng_link_lquat"] = lquat
     t["eng_link_axis"] = axis; t["eng_link_anchor"] = anchor
     t["eng_link_mass"] = mass; t["eng_link_ipos"] = ipos; t["eng_link_inertia"] = inertia
