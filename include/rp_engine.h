@@ -46,8 +46,11 @@ typedef enum {
   RP_SOLVER_ITER = 12,  /* [E] int32  last substep: bits 0-7 Newton iterations, 8-15 rows in the
                            dense (cross-chain) block, 16-23 touched keys */
   RP_CONTACT_DIST = 13, /* [E][RP_MAX_CONTACTS] */
-  RP_TREE_OFFSET = 14   /* [E][ntree][3] per-env root-body translation (hand.shift_pose,
+  RP_TREE_OFFSET = 14,  /* [E][ntree][3] per-env root-body translation (hand.shift_pose,
                            piano_with_shadow_hands.py:491-499) */
+  RP_ACTIVE = 15        /* [E] int32, write-only: envs with 0 are skipped by rp_step/rp_forward
+                           (rp_set(RP_ACTIVE, NULL) re-enables all).  Needed because dm_env's
+                           step-after-LAST is a reset, not a physics step. */
 } rp_field;
 
 #define RP_MAX_CONTACTS 32

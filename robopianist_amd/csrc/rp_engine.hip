@@ -233,10 +233,13 @@ struct Engine : EngineBase {
     S.warn = dalloc<int>(E); S.solver_iter = dalloc<int>(E);
     S.key_trace = nullptr;
     S.prof = nullptr;
+    d_active = dalloc<int>(E);
+    S.active = nullptr;
     S.max_newton = M.iterations; S.max_ls = M.ls_iterations;
   }
 
   long long* d_prof = nullptr;
+  int* d_active = nullptr;
   int profile(long long* out, int n, int enable) override {
     HIP_OK(hipSetDevice(device));
     if (!d_prof) { d_prof = dalloc<long long>(RPK_NPROF); }
@@ -307,6 +310,7 @@ struct Engine : EngineBase {
       case RP_WARN_FLAGS: *p = S.warn; *bytes = sizeof(int) * E; *writable = true; return true;
       case RP_SOLVER_ITER: *p = S.solver_iter; *bytes = sizeof(int) * E; return true;
       case RP_CONTACT_DIST: *p = S.contact_dist; *bytes = sizeof(T) * E * RPK_NC; return true;
+      case RP_ACTIVE: *p = d_active; *bytes = sizeof(int) * E; *writable = true; return true;
       case RP_TREE_OFFSET: *p = S.tree_offset; *bytes = sizeof(T) * E * ntree * 3; *writable = true; return true;
     }
     return false;
@@ -315,9 +319,10 @@ struct Engine : EngineBase {
     void* p; size_t nb; bool w;
     if (!field(f, &p, &nb, &w)) return fail("rp_set: unknown field");
     if (!w) return fail("rp_set: field is read-only");
-    if (!src) return fail("rp_set: null source");
+    if (!src) { if (f == RP_ACTIVE) { S.active = nullptr; return 0; } return fail("rp_set: null source"); }
     HIP_OK(hipSetDevice(device));
     if (nb) HIP_OK(hipMemcpyAsync(p, src, nb, hipMemcpyDefault, stream));
+    if (f == RP_ACTIVE) S.active = d_active;
     return 0;
   }
   int get(rp_field f, void* dst) override {

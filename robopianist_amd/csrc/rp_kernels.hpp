@@ -67,6 +67,7 @@ struct RpState {
   T *qpos, *qvel, *warm, *ctrl, *qfrc_applied, *time, *tree_offset;
   T *act_force, *act_vel, *site_xpos, *contact_dist;
   int *ncon, *contact_geoms, *warn, *solver_iter;
+  const int* active;    // may be null: envs with active[e]==0 are left untouched
   uint32_t* key_trace;  // may be null
   long long* prof;      // may be null: per-phase cycle counters (env 0)
   int max_newton, max_ls;
@@ -519,6 +520,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
   using N = Num<T>;
   const int env = blockIdx.x;
   const int lane = threadIdx.x;
+  if (S.active && S.active[env] == 0) return;
   __shared__ Smem<T> sm;
   int warn = 0;
   long long prof_t = (long long)__builtin_readcyclecounter();

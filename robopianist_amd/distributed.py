@@ -1,0 +1,82 @@
+"""Multi-GPU sharding of independent environments.
+
+Envs never interact, so the data path has no collective: each rank owns a
+contiguous block of envs on its own GPU (one process per GPU, RCCL only for the
+optional trajectory gather).  `gather_trajectories` is the single collective the
+north-star names: an all-gather of the per-step trajectory slab.
+"""
+
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
+    """Initialises torch.distributed from RANK/WORLD_SIZE/LOCAL_RANK (torchrun env).
+    Returns (rank, world_size, local_rank).  No-op for world size 1."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend, **kw)
+    return rank, world, local
+
+
+def shard_envs(total_envs: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous block [start, stop) of the global env index range owned by `rank`.
+    Blocks differ by at most one env; every env has exactly one owner."""
+    if total_envs < 0 or not 0 <= rank < world_size:
+        raise ValueError("bad shard arguments")
+    base, rem = divmod(total_envs, world_size)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def rank_seed(seed: int, rank: int) -> int:
+    """Independent RNG stream per rank (seed + 1000*rank)."""
+    return int(seed) + 1000 * int(rank)
+
+
+def pack_trajectory_record(qpos, reward, discount, step_type, key_activation):
+    """Compact per-env record (§8e): qpos | reward | discount | step_type | activation
+    bits packed in three 32-bit words, as one float32 row per env."""
+    E = qpos.shape[0]
+    act = key_activation.to(torch.int64)
+    weights = (1 << torch.arange(32, device=act.device, dtype=torch.int64))
+    words = []
+    for w in range(3):
+        chunk = act[:, 32 * w: 32 * (w + 1)]
+        words.append((chunk * weights[: chunk.shape[1]]).sum(1))
+    bits = torch.stack(words, dim=1).to(torch.int32).view(torch.float32)
+    return torch.cat([qpos.float(), reward.float().reshape(E, 1), discount.float().reshape(E, 1),
+                      step_type.float().reshape(E, 1), bits], dim=1).contiguous()
+
+
+def unpack_key_activation(record: torch.Tensor, nv: int, n_keys: int = 88) -> torch.Tensor:
+    words = record[:, nv + 3: nv + 6].contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    shifts = torch.arange(32, device=record.device, dtype=torch.int64)
+    bits = ((words[:, :, None] >> shifts) & 1).reshape(record.shape[0], 96)
+    return bits[:, :n_keys].bool()
+
+
+def gather_trajectories(local: torch.Tensor) -> torch.Tensor:
+    """All-gathers equally sized per-rank slabs [E_local, ...] into [world*E_local, ...]
+    ordered by rank (== global env order under `shard_envs`)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
+                      device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    return out

@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "librp_engine.so")
 
 # rp_field
 QPOS, QVEL, QACC_WARMSTART, CTRL, QFRC_APPLIED, ACT_FORCE, ACT_VELOCITY, SITE_XPOS, \
-    TIME, NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER, CONTACT_DIST, TREE_OFFSET = range(15)
+    TIME, NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER, CONTACT_DIST, TREE_OFFSET, ACTIVE = range(16)
 MAX_CONTACTS = 32
 
 WARN_BADSTATE = 1
@@ -120,9 +120,9 @@ class BatchedPhysics:
             QFRC_APPLIED: (self.nv,), ACT_FORCE: (self.nu,), ACT_VELOCITY: (self.nu,),
             SITE_XPOS: (self.nsite, 3), TIME: (), NCON: (), CONTACT_GEOMS: (MAX_CONTACTS, 2),
             WARN_FLAGS: (), SOLVER_ITER: (), CONTACT_DIST: (MAX_CONTACTS,),
-            TREE_OFFSET: (self.ntree, 3),
+            TREE_OFFSET: (self.ntree, 3), ACTIVE: (),
         }
-        self._int_fields = {NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER}
+        self._int_fields = {NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER, ACTIVE}
 
     def __del__(self):
         try:
@@ -152,7 +152,11 @@ class BatchedPhysics:
         self._check(self._L.rp_reset(self._h, _ptr(mask)))
 
     def set(self, f, value):
-        """value: numpy array or torch tensor (host or device) of the field's shape."""
+        """value: numpy array or torch tensor (host or device) of the field's shape.
+        set(ACTIVE, None) re-enables every env."""
+        if value is None:
+            self._check(self._L.rp_set(self._h, f, None))
+            return
         if isinstance(value, np.ndarray) or not hasattr(value, "data_ptr"):
             value = np.ascontiguousarray(np.broadcast_to(
                 np.asarray(value, self.field_dtype(f)), self.field_shape(f)))

@@ -1,0 +1,125 @@
+"""Vectorised dm_env-style Environment.
+
+Reproduces the hook order of dm_control's composer.Environment.step as the
+reference relies on it (in-tree corroboration at
+piano_with_shadow_hands.py:372-376 and self_actuated_piano.py:160-167):
+
+    before_step -> n_sub x physics.step (+ after_substep) -> after_step
+    -> observation update -> reward -> discount / termination
+
+for all envs at once.  dm_env's protocol is kept per env: the first step()
+after a LAST (or before any reset) resets that env and returns FIRST without
+simulating it (the engine's RP_ACTIVE mask).
+"""
+
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from robopianist_amd.suite import specs
+from robopianist_amd.suite.specs import StepType, TimeStep
+
+
+class Environment:
+    def __init__(self, task, n_envs: int = 1, random_state=None, device_id: int = 0,
+                 precision: int = 32, physics=None, record_key_trace: bool = False):
+        self._task = task
+        self._n_envs = int(n_envs)
+        if isinstance(random_state, np.random.RandomState):
+            self._random_state = random_state
+        else:
+            self._random_state = np.random.RandomState(random_state)
+        if physics is None:
+            from robopianist_amd.suite.physics import TorchPhysics
+            physics = TorchPhysics(task.scene, self._n_envs, device_id=device_id, precision=precision)
+        self._physics = physics
+        self._n_sub_steps = task.physics_steps_per_control_step
+        task.bind(physics, self._n_envs, self._random_state)
+        self._needs_reset = torch.ones(self._n_envs, dtype=torch.bool, device=physics.device)
+        self._record_key_trace = record_key_trace
+        self._key_trace = None
+        if record_key_trace:
+            self._key_trace = torch.zeros((self._n_envs, self._n_sub_steps, 4), dtype=torch.int32,
+                                          device=physics.device)
+
+    # -- accessors ---------------------------------------------------------------
+    @property
+    def task(self):
+        return self._task
+
+    @property
+    def physics(self):
+        return self._physics
+
+    @property
+    def random_state(self):
+        return self._random_state
+
+    @property
+    def n_envs(self):
+        return self._n_envs
+
+    @property
+    def key_trace(self):
+        """[n_envs, n_substeps, 4] int32 activation bit masks of the last step."""
+        return self._key_trace
+
+    def control_timestep(self):
+        return self._task.control_timestep
+
+    def action_spec(self):
+        return self._task.action_spec(self._physics)
+
+    def observation_spec(self):
+        return self._task.observation_spec()
+
+    # -- protocol -----------------------------------------------------------------
+    def _reset_envs(self, mask: Optional[torch.Tensor]):
+        self._physics.reset(mask)
+        self._task.initialize_episode(self._physics, mask)
+        # physics.forward() after initialize_episode, as composer does
+        self._physics.forward()
+        self._physics.refresh()
+        self._task.piano._update_key_state(self._physics)
+
+    def reset(self) -> TimeStep:
+        self._physics.set_active(torch.ones(self._n_envs, dtype=torch.bool, device=self._physics.device))
+        self._reset_envs(None)
+        self._needs_reset[:] = False
+        obs = self._task.get_observation(self._physics)
+        st = torch.full((self._n_envs,), int(StepType.FIRST), dtype=torch.int32,
+                        device=self._physics.device)
+        return TimeStep(st, None, None, obs)
+
+    def step(self, action) -> TimeStep:
+        phys, task = self._physics, self._task
+        resetting = self._needs_reset.clone()
+        if bool(resetting.all()):
+            return self.reset()
+        active = ~resetting
+        if bool(resetting.any()):
+            self._reset_envs(resetting)
+        phys.set_active(active)
+        task.before_step(phys, action)
+        phys.step(self._n_sub_steps, self._key_trace)
+        phys.refresh()
+        task.after_substeps(phys)
+        task.after_step(phys, active)
+        obs = task.get_observation(phys)
+        reward = task.get_reward(phys)
+        terminate = task.should_terminate_episode(phys) & active
+        discount = task.get_discount(phys)
+        # physics divergence terminates the episode (dm_control PhysicsError semantics)
+        bad = (phys.warn & 1).bool() & active
+        terminate = terminate | bad
+        reward = torch.where(bad, torch.zeros_like(reward), reward)
+        discount = torch.where(bad, torch.zeros_like(discount), discount)
+        st = torch.where(terminate, int(StepType.LAST), int(StepType.MID)).to(torch.int32)
+        st = torch.where(resetting, torch.full_like(st, int(StepType.FIRST)), st)
+        reward = torch.where(resetting, torch.zeros_like(reward), reward)
+        discount = torch.where(resetting, torch.ones_like(discount), discount)
+        self._needs_reset = terminate
+        return TimeStep(st, reward, discount, obs)

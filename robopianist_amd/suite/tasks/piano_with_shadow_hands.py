@@ -1,0 +1,375 @@
+"""Vectorised `PianoWithShadowHands` task.
+
+Same constructor arguments, hook order, observation names, reward terms and
+termination rule as robopianist/suite/tasks/piano_with_shadow_hands.py (line
+references below), batched over n_envs.  `midi` may also be a list of MidiFiles:
+env e then plays song e % len(midi) (heterogeneous goal bank, BASELINE config #5).
+"""
+
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from robopianist_amd.music import midi_file
+from robopianist_amd.suite import composite_reward, specs
+from robopianist_amd.suite.rewards import tolerance
+from robopianist_amd.suite.tasks import base
+
+# piano_with_shadow_hands.py:35-46
+_FINGER_CLOSE_ENOUGH_TO_KEY = 0.01
+_KEY_CLOSE_ENOUGH_TO_PRESSED = 0.05
+_ENERGY_PENALTY_COEF = 5e-3
+_POSITION_OFFSET = 0.05
+
+
+class PianoWithShadowHands(base.PianoTask):
+    def __init__(
+        self,
+        midi: Union[midi_file.MidiFile, Sequence[midi_file.MidiFile]],
+        n_steps_lookahead: int = 1,
+        n_seconds_lookahead: Optional[float] = None,
+        trim_silence: bool = False,
+        wrong_press_termination: bool = False,
+        initial_buffer_time: float = 0.0,
+        disable_fingering_reward: bool = False,
+        disable_forearm_reward: bool = False,
+        disable_colorization: bool = False,
+        disable_hand_collisions: bool = False,
+        augmentations=None,
+        energy_penalty_coef: float = _ENERGY_PENALTY_COEF,
+        randomize_hand_positions: bool = False,
+        **kwargs,
+    ) -> None:
+        super().__init__(disable_hand_collisions=disable_hand_collisions, **kwargs)
+        del disable_colorization  # cosmetic (:451-474)
+        if augmentations is not None:
+            raise NotImplementedError(
+                "MIDI augmentations (robopianist/suite/variations.py) are a next-row item.")
+        midis = list(midi) if isinstance(midi, (list, tuple)) else [midi]
+        if trim_silence:
+            midis = [m.trim_silence() for m in midis]
+        self._midis = midis
+        self._midi = midis[0]
+        self._n_steps_lookahead = n_steps_lookahead
+        if n_seconds_lookahead is not None:
+            self._n_steps_lookahead = int(np.ceil(n_seconds_lookahead / self.control_timestep))
+        self._initial_buffer_time = initial_buffer_time
+        self._disable_fingering_reward = disable_fingering_reward or not all(
+            m.has_fingering() for m in midis)
+        self._disable_forearm_reward = disable_forearm_reward
+        self._wrong_press_termination = wrong_press_termination
+        self._disable_hand_collisions = disable_hand_collisions
+        self._energy_penalty_coef = energy_penalty_coef
+        self._randomize_hand_positions = randomize_hand_positions
+        self._reset_trajectory()
+        self._set_rewards()
+
+    # -- construction ------------------------------------------------------------
+    def _set_rewards(self) -> None:
+        """:130-144 (insertion order matters: CompositeReward sums in order)."""
+        self._reward_fn = composite_reward.CompositeReward(
+            key_press_reward=self._compute_key_press_reward,
+            sustain_reward=self._compute_sustain_reward,
+            energy_reward=self._compute_energy_reward,
+        )
+        if not self._disable_fingering_reward:
+            self._reward_fn.add("fingering_reward", self._compute_fingering_reward)
+        else:
+            self._reward_fn.add("ot_fingering_reward", self._compute_ot_fingering_reward)
+        if not self._disable_forearm_reward:
+            self._reward_fn.add("forearm_reward", self._compute_forearm_reward)
+
+    def _reset_trajectory(self) -> None:
+        """:159-165 — one NoteTrajectory per song; dense [song, T, .] goal bank."""
+        trajs = []
+        for m in self._midis:
+            t = midi_file.NoteTrajectory.from_midi(m, self.control_timestep)
+            t.add_initial_buffer_time(self._initial_buffer_time)
+            trajs.append(t)
+        self._trajs = trajs
+        self._notes = trajs[0].notes
+        self._sustains = trajs[0].sustains
+        tmax = max(len(t) for t in trajs)
+        ns = len(trajs)
+        goal = np.zeros((ns, tmax, 89), np.float32)
+        finger = np.full((ns, tmax, 88), -1, np.int64)
+        for s, t in enumerate(trajs):
+            g, f = t.to_goal_tables()
+            goal[s, :len(t)] = g
+            finger[s, :len(t)] = f
+        self._goal_bank_np, self._finger_bank_np = goal, finger
+        self._song_len_np = np.array([len(t) for t in trajs], np.int64)
+
+    def bind(self, physics, n_envs, random_state):
+        super().bind(physics, n_envs, random_state)
+        dev, E = physics.device, n_envs
+        self._goal_bank = torch.as_tensor(self._goal_bank_np, device=dev, dtype=self._dtype)
+        self._finger_bank = torch.as_tensor(self._finger_bank_np, device=dev)
+        self._song_len = torch.as_tensor(self._song_len_np, device=dev)
+        self._song_id = torch.arange(E, device=dev) % len(self._midis)
+        m = self.scene.model
+        self._rh_act = torch.as_tensor(self.right_hand.actuators, device=dev, dtype=torch.long)
+        self._lh_act = torch.as_tensor(self.left_hand.actuators, device=dev, dtype=torch.long)
+        self._rh_jnt = torch.as_tensor(self.right_hand.joints, device=dev, dtype=torch.long)
+        self._lh_jnt = torch.as_tensor(self.left_hand.joints, device=dev, dtype=torch.long)
+        # fingertip sites in fingering-id order: 0-4 right (th..lf), 5-9 left
+        self._tip_sites = list(self.right_hand.fingertip_sites) + list(self.left_hand.fingertip_sites)
+        # key geometry for the fingering target (:312-313)
+        kg = self.piano.key_geom_ids
+        kb = m.geom_bodyid[kg]
+        half = m.geom_size[kg]
+        self._key_anchor = torch.as_tensor(m.body_pos[kb] + m.jnt_pos[self.piano.joints],
+                                           device=dev, dtype=self._dtype)
+        self._key_half = torch.as_tensor(half, device=dev, dtype=self._dtype)
+        self._rfa = torch.as_tensor(self.right_hand.forearm_geom_ids, device=dev, dtype=torch.int32)
+        self._lfa = torch.as_tensor(self.left_hand.forearm_geom_ids, device=dev, dtype=torch.int32)
+        self._reset_quantities_at_episode_init()
+        L = self._n_steps_lookahead
+        self._goal_state = torch.zeros((E, L + 1, 89), device=dev, dtype=self._dtype)
+        self._goal_current = torch.zeros((E, 89), device=dev, dtype=self._dtype)
+        self._finger_next = torch.full((E, 88), -1, device=dev, dtype=torch.long)
+        self._finger_current = torch.full((E, 88), -1, device=dev, dtype=torch.long)
+        self._fingering_state = torch.zeros((E, 10), device=dev, dtype=self._dtype)
+        self._failure_termination = torch.zeros(E, device=dev, dtype=torch.bool)
+
+    def _reset_quantities_at_episode_init(self, mask=None) -> None:
+        """:146-149."""
+        dev, E = self._physics_device, self._E
+        if mask is None or not hasattr(self, "_t_idx"):
+            self._t_idx = torch.zeros(E, device=dev, dtype=torch.long)
+            self._should_terminate = torch.zeros(E, device=dev, dtype=torch.bool)
+            self._discount = torch.ones(E, device=dev, dtype=self._dtype)
+        else:
+            self._t_idx[mask] = 0
+            self._should_terminate[mask] = False
+            self._discount[mask] = 1.0
+
+    # -- composer-style hooks --------------------------------------------------------
+    def initialize_episode(self, physics, mask=None) -> None:
+        """:167-174 for the envs selected by `mask` (None = all)."""
+        self._reset_quantities_at_episode_init(mask)
+        self._randomize_initial_hand_positions(physics, mask)
+        self.piano.initialize_episode(physics, mask)
+
+    def before_step(self, physics, action) -> None:
+        """:176-186 — action layout [right(22), left(22), sustain]."""
+        action = torch.as_tensor(action, device=self._physics_device, dtype=self._dtype)
+        action = action.reshape(self._E, -1)
+        hands = action[:, :-1]
+        n_r = len(self.right_hand.actuators)
+        ctrl = physics.ctrl.clone()
+        ctrl[:, self._rh_act] = hands[:, :n_r]
+        ctrl[:, self._lh_act] = hands[:, n_r:]
+        physics.set_ctrl(ctrl)
+        self.piano.apply_sustain(action[:, -1])
+
+    def after_substeps(self, physics) -> None:
+        """Piano.after_substep (piano.py:154-162): only the state after the last
+        substep is observable by rewards; the per-substep trace is the engine's
+        `key_trace`."""
+        self.piano._update_key_state(physics)
+
+    def after_step(self, physics, active=None) -> None:
+        """:188-204."""
+        inc = torch.ones_like(self._t_idx) if active is None else active.to(torch.long)
+        self._t_idx = self._t_idx + inc
+        slen = self._song_len[self._song_id]
+        self._should_terminate = (self._t_idx - 1) == slen - 1
+        self._goal_current = self._goal_state[:, 0].clone()
+        self._finger_current = self._finger_next.clone()
+        off = self._goal_current[:, :-1] == 0
+        self._failure_termination = (self.piano.activation & off).any(dim=1)
+
+    def get_reward(self, physics):
+        return self._reward_fn.compute(physics)
+
+    def get_discount(self, physics=None):
+        return self._discount
+
+    def should_terminate_episode(self, physics=None):
+        """:213-220."""
+        term = self._should_terminate.clone()
+        if self._wrong_press_termination:
+            fail = self._failure_termination & ~term
+            self._discount = torch.where(fail, torch.zeros_like(self._discount), self._discount)
+            term = term | self._failure_termination
+        return term
+
+    def action_spec(self, physics=None) -> specs.BoundedArray:
+        """:226-237."""
+        hands_spec = specs.merge_specs([self.right_hand.action_spec(), self.left_hand.action_spec()])
+        sustain_spec = specs.BoundedArray((1,), hands_spec.dtype, [0.0], [1.0], name="sustain")
+        return specs.merge_specs([hands_spec, sustain_spec])
+
+    @property
+    def midi(self):
+        return self._midi
+
+    @property
+    def reward_fn(self):
+        return self._reward_fn
+
+    # -- observations ---------------------------------------------------------------------
+    def _update_goal_state(self) -> None:
+        """:371-389 — skipped for envs whose t_idx ran past the end (kept stale, as
+        the reference returns early)."""
+        slen = self._song_len[self._song_id]
+        live = self._t_idx < slen
+        L = self._n_steps_lookahead
+        steps = self._t_idx[:, None] + torch.arange(L + 1, device=self._t_idx.device)[None, :]
+        valid = steps < slen[:, None]
+        idx = torch.clamp(steps, max=self._goal_bank.shape[1] - 1)
+        g = self._goal_bank[self._song_id[:, None], idx]
+        g = torch.where(valid[..., None], g, torch.zeros_like(g))
+        self._goal_state = torch.where(live[:, None, None], g, self._goal_state)
+
+    def _update_fingering_state(self) -> None:
+        """:391-412."""
+        slen = self._song_len[self._song_id]
+        live = self._t_idx < slen
+        idx = torch.clamp(self._t_idx, max=self._finger_bank.shape[1] - 1)
+        f = self._finger_bank[self._song_id, idx]  # [E, 88], -1 = key not in goal
+        goal_now = self._goal_bank[self._song_id, idx][:, :88] > 0
+        f = torch.where(goal_now, f, torch.full_like(f, -1))
+        self._finger_next = torch.where(live[:, None], f, self._finger_next)
+        # observable [right 5, left 5]; a note without fingering (-1) counts as
+        # right-hand finger index -1 (python indexing), as in the reference (:401-412)
+        fs = torch.zeros((self._E, 10), device=f.device, dtype=self._dtype)
+        has = goal_now & live[:, None]
+        fid = torch.where(f < 0, torch.full_like(f, 4), f)
+        fs.scatter_add_(1, torch.where(has, fid, torch.zeros_like(fid)),
+                        has.to(self._dtype))
+        fs = (fs > 0).to(self._dtype)
+        self._fingering_state = torch.where(live[:, None], fs, self._fingering_state)
+
+    def get_observation(self, physics):
+        """Enabled observables (:414-449), evaluated once per control step."""
+        self._update_goal_state()
+        obs = {
+            f"{self.right_hand.name}/joints_pos": physics.qpos[:, self._rh_jnt],
+            f"{self.left_hand.name}/joints_pos": physics.qpos[:, self._lh_jnt],
+            "piano/state": self.piano.normalized_state,
+            "piano/sustain_state": self.piano.sustain_state,
+            "goal": self._goal_state.reshape(self._E, -1),
+        }
+        self._update_fingering_state()
+        if not self._disable_fingering_reward:
+            obs["fingering"] = self._fingering_state
+        return obs
+
+    def observation_spec(self):
+        L = self._n_steps_lookahead
+        d = np.float64
+        out = {
+            f"{self.right_hand.name}/joints_pos": specs.Array((len(self.right_hand.joints),), d),
+            f"{self.left_hand.name}/joints_pos": specs.Array((len(self.left_hand.joints),), d),
+            "piano/state": specs.Array((88,), d),
+            "piano/sustain_state": specs.Array((1,), d),
+            "goal": specs.Array(((L + 1) * 89,), d),
+        }
+        if not self._disable_fingering_reward:
+            out["fingering"] = specs.Array((10,), d)
+        return out
+
+    # -- rewards ------------------------------------------------------------------------------
+    def _compute_forearm_reward(self, physics):
+        """:251-259 — 0.5 unless the two forearms' geoms are in contact."""
+        cg = physics.contact_geoms  # [E, C, 2]
+        a, b = cg[..., 0], cg[..., 1]
+        in_r = lambda x: (x[..., None] == self._rfa).any(-1)
+        in_l = lambda x: (x[..., None] == self._lfa).any(-1)
+        hit = ((in_r(a) & in_l(b)) | (in_l(a) & in_r(b))).any(dim=1)
+        return torch.where(hit, 0.0, 0.5).to(self._dtype)
+
+    def _compute_sustain_reward(self, physics):
+        """:261-269."""
+        return tolerance(self._goal_current[:, -1] - self.piano.sustain_activation[:, 0].to(self._dtype),
+                         bounds=(0, _KEY_CLOSE_ENOUGH_TO_PRESSED),
+                         margin=_KEY_CLOSE_ENOUGH_TO_PRESSED * 10)
+
+    def _compute_energy_reward(self, physics):
+        """:271-277 with actuators_power = |actuatorfrc| * |actuatorvel|
+        (shadow_hand.py:407-416)."""
+        power = physics.act_force.abs() * physics.act_vel.abs()
+        rew = -self._energy_penalty_coef * (power[:, self._rh_act].sum(1) + power[:, self._lh_act].sum(1))
+        return rew
+
+    def _compute_key_press_reward(self, physics):
+        """:279-298."""
+        goal = self._goal_current[:, :-1]
+        on = goal > 0
+        actual = self.piano.state / self.piano._qpos_range[:, 1]
+        rews = tolerance(goal - actual, bounds=(0, _KEY_CLOSE_ENOUGH_TO_PRESSED),
+                         margin=_KEY_CLOSE_ENOUGH_TO_PRESSED * 10)
+        n_on = on.sum(1)
+        mean_on = (rews * on).sum(1) / torch.clamp(n_on, min=1)
+        rew = torch.where(n_on > 0, 0.5 * mean_on, torch.zeros_like(mean_on))
+        false_pos = (self.piano.activation & ~on).any(1)
+        return rew + 0.5 * (1 - false_pos.to(self._dtype))
+
+    def _key_targets(self, physics):
+        """World position the fingertip should reach for every key: key geom centre
+        + (0.35 size_x, 0, 0.5 size_z)  (:311-313)."""
+        q = physics.qpos[:, self.piano._jidx]
+        hx = self._key_half[:, 0]
+        cx = self._key_anchor[:, 0] + hx * torch.cos(q)
+        cz = self._key_anchor[:, 2] - hx * torch.sin(q)
+        cy = self._key_anchor[:, 1].expand_as(cx)
+        return torch.stack([cx + 0.35 * hx, cy, cz + 0.5 * self._key_half[:, 2]], dim=-1)
+
+    def _compute_fingering_reward(self, physics):
+        """:300-331."""
+        f = self._finger_current  # [E, 88]; finger id of each goal key or -1
+        has = self._goal_current[:, :-1] > 0
+        fid = torch.where(f < 0, torch.full_like(f, 4), f)  # -1 -> right little finger
+        tips = physics.site_xpos(self._tip_sites)  # [E, 10, 3]
+        tgt = self._key_targets(physics)  # [E, 88, 3]
+        tip_for_key = torch.gather(tips, 1, fid[..., None].expand(-1, -1, 3))
+        dist = torch.linalg.norm(tgt - tip_for_key, dim=-1)
+        rews = tolerance(dist, bounds=(0, _FINGER_CLOSE_ENOUGH_TO_KEY),
+                         margin=_FINGER_CLOSE_ENOUGH_TO_KEY * 10)
+        n = has.sum(1)
+        mean = (rews * has).sum(1) / torch.clamp(n, min=1)
+        return torch.where(n > 0, mean, torch.zeros_like(mean))
+
+    def _compute_ot_fingering_reward(self, physics):
+        """:333-369 — optimal assignment of the 10 fingertips (left first) to the keys to
+        press.  Runs scipy's Hungarian solver per env on the host."""
+        from scipy.optimize import linear_sum_assignment
+        tips = torch.cat([physics.site_xpos(list(self.left_hand.fingertip_sites)),
+                          physics.site_xpos(list(self.right_hand.fingertip_sites))], dim=1)
+        tips = tips.detach().cpu().numpy().astype(np.float64)
+        tgt = self._key_targets(physics).detach().cpu().numpy().astype(np.float64)
+        goal = (self._goal_current[:, :-1] > 0).detach().cpu().numpy()
+        out = np.ones(self._E)
+        s = np.sqrt(-2 * np.log(0.1))
+        for e in range(self._E):
+            keys = np.flatnonzero(goal[e])
+            if keys.size == 0:
+                continue
+            dist = np.linalg.norm(tips[e][:, None, :] - tgt[e][None, keys, :], axis=-1)
+            r, c = linear_sum_assignment(dist)
+            d = dist[r, c]
+            m = _FINGER_CLOSE_ENOUGH_TO_KEY
+            rew = np.where(d <= m, 1.0, np.exp(-0.5 * (((d - m) / (m * 10)) * s) ** 2))
+            out[e] = rew.mean()
+        return torch.as_tensor(out, device=self._physics_device, dtype=self._dtype)
+
+    # -- misc -------------------------------------------------------------------------------------
+    def _randomize_initial_hand_positions(self, physics, mask=None) -> None:
+        """:491-499 — one offset per env, applied to both hands along world y."""
+        if not self._randomize_hand_positions:
+            return
+        E = self._E
+        if not hasattr(self, "_tree_offset"):
+            self._tree_offset = torch.zeros((E, 2, 3), device=self._physics_device, dtype=self._dtype)
+        off = self._random_state.uniform(low=-_POSITION_OFFSET, high=_POSITION_OFFSET, size=E)
+        off = torch.as_tensor(off, device=self._physics_device, dtype=self._dtype)
+        sel = torch.ones(E, dtype=torch.bool, device=off.device) if mask is None else mask
+        # shift_pose is cumulative in the reference (it edits body_pos in place)
+        self._tree_offset[:, :, 1] = torch.where(sel[:, None], self._tree_offset[:, :, 1] + off[:, None],
+                                                 self._tree_offset[:, :, 1])
+        physics.set_tree_offset(self._tree_offset)

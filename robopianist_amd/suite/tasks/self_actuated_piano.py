@@ -1,0 +1,152 @@
+"""Vectorised `SelfActuatedPiano` (mirror of
+robopianist/suite/tasks/self_actuated_piano.py): 88 key actuators + sustain,
+activation derived from ctrl (piano.py:180-182), reward = f(activation, goal)."""
+
+from __future__ import annotations
+
+import enum
+from typing import Optional
+
+import numpy as np
+import torch
+
+from robopianist_amd.music import midi_file
+from robopianist_amd.suite import composite_reward, specs
+from robopianist_amd.suite.tasks import base
+
+_EPS = 1e-6  # self_actuated_piano.py:33
+
+
+def negative_binary_cross_entropy(predictions, targets):
+    """:38-47 (batched over the leading dim)."""
+    log_p = torch.log(predictions + _EPS)
+    log_1_minus_p = torch.log(1 - predictions + _EPS)
+    return torch.sum(targets * log_p + (1 - targets) * log_1_minus_p, dim=-1)
+
+
+def negative_l2_distance(predictions, targets):
+    """:50-57."""
+    return -torch.sqrt(torch.sum((predictions - targets) ** 2, dim=-1))
+
+
+class RewardType(enum.Enum):
+    NEGATIVE_XENT = "negative_xent"
+    NEGATIVE_L2 = "negative_l2"
+
+    def get(self):
+        if self == RewardType.NEGATIVE_XENT:
+            return negative_binary_cross_entropy
+        elif self == RewardType.NEGATIVE_L2:
+            return negative_l2_distance
+        raise ValueError(f"Invalid reward type: {self}")
+
+
+class SelfActuatedPiano(base.PianoOnlyTask):
+    def __init__(self, midi: midi_file.MidiFile, n_steps_lookahead: int = 0,
+                 trim_silence: bool = False, reward_type: RewardType = RewardType.NEGATIVE_L2,
+                 augmentations=None, **kwargs) -> None:
+        super().__init__(add_piano_actuators=True, **kwargs)
+        if augmentations is not None:
+            raise NotImplementedError("MIDI augmentations are a next-row item.")
+        if trim_silence:
+            midi = midi.trim_silence()
+        self._midi = midi
+        self._n_steps_lookahead = n_steps_lookahead
+        self._key_press_reward = reward_type.get()
+        self._reward_fn = composite_reward.CompositeReward(
+            key_press_reward=self._compute_key_press_reward)
+        note_traj = midi_file.NoteTrajectory.from_midi(self._midi, self.control_timestep)
+        self._notes, self._sustains = note_traj.notes, note_traj.sustains
+        self._goal_np, _ = note_traj.to_goal_tables()
+
+    def bind(self, physics, n_envs, random_state):
+        super().bind(physics, n_envs, random_state)
+        dev = physics.device
+        self._goal_table = torch.as_tensor(self._goal_np, device=dev, dtype=self._dtype)
+        self._T = self._goal_table.shape[0]
+        L = self._n_steps_lookahead
+        self._goal_state = torch.zeros((n_envs, L + 1, 89), device=dev, dtype=self._dtype)
+        self._goal_current = torch.zeros((n_envs, 89), device=dev, dtype=self._dtype)
+        self._aidx = torch.as_tensor(self.piano.actuators, device=dev, dtype=torch.long)
+        self._reset_quantities_at_episode_init()
+
+    def _reset_quantities_at_episode_init(self, mask=None):
+        dev, E = self._physics_device, self._E
+        if mask is None or not hasattr(self, "_t_idx"):
+            self._t_idx = torch.zeros(E, device=dev, dtype=torch.long)
+            self._should_terminate = torch.zeros(E, device=dev, dtype=torch.bool)
+        else:
+            self._t_idx[mask] = 0
+            self._should_terminate[mask] = False
+
+    def initialize_episode(self, physics, mask=None):
+        self._reset_quantities_at_episode_init(mask)
+        self.piano.initialize_episode(physics, mask)
+
+    def before_step(self, physics, action):
+        """:143-151 — Piano.apply_action: ctrl = action[:-1], sustain = action[-1]."""
+        action = torch.as_tensor(action, device=self._physics_device, dtype=self._dtype)
+        action = action.reshape(self._E, -1)
+        ctrl = physics.ctrl.clone()
+        ctrl[:, self._aidx] = action[:, :-1]
+        physics.set_ctrl(ctrl)
+        self.piano.apply_sustain(action[:, -1])
+
+    def after_substeps(self, physics):
+        self.piano._update_key_state(physics)
+
+    def after_step(self, physics, active=None):
+        inc = torch.ones_like(self._t_idx) if active is None else active.to(torch.long)
+        self._t_idx = self._t_idx + inc
+        self._should_terminate = (self._t_idx - 1) == self._T - 1
+        self._goal_current = self._goal_state[:, 0].clone()
+
+    def get_reward(self, physics):
+        return self._reward_fn.compute(physics)
+
+    def should_terminate_episode(self, physics=None):
+        return self._should_terminate.clone()
+
+    def action_spec(self, physics=None):
+        m = self.scene.model
+        cr = m.actuator_ctrlrange[self.piano.actuators]
+        keys_spec = specs.BoundedArray((88,), np.float64, cr[:, 0], cr[:, 1],
+                                       name="\t".join(m.names["actuator"][a] for a in self.piano.actuators))
+        sustain_spec = specs.BoundedArray((1,), np.float64, [0.0], [1.0], name="sustain")
+        return specs.merge_specs([keys_spec, sustain_spec])
+
+    @property
+    def midi(self):
+        return self._midi
+
+    @property
+    def reward_fn(self):
+        return self._reward_fn
+
+    def _compute_key_press_reward(self, physics):
+        """:203-208."""
+        pred = torch.cat([self.piano.activation, self.piano.sustain_activation], dim=1).to(self._dtype)
+        return self._key_press_reward(pred, self._goal_current)
+
+    def _update_goal_state(self):
+        live = self._t_idx < self._T
+        L = self._n_steps_lookahead
+        steps = self._t_idx[:, None] + torch.arange(L + 1, device=self._t_idx.device)[None, :]
+        valid = steps < self._T
+        g = self._goal_table[torch.clamp(steps, max=self._T - 1)]
+        g = torch.where(valid[..., None], g, torch.zeros_like(g))
+        self._goal_state = torch.where(live[:, None, None], g, self._goal_state)
+
+    def get_observation(self, physics):
+        self._update_goal_state()
+        return {
+            "piano/activation": self.piano.activation.to(self._dtype),
+            "piano/sustain_activation": self.piano.sustain_activation.to(self._dtype),
+            "goal": self._goal_state.reshape(self._E, -1),
+        }
+
+    def observation_spec(self):
+        L = self._n_steps_lookahead
+        return {"piano/activation": specs.Array((88,), np.float64),
+                "piano/sustain_activation": specs.Array((1,), np.float64),
+                "goal": specs.Array(((L + 1) * 89,), np.float64)}

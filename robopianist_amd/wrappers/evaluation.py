@@ -1,0 +1,74 @@
+"""MidiEvaluationWrapper: per-episode precision / recall / F1 of key presses and of the
+sustain pedal against the MIDI goal (mirror of robopianist/wrappers/evaluation.py:40-177),
+computed as batched device reductions instead of sklearn calls.
+
+Per step and env: precision/recall/F1 of activation vs the goal row of that step with
+sklearn's `average="binary", zero_division=1` convention, averaged over the episode."""
+
+from __future__ import annotations
+
+from collections import deque
+from typing import Dict
+
+import torch
+
+
+def _prf(y_true: torch.Tensor, y_pred: torch.Tensor):
+    """Binary precision/recall/F1 along the last dim, zero_division=1 (sklearn)."""
+    tp = (y_true & y_pred).sum(-1).double()
+    fp = (~y_true & y_pred).sum(-1).double()
+    fn = (y_true & ~y_pred).sum(-1).double()
+    one = torch.ones_like(tp)
+    precision = torch.where(tp + fp > 0, tp / torch.clamp(tp + fp, min=1), one)
+    recall = torch.where(tp + fn > 0, tp / torch.clamp(tp + fn, min=1), one)
+    denom = precision + recall
+    f1 = torch.where(denom > 0, 2 * precision * recall / torch.clamp(denom, min=1e-300), torch.zeros_like(tp))
+    # sklearn: if there are no positives at all (tp+fp+fn == 0) f-score is zero_division=1
+    f1 = torch.where(tp + fp + fn == 0, one, f1)
+    return precision, recall, f1
+
+
+class MidiEvaluationWrapper:
+    def __init__(self, environment, deque_size: int = 1) -> None:
+        self._environment = environment
+        E = environment.n_envs
+        dev = environment.physics.device
+        self._sums = torch.zeros((E, 6), dtype=torch.float64, device=dev)
+        self._count = torch.zeros(E, dtype=torch.float64, device=dev)
+        self._episodes = deque(maxlen=deque_size)  # tensors [n_finished, 6]
+
+    def __getattr__(self, name):
+        return getattr(self._environment, name)
+
+    def reset(self):
+        self._sums.zero_()
+        self._count.zero_()
+        return self._environment.reset()
+
+    def step(self, action):
+        task = self._environment.task
+        # goal row of the step about to be simulated = goal_state[:, 0]
+        goal = task._goal_state[:, 0].clone()
+        timestep = self._environment.step(action)
+        stepped = ~timestep.first()
+        keys_true = goal[:, :-1] > 0
+        keys_pred = task.piano.activation
+        sus_true = goal[:, -1:] > 0
+        sus_pred = task.piano.sustain_activation
+        vals = torch.stack(_prf(keys_true, keys_pred) + _prf(sus_true, sus_pred), dim=-1)
+        self._sums += vals * stepped[:, None]
+        self._count += stepped.double()
+        last = timestep.last()
+        if bool(last.any()):
+            self._episodes.append((self._sums[last] / self._count[last, None]).cpu())
+            self._sums[last] = 0
+            self._count[last] = 0
+        return timestep
+
+    def get_musical_metrics(self) -> Dict[str, float]:
+        """Mean over the last `deque_size` batches of finished episodes."""
+        if not self._episodes:
+            raise ValueError("No episode metrics available yet.")
+        allv = torch.cat(list(self._episodes), dim=0).mean(0)
+        names = ["precision", "recall", "f1", "sustain_precision", "sustain_recall", "sustain_f1"]
+        return {n: float(v) for n, v in zip(names, allv)}

@@ -1,0 +1,58 @@
+"""The C-ABI library loads and exports every symbol include/rp_engine.h declares;
+without a GPU the product path fails loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from robopianist_amd import engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "rp_engine.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rp_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_symbols() == sorted(engine.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(engine.LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(lib, name), f"{name} missing from librp_engine.so"
+
+
+def test_bad_arguments_are_rejected_without_touching_a_device():
+    L = engine.load_library()
+    h = ctypes.c_void_p()
+    assert L.rp_create(b"xxxx", 4, 1, 0, 32, ctypes.byref(h)) != 0
+    assert b"blob" in L.rp_last_error() or b"magic" in L.rp_last_error()
+    assert L.rp_create(None, 0, 1, 0, 32, ctypes.byref(h)) != 0
+    assert L.rp_create(b"xxxx", 4, 1, 0, 16, ctypes.byref(h)) != 0
+    assert b"precision" in L.rp_last_error()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_gpu_means_loud_failure(piano_only_scene):
+    with pytest.raises(engine.EngineError, match="no HIP device|HIP"):
+        engine.BatchedPhysics(piano_only_scene.model, piano_only_scene.key_joint_ids, n_envs=2)
+    from robopianist_amd.suite.physics import TorchPhysics
+    with pytest.raises(engine.EngineError):
+        TorchPhysics(piano_only_scene, 2)
+
+
+def test_key_trace_decoding():
+    import numpy as np
+    t = np.zeros((1, 2, 4), np.uint32)
+    t[0, 0, 0] = 0b101
+    t[0, 1, 2] = 1 << 3  # key 64 + 3
+    bits = engine.decode_key_trace(t)
+    assert bits.shape == (1, 2, 88)
+    assert bits[0, 0].nonzero()[0].tolist() == [0, 2]
+    assert bits[0, 1].nonzero()[0].tolist() == [67]

@@ -1,0 +1,177 @@
+"""The vectorised Environment on the real engine (GPU): ports of the reference's
+env-level tests (suite/suite_test.py:35-56, piano_with_shadow_hands_test.py:228-242,
+examples/self_actuated_piano_env.py:82-109) plus engine-vs-oracle checks at the
+env.step boundary."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _quiet():
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        yield
+
+
+def _np(x):
+    return x.detach().cpu().numpy()
+
+
+def test_suite_load_smoke_all_debug_envs():
+    """suite_test.py:35-56 with n_envs=4."""
+    from robopianist_amd import suite
+    for name in suite.DEBUG[:4]:
+        env = suite.load(name, seed=12345, n_envs=4, task_kwargs=dict(primitive_fingertip_collisions=True))
+        spec = env.action_spec()
+        assert np.isfinite(spec.minimum).all() and np.isfinite(spec.maximum).all()
+        ts = env.reset()
+        assert ts.reward is None and ts.discount is None
+        rng = np.random.RandomState(12345)
+        for _ in range(10):
+            a = rng.uniform(spec.minimum, spec.maximum, size=(4,) + spec.shape)
+            ts = env.step(a)
+            ospec = env.observation_spec()
+            for k, v in ts.observation.items():
+                assert tuple(v.shape[1:]) == ospec[k].shape
+                assert torch.isfinite(v).all()
+            assert torch.isfinite(ts.reward).all()
+        assert int(env.physics.warn.max()) == 0
+
+
+def test_unknown_environment_raises():
+    from robopianist_amd import suite
+    with pytest.raises(ValueError):
+        suite.load("RoboPianist-debug-NoSuchSong-v0")
+
+
+def test_failure_termination_with_applied_force():
+    """piano_with_shadow_hands_test.py:228-242."""
+    from robopianist_amd.suite import environment
+    from robopianist_amd.suite.tasks import piano_with_shadow_hands
+    from test_tasks_host import _get_test_midi
+    task = piano_with_shadow_hands.PianoWithShadowHands(
+        midi=_get_test_midi(0.01), control_timestep=0.01, wrong_press_termination=True,
+        primitive_fingertip_collisions=True)
+    env = environment.Environment(task, n_envs=3, precision=64)
+    env.reset()
+    f = np.zeros(task.scene.model.nv)
+    f[task.piano.joints] = 3.0
+    env.physics.set_qfrc_applied(f)
+    ts = env.step(np.zeros((3,) + env.action_spec().shape))
+    assert bool(ts.last().all())
+    np.testing.assert_array_equal(_np(ts.discount), 0.0)
+
+
+def test_env_step_matches_oracle_and_key_trace():
+    from oracle.rp_oracle import Oracle
+    from robopianist_amd import engine, music
+    from robopianist_amd.suite import environment
+    from robopianist_amd.suite.tasks import piano_with_shadow_hands
+    task = piano_with_shadow_hands.PianoWithShadowHands(
+        midi=music.load("CMajorScaleTwoHands"), gravity_compensation=True,
+        primitive_fingertip_collisions=True)
+    env = environment.Environment(task, n_envs=2, precision=64, record_key_trace=True)
+    m = task.scene.model
+    orc = Oracle(m, env.physics.engine.blob)
+    spec = env.action_spec()
+    rng = np.random.RandomState(7)
+    env.reset()
+    for step in range(12):
+        a = spec.minimum + rng.uniform(0.2, 0.9, spec.shape) * (spec.maximum - spec.minimum)
+        ts = env.step(np.tile(a, (2, 1)))
+        # same ctrl on the oracle: action layout = [right 22, left 22, sustain]
+        orc.ctrl[task.right_hand.actuators] = a[:22]
+        orc.ctrl[task.left_hand.actuators] = a[22:44]
+        acts = []
+        for _ in range(10):
+            orc.step()
+            q = np.clip(orc.qpos[:88], 0, m.jnt_range[:88, 1])
+            acts.append(np.abs(q - m.jnt_range[:88, 1]) <= 0.00872665)
+        np.testing.assert_allclose(_np(env.physics.qpos)[0], orc.qpos, atol=1e-9)
+        # sensors seen by the energy reward: force of the last substep's pre-integration
+        # state, velocity of the new state
+        np.testing.assert_allclose(_np(env.physics.act_vel)[0], orc.actuator_velocity, atol=1e-8)
+        np.testing.assert_allclose(_np(env.physics.act_force)[0], orc.actuator_force, atol=1e-7)
+        trace = engine.decode_key_trace(_np(env.key_trace).view(np.uint32))
+        np.testing.assert_array_equal(trace[0], np.array(acts))
+        np.testing.assert_array_equal(_np(task.piano.activation)[0], acts[-1])
+        # fingertip sites
+        tips = _np(env.physics.site_xpos(list(task.right_hand.fingertip_sites)))[0]
+        np.testing.assert_allclose(
+            tips, orc.site_xpos.reshape(-1, 3)[task.right_hand.fingertip_sites], atol=1e-9)
+
+
+def test_step_after_last_resets_only_finished_envs():
+    from robopianist_amd import music
+    from robopianist_amd.suite import environment
+    from robopianist_amd.suite.tasks import piano_with_shadow_hands
+    midis = [music.load("CMajorChordProgressionTwoHands"), music.load("CMajorScaleTwoHands")]
+    task = piano_with_shadow_hands.PianoWithShadowHands(midi=midis, primitive_fingertip_collisions=True)
+    env = environment.Environment(task, n_envs=2)
+    spec = env.action_spec()
+    a = np.tile(0.5 * (spec.minimum + spec.maximum), (2, 1))
+    env.reset()
+    for t in range(81):
+        ts = env.step(a)
+    assert ts.step_type.tolist() == [2, 1]
+    q_before = _np(env.physics.qpos)[1].copy()
+    ts = env.step(a)
+    assert ts.step_type.tolist() == [0, 1]
+    assert float(ts.reward[0]) == 0.0 and float(ts.discount[0]) == 1.0
+    # env 0 was reset and NOT simulated; env 1 kept going
+    assert np.abs(_np(env.physics.qpos)[0, 88:]).max() == 0.0
+    assert np.abs(_np(env.physics.qpos)[1] - q_before).max() > 0
+    assert int(task._t_idx[0]) == 0 and int(task._t_idx[1]) == 82
+
+
+def test_self_actuated_oracle_policy_is_perfect():
+    """examples/self_actuated_piano_env.py:82-109: all six musical metrics == 1."""
+    from robopianist_amd import music
+    from robopianist_amd.suite import environment
+    from robopianist_amd.suite.tasks import self_actuated_piano
+    from robopianist_amd.wrappers import MidiEvaluationWrapper
+    task = self_actuated_piano.SelfActuatedPiano(midi=music.load("TwinkleTwinkleLittleStar"),
+                                                 n_steps_lookahead=0)
+    env = MidiEvaluationWrapper(environment.Environment(task, n_envs=3))
+    spec = env.action_spec()
+    ts = env.reset()
+    while True:
+        goal = _np(ts.observation["goal"])[:, :89]
+        act = np.where(goal[:, :88] > 0, spec.maximum[:88], spec.minimum[:88])
+        ts = env.step(np.concatenate([act, goal[:, 88:]], axis=1))
+        if bool(ts.last().all()):
+            break
+    for k, v in env.get_musical_metrics().items():
+        assert v == pytest.approx(1.0), k
+
+
+def test_scripted_twinkle_replay_through_canonical_wrapper():
+    """BASELINE config #2 plumbing: notebook kwargs + CanonicalSpecWrapper + .npy replay."""
+    from robopianist_amd import suite
+    from robopianist_amd.wrappers import CanonicalSpecWrapper, MidiEvaluationWrapper
+    env = suite.load(
+        "RoboPianist-debug-TwinkleTwinkleRousseau-v0", n_envs=8,
+        task_kwargs=dict(trim_silence=True, control_timestep=0.05, gravity_compensation=True,
+                         primitive_fingertip_collisions=True, reduced_action_space=False,
+                         n_steps_lookahead=10))
+    env = MidiEvaluationWrapper(CanonicalSpecWrapper(env))
+    assert env.action_spec().minimum.min() == -1 and env.action_spec().maximum.max() == 1
+    actions = np.load("tests/golden/twinkle_twinkle_actions.npy")
+    ts = env.reset()
+    assert ts.observation["goal"].shape == (8, 11 * 89)
+    total = 0
+    for t, a in enumerate(actions):
+        ts = env.step(np.tile(a, (8, 1)))
+        total += 1
+        assert torch.isfinite(ts.reward).all()
+        if t < len(actions) - 1:
+            assert bool(ts.mid().all())
+    assert bool(ts.last().all()) and total == 158
+    assert int(env.physics.warn.max()) == 0
+    metrics = env.get_musical_metrics()
+    assert 0.0 <= metrics["f1"] <= 1.0

@@ -1,0 +1,119 @@
+"""Structural tests of the compiled scene, mirroring the reference's
+models/piano/piano_test.py:25-65 and models/hands/shadow_hand_test.py:44-124."""
+import warnings
+
+import numpy as np
+import pytest
+
+from robopianist_amd.model import compile as mc
+from robopianist_amd.model import engine_tables, piano, scene, shadow_hand, spec
+
+
+def test_piano_counts_and_order(piano_only_scene):
+    m = piano_only_scene.model
+    assert len(piano_only_scene.key_joint_ids) == 88 == piano.NUM_KEYS
+    assert list(piano_only_scene.key_joint_ids) == list(range(88))  # sorted by key id
+    # white / black alternate like a real keyboard, 52 + 36
+    blacks = [piano.is_key_black(k) for k in range(88)]
+    assert sum(blacks) == 36 and not blacks[0] and blacks[1]
+    ys = m.body_pos[piano_only_scene.key_body_ids, 1]
+    assert np.all(np.diff(ys) > 0)  # left to right
+    assert m.nu == 88 and m.nv == 88
+    # known answers derived from piano_constants.py
+    assert m.dof_M0[0] == pytest.approx(1.3017e-3, rel=1e-3)
+    assert m.dof_M0[1] == pytest.approx(1.0545e-3, rel=1e-3)
+    assert m.jnt_range[0, 1] == pytest.approx(np.arctan(0.01 / 0.15))
+    assert m.jnt_range[1, 1] == pytest.approx(np.arctan(0.008 / 0.09))
+    assert piano.PIANO_LENGTH == pytest.approx(1.221)
+    assert m.npair == 0  # keys never collide with keys or base
+
+
+def test_two_hand_scene_counts(two_hand_scene):
+    m = two_hand_scene.model
+    assert m.nq == m.nv == 140 and m.nu == 44 and m.ntendon == 8
+    for side in ("right", "left"):
+        h = two_hand_scene.hands[side]
+        assert len(h.joint_ids) == shadow_hand.NQ + 2
+        assert len(h.actuator_ids) == shadow_hand.NU + 2
+        names = [m.names["joint"][j].split("/")[-1] for j in h.joint_ids]
+        assert names[0].endswith("WRJ2")                     # shadow_hand_test.py:101-106
+        assert names[-2:] == ["forearm_tx", "forearm_ty"]
+        assert len(h.fingertip_site_ids) == 5
+        tips = [m.names["site"][s].split("/")[-1] for s in h.fingertip_site_ids]
+        assert [t[3:5] for t in tips] == ["th", "ff", "mf", "rf", "lf"]
+    # dof order: keys, right hand, left hand
+    assert m.names["joint"][88].startswith("rh_shadow_hand")
+    assert m.names["joint"][114].startswith("lh_shadow_hand")
+    # forearm_tx spans the keyboard (base.py:160-163,189-194)
+    r = two_hand_scene.hands["right"]
+    tx = r.joint_ids[-2]
+    np.testing.assert_allclose(m.jnt_range[tx], [-0.6105 - 0.15, 0.6105 - 0.15])
+    # critical damping 2 sqrt(M0 k) (shadow_hand.py:299-301)
+    assert m.dof_damping[tx] == pytest.approx(2 * np.sqrt(m.dof_M0[tx] * 300.0))
+    # position actuators: gain kp, bias -kp
+    np.testing.assert_allclose(m.actuator_biasprm[:, 1], -m.actuator_gainprm)
+
+
+def test_invalid_forearm_dof_raises():
+    with pytest.raises(ValueError):
+        shadow_hand.HandBuilder("right", forearm_dofs=("forearm_bogus",))
+
+
+@pytest.mark.parametrize("reduced", [False, True])
+@pytest.mark.parametrize("dofs", [(), ("forearm_tx",), ("forearm_tx", "forearm_ty", "forearm_roll")])
+def test_hand_variants(reduced, dofs):
+    hb = shadow_hand.HandBuilder("left", forearm_dofs=dofs, reduced_action_space=reduced)
+    assert len(hb.joint_names) == shadow_hand.NQ + len(dofs) - 3 * reduced
+    assert len(hb.actuator_names) == shadow_hand.NU + len(dofs) - 3 * reduced
+
+
+def test_disable_hand_collisions_leaves_only_hand_piano_pairs():
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        si = scene.build_scene(disable_hand_collisions=True, primitive_fingertip_collisions=True)
+    m = si.model
+    piano_geoms = set(int(g) for g in si.key_geom_ids) | {0}
+    for a, b in m.pair_geom:
+        assert (int(a) in piano_geoms) != (int(b) in piano_geoms)
+
+
+def test_palm_boxes_cannot_reach_keys(two_hand_scene):
+    """Justifies dropping box-box pairs (compile.py): within joint ranges the hands'
+    box colliders stay above the highest key surface."""
+    m = two_hand_scene.model
+    rng = np.random.default_rng(0)
+    key_top = 0.0225 + 0.0125 + 0.002
+    boxes = [g for g in range(m.ngeom) if m.geom_type[g] == spec.GEOM_BOX
+             and m.geom_bodyid[g] > 89]
+    lowest = np.inf
+    for _ in range(200):
+        q = np.zeros(m.nv)
+        for j in range(88, m.nv):
+            q[j] = rng.uniform(*m.jnt_range[j])
+        kin = mc.kinematics(m, q)
+        for g in boxes:
+            b = m.geom_bodyid[g]
+            c = kin["xpos"][b] + kin["xmat"][b] @ m.geom_pos[g]
+            lowest = min(lowest, c[2] - m.geom_rbound[g])
+    assert lowest > key_top
+
+
+def test_blob_round_trip_and_engine_tables(two_hand_scene):
+    m = two_hand_scene.model
+    t = engine_tables.build_engine_tables(m, two_hand_scene.key_joint_ids)
+    assert t["eng_nlink"][0] == 52 and t["eng_ntree"][0] == 2 and t["eng_maxdepth"][0] == 9
+    assert t["eng_npair"][0] + t["eng_nkeycap"][0] * 88 == m.npair
+    blob = mc.to_blob(m, extra=t)
+    assert blob[:4] == (0x52504D42).to_bytes(4, "little")
+    # every link's ancestors have smaller lane ids (the kernels rely on it)
+    anc = t["eng_link_anc"]
+    for i in range(52):
+        a = anc[i][anc[i] >= 0]
+        assert np.all(a <= i) and a[-1] == i
+    # descendant table is the transpose of the ancestor table
+    desc = t["eng_link_desc"]
+    for i in range(52):
+        for d in range(9):
+            for k in desc[i, d]:
+                if k >= 0:
+                    assert anc[k][t["eng_link_depth"][i]] == i and t["eng_link_depth"][k] == d

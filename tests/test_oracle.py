@@ -1,0 +1,164 @@
+"""Pins the CPU oracle (oracle/rp_oracle.c) with what IS available.
+
+PARITY UNPINNED w.r.t. MuJoCo: the reference holds no numeric physics vectors and
+MuJoCo is absent.  The anchors here are the reference's one
+physical inequality (piano_with_shadow_hands_test.py:228-242) and analytic known
+answers (SURVEY.md §8c "analytic known-answers")."""
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle.rp_oracle import Oracle
+from robopianist_amd.model import compile as mc
+from robopianist_amd.model import scene
+
+
+def _oracle(si, **overrides):
+    m = si.model
+    for k, v in overrides.items():
+        m[k] = v
+    return Oracle(m, mc.to_blob(m))
+
+
+def _fresh_two_hands(**kw):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return scene.build_scene(primitive_fingertip_collisions=True, **kw)
+
+
+def test_mass_matrix_matches_jacobian_sum(two_hand_scene):
+    o = _oracle(two_hand_scene)
+    rng = np.random.default_rng(0)
+    m = two_hand_scene.model
+    o.qpos[88:] = rng.uniform(-0.3, 0.3, 52)
+    o.forward()
+    M = mc.mass_matrix(m, mc.kinematics(m, o.qpos.copy()))
+    np.testing.assert_allclose(o.qM.reshape(m.nv, m.nv), M, atol=1e-13)
+
+
+def test_keys_rest_on_their_lower_limit(piano_only_scene):
+    """Spring preload 2*0.01745 = 0.0349 N.m beats gravity 0.0294 (white) / 0.0088
+    (black): the keys sit slightly below q=0 on the soft limit."""
+    o = _oracle(piano_only_scene)
+    o.step(400)
+    q = o.qpos.copy()
+    assert np.all(q < 0) and np.all(q > -2e-3)
+    assert np.abs(o.qvel).max() < 1e-6
+    assert o.ncon == 0 and o.nefc == 88
+
+
+def test_free_key_is_a_damped_oscillator(piano_only_scene):
+    """Isolated key away from its limits = 1-dof spring/damper/gravity; compare with a
+    fine-step integration of the scalar ODE."""
+    si = scene.build_scene(hands=(), add_piano_actuators=True)
+    m = si.model
+    o = Oracle(m, mc.to_blob(m))
+    k = 40
+    q0 = 0.03
+    o.qpos[k] = q0
+    o.forward()
+    I, kk, b = m.dof_M0[k], m.jnt_stiffness[k], m.dof_damping[k]
+    qref = m.qpos_spring[k]
+    mass = m.body_mass[si.key_body_ids[k]]
+    hx = m.geom_size[si.key_geom_ids[k], 0]
+    h = m.opt_timestep
+    # same implicit-damping Euler written out for the scalar system
+    q, v = q0, 0.0
+    for _ in range(20):
+        f = -kk * (q - qref) - b * v + mass * 9.81 * hx * np.cos(q)
+        v += h * f / (I + h * b)
+        q += h * v
+        o.step()
+        if not (0 < q < m.jnt_range[k, 1]):
+            break
+        assert o.qpos[k] == pytest.approx(q, abs=1e-12)
+
+
+def test_energy_drift_is_first_order_in_dt():
+    drift = []
+    for dt in (2e-4, 1e-4):
+        si = _fresh_two_hands()
+        m = si.model
+        m["dof_damping"][:] = 0; m["dof_frictionloss"][:] = 0; m["jnt_limited"][:] = 0
+        m["jnt_stiffness"][:] = 0; m["npair"] = 0; m["pair_geom"] = np.zeros((0, 2), np.int32)
+        m["actuator_gainprm"][:] = 0; m["actuator_biasprm"][:] = 0; m["opt_timestep"] = dt
+        o = Oracle(m, mc.to_blob(m))
+        rng = np.random.default_rng(0)
+        o.qpos[88:] = rng.uniform(-0.3, 0.3, 52)
+        o.qvel[88:] = rng.uniform(-3, 3, 52)
+        o.qvel[[88, 89, 114, 115]] *= 0.1
+        o.forward()
+
+        def energy():
+            kin = mc.kinematics(m, o.qpos.copy())
+            M = o.qM.reshape(m.nv, m.nv)
+            return 0.5 * o.qvel @ M @ o.qvel + np.sum(m.body_mass * 9.81 * kin["xipos"][:, 2])
+
+        e0 = energy()
+        o.step(int(round(0.05 / dt)))
+        drift.append(abs(energy() - e0))
+    assert drift[1] < 2e-3
+    assert drift[0] / drift[1] == pytest.approx(2.0, rel=0.05)
+
+
+def test_gravity_compensation_cancels_gravity():
+    si = _fresh_two_hands(gravity_compensation=True)
+    o = _oracle(si)
+    o.forward()
+    # hands hang still: passive gravcomp force == gravity bias on every hand dof
+    np.testing.assert_allclose(o.qfrc_passive[88:] - o.qfrc_bias[88:], 0, atol=1e-9)
+
+
+def test_solver_kkt_residual(two_hand_scene):
+    """At the solution: M qacc - qfrc_smooth - J^T f = 0 with f consistent with the
+    active set (limits/contacts push only)."""
+    o = _oracle(two_hand_scene)
+    m = two_hand_scene.model
+    rng = np.random.default_rng(3)
+    lo, hi = m.actuator_ctrlrange[:, 0], m.actuator_ctrlrange[:, 1]
+    o.ctrl[:] = lo + rng.uniform(0.2, 0.8, m.nu) * (hi - lo)
+    worst = 0.0
+    for _ in range(150):
+        o.step()
+        o.forward()
+        M = o.qM.reshape(m.nv, m.nv)
+        J = o.efc_J.reshape(-1, m.nv)
+        f = o.efc_force.copy()
+        res = M @ o.qacc - o.qfrc_smooth - J.T @ f
+        scale = max(1.0, np.abs(o.qfrc_smooth).max())
+        worst = max(worst, np.abs(res).max() / scale)
+    assert worst < 1e-6
+    assert o.ncon >= 0
+
+
+def test_three_newton_metres_press_every_key(two_hand_scene):
+    """piano_with_shadow_hands_test.py:228-242: qfrc_applied = 3 on all key joints =>
+    within one 0.01 s control step (2 substeps) a non-goal key is inside the 0.5 deg
+    activation band."""
+    o = _oracle(two_hand_scene)
+    m = two_hand_scene.model
+    o.qfrc_applied[:88] = 3.0
+    o.step(2)
+    qmax = m.jnt_range[:88, 1]
+    state = np.clip(o.qpos[:88], 0, qmax)
+    assert (np.abs(state - qmax) <= 0.00872665).all()
+
+
+def test_capsule_box_contact_geometry(two_hand_scene):
+    """A fingertip lowered onto a white key: one contact, normal along -z (capsule ->
+    box), distance = gap between capsule surface and key top."""
+    si = two_hand_scene
+    m = si.model
+    o = _oracle(si)
+    names = m.names["joint"]
+    j3 = names.index("rh_shadow_hand/rh_FFJ3")
+    o.qpos[j3] = 1.2
+    o.forward()
+    c = o.contact.reshape(-1, 16)
+    for row in c:
+        g1, g2 = int(row[13]), int(row[14])
+        assert m.geom_type[g1] <= m.geom_type[g2]
+        n = row[4:7]
+        assert np.linalg.norm(n) == pytest.approx(1.0)
+        assert row[0] < 0

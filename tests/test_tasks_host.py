@@ -1,0 +1,220 @@
+"""Host-side task logic on a CPU test double (no physics): ports of the
+reference's semantic tests — goal / fingering observables, `_goal_current` lag,
+episode length, lookahead arithmetic, observation names, action layout
+(robopianist/suite/tasks/piano_with_shadow_hands_test.py:76-226,
+self_actuated_piano_test.py:66-166)."""
+import itertools
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from fake_physics import FakePhysics
+from robopianist_amd import music
+from robopianist_amd.music import midi_file
+from robopianist_amd.music.sequence import NoteSequence
+from robopianist_amd.suite import environment
+from robopianist_amd.suite.tasks import piano_with_shadow_hands, self_actuated_piano
+
+
+def _get_test_midi(dt=0.01):
+    """piano_with_shadow_hands_test.py:28-50."""
+    seq = NoteSequence()
+    seq.notes.add(start_time=0.0, end_time=2 * dt, velocity=80,
+                  pitch=midi_file.note_name_to_midi_number("C6"), part=1)
+    seq.notes.add(start_time=2 * dt, end_time=3 * dt, velocity=80,
+                  pitch=midi_file.note_name_to_midi_number("G5"), part=0)
+    seq.total_time = 3 * dt
+    seq.tempos.add(qpm=60)
+    return midi_file.MidiFile(seq=seq)
+
+
+def _get_env(n_envs=3, control_timestep=0.01, n_steps_lookahead=0, n_seconds_lookahead=None,
+             wrong_press_termination=False, disable_fingering_reward=False, midi=None):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        task = piano_with_shadow_hands.PianoWithShadowHands(
+            midi=midi or _get_test_midi(dt=control_timestep),
+            n_steps_lookahead=n_steps_lookahead, n_seconds_lookahead=n_seconds_lookahead,
+            control_timestep=control_timestep, wrong_press_termination=wrong_press_termination,
+            change_color_on_activation=True, disable_fingering_reward=disable_fingering_reward)
+    return environment.Environment(task, n_envs=n_envs, physics=FakePhysics(task.scene, n_envs))
+
+
+@pytest.mark.parametrize("disable_fingering_reward", [True, False])
+def test_observables(disable_fingering_reward):
+    env = _get_env(disable_fingering_reward=disable_fingering_reward)
+    ts = env.reset()
+    assert ts.reward is None and ts.discount is None and bool(ts.first().all())
+    for k in ("piano/state", "piano/sustain_state", "goal",
+              "rh_shadow_hand/joints_pos", "lh_shadow_hand/joints_pos"):
+        assert k in ts.observation
+    assert ("fingering" in ts.observation) == (not disable_fingering_reward)
+    assert ts.observation["rh_shadow_hand/joints_pos"].shape == (3, 26)
+    spec = env.observation_spec()
+    for k, v in ts.observation.items():
+        assert tuple(v.shape[1:]) == spec[k].shape
+
+
+def test_action_spec_and_ctrl_write_through():
+    """piano_with_shadow_hands_test.py:96-117."""
+    env = _get_env(n_envs=2)
+    rh = env.task.right_hand.action_spec(env.physics)
+    lh = env.task.left_hand.action_spec(env.physics)
+    assert env.action_spec().shape[0] - 1 == rh.shape[0] + lh.shape[0] == 44
+    assert np.isfinite(env.action_spec().minimum).all() and np.isfinite(env.action_spec().maximum).all()
+    rng = np.random.RandomState(0)
+    ra = rng.uniform(rh.minimum, rh.maximum, size=(2, 22))
+    la = rng.uniform(lh.minimum, lh.maximum, size=(2, 22))
+    action = np.concatenate([ra, la, np.zeros((2, 1))], axis=1)
+    env.reset()
+    env.task.before_step(env.physics, action)
+    np.testing.assert_array_equal(env.physics.ctrl[:, env.task.right_hand.actuators].numpy(), ra)
+    np.testing.assert_array_equal(env.physics.ctrl[:, env.task.left_hand.actuators].numpy(), la)
+
+
+def test_termination_and_discount():
+    """:119-136 — 3-dt midi => 4 frames => LAST on the 4th step, discount 1."""
+    env = _get_env()
+    zero = np.zeros((3,) + env.action_spec().shape)
+    env.reset()
+    for _ in range(3):
+        ts = env.step(zero)
+        assert not bool(env.task.should_terminate_episode().any())
+        assert bool(ts.mid().all())
+        np.testing.assert_array_equal(env.task.get_discount().numpy(), 1.0)
+    ts = env.step(zero)
+    assert bool(ts.last().all())
+    np.testing.assert_array_equal(ts.discount.numpy(), 1.0)
+    # dm_env: the step after LAST is a reset and does not simulate
+    n = env.physics.n_steps
+    ts = env.step(zero)
+    assert bool(ts.first().all()) and env.physics.n_steps == n
+
+
+@pytest.mark.parametrize("control_timestep,n_seconds_lookahead",
+                         list(itertools.product([0.01, 0.05, 0.1], [0, 0.01, 0.1, 1])))
+def test_n_seconds_lookahead(control_timestep, n_seconds_lookahead):
+    env = _get_env(n_envs=1, control_timestep=control_timestep,
+                   n_seconds_lookahead=n_seconds_lookahead)
+    assert env.task._n_steps_lookahead == int(np.ceil(n_seconds_lookahead / control_timestep))
+
+
+@pytest.mark.parametrize("n_steps_lookahead", [0, 1, 2, 5])
+def test_goal_observable_lookahead(n_steps_lookahead):
+    """:152-192 exact goal arrays + the one-step lag of `_goal_current`."""
+    env = _get_env(control_timestep=0.01, n_steps_lookahead=n_steps_lookahead)
+    zero = np.zeros((3,) + env.action_spec().shape)
+    ts = env.reset()
+    traj = midi_file.NoteTrajectory.from_midi(_get_test_midi(0.01), dt=0.01)
+    notes, sustains = traj.notes, traj.sustains
+    assert len(notes) == 4
+    for i in range(len(notes)):
+        expected = np.zeros((n_steps_lookahead + 1, 89))
+        for j, t in enumerate(range(i, min(i + n_steps_lookahead + 1, len(notes)))):
+            expected[j, [n.key for n in notes[t]]] = 1.0
+            expected[j, -1] = sustains[t]
+        for e in range(3):
+            np.testing.assert_array_equal(ts.observation["goal"][e].numpy(), expected.ravel())
+        current = expected[0]
+        ts = env.step(zero)
+        for e in range(3):
+            np.testing.assert_array_equal(env.task._goal_current[e].numpy(), current)
+
+
+def test_fingering_observable():
+    """:194-226."""
+    env = _get_env(control_timestep=0.01)
+    zero = np.zeros((3,) + env.action_spec().shape)
+    ts = env.reset()
+    notes = midi_file.NoteTrajectory.from_midi(_get_test_midi(0.01), dt=0.01).notes
+    for i in range(len(notes)):
+        expected = np.zeros((2, 5))
+        idxs = [n.fingering for n in notes[i]]
+        expected[0, [k for k in idxs if k < 5]] = 1.0
+        expected[1, [k - 5 for k in idxs if k >= 5]] = 1.0
+        np.testing.assert_array_equal(ts.observation["fingering"][0].numpy(), expected.ravel())
+        ts = env.step(zero)
+        cur = env.task._finger_current[0].numpy()
+        assert sorted(cur[cur >= 0].tolist()) == sorted(idxs)
+
+
+def test_wrong_press_sets_discount_zero_and_terminates():
+    env = _get_env(wrong_press_termination=True)
+    zero = np.zeros((3,) + env.action_spec().shape)
+    env.reset()
+    # env 1 fully presses key 0, which is never in the goal
+    env.physics.qpos[1, env.task.piano.joints[0]] = 1.0
+    ts = env.step(zero)
+    assert ts.step_type.tolist() == [1, 2, 1]
+    np.testing.assert_array_equal(ts.discount.numpy(), [1.0, 0.0, 1.0])
+
+
+def test_rewards_as_functions_of_state():
+    env = _get_env(n_envs=2, control_timestep=0.01)
+    zero = np.zeros((2,) + env.action_spec().shape)
+    env.reset()
+    key = midi_file.note_name_to_key_number("C6")
+    qmax = env.task.piano._qpos_range[key, 1].item()
+    env.physics.qpos[1, env.task.piano.joints[key]] = qmax  # env 1 plays the right key
+    ts = env.step(zero)
+    terms = env.task.reward_fn.reward_terms
+    assert set(terms) == {"key_press_reward", "sustain_reward", "energy_reward",
+                          "fingering_reward", "forearm_reward"}
+    kp = terms["key_press_reward"].numpy()
+    assert kp[1] == pytest.approx(1.0)  # 0.5 (pressed) + 0.5 (no false positives)
+    assert 0.5 < kp[0] < 1.0            # tolerance(1 - 0) with margin 0.5 -> 0.5*0.0001.. + 0.5
+    np.testing.assert_allclose(terms["sustain_reward"].numpy(), 1.0)
+    np.testing.assert_allclose(terms["energy_reward"].numpy(), 0.0)
+    np.testing.assert_allclose(terms["forearm_reward"].numpy(), 0.5)
+    np.testing.assert_allclose(ts.reward.numpy(), sum(t.numpy() for t in terms.values()))
+    # forearm contact removes the 0.5
+    rf, lf = env.task.right_hand.forearm_geom_ids[0], env.task.left_hand.forearm_geom_ids[0]
+    env.physics.contact_geoms[0, 0] = torch.tensor([rf, lf], dtype=torch.int32)
+    np.testing.assert_allclose(env.task._compute_forearm_reward(env.physics).numpy(), [0.0, 0.5])
+
+
+def test_heterogeneous_song_bank():
+    midis = [music.load("CMajorScaleTwoHands"), music.load("CMajorChordProgressionTwoHands")]
+    env = _get_env(n_envs=4, control_timestep=0.05, midi=midis)
+    zero = np.zeros((4,) + env.action_spec().shape)
+    env.reset()
+    lens = [151, 81, 151, 81]
+    last_at = [None] * 4
+    for t in range(1, 152):
+        ts = env.step(zero)
+        for e in range(4):
+            if ts.step_type[e] == 2 and last_at[e] is None:
+                last_at[e] = t
+    assert last_at == lens
+
+
+# ------------------------------------------------------------------ self-actuated piano
+def _sa_env(n_envs=2, **kw):
+    task = self_actuated_piano.SelfActuatedPiano(midi=music.load("TwinkleTwinkleLittleStar"), **kw)
+    return environment.Environment(task, n_envs=n_envs, physics=FakePhysics(task.scene, n_envs))
+
+
+def test_self_actuated_observables_and_action_shape():
+    env = _sa_env()
+    ts = env.reset()
+    assert set(ts.observation) == {"piano/activation", "piano/sustain_activation", "goal"}
+    assert env.action_spec().shape == (89,)
+
+
+def test_self_actuated_oracle_policy_reward_is_zero():
+    """examples/self_actuated_piano_env.py:82-109: ctrl = max on goal keys -> perfect play."""
+    env = _sa_env(n_envs=2, n_steps_lookahead=0)
+    spec = env.action_spec()
+    ts = env.reset()
+    total = 0.0
+    while True:
+        goal = ts.observation["goal"][:, :89].numpy()
+        act = np.where(goal[:, :88] > 0, spec.maximum[:88], spec.minimum[:88])
+        action = np.concatenate([act, goal[:, 88:]], axis=1)
+        ts = env.step(action)
+        np.testing.assert_allclose(ts.reward.numpy(), 0.0, atol=1e-12)  # -L2 distance == 0
+        if bool(ts.last().all()):
+            break
+    assert int(env.task._t_idx[0]) == 161
