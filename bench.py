@@ -28,6 +28,18 @@ ALGO_BYTES_PER_ENV_STEP = 4352  # 1856 in + 1680 out + 712 ep
 HBM_PEAK_GBS = 8000.0
 
 
+def _pmc_traffic(E):
+    """HBM bytes per step-kernel launch from the committed rocprofv3 --pmc passes
+    (profiles/traffic_r01.json); null if not collected for
+    this env count."""
+    p = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    try:
+        d = json.load(open(p))
+        return d["bytes_per_launch"] if int(d["envs"]) == int(E) else None
+    except Exception:
+        return None
+
+
 def load_actions(m):
     a = np.load(os.path.join(ROOT, "tests", "golden", "twinkle_twinkle_actions.npy")).astype(np.float64)
     hands = a[:, :-1]
@@ -48,6 +60,7 @@ def main():
     ap.add_argument("--substeps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", type=int, default=1, help="all-gather trajectory slab when gpus>1")
+    ap.add_argument("--engine-only", action="store_true", help="time rp_step alone (no obs/reward epilogue)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -63,37 +76,56 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = local_rank if torch.cuda.is_available() else 0
 
-    from robopianist_amd import engine
-    from robopianist_amd.model import scene
+    from robopianist_amd import engine, suite
+    from robopianist_amd import distributed as rpd
+    from robopianist_amd.wrappers import CanonicalSpecWrapper
 
+    E = args.envs
+    device = torch.device("cuda", dev)
+    tdt = torch.float32 if args.precision == 32 else torch.float64
+    actions = np.load(os.path.join(ROOT, "tests", "golden", "twinkle_twinkle_actions.npy"))
+    T = actions.shape[0]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         # notebook cell 15 kwargs; capsule fingertips (no meshes available)
-        si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=True)
-    m = si.model
-    E = args.envs
-    phys = engine.BatchedPhysics(m, si.key_joint_ids, n_envs=E, device_id=dev, precision=args.precision)
-    ctrl_seq, _ = load_actions(m)
-    T = ctrl_seq.shape[0]
-    tdt = torch.float32 if args.precision == 32 else torch.float64
-    device = torch.device("cuda", dev)
+        base_env = suite.load(
+            "RoboPianist-debug-TwinkleTwinkleRousseau-v0", seed=rpd.rank_seed(12345, rank), n_envs=E,
+            device_id=dev, precision=args.precision,
+            task_kwargs=dict(trim_silence=True, control_timestep=0.05, gravity_compensation=True,
+                             primitive_fingertip_collisions=True, reduced_action_space=False,
+                             n_steps_lookahead=10))
+    env = CanonicalSpecWrapper(base_env)
+    phys = base_env.physics.engine
+    m = base_env.task.scene.model
+    assert base_env.task.physics_steps_per_control_step == args.substeps == 10
     # all envs replay the same action stream (config #2); rows pre-expanded on device
-    ctrl_dev = torch.as_tensor(ctrl_seq, dtype=tdt, device=device)
-    ctrl_buf = torch.empty((E, m.nu), dtype=tdt, device=device)
-    qpos_buf = torch.empty((E, m.nv), dtype=tdt, device=device)
-    gathered = torch.empty((world * E, m.nv), dtype=tdt, device=device) if world > 1 else None
+    act_dev = torch.as_tensor(actions, dtype=tdt, device=device)
+    state = {"t": 0}
 
-    def one_step(t):
-        ctrl_buf.copy_(ctrl_dev[t % T].expand(E, -1))
-        torch.cuda.current_stream().synchronize()  # ctrl_buf ready before the engine stream reads it
-        phys.set(engine.CTRL, ctrl_buf)
-        phys.step(args.substeps)
-        if (t + 1) % T == 0:
-            phys.sync()
-            phys.reset()
-        if world > 1 and args.gather:
-            phys.get(engine.QPOS, qpos_buf)  # D2D on the engine stream, synchronises
-            dist.all_gather_into_tensor(gathered, qpos_buf)
+    def one_step(_):
+        t = state["t"]
+        if args.engine_only:
+            lo = torch.as_tensor(m.actuator_ctrlrange[:, 0], dtype=tdt, device=device)
+            hi = torch.as_tensor(m.actuator_ctrlrange[:, 1], dtype=tdt, device=device)
+            c = lo + (act_dev[t, :-1] + 1) * 0.5 * (hi - lo)
+            base_env.physics.set_ctrl(c.expand(E, -1))
+            phys.step(args.substeps)
+            ts_last = (t + 1 == T)
+        else:
+            ts = env.step(act_dev[t].expand(E, -1))
+            ts_last = (t + 1 == T)
+            if world > 1 and args.gather:
+                rec = rpd.pack_trajectory_record(
+                    base_env.physics.qpos, ts.reward, ts.discount, ts.step_type,
+                    base_env.task.piano.activation)
+                rpd.gather_trajectories(rec)
+        state["t"] = t + 1
+        if ts_last:  # episode boundary: reset (not counted as a step, but timed)
+            if args.engine_only:
+                phys.sync(); phys.reset()
+            else:
+                env.reset()
+            state["t"] = 0
 
     def barrier():
         phys.sync()
@@ -102,6 +134,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    env.reset()
     for t in range(args.warmup):
         one_step(t)
     barrier()
@@ -119,6 +152,7 @@ def main():
     warn = int(phys.warn_flags.max())
     q = phys.qpos
     finite = bool(np.isfinite(q).all())
+    ctrl_seq, _ = load_actions(m)
 
     if rank == 0:
         value = world * E * args.steps / dt
@@ -137,14 +171,14 @@ def main():
             "dtype": "f32" if args.precision == 32 else "f64",
             "data": "synthetic (scripted twinkle_twinkle_actions.npy replay on the stand-in hand model)",
             "config": {
-                "workload": "PianoWithShadowHands-TwinkleTwinkle scripted replay (BASELINE configs[1]), engine-level rp_step",
+                "workload": "PianoWithShadowHands-TwinkleTwinkle scripted replay (BASELINE configs[1]), " + ("engine-level rp_step only" if args.engine_only else "full vectorised env.step (obs + rewards)"),
                 "envs_per_gpu": E, "substeps_per_step": args.substeps, "nv": int(m.nv), "nu": int(m.nu),
                 "fingertips": "capsule (primitive) stand-in", "mj_steps_per_s": value * args.substeps,
                 "trajectory_gather": bool(world > 1 and args.gather),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(E),
                 "kernel": "rp_step_kernel", "kernel_avg_ms": kms, "kernel_launches": nl,
                 "note": "path is latency/VALU bound by construction (BASELINE.md §2.3); HBM fraction reported as the north-star asks",
             },

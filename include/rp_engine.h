@@ -15,7 +15,8 @@
  *   - Physics divergence is not an error; it sets per-env RP_WARN_* bits
  *     (mirrors mj_checkPos/Vel -> dm_control PhysicsError).
  *   - Calls are asynchronous on the engine's HIP stream; rp_get() to host
- *     memory and rp_sync() synchronise.  One host thread per engine.
+ *     memory and rp_sync() synchronise (rp_get to device memory does not).
+ *     One host thread per engine.
  */
 #ifndef RP_ENGINE_H
 #define RP_ENGINE_H
@@ -71,7 +72,7 @@ int rp_destroy(rp_engine* e);
 
 /* physics.reset(): qpos<-qpos0, qvel<-0, ctrl<-0, warmstart<-0, qfrc_applied<-0,
  * time<-0 for envs with mask[e]!=0 (mask==NULL: all).  mask is a host or
- * device uint8 array. */
+ * device uint8 array; a device mask keeps the call fully asynchronous. */
 int rp_reset(rp_engine* e, const uint8_t* mask);
 
 /* Generic field write/read (RP_QPOS, RP_QVEL, RP_QACC_WARMSTART, RP_CTRL,
@@ -95,6 +96,13 @@ int rp_set_solver_limits(rp_engine* e, int max_newton_iter, int max_ls_iter);
 
 int rp_sync(rp_engine* e);
 int rp_get_stream(rp_engine* e, void** hip_stream);
+/* Makes the engine enqueue on a caller-owned HIP stream (e.g. PyTorch's current stream),
+ * so engine kernels and the caller's own kernels are ordered without host syncs. */
+int rp_set_stream(rp_engine* e, void* hip_stream);
+/* Device address and size of a field's backing array (zero-copy views: the
+ * `physics.bind(...)` arrays of the reference become tensors aliasing engine memory).
+ * Accesses must be ordered on the engine's stream. */
+int rp_field_ptr(rp_engine* e, rp_field f, void** ptr, size_t* bytes);
 int rp_n_envs(const rp_engine* e);
 int rp_dim(const rp_engine* e, const char* name); /* "nv","nu","nsite","ntree","nkey","nlink" */
 /* Average device time (ms) of the step kernel since the last call, measured

@@ -90,6 +90,8 @@ struct EngineBase {
   virtual int get(rp_field f, void* dst) = 0;
   virtual int step(int nsub, uint32_t* trace, int mode) = 0;
   virtual void limits(int newton, int ls) = 0;
+  virtual int field_ptr(rp_field f, void** p, size_t* bytes) = 0;
+  bool own_stream = true;
   virtual int profile(long long* out, int n, int enable) = 0;
 };
 
@@ -99,6 +101,7 @@ struct Engine : EngineBase {
   RpState<T> S{};
   std::vector<void*> allocs;
   std::vector<T> qpos0;
+  T* d_qpos0 = nullptr;
   uint32_t* d_trace = nullptr; size_t trace_cap = 0;
   uint8_t* d_mask = nullptr;
 
@@ -108,7 +111,7 @@ struct Engine : EngineBase {
     if (d_trace) hipFree(d_trace);
     if (d_mask) hipFree(d_mask);
     for (int i = 0; i < kRing; i++) { if (ev0[i]) hipEventDestroy(ev0[i]); if (ev1[i]) hipEventDestroy(ev1[i]); }
-    if (stream) hipStreamDestroy(stream);
+    if (stream && own_stream) hipStreamDestroy(stream);
   }
   template <typename U> U* dalloc(size_t n) {
     void* p = nullptr;
@@ -220,6 +223,7 @@ struct Engine : EngineBase {
     {
       auto q0 = b.f("qpos0");
       qpos0.assign(q0.begin(), q0.end());
+      d_qpos0 = const_cast<T*>(upF(q0));
     }
     size_t E = (size_t)nenv;
     S.nenv = nenv;
@@ -260,35 +264,22 @@ struct Engine : EngineBase {
 
   int reset(const uint8_t* mask) override {
     HIP_OK(hipSetDevice(device));
-    std::vector<uint8_t> hm((size_t)nenv, 1);
-    if (mask) HIP_OK(hipMemcpy(hm.data(), mask, nenv, hipMemcpyDefault));
-    bool all = true;
-    for (auto v : hm) if (!v) all = false;
-    size_t E = (size_t)nenv;
-    if (all) {
-      std::vector<T> q(E * nv);
-      for (size_t e = 0; e < E; e++) memcpy(&q[e * nv], qpos0.data(), sizeof(T) * nv);
-      HIP_OK(hipMemcpyAsync(S.qpos, q.data(), sizeof(T) * E * nv, hipMemcpyHostToDevice, stream));
-      HIP_OK(hipMemsetAsync(S.qvel, 0, sizeof(T) * E * nv, stream));
-      HIP_OK(hipMemsetAsync(S.warm, 0, sizeof(T) * E * nv, stream));
-      HIP_OK(hipMemsetAsync(S.ctrl, 0, sizeof(T) * E * nu, stream));
-      HIP_OK(hipMemsetAsync(S.qfrc_applied, 0, sizeof(T) * E * nv, stream));
-      HIP_OK(hipMemsetAsync(S.time, 0, sizeof(T) * E, stream));
-      HIP_OK(hipMemsetAsync(S.warn, 0, sizeof(int) * E, stream));
-      HIP_OK(hipStreamSynchronize(stream));
-    } else {
-      for (size_t e = 0; e < E; e++) {
-        if (!hm[e]) continue;
-        HIP_OK(hipMemcpyAsync(S.qpos + e * nv, qpos0.data(), sizeof(T) * nv, hipMemcpyHostToDevice, stream));
-        HIP_OK(hipMemsetAsync(S.qvel + e * nv, 0, sizeof(T) * nv, stream));
-        HIP_OK(hipMemsetAsync(S.warm + e * nv, 0, sizeof(T) * nv, stream));
-        HIP_OK(hipMemsetAsync(S.ctrl + e * nu, 0, sizeof(T) * nu, stream));
-        HIP_OK(hipMemsetAsync(S.qfrc_applied + e * nv, 0, sizeof(T) * nv, stream));
-        HIP_OK(hipMemsetAsync(S.time + e, 0, sizeof(T), stream));
-        HIP_OK(hipMemsetAsync(S.warn + e, 0, sizeof(int), stream));
+    const unsigned char* dmask = nullptr;
+    if (mask) {
+      hipPointerAttribute_t attr;
+      bool on_device = hipPointerGetAttributes(&attr, mask) == hipSuccess &&
+                       attr.type == hipMemoryTypeDevice;
+      (void)hipGetLastError();
+      if (on_device) dmask = mask;
+      else {
+        if (!d_mask) HIP_OK(hipMalloc((void**)&d_mask, (size_t)nenv));
+        HIP_OK(hipMemcpyAsync(d_mask, mask, (size_t)nenv, hipMemcpyHostToDevice, stream));
+        HIP_OK(hipStreamSynchronize(stream));  // host source may go away
+        dmask = d_mask;
       }
-      HIP_OK(hipStreamSynchronize(stream));
     }
+    hipLaunchKernelGGL(rp_reset_kernel<T>, dim3(nenv), dim3(64), 0, stream, S, d_qpos0, dmask, nv, nu);
+    HIP_OK(hipGetLastError());
     return 0;
   }
 
@@ -315,6 +306,12 @@ struct Engine : EngineBase {
     }
     return false;
   }
+  int field_ptr(rp_field f, void** p, size_t* bytes) override {
+    bool w;
+    if (!field(f, p, bytes, &w)) return fail("rp_field_ptr: unknown field");
+    if (f == RP_ACTIVE) S.active = d_active;  // a caller that maps the mask uses it
+    return 0;
+  }
   int set(rp_field f, const void* src) override {
     void* p; size_t nb; bool w;
     if (!field(f, &p, &nb, &w)) return fail("rp_set: unknown field");
@@ -331,7 +328,10 @@ struct Engine : EngineBase {
     if (!dst) return fail("rp_get: null destination");
     HIP_OK(hipSetDevice(device));
     if (nb) HIP_OK(hipMemcpyAsync(dst, p, nb, hipMemcpyDefault, stream));
-    HIP_OK(hipStreamSynchronize(stream));
+    hipPointerAttribute_t attr;
+    bool on_device = hipPointerGetAttributes(&attr, dst) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();
+    if (!on_device) HIP_OK(hipStreamSynchronize(stream));  // device destinations stay stream-ordered
     return 0;
   }
   int step(int nsub, uint32_t* trace, int mode) override {
@@ -428,6 +428,21 @@ int rp_sync(rp_engine* e) {
   HIP_OK(hipSetDevice(E(e)->device));
   HIP_OK(hipStreamSynchronize(E(e)->stream));
   return 0;
+}
+int rp_set_stream(rp_engine* e, void* hip_stream) {
+  if (!e) return fail("null engine");
+  EngineBase* b = E(e);
+  HIP_OK(hipSetDevice(b->device));
+  HIP_OK(hipStreamSynchronize(b->stream));
+  for (int i = 0; i < EngineBase::kRing; i++) b->harvest(i, true);
+  if (b->own_stream && b->stream) HIP_OK(hipStreamDestroy(b->stream));
+  b->stream = (hipStream_t)hip_stream;
+  b->own_stream = false;
+  return 0;
+}
+int rp_field_ptr(rp_engine* e, rp_field f, void** ptr, size_t* bytes) {
+  if (!e || !ptr || !bytes) return fail("null argument");
+  return E(e)->field_ptr(f, ptr, bytes);
 }
 int rp_get_stream(rp_engine* e, void** hip_stream) {
   if (!e || !hip_stream) return fail("null argument");

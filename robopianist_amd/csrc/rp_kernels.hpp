@@ -510,6 +510,21 @@ __device__ T symv_packed(const T* M, int n, int lane, T x) {
 
 }  // namespace rpk
 
+// physics.reset() for the envs selected by a device-side mask (null = all).
+template <typename T>
+__global__ void rp_reset_kernel(RpState<T> S, const T* qpos0, const unsigned char* mask, int nv, int nu) {
+  const int env = blockIdx.x;
+  if (mask && !mask[env]) return;
+  for (int i = threadIdx.x; i < nv; i += blockDim.x) {
+    S.qpos[(size_t)env * nv + i] = qpos0[i];
+    S.qvel[(size_t)env * nv + i] = 0;
+    S.warm[(size_t)env * nv + i] = 0;
+    S.qfrc_applied[(size_t)env * nv + i] = 0;
+  }
+  for (int i = threadIdx.x; i < nu; i += blockDim.x) S.ctrl[(size_t)env * nu + i] = 0;
+  if (threadIdx.x == 0) { S.time[env] = 0; S.warn[env] = 0; }
+}
+
 // ============================================================================
 // The step kernel.  mode 0: n_sub x (acceleration stage, Euler, position/velocity
 // stage).  mode 1: position/velocity stage only (physics.forward()).

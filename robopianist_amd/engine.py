@@ -34,7 +34,8 @@ WARN_WORK_FULL = 16
 
 EXPORTED_SYMBOLS = (
     "rp_create", "rp_destroy", "rp_reset", "rp_set", "rp_get", "rp_step", "rp_forward",
-    "rp_set_solver_limits", "rp_sync", "rp_get_stream", "rp_n_envs", "rp_dim",
+    "rp_set_solver_limits", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
+    "rp_n_envs", "rp_dim",
     "rp_kernel_time", "rp_profile", "rp_last_error",
 )
 
@@ -74,6 +75,9 @@ def load_library(path: str = LIB_PATH):
     L.rp_kernel_time.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                  ctypes.POINTER(ctypes.c_int)]
     L.rp_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    L.rp_set_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.rp_field_ptr.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                               ctypes.POINTER(ctypes.c_size_t)]
     _lib = L
     return L
 
@@ -105,6 +109,7 @@ class BatchedPhysics:
         self._L = load_library()
         self.model = model
         self.n_envs = int(n_envs)
+        self.device_id = int(device_id)
         self.precision = int(precision)
         self.dtype = np.float32 if precision == 32 else np.float64
         self.blob = blob if blob is not None else make_blob(model, key_joint_ids)
@@ -146,10 +151,36 @@ class BatchedPhysics:
         return np.int32 if f in self._int_fields else self.dtype
 
     def reset(self, mask=None):
-        if mask is not None:
+        """mask: None, a numpy uint8/bool array, or a torch uint8 tensor (device masks keep
+        the call asynchronous)."""
+        if mask is not None and isinstance(mask, np.ndarray):
             mask = np.ascontiguousarray(mask, np.uint8)
             assert mask.shape == (self.n_envs,)
         self._check(self._L.rp_reset(self._h, _ptr(mask)))
+
+    def set_stream(self, hip_stream: int):
+        self._check(self._L.rp_set_stream(self._h, ctypes.c_void_p(hip_stream)))
+
+    def view(self, f):
+        """Zero-copy torch tensor aliasing the engine's array for field `f`."""
+        import torch
+        p = ctypes.c_void_p(); nb = ctypes.c_size_t()
+        self._check(self._L.rp_field_ptr(self._h, f, ctypes.byref(p), ctypes.byref(nb)))
+        shape = self.field_shape(f)
+        dt = self.field_dtype(f)
+
+        class _Mem:
+            pass
+        mem = _Mem()
+        mem.__cuda_array_interface__ = {
+            "shape": shape, "typestr": np.dtype(dt).str, "data": (p.value or 0, False),
+            "version": 2, "strides": None,
+        }
+        if int(np.prod(shape)) == 0:
+            return torch.zeros(shape, dtype=getattr(torch, np.dtype(dt).name), device="cuda")
+        t = torch.as_tensor(mem, device=torch.device("cuda", self.device_id))
+        t._rp_owner = self  # keep the engine alive as long as the view
+        return t
 
     def set(self, f, value):
         """value: numpy array or torch tensor (host or device) of the field's shape.

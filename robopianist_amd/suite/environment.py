@@ -77,35 +77,35 @@ class Environment:
         return self._task.observation_spec()
 
     # -- protocol -----------------------------------------------------------------
-    def _reset_envs(self, mask: Optional[torch.Tensor]):
-        self._physics.reset(mask)
-        self._task.initialize_episode(self._physics, mask)
-        # physics.forward() after initialize_episode, as composer does
-        self._physics.forward()
-        self._physics.refresh()
-        self._task.piano._update_key_state(self._physics)
-
     def reset(self) -> TimeStep:
-        self._physics.set_active(torch.ones(self._n_envs, dtype=torch.bool, device=self._physics.device))
-        self._reset_envs(None)
-        self._needs_reset[:] = False
+        phys = self._physics
+        phys.set_active(torch.ones(self._n_envs, dtype=torch.bool, device=phys.device))
+        phys.reset(None)
+        self._task.initialize_episode(phys, None)
+        phys.forward()  # physics.forward() after initialize_episode, as composer does
+        self._task.piano._update_key_state(phys)
+        self._needs_reset = torch.zeros(self._n_envs, dtype=torch.bool, device=phys.device)
         obs = self._task.get_observation(self._physics)
         st = torch.full((self._n_envs,), int(StepType.FIRST), dtype=torch.int32,
                         device=self._physics.device)
         return TimeStep(st, None, None, obs)
 
     def step(self, action) -> TimeStep:
+        """Fully asynchronous for n_envs > 1: resets are applied through device-side
+        masks, nothing is read back to the host."""
         phys, task = self._physics, self._task
-        resetting = self._needs_reset.clone()
-        if bool(resetting.all()):
-            return self.reset()
+        resetting = self._needs_reset
+        if self._n_envs == 1 and bool(resetting.all()):
+            return self.reset()  # dm_env: step after LAST == reset (reward None)
         active = ~resetting
-        if bool(resetting.any()):
-            self._reset_envs(resetting)
+        # envs that finished (or were never reset) start a new episode and are not simulated
+        phys.reset(resetting)
+        task.initialize_episode(phys, resetting)
+        phys.set_active(resetting)
+        phys.forward()
         phys.set_active(active)
         task.before_step(phys, action)
         phys.step(self._n_sub_steps, self._key_trace)
-        phys.refresh()
         task.after_substeps(phys)
         task.after_step(phys, active)
         obs = task.get_observation(phys)

@@ -35,7 +35,10 @@ class MidiEvaluationWrapper:
         dev = environment.physics.device
         self._sums = torch.zeros((E, 6), dtype=torch.float64, device=dev)
         self._count = torch.zeros(E, dtype=torch.float64, device=dev)
-        self._episodes = deque(maxlen=deque_size)  # tensors [n_finished, 6]
+        # per env: ring of the last `deque_size` finished episodes (device side, no syncs)
+        self._hist = torch.zeros((E, deque_size, 6), dtype=torch.float64, device=dev)
+        self._n_finished = torch.zeros(E, dtype=torch.long, device=dev)
+        self._deque_size = deque_size
 
     def __getattr__(self, name):
         return getattr(self._environment, name)
@@ -59,16 +62,22 @@ class MidiEvaluationWrapper:
         self._sums += vals * stepped[:, None]
         self._count += stepped.double()
         last = timestep.last()
-        if bool(last.any()):
-            self._episodes.append((self._sums[last] / self._count[last, None]).cpu())
-            self._sums[last] = 0
-            self._count[last] = 0
+        mean = self._sums / torch.clamp(self._count, min=1)[:, None]
+        slot = (self._n_finished % self._deque_size)
+        cur = self._hist[torch.arange(self._hist.shape[0], device=slot.device), slot]
+        self._hist[torch.arange(self._hist.shape[0], device=slot.device), slot] = torch.where(
+            last[:, None], mean, cur)
+        self._n_finished += last.long()
+        self._sums = torch.where(last[:, None], torch.zeros_like(self._sums), self._sums)
+        self._count = torch.where(last, torch.zeros_like(self._count), self._count)
         return timestep
 
     def get_musical_metrics(self) -> Dict[str, float]:
-        """Mean over the last `deque_size` batches of finished episodes."""
-        if not self._episodes:
+        """Mean over the last `deque_size` finished episodes of every env."""
+        n = torch.clamp(self._n_finished, max=self._deque_size)
+        if int(n.sum()) == 0:
             raise ValueError("No episode metrics available yet.")
-        allv = torch.cat(list(self._episodes), dim=0).mean(0)
+        valid = torch.arange(self._deque_size, device=n.device)[None, :] < n[:, None]
+        allv = (self._hist * valid[..., None]).sum((0, 1)) / valid.sum()
         names = ["precision", "recall", "f1", "sustain_precision", "sustain_recall", "sustain_f1"]
-        return {n: float(v) for n, v in zip(names, allv)}
+        return {k: float(v) for k, v in zip(names, allv)}

@@ -47,7 +47,7 @@ class FakePhysics:
         return self._sites[:, [int(i) for i in ids], :]
 
     def reset(self, mask=None):
-        sel = slice(None) if mask is None else mask
+        sel = slice(None) if mask is None else mask.bool()
         self.qpos[sel] = 0
         self.qvel[sel] = 0
         self._ctrl[sel] = 0

@@ -87,10 +87,11 @@ def test_termination_and_discount():
     ts = env.step(zero)
     assert bool(ts.last().all())
     np.testing.assert_array_equal(ts.discount.numpy(), 1.0)
-    # dm_env: the step after LAST is a reset and does not simulate
-    n = env.physics.n_steps
+    # dm_env: the step after LAST is a reset and does not simulate those envs
     ts = env.step(zero)
-    assert bool(ts.first().all()) and env.physics.n_steps == n
+    assert bool(ts.first().all())
+    assert not bool(env.physics.active.any())       # every env was masked out of the kernel
+    np.testing.assert_array_equal(env.physics.time.numpy(), 0.0)
 
 
 @pytest.mark.parametrize("control_timestep,n_seconds_lookahead",
