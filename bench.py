@@ -28,6 +28,22 @@ ALGO_BYTES_PER_ENV_STEP = 4352  # 1856 in + 1680 out + 712 ep
 HBM_PEAK_GBS = 8000.0
 
 
+def _usable_cores():
+    """Host cores this process may actually use: the cgroup CPU quota if there is one
+    (the GPU boxes expose 256 logical CPUs but cap the container), else the affinity mask."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def _pmc_traffic(E):
     """HBM bytes per step-kernel launch from the committed rocprofv3 --pmc passes
     (profiles/traffic_r01.json); null if not collected for
@@ -56,7 +72,9 @@ def main():
     ap.add_argument("--steps", type=int, default=158)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
-    ap.add_argument("--precision", type=int, default=32, choices=(32, 64))
+    ap.add_argument("--precision", type=int, default=64, choices=(32, 64),
+                    help="64 (default) is the precision that meets the 1e-4 parity bar on this replay")
+    ap.add_argument("--aux-fp32", type=int, default=1, help="also time the fp32 engine (reported under aux)")
     ap.add_argument("--substeps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", type=int, default=1, help="all-gather trajectory slab when gpus>1")
@@ -76,83 +94,90 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = local_rank if torch.cuda.is_available() else 0
 
-    from robopianist_amd import engine, suite
-    from robopianist_amd import distributed as rpd
-    from robopianist_amd.wrappers import CanonicalSpecWrapper
+    def measure(precision, steps, warmup):
+        from robopianist_amd import engine, suite
+        from robopianist_amd import distributed as rpd
+        from robopianist_amd.wrappers import CanonicalSpecWrapper
 
-    E = args.envs
-    device = torch.device("cuda", dev)
-    tdt = torch.float32 if args.precision == 32 else torch.float64
-    actions = np.load(os.path.join(ROOT, "tests", "golden", "twinkle_twinkle_actions.npy"))
-    T = actions.shape[0]
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        # notebook cell 15 kwargs; capsule fingertips (no meshes available)
-        base_env = suite.load(
-            "RoboPianist-debug-TwinkleTwinkleRousseau-v0", seed=rpd.rank_seed(12345, rank), n_envs=E,
-            device_id=dev, precision=args.precision,
-            task_kwargs=dict(trim_silence=True, control_timestep=0.05, gravity_compensation=True,
-                             primitive_fingertip_collisions=True, reduced_action_space=False,
-                             n_steps_lookahead=10))
-    env = CanonicalSpecWrapper(base_env)
-    phys = base_env.physics.engine
-    m = base_env.task.scene.model
-    assert base_env.task.physics_steps_per_control_step == args.substeps == 10
-    # all envs replay the same action stream (config #2); rows pre-expanded on device
-    act_dev = torch.as_tensor(actions, dtype=tdt, device=device)
-    state = {"t": 0}
+        E = args.envs
+        device = torch.device("cuda", dev)
+        tdt = torch.float32 if precision == 32 else torch.float64
+        actions = np.load(os.path.join(ROOT, "tests", "golden", "twinkle_twinkle_actions.npy"))
+        T = actions.shape[0]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            # notebook cell 15 kwargs; capsule fingertips (no meshes available)
+            base_env = suite.load(
+                "RoboPianist-debug-TwinkleTwinkleRousseau-v0", seed=rpd.rank_seed(12345, rank), n_envs=E,
+                device_id=dev, precision=precision,
+                task_kwargs=dict(trim_silence=True, control_timestep=0.05, gravity_compensation=True,
+                                 primitive_fingertip_collisions=True, reduced_action_space=False,
+                                 n_steps_lookahead=10))
+        env = CanonicalSpecWrapper(base_env)
+        phys = base_env.physics.engine
+        m = base_env.task.scene.model
+        assert base_env.task.physics_steps_per_control_step == args.substeps == 10
+        # all envs replay the same action stream (config #2); rows pre-expanded on device
+        act_dev = torch.as_tensor(actions, dtype=tdt, device=device)
+        state = {"t": 0}
 
-    def one_step(_):
-        t = state["t"]
-        if args.engine_only:
-            lo = torch.as_tensor(m.actuator_ctrlrange[:, 0], dtype=tdt, device=device)
-            hi = torch.as_tensor(m.actuator_ctrlrange[:, 1], dtype=tdt, device=device)
-            c = lo + (act_dev[t, :-1] + 1) * 0.5 * (hi - lo)
-            base_env.physics.set_ctrl(c.expand(E, -1))
-            phys.step(args.substeps)
-            ts_last = (t + 1 == T)
-        else:
-            ts = env.step(act_dev[t].expand(E, -1))
-            ts_last = (t + 1 == T)
-            if world > 1 and args.gather:
-                rec = rpd.pack_trajectory_record(
-                    base_env.physics.qpos, ts.reward, ts.discount, ts.step_type,
-                    base_env.task.piano.activation)
-                rpd.gather_trajectories(rec)
-        state["t"] = t + 1
-        if ts_last:  # episode boundary: reset (not counted as a step, but timed)
+        def one_step(_):
+            t = state["t"]
             if args.engine_only:
-                phys.sync(); phys.reset()
+                lo = torch.as_tensor(m.actuator_ctrlrange[:, 0], dtype=tdt, device=device)
+                hi = torch.as_tensor(m.actuator_ctrlrange[:, 1], dtype=tdt, device=device)
+                c = lo + (act_dev[t, :-1] + 1) * 0.5 * (hi - lo)
+                base_env.physics.set_ctrl(c.expand(E, -1))
+                phys.step(args.substeps)
+                ts_last = (t + 1 == T)
             else:
-                env.reset()
-            state["t"] = 0
+                ts = env.step(act_dev[t].expand(E, -1))
+                ts_last = (t + 1 == T)
+                if world > 1 and args.gather:
+                    rec = rpd.pack_trajectory_record(
+                        base_env.physics.qpos, ts.reward, ts.discount, ts.step_type,
+                        base_env.task.piano.activation)
+                    rpd.gather_trajectories(rec)
+            state["t"] = t + 1
+            if ts_last:  # episode boundary: reset (not counted as a step, but timed)
+                if args.engine_only:
+                    phys.sync(); phys.reset()
+                else:
+                    env.reset()
+                state["t"] = 0
 
-    def barrier():
-        phys.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        def barrier():
+            phys.sync()
             torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+                torch.cuda.synchronize()
 
-    env.reset()
-    for t in range(args.warmup):
-        one_step(t)
-    barrier()
-    phys.kernel_time()  # reset kernel timer
-    t0 = time.perf_counter()
-    for t in range(args.steps):
-        one_step(args.warmup + t)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    kms, nl = phys.kernel_time()
-    warn = int(phys.warn_flags.max())
-    q = phys.qpos
-    finite = bool(np.isfinite(q).all())
-    ctrl_seq, _ = load_actions(m)
+        env.reset()
+        for t in range(warmup):
+            one_step(t)
+        barrier()
+        phys.kernel_time()  # reset kernel timer
+        t0 = time.perf_counter()
+        for t in range(steps):
+            one_step(warmup + t)
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        kms, nl = phys.kernel_time()
+        warn = int(phys.warn_flags.max())
+        q = phys.qpos
+        finite = bool(np.isfinite(q).all())
+        ctrl_seq, _ = load_actions(m)
+
+
+        return dict(dt=dt, kms=kms, nl=nl, warn=warn, finite=finite, phys=phys, m=m, ctrl_seq=ctrl_seq, E=E)
+
+    r = measure(args.precision, args.steps, args.warmup)
+    dt, kms, nl, warn, finite, phys, m, ctrl_seq, E = (r[k] for k in ('dt','kms','nl','warn','finite','phys','m','ctrl_seq','E'))
 
     if rank == 0:
         value = world * E * args.steps / dt
@@ -179,23 +204,36 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(E),
-                "kernel": "rp_step_kernel", "kernel_avg_ms": kms, "kernel_launches": nl,
-                "note": "path is latency/VALU bound by construction (BASELINE.md §2.3); HBM fraction reported as the north-star asks",
+                "kernel": "rp_step_kernel<%s>" % ("double" if args.precision == 64 else "float"),
+                "kernel_avg_ms": kms, "kernel_launches": nl,
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * (2 if args.precision == 64 else 1) * E,
+                "note": "fused 10-substep kernel: state lives in registers/LDS, so the path is latency/issue bound by construction (BASELINE.md 2.3); HBM fraction reported because the north-star asks for it",
             },
             "sanity": {"warn_flags": warn, "finite": finite},
+            "parity": "fp64 engine: max rel |dq| vs CPU oracle over 1000 mj_steps of this replay = 9e-5 (<1e-4), "
+                      "tests/test_gpu_parity.py::test_replay_fp64_1000_steps; fp32 engine diverges on this "
+                      "(chaotic, self-colliding) replay and is reported under aux only",
         }
+        if args.aux_fp32 and args.precision == 64 and world == 1:
+            del r, phys
+            r32 = measure(32, min(args.steps, 80), min(args.warmup, 10))
+            out["aux"] = {"fp32_engine": {
+                "value": E * min(args.steps, 80) / r32["dt"], "unit": "env-steps/s", "kernel_avg_ms": r32["kms"],
+                "warn_flags": r32["warn"],
+                "note": "same workload on the fp32 build; meets 1e-4 on smooth key-press scenarios only"}}
+            phys = r32["phys"]
         if not args.no_cpu_baseline:
             from oracle.rp_oracle import Oracle
             orc = Oracle(m, phys.blob)
-            cores = os.cpu_count() or 1
+            cores = _usable_cores()
             nenv_cpu = max(cores, 8)
-            nstep = 200
+            nstep = 400
             cc = np.tile(ctrl_seq[40], (nenv_cpu, 1))
             secs, _ = orc.bench(nenv_cpu, nstep, cc, cores)
             out["cpu_baseline"] = {
                 "value": nenv_cpu * nstep / args.substeps / secs, "unit": "env-steps/s",
                 "cores": cores, "kind": "port",
-                "sample": f"{nenv_cpu} envs x {nstep} mj_steps, fp64 C oracle (not MuJoCo), OpenMP {cores} threads, ctrl = action row 40 held",
+                "sample": f"{nenv_cpu} envs x {nstep} mj_steps from reset, fp64 C oracle (CPU restatement, not MuJoCo), OpenMP {cores} threads, ctrl = replay row 40 held",
                 "mj_steps_per_s": nenv_cpu * nstep / secs,
             }
         print(json.dumps(out))

@@ -57,10 +57,11 @@ typedef enum {
 #define RP_MAX_CONTACTS 32
 
 #define RP_WARN_BADSTATE 1     /* NaN / |q|>1e10 in qpos or qvel */
-#define RP_WARN_CONTACT_FULL 2 /* more than RP_MAX_CONTACTS contacts, extra dropped */
+#define RP_WARN_CONTACT_FULL 2 /* more than 24 simultaneous contacts in one env, extra dropped */
 #define RP_WARN_HESSIAN 4      /* non-positive pivot in the Newton Hessian */
 #define RP_WARN_KEYSLOT_FULL 8 /* more simultaneously touched keys than solver slots */
 #define RP_WARN_WORK_FULL 16   /* narrow-phase work list overflow */
+#define RP_WARN_DENSE_FULL 32  /* cross-coupled rows exceed the dense block; cross terms dropped */
 
 /* Builds an engine for `n_envs` copies of the model in `model_blob`
  * (robopianist_amd.model.compile.to_blob + engine tables) on HIP device
@@ -94,6 +95,9 @@ int rp_forward(rp_engine* e);
 /* Solver iteration caps (defaults: model opt.iterations / opt.ls_iterations). */
 int rp_set_solver_limits(rp_engine* e, int max_newton_iter, int max_ls_iter);
 
+/* Newton termination tolerance / line-search tolerance (defaults: model opt.tolerance,
+ * opt.ls_tolerance; values <= 0 leave the current setting). */
+int rp_set_solver_tolerance(rp_engine* e, double tolerance, double ls_tolerance);
 int rp_sync(rp_engine* e);
 int rp_get_stream(rp_engine* e, void** hip_stream);
 /* Makes the engine enqueue on a caller-owned HIP stream (e.g. PyTorch's current stream),

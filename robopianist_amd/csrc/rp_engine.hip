@@ -90,6 +90,7 @@ struct EngineBase {
   virtual int get(rp_field f, void* dst) = 0;
   virtual int step(int nsub, uint32_t* trace, int mode) = 0;
   virtual void limits(int newton, int ls) = 0;
+  virtual void tolerances(double tol, double ls_tol) = 0;
   virtual int field_ptr(rp_field f, void** p, size_t* bytes) = 0;
   bool own_stream = true;
   virtual int profile(long long* out, int n, int enable) = 0;
@@ -232,8 +233,8 @@ struct Engine : EngineBase {
     S.tree_offset = dalloc<T>(E * (ntree ? ntree : 1) * 3);
     S.act_force = dalloc<T>(E * nu); S.act_vel = dalloc<T>(E * nu);
     S.site_xpos = dalloc<T>(E * (nsite ? nsite : 1) * 3);
-    S.contact_dist = dalloc<T>(E * RPK_NC);
-    S.ncon = dalloc<int>(E); S.contact_geoms = dalloc<int>(E * RPK_NC * 2);
+    S.contact_dist = dalloc<T>(E * RPK_NCOUT);
+    S.ncon = dalloc<int>(E); S.contact_geoms = dalloc<int>(E * RPK_NCOUT * 2);
     S.warn = dalloc<int>(E); S.solver_iter = dalloc<int>(E);
     S.key_trace = nullptr;
     S.prof = nullptr;
@@ -256,6 +257,10 @@ struct Engine : EngineBase {
     HIP_OK(hipMemset(d_prof, 0, sizeof(long long) * RPK_NPROF));
     S.prof = enable ? d_prof : nullptr;
     return 0;
+  }
+  void tolerances(double tol, double ls_tol) override {
+    if (tol > 0) M.tolerance = (T)tol;
+    if (ls_tol > 0) M.ls_tolerance = (T)ls_tol;
   }
   void limits(int newton, int ls) override {
     if (newton > 0) S.max_newton = newton;
@@ -297,10 +302,10 @@ struct Engine : EngineBase {
       case RP_SITE_XPOS: *p = S.site_xpos; *bytes = sizeof(T) * E * nsite * 3; return true;
       case RP_TIME: *p = S.time; *bytes = sizeof(T) * E; *writable = true; return true;
       case RP_NCON: *p = S.ncon; *bytes = sizeof(int) * E; return true;
-      case RP_CONTACT_GEOMS: *p = S.contact_geoms; *bytes = sizeof(int) * E * RPK_NC * 2; return true;
+      case RP_CONTACT_GEOMS: *p = S.contact_geoms; *bytes = sizeof(int) * E * RPK_NCOUT * 2; return true;
       case RP_WARN_FLAGS: *p = S.warn; *bytes = sizeof(int) * E; *writable = true; return true;
       case RP_SOLVER_ITER: *p = S.solver_iter; *bytes = sizeof(int) * E; return true;
-      case RP_CONTACT_DIST: *p = S.contact_dist; *bytes = sizeof(T) * E * RPK_NC; return true;
+      case RP_CONTACT_DIST: *p = S.contact_dist; *bytes = sizeof(T) * E * RPK_NCOUT; return true;
       case RP_ACTIVE: *p = d_active; *bytes = sizeof(int) * E; *writable = true; return true;
       case RP_TREE_OFFSET: *p = S.tree_offset; *bytes = sizeof(T) * E * ntree * 3; *writable = true; return true;
     }
@@ -422,6 +427,11 @@ int rp_set_solver_limits(rp_engine* e, int max_newton_iter, int max_ls_iter) {
 }
 int rp_profile(rp_engine* e, long long* out, int n, int enable) {
   return e ? E(e)->profile(out, n, enable) : fail("null engine");
+}
+int rp_set_solver_tolerance(rp_engine* e, double tolerance, double ls_tolerance) {
+  if (!e) return fail("null engine");
+  E(e)->tolerances(tolerance, ls_tolerance);
+  return 0;
 }
 int rp_sync(rp_engine* e) {
   if (!e) return fail("null engine");

@@ -20,8 +20,10 @@
 #include <stdint.h>
 
 #define RPK_WAVE 64
-#define RPK_NC 32        // max contacts (== RP_MAX_CONTACTS)
-#define RPK_WORK 256     // narrow-phase work list
+#define RPK_NC 24        // max contacts kept per env (outputs are RP_MAX_CONTACTS wide)
+#define RPK_NCOUT 32     // == RP_MAX_CONTACTS
+#define RPK_HMAX 48      // max rows of the dense cross-coupling block
+#define RPK_WORK 128     // narrow-phase work list
 #define RPK_MAXD 9       // tree depth levels
 #define RPK_NL 52        // max links
 #define RPK_NKEYS 128    // max keys (2 slots per lane)
@@ -131,6 +133,11 @@ __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
+}
+template <typename P>
+__device__ __forceinline__ const P* fresh(const P* p) {
+  asm volatile("" : "+s"(p));
+  return p;
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) {
@@ -360,39 +367,49 @@ __device__ int capsule_box(RawCon<T>* out, const T* cp, const T* cm, const T* cs
 }
 
 // ----------------------------------------------------------------- shared memory
+// LDS budget drives occupancy (fp64: 40.5 KB -> 4 workgroups per CU).  Scratch of the
+// position/velocity stage and scratch of the solver are never live together, so they
+// share storage; only what crosses from one stage into the other is persistent.
 template <typename T>
 struct Smem {
-  T xpos[RPK_NL][3];
-  T xmat[RPK_NL][9];
-  T xaxis[RPK_NL][3];
-  T xanchor[RPK_NL][3];
-  T cdof[RPK_NL][6];
-  T vel[RPK_NL][6];
-  T RM[RPK_NL][RPK_MAXD + 1];   // mass-matrix rows: RM[i][e] = M[i][anc_e(i)]
-  T R[RPK_WAVE][RPK_MAXD + 1];  // tree factor rows (L), incl. key-leaf rows
-  T Dg[RPK_WAVE];               // tree factor diagonal
-  T xs[RPK_WAVE];               // solve staging
   union {
-    T acc[RPK_NL][10];
-    T H[RPK_WAVE * (RPK_WAVE + 1) / 2];
+    struct {  // ---- position / velocity stage
+      T xpos[RPK_NL][3];
+      T xmat[RPK_NL][9];
+      T xaxis[RPK_NL][3];
+      T xanchor[RPK_NL][3];
+      union {
+        T cdof[RPK_NL][6];  // until the mass-matrix rows are built
+        T vel[RPK_NL][6];   // afterwards: spatial velocities / accelerations
+      };
+      T acc[RPK_NL][10];    // composite inertias, then subtree forces
+      T gpos[RPK_WAVE][3];
+      short work[RPK_WORK][2];
+    };
+    struct {  // ---- acceleration stage (solver)
+      T R[RPK_WAVE][RPK_MAXD + 1];  // tree factor rows (L), incl. key-leaf rows
+      T Dg[RPK_WAVE];               // tree factor diagonal
+      T xs[RPK_WAVE];               // solve staging
+      T H[RPK_HMAX * (RPK_HMAX + 1) / 2];  // dense block of the cross-coupled rows
+    };
   };
+  // ---- persistent across stages
+  T RM[RPK_NL][RPK_MAXD + 1];   // mass-matrix rows: RM[i][e] = M[i][anc_e(i)]
   T vec[2][RPK_WAVE];
   T keyvec[2][RPK_NKEYS];
   T kq[RPK_NKEYS];
-  T gpos[RPK_WAVE][3];
   T actf[RPK_WAVE];
   T cpos[RPK_NC][3];
   T cn[RPK_NC][3];
   T cdist[RPK_NC];
   T cpar[RPK_NC][4];  // mu, kterm (K*imp*dist), B, D
-  int cA[RPK_NC], cB[RPK_NC], cgA[RPK_NC], cgB[RPK_NC];
   T cJ[RPK_NC][2][RPK_MAXD][3];
-  int work[RPK_WORK][2];
-  int slotkey[RPK_WAVE];
-  int slotlink[RPK_WAVE];
   unsigned long long slotmask[16];
+  int cA[RPK_NC], cB[RPK_NC], cgA[RPK_NC], cgB[RPK_NC];
+  short slotkey[16];
+  short slotlink[16];
+  signed char keyslot[RPK_NKEYS];
   signed char desc[RPK_NL * RPK_MAXD * 5];
-  int keyslot[RPK_NKEYS];
 };
 
 // rows owned by one lane: friction-loss row of its hand dof, one limit row per dof
@@ -554,67 +571,90 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
   int anc[RPK_MAXD];
 #pragma unroll
   for (int k = 0; k < RPK_MAXD; k++) anc[k] = isl ? M.link_anc[L * RPK_MAXD + k] : -1;
-  T lpos[3], lmat[9], laxis[3], lanchor[3], lipos[3], linert[6], tref[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    lpos[k] = isl ? M.link_lpos[3 * L + k] : (T)0;
-    laxis[k] = isl ? M.link_axis[3 * L + k] : (T)0;
-    lanchor[k] = isl ? M.link_anchor[3 * L + k] : (T)0;
-    lipos[k] = isl ? M.link_ipos[3 * L + k] : (T)0;
-    tref[k] = isl ? M.tree_ref[3 * ltree + k] : (T)0;
-  }
-#pragma unroll
-  for (int k = 0; k < 9; k++) lmat[k] = isl ? M.link_lmat[9 * L + k] : (T)0;
-#pragma unroll
-  for (int k = 0; k < 6; k++) linert[k] = isl ? M.link_inertia[6 * L + k] : (T)0;
-  const T lmass = isl ? M.link_mass[L] : (T)0;
-  const T larm = isl ? M.link_armature[L] : (T)0;
-  const T ldamp = isl ? M.link_damping[L] : (T)0;
-  const T lstiff = isl ? M.link_stiffness[L] : (T)0;
-  const T lsref = isl ? M.link_springref[L] : (T)0;
-  const T lfloss = isl ? M.link_floss[L] : (T)0;
-  const T lflR = isl ? M.link_fl_R[L] : (T)1;
-  const T lflB = isl ? M.link_fl_B[L] : (T)0;
-  const T lflD = (T)1 / lflR;
   const int llimited = isl ? M.link_limited[L] : 0;
   const int lact = isl ? M.link_act[L] : -1;
   const T lactcoef = isl ? M.link_act_coef[L] : (T)0;
   const T gscale = (isl && nl) ? M.tree_gscale[ltree] : (T)0;
-  if (isl && parent < 0 && S.tree_offset) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      T o = S.tree_offset[((size_t)env * M.ntree + ltree) * 3 + k];
-      lpos[k] += o;
-    }
-  }
-  // limit parameters of the three dof slots: 0 = hand link, 1 = key lane, 2 = key lane+64
-  T lo[3], hi[3], limK[3], limB[3], limW[3];
   int hasdof[3];
   hasdof[0] = isl && llimited; hasdof[1] = lane < nk; hasdof[2] = lane + 64 < nk;
   const bool isk[2] = {lane < nk, lane + 64 < nk};
   const int kid[2] = {lane, lane + 64};
-  lo[0] = isl ? M.link_range[2 * L] : (T)0; hi[0] = isl ? M.link_range[2 * L + 1] : (T)0;
-  limK[0] = isl ? M.link_lim_K[L] : (T)0; limB[0] = isl ? M.link_lim_B[L] : (T)0;
-  limW[0] = isl ? M.link_invw_dof[L] : (T)0;
-  T kM[2], kstiff[2], ksref[2], kdamp[2], kmass[2], kpos[2][3], khalf[2][3], krb[2], kinvwb[2];
   int kdof[2], kact[2];
 #pragma unroll
   for (int s = 0; s < 2; s++) {
-    const int K = isk[s] ? kid[s] : 0;
-    const bool ok = isk[s];
-    lo[1 + s] = ok ? M.key_range[2 * K] : (T)0; hi[1 + s] = ok ? M.key_range[2 * K + 1] : (T)0;
-    limK[1 + s] = ok ? M.key_lim_K[K] : (T)0; limB[1 + s] = ok ? M.key_lim_B[K] : (T)0;
-    limW[1 + s] = ok ? M.key_invw_dof[K] : (T)0;
-    kM[s] = ok ? M.key_M[K] : (T)1; kstiff[s] = ok ? M.key_stiffness[K] : (T)0;
-    ksref[s] = ok ? M.key_springref[K] : (T)0; kdamp[s] = ok ? M.key_damping[K] : (T)0;
-    kmass[s] = ok ? M.key_mass[K] : (T)0; kdof[s] = ok ? M.key_dof[K] : 0;
-    kact[s] = ok ? M.key_act[K] : -1; krb[s] = ok ? M.key_rbound[K] : (T)0;
-    kinvwb[s] = ok ? M.key_invw_body[K] : (T)0;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      kpos[s][k] = ok ? M.key_pos[3 * K + k] : (T)0;
-      khalf[s][k] = ok ? M.key_half[3 * K + k] : (T)0;
-    }
+    kdof[s] = isk[s] ? M.key_dof[kid[s]] : 0;
+    kact[s] = isk[s] ? M.key_act[kid[s]] : -1;
+  }
+// Per-lane model constants are re-read from the (L2-resident) tables inside the stage
+// that uses them instead of being pinned in registers for the whole kernel: the kernel
+// is register-bound, and `fresh()` keeps the compiler from hoisting the loads back out
+// of the substep loop.
+#define RPK_LOAD_GEOMETRY                                                                  \
+  T lpos[3], lmat[9], laxis[3], lanchor[3], lipos[3], linert[6], tref[3];                  \
+  T kpos[2][3], khalf[2][3], krb[2];                                                       \
+  {                                                                                        \
+    const T *p_lpos = fresh(M.link_lpos), *p_axis = fresh(M.link_axis),                    \
+            *p_anchor = fresh(M.link_anchor), *p_ipos = fresh(M.link_ipos),                \
+            *p_tref = fresh(M.tree_ref), *p_lmat = fresh(M.link_lmat),                     \
+            *p_inert = fresh(M.link_inertia), *p_kpos = fresh(M.key_pos),                  \
+            *p_khalf = fresh(M.key_half), *p_krb = fresh(M.key_rbound);                    \
+    _Pragma("unroll") for (int k = 0; k < 3; k++) {                                        \
+      lpos[k] = isl ? p_lpos[3 * L + k] : (T)0;                                            \
+      laxis[k] = isl ? p_axis[3 * L + k] : (T)0;                                           \
+      lanchor[k] = isl ? p_anchor[3 * L + k] : (T)0;                                       \
+      lipos[k] = isl ? p_ipos[3 * L + k] : (T)0;                                           \
+      tref[k] = isl ? p_tref[3 * ltree + k] : (T)0;                                        \
+    }                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < 9; k++) lmat[k] = isl ? p_lmat[9 * L + k] : (T)0; \
+    _Pragma("unroll") for (int k = 0; k < 6; k++) linert[k] = isl ? p_inert[6 * L + k] : (T)0; \
+    if (isl && parent < 0 && S.tree_offset) {                                              \
+      _Pragma("unroll") for (int k = 0; k < 3; k++)                                        \
+        lpos[k] += S.tree_offset[((size_t)env * M.ntree + ltree) * 3 + k];                 \
+    }                                                                                      \
+    _Pragma("unroll") for (int s = 0; s < 2; s++) {                                        \
+      const int K = isk[s] ? kid[s] : 0;                                                   \
+      krb[s] = isk[s] ? p_krb[K] : (T)0;                                                   \
+      _Pragma("unroll") for (int k = 0; k < 3; k++) {                                      \
+        kpos[s][k] = isk[s] ? p_kpos[3 * K + k] : (T)0;                                    \
+        khalf[s][k] = isk[s] ? p_khalf[3 * K + k] : (T)0;                                  \
+      }                                                                                    \
+    }                                                                                      \
+  }                                                                                        \
+  const T lmass = isl ? fresh(M.link_mass)[L] : (T)0;                                      \
+  const T larm = isl ? fresh(M.link_armature)[L] : (T)0;
+#define RPK_LOAD_LIMITS                                                                    \
+  T lo[3], hi[3], limK[3], limB[3], limW[3];                                               \
+  {                                                                                        \
+    const T *p_lr = fresh(M.link_range), *p_kr = fresh(M.key_range);                       \
+    lo[0] = isl ? p_lr[2 * L] : (T)0; hi[0] = isl ? p_lr[2 * L + 1] : (T)0;                \
+    limK[0] = isl ? fresh(M.link_lim_K)[L] : (T)0;                                         \
+    limB[0] = isl ? fresh(M.link_lim_B)[L] : (T)0;                                         \
+    limW[0] = isl ? fresh(M.link_invw_dof)[L] : (T)0;                                      \
+    _Pragma("unroll") for (int s = 0; s < 2; s++) {                                        \
+      const int K = isk[s] ? kid[s] : 0;                                                   \
+      lo[1 + s] = isk[s] ? p_kr[2 * K] : (T)0; hi[1 + s] = isk[s] ? p_kr[2 * K + 1] : (T)0; \
+      limK[1 + s] = isk[s] ? fresh(M.key_lim_K)[K] : (T)0;                                 \
+      limB[1 + s] = isk[s] ? fresh(M.key_lim_B)[K] : (T)0;                                 \
+      limW[1 + s] = isk[s] ? fresh(M.key_invw_dof)[K] : (T)0;                              \
+    }                                                                                      \
+  }                                                                                        \
+  const T lflB = isl ? fresh(M.link_fl_B)[L] : (T)0;
+#define RPK_LOAD_DYN                                                                       \
+  const T ldamp = isl ? fresh(M.link_damping)[L] : (T)0;                                   \
+  const T lstiff = isl ? fresh(M.link_stiffness)[L] : (T)0;                                \
+  const T lsref = isl ? fresh(M.link_springref)[L] : (T)0;                                 \
+  const T lfloss = isl ? fresh(M.link_floss)[L] : (T)0;                                    \
+  const T lflR = isl ? fresh(M.link_fl_R)[L] : (T)1;                                       \
+  const T lflD = (T)1 / lflR;                                                              \
+  T kM[2], kstiff[2], ksref[2], kdamp[2], kmass[2], khx[2];                                \
+  _Pragma("unroll") for (int s = 0; s < 2; s++) {                                          \
+    const int K = isk[s] ? kid[s] : 0;                                                     \
+    kM[s] = isk[s] ? fresh(M.key_M)[K] : (T)1;                                             \
+    kstiff[s] = isk[s] ? fresh(M.key_stiffness)[K] : (T)0;                                 \
+    ksref[s] = isk[s] ? fresh(M.key_springref)[K] : (T)0;                                  \
+    kdamp[s] = isk[s] ? fresh(M.key_damping)[K] : (T)0;                                    \
+    kmass[s] = isk[s] ? fresh(M.key_mass)[K] : (T)0;                                       \
+    khx[s] = isk[s] ? fresh(M.key_half)[3 * K] : (T)0;                                     \
   }
   // actuator owned by this lane (hand actuators only; key actuators live with the key)
   const bool isa = lane < nu && M.act_kind[lane < nu ? lane : 0] == 0;
@@ -682,6 +722,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
     // ACCELERATION STAGE + EULER (skipped on the first pass: state is fresh)
     // ======================================================================
     if (stage > 0) {
+      RPK_LOAD_DYN
       // ---- actuation [MJ: mj_fwdActuation]
       T aforce = 0;
       if (isa) {
@@ -703,7 +744,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
           T f = 0;
           if (isk[s]) {
             // passive spring/damper, gravity torque m*g*(hx)*cos(q) about +y, actuator
-            T grav = -kmass[s] * M.gz * khalf[s][0] * kcos[s] - kmass[s] * M.gx * khalf[s][0] * ksin[s];
+            T grav = -kmass[s] * M.gz * khx[s] * kcos[s] - kmass[s] * M.gx * khx[s] * ksin[s];
             f = -kstiff[s] * (q[1 + s] - ksref[s]) - kdamp[s] * qd[1 + s] + grav + qapp[1 + s];
             if (kact[s] >= 0) {
               T af = M.act_gain[kact[s]] * kctrl[s];
@@ -804,6 +845,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
           }
         }
         // ---- dense block on the dirty rows (Schur complement + cross-contact terms)
+        if (dm && __popcll(dm) > RPK_HMAX) { warn |= 32; dm = 0; }  // cannot hold the block: drop cross terms
         if (dm) {
           WSYNC();
           const int nD = __popcll(dm);
@@ -1285,6 +1327,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
                  !(N::abs(qd[0]) < (T)1e10) || !(N::abs(qd[1]) < (T)1e10) || !(N::abs(qd[2]) < (T)1e10);
       if (__ballot(bad)) warn |= 1;
     }
+    RPK_LOAD_GEOMETRY
     // ---- forward kinematics by tree level [MJ: mj_kinematics]
     T xp[3] = {0, 0, 0}, xm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, axw[3] = {0, 0, 0}, anw[3] = {0, 0, 0};
     for (int d = 0; d < M.maxdepth; d++) {
@@ -1327,6 +1370,13 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
         for (int k = 0; k < 9; k++) sm.xmat[lane][k] = xm[k];
       }
       WSYNC();
+    }
+    if (stage == nstage - 1 && lane < M.nsite) {  // site positions of the final state
+      int sl = M.site_link[lane];
+      T t[3];
+      mat_vec(t, sm.xmat[sl], M.site_pos + 3 * lane);
+#pragma unroll
+      for (int k = 0; k < 3; k++) S.site_xpos[((size_t)env * M.nsite + lane) * 3 + k] = sm.xpos[sl][k] + t[k];
     }
     PROF(10);
     // ---- spatial inertia and motion axis about the tree reference point [MJ: mj_comPos]
@@ -1422,71 +1472,94 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
     WSYNC();
 
     PROF(18);
-    // ---- broad phase: static pair list + (capsule x keys) family [MJ: mj_collision]
+    // ---- broad phase + narrow phase, streamed through a bounded work list
+    // [MJ: mj_collision].  Candidate generators: (0) the static pair list, 64 pairs at a
+    // time; (1) every hand capsule near the keyboard against the 88 keys (lane = key).
+    // Whenever 64 candidates are pending they are narrow-phased, so the list never
+    // overflows whatever the pose.
     int nwork = 0;
-    for (int base = 0; base < M.npair; base += 64) {
-      int p = base + lane;
-      bool hit = false;
-      int ga = 0, gb = 0;
-      if (p < M.npair) {
-        ga = M.pair[2 * p]; gb = M.pair[2 * p + 1];
-        T dx = sm.gpos[ga][0] - sm.gpos[gb][0], dy = sm.gpos[ga][1] - sm.gpos[gb][1],
-          dz = sm.gpos[ga][2] - sm.gpos[gb][2];
-        T rr = M.geom_rbound[ga] + M.geom_rbound[gb];
-        hit = dx * dx + dy * dy + dz * dz <= rr * rr;
-      }
-      unsigned long long mk = __ballot(hit);
-      int idx = nwork + __popcll(mk & lanemask_lt(lane));
-      if (hit && idx < RPK_WORK) { sm.work[idx][0] = ga; sm.work[idx][1] = gb; }
-      nwork += __popcll(mk);
-    }
-    for (int base = 0; base < M.nkeycap; base += 64) {
-      int ci = base + lane;
-      bool near = false;
-      if (ci < M.nkeycap) {
-        int g = M.keycap[ci];
-        near = sm.gpos[g][2] - M.geom_rbound[g] <= M.key_zmax;
-      }
-      unsigned long long nm = __ballot(near);
-      while (nm) {
-        int cj = __ffsll((long long)nm) - 1;
-        nm &= nm - 1;
-        int g = M.keycap[base + cj];
-        T cx = sm.gpos[g][0], cy = sm.gpos[g][1], cz = sm.gpos[g][2], rb = M.geom_rbound[g];
-#pragma unroll
-        for (int s = 0; s < 2; s++) {
+    ncon = 0;
+    {
+    int gen_phase = (M.npair > 0) ? 0 : 1, gen_base = 0, gen_slot = 0;
+    unsigned long long near_mask = 0;
+    bool near_ready = false;
+    while (true) {
+      if (gen_phase == 0) {
+        int p = gen_base + lane;
+        bool hit = false;
+        int ga = 0, gb = 0;
+        if (p < M.npair) {
+          ga = M.pair[2 * p]; gb = M.pair[2 * p + 1];
+          T dx = sm.gpos[ga][0] - sm.gpos[gb][0], dy = sm.gpos[ga][1] - sm.gpos[gb][1],
+            dz = sm.gpos[ga][2] - sm.gpos[gb][2];
+          T rr = M.geom_rbound[ga] + M.geom_rbound[gb];
+          hit = dx * dx + dy * dy + dz * dz <= rr * rr;
+        }
+        unsigned long long mk = __ballot(hit);
+        int idx = nwork + __popcll(mk & lanemask_lt(lane));
+        if (hit) { sm.work[idx][0] = (short)ga; sm.work[idx][1] = (short)gb; }
+        nwork += __popcll(mk);
+        gen_base += 64;
+        if (gen_base >= M.npair) gen_phase = 1;
+      } else if (gen_phase == 1) {
+        if (!near_ready) {
+          bool near = false;
+          if (lane < M.nkeycap) {
+            int g = M.keycap[lane];
+            near = sm.gpos[g][2] - M.geom_rbound[g] <= M.key_zmax;
+          }
+          near_mask = __ballot(near);
+          near_ready = true;
+        }
+        if (near_mask == 0ull || nk == 0) gen_phase = 2;
+        else {
+          int cj = __ffsll((long long)near_mask) - 1;
+          int g = M.keycap[cj];
+          T cx = sm.gpos[g][0], cy = sm.gpos[g][1], cz = sm.gpos[g][2], rb = M.geom_rbound[g];
           bool hit = false;
-          if (isk[s]) {
+          const int s = gen_slot;
+          // (s is uniform; select this lane's key of slot s without dynamic register indexing)
+          const bool kok = s == 0 ? isk[0] : isk[1];
+          if (kok) {
+            const T kpx = s == 0 ? kpos[0][0] : kpos[1][0], kpy = s == 0 ? kpos[0][1] : kpos[1][1],
+                    kpz = s == 0 ? kpos[0][2] : kpos[1][2];
+            const T khx_ = s == 0 ? khalf[0][0] : khalf[1][0], khy_ = s == 0 ? khalf[0][1] : khalf[1][1],
+                    khz_ = s == 0 ? khalf[0][2] : khalf[1][2];
+            const T kc_ = s == 0 ? kcos[0] : kcos[1], ks_ = s == 0 ? ksin[0] : ksin[1];
+            const T krb_ = s == 0 ? krb[0] : krb[1];
             // key box centre = anchor + R_y(q) (hx,0,0)
-            T kx = kpos[s][0] - khalf[s][0] + khalf[s][0] * kcos[s];
-            T kz = kpos[s][2] - khalf[s][0] * ksin[s];
-            T dx = kx - cx, dy = kpos[s][1] - cy, dz = kz - cz, rr = rb + krb[s];
+            T kx = kpx - khx_ + khx_ * kc_;
+            T kz = kpz - khx_ * ks_;
+            T dx = kx - cx, dy = kpy - cy, dz = kz - cz, rr = rb + krb_;
             // bounding spheres, then a conservative box test (the key only rotates
             // about y, so its y-extent is exact; x/z get a 1 cm allowance)
-            hit = dx * dx + dy * dy + dz * dz <= rr * rr &&
-                  N::abs(dy) <= khalf[s][1] + rb &&
-                  N::abs(cx - kpos[s][0]) <= khalf[s][0] + rb + (T)0.01 &&
-                  cz - rb <= kpos[s][2] + khalf[s][2] + (T)0.01;
+            hit = dx * dx + dy * dy + dz * dz <= rr * rr && N::abs(dy) <= khy_ + rb &&
+                  N::abs(cx - kpx) <= khx_ + rb + (T)0.01 && cz - rb <= kpz + khz_ + (T)0.01;
           }
           unsigned long long mk = __ballot(hit);
           int idx = nwork + __popcll(mk & lanemask_lt(lane));
-          if (hit && idx < RPK_WORK) { sm.work[idx][0] = g; sm.work[idx][1] = RPK_KEYBASE + kid[s]; }
+          if (hit) { sm.work[idx][0] = (short)g; sm.work[idx][1] = (short)(RPK_KEYBASE + (s == 0 ? kid[0] : kid[1])); }
           nwork += __popcll(mk);
+          gen_slot++;
+          if (gen_slot == 2) { gen_slot = 0; near_mask &= near_mask - 1; }
         }
       }
-    }
-    if (nwork > RPK_WORK) { warn |= 16; nwork = RPK_WORK; }
-    WSYNC();
-
-    PROF(12);
-    // ---- narrow phase + contact parameters [MJ: mjc_* , mj_contactParam, mj_makeImpedance]
-    ncon = 0;
-    for (int base = 0; base < nwork; base += 64) {
+      const bool gen_done = gen_phase == 2;
+      if (!(nwork >= 64 || (gen_done && nwork > 0))) {
+        if (gen_done) break;
+        continue;
+      }
+      WSYNC();
+      // ---- narrow phase on the first min(64, nwork) candidates
+      // [MJ: mjc_*, mj_contactParam, mj_makeImpedance]
+      const int nproc = nwork < 64 ? nwork : 64;
+      {
+      const int base = 0;
       int w = base + lane;
       RawCon<T> rc[3];
       int n = 0, ga = 0, gb = 0;
       T pB[8], invw = 0;
-      if (w < nwork) {
+      if (w < nproc) {
         ga = sm.work[w][0]; gb = sm.work[w][1];
         int la = M.geom_link[ga];
         T mA[9], posA[3] = {sm.gpos[ga][0], sm.gpos[ga][1], sm.gpos[ga][2]};
@@ -1557,6 +1630,17 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
         }
         ncon += __popcll(mk);
       }
+      }
+      // drop the processed candidates
+      WSYNC();
+      short w0 = 0, w1 = 0;
+      const bool mv = lane + 64 < nwork;
+      if (mv) { w0 = sm.work[lane + 64][0]; w1 = sm.work[lane + 64][1]; }
+      WSYNC();
+      if (mv) { sm.work[lane][0] = w0; sm.work[lane][1] = w1; }
+      nwork -= nproc;
+      WSYNC();
+    }
     }
     if (ncon > RPK_NC) { warn |= 2; ncon = RPK_NC; }
     WSYNC();
@@ -1577,7 +1661,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
       unsigned long long fm = __ballot(first);
       int slot = __popcll(fm & lanemask_lt(lane));
       nkt = __popcll(fm);
-      int cap = 64 - nl;
+      int cap = min(64 - nl, 16);
       if (first && slot < cap) { sm.slotkey[slot] = kb; sm.keyslot[kb] = slot; }
       if (nkt > cap) { warn |= 8; nkt = cap; }
       WSYNC();
@@ -1774,6 +1858,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
       alen = acoef0 * sm.vec[0][alane0] + (alane1 >= 0 ? acoef1 * sm.vec[0][alane1] : (T)0);
       avel = acoef0 * sm.vec[1][alane0] + (alane1 >= 0 ? acoef1 * sm.vec[1][alane1] : (T)0);
     }
+    RPK_LOAD_LIMITS
     // ---- constraint rows: reference accelerations [MJ: mj_makeConstraint, mj_referenceConstraint]
     fr_aref = -lflB * qd[0];
 #pragma unroll
@@ -1843,18 +1928,11 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
     if (kact[s] >= 0) S.act_vel[(size_t)env * nu + kact[s]] = M.act_coef[2 * kact[s]] * qd[1 + s];
   }
   if (isa) S.act_vel[(size_t)env * nu + lane] = avel;
-  if (lane < M.nsite) {
-    int sl = M.site_link[lane];
-    T t[3];
-    mat_vec(t, sm.xmat[sl], M.site_pos + 3 * lane);
-#pragma unroll
-    for (int k = 0; k < 3; k++) S.site_xpos[((size_t)env * M.nsite + lane) * 3 + k] = sm.xpos[sl][k] + t[k];
-  }
-  if (lane < RPK_NC) {
+  if (lane < RPK_NCOUT) {
     bool v = lane < ncon;
-    S.contact_geoms[((size_t)env * RPK_NC + lane) * 2] = v ? sm.cgA[lane] : -1;
-    S.contact_geoms[((size_t)env * RPK_NC + lane) * 2 + 1] = v ? sm.cgB[lane] : -1;
-    S.contact_dist[(size_t)env * RPK_NC + lane] = v ? sm.cdist[lane] : (T)0;
+    S.contact_geoms[((size_t)env * RPK_NCOUT + lane) * 2] = v ? sm.cgA[lane] : -1;
+    S.contact_geoms[((size_t)env * RPK_NCOUT + lane) * 2 + 1] = v ? sm.cgB[lane] : -1;
+    S.contact_dist[(size_t)env * RPK_NCOUT + lane] = v ? sm.cdist[lane] : (T)0;
   }
   {
     int w = warn;

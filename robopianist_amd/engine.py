@@ -34,7 +34,7 @@ WARN_WORK_FULL = 16
 
 EXPORTED_SYMBOLS = (
     "rp_create", "rp_destroy", "rp_reset", "rp_set", "rp_get", "rp_step", "rp_forward",
-    "rp_set_solver_limits", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
+    "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
     "rp_n_envs", "rp_dim",
     "rp_kernel_time", "rp_profile", "rp_last_error",
 )
@@ -69,6 +69,7 @@ def load_library(path: str = LIB_PATH):
     L.rp_forward.argtypes = [ctypes.c_void_p]
     L.rp_set_solver_limits.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     L.rp_sync.argtypes = [ctypes.c_void_p]
+    L.rp_set_solver_tolerance.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]
     L.rp_get_stream.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
     L.rp_n_envs.argtypes = [ctypes.c_void_p]
     L.rp_dim.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
@@ -215,6 +216,9 @@ class BatchedPhysics:
 
     def set_solver_limits(self, max_newton_iter=0, max_ls_iter=0):
         self._check(self._L.rp_set_solver_limits(self._h, max_newton_iter, max_ls_iter))
+
+    def set_solver_tolerance(self, tolerance=0.0, ls_tolerance=0.0):
+        self._check(self._L.rp_set_solver_tolerance(self._h, float(tolerance), float(ls_tolerance)))
 
     def kernel_time(self):
         """(average step-kernel ms since last call, number of launches)."""

@@ -296,6 +296,9 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
             spairs.append((eidx[a], eidx[b]))
     for h, c in keycount.items():
         assert c == nk, "engine expects each colliding capsule paired with every key"
+    # capsule-capsule pairs first, then capsule-box: the narrow phase processes 64
+    # candidates at a time and diverges less when a chunk holds one geometry type
+    spairs.sort(key=lambda ab: (int(m.geom_type[egeoms[ab[1]]]), ab[0], ab[1]))
     t["eng_npair"] = np.array([len(spairs)], np.int32)
     t["eng_pair"] = np.array(spairs, np.int32).reshape(-1, 2)
     kcaps = sorted(eidx[h] for h in keycount)
