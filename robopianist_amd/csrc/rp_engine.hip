@@ -100,6 +100,7 @@ template <typename T>
 struct Engine : EngineBase {
   RpModel<T> M{};
   RpState<T> S{};
+  RpStage<T> B{};
   std::vector<void*> allocs;
   std::vector<T> qpos0;
   T* d_qpos0 = nullptr;
@@ -236,6 +237,13 @@ struct Engine : EngineBase {
     S.contact_dist = dalloc<T>(E * RPK_NCOUT);
     S.ncon = dalloc<int>(E); S.contact_geoms = dalloc<int>(E * RPK_NCOUT * 2);
     S.warn = dalloc<int>(E); S.solver_iter = dalloc<int>(E);
+    B.RM = dalloc<T>(E * RPK_NL * (RPK_MAXD + 1));
+    B.lanef = dalloc<T>(E * RPK_NLF * 64);
+    B.lanei = dalloc<int>(E * RPK_NLI * 64);
+    B.hdr = dalloc<int>(E * 4);
+    B.cJ = dalloc<T>(E * RPK_NC * 2 * RPK_MAXD * 3);
+    B.slots = dalloc<int>(E * 64);
+    B.keyslot = dalloc<int>(E * (RPK_NKEYS / 4));
     S.key_trace = nullptr;
     S.prof = nullptr;
     d_active = dalloc<int>(E);
@@ -357,7 +365,16 @@ struct Engine : EngineBase {
     harvest(slot, true);
     const bool timeit = (mode == 0);
     if (timeit) HIP_OK(hipEventRecord(ev0[slot], stream));
-    hipLaunchKernelGGL(rp_step_kernel<T>, dim3(nenv), dim3(64), 0, stream, M, s, nsub, mode);
+    // mj_step1 for the current state, then n_sub x (mj_step2; mj_step1): dm_control's legacy
+    // order.  Two small kernels per substep instead of one fused launch: each half fits in
+    // registers, and the hand-over (RpStage) stays in L2 / Infinity Cache.
+    hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(nenv), dim3(64), 0, stream, M, s, B, -1, nsub);
+    if (mode == 0) {
+      for (int k = 0; k < nsub; k++) {
+        hipLaunchKernelGGL((rp_stage_kernel<T, 1>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
+        hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
+      }
+    }
     HIP_OK(hipGetLastError());
     if (timeit) { HIP_OK(hipEventRecord(ev1[slot], stream)); ev_pending[slot] = true; }
     if (trace && mode == 0)

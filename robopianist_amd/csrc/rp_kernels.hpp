@@ -93,6 +93,22 @@ struct RpState {
     }                                                                   \
   } while (0)
 
+// Hand-over between the position/velocity kernel (MODE 0) and the solver kernel
+// (MODE 1): everything `mj_step1` leaves behind for `mj_step2`, per env.  Lives in
+// HBM but is L2 / Infinity-Cache resident (<= 25 KB per env).
+#define RPK_NLF 29  // per-lane float fields
+#define RPK_NLI 10  // per-lane int fields
+template <typename T>
+struct RpStage {
+  T* RM;      // [E][RPK_NL][RPK_MAXD+1] mass-matrix rows
+  T* lanef;   // [E][RPK_NLF][64]
+  int* lanei; // [E][RPK_NLI][64]
+  int* hdr;   // [E][4]: ncon, nkt, dirty mask lo/hi
+  T* cJ;      // [E][RPK_NC][2][RPK_MAXD][3]
+  int* slots; // [E][64]: slotkey[16], slotlink[16], slotmask lo[16], hi[16]
+  int* keyslot; // [E][RPK_NKEYS/4] (packed signed char)
+};
+
 namespace rpk {
 
 template <typename T> struct Num;
@@ -546,8 +562,9 @@ __global__ void rp_reset_kernel(RpState<T> S, const T* qpos0, const unsigned cha
 // The step kernel.  mode 0: n_sub x (acceleration stage, Euler, position/velocity
 // stage).  mode 1: position/velocity stage only (physics.forward()).
 // ============================================================================
-template <typename T>
-__global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S, int nsub, int mode) {
+template <typename T, int MODE>
+__global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep,
+                                                     int nsub) {
   using namespace rpk;
   using N = Num<T>;
   const int env = blockIdx.x;
@@ -716,12 +733,62 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
   unsigned long long con_maskA = 0, con_maskB = 0;
   int niter_last = 0;
 
-  const int nstage = (mode == 1) ? 1 : nsub + 1;
-  for (int stage = 0; stage < nstage; stage++) {
+  const size_t lf = (size_t)env * RPK_NLF * 64 + lane, li = (size_t)env * RPK_NLI * 64 + lane;
+#define LF(i) B.lanef[lf + (size_t)(i) * 64]
+#define LI(i) B.lanei[li + (size_t)(i) * 64]
+  {
     // ======================================================================
-    // ACCELERATION STAGE + EULER (skipped on the first pass: state is fresh)
+    // MODE 1: ACCELERATION STAGE + EULER  (mj_step2)
     // ======================================================================
-    if (stage > 0) {
+    if constexpr (MODE == 1) {
+      // ---- what the position/velocity kernel left behind
+      {
+        ncon = B.hdr[env * 4]; nkt = B.hdr[env * 4 + 1];
+        dirty_mask = ((unsigned long long)(unsigned)B.hdr[env * 4 + 3] << 32) | (unsigned)B.hdr[env * 4 + 2];
+        qbias = LF(0); alen = LF(1); avel = LF(2);
+        ksin[0] = LF(3); ksin[1] = LF(4); kcos[0] = LF(5); kcos[1] = LF(6);
+        fr_aref = LF(7);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { lim_D[k] = LF(8 + k); lim_aref[k] = LF(11 + k); }
+        con_D = LF(14); con_mu = LF(15);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { con_n[k] = LF(16 + k); con_t1[k] = LF(19 + k); con_t2[k] = LF(22 + k); }
+#pragma unroll
+        for (int k = 0; k < 4; k++) con_aref[k] = LF(25 + k);
+        int ls = LI(0);
+        lim_sign[0] = (ls & 3) - 1; lim_sign[1] = ((ls >> 2) & 3) - 1; lim_sign[2] = ((ls >> 4) & 3) - 1;
+        con_A = LI(1); con_B = LI(2); con_slot = LI(3); con_cross = LI(4);
+        con_maskA = ((unsigned long long)(unsigned)LI(6) << 32) | (unsigned)LI(5);
+        con_maskB = ((unsigned long long)(unsigned)LI(8) << 32) | (unsigned)LI(7);
+        sdepth = LI(9);
+        if (isl) {
+#pragma unroll
+          for (int e = 0; e <= RPK_MAXD; e++) {
+            Mr[e] = B.RM[((size_t)env * RPK_NL + lane) * (RPK_MAXD + 1) + e];
+            sm.RM[lane][e] = Mr[e];
+          }
+        }
+        {
+          T* dst = &sm.cJ[0][0][0][0];
+          const T* src = B.cJ + (size_t)env * RPK_NC * 2 * RPK_MAXD * 3;
+          for (int i = lane; i < ncon * 2 * RPK_MAXD * 3; i += 64) dst[i] = src[i];
+        }
+        if (lane < 16) {
+          const int* sl = B.slots + (size_t)env * 64;
+          sm.slotkey[lane] = (short)sl[lane];
+          sm.slotlink[lane] = (short)sl[16 + lane];
+          sm.slotmask[lane] = ((unsigned long long)(unsigned)sl[48 + lane] << 32) | (unsigned)sl[32 + lane];
+        }
+        if (lane < RPK_NKEYS / 4) ((int*)sm.keyslot)[lane] = B.keyslot[(size_t)env * (RPK_NKEYS / 4) + lane];
+        WSYNC();
+        if (!isl && lane < nl + nkt) {
+          int al = sm.slotlink[lane - nl];
+          if (al >= 0) {
+#pragma unroll
+            for (int e = 0; e < RPK_MAXD; e++) sanc[e] = M.link_anc[al * RPK_MAXD + e];
+          }
+        }
+      }
       RPK_LOAD_DYN
       // ---- actuation [MJ: mj_fwdActuation]
       T aforce = 0;
@@ -1316,12 +1383,19 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
 #pragma unroll
       for (int s = 0; s < 3; s++) { qd[s] += h * qe[s]; q[s] += h * qd[s]; }
       time += h;
+      PROF(9);
+      // ---- new state
+      if (isl) { S.qpos[eo + ldof] = q[0]; S.qvel[eo + ldof] = qd[0]; S.warm[eo + ldof] = qw[0]; }
+#pragma unroll
+      for (int s = 0; s < 2; s++) if (isk[s]) {
+        S.qpos[eo + kdof[s]] = q[1 + s]; S.qvel[eo + kdof[s]] = qd[1 + s]; S.warm[eo + kdof[s]] = qw[1 + s];
+      }
     }
 
     // ======================================================================
-    if (stage > 0) PROF(9);
-    // POSITION STAGE
+    // MODE 0: POSITION + VELOCITY STAGE  (mj_step1)
     // ======================================================================
+    if constexpr (MODE == 0) {
     {
       bool bad = !(N::abs(q[0]) < (T)1e10) || !(N::abs(q[1]) < (T)1e10) || !(N::abs(q[2]) < (T)1e10) ||
                  !(N::abs(qd[0]) < (T)1e10) || !(N::abs(qd[1]) < (T)1e10) || !(N::abs(qd[2]) < (T)1e10);
@@ -1371,7 +1445,7 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
       }
       WSYNC();
     }
-    if (stage == nstage - 1 && lane < M.nsite) {  // site positions of the final state
+    if (lane < M.nsite) {  // site positions of this state
       int sl = M.site_link[lane];
       T t[3];
       mat_vec(t, sm.xmat[sl], M.site_pos + 3 * lane);
@@ -1909,22 +1983,59 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
 
     PROF(16);
     // ---- per-substep key activation trace (Piano._update_key_state, piano.py:178-192)
-    if (S.key_trace && stage > 0) {
+    if (S.key_trace && substep >= 0) {
       unsigned long long b0 = __ballot(isk[0] && (fmin(hi[1], fmax(lo[1], q[1])) >= hi[1] - (T)0.00872665));
       unsigned long long b1 = __ballot(isk[1] && (fmin(hi[2], fmax(lo[2], q[2])) >= hi[2] - (T)0.00872665));
       if (lane == 0) {
-        uint32_t* o = S.key_trace + ((size_t)env * nsub + (stage - 1)) * 4;
+        uint32_t* o = S.key_trace + ((size_t)env * nsub + substep) * 4;
         o[0] = (uint32_t)b0; o[1] = (uint32_t)(b0 >> 32); o[2] = (uint32_t)b1; o[3] = (uint32_t)(b1 >> 32);
       }
     }
+    // ---- hand over to the solver kernel
+    {
+      LF(0) = qbias; LF(1) = alen; LF(2) = avel;
+      LF(3) = ksin[0]; LF(4) = ksin[1]; LF(5) = kcos[0]; LF(6) = kcos[1];
+      LF(7) = fr_aref;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { LF(8 + k) = lim_D[k]; LF(11 + k) = lim_aref[k]; }
+      LF(14) = con_D; LF(15) = con_mu;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { LF(16 + k) = con_n[k]; LF(19 + k) = con_t1[k]; LF(22 + k) = con_t2[k]; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) LF(25 + k) = con_aref[k];
+      LI(0) = (lim_sign[0] + 1) | ((lim_sign[1] + 1) << 2) | ((lim_sign[2] + 1) << 4);
+      LI(1) = con_A; LI(2) = con_B; LI(3) = con_slot; LI(4) = con_cross;
+      LI(5) = (int)(con_maskA & 0xffffffffu); LI(6) = (int)(con_maskA >> 32);
+      LI(7) = (int)(con_maskB & 0xffffffffu); LI(8) = (int)(con_maskB >> 32);
+      LI(9) = sdepth;
+      if (isl) {
+#pragma unroll
+        for (int e = 0; e <= RPK_MAXD; e++) B.RM[((size_t)env * RPK_NL + lane) * (RPK_MAXD + 1) + e] = Mr[e];
+      }
+      {
+        const T* src = &sm.cJ[0][0][0][0];
+        T* dst = B.cJ + (size_t)env * RPK_NC * 2 * RPK_MAXD * 3;
+        for (int i = lane; i < ncon * 2 * RPK_MAXD * 3; i += 64) dst[i] = src[i];
+      }
+      if (lane < 16) {
+        int* sl = B.slots + (size_t)env * 64;
+        sl[lane] = sm.slotkey[lane]; sl[16 + lane] = sm.slotlink[lane];
+        sl[32 + lane] = (int)(sm.slotmask[lane] & 0xffffffffu); sl[48 + lane] = (int)(sm.slotmask[lane] >> 32);
+      }
+      if (lane < RPK_NKEYS / 4) B.keyslot[(size_t)env * (RPK_NKEYS / 4) + lane] = ((int*)sm.keyslot)[lane];
+      if (lane == 0) {
+        B.hdr[env * 4] = ncon; B.hdr[env * 4 + 1] = nkt;
+        B.hdr[env * 4 + 2] = (int)(dirty_mask & 0xffffffffu); B.hdr[env * 4 + 3] = (int)(dirty_mask >> 32);
+      }
+    }
+    }  // MODE 0
   }
 
   PROF(17);
   // ------------------------------------------------------------------ outputs
-  if (isl) { S.qpos[eo + ldof] = q[0]; S.qvel[eo + ldof] = qd[0]; S.warm[eo + ldof] = qw[0]; }
+  if constexpr (MODE == 0) {
 #pragma unroll
   for (int s = 0; s < 2; s++) if (isk[s]) {
-    S.qpos[eo + kdof[s]] = q[1 + s]; S.qvel[eo + kdof[s]] = qd[1 + s]; S.warm[eo + kdof[s]] = qw[1 + s];
     if (kact[s] >= 0) S.act_vel[(size_t)env * nu + kact[s]] = M.act_coef[2 * kact[s]] * qd[1 + s];
   }
   if (isa) S.act_vel[(size_t)env * nu + lane] = avel;
@@ -1934,15 +2045,20 @@ __global__ __launch_bounds__(64) void rp_step_kernel(RpModel<T> M, RpState<T> S,
     S.contact_geoms[((size_t)env * RPK_NCOUT + lane) * 2 + 1] = v ? sm.cgB[lane] : -1;
     S.contact_dist[(size_t)env * RPK_NCOUT + lane] = v ? sm.cdist[lane] : (T)0;
   }
+  }
   {
     int w = warn;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) w |= __shfl_xor(w, off, 64);
     if (lane == 0) {
       S.warn[env] |= w;
-      S.ncon[env] = ncon;
-      S.solver_iter[env] = (niter_last & 255) | ((__popcll(dirty_mask) & 255) << 8) | ((nkt & 255) << 16);
-      S.time[env] = time;
+      if constexpr (MODE == 0) S.ncon[env] = ncon;
+      if constexpr (MODE == 1) {
+        S.solver_iter[env] = (niter_last & 255) | ((__popcll(dirty_mask) & 255) << 8) | ((nkt & 255) << 16);
+        S.time[env] = time;
+      }
     }
   }
+#undef LF
+#undef LI
 }
