@@ -163,6 +163,9 @@ struct Engine : EngineBase {
     M.level_maxrank = upI(b.i("eng_level_maxrank")); M.link_anc = upI(b.i("eng_link_anc"));
     M.link_limited = upI(b.i("eng_link_limited")); M.link_act = upI(b.i("eng_link_act"));
     M.link_desc = upI(b.i("eng_link_desc"));
+    M.link_ndesc = upI(b.i("eng_link_ndesc")); M.tree_base = upI(b.i("eng_tree_base"));
+    M.tree_trunk = upI(b.i("eng_tree_trunk")); M.chain_first = upI(b.i("eng_chain_first"));
+    M.chain_len = upI(b.i("eng_chain_len"));
     M.link_ancmask = (const unsigned*)upI(b.i("eng_link_ancmask"));
     M.link_lpos = upF(b.f("eng_link_lpos"));
     {

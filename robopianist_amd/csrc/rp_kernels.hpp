@@ -41,7 +41,8 @@ struct RpModel {
   T timestep, gx, gy, gz, tolerance, ls_tolerance, meaninertia, key_zmax;
   // links
   const int *link_parent, *link_depth, *link_tree, *link_jtype, *link_dof, *link_sibrank,
-      *level_maxrank, *link_anc, *link_limited, *link_act, *link_desc;
+      *level_maxrank, *link_anc, *link_limited, *link_act, *link_desc, *link_ndesc, *tree_base,
+      *tree_trunk, *chain_first, *chain_len;
   const unsigned* link_ancmask;
   const T *link_lpos, *link_lmat, *link_axis, *link_anchor, *link_mass, *link_ipos,
       *link_inertia, *link_invw_body, *link_armature, *link_damping, *link_stiffness,
@@ -588,6 +589,28 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
   int anc[RPK_MAXD];
 #pragma unroll
   for (int k = 0; k < RPK_MAXD; k++) anc[k] = isl ? M.link_anc[L * RPK_MAXD + k] : -1;
+  // chain structure (lanes are in preorder: trunk chain, then up to 5 leaf chains)
+  const int tbase = isl ? M.tree_base[ltree] : 0, TL = isl ? M.tree_trunk[ltree] : 0;
+  int cf[5], cl[5];
+#pragma unroll
+  for (int c = 0; c < 5; c++) {
+    cf[c] = isl ? M.chain_first[ltree * 5 + c] : -1;
+    cl[c] = isl ? M.chain_len[ltree * 5 + c] : 0;
+  }
+  const int ndesc = isl ? M.link_ndesc[L] : 0;
+  int chain_end = 0;  // chain lanes: first depth past the end of my chain
+#pragma unroll
+  for (int c = 0; c < 5; c++) if (isl && lane >= cf[c] && lane < cf[c] + cl[c]) chain_end = TL + cl[c];
+  // lane of my ancestor at depth e (e <= depth), and of my descendants at depth d > depth
+  auto anc_at = [&](int e) -> int { return e < TL ? tbase + e : lane - (depth - e); };
+  auto desc_at = [&](int d, int c) -> int {
+    if (depth >= TL) return (c == 0 && d < chain_end) ? lane + (d - depth) : -1;
+    if (d < TL) return c == 0 ? tbase + d : -1;
+    const int o = d - TL;
+    const int first = c == 0 ? cf[0] : (c == 1 ? cf[1] : (c == 2 ? cf[2] : (c == 3 ? cf[3] : cf[4])));
+    const int len = c == 0 ? cl[0] : (c == 1 ? cl[1] : (c == 2 ? cl[2] : (c == 3 ? cl[3] : cl[4])));
+    return o < len ? first + o : -1;
+  };
   const int llimited = isl ? M.link_limited[L] : 0;
   const int lact = isl ? M.link_act[L] : -1;
   const T lactcoef = isl ? M.link_act_coef[L] : (T)0;
@@ -838,56 +861,47 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
         const bool isslot = !isl && lane < nl + nslots;
         const bool dirty = (dm >> lane) & 1;
         const int mydiag = isl ? depth : sdepth + 1;
+        if (isl || isslot) {
+#pragma unroll
+          for (int e = 0; e <= RPK_MAXD; e++) if (e <= mydiag) sm.R[lane][e] = Rr[e];
+        }
         T Dme = 1;
+        WSYNC();
+        // finalize this lane's row: D = diag, L = row / D
+        auto finalize = [&]() {
+          T Dk = sm.R[lane][mydiag];
+          if (!(Dk >= RPK_MINVAL)) { Dk = RPK_MINVAL; warn |= 4; }
+          Dme = Dk;
+          const T inv = (T)1 / Dk;
+          for (int e = 0; e < mydiag; e++) sm.R[lane][e] *= inv;
+          sm.Dg[lane] = Dk;
+        };
+        // subtract the Schur contribution of eliminated row k from this lane's row
+        auto pull = [&](int k) {
+          const T* Lk = sm.R[k];
+          const T t = Lk[depth] * sm.Dg[k];
+          for (int e = 0; e <= depth; e++) sm.R[lane][e] -= t * Lk[e];
+        };
         if (nslots > 0) {
-          if (isslot && !dirty) {
-            T Dk = 1;
-#pragma unroll
-            for (int e = 0; e <= RPK_MAXD; e++) if (e == mydiag) Dk = Rr[e];
-            if (!(Dk >= RPK_MINVAL)) { Dk = RPK_MINVAL; warn |= 4; }
-            Dme = Dk;
-            T inv = (T)1 / Dk;
-#pragma unroll
-            for (int e = 0; e < RPK_MAXD; e++) if (e < mydiag) { Rr[e] *= inv; sm.R[lane][e] = Rr[e]; }
-            sm.Dg[lane] = Dk;
-          }
+          if (isslot && !dirty) finalize();
           WSYNC();
           if (isl) {
-            for (int sidx = 0; sidx < nslots; sidx++) {
-              if (((sm.slotmask[sidx] >> lane) & 1) && !((dm >> (nl + sidx)) & 1)) {
-                const T* Lk = sm.R[nl + sidx];
-                T t = Lk[depth] * sm.Dg[nl + sidx];
-#pragma unroll
-                for (int e = 0; e < RPK_MAXD; e++) if (e <= depth) Rr[e] -= t * Lk[e];
-              }
-            }
+            for (int sidx = 0; sidx < nslots; sidx++)
+              if (((sm.slotmask[sidx] >> lane) & 1) && !((dm >> (nl + sidx)) & 1)) pull(nl + sidx);
           }
+          WSYNC();
         }
+        for (int d = M.maxdepth - 1; d >= 0; d--) {
+          if (isl && depth == d && !dirty) finalize();
+          WSYNC();
+          if (isl && depth < d) {
 #pragma unroll
-        for (int d = RPK_MAXD - 1; d >= 0; d--) {
-          if (d < M.maxdepth) {
-            if (isl && depth == d && !dirty) {
-              T Dk = Rr[d];
-              if (!(Dk >= RPK_MINVAL)) { Dk = RPK_MINVAL; warn |= 4; }
-              Dme = Dk;
-              T inv = (T)1 / Dk;
-#pragma unroll
-              for (int e = 0; e < RPK_MAXD; e++) if (e < d) { Rr[e] *= inv; sm.R[lane][e] = Rr[e]; }
-              sm.Dg[lane] = Dk;
-            }
-            WSYNC();
-            if (isl && depth < d) {
-              for (int r = 0; r < 5; r++) {
-                int k = sm.desc[(lane * RPK_MAXD + d) * 5 + r];
-                if (k < 0) break;
-                if ((dm >> k) & 1) continue;
-                const T* Lk = sm.R[k];
-                T t = Lk[depth] * sm.Dg[k];
-#pragma unroll
-                for (int e = 0; e < RPK_MAXD; e++) if (e <= depth) Rr[e] -= t * Lk[e];
-              }
+            for (int c = 0; c < 5; c++) {
+              const int k = desc_at(d, c);
+              if (k >= 0 && !((dm >> k) & 1)) pull(k);
             }
           }
+          WSYNC();
         }
         // ---- solve, part 1: x <- L^-T restricted to clean rows
         T x = (isl || isslot) ? rhs : (T)0;
@@ -903,11 +917,10 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           if (isl && depth == d && !dirty) sm.xs[lane] = x;
           WSYNC();
           if (isl && depth < d) {
-            for (int r = 0; r < 5; r++) {
-              int k = sm.desc[(lane * RPK_MAXD + d) * 5 + r];
-              if (k < 0) break;
-              if ((dm >> k) & 1) continue;
-              x -= sm.R[k][depth] * sm.xs[k];
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+              const int k = desc_at(d, c);
+              if (k >= 0 && !((dm >> k) & 1)) x -= sm.R[k][depth] * sm.xs[k];
             }
           }
         }
@@ -922,16 +935,14 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           WSYNC();
           if (dirty) {
             if (isl) {
-#pragma unroll
-              for (int e = 0; e < RPK_MAXD; e++) if (e <= depth) sm.H[tri(ci, cidx(anc[e]))] = Rr[e];
+              for (int e = 0; e <= depth; e++) sm.H[tri(ci, cidx(anc_at(e)))] = sm.R[lane][e];
             } else {
-              T Dk = 0;
-#pragma unroll
-              for (int e = 0; e <= RPK_MAXD; e++) if (e == mydiag) Dk = Rr[e];
-              sm.H[tri(ci, ci)] = Dk;
-#pragma unroll
-              for (int e = 0; e < RPK_MAXD; e++)
-                if (e <= sdepth && ((dm >> sanc[e]) & 1)) sm.H[tri(ci, cidx(sanc[e]))] = Rr[e];
+              sm.H[tri(ci, ci)] = sm.R[lane][mydiag];
+              const int al_ = sm.slotlink[lane - nl];
+              for (int e = 0; e <= sdepth; e++) {
+                const int a_ = M.link_anc[al_ * RPK_MAXD + e];
+                if ((dm >> a_) & 1) sm.H[tri(ci, cidx(a_))] = sm.R[lane][e];
+              }
             }
             sm.xs[ci] = x;
           }
@@ -949,20 +960,17 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
         }
         if (!dirty) x /= Dme;
         // ---- solve, part 2: forward substitution of the clean rows, root to leaves
-#pragma unroll
-        for (int d = 0; d < RPK_MAXD - 1; d++) {
-          if (d < M.maxdepth - 1) {
-            if (isl && depth == d) sm.xs[lane] = x;
-            WSYNC();
-            if (isl && depth > d && !dirty) x -= Rr[d] * sm.xs[anc[d]];
-          }
+        for (int d = 0; d < M.maxdepth - 1; d++) {
+          if (isl && depth == d) sm.xs[lane] = x;
+          WSYNC();
+          if (isl && depth > d && !dirty) x -= sm.R[lane][d] * sm.xs[anc_at(d)];
         }
         if (nslots > 0) {
           if (isl && depth == M.maxdepth - 1) sm.xs[lane] = x;
           WSYNC();
           if (isslot && !dirty) {
-#pragma unroll
-            for (int e = 0; e < RPK_MAXD; e++) if (e <= sdepth) x -= Rr[e] * sm.xs[sanc[e]];
+            const int al_ = sm.slotlink[lane - nl];
+            for (int e = 0; e <= sdepth; e++) x -= sm.R[lane][e] * sm.xs[M.link_anc[al_ * RPK_MAXD + e]];
           }
         }
         WSYNC();
@@ -1098,15 +1106,9 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
         WSYNC();
         T y = 0;
         if (isl) {
-#pragma unroll
-          for (int e = 0; e < RPK_MAXD; e++) if (e <= depth) y += Mr[e] * sm.xs[anc[e]];
-          for (int d = depth + 1; d < M.maxdepth; d++) {
-            for (int r = 0; r < 5; r++) {
-              int k = sm.desc[(lane * RPK_MAXD + d) * 5 + r];
-              if (k < 0) break;
-              y += sm.RM[k][depth] * sm.xs[k];
-            }
-          }
+          for (int e = 0; e <= depth; e++) y += sm.RM[lane][e] * sm.xs[anc_at(e)];
+          // descendants are the next `ndesc` lanes (preorder)
+          for (int j = 1; j <= ndesc; j++) y += sm.RM[lane + j][depth] * sm.xs[lane + j];
         }
         out[0] = y;
         out[1] = kM[0] * x[1];

@@ -125,6 +125,48 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
             desc[a, depth[k], c] = k
             dcount[a, depth[k]] += 1
             a = int(parent[a])
+    # chain structure used by the tree-sparse solver: each tree is a trunk chain (root ..
+    # first branching link) whose last link carries up to 5 leaf chains; lanes are in
+    # preorder, so a link's descendants are the next `ndesc` lanes.
+    MAXCH = 5
+    ndesc = np.zeros(nl, np.int32)
+    for k in range(nl):
+        a = int(parent[k])
+        while a >= 0:
+            ndesc[a] += 1
+            a = int(parent[a])
+    nchild = np.zeros(nl, np.int32)
+    for k in range(nl):
+        if parent[k] >= 0:
+            nchild[parent[k]] += 1
+    tree_base = np.zeros(max(ntree, 1), np.int32)
+    tree_trunk = np.zeros(max(ntree, 1), np.int32)
+    chain_first = np.full((max(ntree, 1), MAXCH), -1, np.int32)
+    chain_len = np.zeros((max(ntree, 1), MAXCH), np.int32)
+    for ti in range(ntree):
+        lanes = [i for i in range(nl) if tree_local[i] == ti]
+        assert lanes == list(range(lanes[0], lanes[0] + len(lanes))), "tree lanes must be contiguous"
+        tree_base[ti] = lanes[0]
+        i = lanes[0]
+        tl = 1
+        while nchild[i] == 1:
+            i += 1
+            tl += 1
+            assert parent[i] == i - 1
+        tree_trunk[ti] = tl
+        kids = [k for k in lanes if parent[k] == i]
+        assert len(kids) <= MAXCH, "more than 5 chains on one trunk"
+        for c, k0 in enumerate(kids):
+            ln = 1
+            k = k0
+            while nchild[k] == 1:
+                assert parent[k + 1] == k
+                k += 1
+                ln += 1
+            assert nchild[k] == 0, "chains must not branch"
+            chain_first[ti, c] = k0
+            chain_len[ti, c] = ln
+        assert tl + sum(chain_len[ti]) == len(lanes)
     # sibling rank (for deterministic child->parent accumulation)
     sibrank = np.zeros(nl, np.int32)
     cnt = {}
@@ -172,6 +214,11 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
     t["eng_link_anc"] = anc
     t["eng_link_ancmask"] = ancmask.view(np.int32)
     t["eng_link_desc"] = desc
+    t["eng_link_ndesc"] = ndesc
+    t["eng_tree_base"] = tree_base
+    t["eng_tree_trunk"] = tree_trunk
+    t["eng_chain_first"] = chain_first
+    t["eng_chain_len"] = chain_len
     t["eng_link_lpos"] = lpos; t["eng_link_lquat"] = lquat
     t["eng_link_axis"] = axis; t["eng_link_anchor"] = anchor
     t["eng_link_mass"] = mass; t["eng_link_ipos"] = ipos; t["eng_link_inertia"] = inertia
