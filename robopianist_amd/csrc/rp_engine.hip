@@ -166,6 +166,8 @@ struct Engine : EngineBase {
     M.link_ndesc = upI(b.i("eng_link_ndesc")); M.tree_base = upI(b.i("eng_tree_base"));
     M.tree_trunk = upI(b.i("eng_tree_trunk")); M.chain_first = upI(b.i("eng_chain_first"));
     M.chain_len = upI(b.i("eng_chain_len"));
+    for (int v : b.i("eng_tree_trunk")) if (v > 4) throw std::string("trunk chain longer than 4 links is not supported by the solver");
+    for (int v : b.i("eng_chain_len")) if (v > 5) throw std::string("finger chain longer than 5 links is not supported by the solver");
     M.link_ancmask = (const unsigned*)upI(b.i("eng_link_ancmask"));
     M.link_lpos = upF(b.f("eng_link_lpos"));
     {

@@ -598,9 +598,9 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
     cl[c] = isl ? M.chain_len[ltree * 5 + c] : 0;
   }
   const int ndesc = isl ? M.link_ndesc[L] : 0;
-  int chain_end = 0;  // chain lanes: first depth past the end of my chain
+  int chain_end = 0, mychain = 0;  // chain lanes: first depth past the end of my chain / chain index
 #pragma unroll
-  for (int c = 0; c < 5; c++) if (isl && lane >= cf[c] && lane < cf[c] + cl[c]) chain_end = TL + cl[c];
+  for (int c = 0; c < 5; c++) if (isl && lane >= cf[c] && lane < cf[c] + cl[c]) { chain_end = TL + cl[c]; mychain = c; }
   // lane of my ancestor at depth e (e <= depth), and of my descendants at depth d > depth
   auto anc_at = [&](int e) -> int { return e < TL ? tbase + e : lane - (depth - e); };
   auto desc_at = [&](int d, int c) -> int {
@@ -858,75 +858,189 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
       // an ancestor-closed set) receive the Schur complement and are solved with a
       // small dense Cholesky; `cross_fn(cidx)` adds the cross-contact blocks to it.
       auto tree_solve = [&](T* Rr, T rhs, int nslots, unsigned long long dm, auto&& cross_fn) -> T {
+        // Chain-blocked elimination.  Each tree is a trunk chain (<= 4 links) carrying up
+        // to five leaf chains (<= 5 links).  The first lane of every chain ("leader")
+        // gathers its chain's rows and eliminates the clean links, deepest first, entirely
+        // in registers; what that leaves on the trunk is summed per trunk row, the trunk
+        // leader eliminates the clean trunk links, the dense block (if any) solves the
+        // dirty rows, and the leaders back-substitute.  Same arithmetic as the level-by-
+        // level L^T D L, five LDS hand-overs instead of one per tree level.
         const bool isslot = !isl && lane < nl + nslots;
         const bool dirty = (dm >> lane) & 1;
         const int mydiag = isl ? depth : sdepth + 1;
         if (isl || isslot) {
 #pragma unroll
           for (int e = 0; e <= RPK_MAXD; e++) if (e <= mydiag) sm.R[lane][e] = Rr[e];
+          sm.xs[lane] = rhs;
         }
-        T Dme = 1;
+        T Dslot = 1;
         WSYNC();
-        // finalize this lane's row: D = diag, L = row / D
-        auto finalize = [&]() {
-          T Dk = sm.R[lane][mydiag];
-          if (!(Dk >= RPK_MINVAL)) { Dk = RPK_MINVAL; warn |= 4; }
-          Dme = Dk;
-          const T inv = (T)1 / Dk;
-          for (int e = 0; e < mydiag; e++) sm.R[lane][e] *= inv;
-          sm.Dg[lane] = Dk;
-        };
-        // subtract the Schur contribution of eliminated row k from this lane's row
-        auto pull = [&](int k) {
-          const T* Lk = sm.R[k];
-          const T t = Lk[depth] * sm.Dg[k];
-          for (int e = 0; e <= depth; e++) sm.R[lane][e] -= t * Lk[e];
-        };
+        // ---- key leaves first (they hang under chain links)
         if (nslots > 0) {
-          if (isslot && !dirty) finalize();
+          if (isslot && !dirty) {
+            T Dk = sm.R[lane][mydiag];
+            if (!(Dk >= RPK_MINVAL)) { Dk = RPK_MINVAL; warn |= 4; }
+            Dslot = Dk;
+            const T inv = (T)1 / Dk;
+            for (int e = 0; e < mydiag; e++) sm.R[lane][e] *= inv;
+            sm.Dg[lane] = Dk;
+          }
           WSYNC();
           if (isl) {
-            for (int sidx = 0; sidx < nslots; sidx++)
-              if (((sm.slotmask[sidx] >> lane) & 1) && !((dm >> (nl + sidx)) & 1)) pull(nl + sidx);
+            T xr = sm.xs[lane];
+            for (int sidx = 0; sidx < nslots; sidx++) {
+              if (((sm.slotmask[sidx] >> lane) & 1) && !((dm >> (nl + sidx)) & 1)) {
+                const T* Lk = sm.R[nl + sidx];
+                const T lk = Lk[depth];
+                const T t = lk * sm.Dg[nl + sidx];
+                for (int e = 0; e <= depth; e++) sm.R[lane][e] -= t * Lk[e];
+                xr -= lk * sm.xs[nl + sidx];
+              }
+            }
+            sm.xs[lane] = xr;
           }
           WSYNC();
         }
-        for (int d = M.maxdepth - 1; d >= 0; d--) {
-          if (isl && depth == d && !dirty) finalize();
-          WSYNC();
-          if (isl && depth < d) {
+        // ---- chain leaders: local variables 0..3 = trunk, 4..8 = my chain (depth order)
+        const bool leader = isl && depth == TL && TL > 0;
+        const int clen = chain_end - TL;
+        T Ac[5][9];   // Ac[ci][j]: chain link ci vs local variable j <= 4+ci
+        T rc_[5], inv_[5];
+        T dT[10], drT[4];  // what the eliminated links leave on the trunk block / rhs
+        int mc[5];
 #pragma unroll
-            for (int c = 0; c < 5; c++) {
-              const int k = desc_at(d, c);
-              if (k >= 0 && !((dm >> k) & 1)) pull(k);
+        for (int k = 0; k < 10; k++) dT[k] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) drT[k] = 0;
+        if (leader) {
+#pragma unroll
+          for (int ci = 0; ci < 5; ci++) {
+            const bool pi = ci < clen;
+            mc[ci] = pi && !((dm >> (lane + ci)) & 1);
+            rc_[ci] = pi ? sm.xs[lane + ci] : (T)0;
+#pragma unroll
+            for (int j = 0; j < 9; j++) {
+              if (j <= 4 + ci) {
+                const bool pj = j < 4 ? j < TL : (j - 4) < clen;
+                const int e = j < 4 ? j : TL + (j - 4);
+                Ac[ci][j] = (pi && pj) ? sm.R[lane + ci][e] : (j == 4 + ci ? (T)1 : (T)0);
+              }
             }
           }
-          WSYNC();
-        }
-        // ---- solve, part 1: x <- L^-T restricted to clean rows
-        T x = (isl || isslot) ? rhs : (T)0;
-        if (nslots > 0) {
-          if (isslot && !dirty) sm.xs[lane] = x;
-          WSYNC();
-          if (isl)
-            for (int sidx = 0; sidx < nslots; sidx++)
-              if (((sm.slotmask[sidx] >> lane) & 1) && !((dm >> (nl + sidx)) & 1))
-                x -= sm.R[nl + sidx][depth] * sm.xs[nl + sidx];
-        }
-        for (int d = M.maxdepth - 1; d >= 1; d--) {
-          if (isl && depth == d && !dirty) sm.xs[lane] = x;
-          WSYNC();
-          if (isl && depth < d) {
 #pragma unroll
-            for (int c = 0; c < 5; c++) {
-              const int k = desc_at(d, c);
-              if (k >= 0 && !((dm >> k) & 1)) x -= sm.R[k][depth] * sm.xs[k];
+          for (int ci = 4; ci >= 0; ci--) {
+            const int v = 4 + ci;
+            T dv = Ac[ci][v];
+            if (mc[ci] && !(dv >= RPK_MINVAL)) { dv = RPK_MINVAL; warn |= 4; }
+            const T iv = mc[ci] ? (T)1 / dv : (T)0;
+            inv_[ci] = iv;
+            T l[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) if (i < v) l[i] = Ac[ci][i] * iv;
+            // chain rows above me
+#pragma unroll
+            for (int ci2 = 0; ci2 < 4; ci2++) {
+              if (ci2 < ci) {
+                const int i = 4 + ci2;
+#pragma unroll
+                for (int j = 0; j < 9; j++) if (j <= i) Ac[ci2][j] -= l[i] * Ac[ci][j];
+                rc_[ci2] -= l[i] * rc_[ci];
+              }
+            }
+            // trunk block
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+#pragma unroll
+              for (int j = 0; j < 4; j++) if (j <= i) dT[i * (i + 1) / 2 + j] -= l[i] * Ac[ci][j];
+              drT[i] -= l[i] * rc_[ci];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) if (i < v && mc[ci]) Ac[ci][i] = l[i];
+          }
+          // rows / rhs of the links I did not eliminate go back for the dense block
+#pragma unroll
+          for (int ci = 0; ci < 5; ci++) {
+            if (ci < clen && !mc[ci]) {
+#pragma unroll
+              for (int j = 0; j < 9; j++) {
+                if (j <= 4 + ci) {
+                  const bool pj = j < 4 ? j < TL : (j - 4) < clen;
+                  const int e = j < 4 ? j : TL + (j - 4);
+                  if (pj) sm.R[lane + ci][e] = Ac[ci][j];
+                }
+              }
+              sm.xs[lane + ci] = rc_[ci];
+            }
+          }
+          // trunk deltas, one 14-entry record per chain (the dense block is not live yet)
+          T* rec = sm.H + (size_t)(ltree * 5 + mychain) * 14;
+#pragma unroll
+          for (int k = 0; k < 10; k++) rec[k] = dT[k];
+#pragma unroll
+          for (int k = 0; k < 4; k++) rec[10 + k] = drT[k];
+        }
+        WSYNC();
+        // ---- trunk rows collect the chains' contributions (fixed order: deterministic)
+        if (isl && depth < TL) {
+          T xr = sm.xs[lane];
+#pragma unroll
+          for (int c = 0; c < 5; c++) {
+            if ((c == 0 ? cl[0] : c == 1 ? cl[1] : c == 2 ? cl[2] : c == 3 ? cl[3] : cl[4]) > 0) {
+              const T* rec = sm.H + (size_t)(ltree * 5 + c) * 14;
+              for (int e = 0; e <= depth; e++) sm.R[lane][e] += rec[depth * (depth + 1) / 2 + e];
+              xr += rec[10 + depth];
+            }
+          }
+          sm.xs[lane] = xr;
+        }
+        WSYNC();
+        // ---- trunk leader eliminates the clean trunk links (deepest first)
+        const bool tleader = isl && depth == 0;
+        T At[4][4], rt[4], invt[4];
+        int mt[4];
+        if (tleader) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const bool pi = i < TL;
+            mt[i] = pi && !((dm >> (lane + i)) & 1);
+            rt[i] = pi ? sm.xs[lane + i] : (T)0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (j <= i) At[i][j] = pi ? sm.R[lane + i][j] : (j == i ? (T)1 : (T)0);
+          }
+#pragma unroll
+          for (int v = 3; v >= 0; v--) {
+            T dv = At[v][v];
+            if (mt[v] && !(dv >= RPK_MINVAL)) { dv = RPK_MINVAL; warn |= 4; }
+            const T iv = mt[v] ? (T)1 / dv : (T)0;
+            invt[v] = iv;
+            T l[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) if (i < v) l[i] = At[v][i] * iv;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+              if (i < v) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) if (j <= i) At[i][j] -= l[i] * At[v][j];
+                rt[i] -= l[i] * rt[v];
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) if (i < v && mt[v]) At[v][i] = l[i];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            if (i < TL && !mt[i]) {
+#pragma unroll
+              for (int j = 0; j < 4; j++) if (j <= i) sm.R[lane + i][j] = At[i][j];
+              sm.xs[lane + i] = rt[i];
             }
           }
         }
+        WSYNC();
         // ---- dense block on the dirty rows (Schur complement + cross-contact terms)
         if (dm && __popcll(dm) > RPK_HMAX) { warn |= 32; dm = 0; }  // cannot hold the block: drop cross terms
         if (dm) {
+          T x = (isl || isslot) ? sm.xs[lane] : (T)0;
           WSYNC();
           const int nD = __popcll(dm);
           auto cidx = [&](int l) -> int { return __popcll(dm & lanemask_lt(l)); };
@@ -944,31 +1058,60 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
                 if ((dm >> a_) & 1) sm.H[tri(ci, cidx(a_))] = sm.R[lane][e];
               }
             }
-            sm.xs[ci] = x;
           }
           WSYNC();
           cross_fn(cidx);
           WSYNC();
-          T xr = lane < nD ? sm.xs[lane] : (T)0;
+          // rhs of compact row r comes from the lane that owns it
+          if (dirty) sm.Dg[ci] = x;   // Dg of dirty rows is unused: staging for the compact rhs
+          WSYNC();
+          T xr = lane < nD ? sm.Dg[lane] : (T)0;
           WSYNC();
           chol_packed(sm.H, nD, lane, &warn);
           xr = solve_packed(sm.H, nD, lane, xr);
-          if (lane < nD) sm.xs[lane] = xr;
           WSYNC();
-          if (dirty) x = sm.xs[ci];
+          if (lane < nD) sm.Dg[lane] = xr;
+          WSYNC();
+          if (dirty) sm.xs[lane] = sm.Dg[ci];
           WSYNC();
         }
-        if (!dirty) x /= Dme;
-        // ---- solve, part 2: forward substitution of the clean rows, root to leaves
-        for (int d = 0; d < M.maxdepth - 1; d++) {
-          if (isl && depth == d) sm.xs[lane] = x;
-          WSYNC();
-          if (isl && depth > d && !dirty) x -= sm.R[lane][d] * sm.xs[anc_at(d)];
+        // ---- back-substitution: trunk leader, then chain leaders, then key leaves
+        if (tleader) {
+          T xt[4];
+#pragma unroll
+          for (int v = 0; v < 4; v++) {
+            if (mt[v]) {
+              T xv = rt[v] * invt[v];
+#pragma unroll
+              for (int i = 0; i < 3; i++) if (i < v) xv -= At[v][i] * xt[i];
+              xt[v] = xv;
+              sm.xs[lane + v] = xv;
+            } else xt[v] = v < TL ? sm.xs[lane + v] : (T)0;
+          }
         }
-        if (nslots > 0) {
-          if (isl && depth == M.maxdepth - 1) sm.xs[lane] = x;
-          WSYNC();
-          if (isslot && !dirty) {
+        WSYNC();
+        if (leader) {
+          T xl[9];
+#pragma unroll
+          for (int j = 0; j < 4; j++) xl[j] = j < TL ? sm.xs[tbase + j] : (T)0;
+#pragma unroll
+          for (int ci = 0; ci < 5; ci++) {
+            const int v = 4 + ci;
+            if (mc[ci]) {
+              T xv = rc_[ci] * inv_[ci];
+#pragma unroll
+              for (int i = 0; i < 8; i++) if (i < v) xv -= Ac[ci][i] * xl[i];
+              xl[v] = xv;
+              sm.xs[lane + ci] = xv;
+            } else xl[v] = ci < clen ? sm.xs[lane + ci] : (T)0;
+          }
+        }
+        WSYNC();
+        T x = isl ? sm.xs[lane] : (T)0;
+        if (isslot) {
+          x = sm.xs[lane];
+          if (!dirty) {
+            x = rhs / Dslot;
             const int al_ = sm.slotlink[lane - nl];
             for (int e = 0; e <= sdepth; e++) x -= sm.R[lane][e] * sm.xs[M.link_anc[al_ * RPK_MAXD + e]];
           }
