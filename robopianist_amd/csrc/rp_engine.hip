@@ -138,12 +138,12 @@ struct Engine : EngineBase {
     nenv = n_envs;
     M.nlink = nlink = b.i1("eng_nlink"); M.ntree = ntree = b.i1("eng_ntree");
     M.maxdepth = b.i1("eng_maxdepth"); M.nkey = nkey = b.i1("eng_nkey");
-    M.ngeom = b.i1("eng_ngeom"); M.npair = b.i1("eng_npair"); M.nkeycap = b.i1("eng_nkeycap");
+    M.ngeom = b.i1("eng_ngeom");
     M.nu = nu = b.i1("eng_nu"); M.nsite = nsite = b.i1("eng_nsite"); M.nv = nv = b.i1("nv");
     if (M.nlink > RPK_NL) throw std::string("too many hand dofs for the engine (max 52)");
     if (M.nkey > RPK_NKEYS) throw std::string("too many keys (max 128)");
     if (M.ngeom > RPK_WAVE) throw std::string("too many collision geoms (max 64)");
-    if (M.nu > RPK_WAVE + M.nkey) throw std::string("too many actuators");
+    if (M.nu > RPK_MAXACT) throw std::string("too many actuators");
     if (M.nsite > RPK_WAVE) throw std::string("too many sites (max 64)");
     if (M.maxdepth > RPK_MAXD) throw std::string("tree too deep (max 9 levels)");
     {
@@ -157,19 +157,28 @@ struct Engine : EngineBase {
     M.gx = (T)g[0]; M.gy = (T)g[1]; M.gz = (T)g[2];
     M.tolerance = (T)b.f1("opt_tolerance"); M.ls_tolerance = (T)b.f1("opt_ls_tolerance");
     M.meaninertia = (T)b.f1("stat_meaninertia");
-    M.link_parent = upI(b.i("eng_link_parent")); M.link_depth = upI(b.i("eng_link_depth"));
-    M.link_tree = upI(b.i("eng_link_tree")); M.link_jtype = upI(b.i("eng_link_jtype"));
-    M.link_dof = upI(b.i("eng_link_dof")); M.link_sibrank = upI(b.i("eng_link_sibrank"));
-    M.level_maxrank = upI(b.i("eng_level_maxrank")); M.link_anc = upI(b.i("eng_link_anc"));
-    M.link_limited = upI(b.i("eng_link_limited")); M.link_act = upI(b.i("eng_link_act"));
-    M.link_desc = upI(b.i("eng_link_desc"));
-    M.link_ndesc = upI(b.i("eng_link_ndesc")); M.tree_base = upI(b.i("eng_tree_base"));
-    M.tree_trunk = upI(b.i("eng_tree_trunk")); M.chain_first = upI(b.i("eng_chain_first"));
-    M.chain_len = upI(b.i("eng_chain_len"));
+    // ---- pack every model table into the two device arrays (RpLayout offsets)
+    std::vector<double> ft((size_t)RpLayout::F_TOTAL, 0.0);
+    std::vector<int> it((size_t)RpLayout::I_TOTAL, 0);
+    auto putF = [&](int off, int cap, const std::vector<double>& v, const char* name) {
+      if ((int)v.size() > cap) throw std::string("model table too large: ") + name;
+      for (size_t i = 0; i < v.size(); i++) ft[(size_t)off + i] = v[i];
+    };
+    auto putI = [&](int off, int cap, const std::vector<int>& v, const char* name) {
+      if ((int)v.size() > cap) throw std::string("model table too large: ") + name;
+      for (size_t i = 0; i < v.size(); i++) it[(size_t)off + i] = v[i];
+    };
+#define PF(name, blobname) putF(RpLayout::F_##name, RpLayout::F_##name##_end - RpLayout::F_##name + 1, b.f(blobname), blobname)
+#define PI(name, blobname) putI(RpLayout::I_##name, RpLayout::I_##name##_end - RpLayout::I_##name + 1, b.i(blobname), blobname)
+    PI(link_parent, "eng_link_parent"); PI(link_depth, "eng_link_depth"); PI(link_tree, "eng_link_tree");
+    PI(link_jtype, "eng_link_jtype"); PI(link_dof, "eng_link_dof"); PI(link_sibrank, "eng_link_sibrank");
+    PI(level_maxrank, "eng_level_maxrank"); PI(link_anc, "eng_link_anc"); PI(link_limited, "eng_link_limited");
+    PI(link_act, "eng_link_act"); PI(link_desc, "eng_link_desc"); PI(link_ndesc, "eng_link_ndesc");
+    PI(tree_base, "eng_tree_base"); PI(tree_trunk, "eng_tree_trunk"); PI(chain_first, "eng_chain_first");
+    PI(chain_len, "eng_chain_len"); PI(link_ancmask, "eng_link_ancmask");
     for (int v : b.i("eng_tree_trunk")) if (v > 4) throw std::string("trunk chain longer than 4 links is not supported by the solver");
     for (int v : b.i("eng_chain_len")) if (v > 5) throw std::string("finger chain longer than 5 links is not supported by the solver");
-    M.link_ancmask = (const unsigned*)upI(b.i("eng_link_ancmask"));
-    M.link_lpos = upF(b.f("eng_link_lpos"));
+    PF(link_lpos, "eng_link_lpos");
     {
       auto q = b.f("eng_link_lquat");
       std::vector<double> m(9 * (size_t)M.nlink);
@@ -180,23 +189,19 @@ struct Engine : EngineBase {
         o[3] = 2 * (x * y + w * z); o[4] = 1 - 2 * (x * x + z * z); o[5] = 2 * (y * z - w * x);
         o[6] = 2 * (x * z - w * y); o[7] = 2 * (y * z + w * x); o[8] = 1 - 2 * (x * x + y * y);
       }
-      M.link_lmat = upF(m);
+      putF(RpLayout::F_link_lmat, RPK_NL * 9, m, "link_lmat");
     }
-    M.link_axis = upF(b.f("eng_link_axis")); M.link_anchor = upF(b.f("eng_link_anchor"));
-    M.link_mass = upF(b.f("eng_link_mass")); M.link_ipos = upF(b.f("eng_link_ipos"));
-    M.link_inertia = upF(b.f("eng_link_inertia")); M.link_invw_body = upF(b.f("eng_link_invw_body"));
-    M.link_armature = upF(b.f("eng_link_armature")); M.link_damping = upF(b.f("eng_link_damping"));
-    M.link_stiffness = upF(b.f("eng_link_stiffness")); M.link_springref = upF(b.f("eng_link_springref"));
-    M.link_floss = upF(b.f("eng_link_floss")); M.link_fl_R = upF(b.f("eng_link_fl_R"));
-    M.link_fl_B = upF(b.f("eng_link_fl_B")); M.link_range = upF(b.f("eng_link_range"));
-    M.link_lim_K = upF(b.f("eng_link_lim_K")); M.link_lim_B = upF(b.f("eng_link_lim_B"));
-    M.link_lim_solimp = upF(b.f("eng_link_lim_solimp")); M.link_invw_dof = upF(b.f("eng_link_invw_dof"));
-    M.link_act_coef = upF(b.f("eng_link_act_coef"));
-    M.tree_gscale = upF(b.f("eng_tree_gscale")); M.tree_ref = upF(b.f("eng_tree_ref"));
-    M.key_dof = upI(b.i("eng_key_dof")); M.key_act = upI(b.i("eng_key_act"));
-    M.key_geomid = upI(b.i("eng_key_geomid"));
+    PF(link_axis, "eng_link_axis"); PF(link_anchor, "eng_link_anchor"); PF(link_mass, "eng_link_mass");
+    PF(link_ipos, "eng_link_ipos"); PF(link_inertia, "eng_link_inertia"); PF(link_invw_body, "eng_link_invw_body");
+    PF(link_armature, "eng_link_armature"); PF(link_damping, "eng_link_damping");
+    PF(link_stiffness, "eng_link_stiffness"); PF(link_springref, "eng_link_springref");
+    PF(link_floss, "eng_link_floss"); PF(link_fl_R, "eng_link_fl_R"); PF(link_fl_B, "eng_link_fl_B");
+    PF(link_range, "eng_link_range"); PF(link_lim_K, "eng_link_lim_K"); PF(link_lim_B, "eng_link_lim_B");
+    PF(link_lim_solimp, "eng_link_lim_solimp"); PF(link_invw_dof, "eng_link_invw_dof");
+    PF(link_act_coef, "eng_link_act_coef"); PF(tree_gscale, "eng_tree_gscale"); PF(tree_ref, "eng_tree_ref");
+    PI(key_dof, "eng_key_dof"); PI(key_act, "eng_key_act"); PI(key_geomid, "eng_key_geomid");
     auto kpos = b.f("eng_key_pos"), khalf = b.f("eng_key_half");
-    M.key_pos = upF(kpos); M.key_half = upF(khalf);
+    PF(key_pos, "eng_key_pos"); PF(key_half, "eng_key_half");
     {
       std::vector<double> rb((size_t)M.nkey);
       double zmax = -1e30;
@@ -206,27 +211,26 @@ struct Engine : EngineBase {
         // the key box centre moves on a circle of radius hx about the hinge
         zmax = std::max(zmax, kpos[3 * k + 2] + khalf[3 * k] + rb[k]);
       }
-      M.key_rbound = upF(rb);
+      putF(RpLayout::F_key_rbound, RPK_NKEYS, rb, "key_rbound");
       M.key_zmax = (T)zmax;
     }
-    M.key_mass = upF(b.f("eng_key_mass")); M.key_M = upF(b.f("eng_key_M"));
-    M.key_stiffness = upF(b.f("eng_key_stiffness")); M.key_springref = upF(b.f("eng_key_springref"));
-    M.key_damping = upF(b.f("eng_key_damping")); M.key_range = upF(b.f("eng_key_range"));
-    M.key_lim_K = upF(b.f("eng_key_lim_K")); M.key_lim_B = upF(b.f("eng_key_lim_B"));
-    M.key_lim_solimp = upF(b.f("eng_key_lim_solimp")); M.key_invw_dof = upF(b.f("eng_key_invw_dof"));
-    M.key_invw_body = upF(b.f("eng_key_invw_body")); M.key_cparam = upF(b.f("eng_key_cparam"));
-    M.geom_link = upI(b.i("eng_geom_link")); M.geom_type = upI(b.i("eng_geom_type"));
-    M.geom_modelid = upI(b.i("eng_geom_modelid")); M.pair = upI(b.i("eng_pair"));
-    M.keycap = upI(b.i("eng_keycap"));
-    M.geom_size = upF(b.f("eng_geom_size")); M.geom_pos = upF(b.f("eng_geom_pos"));
-    M.geom_mat = upF(b.f("eng_geom_mat")); M.geom_rbound = upF(b.f("eng_geom_rbound"));
-    M.geom_invw = upF(b.f("eng_geom_invw")); M.geom_cparam = upF(b.f("eng_geom_cparam"));
-    M.act_kind = upI(b.i("eng_act_kind")); M.act_lane = upI(b.i("eng_act_lane"));
-    M.act_ctrllimited = upI(b.i("eng_act_ctrllimited")); M.act_forcelimited = upI(b.i("eng_act_forcelimited"));
-    M.act_coef = upF(b.f("eng_act_coef")); M.act_gain = upF(b.f("eng_act_gain"));
-    M.act_bias = upF(b.f("eng_act_bias")); M.act_ctrlrange = upF(b.f("eng_act_ctrlrange"));
-    M.act_forcerange = upF(b.f("eng_act_forcerange"));
-    M.site_link = upI(b.i("eng_site_link")); M.site_pos = upF(b.f("eng_site_pos"));
+    PF(key_mass, "eng_key_mass"); PF(key_M, "eng_key_M"); PF(key_stiffness, "eng_key_stiffness");
+    PF(key_springref, "eng_key_springref"); PF(key_damping, "eng_key_damping"); PF(key_range, "eng_key_range");
+    PF(key_lim_K, "eng_key_lim_K"); PF(key_lim_B, "eng_key_lim_B"); PF(key_lim_solimp, "eng_key_lim_solimp");
+    PF(key_invw_dof, "eng_key_invw_dof"); PF(key_invw_body, "eng_key_invw_body"); PF(key_cparam, "eng_key_cparam");
+    PI(geom_link, "eng_geom_link"); PI(geom_type, "eng_geom_type"); PI(geom_modelid, "eng_geom_modelid");
+    PI(geom_pairmask, "eng_geom_pairmask"); PI(geom_iskeycap, "eng_geom_iskeycap");
+    PF(geom_size, "eng_geom_size"); PF(geom_pos, "eng_geom_pos"); PF(geom_mat, "eng_geom_mat");
+    PF(geom_rbound, "eng_geom_rbound"); PF(geom_invw, "eng_geom_invw"); PF(geom_cparam, "eng_geom_cparam");
+    PI(act_kind, "eng_act_kind"); PI(act_lane, "eng_act_lane"); PI(act_ctrllimited, "eng_act_ctrllimited");
+    PI(act_forcelimited, "eng_act_forcelimited");
+    PF(act_coef, "eng_act_coef"); PF(act_gain, "eng_act_gain"); PF(act_bias, "eng_act_bias");
+    PF(act_ctrlrange, "eng_act_ctrlrange"); PF(act_forcerange, "eng_act_forcerange");
+    PI(site_link, "eng_site_link"); PF(site_pos, "eng_site_pos");
+#undef PF
+#undef PI
+    M.ft = upF(ft);
+    M.it = upI(it);
     {
       auto q0 = b.f("qpos0");
       qpos0.assign(q0.begin(), q0.end());

@@ -34,34 +34,76 @@
 #define GEOM_CAPSULE_ 3
 #define GEOM_BOX_ 6
 
+// All model tables live in TWO device arrays (one of T, one of int) at compile-time
+// offsets (tables are padded to their maximum item counts).  A table access is then
+// `base pointer + immediate`, instead of one kernarg pointer load per table: with ~80
+// tables the pointers do not fit in SGPRs, and every re-load costs an s_waitcnt
+// lgkmcnt(0) that also drains the LDS queue.
+#define RPK_MAXACT 192
+#define RPK_MAXTREE 4
+//      name            items        stride
+#define RPK_FTABLES(X) \
+  X(link_lpos,        RPK_NL,      3) X(link_lmat,       RPK_NL,      9) X(link_axis,      RPK_NL, 3) \
+  X(link_anchor,      RPK_NL,      3) X(link_mass,       RPK_NL,      1) X(link_ipos,      RPK_NL, 3) \
+  X(link_inertia,     RPK_NL,      6) X(link_invw_body,  RPK_NL,      1) X(link_armature,  RPK_NL, 1) \
+  X(link_damping,     RPK_NL,      1) X(link_stiffness,  RPK_NL,      1) X(link_springref, RPK_NL, 1) \
+  X(link_floss,       RPK_NL,      1) X(link_fl_R,       RPK_NL,      1) X(link_fl_B,      RPK_NL, 1) \
+  X(link_range,       RPK_NL,      2) X(link_lim_K,      RPK_NL,      1) X(link_lim_B,     RPK_NL, 1) \
+  X(link_lim_solimp,  RPK_NL,      5) X(link_invw_dof,   RPK_NL,      1) X(link_act_coef,  RPK_NL, 1) \
+  X(tree_gscale,      RPK_MAXTREE, 1) X(tree_ref,        RPK_MAXTREE, 3) \
+  X(key_pos,          RPK_NKEYS,   3) X(key_half,        RPK_NKEYS,   3) X(key_mass,       RPK_NKEYS, 1) \
+  X(key_M,            RPK_NKEYS,   1) X(key_stiffness,   RPK_NKEYS,   1) X(key_springref,  RPK_NKEYS, 1) \
+  X(key_damping,      RPK_NKEYS,   1) X(key_range,       RPK_NKEYS,   2) X(key_lim_K,      RPK_NKEYS, 1) \
+  X(key_lim_B,        RPK_NKEYS,   1) X(key_lim_solimp,  RPK_NKEYS,   5) X(key_invw_dof,   RPK_NKEYS, 1) \
+  X(key_invw_body,    RPK_NKEYS,   1) X(key_rbound,      RPK_NKEYS,   1) X(key_cparam,     1,         8) \
+  X(geom_size,        RPK_WAVE,    3) X(geom_pos,        RPK_WAVE,    3) X(geom_mat,       RPK_WAVE,  9) \
+  X(geom_rbound,      RPK_WAVE,    1) X(geom_invw,       RPK_WAVE,    1) X(geom_cparam,    RPK_WAVE,  8) \
+  X(act_coef,         RPK_MAXACT,  2) X(act_gain,        RPK_MAXACT,  1) X(act_bias,       RPK_MAXACT, 3) \
+  X(act_ctrlrange,    RPK_MAXACT,  2) X(act_forcerange,  RPK_MAXACT,  2) X(site_pos,       RPK_WAVE,  3)
+#define RPK_ITABLES(X) \
+  X(link_parent,  RPK_NL, 1) X(link_depth,   RPK_NL, 1) X(link_tree,    RPK_NL, 1) X(link_jtype,  RPK_NL, 1) \
+  X(link_dof,     RPK_NL, 1) X(link_sibrank, RPK_NL, 1) X(link_limited, RPK_NL, 1) X(link_act,    RPK_NL, 1) \
+  X(link_ndesc,   RPK_NL, 1) X(link_anc,     RPK_NL, RPK_MAXD) X(link_ancmask, RPK_NL, 2) \
+  X(link_desc,    RPK_NL, RPK_MAXD * 5) X(level_maxrank, 1, RPK_MAXD) \
+  X(tree_base,    RPK_MAXTREE, 1) X(tree_trunk, RPK_MAXTREE, 1) X(chain_first, RPK_MAXTREE, 5) \
+  X(chain_len,    RPK_MAXTREE, 5) \
+  X(key_dof,      RPK_NKEYS, 1) X(key_act,   RPK_NKEYS, 1) X(key_geomid, RPK_NKEYS, 1) \
+  X(geom_link,    RPK_WAVE, 1) X(geom_type,  RPK_WAVE, 1) X(geom_modelid, RPK_WAVE, 1) \
+  X(geom_pairmask, RPK_WAVE, 2) X(geom_iskeycap, RPK_WAVE, 1) \
+  X(act_kind,     RPK_MAXACT, 1) X(act_lane, RPK_MAXACT, 2) X(act_ctrllimited, RPK_MAXACT, 1) \
+  X(act_forcelimited, RPK_MAXACT, 1) X(site_link, RPK_WAVE, 1)
+
+struct RpLayout {
+  enum : int {
+#define X(name, items, stride) F_##name, F_##name##_end = F_##name + (items) * (stride) - 1,
+    RPK_FTABLES(X)
+#undef X
+    F_TOTAL,
+#define X(name, items, stride) I_##name, I_##name##_end = I_##name + (items) * (stride) - 1,
+    RPK_ITABLES(X)
+#undef X
+    I_TOTAL
+  };
+};
+
 template <typename T>
 struct RpModel {
-  int nlink, ntree, maxdepth, nkey, ngeom, npair, nkeycap, nu, nsite, nv;
+  int nlink, ntree, maxdepth, nkey, ngeom, nu, nsite, nv;
   int iterations, ls_iterations;
   T timestep, gx, gy, gz, tolerance, ls_tolerance, meaninertia, key_zmax;
-  // links
-  const int *link_parent, *link_depth, *link_tree, *link_jtype, *link_dof, *link_sibrank,
-      *level_maxrank, *link_anc, *link_limited, *link_act, *link_desc, *link_ndesc, *tree_base,
-      *tree_trunk, *chain_first, *chain_len;
-  const unsigned* link_ancmask;
-  const T *link_lpos, *link_lmat, *link_axis, *link_anchor, *link_mass, *link_ipos,
-      *link_inertia, *link_invw_body, *link_armature, *link_damping, *link_stiffness,
-      *link_springref, *link_floss, *link_fl_R, *link_fl_B, *link_range, *link_lim_K,
-      *link_lim_B, *link_lim_solimp, *link_invw_dof, *link_act_coef, *tree_gscale, *tree_ref;
-  // keys
-  const int *key_dof, *key_act;
-  const T *key_pos, *key_half, *key_mass, *key_M, *key_stiffness, *key_springref,
-      *key_damping, *key_range, *key_lim_K, *key_lim_B, *key_lim_solimp, *key_invw_dof,
-      *key_invw_body, *key_cparam, *key_rbound;
-  // geoms
-  const int *geom_link, *geom_type, *geom_modelid, *pair, *keycap, *key_geomid;
-  const T *geom_size, *geom_pos, *geom_mat, *geom_rbound, *geom_invw, *geom_cparam;
-  // actuators
-  const int *act_kind, *act_lane, *act_ctrllimited, *act_forcelimited;
-  const T *act_coef, *act_gain, *act_bias, *act_ctrlrange, *act_forcerange;
-  // sites
-  const int* site_link;
-  const T* site_pos;
+  const T* ft;    // RpLayout::F_* offsets
+  const int* it;  // RpLayout::I_* offsets
+#define X(name, items, stride) \
+  __device__ __forceinline__ const T* name() const { return ft + RpLayout::F_##name; }
+  RPK_FTABLES(X)
+#undef X
+#define X(name, items, stride) \
+  __device__ __forceinline__ const int* name() const { return it + RpLayout::I_##name; }
+  RPK_ITABLES(X)
+#undef X
+  __device__ __forceinline__ const unsigned* link_ancmask_u() const {
+    return (const unsigned*)(it + RpLayout::I_link_ancmask);
+  }
 };
 
 template <typename T>
@@ -84,12 +126,14 @@ struct RpState {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
     __builtin_amdgcn_wave_barrier();                         \
   } while (0)
-#define RPK_NPROF 24
+#define RPK_NPROF 32
+// Per-phase shader-clock counters of env 0 (debug aid), accumulated in LDS so a probe
+// costs about one LDS round trip; flushed to global memory once at kernel exit.
 #define PROF(i)                                                         \
   do {                                                                  \
     if (S.prof && env == 0) {                                           \
       long long t_ = (long long)__builtin_readcyclecounter();           \
-      if (lane == 0) S.prof[i] += t_ - prof_t;                          \
+      if (lane == 0) sm.prof[i] += t_ - prof_t;                         \
       prof_t = t_;                                                      \
     }                                                                   \
   } while (0)
@@ -427,6 +471,7 @@ struct Smem {
   short slotlink[16];
   signed char keyslot[RPK_NKEYS];
   signed char desc[RPK_NL * RPK_MAXD * 5];
+  long long prof[RPK_NPROF];
 };
 
 // rows owned by one lane: friction-loss row of its hand dof, one limit row per dof
@@ -573,6 +618,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
   if (S.active && S.active[env] == 0) return;
   __shared__ Smem<T> sm;
   int warn = 0;
+  if (S.prof && env == 0 && lane < RPK_NPROF) sm.prof[lane] = 0;
   long long prof_t = (long long)__builtin_readcyclecounter();
   const int nl = M.nlink, nk = M.nkey, nv = M.nv, nu = M.nu;
   const T h = M.timestep;
@@ -580,24 +626,24 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
   // ------------------------------------------------------------ lane constants
   const bool isl = lane < nl;
   const int L = isl ? lane : 0;
-  const int parent = isl ? M.link_parent[L] : -1;
-  const int depth = isl ? M.link_depth[L] : -1;
-  const int jtype = M.link_jtype ? (isl ? M.link_jtype[L] : 0) : 0;
-  const int sibrank = isl ? M.link_sibrank[L] : 0;
-  const int ltree = isl ? M.link_tree[L] : 0;
-  const int ldof = isl ? M.link_dof[L] : 0;
+  const int parent = isl ? M.link_parent()[L] : -1;
+  const int depth = isl ? M.link_depth()[L] : -1;
+  const int jtype = isl ? M.link_jtype()[L] : 0;
+  const int sibrank = isl ? M.link_sibrank()[L] : 0;
+  const int ltree = isl ? M.link_tree()[L] : 0;
+  const int ldof = isl ? M.link_dof()[L] : 0;
   int anc[RPK_MAXD];
 #pragma unroll
-  for (int k = 0; k < RPK_MAXD; k++) anc[k] = isl ? M.link_anc[L * RPK_MAXD + k] : -1;
+  for (int k = 0; k < RPK_MAXD; k++) anc[k] = isl ? M.link_anc()[L * RPK_MAXD + k] : -1;
   // chain structure (lanes are in preorder: trunk chain, then up to 5 leaf chains)
-  const int tbase = isl ? M.tree_base[ltree] : 0, TL = isl ? M.tree_trunk[ltree] : 0;
+  const int tbase = isl ? M.tree_base()[ltree] : 0, TL = isl ? M.tree_trunk()[ltree] : 0;
   int cf[5], cl[5];
 #pragma unroll
   for (int c = 0; c < 5; c++) {
-    cf[c] = isl ? M.chain_first[ltree * 5 + c] : -1;
-    cl[c] = isl ? M.chain_len[ltree * 5 + c] : 0;
+    cf[c] = isl ? M.chain_first()[ltree * 5 + c] : -1;
+    cl[c] = isl ? M.chain_len()[ltree * 5 + c] : 0;
   }
-  const int ndesc = isl ? M.link_ndesc[L] : 0;
+  const int ndesc = isl ? M.link_ndesc()[L] : 0;
   int chain_end = 0, mychain = 0;  // chain lanes: first depth past the end of my chain / chain index
 #pragma unroll
   for (int c = 0; c < 5; c++) if (isl && lane >= cf[c] && lane < cf[c] + cl[c]) { chain_end = TL + cl[c]; mychain = c; }
@@ -611,10 +657,10 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
     const int len = c == 0 ? cl[0] : (c == 1 ? cl[1] : (c == 2 ? cl[2] : (c == 3 ? cl[3] : cl[4])));
     return o < len ? first + o : -1;
   };
-  const int llimited = isl ? M.link_limited[L] : 0;
-  const int lact = isl ? M.link_act[L] : -1;
-  const T lactcoef = isl ? M.link_act_coef[L] : (T)0;
-  const T gscale = (isl && nl) ? M.tree_gscale[ltree] : (T)0;
+  const int llimited = isl ? M.link_limited()[L] : 0;
+  const int lact = isl ? M.link_act()[L] : -1;
+  const T lactcoef = isl ? M.link_act_coef()[L] : (T)0;
+  const T gscale = (isl && nl) ? M.tree_gscale()[ltree] : (T)0;
   int hasdof[3];
   hasdof[0] = isl && llimited; hasdof[1] = lane < nk; hasdof[2] = lane + 64 < nk;
   const bool isk[2] = {lane < nk, lane + 64 < nk};
@@ -622,8 +668,8 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
   int kdof[2], kact[2];
 #pragma unroll
   for (int s = 0; s < 2; s++) {
-    kdof[s] = isk[s] ? M.key_dof[kid[s]] : 0;
-    kact[s] = isk[s] ? M.key_act[kid[s]] : -1;
+    kdof[s] = isk[s] ? M.key_dof()[kid[s]] : 0;
+    kact[s] = isk[s] ? M.key_act()[kid[s]] : -1;
   }
 // Per-lane model constants are re-read from the (L2-resident) tables inside the stage
 // that uses them instead of being pinned in registers for the whole kernel: the kernel
@@ -633,11 +679,11 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
   T lpos[3], lmat[9], laxis[3], lanchor[3], lipos[3], linert[6], tref[3];                  \
   T kpos[2][3], khalf[2][3], krb[2];                                                       \
   {                                                                                        \
-    const T *p_lpos = fresh(M.link_lpos), *p_axis = fresh(M.link_axis),                    \
-            *p_anchor = fresh(M.link_anchor), *p_ipos = fresh(M.link_ipos),                \
-            *p_tref = fresh(M.tree_ref), *p_lmat = fresh(M.link_lmat),                     \
-            *p_inert = fresh(M.link_inertia), *p_kpos = fresh(M.key_pos),                  \
-            *p_khalf = fresh(M.key_half), *p_krb = fresh(M.key_rbound);                    \
+    const T *p_lpos = fresh(M.link_lpos()), *p_axis = fresh(M.link_axis()),                    \
+            *p_anchor = fresh(M.link_anchor()), *p_ipos = fresh(M.link_ipos()),                \
+            *p_tref = fresh(M.tree_ref()), *p_lmat = fresh(M.link_lmat()),                     \
+            *p_inert = fresh(M.link_inertia()), *p_kpos = fresh(M.key_pos()),                  \
+            *p_khalf = fresh(M.key_half()), *p_krb = fresh(M.key_rbound());                    \
     _Pragma("unroll") for (int k = 0; k < 3; k++) {                                        \
       lpos[k] = isl ? p_lpos[3 * L + k] : (T)0;                                            \
       laxis[k] = isl ? p_axis[3 * L + k] : (T)0;                                           \
@@ -660,47 +706,47 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
       }                                                                                    \
     }                                                                                      \
   }                                                                                        \
-  const T lmass = isl ? fresh(M.link_mass)[L] : (T)0;                                      \
-  const T larm = isl ? fresh(M.link_armature)[L] : (T)0;
+  const T lmass = isl ? fresh(M.link_mass())[L] : (T)0;                                      \
+  const T larm = isl ? fresh(M.link_armature())[L] : (T)0;
 #define RPK_LOAD_LIMITS                                                                    \
   T lo[3], hi[3], limK[3], limB[3], limW[3];                                               \
   {                                                                                        \
-    const T *p_lr = fresh(M.link_range), *p_kr = fresh(M.key_range);                       \
+    const T *p_lr = fresh(M.link_range()), *p_kr = fresh(M.key_range());                       \
     lo[0] = isl ? p_lr[2 * L] : (T)0; hi[0] = isl ? p_lr[2 * L + 1] : (T)0;                \
-    limK[0] = isl ? fresh(M.link_lim_K)[L] : (T)0;                                         \
-    limB[0] = isl ? fresh(M.link_lim_B)[L] : (T)0;                                         \
-    limW[0] = isl ? fresh(M.link_invw_dof)[L] : (T)0;                                      \
+    limK[0] = isl ? fresh(M.link_lim_K())[L] : (T)0;                                         \
+    limB[0] = isl ? fresh(M.link_lim_B())[L] : (T)0;                                         \
+    limW[0] = isl ? fresh(M.link_invw_dof())[L] : (T)0;                                      \
     _Pragma("unroll") for (int s = 0; s < 2; s++) {                                        \
       const int K = isk[s] ? kid[s] : 0;                                                   \
       lo[1 + s] = isk[s] ? p_kr[2 * K] : (T)0; hi[1 + s] = isk[s] ? p_kr[2 * K + 1] : (T)0; \
-      limK[1 + s] = isk[s] ? fresh(M.key_lim_K)[K] : (T)0;                                 \
-      limB[1 + s] = isk[s] ? fresh(M.key_lim_B)[K] : (T)0;                                 \
-      limW[1 + s] = isk[s] ? fresh(M.key_invw_dof)[K] : (T)0;                              \
+      limK[1 + s] = isk[s] ? fresh(M.key_lim_K())[K] : (T)0;                                 \
+      limB[1 + s] = isk[s] ? fresh(M.key_lim_B())[K] : (T)0;                                 \
+      limW[1 + s] = isk[s] ? fresh(M.key_invw_dof())[K] : (T)0;                              \
     }                                                                                      \
   }                                                                                        \
-  const T lflB = isl ? fresh(M.link_fl_B)[L] : (T)0;
+  const T lflB = isl ? fresh(M.link_fl_B())[L] : (T)0;
 #define RPK_LOAD_DYN                                                                       \
-  const T ldamp = isl ? fresh(M.link_damping)[L] : (T)0;                                   \
-  const T lstiff = isl ? fresh(M.link_stiffness)[L] : (T)0;                                \
-  const T lsref = isl ? fresh(M.link_springref)[L] : (T)0;                                 \
-  const T lfloss = isl ? fresh(M.link_floss)[L] : (T)0;                                    \
-  const T lflR = isl ? fresh(M.link_fl_R)[L] : (T)1;                                       \
+  const T ldamp = isl ? fresh(M.link_damping())[L] : (T)0;                                   \
+  const T lstiff = isl ? fresh(M.link_stiffness())[L] : (T)0;                                \
+  const T lsref = isl ? fresh(M.link_springref())[L] : (T)0;                                 \
+  const T lfloss = isl ? fresh(M.link_floss())[L] : (T)0;                                    \
+  const T lflR = isl ? fresh(M.link_fl_R())[L] : (T)1;                                       \
   const T lflD = (T)1 / lflR;                                                              \
   T kM[2], kstiff[2], ksref[2], kdamp[2], kmass[2], khx[2];                                \
   _Pragma("unroll") for (int s = 0; s < 2; s++) {                                          \
     const int K = isk[s] ? kid[s] : 0;                                                     \
-    kM[s] = isk[s] ? fresh(M.key_M)[K] : (T)1;                                             \
-    kstiff[s] = isk[s] ? fresh(M.key_stiffness)[K] : (T)0;                                 \
-    ksref[s] = isk[s] ? fresh(M.key_springref)[K] : (T)0;                                  \
-    kdamp[s] = isk[s] ? fresh(M.key_damping)[K] : (T)0;                                    \
-    kmass[s] = isk[s] ? fresh(M.key_mass)[K] : (T)0;                                       \
-    khx[s] = isk[s] ? fresh(M.key_half)[3 * K] : (T)0;                                     \
+    kM[s] = isk[s] ? fresh(M.key_M())[K] : (T)1;                                             \
+    kstiff[s] = isk[s] ? fresh(M.key_stiffness())[K] : (T)0;                                 \
+    ksref[s] = isk[s] ? fresh(M.key_springref())[K] : (T)0;                                  \
+    kdamp[s] = isk[s] ? fresh(M.key_damping())[K] : (T)0;                                    \
+    kmass[s] = isk[s] ? fresh(M.key_mass())[K] : (T)0;                                       \
+    khx[s] = isk[s] ? fresh(M.key_half())[3 * K] : (T)0;                                     \
   }
   // actuator owned by this lane (hand actuators only; key actuators live with the key)
-  const bool isa = lane < nu && M.act_kind[lane < nu ? lane : 0] == 0;
+  const bool isa = lane < nu && M.act_kind()[lane < nu ? lane : 0] == 0;
   const int A = lane < nu ? lane : 0;
-  const int alane0 = isa ? M.act_lane[2 * A] : -1, alane1 = isa ? M.act_lane[2 * A + 1] : -1;
-  const T acoef0 = isa ? M.act_coef[2 * A] : (T)0, acoef1 = isa ? M.act_coef[2 * A + 1] : (T)0;
+  const int alane0 = isa ? M.act_lane()[2 * A] : -1, alane1 = isa ? M.act_lane()[2 * A + 1] : -1;
+  const T acoef0 = isa ? M.act_coef()[2 * A] : (T)0, acoef1 = isa ? M.act_coef()[2 * A + 1] : (T)0;
 
   // ------------------------------------------------------------------- state
   const size_t eo = (size_t)env * nv;
@@ -716,20 +762,20 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
     qapp[1 + s] = (isk[s] && S.qfrc_applied) ? S.qfrc_applied[eo + kdof[s]] : (T)0;
   }
   T ctrl = (lane < nu) ? S.ctrl[(size_t)env * nu + lane] : (T)0;
-  if (lane < nu && M.act_ctrllimited[A])
-    ctrl = fmin(M.act_ctrlrange[2 * A + 1], fmax(M.act_ctrlrange[2 * A], ctrl));
+  if (lane < nu && M.act_ctrllimited()[A])
+    ctrl = fmin(M.act_ctrlrange()[2 * A + 1], fmax(M.act_ctrlrange()[2 * A], ctrl));
   T kctrl[2] = {0, 0};
 #pragma unroll
   for (int s = 0; s < 2; s++) if (isk[s] && kact[s] >= 0) {
     T c = S.ctrl[(size_t)env * nu + kact[s]];
-    if (M.act_ctrllimited[kact[s]])
-      c = fmin(M.act_ctrlrange[2 * kact[s] + 1], fmax(M.act_ctrlrange[2 * kact[s]], c));
+    if (M.act_ctrllimited()[kact[s]])
+      c = fmin(M.act_ctrlrange()[2 * kact[s] + 1], fmax(M.act_ctrlrange()[2 * kact[s]], c));
     kctrl[s] = c;
   }
   T time = S.time[env];
 
   // descendant table (link, depth) -> <=5 lanes, used by the tree-sparse routines
-  for (int i = lane; i < nl * RPK_MAXD * 5; i += 64) sm.desc[i] = (signed char)M.link_desc[i];
+  for (int i = lane; i < nl * RPK_MAXD * 5; i += 64) sm.desc[i] = (signed char)M.link_desc()[i];
   WSYNC();
 
   PROF(0);
@@ -808,7 +854,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           int al = sm.slotlink[lane - nl];
           if (al >= 0) {
 #pragma unroll
-            for (int e = 0; e < RPK_MAXD; e++) sanc[e] = M.link_anc[al * RPK_MAXD + e];
+            for (int e = 0; e < RPK_MAXD; e++) sanc[e] = M.link_anc()[al * RPK_MAXD + e];
           }
         }
       }
@@ -816,10 +862,10 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
       // ---- actuation [MJ: mj_fwdActuation]
       T aforce = 0;
       if (isa) {
-        aforce = M.act_gain[A] * ctrl + M.act_bias[3 * A] + M.act_bias[3 * A + 1] * alen +
-                 M.act_bias[3 * A + 2] * avel;
-        if (M.act_forcelimited[A])
-          aforce = fmin(M.act_forcerange[2 * A + 1], fmax(M.act_forcerange[2 * A], aforce));
+        aforce = M.act_gain()[A] * ctrl + M.act_bias()[3 * A] + M.act_bias()[3 * A + 1] * alen +
+                 M.act_bias()[3 * A + 2] * avel;
+        if (M.act_forcelimited()[A])
+          aforce = fmin(M.act_forcerange()[2 * A + 1], fmax(M.act_forcerange()[2 * A], aforce));
         sm.actf[lane] = aforce;
         S.act_force[(size_t)env * nu + lane] = aforce;
       }
@@ -837,10 +883,10 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
             T grav = -kmass[s] * M.gz * khx[s] * kcos[s] - kmass[s] * M.gx * khx[s] * ksin[s];
             f = -kstiff[s] * (q[1 + s] - ksref[s]) - kdamp[s] * qd[1 + s] + grav + qapp[1 + s];
             if (kact[s] >= 0) {
-              T af = M.act_gain[kact[s]] * kctrl[s];
-              if (M.act_forcelimited[kact[s]])
-                af = fmin(M.act_forcerange[2 * kact[s] + 1], fmax(M.act_forcerange[2 * kact[s]], af));
-              f += M.act_coef[2 * kact[s]] * af;
+              T af = M.act_gain()[kact[s]] * kctrl[s];
+              if (M.act_forcelimited()[kact[s]])
+                af = fmin(M.act_forcerange()[2 * kact[s] + 1], fmax(M.act_forcerange()[2 * kact[s]], af));
+              f += M.act_coef()[2 * kact[s]] * af;
               S.act_force[(size_t)env * nu + kact[s]] = af;
             }
           }
@@ -875,6 +921,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
         }
         T Dslot = 1;
         WSYNC();
+        PROF(19);
         // ---- key leaves first (they hang under chain links)
         if (nslots > 0) {
           if (isslot && !dirty) {
@@ -901,6 +948,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           }
           WSYNC();
         }
+        PROF(20);
         // ---- chain leaders: local variables 0..3 = trunk, 4..8 = my chain (depth order)
         const bool leader = isl && depth == TL && TL > 0;
         const int clen = chain_end - TL;
@@ -1037,6 +1085,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           }
         }
         WSYNC();
+        PROF(21);
         // ---- dense block on the dirty rows (Schur complement + cross-contact terms)
         if (dm && __popcll(dm) > RPK_HMAX) { warn |= 32; dm = 0; }  // cannot hold the block: drop cross terms
         if (dm) {
@@ -1054,14 +1103,16 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
               sm.H[tri(ci, ci)] = sm.R[lane][mydiag];
               const int al_ = sm.slotlink[lane - nl];
               for (int e = 0; e <= sdepth; e++) {
-                const int a_ = M.link_anc[al_ * RPK_MAXD + e];
+                const int a_ = M.link_anc()[al_ * RPK_MAXD + e];
                 if ((dm >> a_) & 1) sm.H[tri(ci, cidx(a_))] = sm.R[lane][e];
               }
             }
           }
           WSYNC();
+          PROF(22);
           cross_fn(cidx);
           WSYNC();
+          PROF(23);
           // rhs of compact row r comes from the lane that owns it
           if (dirty) sm.Dg[ci] = x;   // Dg of dirty rows is unused: staging for the compact rhs
           WSYNC();
@@ -1075,6 +1126,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           if (dirty) sm.xs[lane] = sm.Dg[ci];
           WSYNC();
         }
+        PROF(25);
         // ---- back-substitution: trunk leader, then chain leaders, then key leaves
         if (tleader) {
           T xt[4];
@@ -1113,7 +1165,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           if (!dirty) {
             x = rhs / Dslot;
             const int al_ = sm.slotlink[lane - nl];
-            for (int e = 0; e <= sdepth; e++) x -= sm.R[lane][e] * sm.xs[M.link_anc[al_ * RPK_MAXD + e]];
+            for (int e = 0; e <= sdepth; e++) x -= sm.R[lane][e] * sm.xs[M.link_anc()[al_ * RPK_MAXD + e]];
           }
         }
         WSYNC();
@@ -1156,9 +1208,9 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
               const T* jc = sm.cJ[lane][side][0];
               vc[0] += jc[0] * xv; vc[1] += jc[1] * xv; vc[2] += jc[2] * xv;
             } else if (Lk >= 0) {
-              int dL = M.link_depth[Lk];
+              int dL = M.link_depth()[Lk];
               for (int lv = 0; lv <= dL; lv++) {
-                T xv = sm.vec[0][M.link_anc[Lk * RPK_MAXD + lv]];
+                T xv = sm.vec[0][M.link_anc()[Lk * RPK_MAXD + lv]];
                 const T* jc = sm.cJ[lane][side][lv];
                 vc[0] += jc[0] * xv; vc[1] += jc[1] * xv; vc[2] += jc[2] * xv;
               }
@@ -1361,7 +1413,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
                 T u2 = C4 * jp[0] + C5 * jp[1] + C2 * jp[2];
                 if (myslot) diag_acc += u0 * jp[0] + u1 * jp[1] + u2 * jp[2];
                 if (lside >= 0) {
-                  int top = mine ? depth : M.link_depth[lk];
+                  int top = mine ? depth : M.link_depth()[lk];
 #pragma unroll
                   for (int e = 0; e < RPK_MAXD; e++) {
                     if (e <= top) {
@@ -1591,9 +1643,9 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
       WSYNC();
     }
     if (lane < M.nsite) {  // site positions of this state
-      int sl = M.site_link[lane];
+      int sl = M.site_link()[lane];
       T t[3];
-      mat_vec(t, sm.xmat[sl], M.site_pos + 3 * lane);
+      mat_vec(t, sm.xmat[sl], M.site_pos() + 3 * lane);
 #pragma unroll
       for (int k = 0; k < 3; k++) S.site_xpos[((size_t)env * M.nsite + lane) * 3 + k] = sm.xpos[sl][k] + t[k];
     }
@@ -1642,7 +1694,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
     WSYNC();
     // ---- composite inertias, children -> parent by level and sibling rank [MJ: mj_crb]
     for (int d = M.maxdepth - 1; d >= 1; d--) {
-      int mr = M.level_maxrank[d];
+      int mr = M.level_maxrank()[d];
       for (int r = 0; r < mr; r++) {
         if (isl && depth == d && sibrank == r) {
 #pragma unroll
@@ -1679,8 +1731,8 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
     }
     WSYNC();
     if (lane < M.ngeom) {
-      int gl = M.geom_link[lane];
-      T gp[3] = {M.geom_pos[3 * lane], M.geom_pos[3 * lane + 1], M.geom_pos[3 * lane + 2]};
+      int gl = M.geom_link()[lane];
+      T gp[3] = {M.geom_pos()[3 * lane], M.geom_pos()[3 * lane + 1], M.geom_pos()[3 * lane + 2]};
       if (gl >= 0) {
         T t[3];
         mat_vec(t, sm.xmat[gl], gp);
@@ -1699,42 +1751,41 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
     int nwork = 0;
     ncon = 0;
     {
-    int gen_phase = (M.npair > 0) ? 0 : 1, gen_base = 0, gen_slot = 0;
+    // lane g < ngeom holds geom g (centre, bounding radius, allowed partners): candidate
+    // generation is pure ALU + readlane broadcasts, no memory access in the loop
+    const bool isg = lane < M.ngeom;
+    const T gcx = isg ? sm.gpos[lane][0] : (T)0, gcy = isg ? sm.gpos[lane][1] : (T)0,
+            gcz = isg ? sm.gpos[lane][2] : (T)0;
+    const T grb = isg ? M.geom_rbound()[lane] : (T)0;
+    const unsigned long long gpm =
+        isg ? (((unsigned long long)(unsigned)M.geom_pairmask()[2 * lane + 1] << 32) | (unsigned)M.geom_pairmask()[2 * lane])
+            : 0ull;
+    const bool gkc = isg && M.geom_iskeycap()[lane] != 0;
+    int gen_phase = (M.ngeom > 1) ? 0 : 1, gen_base = 1, gen_slot = 0;
     unsigned long long near_mask = 0;
     bool near_ready = false;
     while (true) {
       if (gen_phase == 0) {
-        int p = gen_base + lane;
-        bool hit = false;
-        int ga = 0, gb = 0;
-        if (p < M.npair) {
-          ga = M.pair[2 * p]; gb = M.pair[2 * p + 1];
-          T dx = sm.gpos[ga][0] - sm.gpos[gb][0], dy = sm.gpos[ga][1] - sm.gpos[gb][1],
-            dz = sm.gpos[ga][2] - sm.gpos[gb][2];
-          T rr = M.geom_rbound[ga] + M.geom_rbound[gb];
-          hit = dx * dx + dy * dy + dz * dz <= rr * rr;
-        }
+        // all geoms i < j against geom j = gen_base
+        const int j = gen_base;
+        const T jx = bcast(gcx, j), jy = bcast(gcy, j), jz = bcast(gcz, j), jr = bcast(grb, j);
+        const T dx = gcx - jx, dy = gcy - jy, dz = gcz - jz, rr = grb + jr;
+        const bool hit = ((gpm >> j) & 1) && (dx * dx + dy * dy + dz * dz <= rr * rr);
         unsigned long long mk = __ballot(hit);
         int idx = nwork + __popcll(mk & lanemask_lt(lane));
-        if (hit) { sm.work[idx][0] = (short)ga; sm.work[idx][1] = (short)gb; }
+        if (hit) { sm.work[idx][0] = (short)lane; sm.work[idx][1] = (short)j; }
         nwork += __popcll(mk);
-        gen_base += 64;
-        if (gen_base >= M.npair) gen_phase = 1;
+        gen_base++;
+        if (gen_base >= M.ngeom) gen_phase = 1;
       } else if (gen_phase == 1) {
         if (!near_ready) {
-          bool near = false;
-          if (lane < M.nkeycap) {
-            int g = M.keycap[lane];
-            near = sm.gpos[g][2] - M.geom_rbound[g] <= M.key_zmax;
-          }
-          near_mask = __ballot(near);
+          near_mask = __ballot(gkc && (gcz - grb <= M.key_zmax));
           near_ready = true;
         }
         if (near_mask == 0ull || nk == 0) gen_phase = 2;
         else {
-          int cj = __ffsll((long long)near_mask) - 1;
-          int g = M.keycap[cj];
-          T cx = sm.gpos[g][0], cy = sm.gpos[g][1], cz = sm.gpos[g][2], rb = M.geom_rbound[g];
+          int g = __ffsll((long long)near_mask) - 1;
+          T cx = bcast(gcx, g), cy = bcast(gcy, g), cz = bcast(gcz, g), rb = bcast(grb, g);
           bool hit = false;
           const int s = gen_slot;
           // (s is uniform; select this lane's key of slot s without dynamic register indexing)
@@ -1763,6 +1814,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           if (gen_slot == 2) { gen_slot = 0; near_mask &= near_mask - 1; }
         }
       }
+      PROF(12);
       const bool gen_done = gen_phase == 2;
       if (!(nwork >= 64 || (gen_done && nwork > 0))) {
         if (gen_done) break;
@@ -1780,49 +1832,50 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
       T pB[8], invw = 0;
       if (w < nproc) {
         ga = sm.work[w][0]; gb = sm.work[w][1];
-        int la = M.geom_link[ga];
+        int la = M.geom_link()[ga];
         T mA[9], posA[3] = {sm.gpos[ga][0], sm.gpos[ga][1], sm.gpos[ga][2]};
-        if (la >= 0) mat_mul(mA, sm.xmat[la], M.geom_mat + 9 * ga);
+        if (la >= 0) mat_mul(mA, sm.xmat[la], M.geom_mat() + 9 * ga);
         else {
 #pragma unroll
-          for (int k = 0; k < 9; k++) mA[k] = M.geom_mat[9 * ga + k];
+          for (int k = 0; k < 9; k++) mA[k] = M.geom_mat()[9 * ga + k];
         }
-        invw = M.geom_invw[ga];
+        invw = M.geom_invw()[ga];
         if (gb >= RPK_KEYBASE) {
           int k = gb - RPK_KEYBASE;
           T s, c;
           N::sincos(sm.kq[k], &s, &c);
-          T hx = M.key_half[3 * k];
-          T bp[3] = {M.key_pos[3 * k] - hx + hx * c, M.key_pos[3 * k + 1], M.key_pos[3 * k + 2] - hx * s};
+          T hx = M.key_half()[3 * k];
+          T bp[3] = {M.key_pos()[3 * k] - hx + hx * c, M.key_pos()[3 * k + 1], M.key_pos()[3 * k + 2] - hx * s};
           T bm[9] = {c, 0, s, 0, 1, 0, -s, 0, c};
-          n = capsule_box(rc, posA, mA, M.geom_size + 3 * ga, bp, bm, M.key_half + 3 * k);
+          n = capsule_box(rc, posA, mA, M.geom_size() + 3 * ga, bp, bm, M.key_half() + 3 * k);
 #pragma unroll
-          for (int e = 0; e < 8; e++) pB[e] = M.key_cparam[e];
-          invw += M.key_invw_body[k];
+          for (int e = 0; e < 8; e++) pB[e] = M.key_cparam()[e];
+          invw += M.key_invw_body()[k];
         } else {
-          int lb = M.geom_link[gb];
+          int lb = M.geom_link()[gb];
           T mB[9], posB[3] = {sm.gpos[gb][0], sm.gpos[gb][1], sm.gpos[gb][2]};
-          if (lb >= 0) mat_mul(mB, sm.xmat[lb], M.geom_mat + 9 * gb);
+          if (lb >= 0) mat_mul(mB, sm.xmat[lb], M.geom_mat() + 9 * gb);
           else {
 #pragma unroll
-            for (int k = 0; k < 9; k++) mB[k] = M.geom_mat[9 * gb + k];
+            for (int k = 0; k < 9; k++) mB[k] = M.geom_mat()[9 * gb + k];
           }
-          if (M.geom_type[gb] == GEOM_CAPSULE_)
-            n = capsule_capsule(rc, posA, mA, M.geom_size + 3 * ga, posB, mB, M.geom_size + 3 * gb);
+          if (M.geom_type()[gb] == GEOM_CAPSULE_)
+            n = capsule_capsule(rc, posA, mA, M.geom_size() + 3 * ga, posB, mB, M.geom_size() + 3 * gb);
           else
-            n = capsule_box(rc, posA, mA, M.geom_size + 3 * ga, posB, mB, M.geom_size + 3 * gb);
+            n = capsule_box(rc, posA, mA, M.geom_size() + 3 * ga, posB, mB, M.geom_size() + 3 * gb);
 #pragma unroll
-          for (int e = 0; e < 8; e++) pB[e] = M.geom_cparam[8 * gb + e];
-          invw += M.geom_invw[gb];
+          for (int e = 0; e < 8; e++) pB[e] = M.geom_cparam()[8 * gb + e];
+          invw += M.geom_invw()[gb];
         }
       }
+      PROF(13);
 #pragma unroll
       for (int slot = 0; slot < 3; slot++) {
         bool has = n > slot;
         unsigned long long mk = __ballot(has);
         int idx = ncon + __popcll(mk & lanemask_lt(lane));
         if (has && idx < RPK_NC) {
-          const T* pA = M.geom_cparam + 8 * ga;
+          const T* pA = M.geom_cparam() + 8 * ga;
           T solref0 = (T)0.5 * (pA[0] + pB[0]), solref1 = (T)0.5 * (pA[1] + pB[1]);
           T solimp[5];
 #pragma unroll
@@ -1841,15 +1894,16 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           sm.cdist[idx] = dist;
           sm.cpar[idx][0] = mu; sm.cpar[idx][1] = Kc * imp * dist; sm.cpar[idx][2] = Bc;
           sm.cpar[idx][3] = (T)1 / Rpy;
-          int la = M.geom_link[ga];
+          int la = M.geom_link()[ga];
           sm.cA[idx] = la;
-          sm.cB[idx] = gb >= RPK_KEYBASE ? gb : M.geom_link[gb];
-          sm.cgA[idx] = M.geom_modelid[ga];
-          sm.cgB[idx] = gb >= RPK_KEYBASE ? M.key_geomid[gb - RPK_KEYBASE] : M.geom_modelid[gb];
+          sm.cB[idx] = gb >= RPK_KEYBASE ? gb : M.geom_link()[gb];
+          sm.cgA[idx] = M.geom_modelid()[ga];
+          sm.cgB[idx] = gb >= RPK_KEYBASE ? M.key_geomid()[gb - RPK_KEYBASE] : M.geom_modelid()[gb];
         }
         ncon += __popcll(mk);
       }
       }
+      PROF(24);
       // drop the processed candidates
       WSYNC();
       short w0 = 0, w1 = 0;
@@ -1896,9 +1950,9 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
         for (int k = 0; k < 3; k++) con_n[k] = sm.cn[lane][k];
         make_frame(con_n, con_t1, con_t2);
         if (con_A >= 0 && con_A < RPK_KEYBASE)
-          con_maskA = ((unsigned long long)M.link_ancmask[2 * con_A + 1] << 32) | M.link_ancmask[2 * con_A];
+          con_maskA = ((unsigned long long)M.link_ancmask_u()[2 * con_A + 1] << 32) | M.link_ancmask_u()[2 * con_A];
         if (con_B >= 0 && con_B < RPK_KEYBASE)
-          con_maskB = ((unsigned long long)M.link_ancmask[2 * con_B + 1] << 32) | M.link_ancmask[2 * con_B];
+          con_maskB = ((unsigned long long)M.link_ancmask_u()[2 * con_B + 1] << 32) | M.link_ancmask_u()[2 * con_B];
       }
     }
     // ---- contact Jacobian columns (J_diff = J(body2) - J(body1)) [MJ: mj_jacDifPair]
@@ -1911,13 +1965,13 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
       if (Lk >= RPK_KEYBASE) {
         if (lv == 0) {
           int k = Lk - RPK_KEYBASE;
-          T rx = sm.cpos[c][0] - (M.key_pos[3 * k] - M.key_half[3 * k]);
-          T rz = sm.cpos[c][2] - M.key_pos[3 * k + 2];
+          T rx = sm.cpos[c][0] - (M.key_pos()[3 * k] - M.key_half()[3 * k]);
+          T rz = sm.cpos[c][2] - M.key_pos()[3 * k + 2];
           col[0] = rz; col[1] = 0; col[2] = -rx;  // (0,1,0) x r
         }
-      } else if (Lk >= 0 && lv <= M.link_depth[Lk]) {
-        int a = M.link_anc[Lk * RPK_MAXD + lv];
-        if (M.link_jtype[a] == JNT_SLIDE_) {
+      } else if (Lk >= 0 && lv <= M.link_depth()[Lk]) {
+        int a = M.link_anc()[Lk * RPK_MAXD + lv];
+        if (M.link_jtype()[a] == JNT_SLIDE_) {
           col[0] = sm.xaxis[a][0]; col[1] = sm.xaxis[a][1]; col[2] = sm.xaxis[a][2];
         } else {
           T r[3] = {sm.cpos[c][0] - sm.xanchor[a][0], sm.cpos[c][1] - sm.xanchor[a][1],
@@ -1944,7 +1998,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           if (deep < 0) cross = 1;
           else {
             const int sh = 1 - deep;
-            const int dsh = M.link_depth[sh ? con_B : con_A];
+            const int dsh = M.link_depth()[sh ? con_B : con_A];
             for (int e = 0; e <= dsh; e++) {
 #pragma unroll
               for (int k = 0; k < 3; k++) sm.cJ[lane][deep][e][k] += sm.cJ[lane][sh][e][k];
@@ -1958,7 +2012,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
       // pressing the same key must lie on the anchor's chain
       const int mylink = (con_A >= 0 && con_A < RPK_KEYBASE) ? con_A : ((con_B >= 0 && con_B < RPK_KEYBASE) ? con_B : -1);
       const unsigned long long mymask = con_maskA | con_maskB;
-      const int mydepthc = (lane < ncon && mylink >= 0) ? M.link_depth[mylink] : -1;
+      const int mydepthc = (lane < ncon && mylink >= 0) ? M.link_depth()[mylink] : -1;
       for (int sidx = 0; sidx < nkt; sidx++) {
         int cand = (lane < ncon && con_slot == sidx && mylink >= 0) ? ((mydepthc << 8) | lane) : -1;
 #pragma unroll
@@ -1996,9 +2050,9 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
       if (!isl && lane < nl + nkt) {
         int al = sm.slotlink[lane - nl];
         if (al >= 0) {
-          sdepth = M.link_depth[al];
+          sdepth = M.link_depth()[al];
 #pragma unroll
-          for (int e = 0; e < RPK_MAXD; e++) sanc[e] = M.link_anc[al * RPK_MAXD + e];
+          for (int e = 0; e < RPK_MAXD; e++) sanc[e] = M.link_anc()[al * RPK_MAXD + e];
         }
       }
     }
@@ -2057,7 +2111,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
     }
     WSYNC();
     for (int d = M.maxdepth - 1; d >= 1; d--) {
-      int mr = M.level_maxrank[d];
+      int mr = M.level_maxrank()[d];
       for (int r = 0; r < mr; r++) {
         if (isl && depth == d && sibrank == r) {
 #pragma unroll
@@ -2089,7 +2143,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
         if (dl < 0) { lim_sign[s] = 1; dist = dl; }
         else if (du < 0) { lim_sign[s] = -1; dist = du; }
         if (lim_sign[s] != 0) {
-          const T* si = (s == 0) ? (M.link_lim_solimp + 5 * L) : (M.key_lim_solimp + 5 * kid[s - 1]);
+          const T* si = (s == 0) ? (M.link_lim_solimp() + 5 * L) : (M.key_lim_solimp() + 5 * kid[s - 1]);
           T imp = impedance(si, dist);
           T R = fmax(RPK_MINVAL, ((T)1 - imp) * limW[s] / imp);
           lim_D[s] = (T)1 / R;
@@ -2108,9 +2162,9 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
             const T* jc = sm.cJ[lane][side][0];
             vc[0] += jc[0] * xv; vc[1] += jc[1] * xv; vc[2] += jc[2] * xv;
           } else if (Lk >= 0) {
-            int dL = M.link_depth[Lk];
+            int dL = M.link_depth()[Lk];
             for (int lv = 0; lv <= dL; lv++) {
-              T xv = sm.vec[1][M.link_anc[Lk * RPK_MAXD + lv]];
+              T xv = sm.vec[1][M.link_anc()[Lk * RPK_MAXD + lv]];
               const T* jc = sm.cJ[lane][side][lv];
               vc[0] += jc[0] * xv; vc[1] += jc[1] * xv; vc[2] += jc[2] * xv;
             }
@@ -2181,7 +2235,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
   if constexpr (MODE == 0) {
 #pragma unroll
   for (int s = 0; s < 2; s++) if (isk[s]) {
-    if (kact[s] >= 0) S.act_vel[(size_t)env * nu + kact[s]] = M.act_coef[2 * kact[s]] * qd[1 + s];
+    if (kact[s] >= 0) S.act_vel[(size_t)env * nu + kact[s]] = M.act_coef()[2 * kact[s]] * qd[1 + s];
   }
   if (isa) S.act_vel[(size_t)env * nu + lane] = avel;
   if (lane < RPK_NCOUT) {
@@ -2203,6 +2257,10 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
         S.time[env] = time;
       }
     }
+  }
+  if (S.prof && env == 0 && lane < RPK_NPROF) {
+    WSYNC();
+    atomicAdd((unsigned long long*)&S.prof[lane], (unsigned long long)sm.prof[lane]);
   }
 #undef LF
 #undef LI

@@ -288,6 +288,10 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
     key_geom_set = set(int(g) for g in key_geom)
     egeoms = [g for g in range(m.ngeom) if g not in key_geom_set
               and (m.geom_contype[g] or m.geom_conaffinity[g])]
+    # capsules before boxes: with geoms in lanes and partners visited in lane order, the
+    # candidate stream is capsule-capsule first, then capsule-box (homogeneous chunks),
+    # and (lower lane, higher lane) is always (geom1, geom2) of MuJoCo's type ordering
+    egeoms.sort(key=lambda g: (int(m.geom_type[g]), g))
     eidx = {g: i for i, g in enumerate(egeoms)}
     ng = len(egeoms)
     g_link = np.full(ng, -1, np.int32)
@@ -351,6 +355,16 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
     kcaps = sorted(eidx[h] for h in keycount)
     t["eng_nkeycap"] = np.array([len(kcaps)], np.int32)
     t["eng_keycap"] = np.array(kcaps, np.int32)
+    # per-geom partner masks (bit j of row i: static pair (i, j), j > i) and key-capsule flags
+    pmask = np.zeros((max(ng, 1), 2), np.uint32)
+    for a, b in spairs:
+        lo_, hi_ = min(a, b), max(a, b)
+        assert m.geom_type[egeoms[lo_]] <= m.geom_type[egeoms[hi_]]
+        pmask[lo_, hi_ // 32] |= np.uint32(1 << (hi_ % 32))
+    t["eng_geom_pairmask"] = pmask.view(np.int32)
+    iskc = np.zeros(max(ng, 1), np.int32)
+    iskc[kcaps] = 1
+    t["eng_geom_iskeycap"] = iskc
 
     # ---- actuators -------------------------------------------------------------
     nu = m.nu
