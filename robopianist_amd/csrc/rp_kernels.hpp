@@ -189,11 +189,43 @@ __device__ __forceinline__ double bcast(double v, int l) {
   long long r = ((long long)hi << 32) | (unsigned int)lo;
   return __builtin_bit_cast(double, r);
 }
+// Wave-wide sum, result uniform in every lane.  Four DPP butterfly steps (xor 1, xor 2,
+// half-mirror, mirror) leave each 16-lane row holding its row sum without touching the
+// LDS crossbar; the four row sums are then read with v_readlane and added as scalars.
+template <int CTRL> __device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_move(double v) {
+  long long b = __builtin_bit_cast(long long, v);
+  int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);  // row_half_mirror
+  v += dpp_move<0x140>(v);  // row_mirror
+  return (bcast(v, 0) + bcast(v, 16)) + (bcast(v, 32) + bcast(v, 48));
+}
+template <int CTRL> __device__ __forceinline__ int dpp_move(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+// integer wave reductions on the same DPP butterfly (uniform result)
+__device__ __forceinline__ int wave_or(int v) {
+  v |= dpp_move<0xB1>(v); v |= dpp_move<0x4E>(v); v |= dpp_move<0x141>(v); v |= dpp_move<0x140>(v);
+  return (bcast(v, 0) | bcast(v, 16)) | (bcast(v, 32) | bcast(v, 48));
+}
+__device__ __forceinline__ int wave_max(int v) {
+  v = max(v, dpp_move<0xB1>(v)); v = max(v, dpp_move<0x4E>(v));
+  v = max(v, dpp_move<0x141>(v)); v = max(v, dpp_move<0x140>(v));
+  return max(max(bcast(v, 0), bcast(v, 16)), max(bcast(v, 32), bcast(v, 48)));
+}
+__device__ __forceinline__ unsigned long long wave_or(unsigned long long v) {
+  unsigned lo = (unsigned)wave_or((int)(v & 0xffffffffull)), hi = (unsigned)wave_or((int)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
 }
 template <typename P>
 __device__ __forceinline__ const P* fresh(const P* p) {
@@ -271,7 +303,10 @@ __device__ __forceinline__ T impedance(const T* solimp, T pos) {  // margin == 0
   if (x >= (T)1) return dmax;
   if (x == (T)0) return dmin;
   T y;
-  if (x <= mid) y = Num<T>::pow(x, power) / Num<T>::pow(mid, power - 1);
+  if (power == (T)2) {  // the MuJoCo default; pow(x, 2) is exactly x * x
+    if (x <= mid) y = x * x / mid;
+    else y = (T)1 - ((T)1 - x) * ((T)1 - x) / ((T)1 - mid);
+  } else if (x <= mid) y = Num<T>::pow(x, power) / Num<T>::pow(mid, power - 1);
   else y = (T)1 - Num<T>::pow((T)1 - x, power) / Num<T>::pow((T)1 - mid, power - 1);
   return dmin + y * (dmax - dmin);
 }
@@ -292,6 +327,15 @@ __device__ __forceinline__ int sphere_sphere(RawCon<T>* c, const T* c1, T r1, co
   return 1;
 }
 
+// out[n++] = c with a static register index (out[] must never be indexed dynamically,
+// or the compiler places it in scratch memory)
+template <typename T>
+__device__ __forceinline__ void put_con(RawCon<T>* out, int& n, const RawCon<T>& c) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) if (n == i) out[i] = c;
+  n++;
+}
+
 template <typename T>
 __device__ int capsule_capsule(RawCon<T>* out, const T* p1, const T* m1, const T* s1, const T* p2,
                                const T* m2, const T* s2) {
@@ -309,7 +353,8 @@ __device__ int capsule_capsule(RawCon<T>* out, const T* p1, const T* m1, const T
     else if (x2 < -l2) { x2 = -l2; x1 = fmin(l1, fmax(-l1, u + b * x2)); }
 #pragma unroll
     for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * x1; c2[k] = p2[k] + a2[k] * x2; }
-    n += sphere_sphere(out + n, c1, r1, c2, r2);
+    RawCon<T> rc;
+    if (sphere_sphere(&rc, c1, r1, c2, r2)) put_con(out, n, rc);
   } else {
     T sgn = b >= 0 ? (T)1 : (T)-1, mid = u;
     T lo = fmax(-l1, mid - l2), hi = fmin(l1, mid + l2);
@@ -319,14 +364,16 @@ __device__ int capsule_capsule(RawCon<T>* out, const T* p1, const T* m1, const T
         T x1 = q == 0 ? lo : hi, x2 = sgn * (x1 - mid);
 #pragma unroll
         for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * x1; c2[k] = p2[k] + a2[k] * x2; }
-        n += sphere_sphere(out + n, c1, r1, c2, r2);
+        RawCon<T> rc;
+        if (sphere_sphere(&rc, c1, r1, c2, r2)) put_con(out, n, rc);
       }
     } else {
       T x1 = mid > 0 ? l1 : -l1;
       T x2 = fmin(l2, fmax(-l2, sgn * (x1 - mid)));
 #pragma unroll
       for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * x1; c2[k] = p2[k] + a2[k] * x2; }
-      n += sphere_sphere(out + n, c1, r1, c2, r2);
+      RawCon<T> rc;
+      if (sphere_sphere(&rc, c1, r1, c2, r2)) put_con(out, n, rc);
     }
   }
   return n;
@@ -417,11 +464,12 @@ __device__ int capsule_box(RawCon<T>* out, const T* cp, const T* cm, const T* cs
     RawCon<T> rc;
     if (sphere_box_local(&rc, p, r, bs)) {
       T w[3];
+      RawCon<T> wc;
       mat_vec(w, bm, rc.pos);
-      out[n].pos[0] = bp[0] + w[0]; out[n].pos[1] = bp[1] + w[1]; out[n].pos[2] = bp[2] + w[2];
-      mat_vec(out[n].n, bm, rc.n);
-      out[n].dist = rc.dist;
-      n++;
+      wc.pos[0] = bp[0] + w[0]; wc.pos[1] = bp[1] + w[1]; wc.pos[2] = bp[2] + w[2];
+      mat_vec(wc.n, bm, rc.n);
+      wc.dist = rc.dist;
+      put_con(out, n, wc);
     }
   }
   return n;
@@ -786,9 +834,13 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
 #pragma unroll
   for (int e = 0; e <= RPK_MAXD; e++) Mr[e] = 0;
   int tree_ok = 1;     // all contacts lie on single root-to-leaf paths (uniform)
-  int sdepth = -1, sanc[RPK_MAXD];  // solver-slot lanes: anchor link depth / ancestors
-#pragma unroll
-  for (int e = 0; e < RPK_MAXD; e++) sanc[e] = 0;
+  int sdepth = -1;  // solver-slot lanes: anchor link depth
+  // Lanes are numbered in preorder (trunk chain, then the leaf chains), so the ancestor
+  // of link `lk` at depth e is arithmetic: trunk base + e on the trunk, lk - (depth - e)
+  // on lk's own chain.  (depth, trunk length, trunk base) of the links a lane needs:
+  int sTL = 0, sTB = 0, salink = 0;          // slot lanes: anchor link of my key
+  int cdep[2] = {-1, -1}, cTL[2] = {0, 0}, cTB[2] = {0, 0};  // contact lanes: side A / B link
+  auto anc_of = [](int lk, int dl, int tl, int tb, int e) -> int { return e < tl ? tb + e : lk - (dl - e); };
   T ksin[2] = {0, 0}, kcos[2] = {1, 1};
   int ncon = 0, nkt = 0;
   // rows
@@ -853,8 +905,16 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
         if (!isl && lane < nl + nkt) {
           int al = sm.slotlink[lane - nl];
           if (al >= 0) {
+            const int t = M.link_tree()[al];
+            salink = al; sTL = M.tree_trunk()[t]; sTB = M.tree_base()[t];
+          }
+        }
 #pragma unroll
-            for (int e = 0; e < RPK_MAXD; e++) sanc[e] = M.link_anc()[al * RPK_MAXD + e];
+        for (int side = 0; side < 2; side++) {
+          const int Lk = side ? con_B : con_A;
+          if (lane < ncon && Lk >= 0 && Lk < RPK_KEYBASE) {
+            const int t = M.link_tree()[Lk];
+            cdep[side] = M.link_depth()[Lk]; cTL[side] = M.tree_trunk()[t]; cTB[side] = M.tree_base()[t];
           }
         }
       }
@@ -1101,10 +1161,12 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
               for (int e = 0; e <= depth; e++) sm.H[tri(ci, cidx(anc_at(e)))] = sm.R[lane][e];
             } else {
               sm.H[tri(ci, ci)] = sm.R[lane][mydiag];
-              const int al_ = sm.slotlink[lane - nl];
-              for (int e = 0; e <= sdepth; e++) {
-                const int a_ = M.link_anc()[al_ * RPK_MAXD + e];
-                if ((dm >> a_) & 1) sm.H[tri(ci, cidx(a_))] = sm.R[lane][e];
+#pragma unroll
+              for (int e = 0; e < RPK_MAXD; e++) {
+                if (e <= sdepth) {
+                  const int a_ = anc_of(salink, sdepth, sTL, sTB, e);
+                  if ((dm >> a_) & 1) sm.H[tri(ci, cidx(a_))] = sm.R[lane][e];
+                }
               }
             }
           }
@@ -1164,8 +1226,9 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           x = sm.xs[lane];
           if (!dirty) {
             x = rhs / Dslot;
-            const int al_ = sm.slotlink[lane - nl];
-            for (int e = 0; e <= sdepth; e++) x -= sm.R[lane][e] * sm.xs[M.link_anc()[al_ * RPK_MAXD + e]];
+#pragma unroll
+            for (int e = 0; e < RPK_MAXD; e++)
+              if (e <= sdepth) x -= sm.R[lane][e] * sm.xs[anc_of(salink, sdepth, sTL, sTB, e)];
           }
         }
         WSYNC();
@@ -1208,11 +1271,13 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
               const T* jc = sm.cJ[lane][side][0];
               vc[0] += jc[0] * xv; vc[1] += jc[1] * xv; vc[2] += jc[2] * xv;
             } else if (Lk >= 0) {
-              int dL = M.link_depth()[Lk];
-              for (int lv = 0; lv <= dL; lv++) {
-                T xv = sm.vec[0][M.link_anc()[Lk * RPK_MAXD + lv]];
-                const T* jc = sm.cJ[lane][side][lv];
-                vc[0] += jc[0] * xv; vc[1] += jc[1] * xv; vc[2] += jc[2] * xv;
+#pragma unroll
+              for (int lv = 0; lv < RPK_MAXD; lv++) {
+                if (lv <= cdep[side]) {
+                  T xv = sm.vec[0][anc_of(Lk, cdep[side], cTL[side], cTB[side], lv)];
+                  const T* jc = sm.cJ[lane][side][lv];
+                  vc[0] += jc[0] * xv; vc[1] += jc[1] * xv; vc[2] += jc[2] * xv;
+                }
               }
             }
           }
@@ -1296,13 +1361,15 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
         for (int s = 0; s < 3; s++) g += (Ma_[s] - qfs[s]) * (qa_[s] - qs[s]);
         return (T)0.5 * g;
       };
+      // y = M x with the tree-sparse rows: ancestor terms from this lane's own row
+      // (registers), descendant terms from the rows of the next `ndesc` lanes (preorder).
       auto mulM = [&](const T* x, T* out) {
         sm.xs[lane] = x[0];
         WSYNC();
         T y = 0;
         if (isl) {
-          for (int e = 0; e <= depth; e++) y += sm.RM[lane][e] * sm.xs[anc_at(e)];
-          // descendants are the next `ndesc` lanes (preorder)
+#pragma unroll
+          for (int e = 0; e <= RPK_MAXD; e++) if (e <= depth) y += Mr[e] * sm.xs[anc_at(e)];
           for (int j = 1; j <= ndesc; j++) y += sm.RM[lane + j][depth] * sm.xs[lane + j];
         }
         out[0] = y;
@@ -1400,6 +1467,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
               int lside = (cA >= 0 && cA < RPK_KEYBASE) ? 0 : ((cB >= 0 && cB < RPK_KEYBASE) ? 1 : -1);
               int keyside = cA >= RPK_KEYBASE ? 0 : (cB >= RPK_KEYBASE ? 1 : -1);
               int lk = lside == 0 ? cA : cB;
+              const int lkdep = bcast(lside == 0 ? cdep[0] : cdep[1], c);
               unsigned long long mk = lside == 0
                   ? (((unsigned long long)(unsigned)bcast((int)(con_maskA >> 32), c) << 32) | (unsigned)bcast((int)(con_maskA & 0xffffffffu), c))
                   : (((unsigned long long)(unsigned)bcast((int)(con_maskB >> 32), c) << 32) | (unsigned)bcast((int)(con_maskB & 0xffffffffu), c));
@@ -1413,7 +1481,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
                 T u2 = C4 * jp[0] + C5 * jp[1] + C2 * jp[2];
                 if (myslot) diag_acc += u0 * jp[0] + u1 * jp[1] + u2 * jp[2];
                 if (lside >= 0) {
-                  int top = mine ? depth : M.link_depth()[lk];
+                  int top = mine ? depth : lkdep;
 #pragma unroll
                   for (int e = 0; e < RPK_MAXD; e++) {
                     if (e <= top) {
@@ -2015,8 +2083,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
       const int mydepthc = (lane < ncon && mylink >= 0) ? M.link_depth()[mylink] : -1;
       for (int sidx = 0; sidx < nkt; sidx++) {
         int cand = (lane < ncon && con_slot == sidx && mylink >= 0) ? ((mydepthc << 8) | lane) : -1;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) cand = max(cand, __shfl_xor(cand, off, 64));
+        cand = wave_max(cand);
         int cl = cand >= 0 ? (cand & 255) : 0;
         unsigned long long am = ((unsigned long long)(unsigned)bcast((int)(mymask >> 32), cl) << 32) |
                                 (unsigned)bcast((int)(mymask & 0xffffffffu), cl);
@@ -2029,8 +2096,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
       {
         unsigned long long badslots = 0;
         if (cross && lane < ncon && con_slot >= 0) badslots = 1ull << con_slot;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) badslots |= __shfl_xor(badslots, off, 64);
+        badslots = wave_or(badslots);
         if (lane < ncon && con_slot >= 0 && ((badslots >> con_slot) & 1)) cross = 1;
       }
       con_cross = cross;
@@ -2040,8 +2106,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           dmk = con_maskA | con_maskB;
           if (con_slot >= 0) dmk |= 1ull << (nl + con_slot);
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) dmk |= __shfl_xor(dmk, off, 64);
+        dmk = wave_or(dmk);
         dirty_mask = dmk;
       }
       tree_ok = dirty_mask == 0ull;
@@ -2051,8 +2116,6 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
         int al = sm.slotlink[lane - nl];
         if (al >= 0) {
           sdepth = M.link_depth()[al];
-#pragma unroll
-          for (int e = 0; e < RPK_MAXD; e++) sanc[e] = M.link_anc()[al * RPK_MAXD + e];
         }
       }
     }
@@ -2247,8 +2310,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
   }
   {
     int w = warn;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) w |= __shfl_xor(w, off, 64);
+    w = wave_or(w);
     if (lane == 0) {
       S.warn[env] |= w;
       if constexpr (MODE == 0) S.ncon[env] = ncon;
