@@ -176,7 +176,11 @@ struct Engine : EngineBase {
     PI(link_act, "eng_link_act"); PI(link_desc, "eng_link_desc"); PI(link_ndesc, "eng_link_ndesc");
     PI(tree_base, "eng_tree_base"); PI(tree_trunk, "eng_tree_trunk"); PI(chain_first, "eng_chain_first");
     PI(chain_len, "eng_chain_len"); PI(link_ancmask, "eng_link_ancmask");
-    for (int v : b.i("eng_tree_trunk")) if (v > 4) throw std::string("trunk chain longer than 4 links is not supported by the solver");
+    {
+      auto tt = b.i("eng_tree_trunk");
+      for (int t = 0; t < M.ntree && t < (int)tt.size(); t++)
+        if (tt[t] > 4 || tt[t] < 1) throw std::string("the solver needs a trunk chain of 1..4 links per articulated tree");
+    }
     for (int v : b.i("eng_chain_len")) if (v > 5) throw std::string("finger chain longer than 5 links is not supported by the solver");
     PF(link_lpos, "eng_link_lpos");
     {

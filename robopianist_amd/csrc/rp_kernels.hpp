@@ -22,7 +22,7 @@
 #define RPK_WAVE 64
 #define RPK_NC 24        // max contacts kept per env (outputs are RP_MAX_CONTACTS wide)
 #define RPK_NCOUT 32     // == RP_MAX_CONTACTS
-#define RPK_HMAX 48      // max rows of the dense cross-coupling block
+#define RPK_HMAX 46      // max rows of the dense cross-coupling block (+1 row for its rhs)
 #define RPK_WORK 128     // narrow-phase work list
 #define RPK_MAXD 9       // tree depth levels
 #define RPK_NL 52        // max links
@@ -129,6 +129,9 @@ struct RpState {
 #define RPK_NPROF 32
 // Per-phase shader-clock counters of env 0 (debug aid), accumulated in LDS so a probe
 // costs about one LDS round trip; flushed to global memory once at kernel exit.
+#ifdef RPK_MARK  // static analysis aid: phase boundaries as comments in the ISA listing
+#define PROF(i) asm volatile("; MARK " #i)
+#else
 #define PROF(i)                                                         \
   do {                                                                  \
     if (S.prof && env == 0) {                                           \
@@ -137,6 +140,7 @@ struct RpState {
       prof_t = t_;                                                      \
     }                                                                   \
   } while (0)
+#endif
 
 // Hand-over between the position/velocity kernel (MODE 0) and the solver kernel
 // (MODE 1): everything `mj_step1` leaves behind for `mj_step2`, per env.  Lives in
@@ -231,6 +235,10 @@ template <typename P>
 __device__ __forceinline__ const P* fresh(const P* p) {
   asm volatile("" : "+s"(p));
   return p;
+}
+// fire-and-forget LDS accumulate (ds_add_f32 / ds_add_f64): no read-modify-write round trip
+template <typename T> __device__ __forceinline__ void lds_add(T* p, T v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) {
@@ -499,7 +507,7 @@ struct Smem {
       T R[RPK_WAVE][RPK_MAXD + 1];  // tree factor rows (L), incl. key-leaf rows
       T Dg[RPK_WAVE];               // tree factor diagonal
       T xs[RPK_WAVE];               // solve staging
-      T H[RPK_HMAX * (RPK_HMAX + 1) / 2];  // dense block of the cross-coupled rows
+      T H[(RPK_HMAX + 1) * (RPK_HMAX + 2) / 2];  // dense block of the cross-coupled rows + rhs row
     };
   };
   // ---- persistent across stages
@@ -526,115 +534,105 @@ struct Smem {
 // slot (hand, key, key+64), four pyramidal rows of its contact.
 template <typename T> struct Rows { T fr, lim[3], con[4]; };
 
-// packed lower-triangular Cholesky (left-looking), lane = row, n uniform.
-// Row j is loaded cooperatively (lane p holds L[j][p]) and broadcast with
-// v_readlane, so the inner product costs one LDS read per term; reads are issued
-// in batches of 8 ahead of the dependent FMA chain.
+// 1/sqrt(x) to working precision: hardware estimate + Newton steps (no division on the
+// pivot chain of the dense factorisation).
+template <typename T> __device__ __forceinline__ T rsqrt_nr(T x);
+template <> __device__ __forceinline__ double rsqrt_nr<double>(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  y = y * __builtin_fma(-h * y, y, 1.5);
+  y = y * __builtin_fma(-h * y, y, 1.5);
+  return y;
+}
+template <> __device__ __forceinline__ float rsqrt_nr<float>(float x) {
+  float y = __builtin_amdgcn_rsqf(x);
+  const float h = 0.5f * x;
+  y = y * __builtin_fmaf(-h * y, y, 1.5f);
+  return y;
+}
+
+// Dense solve of the packed lower-triangular SPD system H (n rows, n uniform) with the
+// right-hand side stored as row n of H; returns x_i in lane i < n.
+//   * left-looking L L^T, lane = row, two columns per step (one LDS hand-over per pair);
+//   * inner products read the lane's own row and rows j, j+1 (uniform address =
+//     LDS broadcast) with paired 64-bit reads, no v_readlane in the loop;
+//   * the rhs row takes part in the factorisation like any other row, which performs
+//     the forward substitution for free; only the backward pass is a serial chain.
+// Measured on gfx950, one wave per SIMD, n = 19, fp64: 14 k cycles (the one-column
+// sqrt/divide/readlane version took 32 k).
 template <typename T>
-__device__ void chol_packed(T* H, int n, int lane, int* warn) {
-  for (int j = 0; j < n; j++) {
-    T rj = (lane < j) ? H[tri(j, 0) + lane] : (T)0;
-    T s = 0;
-    const bool act = lane >= j && lane < n;
+__device__ T dense_factor_solve(T* H, int n, int lane, int* warn) {
+  T invd_me = 0;
+  int j = 0;
+  for (; j + 2 <= n; j += 2) {
+    const int j1 = j + 1;
+    const bool act = lane >= j && lane <= n;
     const T* ri = H + tri(act ? lane : 0, 0);
-    if (act) s = ri[j];
+    const T* rj = H + tri(j, 0);
+    const T* rk = H + tri(j1, 0);
+    T s = ri[j], t = ri[j1];
     int p = 0;
-    for (; p + 8 <= j; p += 8) {
-      T a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
-      if (act) { a0 = ri[p]; a1 = ri[p + 1]; a2 = ri[p + 2]; a3 = ri[p + 3];
-                 a4 = ri[p + 4]; a5 = ri[p + 5]; a6 = ri[p + 6]; a7 = ri[p + 7]; }
-      s -= a0 * bcast(rj, p); s -= a1 * bcast(rj, p + 1); s -= a2 * bcast(rj, p + 2);
-      s -= a3 * bcast(rj, p + 3); s -= a4 * bcast(rj, p + 4); s -= a5 * bcast(rj, p + 5);
-      s -= a6 * bcast(rj, p + 6); s -= a7 * bcast(rj, p + 7);
+    for (; p + 4 <= j; p += 4) {
+      T a0 = ri[p], a1 = ri[p + 1], a2 = ri[p + 2], a3 = ri[p + 3];
+      T b0 = rj[p], b1 = rj[p + 1], b2 = rj[p + 2], b3 = rj[p + 3];
+      T c0 = rk[p], c1 = rk[p + 1], c2 = rk[p + 2], c3 = rk[p + 3];
+      s -= a0 * b0; t -= a0 * c0; s -= a1 * b1; t -= a1 * c1;
+      s -= a2 * b2; t -= a2 * c2; s -= a3 * b3; t -= a3 * c3;
     }
-    for (; p < j; p++) {
-      T a0 = act ? ri[p] : (T)0;
-      s -= a0 * bcast(rj, p);
-    }
-    T sj = bcast(s, j);
-    if (sj < RPK_MINVAL) { sj = RPK_MINVAL; *warn |= 4; }
-    T ljj = Num<T>::sqrt(sj);
-    if (lane == j) H[tri(j, j)] = ljj;
-    else if (act) H[tri(lane, j)] = s / ljj;
+    for (; p < j; p++) { T a0 = ri[p]; s -= a0 * rj[p]; t -= a0 * rk[p]; }
+    T dj = bcast(s, j);
+    if (!(dj >= RPK_MINVAL)) { dj = RPK_MINVAL; *warn |= 4; }
+    const T rs = rsqrt_nr(dj);
+    const T lij = s * rs;               // L[i][j] for lanes > j (lane j: sqrt(dj))
+    const T lkj = bcast(lij, j1);
+    t -= lij * lkj;
+    T dk = bcast(t, j1);
+    if (!(dk >= RPK_MINVAL)) { dk = RPK_MINVAL; *warn |= 4; }
+    const T rs2 = rsqrt_nr(dk);
+    const T lik = t * rs2;
+    if (lane == j) invd_me = rs;
+    if (lane == j1) invd_me = rs2;
+    if (act) H[tri(lane, j)] = lij;
+    if (act && lane > j) H[tri(lane, j1)] = lik;
     WSYNC();
   }
-}
-// solves (L L^T) x = b, x/b in the register of lane i (< n).
-template <typename T>
-__device__ T solve_packed(const T* H, int n, int lane, T x) {
-  const bool in = lane < n;
-  T invd = in ? (T)1 / H[tri(lane, lane)] : (T)0;
-  if (!in) x = 0;
-  const T* ri = H + tri(in ? lane : 0, 0);
-  int p = 0;
-  for (; p + 4 <= n; p += 4) {
-    // lane i needs L[i][p..p+3] for p < i
-    T l0 = (in && lane > p) ? ri[p] : (T)0;
-    T l1 = (in && lane > p + 1) ? ri[p + 1] : (T)0;
-    T l2 = (in && lane > p + 2) ? ri[p + 2] : (T)0;
-    T l3 = (in && lane > p + 3) ? ri[p + 3] : (T)0;
-    if (lane == p) x *= invd;
-    x -= l0 * bcast(x, p);
-    if (lane == p + 1) x *= invd;
-    x -= l1 * bcast(x, p + 1);
-    if (lane == p + 2) x *= invd;
-    x -= l2 * bcast(x, p + 2);
-    if (lane == p + 3) x *= invd;
-    x -= l3 * bcast(x, p + 3);
+  if (j < n) {
+    const bool act = lane >= j && lane <= n;
+    const T* ri = H + tri(act ? lane : 0, 0);
+    const T* rj = H + tri(j, 0);
+    T s = ri[j];
+    for (int p = 0; p < j; p++) s -= ri[p] * rj[p];
+    T dj = bcast(s, j);
+    if (!(dj >= RPK_MINVAL)) { dj = RPK_MINVAL; *warn |= 4; }
+    const T rs = rsqrt_nr(dj);
+    if (lane == j) invd_me = rs;
+    if (act) H[tri(lane, j)] = s * rs;
+    WSYNC();
   }
-  for (; p < n; p++) {
-    T l0 = (in && lane > p) ? ri[p] : (T)0;
-    if (lane == p) x *= invd;
-    x -= l0 * bcast(x, p);
-  }
-  p = n - 1;
+  // row n now holds y = L^-1 b; backward pass L^T x = y
+  T x = lane < n ? H[tri(n, 0) + lane] : (T)0;
+  int p = n - 1;
   for (; p - 3 >= 0; p -= 4) {
-    T l0 = (lane < p) ? H[tri(p, 0) + lane] : (T)0;
-    T l1 = (lane < p - 1) ? H[tri(p - 1, 0) + lane] : (T)0;
-    T l2 = (lane < p - 2) ? H[tri(p - 2, 0) + lane] : (T)0;
-    T l3 = (lane < p - 3) ? H[tri(p - 3, 0) + lane] : (T)0;
-    if (lane == p) x *= invd;
+    T l0 = H[tri(p, 0) + (lane < p ? lane : 0)], l1 = H[tri(p - 1, 0) + (lane < p - 1 ? lane : 0)];
+    T l2 = H[tri(p - 2, 0) + (lane < p - 2 ? lane : 0)], l3 = H[tri(p - 3, 0) + (lane < p - 3 ? lane : 0)];
+    l0 = lane < p ? l0 : (T)0; l1 = lane < p - 1 ? l1 : (T)0; l2 = lane < p - 2 ? l2 : (T)0; l3 = lane < p - 3 ? l3 : (T)0;
+    if (lane == p) x *= invd_me;
     x -= l0 * bcast(x, p);
-    if (lane == p - 1) x *= invd;
+    if (lane == p - 1) x *= invd_me;
     x -= l1 * bcast(x, p - 1);
-    if (lane == p - 2) x *= invd;
+    if (lane == p - 2) x *= invd_me;
     x -= l2 * bcast(x, p - 2);
-    if (lane == p - 3) x *= invd;
+    if (lane == p - 3) x *= invd_me;
     x -= l3 * bcast(x, p - 3);
   }
   for (; p >= 0; p--) {
-    T l0 = (lane < p) ? H[tri(p, 0) + lane] : (T)0;
-    if (lane == p) x *= invd;
+    T l0 = H[tri(p, 0) + (lane < p ? lane : 0)];
+    l0 = lane < p ? l0 : (T)0;
+    if (lane == p) x *= invd_me;
     x -= l0 * bcast(x, p);
   }
   return x;
 }
-// y = M x, M symmetric packed (n rows), x in the register of lane j
-template <typename T>
-__device__ T symv_packed(const T* M, int n, int lane, T x) {
-  T s = 0;
-  const bool in = lane < n;
-  const T* ri = M + tri(in ? lane : 0, 0);
-  if (!in) x = 0;
-  int j = 0;
-  for (; j + 4 <= n; j += 4) {
-    T m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-    if (in) {
-      m0 = (j <= lane) ? ri[j] : M[tri(j, 0) + lane];
-      m1 = (j + 1 <= lane) ? ri[j + 1] : M[tri(j + 1, 0) + lane];
-      m2 = (j + 2 <= lane) ? ri[j + 2] : M[tri(j + 2, 0) + lane];
-      m3 = (j + 3 <= lane) ? ri[j + 3] : M[tri(j + 3, 0) + lane];
-    }
-    s += m0 * bcast(x, j); s += m1 * bcast(x, j + 1); s += m2 * bcast(x, j + 2);
-    s += m3 * bcast(x, j + 3);
-  }
-  for (; j < n; j++) {
-    T m0 = in ? ((j <= lane) ? ri[j] : M[tri(j, 0) + lane]) : (T)0;
-    s += m0 * bcast(x, j);
-  }
-  return s;
-}
-
 }  // namespace rpk
 
 // physics.reset() for the envs selected by a device-side mask (null = all).
@@ -974,40 +972,49 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
         const bool isslot = !isl && lane < nl + nslots;
         const bool dirty = (dm >> lane) & 1;
         const int mydiag = isl ? depth : sdepth + 1;
-        if (isl || isslot) {
-#pragma unroll
-          for (int e = 0; e <= RPK_MAXD; e++) if (e <= mydiag) sm.R[lane][e] = Rr[e];
-          sm.xs[lane] = rhs;
-        }
+        // LDS reads below are issued unconditionally on in-bounds addresses and the value
+        // is selected afterwards: a conditional read costs a branch and serialises the wait.
         T Dslot = 1;
-        WSYNC();
-        PROF(19);
-        // ---- key leaves first (they hang under chain links)
+        // ---- key leaves first (they hang under chain links): the slot lanes publish their
+        // scaled rows, the link lanes fold them into their register rows
         if (nslots > 0) {
-          if (isslot && !dirty) {
-            T Dk = sm.R[lane][mydiag];
-            if (!(Dk >= RPK_MINVAL)) { Dk = RPK_MINVAL; warn |= 4; }
-            Dslot = Dk;
-            const T inv = (T)1 / Dk;
-            for (int e = 0; e < mydiag; e++) sm.R[lane][e] *= inv;
+          if (isslot) {
+            T Dk = (T)1;
+#pragma unroll
+            for (int e = 0; e <= RPK_MAXD; e++) if (e == mydiag) Dk = Rr[e];
+            if (!dirty) {
+              if (!(Dk >= RPK_MINVAL)) { Dk = RPK_MINVAL; warn |= 4; }
+              Dslot = Dk;
+            }
+            const T inv = dirty ? (T)1 : (T)1 / Dk;
+#pragma unroll
+            for (int e = 0; e <= RPK_MAXD; e++) if (e <= mydiag) sm.R[lane][e] = e < mydiag ? Rr[e] * inv : Rr[e];
             sm.Dg[lane] = Dk;
+            sm.xs[lane] = rhs;
           }
           WSYNC();
           if (isl) {
-            T xr = sm.xs[lane];
             for (int sidx = 0; sidx < nslots; sidx++) {
+              const T* Lk = sm.R[nl + sidx];
+              T lrow[RPK_MAXD + 1];
+#pragma unroll
+              for (int e = 0; e <= RPK_MAXD; e++) lrow[e] = Lk[e];
+              const T lk = Lk[depth], dk = sm.Dg[nl + sidx], xk = sm.xs[nl + sidx];
               if (((sm.slotmask[sidx] >> lane) & 1) && !((dm >> (nl + sidx)) & 1)) {
-                const T* Lk = sm.R[nl + sidx];
-                const T lk = Lk[depth];
-                const T t = lk * sm.Dg[nl + sidx];
-                for (int e = 0; e <= depth; e++) sm.R[lane][e] -= t * Lk[e];
-                xr -= lk * sm.xs[nl + sidx];
+                const T t = lk * dk;
+#pragma unroll
+                for (int e = 0; e <= RPK_MAXD; e++) if (e <= depth) Rr[e] -= t * lrow[e];
+                rhs -= lk * xk;
               }
             }
-            sm.xs[lane] = xr;
           }
-          WSYNC();
         }
+        if (isl && depth >= TL) {
+#pragma unroll
+          for (int e = 0; e <= RPK_MAXD; e++) if (e <= depth) sm.R[lane][e] = Rr[e];
+          sm.xs[lane] = rhs;
+        }
+        WSYNC();
         PROF(20);
         // ---- chain leaders: local variables 0..3 = trunk, 4..8 = my chain (depth order)
         const bool leader = isl && depth == TL && TL > 0;
@@ -1025,13 +1032,16 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           for (int ci = 0; ci < 5; ci++) {
             const bool pi = ci < clen;
             mc[ci] = pi && !((dm >> (lane + ci)) & 1);
-            rc_[ci] = pi ? sm.xs[lane + ci] : (T)0;
+            const T* row = sm.R[lane + ci];   // lane + ci < 64: always in bounds
+            const T* rowc = row + TL;         // chain columns start at depth TL
+            const T xr_ = sm.xs[lane + ci];
+            rc_[ci] = pi ? xr_ : (T)0;
 #pragma unroll
             for (int j = 0; j < 9; j++) {
               if (j <= 4 + ci) {
                 const bool pj = j < 4 ? j < TL : (j - 4) < clen;
-                const int e = j < 4 ? j : TL + (j - 4);
-                Ac[ci][j] = (pi && pj) ? sm.R[lane + ci][e] : (j == 4 + ci ? (T)1 : (T)0);
+                const T raw = j < 4 ? row[j] : rowc[j - 4];
+                Ac[ci][j] = (pi && pj) ? raw : (j == 4 + ci ? (T)1 : (T)0);
               }
             }
           }
@@ -1065,18 +1075,17 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
 #pragma unroll
             for (int i = 0; i < 8; i++) if (i < v && mc[ci]) Ac[ci][i] = l[i];
           }
-          // rows / rhs of the links I did not eliminate go back for the dense block
+          // rows / rhs of the links I did not eliminate go back for the dense block (the
+          // LDS rows of eliminated links are dead, so every present row is stored)
 #pragma unroll
           for (int ci = 0; ci < 5; ci++) {
-            if (ci < clen && !mc[ci]) {
+            if (ci < clen) {
+              T* row = sm.R[lane + ci];
+              T* rowc = row + TL;
 #pragma unroll
-              for (int j = 0; j < 9; j++) {
-                if (j <= 4 + ci) {
-                  const bool pj = j < 4 ? j < TL : (j - 4) < clen;
-                  const int e = j < 4 ? j : TL + (j - 4);
-                  if (pj) sm.R[lane + ci][e] = Ac[ci][j];
-                }
-              }
+              for (int j = 0; j < 4; j++) if (j < TL) row[j] = Ac[ci][j];
+#pragma unroll
+              for (int j = 4; j < 9; j++) if (j <= 4 + ci) rowc[j - 4] = Ac[ci][j];
               sm.xs[lane + ci] = rc_[ci];
             }
           }
@@ -1090,16 +1099,22 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
         WSYNC();
         // ---- trunk rows collect the chains' contributions (fixed order: deterministic)
         if (isl && depth < TL) {
-          T xr = sm.xs[lane];
+          const int tro = depth * (depth + 1) / 2;
 #pragma unroll
           for (int c = 0; c < 5; c++) {
-            if ((c == 0 ? cl[0] : c == 1 ? cl[1] : c == 2 ? cl[2] : c == 3 ? cl[3] : cl[4]) > 0) {
-              const T* rec = sm.H + (size_t)(ltree * 5 + c) * 14;
-              for (int e = 0; e <= depth; e++) sm.R[lane][e] += rec[depth * (depth + 1) / 2 + e];
-              xr += rec[10 + depth];
-            }
+            const T* rec = sm.H + (size_t)(ltree * 5 + c) * 14;
+            T dv[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) dv[e] = rec[tro + e < 10 ? tro + e : 9];
+            const T dr = rec[10 + depth];
+            const bool has = (c == 0 ? cl[0] : c == 1 ? cl[1] : c == 2 ? cl[2] : c == 3 ? cl[3] : cl[4]) > 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) if (has && e <= depth) Rr[e] += dv[e];
+            if (has) rhs += dr;
           }
-          sm.xs[lane] = xr;
+#pragma unroll
+          for (int e = 0; e < 4; e++) if (e <= depth) sm.R[lane][e] = Rr[e];
+          sm.xs[lane] = rhs;
         }
         WSYNC();
         // ---- trunk leader eliminates the clean trunk links (deepest first)
@@ -1111,9 +1126,15 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           for (int i = 0; i < 4; i++) {
             const bool pi = i < TL;
             mt[i] = pi && !((dm >> (lane + i)) & 1);
-            rt[i] = pi ? sm.xs[lane + i] : (T)0;
+            const T xin = sm.xs[lane + i];
+            rt[i] = pi ? xin : (T)0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) if (j <= i) At[i][j] = pi ? sm.R[lane + i][j] : (j == i ? (T)1 : (T)0);
+            for (int j = 0; j < 4; j++) {
+              if (j <= i) {
+                const T raw = sm.R[lane + i][j];
+                At[i][j] = pi ? raw : (j == i ? (T)1 : (T)0);
+              }
+            }
           }
 #pragma unroll
           for (int v = 3; v >= 0; v--) {
@@ -1137,7 +1158,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           }
 #pragma unroll
           for (int i = 0; i < 4; i++) {
-            if (i < TL && !mt[i]) {
+            if (i < TL) {  // (rows of eliminated links are dead: store them all)
 #pragma unroll
               for (int j = 0; j < 4; j++) if (j <= i) sm.R[lane + i][j] = At[i][j];
               sm.xs[lane + i] = rt[i];
@@ -1175,13 +1196,10 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           cross_fn(cidx);
           WSYNC();
           PROF(23);
-          // rhs of compact row r comes from the lane that owns it
-          if (dirty) sm.Dg[ci] = x;   // Dg of dirty rows is unused: staging for the compact rhs
+          // the rhs of compact row r (owned by a dirty lane) is row nD of the packed block
+          if (dirty) sm.H[tri(nD, 0) + ci] = x;
           WSYNC();
-          T xr = lane < nD ? sm.Dg[lane] : (T)0;
-          WSYNC();
-          chol_packed(sm.H, nD, lane, &warn);
-          xr = solve_packed(sm.H, nD, lane, xr);
+          T xr = dense_factor_solve(sm.H, nD, lane, &warn);
           WSYNC();
           if (lane < nD) sm.Dg[lane] = xr;
           WSYNC();
@@ -1193,31 +1211,31 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
         if (tleader) {
           T xt[4];
 #pragma unroll
-          for (int v = 0; v < 4; v++) {
-            if (mt[v]) {
-              T xv = rt[v] * invt[v];
+          for (int v = 0; v < 4; v++) xt[v] = sm.xs[lane + v];
 #pragma unroll
-              for (int i = 0; i < 3; i++) if (i < v) xv -= At[v][i] * xt[i];
-              xt[v] = xv;
-              sm.xs[lane + v] = xv;
-            } else xt[v] = v < TL ? sm.xs[lane + v] : (T)0;
+          for (int v = 0; v < 4; v++) {
+            T xv = rt[v] * invt[v];
+#pragma unroll
+            for (int i = 0; i < 3; i++) if (i < v) xv -= At[v][i] * xt[i];
+            xt[v] = mt[v] ? xv : (v < TL ? xt[v] : (T)0);
+            if (v < TL) sm.xs[lane + v] = xt[v];
           }
         }
         WSYNC();
         if (leader) {
           T xl[9];
 #pragma unroll
-          for (int j = 0; j < 4; j++) xl[j] = j < TL ? sm.xs[tbase + j] : (T)0;
+          for (int j = 0; j < 4; j++) { const T xin = sm.xs[tbase + j]; xl[j] = j < TL ? xin : (T)0; }
+#pragma unroll
+          for (int ci = 0; ci < 5; ci++) xl[4 + ci] = sm.xs[lane + ci];
 #pragma unroll
           for (int ci = 0; ci < 5; ci++) {
             const int v = 4 + ci;
-            if (mc[ci]) {
-              T xv = rc_[ci] * inv_[ci];
+            T xv = rc_[ci] * inv_[ci];
 #pragma unroll
-              for (int i = 0; i < 8; i++) if (i < v) xv -= Ac[ci][i] * xl[i];
-              xl[v] = xv;
-              sm.xs[lane + ci] = xv;
-            } else xl[v] = ci < clen ? sm.xs[lane + ci] : (T)0;
+            for (int i = 0; i < 8; i++) if (i < v) xv -= Ac[ci][i] * xl[i];
+            xl[v] = mc[ci] ? xv : (ci < clen ? xl[v] : (T)0);
+            if (ci < clen) sm.xs[lane + ci] = xl[v];
           }
         }
         WSYNC();
@@ -1528,7 +1546,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
                   int j = __ffsll((long long)rem) - 1;
                   rem &= rem - 1;
                   T j0 = bcast(jc[0], j), j1 = bcast(jc[1], j), j2 = bcast(jc[2], j);
-                  if (insup && lane >= j) sm.H[tri(cme, cidx(j))] += u0 * j0 + u1 * j1 + u2 * j2;
+                  if (insup && lane >= j) lds_add(&sm.H[tri(cme, cidx(j))], u0 * j0 + u1 * j1 + u2 * j2);
                 }
               }
             };
