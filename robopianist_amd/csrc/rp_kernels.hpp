@@ -1830,78 +1830,93 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
 
     PROF(18);
     // ---- broad phase + narrow phase, streamed through a bounded work list
-    // [MJ: mj_collision].  Candidate generators: (0) the static pair list, 64 pairs at a
-    // time; (1) every hand capsule near the keyboard against the 88 keys (lane = key).
-    // Whenever 64 candidates are pending they are narrow-phased, so the list never
-    // overflows whatever the pose.
+    // [MJ: mj_collision].  Broad phase: lane g holds geom g and collects, as a 64-bit mask,
+    // the partners j > g whose bounding spheres touch (63 readlane broadcasts, no memory,
+    // no per-pair bookkeeping); lane k holds keys k, k+64 and collects the hand capsules
+    // near them.  The culling runs in fp32 with inflated radii: it only has to be a
+    // superset, the narrow phase decides in working precision.  The masks are then
+    // drained one bit per lane per round into the work list; whenever 64 candidates are
+    // pending they are narrow-phased, so the list never overflows whatever the pose.
     int nwork = 0;
     ncon = 0;
     {
-    // lane g < ngeom holds geom g (centre, bounding radius, allowed partners): candidate
-    // generation is pure ALU + readlane broadcasts, no memory access in the loop
     const bool isg = lane < M.ngeom;
-    const T gcx = isg ? sm.gpos[lane][0] : (T)0, gcy = isg ? sm.gpos[lane][1] : (T)0,
-            gcz = isg ? sm.gpos[lane][2] : (T)0;
-    const T grb = isg ? M.geom_rbound()[lane] : (T)0;
+    const float fcx = isg ? (float)sm.gpos[lane][0] : 0.f, fcy = isg ? (float)sm.gpos[lane][1] : 0.f,
+                fcz = isg ? (float)sm.gpos[lane][2] : 0.f;
+    const float frb = isg ? (float)M.geom_rbound()[lane] * 1.0001f + 1e-6f : 0.f;
     const unsigned long long gpm =
         isg ? (((unsigned long long)(unsigned)M.geom_pairmask()[2 * lane + 1] << 32) | (unsigned)M.geom_pairmask()[2 * lane])
             : 0ull;
     const bool gkc = isg && M.geom_iskeycap()[lane] != 0;
-    int gen_phase = (M.ngeom > 1) ? 0 : 1, gen_base = 1, gen_slot = 0;
-    unsigned long long near_mask = 0;
-    bool near_ready = false;
-    while (true) {
-      if (gen_phase == 0) {
-        // all geoms i < j against geom j = gen_base
-        const int j = gen_base;
-        const T jx = bcast(gcx, j), jy = bcast(gcy, j), jz = bcast(gcz, j), jr = bcast(grb, j);
-        const T dx = gcx - jx, dy = gcy - jy, dz = gcz - jz, rr = grb + jr;
-        const bool hit = ((gpm >> j) & 1) && (dx * dx + dy * dy + dz * dz <= rr * rr);
-        unsigned long long mk = __ballot(hit);
-        int idx = nwork + __popcll(mk & lanemask_lt(lane));
-        if (hit) { sm.work[idx][0] = (short)lane; sm.work[idx][1] = (short)j; }
-        nwork += __popcll(mk);
-        gen_base++;
-        if (gen_base >= M.ngeom) gen_phase = 1;
-      } else if (gen_phase == 1) {
-        if (!near_ready) {
-          near_mask = __ballot(gkc && (gcz - grb <= M.key_zmax));
-          near_ready = true;
-        }
-        if (near_mask == 0ull || nk == 0) gen_phase = 2;
-        else {
-          int g = __ffsll((long long)near_mask) - 1;
-          T cx = bcast(gcx, g), cy = bcast(gcy, g), cz = bcast(gcz, g), rb = bcast(grb, g);
-          bool hit = false;
-          const int s = gen_slot;
-          // (s is uniform; select this lane's key of slot s without dynamic register indexing)
-          const bool kok = s == 0 ? isk[0] : isk[1];
-          if (kok) {
-            const T kpx = s == 0 ? kpos[0][0] : kpos[1][0], kpy = s == 0 ? kpos[0][1] : kpos[1][1],
-                    kpz = s == 0 ? kpos[0][2] : kpos[1][2];
-            const T khx_ = s == 0 ? khalf[0][0] : khalf[1][0], khy_ = s == 0 ? khalf[0][1] : khalf[1][1],
-                    khz_ = s == 0 ? khalf[0][2] : khalf[1][2];
-            const T kc_ = s == 0 ? kcos[0] : kcos[1], ks_ = s == 0 ? ksin[0] : ksin[1];
-            const T krb_ = s == 0 ? krb[0] : krb[1];
-            // key box centre = anchor + R_y(q) (hx,0,0)
-            T kx = kpx - khx_ + khx_ * kc_;
-            T kz = kpz - khx_ * ks_;
-            T dx = kx - cx, dy = kpy - cy, dz = kz - cz, rr = rb + krb_;
-            // bounding spheres, then a conservative box test (the key only rotates
-            // about y, so its y-extent is exact; x/z get a 1 cm allowance)
-            hit = dx * dx + dy * dy + dz * dz <= rr * rr && N::abs(dy) <= khy_ + rb &&
-                  N::abs(cx - kpx) <= khx_ + rb + (T)0.01 && cz - rb <= kpz + khz_ + (T)0.01;
-          }
-          unsigned long long mk = __ballot(hit);
-          int idx = nwork + __popcll(mk & lanemask_lt(lane));
-          if (hit) { sm.work[idx][0] = (short)g; sm.work[idx][1] = (short)(RPK_KEYBASE + (s == 0 ? kid[0] : kid[1])); }
-          nwork += __popcll(mk);
-          gen_slot++;
-          if (gen_slot == 2) { gen_slot = 0; near_mask &= near_mask - 1; }
+    unsigned hitlo = 0, hithi = 0;
+#pragma unroll
+    for (int j0 = 0; j0 < 64; j0 += 8) {
+      if (j0 < M.ngeom) {
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) {
+          const int j = j0 + jj;
+          const float dx = fcx - bcast(fcx, j), dy = fcy - bcast(fcy, j), dz = fcz - bcast(fcz, j);
+          const float rr = frb + bcast(frb, j);
+          const bool hit = dx * dx + dy * dy + dz * dz <= rr * rr;
+          if (j < 32) hitlo |= hit ? (1u << j) : 0u; else hithi |= hit ? (1u << (j - 32)) : 0u;
         }
       }
-      PROF(12);
-      const bool gen_done = gen_phase == 2;
+    }
+    // allowed pairs only (the pair mask is upper-triangular and empty beyond ngeom)
+    unsigned long long remA = (((unsigned long long)hithi << 32) | hitlo) & gpm;
+    // keys: capsules that reach down to the keyboard, against this lane's two keys
+    unsigned long long remK0 = 0, remK1 = 0;
+    {
+      unsigned long long near_mask = __ballot(gkc && (fcz - frb <= (float)M.key_zmax));
+      if (nk == 0) near_mask = 0;
+      float kx[2], kz[2], kpx[2], kpy[2], ktop[2], khx_[2], khy_[2], krb_[2];
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        // key box centre = anchor + R_y(q) (hx,0,0)
+        kx[s] = (float)(kpos[s][0] - khalf[s][0] + khalf[s][0] * kcos[s]);
+        kz[s] = (float)(kpos[s][2] - khalf[s][0] * ksin[s]);
+        kpx[s] = (float)kpos[s][0]; kpy[s] = (float)kpos[s][1];
+        ktop[s] = (float)(kpos[s][2] + khalf[s][2]) + 0.01f;
+        khx_[s] = (float)khalf[s][0] + 0.01f; khy_[s] = (float)khalf[s][1];
+        krb_[s] = (float)krb[s] * 1.0001f + 1e-6f;
+      }
+      while (near_mask) {
+        const int g = __ffsll((long long)near_mask) - 1;
+        near_mask &= near_mask - 1;
+        const float cx = bcast(fcx, g), cy = bcast(fcy, g), cz = bcast(fcz, g), rb = bcast(frb, g);
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+          const float dx = kx[s] - cx, dy = kpy[s] - cy, dz = kz[s] - cz, rr = rb + krb_[s];
+          // bounding spheres, then a conservative box test (the key only rotates about
+          // y, so its y-extent is exact; x/z get a 1 cm allowance)
+          const bool hit = isk[s] && dx * dx + dy * dy + dz * dz <= rr * rr && fabsf(dy) <= khy_[s] + rb &&
+                           fabsf(cx - kpx[s]) <= khx_[s] + rb && cz - rb <= ktop[s];
+          if (s == 0) remK0 |= hit ? (1ull << g) : 0ull; else remK1 |= hit ? (1ull << g) : 0ull;
+        }
+      }
+    }
+    PROF(12);
+    int gen_phase = 0;
+    while (true) {
+      // ---- one drain round: every lane contributes at most one candidate
+      if (gen_phase < 3) {
+        const unsigned long long rem = gen_phase == 0 ? remA : (gen_phase == 1 ? remK0 : remK1);
+        const bool has = rem != 0ull;
+        const unsigned long long mk = __ballot(has);
+        if (mk == 0ull) gen_phase++;
+        else {
+          const int bit = has ? __ffsll((long long)rem) - 1 : 0;
+          const unsigned long long rest = rem & (rem - 1);
+          if (gen_phase == 0) remA = rest; else if (gen_phase == 1) remK0 = rest; else remK1 = rest;
+          const int idx = nwork + __popcll(mk & lanemask_lt(lane));
+          if (has) {
+            if (gen_phase == 0) { sm.work[idx][0] = (short)lane; sm.work[idx][1] = (short)bit; }
+            else { sm.work[idx][0] = (short)bit; sm.work[idx][1] = (short)(RPK_KEYBASE + (gen_phase == 1 ? kid[0] : kid[1])); }
+          }
+          nwork += __popcll(mk);
+        }
+      }
+      const bool gen_done = gen_phase == 3;
       if (!(nwork >= 64 || (gen_done && nwork > 0))) {
         if (gen_done) break;
         continue;
