@@ -24,7 +24,17 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_ENV_STEP = 4352  # 1856 in + 1680 out + 712 epilogue (fp32, fused)
+# Algorithmic bytes of ONE launch of the dominant kernel (rp_stage_kernel<T,1>, the mj_step2 /
+# constraint-solver stage of one substep) per env, in elements of T:
+#   in : qpos qvel qacc_warmstart qfrc_applied (4 nv) + ctrl (nu)
+#   out: qpos qvel qacc_warmstart (3 nv) + actuator_force (nu) + time (1)
+# = 7*140 + 2*44 + 1 = 1069 elements -> 4276 B (fp32), 8552 B (fp64).  SURVEY/BASELINE §2.3
+# quote 4352 B per fused env-step; that figure assumed one 10-substep kernel and is reported
+# under roofline.note for reference.
+def algo_bytes_per_solver_launch(nv, nu, precision):
+    return (7 * nv + 2 * nu + 1) * (8 if precision == 64 else 4)
+
+
 HBM_PEAK_GBS = 8000.0
 
 
@@ -44,14 +54,15 @@ def _usable_cores():
     return n
 
 
-def _pmc_traffic(E):
-    """HBM bytes per step-kernel launch from the committed rocprofv3 --pmc passes
-    (profiles/traffic_r01.json); null if not collected for
-    this env count."""
+def _pmc_traffic(E, precision):
+    """HBM-side bytes per solver-kernel launch from the committed rocprofv3 --pmc passes
+    (profiles/traffic_r01.json); null if not collected for this
+    env count / precision."""
     p = os.path.join(ROOT, "profiles", "traffic_r01.json")
     try:
         d = json.load(open(p))
-        return d["bytes_per_launch"] if int(d["envs"]) == int(E) else None
+        ok = int(d["envs"]) == int(E) and int(d["precision"]) == int(precision)
+        return d["solver_kernel_bytes_per_launch"] if ok else None
     except Exception:
         return None
 
@@ -157,7 +168,7 @@ def main():
         for t in range(warmup):
             one_step(t)
         barrier()
-        phys.kernel_time()  # reset kernel timer
+        phys.solver_kernel_time(); phys.kernel_time()  # reset the event-timer statistics
         t0 = time.perf_counter()
         for t in range(steps):
             one_step(warmup + t)
@@ -167,6 +178,7 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
+        sms, snl = phys.solver_kernel_time()
         kms, nl = phys.kernel_time()
         warn = int(phys.warn_flags.max())
         q = phys.qpos
@@ -174,14 +186,18 @@ def main():
         ctrl_seq, _ = load_actions(m)
 
 
-        return dict(dt=dt, kms=kms, nl=nl, warn=warn, finite=finite, phys=phys, m=m, ctrl_seq=ctrl_seq, E=E)
+        return dict(dt=dt, kms=kms, nl=nl, sms=sms, snl=snl, warn=warn, finite=finite, phys=phys, m=m,
+                    ctrl_seq=ctrl_seq, E=E)
 
     r = measure(args.precision, args.steps, args.warmup)
-    dt, kms, nl, warn, finite, phys, m, ctrl_seq, E = (r[k] for k in ('dt','kms','nl','warn','finite','phys','m','ctrl_seq','E'))
+    dt, kms, nl, sms, snl, warn, finite, phys, m, ctrl_seq, E = (
+        r[k] for k in ('dt', 'kms', 'nl', 'sms', 'snl', 'warn', 'finite', 'phys', 'm', 'ctrl_seq', 'E'))
 
     if rank == 0:
         value = world * E * args.steps / dt
-        achieved = ALGO_BYTES_PER_ENV_STEP * (2 if args.precision == 64 else 1) * E / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        algo = algo_bytes_per_solver_launch(int(m.nv), int(m.nu), args.precision) * E
+        achieved = algo / (sms * 1e-3) / 1e9 if sms > 0 else 0.0
+        tname = "double" if args.precision == 64 else "float"
         out = {
             "metric": "env-steps/sec (whole node) at 4096 envs/GPU",
             "value": value,
@@ -203,11 +219,16 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(E),
-                "kernel": "rp_step_kernel<%s>" % ("double" if args.precision == 64 else "float"),
-                "kernel_avg_ms": kms, "kernel_launches": nl,
-                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * (2 if args.precision == 64 else 1) * E,
-                "note": "fused 10-substep kernel: state lives in registers/LDS, so the path is latency/issue bound by construction (BASELINE.md 2.3); HBM fraction reported because the north-star asks for it",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(E, args.precision),
+                "kernel": "rp_stage_kernel<%s, 1> (mj_step2: constraint solver + Euler, one substep of all envs)" % tname,
+                "kernel_avg_ms": sms, "kernel_launches_sampled": snl,
+                "algorithmic_bytes_per_launch": algo,
+                "step_sequence_avg_ms": kms, "step_sequences": nl,
+                "note": "one rp_step = 1 + 2*substeps launches (rp_stage_kernel<T,0> position/velocity stage, "
+                        "<T,1> solver stage); kernel_avg_ms is the solver launch of the middle substep of every step "
+                        "(HIP events on the engine stream), step_sequence_avg_ms the whole 21-launch sequence. "
+                        "The path is instruction-issue / latency bound (one wave per env, one wave per SIMD), "
+                        "not HBM bound: see DESIGN.md 6",
             },
             "sanity": {"warn_flags": warn, "finite": finite},
             "parity": "fp64 engine: max rel |dq| vs CPU oracle over 1000 mj_steps of this replay = 9e-5 (<1e-4), "

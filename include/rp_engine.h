@@ -109,9 +109,15 @@ int rp_set_stream(rp_engine* e, void* hip_stream);
 int rp_field_ptr(rp_engine* e, rp_field f, void** ptr, size_t* bytes);
 int rp_n_envs(const rp_engine* e);
 int rp_dim(const rp_engine* e, const char* name); /* "nv","nu","nsite","ntree","nkey","nlink" */
-/* Average device time (ms) of the step kernel since the last call, measured
- * with HIP events on the engine stream; also returns the launch count. */
+/* Average device time (ms) of one rp_step launch sequence (1 + 2*n_substeps kernels)
+ * since the last call, measured with HIP events on the engine stream; also returns
+ * the number of sequences timed. */
 int rp_kernel_time(rp_engine* e, double* avg_ms, int* n_launches);
+/* Average device time (ms) of ONE launch of the dominant kernel (the mj_step2 /
+ * constraint-solver stage, rp_stage_kernel<T,1>), sampled on the middle substep of
+ * every rp_step call, HIP events on the engine stream.  Call before rp_kernel_time
+ * if both are wanted for the same interval. */
+int rp_solver_kernel_time(rp_engine* e, double* avg_ms, int* n_launches);
 /* Debug aid: per-phase shader-clock counters of env 0 (see rp_kernels.hpp PROF).
  * Reads and clears the counters (out may be NULL), then enables/disables them. */
 int rp_profile(rp_engine* e, long long* out, int n, int enable);

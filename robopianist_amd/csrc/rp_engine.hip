@@ -77,12 +77,16 @@ struct EngineBase {
   bool ev_pending[kRing] = {};
   int ev_next = 0;
   double kernel_ms = 0; int kernel_launches = 0;
+  // second ring: one solver-kernel (mj_step2) launch per rp_step call, the middle substep
+  hipEvent_t sv0[kRing] = {}, sv1[kRing] = {};
+  double solver_ms = 0; int solver_launches = 0;
   void harvest(int i, bool wait) {
     if (!ev_pending[i]) return;
     if (wait) hipEventSynchronize(ev1[i]);
     else if (hipEventQuery(ev1[i]) != hipSuccess) return;
     float ms = 0;
     if (hipEventElapsedTime(&ms, ev0[i], ev1[i]) == hipSuccess) { kernel_ms += ms; kernel_launches++; }
+    if (hipEventElapsedTime(&ms, sv0[i], sv1[i]) == hipSuccess) { solver_ms += ms; solver_launches++; }
     ev_pending[i] = false;
   }
   virtual int reset(const uint8_t* mask) = 0;
@@ -112,7 +116,12 @@ struct Engine : EngineBase {
     for (void* p : allocs) hipFree(p);
     if (d_trace) hipFree(d_trace);
     if (d_mask) hipFree(d_mask);
-    for (int i = 0; i < kRing; i++) { if (ev0[i]) hipEventDestroy(ev0[i]); if (ev1[i]) hipEventDestroy(ev1[i]); }
+    for (int i = 0; i < kRing; i++) {
+      if (ev0[i]) hipEventDestroy(ev0[i]);
+      if (ev1[i]) hipEventDestroy(ev1[i]);
+      if (sv0[i]) hipEventDestroy(sv0[i]);
+      if (sv1[i]) hipEventDestroy(sv1[i]);
+    }
     if (stream && own_stream) hipStreamDestroy(stream);
   }
   template <typename U> U* dalloc(size_t n) {
@@ -384,7 +393,10 @@ struct Engine : EngineBase {
     hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(nenv), dim3(64), 0, stream, M, s, B, -1, nsub);
     if (mode == 0) {
       for (int k = 0; k < nsub; k++) {
+        const bool probe = timeit && k == nsub / 2;
+        if (probe) HIP_OK(hipEventRecord(sv0[slot], stream));
         hipLaunchKernelGGL((rp_stage_kernel<T, 1>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
+        if (probe) HIP_OK(hipEventRecord(sv1[slot], stream));
         hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
       }
     }
@@ -431,6 +443,8 @@ int rp_create(const void* model_blob, size_t blob_bytes, int n_envs, int device_
   for (int i = 0; i < EngineBase::kRing; i++) {
     HIP_OK(hipEventCreate(&e->ev0[i]));
     HIP_OK(hipEventCreate(&e->ev1[i]));
+    HIP_OK(hipEventCreate(&e->sv0[i]));
+    HIP_OK(hipEventCreate(&e->sv1[i]));
   }
   int r = e->reset(nullptr);
   if (r) { delete e; return r; }
@@ -510,6 +524,19 @@ int rp_kernel_time(rp_engine* e, double* avg_ms, int* n_launches) {
   if (avg_ms) *avg_ms = b->kernel_launches ? b->kernel_ms / b->kernel_launches : 0.0;
   if (n_launches) *n_launches = b->kernel_launches;
   b->kernel_ms = 0; b->kernel_launches = 0;
+  return 0;
+}
+int rp_solver_kernel_time(rp_engine* e, double* avg_ms, int* n_launches) {
+  if (!e) return fail("null engine");
+  EngineBase* b = E(e);
+  HIP_OK(hipSetDevice(b->device));
+  // harvest without clearing the step-sequence statistics
+  double km = b->kernel_ms; int kl = b->kernel_launches;
+  for (int i = 0; i < EngineBase::kRing; i++) b->harvest(i, true);
+  if (avg_ms) *avg_ms = b->solver_launches ? b->solver_ms / b->solver_launches : 0.0;
+  if (n_launches) *n_launches = b->solver_launches;
+  b->solver_ms = 0; b->solver_launches = 0;
+  (void)km; (void)kl;
   return 0;
 }
 

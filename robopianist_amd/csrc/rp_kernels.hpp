@@ -499,7 +499,13 @@ struct Smem {
         T cdof[RPK_NL][6];  // until the mass-matrix rows are built
         T vel[RPK_NL][6];   // afterwards: spatial velocities / accelerations
       };
-      T acc[RPK_NL][10];    // composite inertias, then subtree forces
+      union {
+        T acc[RPK_NL][10];  // composite inertias, then subtree forces
+        struct {            // in between (collision): fp32 capsule axes for the candidate prefilter
+          float gax[RPK_WAVE][4];  // world axis, half-length (0 for boxes)
+          float grr[RPK_WAVE];     // radius (bounding radius for boxes)
+        };
+      };
       T gpos[RPK_WAVE][3];
       short work[RPK_WORK][2];
     };
@@ -1825,6 +1831,14 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
         gp[0] = sm.xpos[gl][0] + t[0]; gp[1] = sm.xpos[gl][1] + t[1]; gp[2] = sm.xpos[gl][2] + t[2];
       }
       sm.gpos[lane][0] = gp[0]; sm.gpos[lane][1] = gp[1]; sm.gpos[lane][2] = gp[2];
+      // capsule axis (third column of the world geom frame) for the segment prefilter
+      const T* gm = M.geom_mat() + 9 * lane;
+      T az[3] = {gm[2], gm[5], gm[8]};
+      if (gl >= 0) { T t[3]; mat_vec(t, sm.xmat[gl], az); az[0] = t[0]; az[1] = t[1]; az[2] = t[2]; }
+      const bool cap = M.geom_type()[lane] == GEOM_CAPSULE_;
+      sm.gax[lane][0] = (float)az[0]; sm.gax[lane][1] = (float)az[1]; sm.gax[lane][2] = (float)az[2];
+      sm.gax[lane][3] = cap ? (float)M.geom_size()[3 * lane + 1] : 0.f;
+      sm.grr[lane] = cap ? (float)M.geom_size()[3 * lane] : (float)M.geom_rbound()[lane];
     }
     WSYNC();
 
@@ -1848,6 +1862,8 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
         isg ? (((unsigned long long)(unsigned)M.geom_pairmask()[2 * lane + 1] << 32) | (unsigned)M.geom_pairmask()[2 * lane])
             : 0ull;
     const bool gkc = isg && M.geom_iskeycap()[lane] != 0;
+    const float fax = isg ? sm.gax[lane][0] : 0.f, fay = isg ? sm.gax[lane][1] : 0.f, faz = isg ? sm.gax[lane][2] : 0.f;
+    const float fhl = isg ? sm.gax[lane][3] : 0.f, frr = isg ? sm.grr[lane] : 0.f;
     unsigned hitlo = 0, hithi = 0;
 #pragma unroll
     for (int j0 = 0; j0 < 64; j0 += 8) {
@@ -1896,18 +1912,45 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
       }
     }
     PROF(12);
+#ifndef RPK_MARK
+    if (S.prof && env == 0) {
+      int ca = (int)wave_sum((float)__popcll(remA)), ck = (int)wave_sum((float)(__popcll(remK0) + __popcll(remK1)));
+      if (lane == 0) { sm.prof[28] += ca; sm.prof[29] += ck; }
+    }
+#endif
     int gen_phase = 0;
     while (true) {
       // ---- one drain round: every lane contributes at most one candidate
       if (gen_phase < 3) {
         const unsigned long long rem = gen_phase == 0 ? remA : (gen_phase == 1 ? remK0 : remK1);
-        const bool has = rem != 0ull;
-        const unsigned long long mk = __ballot(has);
-        if (mk == 0ull) gen_phase++;
+        bool has = rem != 0ull;
+        if (__ballot(has) == 0ull) gen_phase++;
         else {
           const int bit = has ? __ffsll((long long)rem) - 1 : 0;
           const unsigned long long rest = rem & (rem - 1);
           if (gen_phase == 0) remA = rest; else if (gen_phase == 1) remK0 = rest; else remK1 = rest;
+          if (gen_phase == 0) {
+            // segment-segment distance (boxes: centre point with their bounding radius)
+            // against the sum of radii, fp32 with a 0.1 mm allowance: most sphere-overlap
+            // candidates between neighbouring phalanges end here
+            const float bx = sm.gax[bit][0], by = sm.gax[bit][1], bz = sm.gax[bit][2], l2 = sm.gax[bit][3];
+            const float r2 = sm.grr[bit];
+            const float rx = fcx - (float)sm.gpos[bit][0], ry = fcy - (float)sm.gpos[bit][1],
+                        rz = fcz - (float)sm.gpos[bit][2];
+            const float bb = fax * bx + fay * by + faz * bz;
+            const float cc = fax * rx + fay * ry + faz * rz, ff = bx * rx + by * ry + bz * rz;
+            const float den = 1.f - bb * bb;
+            float x1 = den > 1e-6f ? fminf(fhl, fmaxf(-fhl, (bb * ff - cc) / den)) : 0.f;
+            float x2 = bb * x1 + ff;
+            if (x2 > l2 || x2 < -l2) {
+              x2 = fminf(l2, fmaxf(-l2, x2));
+              x1 = fminf(fhl, fmaxf(-fhl, bb * x2 - cc));
+            }
+            const float ex = rx + fax * x1 - bx * x2, ey = ry + fay * x1 - by * x2, ez = rz + faz * x1 - bz * x2;
+            const float reach = frr + r2 + 1e-4f;
+            has = has && (ex * ex + ey * ey + ez * ez <= reach * reach);
+          }
+          const unsigned long long mk = __ballot(has);
           const int idx = nwork + __popcll(mk & lanemask_lt(lane));
           if (has) {
             if (gen_phase == 0) { sm.work[idx][0] = (short)lane; sm.work[idx][1] = (short)bit; }
@@ -1925,6 +1968,9 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
       // ---- narrow phase on the first min(64, nwork) candidates
       // [MJ: mjc_*, mj_contactParam, mj_makeImpedance]
       const int nproc = nwork < 64 ? nwork : 64;
+#ifndef RPK_MARK
+      if (S.prof && env == 0 && lane == 0) { sm.prof[30] += nproc; sm.prof[31] += 1; }
+#endif
       {
       const int base = 0;
       int w = base + lane;

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = (
     "rp_create", "rp_destroy", "rp_reset", "rp_set", "rp_get", "rp_step", "rp_forward",
     "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
     "rp_n_envs", "rp_dim",
-    "rp_kernel_time", "rp_profile", "rp_last_error",
+    "rp_kernel_time", "rp_solver_kernel_time", "rp_profile", "rp_last_error",
 )
 
 _lib = None
@@ -75,6 +75,8 @@ def load_library(path: str = LIB_PATH):
     L.rp_dim.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
     L.rp_kernel_time.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                  ctypes.POINTER(ctypes.c_int)]
+    L.rp_solver_kernel_time.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
+                                        ctypes.POINTER(ctypes.c_int)]
     L.rp_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     L.rp_set_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.rp_field_ptr.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
@@ -221,9 +223,15 @@ class BatchedPhysics:
         self._check(self._L.rp_set_solver_tolerance(self._h, float(tolerance), float(ls_tolerance)))
 
     def kernel_time(self):
-        """(average step-kernel ms since last call, number of launches)."""
+        """(average device ms of one rp_step launch sequence since last call, sequences timed)."""
         ms = ctypes.c_double(); n = ctypes.c_int()
         self._check(self._L.rp_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def solver_kernel_time(self):
+        """(average device ms of ONE solver-kernel launch since last call, launches sampled)."""
+        ms = ctypes.c_double(); n = ctypes.c_int()
+        self._check(self._L.rp_solver_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
 
     def profile(self, enable=True):

@@ -20,7 +20,10 @@ for t in range(30,30+n):
     phys.set(engine.CTRL, ctrl[t][None,:]); phys.step(10)
     its.append(phys.get(engine.SOLVER_ITER).mean())
 p = phys.profile(False)
+cand, passes = p[30], p[31]; p[30]=0; p[31]=0
+print('geom-geom cands/mj_step %.1f key cands %.1f' % (p[28]/n/10, p[29]/n/10)); p[28]=0; p[29]=0
 tot = p.sum()
-print('total cycles/env-step (env0): %.0f  -> per mj_step %.0f' % (tot/n, tot/n/10), 'mean newton iters', np.mean(its), 'ncon mean', phys.get(engine.NCON).mean())
+print('candidates/mj_step %.1f  narrow passes/mj_step %.2f' % (cand/n/10, passes/n/10))
+print('total cycles/env-step (env0): %.0f  -> per mj_step %.0f' % (tot/n, tot/n/10), 'mean newton iters', np.mean([int(v)&255 for v in np.array(its).ravel()]) if False else '', 'ncon mean', phys.get(engine.NCON).mean())
 for i in sorted(names, key=lambda i:-p[i]):
     print('%-16s %10.0f cyc/mj_step  %5.1f%%' % (names[i], p[i]/n/10, 100*p[i]/tot))
