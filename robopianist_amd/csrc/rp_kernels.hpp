@@ -532,7 +532,6 @@ struct Smem {
   short slotkey[16];
   short slotlink[16];
   signed char keyslot[RPK_NKEYS];
-  signed char desc[RPK_NL * RPK_MAXD * 5];
   long long prof[RPK_NPROF];
 };
 
@@ -684,9 +683,6 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
   const int sibrank = isl ? M.link_sibrank()[L] : 0;
   const int ltree = isl ? M.link_tree()[L] : 0;
   const int ldof = isl ? M.link_dof()[L] : 0;
-  int anc[RPK_MAXD];
-#pragma unroll
-  for (int k = 0; k < RPK_MAXD; k++) anc[k] = isl ? M.link_anc()[L * RPK_MAXD + k] : -1;
   // chain structure (lanes are in preorder: trunk chain, then up to 5 leaf chains)
   const int tbase = isl ? M.tree_base()[ltree] : 0, TL = isl ? M.tree_trunk()[ltree] : 0;
   int cf[5], cl[5];
@@ -699,16 +695,8 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
   int chain_end = 0, mychain = 0;  // chain lanes: first depth past the end of my chain / chain index
 #pragma unroll
   for (int c = 0; c < 5; c++) if (isl && lane >= cf[c] && lane < cf[c] + cl[c]) { chain_end = TL + cl[c]; mychain = c; }
-  // lane of my ancestor at depth e (e <= depth), and of my descendants at depth d > depth
+  // lane of my ancestor at depth e (e <= depth)
   auto anc_at = [&](int e) -> int { return e < TL ? tbase + e : lane - (depth - e); };
-  auto desc_at = [&](int d, int c) -> int {
-    if (depth >= TL) return (c == 0 && d < chain_end) ? lane + (d - depth) : -1;
-    if (d < TL) return c == 0 ? tbase + d : -1;
-    const int o = d - TL;
-    const int first = c == 0 ? cf[0] : (c == 1 ? cf[1] : (c == 2 ? cf[2] : (c == 3 ? cf[3] : cf[4])));
-    const int len = c == 0 ? cl[0] : (c == 1 ? cl[1] : (c == 2 ? cl[2] : (c == 3 ? cl[3] : cl[4])));
-    return o < len ? first + o : -1;
-  };
   const int llimited = isl ? M.link_limited()[L] : 0;
   const int lact = isl ? M.link_act()[L] : -1;
   const T lactcoef = isl ? M.link_act_coef()[L] : (T)0;
@@ -826,9 +814,6 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
   }
   T time = S.time[env];
 
-  // descendant table (link, depth) -> <=5 lanes, used by the tree-sparse routines
-  for (int i = lane; i < nl * RPK_MAXD * 5; i += 64) sm.desc[i] = (signed char)M.link_desc()[i];
-  WSYNC();
 
   PROF(0);
   // values produced by the position/velocity stage and consumed by the next
@@ -1803,7 +1788,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
 #pragma unroll
       for (int k = 0; k < RPK_MAXD; k++) {
         if (k <= depth) {
-          int a = anc[k];
+          int a = anc_at(k);
           T v = dot6(sm.cdof[a], buf);
           if (a == lane) v += larm;
           Mr[k] = v;
