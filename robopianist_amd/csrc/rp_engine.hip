@@ -262,8 +262,9 @@ struct Engine : EngineBase {
     B.RM = dalloc<T>(E * RPK_NL * (RPK_MAXD + 1));
     B.lanef = dalloc<T>(E * RPK_NLF * 64);
     B.lanei = dalloc<int>(E * RPK_NLI * 64);
-    B.hdr = dalloc<int>(E * 4);
-    B.cJ = dalloc<T>(E * RPK_NC * 2 * RPK_MAXD * 3);
+    B.hdr = dalloc<int>(E * 8);
+    B.entJ = dalloc<T>(E * RPK_NE * 3);
+    B.entM = dalloc<int>(E * RPK_NE * 2);
     B.slots = dalloc<int>(E * 64);
     B.keyslot = dalloc<int>(E * (RPK_NKEYS / 4));
     S.key_trace = nullptr;

@@ -22,6 +22,8 @@
 #define RPK_WAVE 64
 #define RPK_NC 24        // max contacts kept per env (outputs are RP_MAX_CONTACTS wide)
 #define RPK_NCOUT 32     // == RP_MAX_CONTACTS
+#define RPK_NE 192      // max contact Jacobian entries (contact, dof) handed to the solver
+#define RPK_NBOXF 26     // boxes covered by the oriented-box prefilter (fits the cdof scratch in fp32)
 #define RPK_HMAX 46      // max rows of the dense cross-coupling block (+1 row for its rhs)
 #define RPK_WORK 128     // narrow-phase work list
 #define RPK_MAXD 9       // tree depth levels
@@ -146,14 +148,15 @@ struct RpState {
 // (MODE 1): everything `mj_step1` leaves behind for `mj_step2`, per env.  Lives in
 // HBM but is L2 / Infinity-Cache resident (<= 25 KB per env).
 #define RPK_NLF 29  // per-lane float fields
-#define RPK_NLI 10  // per-lane int fields
+#define RPK_NLI 11  // per-lane int fields
 template <typename T>
 struct RpStage {
   T* RM;      // [E][RPK_NL][RPK_MAXD+1] mass-matrix rows
   T* lanef;   // [E][RPK_NLF][64]
   int* lanei; // [E][RPK_NLI][64]
-  int* hdr;   // [E][4]: ncon, nkt, dirty mask lo/hi
-  T* cJ;      // [E][RPK_NC][2][RPK_MAXD][3]
+  int* hdr;   // [E][8]: ncon, nkt, dirty mask lo/hi, nent, max entries per contact
+  T* entJ;    // [E][RPK_NE][3]  contact Jacobian entries: d(contact point velocity)/d(qvel of one dof)
+  int* entM;  // [E][RPK_NE][2]  lane | contact<<6 | column<<11 | cross<<15 ; base | count<<8 | rank<<16
   int* slots; // [E][64]: slotkey[16], slotlink[16], slotmask lo[16], hi[16]
   int* keyslot; // [E][RPK_NKEYS/4] (packed signed char)
 };
@@ -497,7 +500,8 @@ struct Smem {
       T xanchor[RPK_NL][3];
       union {
         T cdof[RPK_NL][6];  // until the mass-matrix rows are built
-        T vel[RPK_NL][6];   // afterwards: spatial velocities / accelerations
+        T vel[RPK_NL][6];   // velocity stage: spatial velocities / accelerations
+        float gbox[RPK_NBOXF][12];  // in between (collision): world frame + half sizes of the boxes
       };
       union {
         T acc[RPK_NL][10];  // composite inertias, then subtree forces
@@ -508,27 +512,32 @@ struct Smem {
       };
       T gpos[RPK_WAVE][3];
       short work[RPK_WORK][2];
+      T kq[RPK_NKEYS];
+      T cpos[RPK_NC][3];
+      T cn[RPK_NC][3];
+      T cdist[RPK_NC];
+      T cpar[RPK_NC][4];  // mu, kterm (K*imp*dist), B, D
+      T cJ[RPK_NC][2][RPK_MAXD][3];  // contact Jacobian chains per (contact, side, tree level)
+      int cA[RPK_NC], cB[RPK_NC], cgA[RPK_NC], cgB[RPK_NC];
     };
     struct {  // ---- acceleration stage (solver)
       T R[RPK_WAVE][RPK_MAXD + 1];  // tree factor rows (L), incl. key-leaf rows
       T Dg[RPK_WAVE];               // tree factor diagonal
       T xs[RPK_WAVE];               // solve staging
       T H[(RPK_HMAX + 1) * (RPK_HMAX + 2) / 2];  // dense block of the cross-coupled rows + rhs row
+      T RM[RPK_NL][RPK_MAXD + 1];   // mass-matrix rows: RM[i][e] = M[i][anc_e(i)]
+      T entJ[RPK_NE][3];            // contact Jacobian entries (see RpStage)
+      int entM[RPK_NE][2];
+      T cC[RPK_NC][6];              // per-contact 3x3 weight of the current Newton iteration
+      T cv[RPK_NC][3];              // per-contact 3-vector staging (J x, or the contact force)
+      T jt[RPK_WAVE];               // J^T f staging, one value per solver row
+      T actf[RPK_WAVE];
     };
   };
-  // ---- persistent across stages
-  T RM[RPK_NL][RPK_MAXD + 1];   // mass-matrix rows: RM[i][e] = M[i][anc_e(i)]
+  // ---- used by both stages
   T vec[2][RPK_WAVE];
   T keyvec[2][RPK_NKEYS];
-  T kq[RPK_NKEYS];
-  T actf[RPK_WAVE];
-  T cpos[RPK_NC][3];
-  T cn[RPK_NC][3];
-  T cdist[RPK_NC];
-  T cpar[RPK_NC][4];  // mu, kterm (K*imp*dist), B, D
-  T cJ[RPK_NC][2][RPK_MAXD][3];
   unsigned long long slotmask[16];
-  int cA[RPK_NC], cB[RPK_NC], cgA[RPK_NC], cgB[RPK_NC];
   short slotkey[16];
   short slotlink[16];
   signed char keyslot[RPK_NKEYS];
@@ -831,7 +840,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
   int cdep[2] = {-1, -1}, cTL[2] = {0, 0}, cTB[2] = {0, 0};  // contact lanes: side A / B link
   auto anc_of = [](int lk, int dl, int tl, int tb, int e) -> int { return e < tl ? tb + e : lk - (dl - e); };
   T ksin[2] = {0, 0}, kcos[2] = {1, 1};
-  int ncon = 0, nkt = 0;
+  int ncon = 0, nkt = 0, nent = 0, maxm = 0;  // contacts, touched keys, Jacobian entries, max per contact
   // rows
   T fr_aref = 0;
   int lim_sign[3] = {0, 0, 0};
@@ -853,8 +862,9 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
     if constexpr (MODE == 1) {
       // ---- what the position/velocity kernel left behind
       {
-        ncon = B.hdr[env * 4]; nkt = B.hdr[env * 4 + 1];
-        dirty_mask = ((unsigned long long)(unsigned)B.hdr[env * 4 + 3] << 32) | (unsigned)B.hdr[env * 4 + 2];
+        ncon = B.hdr[env * 8]; nkt = B.hdr[env * 8 + 1];
+        dirty_mask = ((unsigned long long)(unsigned)B.hdr[env * 8 + 3] << 32) | (unsigned)B.hdr[env * 8 + 2];
+        nent = B.hdr[env * 8 + 4]; maxm = B.hdr[env * 8 + 5];
         qbias = LF(0); alen = LF(1); avel = LF(2);
         ksin[0] = LF(3); ksin[1] = LF(4); kcos[0] = LF(5); kcos[1] = LF(6);
         fr_aref = LF(7);
@@ -878,10 +888,10 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
             sm.RM[lane][e] = Mr[e];
           }
         }
-        {
-          T* dst = &sm.cJ[0][0][0][0];
-          const T* src = B.cJ + (size_t)env * RPK_NC * 2 * RPK_MAXD * 3;
-          for (int i = lane; i < ncon * 2 * RPK_MAXD * 3; i += 64) dst[i] = src[i];
+        for (int i = lane; i < nent; i += 64) {
+          const size_t e = (size_t)env * RPK_NE + i;
+          sm.entJ[i][0] = B.entJ[e * 3]; sm.entJ[i][1] = B.entJ[e * 3 + 1]; sm.entJ[i][2] = B.entJ[e * 3 + 2];
+          sm.entM[i][0] = B.entM[e * 2]; sm.entM[i][1] = B.entM[e * 2 + 1];
         }
         if (lane < 16) {
           const int* sl = B.slots + (size_t)env * 64;
@@ -1261,36 +1271,35 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
       Rows<T> jar, frc;
       int fr_quad = 0, lim_act[3] = {0, 0, 0}, con_act[4] = {0, 0, 0, 0};
 
+      // Contact terms run on "entry lanes": entry = (contact, one dof it touches) with the
+      // 3-vector d(contact point velocity)/d(qvel of that dof).  Lane l of pass p owns entry
+      // 64 p + l; sums over the entries of a contact / over the contacts of a dof are
+      // fire-and-forget LDS adds.
       // y = J x for the rows owned by this lane (x in per-lane slot registers)
       auto mulJ = [&](const T* x, Rows<T>& out) {
         sm.vec[0][lane] = x[0];
         if (isk[0]) sm.keyvec[0][kid[0]] = x[1];
         if (isk[1]) sm.keyvec[0][kid[1]] = x[2];
+        if (lane < ncon) { sm.cv[lane][0] = 0; sm.cv[lane][1] = 0; sm.cv[lane][2] = 0; }
         WSYNC();
         out.fr = x[0];
 #pragma unroll
         for (int s = 0; s < 3; s++) out.lim[s] = (T)lim_sign[s] * x[s];
-        T vc[3] = {0, 0, 0};
-        if (hascon) {
-#pragma unroll
-          for (int side = 0; side < 2; side++) {
-            int Lk = side ? con_B : con_A;
-            if (Lk >= RPK_KEYBASE) {
-              T xv = sm.keyvec[0][Lk - RPK_KEYBASE];
-              const T* jc = sm.cJ[lane][side][0];
-              vc[0] += jc[0] * xv; vc[1] += jc[1] * xv; vc[2] += jc[2] * xv;
-            } else if (Lk >= 0) {
-#pragma unroll
-              for (int lv = 0; lv < RPK_MAXD; lv++) {
-                if (lv <= cdep[side]) {
-                  T xv = sm.vec[0][anc_of(Lk, cdep[side], cTL[side], cTB[side], lv)];
-                  const T* jc = sm.cJ[lane][side][lv];
-                  vc[0] += jc[0] * xv; vc[1] += jc[1] * xv; vc[2] += jc[2] * xv;
-                }
-              }
-            }
+        for (int e0 = 0; e0 < nent; e0 += 64) {
+          const int e = e0 + lane < nent ? e0 + lane : nent - 1;
+          const int m0 = sm.entM[e][0];
+          const int ln = m0 & 63, c = (m0 >> 6) & 31;
+          const T j0 = sm.entJ[e][0], j1 = sm.entJ[e][1], j2 = sm.entJ[e][2];
+          const T xl = sm.vec[0][ln];
+          const T xk = sm.keyvec[0][sm.slotkey[ln >= nl ? ln - nl : 0]];
+          const T xv = ln < nl ? xl : xk;
+          if (e0 + lane < nent) {
+            lds_add(&sm.cv[c][0], j0 * xv); lds_add(&sm.cv[c][1], j1 * xv); lds_add(&sm.cv[c][2], j2 * xv);
           }
         }
+        WSYNC();
+        T vc[3] = {0, 0, 0};
+        if (lane < ncon) { vc[0] = sm.cv[lane][0]; vc[1] = sm.cv[lane][1]; vc[2] = sm.cv[lane][2]; }
         T vn = dot3(con_n, vc), v1 = con_mu * dot3(con_t1, vc), v2 = con_mu * dot3(con_t2, vc);
         out.con[0] = vn + v1; out.con[1] = vn - v1; out.con[2] = vn + v2; out.con[3] = vn - v2;
         WSYNC();
@@ -1330,39 +1339,28 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
         out[2] = (T)lim_sign[2] * f.lim[2];
         T fn = f.con[0] + f.con[1] + f.con[2] + f.con[3];
         T f1 = con_mu * (f.con[0] - f.con[1]), f2 = con_mu * (f.con[2] - f.con[3]);
-        T fc[3];
+        if (lane < ncon) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) fc[k] = fn * con_n[k] + f1 * con_t1[k] + f2 * con_t2[k];
-        for (int c = 0; c < ncon; c++) {
-          T f0 = bcast(fc[0], c), f1c = bcast(fc[1], c), f2c = bcast(fc[2], c);
-          int cA = bcast(con_A, c), cB = bcast(con_B, c);
-          unsigned long long mA = ((unsigned long long)(unsigned)bcast((int)(con_maskA >> 32), c) << 32) |
-                                  (unsigned)bcast((int)(con_maskA & 0xffffffffu), c);
-          unsigned long long mB = ((unsigned long long)(unsigned)bcast((int)(con_maskB >> 32), c) << 32) |
-                                  (unsigned)bcast((int)(con_maskB & 0xffffffffu), c);
-          if (isl) {
-            if ((mA >> lane) & 1) {
-              const T* jc = sm.cJ[c][0][depth];
-              out[0] += jc[0] * f0 + jc[1] * f1c + jc[2] * f2c;
-            }
-            if ((mB >> lane) & 1) {
-              const T* jc = sm.cJ[c][1][depth];
-              out[0] += jc[0] * f0 + jc[1] * f1c + jc[2] * f2c;
-            }
-          }
-#pragma unroll
-          for (int side = 0; side < 2; side++) {
-            int Lk = side ? cB : cA;
-            if (Lk >= RPK_KEYBASE) {
-              int k = Lk - RPK_KEYBASE;
-              if ((k & 63) == lane) {
-                const T* jc = sm.cJ[c][side][0];
-                T v = jc[0] * f0 + jc[1] * f1c + jc[2] * f2c;
-                if (k < 64) out[1] += v; else out[2] += v;
-              }
-            }
-          }
+          for (int k = 0; k < 3; k++) sm.cv[lane][k] = fn * con_n[k] + f1 * con_t1[k] + f2 * con_t2[k];
         }
+        sm.jt[lane] = 0;
+        WSYNC();
+        for (int e0 = 0; e0 < nent; e0 += 64) {
+          const int e = e0 + lane < nent ? e0 + lane : nent - 1;
+          const int m0 = sm.entM[e][0];
+          const int ln = m0 & 63, c = (m0 >> 6) & 31;
+          const T v = sm.entJ[e][0] * sm.cv[c][0] + sm.entJ[e][1] * sm.cv[c][1] + sm.entJ[e][2] * sm.cv[c][2];
+          if (e0 + lane < nent) lds_add(&sm.jt[ln], v);
+        }
+        WSYNC();
+        if (isl) out[0] += sm.jt[lane];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+          const int ks = isk[s] ? sm.keyslot[kid[s]] : -1;
+          const T v = sm.jt[ks >= 0 ? nl + ks : 0];
+          if (ks >= 0) out[1 + s] += v;
+        }
+        WSYNC();
       };
       auto gauss = [&](const T* qa_, const T* Ma_) -> T {
         T g = 0;
@@ -1459,88 +1457,68 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
                       b2 * con_t2[a] * con_t2[b];
             }
           }
-          const int anyact = hascon && (con_act[0] | con_act[1] | con_act[2] | con_act[3]);
           T x;
           {
-            // rows: mass matrix + per-dof terms + every single-chain contact (+ its key leaf)
-            T Rr[RPK_MAXD + 1];
+            // rows: mass matrix + per-dof terms (link lanes), key diagonal (slot lanes) ...
+            if (lane < ncon) {
 #pragma unroll
-            for (int e = 0; e <= RPK_MAXD; e++) Rr[e] = isl ? Mr[e] : (T)0;
-            T diag_acc = isl ? mydiag_add : slotdiag;
-            for (int c = 0; c < ncon; c++) {
-              if (!bcast(anyact, c) || bcast(con_cross, c)) continue;
-              T C0 = bcast(Cm[0], c), C1 = bcast(Cm[1], c), C2 = bcast(Cm[2], c), C3 = bcast(Cm[3], c),
-                C4 = bcast(Cm[4], c), C5 = bcast(Cm[5], c);
-              int cA = bcast(con_A, c), cB = bcast(con_B, c), cslot = bcast(con_slot, c);
-              // after the nested-contact merge at most one side is a link
-              int lside = (cA >= 0 && cA < RPK_KEYBASE) ? 0 : ((cB >= 0 && cB < RPK_KEYBASE) ? 1 : -1);
-              int keyside = cA >= RPK_KEYBASE ? 0 : (cB >= RPK_KEYBASE ? 1 : -1);
-              int lk = lside == 0 ? cA : cB;
-              const int lkdep = bcast(lside == 0 ? cdep[0] : cdep[1], c);
-              unsigned long long mk = lside == 0
-                  ? (((unsigned long long)(unsigned)bcast((int)(con_maskA >> 32), c) << 32) | (unsigned)bcast((int)(con_maskA & 0xffffffffu), c))
-                  : (((unsigned long long)(unsigned)bcast((int)(con_maskB >> 32), c) << 32) | (unsigned)bcast((int)(con_maskB & 0xffffffffu), c));
-              if (lside < 0) mk = 0;
-              const bool mine = isl && ((mk >> lane) & 1);
-              const bool myslot = keyside >= 0 && cslot >= 0 && lane == nl + cslot;
-              if (mine || myslot) {
-                const T* jp = mine ? sm.cJ[c][lside][depth] : sm.cJ[c][keyside][0];
-                T u0 = C0 * jp[0] + C3 * jp[1] + C4 * jp[2];
-                T u1 = C3 * jp[0] + C1 * jp[1] + C5 * jp[2];
-                T u2 = C4 * jp[0] + C5 * jp[1] + C2 * jp[2];
-                if (myslot) diag_acc += u0 * jp[0] + u1 * jp[1] + u2 * jp[2];
-                if (lside >= 0) {
-                  int top = mine ? depth : lkdep;
+              for (int e = 0; e < 6; e++) sm.cC[lane][e] = Cm[e];
+            }
+            if (isl) {
 #pragma unroll
-                  for (int e = 0; e < RPK_MAXD; e++) {
-                    if (e <= top) {
-                      const T* je = sm.cJ[c][lside][e];
-                      Rr[e] += u0 * je[0] + u1 * je[1] + u2 * je[2];
+              for (int e = 0; e <= RPK_MAXD; e++) if (e <= depth) sm.R[lane][e] = Mr[e] + (e == depth ? mydiag_add : (T)0);
+            } else if (isslot) {
+#pragma unroll
+              for (int e = 0; e <= RPK_MAXD; e++) if (e <= sdepth + 1) sm.R[lane][e] = e == sdepth + 1 ? slotdiag : (T)0;
+            }
+            WSYNC();
+            // ... + J^T C J of every contact.  Entry lane a of contact c holds u = C_c J_a and
+            // walks the entries b <= a of its contact (dofs in lane order: b is an ancestor
+            // of a, or the same dof): single-chain contacts add u.J_b to row(a)[col(b)] of the
+            // tree rows, cross-chain contacts to the dense block of the dirty rows.
+            auto contact_terms = [&](const bool cross_pass, auto&& cidx) {
+              for (int e0 = 0; e0 < nent; e0 += 64) {
+                const bool valid = e0 + lane < nent;
+                const int e = valid ? e0 + lane : nent - 1;
+                const int m0 = sm.entM[e][0], m1 = sm.entM[e][1];
+                const int ln = m0 & 63, c = (m0 >> 6) & 31;
+                const int base = m1 & 255, rank = (m1 >> 16) & 255;
+                const T ja0 = sm.entJ[e][0], ja1 = sm.entJ[e][1], ja2 = sm.entJ[e][2];
+                const T* C = sm.cC[c];
+                const T C0 = C[0], C1 = C[1], C2 = C[2], C3 = C[3], C4 = C[4], C5 = C[5];
+                const T u0 = C0 * ja0 + C3 * ja1 + C4 * ja2;
+                const T u1 = C3 * ja0 + C1 * ja1 + C5 * ja2;
+                const T u2 = C4 * ja0 + C5 * ja1 + C2 * ja2;
+                const bool mine = valid && (((m0 >> 15) & 1) != 0) == cross_pass;
+                const int cia = cross_pass ? cidx(ln) : 0;
+                for (int k0 = 0; k0 < maxm; k0 += 4) {
+                  // four entries per trip: the twelve LDS reads go out together
+                  int mb[4];
+                  T val[4];
+#pragma unroll
+                  for (int u = 0; u < 4; u++) {
+                    const int b = base + k0 + u < nent ? base + k0 + u : nent - 1;
+                    mb[u] = sm.entM[b][0];
+                    val[u] = u0 * sm.entJ[b][0] + u1 * sm.entJ[b][1] + u2 * sm.entJ[b][2];
+                  }
+#pragma unroll
+                  for (int u = 0; u < 4; u++) {
+                    if (mine && k0 + u <= rank) {
+                      T* dst = cross_pass ? &sm.H[tri(cia, cidx(mb[u] & 63))] : &sm.R[ln][(mb[u] >> 11) & 15];
+                      lds_add(dst, val[u]);
                     }
                   }
                 }
               }
-            }
-            {
-              const int dg = isl ? depth : sdepth + 1;
-#pragma unroll
-              for (int e = 0; e <= RPK_MAXD; e++) if (e == dg && (isl || isslot)) Rr[e] += diag_acc;
-            }
-            // cross-chain contacts go into the dense block of the dirty rows
-            auto cross_fn = [&](auto&& cidx) {
-              for (int c = 0; c < ncon; c++) {
-                if (!bcast(anyact, c) || !bcast(con_cross, c)) continue;
-                T C0 = bcast(Cm[0], c), C1 = bcast(Cm[1], c), C2 = bcast(Cm[2], c), C3 = bcast(Cm[3], c),
-                  C4 = bcast(Cm[4], c), C5 = bcast(Cm[5], c);
-                int cA = bcast(con_A, c), cB = bcast(con_B, c), cslot = bcast(con_slot, c);
-                unsigned long long mA = ((unsigned long long)(unsigned)bcast((int)(con_maskA >> 32), c) << 32) |
-                                        (unsigned)bcast((int)(con_maskA & 0xffffffffu), c);
-                unsigned long long mB = ((unsigned long long)(unsigned)bcast((int)(con_maskB >> 32), c) << 32) |
-                                        (unsigned)bcast((int)(con_maskB & 0xffffffffu), c);
-                unsigned long long sup = mA | mB;
-                int keyside = cA >= RPK_KEYBASE ? 0 : (cB >= RPK_KEYBASE ? 1 : -1);
-                if (keyside >= 0 && cslot >= 0) sup |= 1ull << (nl + cslot);
-                T jc[3] = {0, 0, 0};
-                if (isl) {
-                  if ((mA >> lane) & 1) { const T* p = sm.cJ[c][0][depth]; jc[0] += p[0]; jc[1] += p[1]; jc[2] += p[2]; }
-                  if ((mB >> lane) & 1) { const T* p = sm.cJ[c][1][depth]; jc[0] += p[0]; jc[1] += p[1]; jc[2] += p[2]; }
-                } else if (keyside >= 0 && lane == nl + cslot) {
-                  const T* p = sm.cJ[c][keyside][0]; jc[0] = p[0]; jc[1] = p[1]; jc[2] = p[2];
-                }
-                T u0 = C0 * jc[0] + C3 * jc[1] + C4 * jc[2];
-                T u1 = C3 * jc[0] + C1 * jc[1] + C5 * jc[2];
-                T u2 = C4 * jc[0] + C5 * jc[1] + C2 * jc[2];
-                bool insup = (sup >> lane) & 1;
-                const int cme = cidx(lane);
-                unsigned long long rem = sup;
-                while (rem) {
-                  int j = __ffsll((long long)rem) - 1;
-                  rem &= rem - 1;
-                  T j0 = bcast(jc[0], j), j1 = bcast(jc[1], j), j2 = bcast(jc[2], j);
-                  if (insup && lane >= j) lds_add(&sm.H[tri(cme, cidx(j))], u0 * j0 + u1 * j1 + u2 * j2);
-                }
-              }
             };
+            contact_terms(false, [](int) { return 0; });
+            WSYNC();
+            T Rr[RPK_MAXD + 1];
+#pragma unroll
+            for (int e = 0; e <= RPK_MAXD; e++) Rr[e] = sm.R[lane][e];
+            WSYNC();
+            // cross-chain contacts go into the dense block of the dirty rows
+            auto cross_fn = [&](auto&& cidx) { contact_terms(true, cidx); };
             PROF(4);
             x = tree_solve(Rr, rhs, nkt, dirty_mask, cross_fn);
           }
@@ -1574,7 +1552,9 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           g0 = (T)0.5 * wave_sum(g0); g1 = wave_sum(g1); g2 = (T)0.5 * wave_sum(g2);
           PROF(6);
           // ---- exact line search: safeguarded Newton on phi'(alpha)
-          auto ls_eval = [&](T alpha, T& d1, T& d2) -> T {
+          // phi(alpha) and its first two derivatives; the cost itself is only needed at
+          // the end points, the Newton iterations on phi' skip that wave reduction
+          auto ls_eval = [&](T alpha, T& d1, T& d2, const bool with_cost) -> T {
             T cst = 0, a = 0, b = 0;
             if (isl && lfloss > 0) {
               T xx = jar.fr + alpha * jv.fr, rf = lflR * lfloss;
@@ -1594,20 +1574,22 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
                 if (xx < 0) { cst += (T)0.5 * con_D * xx * xx; a += con_D * xx * jv.con[r]; b += con_D * jv.con[r] * jv.con[r]; }
               }
             }
-            cst = wave_sum(cst); a = wave_sum(a); b = wave_sum(b);
+            a = wave_sum(a); b = wave_sum(b);
             d1 = a + (T)2 * alpha * g2 + g1;
             d2 = b + (T)2 * g2;
+            if (!with_cost) return (T)0;
+            cst = wave_sum(cst);
             return cst + alpha * alpha * g2 + alpha * g1 + g0;
           };
           T gtol = M.tolerance * M.ls_tolerance * snorm / scale;
           T f0, h0, f, hh;
-          T c0 = ls_eval((T)0, f0, h0);
+          T c0 = ls_eval((T)0, f0, h0, true);
           T alpha = 0;
           if (f0 < 0 && h0 > 0) {
             T lo_ = 0, hi_ = (T)-1;  // hi_<0: unbounded
             alpha = -f0 / h0;
             for (int it = 0; it < S.max_ls; it++) {
-              ls_eval(alpha, f, hh);
+              ls_eval(alpha, f, hh, false);
               if (N::abs(f) < gtol) break;
               if (f < 0) lo_ = alpha; else hi_ = alpha;
               T an = alpha - f / hh;
@@ -1616,7 +1598,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
               if (N::abs(an - alpha) <= (T)4 * N::eps() * N::abs(alpha)) { alpha = an; break; }
               alpha = an;
             }
-            T c1 = ls_eval(alpha, f, hh);
+            T c1 = ls_eval(alpha, f, hh, true);
             if (c1 > c0) alpha = 0;
           }
           PROF(7);
@@ -1792,7 +1774,6 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           T v = dot6(sm.cdof[a], buf);
           if (a == lane) v += larm;
           Mr[k] = v;
-          sm.RM[lane][k] = v;
         }
       }
     }
@@ -1824,6 +1805,22 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
       sm.gax[lane][0] = (float)az[0]; sm.gax[lane][1] = (float)az[1]; sm.gax[lane][2] = (float)az[2];
       sm.gax[lane][3] = cap ? (float)M.geom_size()[3 * lane + 1] : 0.f;
       sm.grr[lane] = cap ? (float)M.geom_size()[3 * lane] : (float)M.geom_rbound()[lane];
+    }
+    // geoms are sorted capsules first: box b is geom ncap + b
+    const int ncap = __popcll(__ballot(lane < M.ngeom && M.geom_type()[lane < M.ngeom ? lane : 0] == GEOM_CAPSULE_));
+    if (lane >= ncap && lane < M.ngeom && lane - ncap < RPK_NBOXF) {
+      const int gl = M.geom_link()[lane];
+      T mw[9];
+      if (gl >= 0) mat_mul(mw, sm.xmat[gl], M.geom_mat() + 9 * lane);
+      else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) mw[k] = M.geom_mat()[9 * lane + k];
+      }
+      float* gb = sm.gbox[lane - ncap];
+#pragma unroll
+      for (int k = 0; k < 9; k++) gb[k] = (float)mw[k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) gb[9 + k] = (float)M.geom_size()[3 * lane + k];
     }
     WSYNC();
 
@@ -1934,8 +1931,28 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
             const float ex = rx + fax * x1 - bx * x2, ey = ry + fay * x1 - by * x2, ez = rz + faz * x1 - bz * x2;
             const float reach = frr + r2 + 1e-4f;
             has = has && (ex * ex + ey * ey + ez * ez <= reach * reach);
+            // boxes: separating-axis test on the three box axes (capsule = segment + radius)
+            const int bi = bit - ncap;
+            if (bi >= 0 && bi < RPK_NBOXF) {
+              const float* gb = sm.gbox[bi];
+              const float reach2 = frr + 1e-4f;
+              bool sep = false;
+#pragma unroll
+              for (int k = 0; k < 3; k++) {
+                const float ck = gb[k] * rx + gb[3 + k] * ry + gb[6 + k] * rz;
+                const float ak = gb[k] * fax + gb[3 + k] * fay + gb[6 + k] * faz;
+                sep = sep || (fabsf(ck) - fhl * fabsf(ak) > gb[9 + k] + reach2);
+              }
+              has = has && !sep;
+            }
           }
           const unsigned long long mk = __ballot(has);
+#ifndef RPK_MARK
+          if (S.prof && env == 0 && gen_phase == 0) {
+            const int nb = __popcll(__ballot(has && M.geom_type()[bit] != GEOM_CAPSULE_));
+            if (lane == 0) sm.prof[27] += nb;
+          }
+#endif
           const int idx = nwork + __popcll(mk & lanemask_lt(lane));
           if (has) {
             if (gen_phase == 0) { sm.work[idx][0] = (short)lane; sm.work[idx][1] = (short)bit; }
@@ -2338,10 +2355,46 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
 #pragma unroll
         for (int e = 0; e <= RPK_MAXD; e++) B.RM[((size_t)env * RPK_NL + lane) * (RPK_MAXD + 1) + e] = Mr[e];
       }
+      // contact Jacobian entries: one record per (contact, dof it touches), the dofs of a
+      // contact in lane order (ancestors first, the key slot last).  The two sides of a
+      // contact that share trunk dofs are summed here.
       {
-        const T* src = &sm.cJ[0][0][0][0];
-        T* dst = B.cJ + (size_t)env * RPK_NC * 2 * RPK_MAXD * 3;
-        for (int i = lane; i < ncon * 2 * RPK_MAXD * 3; i += 64) dst[i] = src[i];
+        unsigned long long sup = 0;
+        if (lane < ncon) {
+          sup = con_maskA | con_maskB;
+          if (con_slot >= 0) sup |= 1ull << (nl + con_slot);
+        }
+        int cnt = __popcll(sup), base = 0;
+        for (int c2 = 0; c2 < ncon; c2++) { const int b2 = bcast(cnt, c2); if (c2 < lane) base += b2; }
+        if (lane < ncon && base + cnt > RPK_NE) { cnt = 0; sup = 0; warn |= 2; LF(14) = (T)0; }  // dropped
+        const int nent = wave_max(lane < ncon ? base + cnt : 0), maxm = wave_max(cnt);
+        LI(10) = base | (cnt << 8);
+        const int mycol = isl ? depth : sdepth + 1;
+        for (int c = 0; c < ncon; c++) {
+          const unsigned long long sc = ((unsigned long long)(unsigned)bcast((int)(sup >> 32), c) << 32) |
+                                        (unsigned)bcast((int)(sup & 0xffffffffu), c);
+          const unsigned long long mA = ((unsigned long long)(unsigned)bcast((int)(con_maskA >> 32), c) << 32) |
+                                        (unsigned)bcast((int)(con_maskA & 0xffffffffu), c);
+          const unsigned long long mB = ((unsigned long long)(unsigned)bcast((int)(con_maskB >> 32), c) << 32) |
+                                        (unsigned)bcast((int)(con_maskB & 0xffffffffu), c);
+          const int cA = bcast(con_A, c), cb = bcast(base, c), cc = bcast(cnt, c), cx = bcast(con_cross, c);
+          if ((sc >> lane) & 1) {
+            T j3[3] = {0, 0, 0};
+            if (isl) {
+              if ((mA >> lane) & 1) { const T* q_ = sm.cJ[c][0][depth]; j3[0] += q_[0]; j3[1] += q_[1]; j3[2] += q_[2]; }
+              if ((mB >> lane) & 1) { const T* q_ = sm.cJ[c][1][depth]; j3[0] += q_[0]; j3[1] += q_[1]; j3[2] += q_[2]; }
+            } else {
+              const T* q_ = sm.cJ[c][cA >= RPK_KEYBASE ? 0 : 1][0];
+              j3[0] = q_[0]; j3[1] = q_[1]; j3[2] = q_[2];
+            }
+            const int rank = __popcll(sc & lanemask_lt(lane));
+            const size_t e = (size_t)env * RPK_NE + cb + rank;
+            B.entJ[e * 3] = j3[0]; B.entJ[e * 3 + 1] = j3[1]; B.entJ[e * 3 + 2] = j3[2];
+            B.entM[e * 2] = lane | (c << 6) | (mycol << 11) | (cx << 15);
+            B.entM[e * 2 + 1] = cb | (cc << 8) | (rank << 16);
+          }
+        }
+        if (lane == 0) { B.hdr[env * 8 + 4] = nent; B.hdr[env * 8 + 5] = maxm; }
       }
       if (lane < 16) {
         int* sl = B.slots + (size_t)env * 64;
@@ -2350,8 +2403,8 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
       }
       if (lane < RPK_NKEYS / 4) B.keyslot[(size_t)env * (RPK_NKEYS / 4) + lane] = ((int*)sm.keyslot)[lane];
       if (lane == 0) {
-        B.hdr[env * 4] = ncon; B.hdr[env * 4 + 1] = nkt;
-        B.hdr[env * 4 + 2] = (int)(dirty_mask & 0xffffffffu); B.hdr[env * 4 + 3] = (int)(dirty_mask >> 32);
+        B.hdr[env * 8] = ncon; B.hdr[env * 8 + 1] = nkt;
+        B.hdr[env * 8 + 2] = (int)(dirty_mask & 0xffffffffu); B.hdr[env * 8 + 3] = (int)(dirty_mask >> 32);
       }
     }
     }  // MODE 0

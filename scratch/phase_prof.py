@@ -21,6 +21,7 @@ for t in range(30,30+n):
     its.append(phys.get(engine.SOLVER_ITER).mean())
 p = phys.profile(False)
 cand, passes = p[30], p[31]; p[30]=0; p[31]=0
+print('capsule-box cands after prefilter/mj_step %.1f' % (p[27]/n/10)); p[27]=0
 print('geom-geom cands/mj_step %.1f key cands %.1f' % (p[28]/n/10, p[29]/n/10)); p[28]=0; p[29]=0
 tot = p.sum()
 print('candidates/mj_step %.1f  narrow passes/mj_step %.2f' % (cand/n/10, passes/n/10))
