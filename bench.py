@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", type=int, default=1, help="all-gather trajectory slab when gpus>1")
     ap.add_argument("--engine-only", action="store_true", help="time rp_step alone (no obs/reward epilogue)")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="replay env.step from a captured hipGraph (wrappers.GraphedStepWrapper)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -108,7 +110,7 @@ def main():
     def measure(precision, steps, warmup):
         from robopianist_amd import engine, suite
         from robopianist_amd import distributed as rpd
-        from robopianist_amd.wrappers import CanonicalSpecWrapper
+        from robopianist_amd.wrappers import CanonicalSpecWrapper, GraphedStepWrapper
 
         E = args.envs
         device = torch.device("cuda", dev)
@@ -124,7 +126,9 @@ def main():
                 task_kwargs=dict(trim_silence=True, control_timestep=0.05, gravity_compensation=True,
                                  primitive_fingertip_collisions=True, reduced_action_space=False,
                                  n_steps_lookahead=10))
-        env = CanonicalSpecWrapper(base_env)
+        eager_env = CanonicalSpecWrapper(base_env)
+        use_graph = bool(args.graph) and not args.engine_only
+        env = GraphedStepWrapper(eager_env, warmup_steps=2) if use_graph else eager_env
         phys = base_env.physics.engine
         m = base_env.task.scene.model
         assert base_env.task.physics_steps_per_control_step == args.substeps == 10
@@ -178,6 +182,13 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
+        if use_graph:
+            # launches inside a replayed hipGraph cannot carry per-kernel events: sample the
+            # kernel times on 16 eager steps of the same rollout right after the timed region
+            phys.solver_kernel_time(); phys.kernel_time()
+            for i in range(16):
+                eager_env.step(act_dev[(state["t"] + i) % T].expand(E, -1))
+            barrier()
         sms, snl = phys.solver_kernel_time()
         kms, nl = phys.kernel_time()
         warn = int(phys.warn_flags.max())
@@ -187,7 +198,7 @@ def main():
 
 
         return dict(dt=dt, kms=kms, nl=nl, sms=sms, snl=snl, warn=warn, finite=finite, phys=phys, m=m,
-                    ctrl_seq=ctrl_seq, E=E)
+                    ctrl_seq=ctrl_seq, E=E, graphed=bool(use_graph and env.graph_captured))
 
     r = measure(args.precision, args.steps, args.warmup)
     dt, kms, nl, sms, snl, warn, finite, phys, m, ctrl_seq, E = (
@@ -215,7 +226,7 @@ def main():
                 "workload": "PianoWithShadowHands-TwinkleTwinkle scripted replay (BASELINE configs[1]), " + ("engine-level rp_step only" if args.engine_only else "full vectorised env.step (obs + rewards)"),
                 "envs_per_gpu": E, "substeps_per_step": args.substeps, "nv": int(m.nv), "nu": int(m.nu),
                 "fingertips": "capsule (primitive) stand-in", "mj_steps_per_s": value * args.substeps,
-                "trajectory_gather": bool(world > 1 and args.gather),
+                "trajectory_gather": bool(world > 1 and args.gather), "hipgraph_step": r["graphed"],
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -224,6 +235,9 @@ def main():
                 "kernel_avg_ms": sms, "kernel_launches_sampled": snl,
                 "algorithmic_bytes_per_launch": algo,
                 "step_sequence_avg_ms": kms, "step_sequences": nl,
+                "kernel_timing": ("HIP events on 16 eager env steps of the same rollout right after the timed region "
+                                  "(the timed region replays a captured hipGraph)") if r["graphed"] else
+                                 "HIP events over the timed region",
                 "note": "one rp_step = 1 + 2*substeps launches (rp_stage_kernel<T,0> position/velocity stage, "
                         "<T,1> solver stage); kernel_avg_ms is the solver launch of the middle substep of every step "
                         "(HIP events on the engine stream), step_sequence_avg_ms the whole 21-launch sequence. "

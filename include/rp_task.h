@@ -1,0 +1,61 @@
+/* rp_task.h — fused task-layer kernels for PianoWithShadowHands (C ABI, gfx950).
+ *
+ * The reference computes its rewards in Python/numpy once per control step
+ * (robopianist/suite/tasks/piano_with_shadow_hands.py:251-331, summed by
+ * suite/composite_reward.py:46-56).  Batched over environments these are ~130 tiny
+ * elementwise launches; rp_task_rewards evaluates all terms for all envs in one launch
+ * (one wavefront per env, lane = piano key).
+ *
+ * All pointers are DEVICE pointers into caller-owned memory; floating arrays have the
+ * element type selected by `precision` (32: float, 64: double).  The launch is enqueued on
+ * `hip_stream` (hipStream_t; NULL = default stream) and never synchronises.
+ * Returns 0, or a negative code with the message in rp_task_last_error().
+ */
+#ifndef RP_TASK_H_
+#define RP_TASK_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RP_TASK_N_KEYS 88
+#define RP_TASK_N_TERMS 5 /* key_press, sustain, energy, fingering, forearm */
+
+typedef struct rp_task_reward_args {
+  int n_envs, precision;
+  int nv, nu, n_sites, n_contacts;   /* row lengths of qpos, act_*, site_xpos, contact_geoms */
+  int use_fingering, use_forearm;    /* disabled terms are written as 0 and not summed */
+  double energy_coef;                /* _ENERGY_PENALTY_COEF (:24) */
+  double key_close, finger_close;    /* _KEY_CLOSE_ENOUGH_TO_PRESSED, _FINGER_CLOSE_ENOUGH_TO_KEY (:22-23) */
+  /* engine state: rp_field_ptr views */
+  const void* qpos;                  /* [E][nv] */
+  const void* act_force;             /* [E][nu]   actuatorfrc sensors (shadow_hand.py:407-416) */
+  const void* act_vel;               /* [E][nu]   actuatorvel sensors */
+  const void* site_xpos;             /* [E][n_sites][3] */
+  const int* contact_geoms;          /* [E][n_contacts][2], -1 = empty */
+  /* task state */
+  const void* goal_current;          /* [E][89]  goal keys + sustain (:196-198) */
+  const void* key_norm_state;        /* [E][88]  Piano.normalized_state (piano.py:186-189) */
+  const unsigned char* key_activation;      /* [E][88] */
+  const unsigned char* sustain_activation;  /* [E] */
+  const long long* finger_current;   /* [E][88]  finger index of each goal key, -1 = none */
+  /* model constants */
+  const int* key_qadr;               /* [88] qpos address of every key joint */
+  const void* key_anchor;            /* [88][3] hinge position */
+  const void* key_half;              /* [88][3] key box half sizes */
+  const int* hand_act; int n_hand_act;      /* actuator ids of both hands (energy term) */
+  const int* tip_site;               /* [10] engine site index of the fingertips, right hand first */
+  const int* rfa; int n_rfa;         /* right / left forearm geom ids (:251-259) */
+  const int* lfa; int n_lfa;
+  /* outputs */
+  void* terms;                       /* [RP_TASK_N_TERMS][E] */
+  void* total;                       /* [E] sum of the enabled terms in the order above */
+} rp_task_reward_args;
+
+int rp_task_rewards(const rp_task_reward_args* args, void* hip_stream);
+const char* rp_task_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RP_TASK_H_ */

@@ -383,10 +383,17 @@ struct Engine : EngineBase {
       }
       s.key_trace = d_trace;
     }
+    // inside a stream capture (the caller is recording a hipGraph of its whole step) no
+    // event may be synchronised and per-launch events are meaningless: skip the timers
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cap);
+    const bool capturing = cap != hipStreamCaptureStatusNone;
     const int slot = ev_next;
-    ev_next = (ev_next + 1) % kRing;
-    harvest(slot, true);
-    const bool timeit = (mode == 0);
+    if (!capturing) {
+      ev_next = (ev_next + 1) % kRing;
+      harvest(slot, true);
+    }
+    const bool timeit = (mode == 0) && !capturing;
     if (timeit) HIP_OK(hipEventRecord(ev0[slot], stream));
     // mj_step1 for the current state, then n_sub x (mj_step2; mj_step1): dm_control's legacy
     // order.  Two small kernels per substep instead of one fused launch: each half fits in

@@ -84,7 +84,7 @@ class Environment:
         self._task.initialize_episode(phys, None)
         phys.forward()  # physics.forward() after initialize_episode, as composer does
         self._task.piano._update_key_state(phys)
-        self._needs_reset = torch.zeros(self._n_envs, dtype=torch.bool, device=phys.device)
+        self._needs_reset.zero_()
         obs = self._task.get_observation(self._physics)
         st = torch.full((self._n_envs,), int(StepType.FIRST), dtype=torch.int32,
                         device=self._physics.device)
@@ -121,5 +121,5 @@ class Environment:
         st = torch.where(resetting, torch.full_like(st, int(StepType.FIRST)), st)
         reward = torch.where(resetting, torch.zeros_like(reward), reward)
         discount = torch.where(resetting, torch.ones_like(discount), discount)
-        self._needs_reset = terminate
+        self._needs_reset.copy_(terminate)  # in place: the step is hipGraph-capturable
         return TimeStep(st, reward, discount, obs)

@@ -46,6 +46,7 @@ class TorchPhysics:
         from robopianist_amd.model import engine_tables
         t = engine_tables.build_engine_tables(self.model, scene_info.key_joint_ids)
         self._site_modelid = {int(s): i for i, s in enumerate(t["eng_site_modelid"])}
+        self._site_index_cache = {}
         self.timestep = float(self.model.opt_timestep)
 
     # -- reads -----------------------------------------------------------------
@@ -53,8 +54,12 @@ class TorchPhysics:
         """Views alias engine memory; nothing to copy."""
 
     def site_xpos(self, model_site_ids):
-        idx = [self._site_modelid[int(s)] for s in model_site_ids]
-        return self.site_xpos_eng[:, idx, :]
+        key = tuple(int(s) for s in model_site_ids)
+        idx = self._site_index_cache.get(key)
+        if idx is None:  # index tensors live on the device: no host->device copy per step
+            idx = torch.as_tensor([self._site_modelid[s] for s in key], dtype=torch.long, device=self.device)
+            self._site_index_cache[key] = idx
+        return self.site_xpos_eng.index_select(1, idx)
 
     # -- writes ----------------------------------------------------------------
     @property

@@ -54,16 +54,22 @@ class Piano:
     def _initialize_state(self, mask=None):
         E, n = self._E, self.n_keys
         f = dict(device=self._device, dtype=self._dtype)
-        if mask is None or not hasattr(self, "_state"):
+        # State tensors are allocated once and only ever updated in place, so that a whole
+        # env.step can be captured in (and replayed from) a hipGraph.
+        if not hasattr(self, "_state"):
             self._state = torch.zeros((E, n), **f)
             self._sustain_state = torch.zeros((E, 1), **f)
             self._activation = torch.zeros((E, n), device=self._device, dtype=torch.bool)
             self._sustain_activation = torch.zeros((E, 1), device=self._device, dtype=torch.bool)
             self._normalized_state = torch.zeros((E, n), **f)
+        elif mask is None:
+            for t in (self._state, self._sustain_state, self._activation,
+                      self._sustain_activation, self._normalized_state):
+                t.zero_()
         else:
             for t in (self._state, self._sustain_state, self._activation,
                       self._sustain_activation, self._normalized_state):
-                t[mask] = 0
+                t.masked_fill_(mask[:, None], 0)
 
     def initialize_episode(self, physics, mask=None):
         self._initialize_state(mask)
@@ -72,17 +78,16 @@ class Piano:
     def _update_key_state(self, physics):
         """piano.py:178-192."""
         if self._add_actuators:
-            self._activation = physics.ctrl[:, self._aidx] >= self._ctrl_midpoint
+            torch.ge(physics.ctrl[:, self._aidx], self._ctrl_midpoint, out=self._activation)
         else:
             joints_pos = physics.qpos[:, self._jidx]
-            self._state = torch.minimum(torch.maximum(joints_pos, self._qpos_range[:, 0]),
-                                        self._qpos_range[:, 1])
-            self._normalized_state = self._state / self._qpos_range[:, 1]
-            self._activation = torch.abs(self._state - self._qpos_range[:, 1]) <= _KEY_THRESHOLD
-        self._sustain_activation = self._sustain_state >= _SUSTAIN_THRESHOLD
+            torch.clamp(joints_pos, min=self._qpos_range[:, 0], max=self._qpos_range[:, 1], out=self._state)
+            torch.div(self._state, self._qpos_range[:, 1], out=self._normalized_state)
+            torch.le(torch.abs(self._state - self._qpos_range[:, 1]), _KEY_THRESHOLD, out=self._activation)
+        torch.ge(self._sustain_state, _SUSTAIN_THRESHOLD, out=self._sustain_activation)
 
     def apply_sustain(self, sustain):
-        self._sustain_state = sustain.reshape(self._E, 1).to(self._dtype).clone()
+        self._sustain_state.copy_(sustain.reshape(self._E, 1))
 
     @property
     def activation(self):

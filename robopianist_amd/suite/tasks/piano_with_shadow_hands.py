@@ -64,6 +64,8 @@ class PianoWithShadowHands(base.PianoTask):
         self._disable_hand_collisions = disable_hand_collisions
         self._energy_penalty_coef = energy_penalty_coef
         self._randomize_hand_positions = randomize_hand_positions
+        self._use_fused_rewards = True   # set False to force the torch reward functions
+        self._fused_rewards = None
         self._reset_trajectory()
         self._set_rewards()
 
@@ -138,14 +140,17 @@ class PianoWithShadowHands(base.PianoTask):
     def _reset_quantities_at_episode_init(self, mask=None) -> None:
         """:146-149."""
         dev, E = self._physics_device, self._E
-        if mask is None or not hasattr(self, "_t_idx"):
+        # (state is allocated once and updated in place: the step must be hipGraph-capturable)
+        if not hasattr(self, "_t_idx"):
             self._t_idx = torch.zeros(E, device=dev, dtype=torch.long)
             self._should_terminate = torch.zeros(E, device=dev, dtype=torch.bool)
             self._discount = torch.ones(E, device=dev, dtype=self._dtype)
+        elif mask is None:
+            self._t_idx.zero_(); self._should_terminate.zero_(); self._discount.fill_(1.0)
         else:
-            self._t_idx[mask] = 0
-            self._should_terminate[mask] = False
-            self._discount[mask] = 1.0
+            self._t_idx.masked_fill_(mask, 0)
+            self._should_terminate.masked_fill_(mask, False)
+            self._discount.masked_fill_(mask, 1.0)
 
     # -- composer-style hooks --------------------------------------------------------
     def initialize_episode(self, physics, mask=None) -> None:
@@ -160,10 +165,9 @@ class PianoWithShadowHands(base.PianoTask):
         action = action.reshape(self._E, -1)
         hands = action[:, :-1]
         n_r = len(self.right_hand.actuators)
-        ctrl = physics.ctrl.clone()
+        ctrl = physics.ctrl  # zero-copy view of the engine's ctrl array
         ctrl[:, self._rh_act] = hands[:, :n_r]
         ctrl[:, self._lh_act] = hands[:, n_r:]
-        physics.set_ctrl(ctrl)
         self.piano.apply_sustain(action[:, -1])
 
     def after_substeps(self, physics) -> None:
@@ -175,16 +179,53 @@ class PianoWithShadowHands(base.PianoTask):
     def after_step(self, physics, active=None) -> None:
         """:188-204."""
         inc = torch.ones_like(self._t_idx) if active is None else active.to(torch.long)
-        self._t_idx = self._t_idx + inc
+        self._t_idx.add_(inc)
         slen = self._song_len[self._song_id]
-        self._should_terminate = (self._t_idx - 1) == slen - 1
-        self._goal_current = self._goal_state[:, 0].clone()
-        self._finger_current = self._finger_next.clone()
+        torch.eq(self._t_idx, slen, out=self._should_terminate)  # (t_idx - 1) == len - 1
+        self._goal_current.copy_(self._goal_state[:, 0])
+        self._finger_current.copy_(self._finger_next)
         off = self._goal_current[:, :-1] == 0
-        self._failure_termination = (self.piano.activation & off).any(dim=1)
+        torch.any(self.piano.activation & off, dim=1, out=self._failure_termination)
 
     def get_reward(self, physics):
-        return self._reward_fn.compute(physics)
+        """CompositeReward.compute (composite_reward.py:46-56).  On the HIP engine the
+        standard terms are evaluated by one fused launch (include/rp_task.h); the torch
+        functions above them remain the definition and are used whenever the reward set
+        has been customised (or on the CPU test double)."""
+        fused = self._fused_rewards_for(physics)
+        if fused is None:
+            return self._reward_fn.compute(physics)
+        total, terms = fused.compute(
+            goal_current=self._goal_current, key_norm_state=self.piano.normalized_state,
+            key_activation=self.piano.activation, sustain_activation=self.piano.sustain_activation,
+            finger_current=self._finger_current)
+        from robopianist_amd import task_kernels
+        for i, name in enumerate(task_kernels.TERM_NAMES):
+            if name in self._reward_fn.reward_fns:
+                self._reward_fn.reward_terms[name] = terms[i]
+        return total
+
+    def _fused_rewards_for(self, physics):
+        if not self._use_fused_rewards or not getattr(physics, "device", None) or physics.device.type != "cuda":
+            return None
+        names = tuple(self._reward_fn.reward_fns)
+        std = ("key_press_reward", "sustain_reward", "energy_reward")
+        want = std + (("fingering_reward",) if not self._disable_fingering_reward else ()) + \
+            (("forearm_reward",) if not self._disable_forearm_reward else ())
+        if names != want or self.piano._add_actuators:
+            return None  # customised reward set (or the OT fingering term): torch path
+        if self._fused_rewards is None:
+            from robopianist_amd import task_kernels
+            tips = [physics._site_modelid[int(s)] for s in self._tip_sites]
+            self._fused_rewards = task_kernels.FusedRewards(
+                physics, n_envs=self._E, key_qadr=[int(j) for j in self.piano.joints],  # 1-dof joints: qpos address == joint id
+                key_anchor=self._key_anchor, key_half=self._key_half,
+                hand_act=list(self.right_hand.actuators) + list(self.left_hand.actuators), tip_site=tips,
+                rfa=self.right_hand.forearm_geom_ids, lfa=self.left_hand.forearm_geom_ids,
+                use_fingering=not self._disable_fingering_reward, use_forearm=not self._disable_forearm_reward,
+                energy_coef=self._energy_penalty_coef, key_close=_KEY_CLOSE_ENOUGH_TO_PRESSED,
+                finger_close=_FINGER_CLOSE_ENOUGH_TO_KEY)
+        return self._fused_rewards
 
     def get_discount(self, physics=None):
         return self._discount
@@ -194,7 +235,7 @@ class PianoWithShadowHands(base.PianoTask):
         term = self._should_terminate.clone()
         if self._wrong_press_termination:
             fail = self._failure_termination & ~term
-            self._discount = torch.where(fail, torch.zeros_like(self._discount), self._discount)
+            self._discount.masked_fill_(fail, 0.0)
             term = term | self._failure_termination
         return term
 
@@ -224,7 +265,7 @@ class PianoWithShadowHands(base.PianoTask):
         idx = torch.clamp(steps, max=self._goal_bank.shape[1] - 1)
         g = self._goal_bank[self._song_id[:, None], idx]
         g = torch.where(valid[..., None], g, torch.zeros_like(g))
-        self._goal_state = torch.where(live[:, None, None], g, self._goal_state)
+        self._goal_state.copy_(torch.where(live[:, None, None], g, self._goal_state))
 
     def _update_fingering_state(self) -> None:
         """:391-412."""
@@ -234,7 +275,7 @@ class PianoWithShadowHands(base.PianoTask):
         f = self._finger_bank[self._song_id, idx]  # [E, 88], -1 = key not in goal
         goal_now = self._goal_bank[self._song_id, idx][:, :88] > 0
         f = torch.where(goal_now, f, torch.full_like(f, -1))
-        self._finger_next = torch.where(live[:, None], f, self._finger_next)
+        self._finger_next.copy_(torch.where(live[:, None], f, self._finger_next))
         # observable [right 5, left 5]; a note without fingering (-1) counts as
         # right-hand finger index -1 (python indexing), as in the reference (:401-412)
         fs = torch.zeros((self._E, 10), device=f.device, dtype=self._dtype)
@@ -243,7 +284,7 @@ class PianoWithShadowHands(base.PianoTask):
         fs.scatter_add_(1, torch.where(has, fid, torch.zeros_like(fid)),
                         has.to(self._dtype))
         fs = (fs > 0).to(self._dtype)
-        self._fingering_state = torch.where(live[:, None], fs, self._fingering_state)
+        self._fingering_state.copy_(torch.where(live[:, None], fs, self._fingering_state))
 
     def get_observation(self, physics):
         """Enabled observables (:414-449), evaluated once per control step."""

@@ -1,0 +1,104 @@
+"""ctypes binding of include/rp_task.h (fused task-layer kernels in librp_engine.so).
+
+Used by suite/tasks/piano_with_shadow_hands.py when the physics is the HIP engine: the
+five reward terms of every env are evaluated by one launch on torch's current stream
+instead of ~130 elementwise torch kernels.  The torch implementation stays as the
+definition of the semantics (CPU tests with FakePhysics, GPU cross-check test)."""
+
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from robopianist_amd import engine
+
+EXPORTED_SYMBOLS = ("rp_task_rewards", "rp_task_last_error")
+TERM_NAMES = ("key_press_reward", "sustain_reward", "energy_reward", "fingering_reward", "forearm_reward")
+
+
+class RewardArgs(ctypes.Structure):
+    _fields_ = [
+        ("n_envs", ctypes.c_int), ("precision", ctypes.c_int),
+        ("nv", ctypes.c_int), ("nu", ctypes.c_int), ("n_sites", ctypes.c_int), ("n_contacts", ctypes.c_int),
+        ("use_fingering", ctypes.c_int), ("use_forearm", ctypes.c_int),
+        ("energy_coef", ctypes.c_double), ("key_close", ctypes.c_double), ("finger_close", ctypes.c_double),
+        ("qpos", ctypes.c_void_p), ("act_force", ctypes.c_void_p), ("act_vel", ctypes.c_void_p),
+        ("site_xpos", ctypes.c_void_p), ("contact_geoms", ctypes.c_void_p),
+        ("goal_current", ctypes.c_void_p), ("key_norm_state", ctypes.c_void_p),
+        ("key_activation", ctypes.c_void_p), ("sustain_activation", ctypes.c_void_p),
+        ("finger_current", ctypes.c_void_p),
+        ("key_qadr", ctypes.c_void_p), ("key_anchor", ctypes.c_void_p), ("key_half", ctypes.c_void_p),
+        ("hand_act", ctypes.c_void_p), ("n_hand_act", ctypes.c_int),
+        ("tip_site", ctypes.c_void_p),
+        ("rfa", ctypes.c_void_p), ("n_rfa", ctypes.c_int),
+        ("lfa", ctypes.c_void_p), ("n_lfa", ctypes.c_int),
+        ("terms", ctypes.c_void_p), ("total", ctypes.c_void_p),
+    ]
+
+
+def _lib():
+    L = engine.load_library()
+    if not getattr(L, "_rp_task_ready", False):
+        L.rp_task_rewards.argtypes = [ctypes.POINTER(RewardArgs), ctypes.c_void_p]
+        L.rp_task_rewards.restype = ctypes.c_int
+        L.rp_task_last_error.restype = ctypes.c_char_p
+        L._rp_task_ready = True
+    return L
+
+
+def _chk(t: torch.Tensor, dtype, shape):
+    if t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous() or not t.is_cuda:
+        raise engine.EngineError(f"fused task kernel: bad array {tuple(t.shape)} {t.dtype} (want {shape} {dtype})")
+    return t.data_ptr()
+
+
+class FusedRewards:
+    """All reward terms of PianoWithShadowHands for every env in one launch."""
+
+    def __init__(self, physics, *, n_envs, key_qadr, key_anchor, key_half, hand_act, tip_site, rfa, lfa,
+                 use_fingering, use_forearm, energy_coef, key_close, finger_close):
+        self._L = _lib()
+        dev, dt = physics.device, physics.dtype
+        self._phys, self._E, self._dt = physics, int(n_envs), dt
+        i32 = lambda v: torch.as_tensor([int(x) for x in v], dtype=torch.int32, device=dev).contiguous()
+        # device-resident constants (kept alive by this object)
+        self._key_qadr, self._hand_act, self._tip_site = i32(key_qadr), i32(hand_act), i32(tip_site)
+        self._rfa, self._lfa = i32(rfa), i32(lfa)
+        self._key_anchor = key_anchor.to(device=dev, dtype=dt).contiguous()
+        self._key_half = key_half.to(device=dev, dtype=dt).contiguous()
+        self.terms = torch.zeros((5, self._E), device=dev, dtype=dt)
+        self.total = torch.zeros((self._E,), device=dev, dtype=dt)
+        a = RewardArgs()
+        a.n_envs, a.precision = self._E, 64 if dt == torch.float64 else 32
+        a.nv, a.nu = int(physics.qpos.shape[1]), int(physics.act_force.shape[1])
+        a.n_sites, a.n_contacts = int(physics.site_xpos_eng.shape[1]), int(physics.contact_geoms.shape[1])
+        a.use_fingering, a.use_forearm = int(bool(use_fingering)), int(bool(use_forearm))
+        a.energy_coef, a.key_close, a.finger_close = float(energy_coef), float(key_close), float(finger_close)
+        E = self._E
+        a.qpos = _chk(physics.qpos, dt, (E, a.nv))
+        a.act_force = _chk(physics.act_force, dt, (E, a.nu))
+        a.act_vel = _chk(physics.act_vel, dt, (E, a.nu))
+        a.site_xpos = _chk(physics.site_xpos_eng, dt, (E, a.n_sites, 3))
+        a.contact_geoms = _chk(physics.contact_geoms, torch.int32, (E, a.n_contacts, 2))
+        a.key_qadr, a.key_anchor, a.key_half = self._key_qadr.data_ptr(), self._key_anchor.data_ptr(), self._key_half.data_ptr()
+        a.hand_act, a.n_hand_act = self._hand_act.data_ptr(), int(self._hand_act.numel())
+        a.tip_site = self._tip_site.data_ptr()
+        a.rfa, a.n_rfa = self._rfa.data_ptr(), int(self._rfa.numel())
+        a.lfa, a.n_lfa = self._lfa.data_ptr(), int(self._lfa.numel())
+        a.terms, a.total = self.terms.data_ptr(), self.total.data_ptr()
+        self._args = a
+
+    def compute(self, *, goal_current, key_norm_state, key_activation, sustain_activation, finger_current):
+        """Enqueues the launch on torch's current stream; returns (total [E], terms [5][E]).
+        The state tensors are the task's persistent (in-place updated) buffers."""
+        a, E = self._args, self._E
+        a.goal_current = _chk(goal_current, self._dt, (E, 89))
+        a.key_norm_state = _chk(key_norm_state, self._dt, (E, 88))
+        a.key_activation = _chk(key_activation, torch.bool, (E, 88))
+        a.sustain_activation = _chk(sustain_activation, torch.bool, (E, 1))
+        a.finger_current = _chk(finger_current, torch.int64, (E, 88))
+        stream = torch.cuda.current_stream(self._phys.device).cuda_stream
+        if self._L.rp_task_rewards(ctypes.byref(a), ctypes.c_void_p(stream)) != 0:
+            raise engine.EngineError(self._L.rp_task_last_error().decode())
+        return self.total, self.terms

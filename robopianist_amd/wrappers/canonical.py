@@ -18,6 +18,7 @@ class CanonicalSpecWrapper:
         spec = environment.action_spec()
         self._lo = spec.minimum.astype(np.float64)
         self._hi = spec.maximum.astype(np.float64)
+        self._bounds = None  # (device, dtype, lo, half-range) cached on the device
 
     def __getattr__(self, name):
         return getattr(self._environment, name)
@@ -29,11 +30,14 @@ class CanonicalSpecWrapper:
     def _convert(self, action):
         dev = self._environment.physics.device
         a = torch.as_tensor(action, device=dev, dtype=self._environment.physics.dtype)
-        lo = torch.as_tensor(self._lo, device=dev, dtype=a.dtype)
-        hi = torch.as_tensor(self._hi, device=dev, dtype=a.dtype)
+        if self._bounds is None or self._bounds[0] != dev or self._bounds[1] != a.dtype:
+            lo = torch.as_tensor(self._lo, device=dev, dtype=a.dtype)
+            hi = torch.as_tensor(self._hi, device=dev, dtype=a.dtype)
+            self._bounds = (dev, a.dtype, lo, hi - lo)
+        _, _, lo, rng = self._bounds
         if self._clip:
             a = torch.clamp(a, -1.0, 1.0)
-        return lo + (a + 1.0) * 0.5 * (hi - lo)
+        return lo + (a + 1.0) * 0.5 * rng
 
     def step(self, action):
         return self._environment.step(self._convert(action))

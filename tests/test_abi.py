@@ -1,4 +1,4 @@
-"""The C-ABI library loads and exports every symbol include/rp_engine.h declares;
+"""The C-ABI library loads and exports every symbol include/*.h declares;
 without a GPU the product path fails loudly (no CPU fallback)."""
 import ctypes
 import os
@@ -13,13 +13,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_symbols():
-    src = open(os.path.join(ROOT, "include", "rp_engine.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(rp_[a-z_0-9]+)\s*\(", src)))
+    out = set()
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if not h.endswith(".h"):
+            continue
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        out |= set(re.findall(r"\b(rp_[a-z_0-9]+)\s*\(", src))
+    return sorted(out)
 
 
 def test_header_and_binding_agree():
-    assert _declared_symbols() == sorted(engine.EXPORTED_SYMBOLS)
+    from robopianist_amd import task_kernels
+    assert _declared_symbols() == sorted(tuple(engine.EXPORTED_SYMBOLS) + tuple(task_kernels.EXPORTED_SYMBOLS))
 
 
 def test_library_exports_every_declared_symbol():

@@ -176,3 +176,70 @@ def test_scripted_twinkle_replay_through_canonical_wrapper():
     assert int(env.physics.warn.max()) == 0
     metrics = env.get_musical_metrics()
     assert 0.0 <= metrics["f1"] <= 1.0
+
+
+def test_graphed_step_matches_eager():
+    """wrappers.GraphedStepWrapper: a whole env.step replayed from one captured hipGraph
+    gives the same TimeSteps and the same physics state as the eager path, across an
+    episode boundary (device-side auto reset) as well."""
+    import os
+    from robopianist_amd import suite
+    from robopianist_amd.wrappers import CanonicalSpecWrapper, GraphedStepWrapper
+    actions = np.load(os.path.join(os.path.dirname(__file__), "golden", "twinkle_twinkle_actions.npy"))
+    kw = dict(seed=7, n_envs=6, precision=64,
+              task_kwargs=dict(trim_silence=True, control_timestep=0.05, gravity_compensation=True,
+                               primitive_fingertip_collisions=True, n_steps_lookahead=3))
+    name = "RoboPianist-debug-TwinkleTwinkleRousseau-v0"
+    eager = CanonicalSpecWrapper(suite.load(name, **kw))
+    graphed = GraphedStepWrapper(CanonicalSpecWrapper(suite.load(name, **kw)), warmup_steps=2)
+    eager.reset(); graphed.reset()
+    dev = eager.physics.device
+    T = actions.shape[0]
+    for t in list(range(8)) + list(range(T - 6, T)) + list(range(3)):
+        a = torch.as_tensor(actions[t % T], device=dev, dtype=torch.float64).expand(6, -1)
+        ts_e, ts_g = eager.step(a), graphed.step(a)
+        if t == T - 6:  # jump both envs close to the end of the song to cross an episode boundary
+            for env in (eager, graphed):
+                env.task._t_idx.fill_(T - 5)
+        assert torch.equal(ts_e.step_type, ts_g.step_type)
+        np.testing.assert_allclose(_np(ts_e.reward), _np(ts_g.reward), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(_np(ts_e.discount), _np(ts_g.discount), rtol=0, atol=0)
+        for k in ts_e.observation:
+            np.testing.assert_allclose(_np(ts_e.observation[k]), _np(ts_g.observation[k]), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(_np(eager.physics.qpos), _np(graphed.physics.qpos), rtol=0, atol=1e-12)
+    assert graphed.graph_captured
+    assert (ts_g.step_type == 0).any() or (ts_g.step_type == 1).all()
+
+
+def test_fused_rewards_match_torch_terms():
+    """include/rp_task.h: the one-launch reward kernel against the torch reward functions
+    (the restatement of piano_with_shadow_hands.py:251-331), term by term, on the replay
+    and on random actions, with and without the fingering / forearm terms."""
+    import os
+    from robopianist_amd import suite
+    from robopianist_amd.wrappers import CanonicalSpecWrapper
+    actions = np.load(os.path.join(os.path.dirname(__file__), "golden", "twinkle_twinkle_actions.npy"))
+    name = "RoboPianist-debug-TwinkleTwinkleRousseau-v0"
+    for extra in (dict(), dict(disable_fingering_reward=True, disable_forearm_reward=True)):
+        for precision, tol in ((64, 1e-12), (32, 2e-5)):
+            if extra.get("disable_fingering_reward"):
+                # the OT fingering term replaces it in the reference: host path, not fused
+                continue
+            env = CanonicalSpecWrapper(suite.load(
+                name, seed=3, n_envs=5, precision=precision,
+                task_kwargs=dict(trim_silence=True, control_timestep=0.05, gravity_compensation=True,
+                                 primitive_fingertip_collisions=True, **extra)))
+            task = env.task
+            env.reset()
+            rng = np.random.RandomState(0)
+            for t in range(25):
+                a = actions[t] if t < 15 else rng.uniform(-1, 1, size=actions.shape[1])
+                ts = env.step(np.tile(a, (5, 1)))
+                fused_total = ts.reward.clone()
+                fused_terms = {k: v.clone() for k, v in task.reward_fn.reward_terms.items()}
+                assert task._fused_rewards is not None
+                ref_total = task.reward_fn.compute(env.physics)  # torch functions, same state
+                for k, v in task.reward_fn.reward_terms.items():
+                    np.testing.assert_allclose(_np(fused_terms[k]), _np(v), rtol=0, atol=tol, err_msg=k)
+                live = _np(ts.step_type) != 0
+                np.testing.assert_allclose(_np(fused_total)[live], _np(ref_total)[live], rtol=0, atol=5 * tol)
