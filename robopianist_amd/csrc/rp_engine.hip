@@ -179,6 +179,7 @@ struct Engine : EngineBase {
     };
 #define PF(name, blobname) putF(RpLayout::F_##name, RpLayout::F_##name##_end - RpLayout::F_##name + 1, b.f(blobname), blobname)
 #define PI(name, blobname) putI(RpLayout::I_##name, RpLayout::I_##name##_end - RpLayout::I_##name + 1, b.i(blobname), blobname)
+    PI(lane_topo, "eng_lane_topo");
     PI(link_parent, "eng_link_parent"); PI(link_depth, "eng_link_depth"); PI(link_tree, "eng_link_tree");
     PI(link_jtype, "eng_link_jtype"); PI(link_dof, "eng_link_dof"); PI(link_sibrank, "eng_link_sibrank");
     PI(level_maxrank, "eng_level_maxrank"); PI(link_anc, "eng_link_anc"); PI(link_limited, "eng_link_limited");
@@ -211,7 +212,7 @@ struct Engine : EngineBase {
     PF(link_floss, "eng_link_floss"); PF(link_fl_R, "eng_link_fl_R"); PF(link_fl_B, "eng_link_fl_B");
     PF(link_range, "eng_link_range"); PF(link_lim_K, "eng_link_lim_K"); PF(link_lim_B, "eng_link_lim_B");
     PF(link_lim_solimp, "eng_link_lim_solimp"); PF(link_invw_dof, "eng_link_invw_dof");
-    PF(link_act_coef, "eng_link_act_coef"); PF(tree_gscale, "eng_tree_gscale"); PF(tree_ref, "eng_tree_ref");
+    PF(link_act_coef, "eng_link_act_coef"); PF(link_gscale, "eng_link_gscale"); PF(tree_gscale, "eng_tree_gscale"); PF(tree_ref, "eng_tree_ref");
     PI(key_dof, "eng_key_dof"); PI(key_act, "eng_key_act"); PI(key_geomid, "eng_key_geomid");
     auto kpos = b.f("eng_key_pos"), khalf = b.f("eng_key_half");
     PF(key_pos, "eng_key_pos"); PF(key_half, "eng_key_half");

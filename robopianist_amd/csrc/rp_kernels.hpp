@@ -52,6 +52,7 @@
   X(link_floss,       RPK_NL,      1) X(link_fl_R,       RPK_NL,      1) X(link_fl_B,      RPK_NL, 1) \
   X(link_range,       RPK_NL,      2) X(link_lim_K,      RPK_NL,      1) X(link_lim_B,     RPK_NL, 1) \
   X(link_lim_solimp,  RPK_NL,      5) X(link_invw_dof,   RPK_NL,      1) X(link_act_coef,  RPK_NL, 1) \
+  X(link_gscale,      RPK_NL,      1) \
   X(tree_gscale,      RPK_MAXTREE, 1) X(tree_ref,        RPK_MAXTREE, 3) \
   X(key_pos,          RPK_NKEYS,   3) X(key_half,        RPK_NKEYS,   3) X(key_mass,       RPK_NKEYS, 1) \
   X(key_M,            RPK_NKEYS,   1) X(key_stiffness,   RPK_NKEYS,   1) X(key_springref,  RPK_NKEYS, 1) \
@@ -63,6 +64,7 @@
   X(act_coef,         RPK_MAXACT,  2) X(act_gain,        RPK_MAXACT,  1) X(act_bias,       RPK_MAXACT, 3) \
   X(act_ctrlrange,    RPK_MAXACT,  2) X(act_forcerange,  RPK_MAXACT,  2) X(site_pos,       RPK_WAVE,  3)
 #define RPK_ITABLES(X) \
+  X(lane_topo,    RPK_NL, 16) \
   X(link_parent,  RPK_NL, 1) X(link_depth,   RPK_NL, 1) X(link_tree,    RPK_NL, 1) X(link_jtype,  RPK_NL, 1) \
   X(link_dof,     RPK_NL, 1) X(link_sibrank, RPK_NL, 1) X(link_limited, RPK_NL, 1) X(link_act,    RPK_NL, 1) \
   X(link_ndesc,   RPK_NL, 1) X(link_anc,     RPK_NL, RPK_MAXD) X(link_ancmask, RPK_NL, 2) \
@@ -148,7 +150,7 @@ struct RpState {
 // (MODE 1): everything `mj_step1` leaves behind for `mj_step2`, per env.  Lives in
 // HBM but is L2 / Infinity-Cache resident (<= 25 KB per env).
 #define RPK_NLF 29  // per-lane float fields
-#define RPK_NLI 11  // per-lane int fields
+#define RPK_NLI 12  // per-lane int fields
 template <typename T>
 struct RpStage {
   T* RM;      // [E][RPK_NL][RPK_MAXD+1] mass-matrix rows
@@ -675,7 +677,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
   using N = Num<T>;
   const int env = blockIdx.x;
   const int lane = threadIdx.x;
-  if (S.active && S.active[env] == 0) return;
+  const int env_active = S.active ? S.active[env] : 1;  // tested after the prologue loads are in flight
   __shared__ Smem<T> sm;
   int warn = 0;
   if (S.prof && env == 0 && lane < RPK_NPROF) sm.prof[lane] = 0;
@@ -686,30 +688,35 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
   // ------------------------------------------------------------ lane constants
   const bool isl = lane < nl;
   const int L = isl ? lane : 0;
-  const int parent = isl ? M.link_parent()[L] : -1;
-  const int depth = isl ? M.link_depth()[L] : -1;
-  const int jtype = isl ? M.link_jtype()[L] : 0;
-  const int sibrank = isl ? M.link_sibrank()[L] : 0;
-  const int ltree = isl ? M.link_tree()[L] : 0;
-  const int ldof = isl ? M.link_dof()[L] : 0;
-  // chain structure (lanes are in preorder: trunk chain, then up to 5 leaf chains)
-  const int tbase = isl ? M.tree_base()[ltree] : 0, TL = isl ? M.tree_trunk()[ltree] : 0;
-  int cf[5], cl[5];
+  // one 64-byte topology record per link lane (engine_tables.py: eng_lane_topo), so that
+  // the prologue is a single batch of independent loads instead of a chain of lookups
+  int tp[16];
+  {
+    const int4* rec = (const int4*)(M.lane_topo() + 16 * L);
 #pragma unroll
-  for (int c = 0; c < 5; c++) {
-    cf[c] = isl ? M.chain_first()[ltree * 5 + c] : -1;
-    cl[c] = isl ? M.chain_len()[ltree * 5 + c] : 0;
+    for (int q = 0; q < 4; q++) {
+      const int4 v = rec[q];
+      tp[4 * q] = v.x; tp[4 * q + 1] = v.y; tp[4 * q + 2] = v.z; tp[4 * q + 3] = v.w;
+    }
   }
-  const int ndesc = isl ? M.link_ndesc()[L] : 0;
-  int chain_end = 0, mychain = 0;  // chain lanes: first depth past the end of my chain / chain index
-#pragma unroll
-  for (int c = 0; c < 5; c++) if (isl && lane >= cf[c] && lane < cf[c] + cl[c]) { chain_end = TL + cl[c]; mychain = c; }
+  const int parent = isl ? tp[0] : -1;
+  const int depth = isl ? tp[1] : -1;
+  const int jtype = isl ? tp[2] : 0;
+  const int sibrank = isl ? tp[3] : 0;
+  const int ltree = isl ? tp[4] : 0;
+  const int ldof = isl ? tp[5] : 0;
+  // chain structure (lanes are in preorder: trunk chain, then up to 5 leaf chains)
+  const int tbase = isl ? tp[6] : 0, TL = isl ? tp[7] : 0;
+  const int ndesc = isl ? tp[8] : 0;
+  // chain lanes: first depth past the end of my chain / chain index; bit c of chainmask:
+  // leaf chain c of my tree exists
+  const int chain_end = isl ? tp[11] : 0, mychain = isl ? tp[12] : 0, chainmask = isl ? tp[13] : 0;
   // lane of my ancestor at depth e (e <= depth)
   auto anc_at = [&](int e) -> int { return e < TL ? tbase + e : lane - (depth - e); };
-  const int llimited = isl ? M.link_limited()[L] : 0;
-  const int lact = isl ? M.link_act()[L] : -1;
+  const int llimited = isl ? tp[9] : 0;
+  const int lact = isl ? tp[10] : -1;
   const T lactcoef = isl ? M.link_act_coef()[L] : (T)0;
-  const T gscale = (isl && nl) ? M.tree_gscale()[ltree] : (T)0;
+  const T gscale = (isl && nl) ? M.link_gscale()[L] : (T)0;
   int hasdof[3];
   hasdof[0] = isl && llimited; hasdof[1] = lane < nk; hasdof[2] = lane + 64 < nk;
   const bool isk[2] = {lane < nk, lane + 64 < nk};
@@ -822,6 +829,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
     kctrl[s] = c;
   }
   T time = S.time[env];
+  if (env_active == 0) return;  // masked env (all loads above are speculative and harmless)
 
 
   PROF(0);
@@ -837,7 +845,6 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
   // of link `lk` at depth e is arithmetic: trunk base + e on the trunk, lk - (depth - e)
   // on lk's own chain.  (depth, trunk length, trunk base) of the links a lane needs:
   int sTL = 0, sTB = 0, salink = 0;          // slot lanes: anchor link of my key
-  int cdep[2] = {-1, -1}, cTL[2] = {0, 0}, cTB[2] = {0, 0};  // contact lanes: side A / B link
   auto anc_of = [](int lk, int dl, int tl, int tb, int e) -> int { return e < tl ? tb + e : lk - (dl - e); };
   T ksin[2] = {0, 0}, kcos[2] = {1, 1};
   int ncon = 0, nkt = 0, nent = 0, maxm = 0;  // contacts, touched keys, Jacobian entries, max per contact
@@ -901,20 +908,9 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
         }
         if (lane < RPK_NKEYS / 4) ((int*)sm.keyslot)[lane] = B.keyslot[(size_t)env * (RPK_NKEYS / 4) + lane];
         WSYNC();
-        if (!isl && lane < nl + nkt) {
-          int al = sm.slotlink[lane - nl];
-          if (al >= 0) {
-            const int t = M.link_tree()[al];
-            salink = al; sTL = M.tree_trunk()[t]; sTB = M.tree_base()[t];
-          }
-        }
-#pragma unroll
-        for (int side = 0; side < 2; side++) {
-          const int Lk = side ? con_B : con_A;
-          if (lane < ncon && Lk >= 0 && Lk < RPK_KEYBASE) {
-            const int t = M.link_tree()[Lk];
-            cdep[side] = M.link_depth()[Lk]; cTL[side] = M.tree_trunk()[t]; cTB[side] = M.tree_base()[t];
-          }
+        {
+          const int sl_ = LI(11);
+          salink = sl_ & 255; sTL = (sl_ >> 8) & 255; sTB = (sl_ >> 16) & 255;
         }
       }
       RPK_LOAD_DYN
@@ -1108,7 +1104,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
 #pragma unroll
             for (int e = 0; e < 4; e++) dv[e] = rec[tro + e < 10 ? tro + e : 9];
             const T dr = rec[10 + depth];
-            const bool has = (c == 0 ? cl[0] : c == 1 ? cl[1] : c == 2 ? cl[2] : c == 3 ? cl[3] : cl[4]) > 0;
+            const bool has = (chainmask >> c) & 1;
 #pragma unroll
             for (int e = 0; e < 4; e++) if (has && e <= depth) Rr[e] += dv[e];
             if (has) rhs += dr;
@@ -2196,7 +2192,9 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
       if (!isl && lane < nl + nkt) {
         int al = sm.slotlink[lane - nl];
         if (al >= 0) {
-          sdepth = M.link_depth()[al];
+          const int* rec = M.lane_topo() + 16 * al;
+          sdepth = rec[1];
+          salink = al; sTB = rec[6]; sTL = rec[7];
         }
       }
     }
@@ -2351,6 +2349,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
       LI(5) = (int)(con_maskA & 0xffffffffu); LI(6) = (int)(con_maskA >> 32);
       LI(7) = (int)(con_maskB & 0xffffffffu); LI(8) = (int)(con_maskB >> 32);
       LI(9) = sdepth;
+      LI(11) = salink | (sTL << 8) | (sTB << 16);
       if (isl) {
 #pragma unroll
         for (int e = 0; e <= RPK_MAXD; e++) B.RM[((size_t)env * RPK_NL + lane) * (RPK_MAXD + 1) + e] = Mr[e];

@@ -427,4 +427,25 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
     t["eng_site_link"] = s_link[hs] if hs else np.zeros(0, np.int32)
     t["eng_site_pos"] = m.site_pos[hs] if hs else np.zeros((0, 3))
     t["eng_site_modelid"] = np.array(hs, np.int32)
+
+    # ---- per-lane topology record: everything a link lane needs about the tree in ONE
+    # 64-byte read (the kernels' prologues are otherwise chains of dependent table reads)
+    topo = np.zeros((max(nl, 1), 16), np.int32)
+    for L in range(nl):
+        tr = int(t["eng_link_tree"][L])
+        TLv, tb = int(t["eng_tree_trunk"][tr]), int(t["eng_tree_base"][tr])
+        cfv = np.asarray(t["eng_chain_first"]).reshape(-1, 5)[tr]
+        clv = np.asarray(t["eng_chain_len"]).reshape(-1, 5)[tr]
+        chain_end, mychain, chainmask = 0, 0, 0
+        for c in range(5):
+            if clv[c] > 0:
+                chainmask |= 1 << c
+            if cfv[c] <= L < cfv[c] + clv[c]:
+                chain_end, mychain = TLv + int(clv[c]), c
+        topo[L, :14] = [t["eng_link_parent"][L], t["eng_link_depth"][L], t["eng_link_jtype"][L],
+                        t["eng_link_sibrank"][L], tr, t["eng_link_dof"][L], tb, TLv,
+                        t["eng_link_ndesc"][L], t["eng_link_limited"][L], t["eng_link_act"][L],
+                        chain_end, mychain, chainmask]
+    t["eng_lane_topo"] = topo
+    t["eng_link_gscale"] = np.array([t["eng_tree_gscale"][int(t["eng_link_tree"][L])] for L in range(nl)], np.float64)
     return t
