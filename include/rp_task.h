@@ -53,6 +53,48 @@ typedef struct rp_task_reward_args {
 } rp_task_reward_args;
 
 int rp_task_rewards(const rp_task_reward_args* args, void* hip_stream);
+
+/* rp_task_advance: everything the reference does in Python between the last physics
+ * substep and the TimeStep it returns, for all envs in one launch:
+ *   Piano._update_key_state            (models/piano/piano.py:178-192)
+ *   PianoWithShadowHands.after_step    (suite/tasks/piano_with_shadow_hands.py:188-204)
+ *   goal / fingering observables       (:371-412)
+ *   the reward terms                   (:251-331, as rp_task_rewards)
+ *   should_terminate_episode, discount (:209-220)
+ *   dm_env step types incl. the device-side auto-reset rule of the vectorised env
+ *     (envs flagged in `needs_reset` on entry are FIRST: task state reset as in
+ *      initialize_episode :167-174, reward 0, discount 1; on exit the flag holds the envs
+ *      that terminated this step).
+ * `rw` supplies the engine views, constants and the reward outputs; its task-state
+ * pointers (goal_current, key_norm_state, key_activation, sustain_activation,
+ * finger_current) must alias the arrays named here. */
+typedef struct rp_task_advance_args {
+  rp_task_reward_args rw;
+  int n_lookahead;                   /* L: goal_state is [E][L+1][89] */
+  int n_songs, bank_len;             /* goal_bank [n_songs][bank_len][89], finger_bank [..][88] */
+  int wrong_press_termination;
+  double key_threshold, sustain_threshold;   /* piano.py:31-32 */
+  const int* warn;                   /* [E] engine warn flags (bit 0: bad state) */
+  const void* key_qrange;            /* [88][2] */
+  const void* goal_bank; const long long* finger_bank;
+  const long long* song_len;         /* [n_songs] */
+  const long long* song_id;          /* [E] */
+  /* piano state */
+  void* key_state;                   /* [E][88] clipped joint position */
+  const void* sustain_state;         /* [E]     latched by before_step */
+  /* task state (in/out) */
+  long long* t_idx; unsigned char* should_terminate; unsigned char* failure_termination;
+  void* discount_state;              /* [E] */
+  void* goal_state;                  /* [E][L+1][89] */
+  long long* finger_next;            /* [E][88] */
+  void* fingering_state;             /* [E][10] */
+  unsigned char* needs_reset;        /* [E] in/out */
+  /* outputs */
+  void* discount;                    /* [E] */
+  int* step_type;                    /* [E] 0 FIRST, 1 MID, 2 LAST */
+} rp_task_advance_args;
+
+int rp_task_advance(const rp_task_advance_args* args, void* hip_stream);
 const char* rp_task_last_error(void);
 
 #ifdef __cplusplus

@@ -21,32 +21,28 @@ template <typename T> __device__ __forceinline__ T tol_gauss(T x, T upper, T mar
   return exp((T)-0.5 * z * z);
 }
 
-// one wavefront per env; lane k owns keys k and k + 64
+// Per-lane view of the task state the reward terms read: lane k owns keys k and k + 64.
+template <typename T> struct KeyView { T goal[2], nstate[2]; bool pressed[2]; long long finger[2]; T goal_sustain; bool sustain_on; };
+
+// All reward terms of one env (one wavefront); the result is valid in lane 0.
 template <typename T>
-__global__ __launch_bounds__(64) void rp_task_reward_kernel(rp_task_reward_args a) {
-  const int env = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ T reward_env(const rp_task_reward_args& a, int env, int lane, const KeyView<T>& kv) {
   const size_t E = (size_t)a.n_envs;
-  const T* goal = (const T*)a.goal_current + (size_t)env * 89;
-  const T* nstate = (const T*)a.key_norm_state + (size_t)env * 88;
-  const unsigned char* act = a.key_activation + (size_t)env * 88;
   const T* qpos = (const T*)a.qpos + (size_t)env * a.nv;
   const T* sites = (const T*)a.site_xpos + (size_t)env * a.n_sites * 3;
   const T kclose = (T)a.key_close, fclose = (T)a.finger_close;
-
   T kp_sum = 0, fg_sum = 0;
   int n_on = 0, false_pos = 0;
 #pragma unroll
   for (int s = 0; s < 2; s++) {
     const int k = lane + 64 * s;
     if (k < RP_TASK_N_KEYS) {
-      const T g = goal[k];
-      const bool on = g > (T)0;
-      const bool pressed = act[k] != 0;
-      if (on) {
+      const T g = kv.goal[s];
+      if (g > (T)0) {
         n_on++;
-        kp_sum += tol_gauss(g - nstate[k], kclose, kclose * (T)10);
+        kp_sum += tol_gauss(g - kv.nstate[s], kclose, kclose * (T)10);
         if (a.use_fingering) {
-          long long f = a.finger_current[(size_t)env * 88 + k];
+          const long long f = kv.finger[s];
           const int fid = f < 0 ? 4 : (int)f;  // a note without fingering counts as finger 4 (:401-412)
           const T* tip = sites + (size_t)a.tip_site[fid] * 3;
           const T* an = (const T*)a.key_anchor + 3 * k;
@@ -60,7 +56,7 @@ __global__ __launch_bounds__(64) void rp_task_reward_kernel(rp_task_reward_args 
           const T dx = tx - tip[0], dy = ty - tip[1], dz = tz - tip[2];
           fg_sum += tol_gauss(sqrt(dx * dx + dy * dy + dz * dz), fclose, fclose * (T)10);
         }
-      } else if (pressed) false_pos = 1;
+      } else if (kv.pressed[s]) false_pos = 1;
     }
   }
   // energy: |actuatorfrc| * |actuatorvel| over the hand actuators
@@ -84,20 +80,140 @@ __global__ __launch_bounds__(64) void rp_task_reward_kernel(rp_task_reward_args 
   kp_sum = wsum(kp_sum); fg_sum = wsum(fg_sum); en = wsum(en);
   const int non = (int)wsum((float)n_on);
   const bool fpos = __ballot(false_pos) != 0ull, fhit = __ballot(hit) != 0ull;
+  T tot = 0;
   if (lane == 0) {
     const T key_press = (non > 0 ? (T)0.5 * kp_sum / (T)non : (T)0) + (T)0.5 * (fpos ? (T)0 : (T)1);
-    const T sustain = tol_gauss(goal[88] - (a.sustain_activation[env] ? (T)1 : (T)0), kclose, kclose * (T)10);
+    const T sustain = tol_gauss(kv.goal_sustain - (kv.sustain_on ? (T)1 : (T)0), kclose, kclose * (T)10);
     const T energy = -(T)a.energy_coef * en;
     const T fingering = a.use_fingering ? (non > 0 ? fg_sum / (T)non : (T)0) : (T)0;
     const T forearm = a.use_forearm ? (fhit ? (T)0 : (T)0.5) : (T)0;
     T* t = (T*)a.terms;
     t[0 * E + env] = key_press; t[1 * E + env] = sustain; t[2 * E + env] = energy;
     t[3 * E + env] = fingering; t[4 * E + env] = forearm;
-    T tot = (T)0 + key_press;
+    tot = (T)0 + key_press;
     tot += sustain; tot += energy;
     if (a.use_fingering) tot += fingering;
     if (a.use_forearm) tot += forearm;
-    ((T*)a.total)[env] = tot;
+  }
+  return tot;
+}
+
+// one wavefront per env
+template <typename T>
+__global__ __launch_bounds__(64) void rp_task_reward_kernel(rp_task_reward_args a) {
+  const int env = blockIdx.x, lane = threadIdx.x;
+  KeyView<T> kv;
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const int k = lane + 64 * s, kk = k < RP_TASK_N_KEYS ? k : 0;
+    kv.goal[s] = ((const T*)a.goal_current)[(size_t)env * 89 + kk];
+    kv.nstate[s] = ((const T*)a.key_norm_state)[(size_t)env * 88 + kk];
+    kv.pressed[s] = a.key_activation[(size_t)env * 88 + kk] != 0;
+    kv.finger[s] = a.finger_current[(size_t)env * 88 + kk];
+  }
+  kv.goal_sustain = ((const T*)a.goal_current)[(size_t)env * 89 + 88];
+  kv.sustain_on = a.sustain_activation[env] != 0;
+  const T tot = reward_env<T>(a, env, lane, kv);
+  if (lane == 0) ((T*)a.total)[env] = tot;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void rp_task_advance_kernel(rp_task_advance_args p) {
+  const rp_task_reward_args& a = p.rw;
+  const int env = blockIdx.x, lane = threadIdx.x;
+  const bool resetting = p.needs_reset[env] != 0, active = !resetting;
+  long long t = p.t_idx[env];
+  T dstate = ((T*)p.discount_state)[env];
+  if (resetting) { t = 0; dstate = (T)1; }  // _reset_quantities_at_episode_init (:146-149)
+  const long long song = p.song_id[env], slen = p.song_len[song];
+  const T* qpos = (const T*)a.qpos + (size_t)env * a.nv;
+  T* gstate = (T*)p.goal_state + (size_t)env * (p.n_lookahead + 1) * 89;
+
+  // ---- Piano._update_key_state + after_step
+  KeyView<T> kv;
+  int fail = 0;
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const int k = lane + 64 * s;
+    kv.goal[s] = 0; kv.nstate[s] = 0; kv.pressed[s] = false; kv.finger[s] = -1;
+    if (k < RP_TASK_N_KEYS) {
+      const T lo = ((const T*)p.key_qrange)[2 * k], hi = ((const T*)p.key_qrange)[2 * k + 1];
+      const T q = qpos[a.key_qadr[k]];
+      const T st = q < lo ? lo : (q > hi ? hi : q);
+      const T ns = st / hi;
+      const bool pressed = fabs(st - hi) <= (T)p.key_threshold;
+      ((T*)p.key_state)[(size_t)env * 88 + k] = st;
+      ((T*)a.key_norm_state)[(size_t)env * 88 + k] = ns;
+      ((unsigned char*)a.key_activation)[(size_t)env * 88 + k] = pressed;
+      const T g = gstate[k];                                   // goal_state[:, 0] of the last observation
+      const long long f = p.finger_next[(size_t)env * 88 + k];
+      ((T*)a.goal_current)[(size_t)env * 89 + k] = g;
+      ((long long*)a.finger_current)[(size_t)env * 88 + k] = f;
+      kv.goal[s] = g; kv.nstate[s] = ns; kv.pressed[s] = pressed; kv.finger[s] = f;
+      if (pressed && g == (T)0) fail = 1;
+    }
+  }
+  const T gsus = gstate[88];
+  const bool sus_on = ((const T*)p.sustain_state)[env] >= (T)p.sustain_threshold;
+  kv.goal_sustain = gsus; kv.sustain_on = sus_on;
+  const bool failure = __ballot(fail) != 0ull;
+  t += active ? 1 : 0;
+  bool term = t == slen;                                       // (t_idx - 1) == len - 1
+  if (lane == 0) {
+    ((T*)a.goal_current)[(size_t)env * 89 + 88] = gsus;
+    ((unsigned char*)a.sustain_activation)[env] = sus_on;
+  }
+
+  // ---- observables for the next step: goal look-ahead and fingering (:371-412)
+  const bool live = t < slen;
+  if (live) {
+    const int n = (p.n_lookahead + 1) * 89;
+    for (int i = lane; i < n; i += 64) {
+      const int j = i / 89, c = i - 89 * j;
+      const long long stp = t + j;
+      const long long bi = stp < p.bank_len - 1 ? stp : p.bank_len - 1;
+      const T g = stp < slen ? ((const T*)p.goal_bank)[((size_t)song * p.bank_len + bi) * 89 + c] : (T)0;
+      gstate[i] = g;
+    }
+    const long long bi = t < p.bank_len - 1 ? t : p.bank_len - 1;
+    unsigned fbits = 0;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const int k = lane + 64 * s;
+      if (k < RP_TASK_N_KEYS) {
+        const bool gn = ((const T*)p.goal_bank)[((size_t)song * p.bank_len + bi) * 89 + k] > (T)0;
+        const long long f = gn ? p.finger_bank[((size_t)song * p.bank_len + bi) * 88 + k] : -1;
+        p.finger_next[(size_t)env * 88 + k] = f;
+        if (gn) fbits |= 1u << (f < 0 ? 4 : (int)f);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) fbits |= __shfl_xor(fbits, off, 64);
+    if (lane < 10) ((T*)p.fingering_state)[(size_t)env * 10 + lane] = (fbits >> lane) & 1u ? (T)1 : (T)0;
+  }
+
+  // ---- rewards, termination, discount, step type
+  T reward = reward_env<T>(a, env, lane, kv);
+  if (lane == 0) {
+    if (p.wrong_press_termination) {
+      if (failure && !term) dstate = (T)0;
+      term = term || failure;
+    }
+    bool terminate = term && active;
+    const bool bad = (p.warn[env] & 1) != 0 && active;       // physics divergence ends the episode
+    terminate = terminate || bad;
+    T disc = dstate;
+    if (bad) { reward = (T)0; disc = (T)0; }
+    int st = terminate ? 2 : 1;
+    if (resetting) { st = 0; reward = (T)0; disc = (T)1; }
+    ((T*)a.total)[env] = reward;
+    ((T*)p.discount)[env] = disc;
+    p.step_type[env] = st;
+    p.t_idx[env] = t;
+    p.should_terminate[env] = t == slen;
+    p.failure_termination[env] = failure;
+    ((T*)p.discount_state)[env] = dstate;
+    p.needs_reset[env] = terminate;
   }
 }
 }  // namespace
@@ -121,6 +237,28 @@ int rp_task_rewards(const rp_task_reward_args* a, void* hip_stream) {
   else hipLaunchKernelGGL(rp_task_reward_kernel<double>, dim3(a->n_envs), dim3(64), 0, s, *a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { g_task_err = std::string("rp_task_rewards: ") + hipGetErrorString(e); return -2; }
+  return 0;
+}
+
+int rp_task_advance(const rp_task_advance_args* p, void* hip_stream) {
+  if (!p) { g_task_err = "rp_task_advance: null args"; return -1; }
+  const rp_task_reward_args* a = &p->rw;
+  if (a->precision != 32 && a->precision != 64) { g_task_err = "rp_task_advance: precision must be 32 or 64"; return -1; }
+  if (a->n_envs <= 0 || p->n_lookahead < 0 || p->bank_len <= 0) { g_task_err = "rp_task_advance: bad sizes"; return -1; }
+  if (!a->qpos || !a->act_force || !a->act_vel || !a->site_xpos || !a->contact_geoms || !a->goal_current ||
+      !a->key_norm_state || !a->key_activation || !a->sustain_activation || !a->finger_current || !a->key_qadr ||
+      !a->key_anchor || !a->key_half || !a->hand_act || !a->tip_site || !a->terms || !a->total || !p->warn ||
+      !p->key_qrange || !p->goal_bank || !p->finger_bank || !p->song_len || !p->song_id || !p->key_state ||
+      !p->sustain_state || !p->t_idx || !p->should_terminate || !p->failure_termination || !p->discount_state ||
+      !p->goal_state || !p->finger_next || !p->fingering_state || !p->needs_reset || !p->discount || !p->step_type) {
+    g_task_err = "rp_task_advance: null array pointer";
+    return -1;
+  }
+  hipStream_t s = (hipStream_t)hip_stream;
+  if (a->precision == 32) hipLaunchKernelGGL(rp_task_advance_kernel<float>, dim3(a->n_envs), dim3(64), 0, s, *p);
+  else hipLaunchKernelGGL(rp_task_advance_kernel<double>, dim3(a->n_envs), dim3(64), 0, s, *p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { g_task_err = std::string("rp_task_advance: ") + hipGetErrorString(e); return -2; }
   return 0;
 }
 

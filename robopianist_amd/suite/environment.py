@@ -25,7 +25,8 @@ from robopianist_amd.suite.specs import StepType, TimeStep
 
 class Environment:
     def __init__(self, task, n_envs: int = 1, random_state=None, device_id: int = 0,
-                 precision: int = 32, physics=None, record_key_trace: bool = False):
+                 precision: int = 32, physics=None, record_key_trace: bool = False,
+                 copy_outputs: bool = True):
         self._task = task
         self._n_envs = int(n_envs)
         if isinstance(random_state, np.random.RandomState):
@@ -40,6 +41,7 @@ class Environment:
         task.bind(physics, self._n_envs, self._random_state)
         self._needs_reset = torch.ones(self._n_envs, dtype=torch.bool, device=physics.device)
         self._record_key_trace = record_key_trace
+        self._copy_outputs = bool(copy_outputs)
         self._key_trace = None
         if record_key_trace:
             self._key_trace = torch.zeros((self._n_envs, self._n_sub_steps, 4), dtype=torch.int32,
@@ -98,6 +100,19 @@ class Environment:
         if self._n_envs == 1 and bool(resetting.all()):
             return self.reset()  # dm_env: step after LAST == reset (reward None)
         active = ~resetting
+        fused = task.fused_advance_for(phys) if hasattr(task, "fused_advance_for") else None
+        if fused is not None:
+            # HIP task layer (include/rp_task.h): the episode reset of the flagged envs, the
+            # key state, after_step, observables, rewards, termination and the step types
+            # are one launch after the physics
+            phys.reset(resetting)
+            phys.set_active(resetting)
+            phys.forward()
+            phys.set_active(active)
+            task.before_step(phys, action)
+            phys.step(self._n_sub_steps, self._key_trace)
+            st, reward, discount, obs = task.fused_advance(phys, self._needs_reset)
+            return self._fresh(TimeStep(st, reward, discount, obs))
         # envs that finished (or were never reset) start a new episode and are not simulated
         phys.reset(resetting)
         task.initialize_episode(phys, resetting)
@@ -122,4 +137,14 @@ class Environment:
         reward = torch.where(resetting, torch.zeros_like(reward), reward)
         discount = torch.where(resetting, torch.ones_like(discount), discount)
         self._needs_reset.copy_(terminate)  # in place: the step is hipGraph-capturable
-        return TimeStep(st, reward, discount, obs)
+        return self._fresh(TimeStep(st, reward, discount, obs))
+
+    def _fresh(self, ts: TimeStep) -> TimeStep:
+        """dm_env hands out arrays the caller may keep; the task state behind them is
+        updated in place, so the TimeStep gets its own copies (`copy_outputs=False` hands
+        out the live buffers instead)."""
+        if not self._copy_outputs:
+            return ts
+        obs = {k: v.clone() for k, v in ts.observation.items()}
+        return TimeStep(ts.step_type.clone(), None if ts.reward is None else ts.reward.clone(),
+                        None if ts.discount is None else ts.discount.clone(), obs)

@@ -66,6 +66,8 @@ class PianoWithShadowHands(base.PianoTask):
         self._randomize_hand_positions = randomize_hand_positions
         self._use_fused_rewards = True   # set False to force the torch reward functions
         self._fused_rewards = None
+        self._use_fused_advance = True   # set False to force the torch task hooks
+        self._fused_advance = None
         self._reset_trajectory()
         self._set_rewards()
 
@@ -226,6 +228,53 @@ class PianoWithShadowHands(base.PianoTask):
                 energy_coef=self._energy_penalty_coef, key_close=_KEY_CLOSE_ENOUGH_TO_PRESSED,
                 finger_close=_FINGER_CLOSE_ENOUGH_TO_KEY)
         return self._fused_rewards
+
+    def fused_advance_for(self, physics):
+        """The one-launch replacement of after_substeps .. TimeStep assembly
+        (include/rp_task.h: rp_task_advance), or None when the configuration is not
+        covered (custom reward set, OT fingering, hand-position randomisation, CPU double)."""
+        if not self._use_fused_advance or self._randomize_hand_positions:
+            return None
+        rewards = self._fused_rewards_for(physics)
+        if rewards is None:
+            return None
+        if self._fused_advance is None:
+            from robopianist_amd import task_kernels
+            from robopianist_amd.suite.tasks import base as _base
+            self._fused_advance = task_kernels.FusedAdvance(
+                rewards, n_lookahead=self._n_steps_lookahead, goal_bank=self._goal_bank,
+                finger_bank=self._finger_bank, song_len=self._song_len, song_id=self._song_id,
+                wrong_press_termination=self._wrong_press_termination,
+                key_threshold=_base._KEY_THRESHOLD, sustain_threshold=_base._SUSTAIN_THRESHOLD,
+                key_qrange=self.piano._qpos_range)
+        return self._fused_advance
+
+    def fused_advance(self, physics, needs_reset):
+        """Runs rp_task_advance; returns (step_type, reward, discount, observation)."""
+        from robopianist_amd import task_kernels
+        fa = self._fused_advance
+        pn = self.piano
+        st, total, disc, terms = fa.advance(
+            needs_reset=needs_reset, key_state=pn._state, key_norm_state=pn._normalized_state,
+            key_activation=pn._activation, sustain_state=pn._sustain_state,
+            sustain_activation=pn._sustain_activation, t_idx=self._t_idx,
+            should_terminate=self._should_terminate, failure_termination=self._failure_termination,
+            discount_state=self._discount, goal_state=self._goal_state, goal_current=self._goal_current,
+            finger_next=self._finger_next, finger_current=self._finger_current,
+            fingering_state=self._fingering_state)
+        for i, name in enumerate(task_kernels.TERM_NAMES):
+            if name in self._reward_fn.reward_fns:
+                self._reward_fn.reward_terms[name] = terms[i]
+        obs = {
+            f"{self.right_hand.name}/joints_pos": physics.qpos[:, self._rh_jnt],
+            f"{self.left_hand.name}/joints_pos": physics.qpos[:, self._lh_jnt],
+            "piano/state": pn.normalized_state,
+            "piano/sustain_state": pn.sustain_state,
+            "goal": self._goal_state.reshape(self._E, -1),
+        }
+        if not self._disable_fingering_reward:
+            obs["fingering"] = self._fingering_state
+        return st, total, disc, obs
 
     def get_discount(self, physics=None):
         return self._discount

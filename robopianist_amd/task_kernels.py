@@ -13,7 +13,7 @@ import torch
 
 from robopianist_amd import engine
 
-EXPORTED_SYMBOLS = ("rp_task_rewards", "rp_task_last_error")
+EXPORTED_SYMBOLS = ("rp_task_rewards", "rp_task_advance", "rp_task_last_error")
 TERM_NAMES = ("key_press_reward", "sustain_reward", "energy_reward", "fingering_reward", "forearm_reward")
 
 
@@ -37,11 +37,30 @@ class RewardArgs(ctypes.Structure):
     ]
 
 
+class AdvanceArgs(ctypes.Structure):
+    _fields_ = [
+        ("rw", RewardArgs),
+        ("n_lookahead", ctypes.c_int), ("n_songs", ctypes.c_int), ("bank_len", ctypes.c_int),
+        ("wrong_press_termination", ctypes.c_int),
+        ("key_threshold", ctypes.c_double), ("sustain_threshold", ctypes.c_double),
+        ("warn", ctypes.c_void_p), ("key_qrange", ctypes.c_void_p),
+        ("goal_bank", ctypes.c_void_p), ("finger_bank", ctypes.c_void_p),
+        ("song_len", ctypes.c_void_p), ("song_id", ctypes.c_void_p),
+        ("key_state", ctypes.c_void_p), ("sustain_state", ctypes.c_void_p),
+        ("t_idx", ctypes.c_void_p), ("should_terminate", ctypes.c_void_p), ("failure_termination", ctypes.c_void_p),
+        ("discount_state", ctypes.c_void_p), ("goal_state", ctypes.c_void_p), ("finger_next", ctypes.c_void_p),
+        ("fingering_state", ctypes.c_void_p), ("needs_reset", ctypes.c_void_p),
+        ("discount", ctypes.c_void_p), ("step_type", ctypes.c_void_p),
+    ]
+
+
 def _lib():
     L = engine.load_library()
     if not getattr(L, "_rp_task_ready", False):
         L.rp_task_rewards.argtypes = [ctypes.POINTER(RewardArgs), ctypes.c_void_p]
         L.rp_task_rewards.restype = ctypes.c_int
+        L.rp_task_advance.argtypes = [ctypes.POINTER(AdvanceArgs), ctypes.c_void_p]
+        L.rp_task_advance.restype = ctypes.c_int
         L.rp_task_last_error.restype = ctypes.c_char_p
         L._rp_task_ready = True
     return L
@@ -102,3 +121,61 @@ class FusedRewards:
         if self._L.rp_task_rewards(ctypes.byref(a), ctypes.c_void_p(stream)) != 0:
             raise engine.EngineError(self._L.rp_task_last_error().decode())
         return self.total, self.terms
+
+
+class FusedAdvance:
+    """rp_task_advance: key state, after_step, goal/fingering observables, rewards,
+    termination, discount and step types of every env in one launch.  All state tensors
+    are the task's persistent buffers and are updated in place."""
+
+    def __init__(self, rewards: FusedRewards, *, n_lookahead, goal_bank, finger_bank, song_len, song_id,
+                 wrong_press_termination, key_threshold, sustain_threshold, key_qrange):
+        self._L = _lib()
+        self._rw = rewards
+        E, dt, dev = rewards._E, rewards._dt, rewards._phys.device
+        self._E, self._dt = E, dt
+        self._goal_bank = goal_bank.to(device=dev, dtype=dt).contiguous()
+        self._finger_bank = finger_bank.to(device=dev, dtype=torch.int64).contiguous()
+        self._song_len = song_len.to(device=dev, dtype=torch.int64).contiguous()
+        self._song_id = song_id.to(device=dev, dtype=torch.int64).contiguous()
+        self._key_qrange = key_qrange.to(device=dev, dtype=dt).contiguous()
+        self.discount = torch.zeros((E,), device=dev, dtype=dt)
+        self.step_type = torch.zeros((E,), device=dev, dtype=torch.int32)
+        p = AdvanceArgs()
+        p.n_lookahead = int(n_lookahead)
+        p.n_songs, p.bank_len = int(self._goal_bank.shape[0]), int(self._goal_bank.shape[1])
+        p.wrong_press_termination = int(bool(wrong_press_termination))
+        p.key_threshold, p.sustain_threshold = float(key_threshold), float(sustain_threshold)
+        p.warn = _chk(rewards._phys.warn, torch.int32, (E,))
+        p.key_qrange = self._key_qrange.data_ptr()
+        p.goal_bank, p.finger_bank = self._goal_bank.data_ptr(), self._finger_bank.data_ptr()
+        p.song_len, p.song_id = self._song_len.data_ptr(), self._song_id.data_ptr()
+        p.discount, p.step_type = self.discount.data_ptr(), self.step_type.data_ptr()
+        self._p = p
+        self._L_lookahead = int(n_lookahead)
+
+    def advance(self, *, needs_reset, key_state, key_norm_state, key_activation, sustain_state, sustain_activation,
+                t_idx, should_terminate, failure_termination, discount_state, goal_state, goal_current,
+                finger_next, finger_current, fingering_state):
+        E, dt, p, L = self._E, self._dt, self._p, self._L_lookahead
+        a = self._rw._args
+        a.goal_current = _chk(goal_current, dt, (E, 89))
+        a.key_norm_state = _chk(key_norm_state, dt, (E, 88))
+        a.key_activation = _chk(key_activation, torch.bool, (E, 88))
+        a.sustain_activation = _chk(sustain_activation, torch.bool, (E, 1))
+        a.finger_current = _chk(finger_current, torch.int64, (E, 88))
+        p.rw = a
+        p.key_state = _chk(key_state, dt, (E, 88))
+        p.sustain_state = _chk(sustain_state, dt, (E, 1))
+        p.t_idx = _chk(t_idx, torch.int64, (E,))
+        p.should_terminate = _chk(should_terminate, torch.bool, (E,))
+        p.failure_termination = _chk(failure_termination, torch.bool, (E,))
+        p.discount_state = _chk(discount_state, dt, (E,))
+        p.goal_state = _chk(goal_state, dt, (E, L + 1, 89))
+        p.finger_next = _chk(finger_next, torch.int64, (E, 88))
+        p.fingering_state = _chk(fingering_state, dt, (E, 10))
+        p.needs_reset = _chk(needs_reset, torch.bool, (E,))
+        stream = torch.cuda.current_stream(self._rw._phys.device).cuda_stream
+        if self._L.rp_task_advance(ctypes.byref(p), ctypes.c_void_p(stream)) != 0:
+            raise engine.EngineError(self._L.rp_task_last_error().decode())
+        return self.step_type, self._rw.total, self.discount, self._rw.terms

@@ -243,3 +243,68 @@ def test_fused_rewards_match_torch_terms():
                     np.testing.assert_allclose(_np(fused_terms[k]), _np(v), rtol=0, atol=tol, err_msg=k)
                 live = _np(ts.step_type) != 0
                 np.testing.assert_allclose(_np(fused_total)[live], _np(ref_total)[live], rtol=0, atol=5 * tol)
+
+
+def _load_pair(n_envs, precision, **task_kwargs):
+    """Two identical envs: HIP task layer (rp_task_advance) and the torch task hooks."""
+    from robopianist_amd import suite
+    from robopianist_amd.wrappers import CanonicalSpecWrapper
+    name = "RoboPianist-debug-TwinkleTwinkleRousseau-v0"
+    kw = dict(seed=11, n_envs=n_envs, precision=precision,
+              task_kwargs=dict(trim_silence=True, control_timestep=0.05, gravity_compensation=True,
+                               primitive_fingertip_collisions=True, **task_kwargs))
+    fused = CanonicalSpecWrapper(suite.load(name, **kw))
+    ref = CanonicalSpecWrapper(suite.load(name, **kw))
+    ref.task._use_fused_advance = False
+    ref.task._use_fused_rewards = False
+    return fused, ref
+
+
+@pytest.mark.parametrize("wrong_press", [False, True])
+def test_fused_task_advance_matches_torch_hooks(wrong_press):
+    """include/rp_task.h rp_task_advance against the torch restatement of the reference's
+    hooks (after_substep, after_step, observables, rewards, termination, discount, auto
+    reset), every TimeStep field and every persistent state array, across episode ends,
+    wrong-press terminations and steps past the end of the song."""
+    import os
+    actions = np.load(os.path.join(os.path.dirname(__file__), "golden", "twinkle_twinkle_actions.npy"))
+    T, E = actions.shape[0], 6
+    fused, ref = _load_pair(E, 64, n_steps_lookahead=4, wrong_press_termination=wrong_press)
+    fused.reset(); ref.reset()
+    assert fused.task.fused_advance_for(fused.physics) is not None
+    assert ref.task.fused_advance_for(ref.physics) is None
+    rng = np.random.RandomState(5)
+    dev = fused.physics.device
+    seen = dict(first=0, last=0, zero_discount=0)
+    for step in range(70):
+        if step < 20:
+            a = np.tile(actions[step], (E, 1))
+        else:  # different envs do different things: some press wrong keys, some finish
+            a = rng.uniform(-1, 1, size=(E, actions.shape[1]))
+            a[0] = actions[step % T]
+        if step == 25:
+            for env in (fused, ref):
+                env.task._t_idx[1:3] = T - 3   # these envs reach the end of the song soon
+        at = torch.as_tensor(a, device=dev, dtype=torch.float64)
+        ts_f, ts_r = fused.step(at), ref.step(at)
+        assert torch.equal(ts_f.step_type, ts_r.step_type), step
+        np.testing.assert_allclose(_np(ts_f.reward), _np(ts_r.reward), rtol=0, atol=1e-12, err_msg=str(step))
+        np.testing.assert_allclose(_np(ts_f.discount), _np(ts_r.discount), rtol=0, atol=0)
+        assert ts_f.observation.keys() == ts_r.observation.keys()
+        for k in ts_f.observation:
+            np.testing.assert_allclose(_np(ts_f.observation[k]), _np(ts_r.observation[k]), rtol=0, atol=1e-12,
+                                       err_msg=f"{k} @ {step}")
+        tf, tr = fused.task, ref.task
+        for name in ("_t_idx", "_should_terminate", "_failure_termination", "_discount", "_goal_current",
+                     "_finger_current", "_finger_next", "_fingering_state", "_goal_state"):
+            assert torch.equal(getattr(tf, name), getattr(tr, name)), f"{name} @ {step}"
+        for name in ("_activation", "_sustain_activation", "_state", "_normalized_state", "_sustain_state"):
+            assert torch.equal(getattr(tf.piano, name), getattr(tr.piano, name)), f"piano.{name} @ {step}"
+        assert torch.equal(fused._needs_reset, ref._needs_reset)
+        seen["first"] += int((ts_f.step_type == 0).sum())
+        seen["last"] += int((ts_f.step_type == 2).sum())
+        seen["zero_discount"] += int(((ts_f.discount == 0) & (ts_f.step_type == 2)).sum())
+    # the scenario did exercise the interesting branches
+    assert seen["last"] >= 2 and seen["first"] >= 2, seen
+    if wrong_press:
+        assert seen["zero_discount"] >= 1, seen
