@@ -493,57 +493,63 @@ __device__ int capsule_box(RawCon<T>* out, const T* cp, const T* cm, const T* cs
 // position/velocity stage and scratch of the solver are never live together, so they
 // share storage; only what crosses from one stage into the other is persistent.
 template <typename T>
-struct Smem {
-  union {
-    struct {  // ---- position / velocity stage
-      T xpos[RPK_NL][3];
-      T xmat[RPK_NL][9];
-      T xaxis[RPK_NL][3];
-      T xanchor[RPK_NL][3];
-      union {
-        T cdof[RPK_NL][6];  // until the mass-matrix rows are built
-        T vel[RPK_NL][6];   // velocity stage: spatial velocities / accelerations
-        float gbox[RPK_NBOXF][12];  // in between (collision): world frame + half sizes of the boxes
-      };
-      union {
-        T acc[RPK_NL][10];  // composite inertias, then subtree forces
-        struct {            // in between (collision): fp32 capsule axes for the candidate prefilter
-          float gax[RPK_WAVE][4];  // world axis, half-length (0 for boxes)
-          float grr[RPK_WAVE];     // radius (bounding radius for boxes)
-        };
-      };
-      T gpos[RPK_WAVE][3];
-      short work[RPK_WORK][2];
-      T kq[RPK_NKEYS];
-      T cpos[RPK_NC][3];
-      T cn[RPK_NC][3];
-      T cdist[RPK_NC];
-      T cpar[RPK_NC][4];  // mu, kterm (K*imp*dist), B, D
-      T cJ[RPK_NC][2][RPK_MAXD][3];  // contact Jacobian chains per (contact, side, tree level)
-      int cA[RPK_NC], cB[RPK_NC], cgA[RPK_NC], cgB[RPK_NC];
-    };
-    struct {  // ---- acceleration stage (solver)
-      T R[RPK_WAVE][RPK_MAXD + 1];  // tree factor rows (L), incl. key-leaf rows
-      T Dg[RPK_WAVE];               // tree factor diagonal
-      T xs[RPK_WAVE];               // solve staging
-      T H[(RPK_HMAX + 1) * (RPK_HMAX + 2) / 2];  // dense block of the cross-coupled rows + rhs row
-      T RM[RPK_NL][RPK_MAXD + 1];   // mass-matrix rows: RM[i][e] = M[i][anc_e(i)]
-      T entJ[RPK_NE][3];            // contact Jacobian entries (see RpStage)
-      int entM[RPK_NE][2];
-      T cC[RPK_NC][6];              // per-contact 3x3 weight of the current Newton iteration
-      T cv[RPK_NC][3];              // per-contact 3-vector staging (J x, or the contact force)
-      T jt[RPK_WAVE];               // J^T f staging, one value per solver row
-      T actf[RPK_WAVE];
-    };
-  };
-  // ---- used by both stages
+struct SmemShared {  // used by both stages
   T vec[2][RPK_WAVE];
-  T keyvec[2][RPK_NKEYS];
   unsigned long long slotmask[16];
   short slotkey[16];
   short slotlink[16];
   signed char keyslot[RPK_NKEYS];
   long long prof[RPK_NPROF];
+#ifdef RPK_OCC_TEST  // occupancy experiment: pad the LDS footprint to force one workgroup per SIMD
+  char occ_pad[RPK_OCC_TEST];
+#endif
+};
+template <typename T, int MODE> struct Smem;
+// ---- position / velocity stage (mj_step1)
+template <typename T>
+struct Smem<T, 0> : SmemShared<T> {
+  T xpos[RPK_NL][3];
+  T xmat[RPK_NL][9];
+  T xaxis[RPK_NL][3];
+  T xanchor[RPK_NL][3];
+  union {
+    T cdof[RPK_NL][6];  // until the mass-matrix rows are built
+    T vel[RPK_NL][6];   // velocity stage: spatial velocities / accelerations
+    float gbox[RPK_NBOXF][12];  // in between (collision): world frame + half sizes of the boxes
+  };
+  union {
+    T acc[RPK_NL][10];  // composite inertias, then subtree forces
+    struct {            // in between (collision .. contact Jacobians):
+      float gax[RPK_WAVE][4];  // fp32 capsule axes for the candidate prefilter: world axis, half-length
+      float grr[RPK_WAVE];     // radius (bounding radius for boxes)
+      T cpos[RPK_NC][3];       // contact points, normals, distances
+      T cn[RPK_NC][3];
+      T cdist[RPK_NC];
+      T cpar[RPK_NC][4];       // mu, kterm (K*imp*dist), B, D
+      T cv[RPK_NC][3];         // J qvel per contact (accumulated with LDS adds)
+    };
+  };
+  T gpos[RPK_WAVE][3];
+  short work[RPK_WORK][2];
+  T kq[RPK_NKEYS];
+  T keyvec[1][RPK_NKEYS];
+  int cA[RPK_NC], cB[RPK_NC], cgA[RPK_NC], cgB[RPK_NC];
+};
+// ---- acceleration stage (mj_step2: constraint solver + Euler)
+template <typename T>
+struct Smem<T, 1> : SmemShared<T> {
+  T R[RPK_WAVE][RPK_MAXD + 1];  // tree factor rows (L), incl. key-leaf rows
+  T Dg[RPK_WAVE];               // tree factor diagonal
+  T xs[RPK_WAVE];               // solve staging
+  T H[(RPK_HMAX + 1) * (RPK_HMAX + 2) / 2];  // dense block of the cross-coupled rows + rhs row
+  T RM[RPK_NL][RPK_MAXD + 1];   // mass-matrix rows: RM[i][e] = M[i][anc_e(i)]
+  T keyvec[2][RPK_NKEYS];
+  T entJ[RPK_NE][3];            // contact Jacobian entries (see RpStage)
+  int entM[RPK_NE][2];
+  T cC[RPK_NC][6];              // per-contact 3x3 weight of the current Newton iteration
+  T cv[RPK_NC][3];              // per-contact 3-vector staging (J x, or the contact force)
+  T jt[RPK_WAVE];               // J^T f staging, one value per solver row
+  T actf[RPK_WAVE];
 };
 
 // rows owned by one lane: friction-loss row of its hand dof, one limit row per dof
@@ -671,14 +677,14 @@ __global__ void rp_reset_kernel(RpState<T> S, const T* qpos0, const unsigned cha
 // stage).  mode 1: position/velocity stage only (physics.forward()).
 // ============================================================================
 template <typename T, int MODE>
-__global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep,
+__global__ __launch_bounds__(64, MODE == 0 ? 2 : 1) void rp_stage_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep,
                                                      int nsub) {
   using namespace rpk;
   using N = Num<T>;
   const int env = blockIdx.x;
   const int lane = threadIdx.x;
   const int env_active = S.active ? S.active[env] : 1;  // tested after the prologue loads are in flight
-  __shared__ Smem<T> sm;
+  __shared__ Smem<T, MODE> sm;
   int warn = 0;
   if (S.prof && env == 0 && lane < RPK_NPROF) sm.prof[lane] = 0;
   long long prof_t = (long long)__builtin_readcyclecounter();
@@ -855,6 +861,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
   T con_aref[4] = {0, 0, 0, 0}, con_D = 0, con_mu = 0, con_n[3] = {0, 0, 0}, con_t1[3] = {0, 0, 0},
     con_t2[3] = {0, 0, 0};
   int con_A = -1, con_B = -1, con_slot = -1, con_cross = 0;
+  T con_dist = 0;
   unsigned long long dirty_mask = 0;  // rows that need the dense block (uniform)
   unsigned long long con_maskA = 0, con_maskB = 0;
   int niter_last = 0;
@@ -2090,6 +2097,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
         con_A = sm.cA[lane]; con_B = sm.cB[lane];
         con_mu = sm.cpar[lane][0];
         con_D = sm.cpar[lane][3];
+        con_dist = sm.cdist[lane];  // (the LDS copy is recycled by the velocity stage)
         if (kb >= 0 && con_slot < 0) con_D = 0;  // dropped (slot overflow)
 #pragma unroll
         for (int k = 0; k < 3; k++) con_n[k] = sm.cn[lane][k];
@@ -2100,38 +2108,12 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           con_maskB = ((unsigned long long)M.link_ancmask_u()[2 * con_B + 1] << 32) | M.link_ancmask_u()[2 * con_B];
       }
     }
-    // ---- contact Jacobian columns (J_diff = J(body2) - J(body1)) [MJ: mj_jacDifPair]
-    for (int it = lane; it < ncon * 2 * RPK_MAXD; it += 64) {
-      int c = it / (2 * RPK_MAXD), rem = it - c * 2 * RPK_MAXD;
-      int side = rem / RPK_MAXD, lv = rem - side * RPK_MAXD;
-      int Lk = side ? sm.cB[c] : sm.cA[c];
-      T sg = side ? (T)1 : (T)-1;
-      T col[3] = {0, 0, 0};
-      if (Lk >= RPK_KEYBASE) {
-        if (lv == 0) {
-          int k = Lk - RPK_KEYBASE;
-          T rx = sm.cpos[c][0] - (M.key_pos()[3 * k] - M.key_half()[3 * k]);
-          T rz = sm.cpos[c][2] - M.key_pos()[3 * k + 2];
-          col[0] = rz; col[1] = 0; col[2] = -rx;  // (0,1,0) x r
-        }
-      } else if (Lk >= 0 && lv <= M.link_depth()[Lk]) {
-        int a = M.link_anc()[Lk * RPK_MAXD + lv];
-        if (M.link_jtype()[a] == JNT_SLIDE_) {
-          col[0] = sm.xaxis[a][0]; col[1] = sm.xaxis[a][1]; col[2] = sm.xaxis[a][2];
-        } else {
-          T r[3] = {sm.cpos[c][0] - sm.xanchor[a][0], sm.cpos[c][1] - sm.xanchor[a][1],
-                    sm.cpos[c][2] - sm.xanchor[a][2]};
-          cross3(col, sm.xaxis[a], r);
-        }
-      }
-      sm.cJ[c][side][lv][0] = sg * col[0]; sm.cJ[c][side][lv][1] = sg * col[1];
-      sm.cJ[c][side][lv][2] = sg * col[2];
-    }
-    WSYNC();
-
     // ======================================================================
     // ---- nested link-link contacts (one link an ancestor of the other) collapse to a
     // single chain of columns; then decide whether the Hessian is tree-structured.
+    // chains of the two bodies as they are (a dof on both chains moves both bodies: its
+    // Jacobian column is the difference, i.e. exactly zero)
+    const unsigned long long omA = con_maskA, omB = con_maskB;
     {
       int cross = 0;
       if (lane < ncon) {
@@ -2141,13 +2123,8 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           if ((con_maskA & ~con_maskB) == 0) deep = 1;       // A's chain is a prefix of B's
           else if ((con_maskB & ~con_maskA) == 0) deep = 0;
           if (deep < 0) cross = 1;
-          else {
+          else {  // the support of the contact is the deeper chain
             const int sh = 1 - deep;
-            const int dsh = M.link_depth()[sh ? con_B : con_A];
-            for (int e = 0; e <= dsh; e++) {
-#pragma unroll
-              for (int k = 0; k < 3; k++) sm.cJ[lane][deep][e][k] += sm.cJ[lane][sh][e][k];
-            }
             if (sh == 0) { con_A = -1; con_maskA = 0; sm.cA[lane] = -1; }
             else { con_B = -1; con_maskB = 0; sm.cB[lane] = -1; }
           }
@@ -2196,6 +2173,85 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
           sdepth = rec[1];
           salink = al; sTB = rec[6]; sTL = rec[7];
         }
+      }
+    }
+    WSYNC();
+    // ---- contact Jacobians [MJ: mj_jacDifPair], J qvel for the reference accelerations, and
+    // the entry list handed to the solver, in one pass over the contacts: every dof lane in
+    // the support of contact c (link lanes on either chain, the key's solver slot) computes
+    // its own column d(contact point velocity)/d(qvel), adds column * qvel to the contact's
+    // sum and writes its entry.  Entries of a contact are in lane order: ancestors first,
+    // the key slot last.
+    {
+      if (isk[0]) sm.keyvec[0][kid[0]] = qd[1];
+      if (isk[1]) sm.keyvec[0][kid[1]] = qd[2];
+      if (lane < ncon) { sm.cv[lane][0] = 0; sm.cv[lane][1] = 0; sm.cv[lane][2] = 0; }
+      unsigned long long sup = 0;
+      if (lane < ncon) {
+        sup = con_maskA | con_maskB;
+        if (con_slot >= 0) sup |= 1ull << (nl + con_slot);
+      }
+      int cnt = __popcll(sup), base = 0;
+      for (int c2 = 0; c2 < ncon; c2++) { const int b2 = bcast(cnt, c2); if (c2 < lane) base += b2; }
+      if (lane < ncon && base + cnt > RPK_NE) { cnt = 0; sup = 0; warn |= 2; con_D = 0; }  // dropped
+      const int nent = wave_max(lane < ncon ? base + cnt : 0), maxm = wave_max(cnt);
+      LI(10) = base | (cnt << 8);
+      if (lane == 0) { B.hdr[env * 8 + 4] = nent; B.hdr[env * 8 + 5] = maxm; }
+      WSYNC();
+      const int mycol = isl ? depth : sdepth + 1;
+      T ax_[3] = {0, 0, 0}, an_[3] = {0, 0, 0}, xv = 0, khx_ = 0, khz_ = 0;
+      if (isl) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { ax_[k] = sm.xaxis[lane][k]; an_[k] = sm.xanchor[lane][k]; }
+        xv = qd[0];
+      } else if (lane < nl + nkt) {
+        const int k = sm.slotkey[lane - nl];
+        xv = sm.keyvec[0][k];
+        khx_ = M.key_pos()[3 * k] - M.key_half()[3 * k];  // hinge line x, z
+        khz_ = M.key_pos()[3 * k + 2];
+      }
+      for (int c = 0; c < ncon; c++) {
+        const unsigned long long sc = ((unsigned long long)(unsigned)bcast((int)(sup >> 32), c) << 32) |
+                                      (unsigned)bcast((int)(sup & 0xffffffffu), c);
+        const unsigned long long mA = ((unsigned long long)(unsigned)bcast((int)(omA >> 32), c) << 32) |
+                                      (unsigned)bcast((int)(omA & 0xffffffffu), c);
+        const unsigned long long mB = ((unsigned long long)(unsigned)bcast((int)(omB >> 32), c) << 32) |
+                                      (unsigned)bcast((int)(omB & 0xffffffffu), c);
+        const int cA = bcast(con_A, c), cb = bcast(base, c), cc = bcast(cnt, c), cx = bcast(con_cross, c);
+        const T px = sm.cpos[c][0], py = sm.cpos[c][1], pz = sm.cpos[c][2];
+        if ((sc >> lane) & 1) {
+          T j3[3];
+          if (isl) {
+            T col[3];
+            if (jtype == JNT_SLIDE_) { col[0] = ax_[0]; col[1] = ax_[1]; col[2] = ax_[2]; }
+            else {
+              const T r[3] = {px - an_[0], py - an_[1], pz - an_[2]};
+              cross3(col, ax_, r);
+            }
+            const T sA = ((mA >> lane) & 1) ? (T)-1 : (T)0, sB = ((mB >> lane) & 1) ? (T)1 : (T)0;
+            j3[0] = sA * col[0] + sB * col[0]; j3[1] = sA * col[1] + sB * col[1]; j3[2] = sA * col[2] + sB * col[2];
+          } else {
+            const T sg = cA >= RPK_KEYBASE ? (T)-1 : (T)1;   // the key is body 1 (side A) or body 2
+            const T rx = px - khx_, rz = pz - khz_;
+            j3[0] = sg * rz; j3[1] = 0; j3[2] = sg * -rx;    // (0,1,0) x r
+          }
+          lds_add(&sm.cv[c][0], j3[0] * xv); lds_add(&sm.cv[c][1], j3[1] * xv); lds_add(&sm.cv[c][2], j3[2] * xv);
+          const int rank = __popcll(sc & lanemask_lt(lane));
+          const size_t e = (size_t)env * RPK_NE + cb + rank;
+          B.entJ[e * 3] = j3[0]; B.entJ[e * 3 + 1] = j3[1]; B.entJ[e * 3 + 2] = j3[2];
+          B.entM[e * 2] = lane | (c << 6) | (mycol << 11) | (cx << 15);
+          B.entM[e * 2 + 1] = cb | (cc << 8) | (rank << 16);
+        }
+      }
+      WSYNC();
+      if (lane < ncon) {
+        const T vc[3] = {sm.cv[lane][0], sm.cv[lane][1], sm.cv[lane][2]};
+        const T vn = dot3(con_n, vc), v1 = con_mu * dot3(con_t1, vc), v2 = con_mu * dot3(con_t2, vc);
+        const T Bc = sm.cpar[lane][2], kt = sm.cpar[lane][1];
+        con_aref[0] = -Bc * (vn + v1) - kt; con_aref[1] = -Bc * (vn - v1) - kt;
+        con_aref[2] = -Bc * (vn + v2) - kt; con_aref[3] = -Bc * (vn - v2) - kt;
+      } else {
+        con_aref[0] = con_aref[1] = con_aref[2] = con_aref[3] = 0;
       }
     }
     WSYNC();
@@ -2293,33 +2349,6 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
         }
       }
     }
-    {
-      T vc[3] = {0, 0, 0};
-      if (lane < ncon) {
-#pragma unroll
-        for (int side = 0; side < 2; side++) {
-          int Lk = side ? con_B : con_A;
-          if (Lk >= RPK_KEYBASE) {
-            T xv = sm.keyvec[0][Lk - RPK_KEYBASE];
-            const T* jc = sm.cJ[lane][side][0];
-            vc[0] += jc[0] * xv; vc[1] += jc[1] * xv; vc[2] += jc[2] * xv;
-          } else if (Lk >= 0) {
-            int dL = M.link_depth()[Lk];
-            for (int lv = 0; lv <= dL; lv++) {
-              T xv = sm.vec[1][M.link_anc()[Lk * RPK_MAXD + lv]];
-              const T* jc = sm.cJ[lane][side][lv];
-              vc[0] += jc[0] * xv; vc[1] += jc[1] * xv; vc[2] += jc[2] * xv;
-            }
-          }
-        }
-        T vn = dot3(con_n, vc), v1 = con_mu * dot3(con_t1, vc), v2 = con_mu * dot3(con_t2, vc);
-        T Bc = sm.cpar[lane][2], kt = sm.cpar[lane][1];
-        con_aref[0] = -Bc * (vn + v1) - kt; con_aref[1] = -Bc * (vn - v1) - kt;
-        con_aref[2] = -Bc * (vn + v2) - kt; con_aref[3] = -Bc * (vn - v2) - kt;
-      } else {
-        con_aref[0] = con_aref[1] = con_aref[2] = con_aref[3] = 0;
-      }
-    }
     WSYNC();
 
     PROF(16);
@@ -2354,47 +2383,6 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
 #pragma unroll
         for (int e = 0; e <= RPK_MAXD; e++) B.RM[((size_t)env * RPK_NL + lane) * (RPK_MAXD + 1) + e] = Mr[e];
       }
-      // contact Jacobian entries: one record per (contact, dof it touches), the dofs of a
-      // contact in lane order (ancestors first, the key slot last).  The two sides of a
-      // contact that share trunk dofs are summed here.
-      {
-        unsigned long long sup = 0;
-        if (lane < ncon) {
-          sup = con_maskA | con_maskB;
-          if (con_slot >= 0) sup |= 1ull << (nl + con_slot);
-        }
-        int cnt = __popcll(sup), base = 0;
-        for (int c2 = 0; c2 < ncon; c2++) { const int b2 = bcast(cnt, c2); if (c2 < lane) base += b2; }
-        if (lane < ncon && base + cnt > RPK_NE) { cnt = 0; sup = 0; warn |= 2; LF(14) = (T)0; }  // dropped
-        const int nent = wave_max(lane < ncon ? base + cnt : 0), maxm = wave_max(cnt);
-        LI(10) = base | (cnt << 8);
-        const int mycol = isl ? depth : sdepth + 1;
-        for (int c = 0; c < ncon; c++) {
-          const unsigned long long sc = ((unsigned long long)(unsigned)bcast((int)(sup >> 32), c) << 32) |
-                                        (unsigned)bcast((int)(sup & 0xffffffffu), c);
-          const unsigned long long mA = ((unsigned long long)(unsigned)bcast((int)(con_maskA >> 32), c) << 32) |
-                                        (unsigned)bcast((int)(con_maskA & 0xffffffffu), c);
-          const unsigned long long mB = ((unsigned long long)(unsigned)bcast((int)(con_maskB >> 32), c) << 32) |
-                                        (unsigned)bcast((int)(con_maskB & 0xffffffffu), c);
-          const int cA = bcast(con_A, c), cb = bcast(base, c), cc = bcast(cnt, c), cx = bcast(con_cross, c);
-          if ((sc >> lane) & 1) {
-            T j3[3] = {0, 0, 0};
-            if (isl) {
-              if ((mA >> lane) & 1) { const T* q_ = sm.cJ[c][0][depth]; j3[0] += q_[0]; j3[1] += q_[1]; j3[2] += q_[2]; }
-              if ((mB >> lane) & 1) { const T* q_ = sm.cJ[c][1][depth]; j3[0] += q_[0]; j3[1] += q_[1]; j3[2] += q_[2]; }
-            } else {
-              const T* q_ = sm.cJ[c][cA >= RPK_KEYBASE ? 0 : 1][0];
-              j3[0] = q_[0]; j3[1] = q_[1]; j3[2] = q_[2];
-            }
-            const int rank = __popcll(sc & lanemask_lt(lane));
-            const size_t e = (size_t)env * RPK_NE + cb + rank;
-            B.entJ[e * 3] = j3[0]; B.entJ[e * 3 + 1] = j3[1]; B.entJ[e * 3 + 2] = j3[2];
-            B.entM[e * 2] = lane | (c << 6) | (mycol << 11) | (cx << 15);
-            B.entM[e * 2 + 1] = cb | (cc << 8) | (rank << 16);
-          }
-        }
-        if (lane == 0) { B.hdr[env * 8 + 4] = nent; B.hdr[env * 8 + 5] = maxm; }
-      }
       if (lane < 16) {
         int* sl = B.slots + (size_t)env * 64;
         sl[lane] = sm.slotkey[lane]; sl[16 + lane] = sm.slotlink[lane];
@@ -2421,7 +2409,7 @@ __global__ __launch_bounds__(64) void rp_stage_kernel(RpModel<T> M, RpState<T> S
     bool v = lane < ncon;
     S.contact_geoms[((size_t)env * RPK_NCOUT + lane) * 2] = v ? sm.cgA[lane] : -1;
     S.contact_geoms[((size_t)env * RPK_NCOUT + lane) * 2 + 1] = v ? sm.cgB[lane] : -1;
-    S.contact_dist[(size_t)env * RPK_NCOUT + lane] = v ? sm.cdist[lane] : (T)0;
+    S.contact_dist[(size_t)env * RPK_NCOUT + lane] = v ? con_dist : (T)0;
   }
   }
   {
