@@ -110,6 +110,7 @@ struct Engine : EngineBase {
   T* d_qpos0 = nullptr;
   uint32_t* d_trace = nullptr; size_t trace_cap = 0;
   uint8_t* d_mask = nullptr;
+  bool trunk4 = false;  // every tree has a 4-link trunk: launch the specialised solver build
 
   ~Engine() override {
     hipSetDevice(device);
@@ -188,8 +189,11 @@ struct Engine : EngineBase {
     PI(chain_len, "eng_chain_len"); PI(link_ancmask, "eng_link_ancmask");
     {
       auto tt = b.i("eng_tree_trunk");
-      for (int t = 0; t < M.ntree && t < (int)tt.size(); t++)
+      trunk4 = M.ntree > 0;
+      for (int t = 0; t < M.ntree && t < (int)tt.size(); t++) {
         if (tt[t] > 4 || tt[t] < 1) throw std::string("the solver needs a trunk chain of 1..4 links per articulated tree");
+        if (tt[t] != 4) trunk4 = false;
+      }
     }
     for (int v : b.i("eng_chain_len")) if (v > 5) throw std::string("finger chain longer than 5 links is not supported by the solver");
     PF(link_lpos, "eng_link_lpos");
@@ -404,7 +408,9 @@ struct Engine : EngineBase {
       for (int k = 0; k < nsub; k++) {
         const bool probe = timeit && k == nsub / 2;
         if (probe) HIP_OK(hipEventRecord(sv0[slot], stream));
-        hipLaunchKernelGGL((rp_stage_kernel<T, 1>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
+        // solver stage; the build specialised for "every tree has a 4-link trunk" when it applies
+        if (trunk4) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 4>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
+        else hipLaunchKernelGGL((rp_stage_kernel<T, 1>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
         if (probe) HIP_OK(hipEventRecord(sv1[slot], stream));
         hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
       }
