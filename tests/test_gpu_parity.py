@@ -168,3 +168,23 @@ def test_replay_fp32_curve_is_reported(two_hand_scene):
     print("fp32 replay rel err @[1,10,100,300,1000]:", rel[[0, 9, 99, 299, 999]])
     assert rel[:10].max() < 1e-4
     assert np.isfinite(rel).all()
+
+
+def test_teacher_forced_fp64_other_topologies():
+    """Scenes whose trees differ from the benchmark's (two hands, 4-link trunks): one hand
+    only, and hands without forearm dofs (2-link trunks -> the generic, not the
+    trunk-specialised, solver build).  Same 1e-9 teacher-forced bar."""
+    import warnings
+    from robopianist_amd.model import scene
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        scenes = {
+            "right hand only": scene.build_scene(hands=("right",), gravity_compensation=True,
+                                                 primitive_fingertip_collisions=True),
+            "no forearm dofs": scene.build_scene(forearm_dofs=(), gravity_compensation=True,
+                                                 primitive_fingertip_collisions=True),
+        }
+    for name, si in scenes.items():
+        worst, maxcon = teacher_forced(si, 64, ctrl_sequence(si.model, 200, 3))
+        print(f"{name}: worst rel dv {worst:.2e}, max contacts {maxcon}, nv {si.model.nv}")
+        assert worst < 1e-9, name
