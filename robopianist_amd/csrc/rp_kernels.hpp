@@ -1588,8 +1588,19 @@ __global__ __launch_bounds__(64, MODE == 0 ? 2 : 1) void rp_stage_kernel(RpModel
             return cst + alpha * alpha * g2 + alpha * g1 + g0;
           };
           T gtol = M.tolerance * M.ls_tolerance * snorm / scale;
-          T f0, h0, f, hh;
-          T c0 = ls_eval((T)0, f0, h0, true);
+          // phi at alpha = 0 needs no row evaluation: phi(0) is the current cost,
+          // phi'(0) = grad . search, and phi''(0) = search^T H search = -phi'(0) because the
+          // search direction solves H search = -grad.  The first trial point is the full
+          // Newton step alpha = 1.
+          // (fp64 only: in fp32 the cost carried over from the last update and the cost
+          // formula of ls_eval differ by more than the improvements being compared.)
+          T f, hh, f0, h0, c0;
+          if constexpr (sizeof(T) == 8) {
+            f0 = wave_sum(grad[0] * search[0] + grad[1] * search[1] + grad[2] * search[2]);
+            h0 = -f0; c0 = cost;
+          } else {
+            c0 = ls_eval((T)0, f0, h0, true);
+          }
           T alpha = 0;
           if (f0 < 0 && h0 > 0) {
             T lo_ = 0, hi_ = (T)-1;  // hi_<0: unbounded
