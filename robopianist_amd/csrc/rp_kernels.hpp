@@ -20,11 +20,11 @@
 #include <stdint.h>
 
 #define RPK_WAVE 64
-#define RPK_NC 24        // max contacts kept per env (outputs are RP_MAX_CONTACTS wide)
+#define RPK_NC 32        // max contacts kept per env (= RP_MAX_CONTACTS; contact c lives in lane c)
 #define RPK_NCOUT 32     // == RP_MAX_CONTACTS
-#define RPK_NE 192      // max contact Jacobian entries (contact, dof) handed to the solver
+#define RPK_NE 256      // max contact Jacobian entries (contact, dof) handed to the solver
 #define RPK_NBOXF 26     // boxes covered by the oriented-box prefilter (fits the cdof scratch in fp32)
-#define RPK_HMAX 46      // max rows of the dense cross-coupling block (+1 row for its rhs)
+#define RPK_HMAX 60      // max rows of the dense cross-coupling block (+1 row for its rhs = one lane each)
 #define RPK_WORK 128     // narrow-phase work list
 #define RPK_MAXD 9       // tree depth levels
 #define RPK_NL 52        // max links
@@ -140,7 +140,7 @@ struct RpState {
   do {                                                                  \
     if (S.prof && env == 0) {                                           \
       long long t_ = (long long)__builtin_readcyclecounter();           \
-      if (lane == 0) sm.prof[i] += t_ - prof_t;                         \
+      if (lane == 0) sm.prof[i] += (unsigned)(t_ - prof_t);                       \
       prof_t = t_;                                                      \
     }                                                                   \
   } while (0)
@@ -494,12 +494,15 @@ __device__ int capsule_box(RawCon<T>* out, const T* cp, const T* cm, const T* cs
 // share storage; only what crosses from one stage into the other is persistent.
 template <typename T>
 struct SmemShared {  // used by both stages
-  T vec[2][RPK_WAVE];
+  union {
+    T vec[2][RPK_WAVE];
+    short work[RPK_WORK][2];  // position stage, collision only: candidate pairs
+  };
   unsigned long long slotmask[16];
   short slotkey[16];
   short slotlink[16];
   signed char keyslot[RPK_NKEYS];
-  long long prof[RPK_NPROF];
+  unsigned prof[RPK_NPROF];   // per-launch phase cycle counts of env 0 (debug aid)
 #ifdef RPK_OCC_TEST  // occupancy experiment: pad the LDS footprint to force one workgroup per SIMD
   char occ_pad[RPK_OCC_TEST];
 #endif
@@ -530,7 +533,6 @@ struct Smem<T, 0> : SmemShared<T> {
     };
   };
   T gpos[RPK_WAVE][3];
-  short work[RPK_WORK][2];
   T kq[RPK_NKEYS];
   T keyvec[1][RPK_NKEYS];
   int cA[RPK_NC], cB[RPK_NC], cgA[RPK_NC], cgB[RPK_NC];
