@@ -152,7 +152,11 @@ def main():
                     rec = rpd.pack_trajectory_record(
                         base_env.physics.qpos, ts.reward, ts.discount, ts.step_type,
                         base_env.task.piano.activation)
-                    rpd.gather_trajectories(rec)
+                    # enqueue only: the all-gather of step t overlaps the physics of step t+1
+                    if state.get("gather") is not None:
+                        state["gather"][1].wait()
+                    state["gather"] = rpd.gather_trajectories(rec, async_op=True, out=state.get("gather_buf"))
+                    state["gather_buf"] = state["gather"][0]
             state["t"] = t + 1
             if ts_last:  # episode boundary: reset (not counted as a step, but timed)
                 if args.engine_only:
@@ -162,6 +166,8 @@ def main():
                 state["t"] = 0
 
         def barrier():
+            if state.get("gather") is not None and state["gather"][1] is not None:
+                state["gather"][1].wait()
             phys.sync()
             torch.cuda.synchronize()
             if dist is not None:

@@ -51,14 +51,13 @@ def rank_seed(seed: int, rank: int) -> int:
 def pack_trajectory_record(qpos, reward, discount, step_type, key_activation):
     """Compact per-env record (§8e): qpos | reward | discount | step_type | activation
     bits packed in three 32-bit words, as one float32 row per env."""
-    E = qpos.shape[0]
-    act = key_activation.to(torch.int64)
-    weights = (1 << torch.arange(32, device=act.device, dtype=torch.int64))
-    words = []
-    for w in range(3):
-        chunk = act[:, 32 * w: 32 * (w + 1)]
-        words.append((chunk * weights[: chunk.shape[1]]).sum(1))
-    bits = torch.stack(words, dim=1).to(torch.int32).view(torch.float32)
+    E, nk = qpos.shape[0], key_activation.shape[1]
+    # bits -> 12 bytes per env (little-endian inside each 32-bit word), a handful of launches
+    byte_w = (1 << torch.arange(8, device=key_activation.device, dtype=torch.int32))
+    padded = torch.zeros((E, 96), dtype=torch.int32, device=key_activation.device)
+    padded[:, :nk] = key_activation
+    by = (padded.view(E, 12, 8) * byte_w).sum(2).to(torch.uint8)          # [E, 12]
+    bits = by.contiguous().view(torch.float32)                              # [E, 3]
     return torch.cat([qpos.float(), reward.float().reshape(E, 1), discount.float().reshape(E, 1),
                       step_type.float().reshape(E, 1), bits], dim=1).contiguous()
 
@@ -70,13 +69,16 @@ def unpack_key_activation(record: torch.Tensor, nv: int, n_keys: int = 88) -> to
     return bits[:, :n_keys].bool()
 
 
-def gather_trajectories(local: torch.Tensor) -> torch.Tensor:
+def gather_trajectories(local: torch.Tensor, async_op: bool = False, out: torch.Tensor | None = None):
     """All-gathers equally sized per-rank slabs [E_local, ...] into [world*E_local, ...]
-    ordered by rank (== global env order under `shard_envs`)."""
+    ordered by rank (== global env order under `shard_envs`).  With `async_op` the
+    collective is only enqueued (it overlaps the next env step) and `(out, work)` is
+    returned; call `work.wait()` before reading `out`."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return local
+        return (local, None) if async_op else local
     world = dist.get_world_size()
-    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
-                      device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous())
-    return out
+    if out is None:
+        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
+                          device=local.device)
+    work = dist.all_gather_into_tensor(out, local.contiguous(), async_op=async_op)
+    return (out, work) if async_op else out

@@ -55,6 +55,10 @@ def _worker(rank, world, port, total_envs, out_q):
     local[:, 0] = torch.arange(start, stop)
     local[:, 1] = torch.rand(stop - start, generator=g)
     full = rpd.gather_trajectories(local)
+    # the enqueue-only form used by bench.py (overlaps the next step)
+    full2, work = rpd.gather_trajectories(local, async_op=True)
+    work.wait()
+    assert torch.equal(full, full2)
     dist.barrier()
     out_q.put((r, full[:, 0].tolist(), float(full[:, 1].sum())))
     dist.destroy_process_group()
