@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", type=int, default=1, help="all-gather trajectory slab when gpus>1")
     ap.add_argument("--engine-only", action="store_true", help="time rp_step alone (no obs/reward epilogue)")
+    ap.add_argument("--dist-backend", default="nccl", help="debug: 'gloo' lets several ranks share one GPU")
+    ap.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0")
     ap.add_argument("--graph", type=int, default=0,
                     help="replay env.step from a captured hipGraph (wrappers.GraphedStepWrapper)")
     args = ap.parse_args()
@@ -103,8 +105,13 @@ def main():
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.same_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
     dev = local_rank if torch.cuda.is_available() else 0
 
     def measure(precision, steps, warmup):
@@ -263,7 +270,7 @@ def main():
                 "warn_flags": r32["warn"],
                 "note": "same workload on the fp32 build; meets 1e-4 on smooth key-press scenarios only"}}
             phys = r32["phys"]
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             from oracle.rp_oracle import Oracle
             orc = Oracle(m, phys.blob)
             cores = _usable_cores()
