@@ -254,8 +254,8 @@ def main():
                 "note": "one rp_step = 1 + 2*substeps launches (rp_stage_kernel<T,0> position/velocity stage, "
                         "<T,1> solver stage); kernel_avg_ms is the solver launch of the middle substep of every step "
                         "(HIP events on the engine stream), step_sequence_avg_ms the whole 21-launch sequence. "
-                        "The path is instruction-issue / latency bound (one wave per env, one wave per SIMD), "
-                        "not HBM bound: see DESIGN.md 6",
+                        "The path is instruction-issue / latency bound (one wave per env; the fp64 solver runs one "
+                        "wave per SIMD, the position kernel two), not HBM bound: see DESIGN.md 6",
             },
             "sanity": {"warn_flags": warn, "finite": finite},
             "parity": "fp64 engine: max rel |dq| vs CPU oracle over 1000 mj_steps of this replay = 9e-5 (<1e-4), "
