@@ -108,7 +108,7 @@ class BatchedPhysics:
     """`n_envs` copies of one compiled scene stepped on one MI355X."""
 
     def __init__(self, model: mcompile.Model, key_joint_ids: np.ndarray, n_envs: int,
-                 device_id: int = 0, precision: int = 32, blob: Optional[bytes] = None):
+                 device_id: int = 0, precision: int = 64, blob: Optional[bytes] = None):
         self._L = load_library()
         self.model = model
         self.n_envs = int(n_envs)

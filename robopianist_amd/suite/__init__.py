@@ -1,7 +1,8 @@
 """RoboPianist suite, vectorised (mirror of robopianist/suite/__init__.py:27-93).
 
 `load()` keeps the reference's signature and adds `n_envs`, `device_id`,
-`precision`.  It returns a batched dm_env-style Environment whose physics is the
+`precision` (64 by default: the reference computes in float64, and only the fp64
+engine tracks the CPU path on chaotic trajectories; 32 selects the faster fp32 build).  It returns a batched dm_env-style Environment whose physics is the
 HIP engine."""
 
 from pathlib import Path
@@ -36,7 +37,7 @@ def load(
     task_kwargs: Optional[Mapping[str, Any]] = None,
     n_envs: int = 1,
     device_id: int = 0,
-    precision: int = 32,
+    precision: int = 64,
 ) -> environment.Environment:
     """Loads a (batched) RoboPianist environment; raises ValueError for unknown names."""
     del recompile_physics  # the model is compiled once and uploaded to the GPU

@@ -25,7 +25,7 @@ from robopianist_amd.suite.specs import StepType, TimeStep
 
 class Environment:
     def __init__(self, task, n_envs: int = 1, random_state=None, device_id: int = 0,
-                 precision: int = 32, physics=None, record_key_trace: bool = False,
+                 precision: int = 64, physics=None, record_key_trace: bool = False,
                  copy_outputs: bool = True):
         self._task = task
         self._n_envs = int(n_envs)

@@ -15,7 +15,7 @@ from robopianist_amd import engine as eng
 
 
 class TorchPhysics:
-    def __init__(self, scene_info, n_envs: int, device_id: int = 0, precision: int = 32):
+    def __init__(self, scene_info, n_envs: int, device_id: int = 0, precision: int = 64):
         if not torch.cuda.is_available():
             raise eng.EngineError(
                 "No HIP device visible: the batched engine has no CPU fallback.")
