@@ -308,3 +308,32 @@ def test_fused_task_advance_matches_torch_hooks(wrong_press):
     assert seen["last"] >= 2 and seen["first"] >= 2, seen
     if wrong_press:
         assert seen["zero_discount"] >= 1, seen
+
+
+def test_rollouts_are_bitwise_reproducible_and_batch_invariant():
+    """Identical envs stay bitwise identical (the LDS-add reductions of the solver have a
+    fixed order), a re-run reproduces the same bits, and an env's trajectory does not depend
+    on how many other envs share the launch."""
+    import os
+    from robopianist_amd import suite
+    from robopianist_amd.wrappers import CanonicalSpecWrapper
+    actions = np.load(os.path.join(os.path.dirname(__file__), "golden", "twinkle_twinkle_actions.npy"))
+
+    def run(n_envs, precision):
+        env = CanonicalSpecWrapper(suite.load(
+            "RoboPianist-debug-TwinkleTwinkleRousseau-v0", seed=1, n_envs=n_envs, precision=precision,
+            task_kwargs=dict(trim_silence=True, control_timestep=0.05, gravity_compensation=True,
+                             primitive_fingertip_collisions=True)))
+        env.reset()
+        a = torch.as_tensor(actions, device=env.physics.device, dtype=env.physics.dtype)
+        for t in range(60):
+            env.step(a[t].expand(n_envs, -1))
+        return env.physics.qpos.clone(), env.physics.qvel.clone()
+
+    for precision in (64, 32):
+        q1, v1 = run(96, precision)
+        q2, v2 = run(96, precision)
+        q3, v3 = run(3, precision)
+        assert torch.equal(q1, q1[0:1].expand_as(q1)) and torch.equal(v1, v1[0:1].expand_as(v1))
+        assert torch.equal(q1, q2) and torch.equal(v1, v2)
+        assert torch.equal(q1[:3], q3) and torch.equal(v1[:3], v3)
