@@ -577,17 +577,66 @@ template <> __device__ __forceinline__ float rsqrt_nr<float>(float x) {
 
 // Dense solve of the packed lower-triangular SPD system H (n rows, n uniform) with the
 // right-hand side stored as row n of H; returns x_i in lane i < n.
-//   * left-looking L L^T, lane = row, two columns per step (one LDS hand-over per pair);
+//   * left-looking L L^T, lane = row, four columns per step (one LDS hand-over per four
+//     pivots; a pair and a single column finish the remainder);
 //   * inner products read the lane's own row and rows j, j+1 (uniform address =
 //     LDS broadcast) with paired 64-bit reads, no v_readlane in the loop;
 //   * the rhs row takes part in the factorisation like any other row, which performs
 //     the forward substitution for free; only the backward pass is a serial chain.
-// Measured on gfx950, one wave per SIMD, n = 19, fp64: 14 k cycles (the one-column
-// sqrt/divide/readlane version took 32 k).
+// Measured on gfx950, one wave per SIMD, n = 20, fp64: 12 k cycles (the first version,
+// one column per step with sqrt/divide/readlane, took 34 k).
 template <typename T>
 __device__ T dense_factor_solve(T* H, int n, int lane, int* warn) {
   T invd_me = 0;
   int j = 0;
+  // four columns per step while they last (one LDS hand-over per four pivots) ...
+  // (fp32 only: the fp64 solver kernel is at its register limit and the four-column step
+  // pushes it into scratch spills, measured -7 %)
+  for (; sizeof(T) == 4 && j + 4 <= n; j += 4) {
+    const bool act = lane >= j && lane <= n;
+    const T* ri = H + tri(act ? lane : 0, 0);
+    const T* r0 = H + tri(j, 0);
+    const T* r1 = H + tri(j + 1, 0);
+    const T* r2 = H + tri(j + 2, 0);
+    const T* r3 = H + tri(j + 3, 0);
+    T s0 = ri[j], s1 = ri[j + 1], s2 = ri[j + 2], s3 = ri[j + 3];
+    for (int p = 0; p < j; p += 2) {  // j is a multiple of 4 here; two p per trip keeps the
+#pragma unroll                       // live set small (the fp64 solver is at its register limit)
+      for (int u = 0; u < 2; u++) {
+        const T a = ri[p + u];
+        s0 -= a * r0[p + u]; s1 -= a * r1[p + u]; s2 -= a * r2[p + u]; s3 -= a * r3[p + u];
+      }
+    }
+    T d0 = bcast(s0, j);
+    if (!(d0 >= RPK_MINVAL)) { d0 = RPK_MINVAL; *warn |= 4; }
+    const T q0 = rsqrt_nr(d0);
+    const T l0 = s0 * q0;
+    s1 -= l0 * bcast(l0, j + 1);
+    T d1 = bcast(s1, j + 1);
+    if (!(d1 >= RPK_MINVAL)) { d1 = RPK_MINVAL; *warn |= 4; }
+    const T q1 = rsqrt_nr(d1);
+    const T l1 = s1 * q1;
+    s2 -= l0 * bcast(l0, j + 2); s2 -= l1 * bcast(l1, j + 2);
+    T d2 = bcast(s2, j + 2);
+    if (!(d2 >= RPK_MINVAL)) { d2 = RPK_MINVAL; *warn |= 4; }
+    const T q2 = rsqrt_nr(d2);
+    const T l2 = s2 * q2;
+    s3 -= l0 * bcast(l0, j + 3); s3 -= l1 * bcast(l1, j + 3); s3 -= l2 * bcast(l2, j + 3);
+    T d3 = bcast(s3, j + 3);
+    if (!(d3 >= RPK_MINVAL)) { d3 = RPK_MINVAL; *warn |= 4; }
+    const T q3 = rsqrt_nr(d3);
+    const T l3 = s3 * q3;
+    if (lane == j) invd_me = q0;
+    if (lane == j + 1) invd_me = q1;
+    if (lane == j + 2) invd_me = q2;
+    if (lane == j + 3) invd_me = q3;
+    if (act) H[tri(lane, j)] = l0;
+    if (act && lane > j) H[tri(lane, j + 1)] = l1;
+    if (act && lane > j + 1) H[tri(lane, j + 2)] = l2;
+    if (act && lane > j + 2) H[tri(lane, j + 3)] = l3;
+    WSYNC();
+  }
+  // ... then a pair, then a single column
   for (; j + 2 <= n; j += 2) {
     const int j1 = j + 1;
     const bool act = lane >= j && lane <= n;

@@ -9,8 +9,8 @@ using namespace rpk;
 
 template <typename T, int V>
 __global__ __launch_bounds__(64) void kb(const T* A, const T* b, T* xout, long long* cyc, int n, int reps) {
-  __shared__ T H[RPK_HMAX * (RPK_HMAX + 1) / 2 + 8];
-  __shared__ T pad[3000];  // mimic the LDS footprint (occupancy 4 WG/CU for fp64)
+  __shared__ T H[(RPK_HMAX + 1) * (RPK_HMAX + 2) / 2 + 8];
+  __shared__ T pad[2500];  // mimic the LDS footprint (occupancy 4 WG/CU for fp64)
   const int lane = threadIdx.x;
   int warn = 0;
   pad[lane] = 0;
@@ -21,7 +21,7 @@ __global__ __launch_bounds__(64) void kb(const T* A, const T* b, T* xout, long l
     x = lane < n ? b[lane] : (T)0;
     WSYNC();
     long long t0 = (long long)__builtin_readcyclecounter();
-    if (V == 0) { chol_packed(H, n, lane, &warn); x = solve_packed(H, n, lane, x); }
+    if (V == 0) { if (lane < n) H[tri(n, 0) + lane] = x; WSYNC(); x = dense_factor_solve(H, n, lane, &warn); }
     else x = chol_solve_variant<T, V>(H, n, lane, x, &warn);
     WSYNC();
     long long t1 = (long long)__builtin_readcyclecounter();
@@ -66,11 +66,10 @@ void run(int n, const char* name) {
 }
 
 int main() {
-  for (int n : {9, 13, 19, 26, 34}) {
-    run<double, 0>(n, "f64 current");
-    run<double, 4>(n, "f64 v4");
-    run<double, 6>(n, "f64 v4 factor only");
-    run<double, 7>(n, "f64 v4 factor only, no rsqrt");
+  for (int n : {9, 13, 16, 20, 24, 28, 34}) {
+    run<double, 0>(n, "f64 production (factor+solve)");
+    run<double, 6>(n, "f64 2-col factor only");
+    run<double, 8>(n, "f64 v8 4-col factor only");
   }
   return 0;
 }
