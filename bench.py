@@ -211,11 +211,12 @@ def main():
 
 
         return dict(dt=dt, kms=kms, nl=nl, sms=sms, snl=snl, warn=warn, finite=finite, phys=phys, m=m,
-                    ctrl_seq=ctrl_seq, E=E, graphed=bool(use_graph and env.graph_captured))
+                    ctrl_seq=ctrl_seq, E=E, key_ids=base_env.task.scene.key_joint_ids, graphed=bool(use_graph and env.graph_captured))
 
     r = measure(args.precision, args.steps, args.warmup)
     dt, kms, nl, sms, snl, warn, finite, phys, m, ctrl_seq, E = (
         r[k] for k in ('dt', 'kms', 'nl', 'sms', 'snl', 'warn', 'finite', 'phys', 'm', 'ctrl_seq', 'E'))
+    base_key_ids = r['key_ids']
 
     if rank == 0:
         value = world * E * args.steps / dt
@@ -282,6 +283,22 @@ def main():
             rows = (40 + 7 * np.arange(nenv_cpu)) % ctrl_seq.shape[0]
             cc = np.ascontiguousarray(ctrl_seq[rows])
             secs, _ = orc.bench(nenv_cpu, nstep, cc, cores)
+            # same leg: the second half of BASELINE.json's metric, measured here -- the engine
+            # (precision of the headline run) against the CPU oracle on this very replay,
+            # free running, 1000 mj_steps, rel = |dq| / max(|q|, 1e-2)
+            from robopianist_amd import engine as _eng
+            chk = _eng.BatchedPhysics(m, base_key_ids, n_envs=2, precision=args.precision)
+            orc.reset()
+            worst = 0.0
+            for i in range(1000):
+                c = ctrl_seq[(i // args.substeps) % ctrl_seq.shape[0]]
+                chk.set(_eng.CTRL, c[None, :]); orc.ctrl[:] = c
+                chk.step(1); orc.step(1)
+                qg = chk.qpos.astype(np.float64)[0]
+                worst = max(worst, float((np.abs(qg - orc.qpos) / np.maximum(np.abs(orc.qpos), 1e-2)).max()))
+            out["cpu_baseline_parity"] = {
+                "max_rel_qpos_error_1000_mj_steps": worst, "bar": 1e-4,
+                "note": "engine (2 envs, same precision as value) vs the CPU oracle, scripted replay, free running"}
             out["cpu_baseline"] = {
                 "value": nenv_cpu * nstep / args.substeps / secs, "unit": "env-steps/s",
                 "cores": cores, "kind": "port",
