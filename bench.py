@@ -259,7 +259,8 @@ def main():
                         "wave per SIMD, the position kernel two), not HBM bound: see DESIGN.md 6",
             },
             "sanity": {"warn_flags": warn, "finite": finite},
-            "parity": "fp64 engine: max rel |dq| vs CPU oracle over 1000 mj_steps of this replay = 9e-5 (<1e-4), "
+            "parity": "fp64 engine: max rel |dq| vs CPU oracle over 1000 mj_steps of this replay < 1e-4 "
+                      "(measured live under cpu_baseline_parity when the CPU leg runs), "
                       "tests/test_gpu_parity.py::test_replay_fp64_1000_steps; fp32 engine diverges on this "
                       "(chaotic, self-colliding) replay and is reported under aux only",
         }
