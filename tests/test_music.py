@@ -133,3 +133,42 @@ def test_goal_tables_match_notes():
         assert sorted(np.flatnonzero(goal[i, :88])) == sorted(n.key for n in notes)
         for n in notes:
             assert finger[i, n.key] == n.fingering
+
+
+def test_midi_module_edge_detection_matches_reference_semantics():
+    """models/piano/midi_module.py:47-98 on an activation trace: note-ons at rising edges
+    (velocity 127), note-offs at falling edges, sustain edges, messages grouped per substep
+    in the reference's order."""
+    import numpy as np
+    from robopianist_amd.music import midi_module as mm
+    from robopianist_amd.music import midi_file
+    mod = mm.MidiModule()
+    act = np.zeros(88, bool)
+    mod.after_substep(0.002, act, False)
+    assert mod.get_latest_midi_messages() == []
+    act2 = act.copy(); act2[[3, 40]] = True
+    mod.after_substep(0.004, act2, True)
+    msgs = mod.get_latest_midi_messages()
+    assert [type(m).__name__ for m in msgs] == ["NoteOn", "NoteOn", "SustainOn"]
+    assert msgs[0].note == midi_file.key_number_to_midi_number(3) and msgs[0].velocity == 127
+    assert msgs[1].note == midi_file.key_number_to_midi_number(40) and msgs[1].time == 0.004
+    act3 = act2.copy(); act3[3] = False; act3[7] = True
+    mod.after_substep(0.006, act3, False)
+    msgs = mod.get_latest_midi_messages()
+    assert [type(m).__name__ for m in msgs] == ["NoteOn", "NoteOff", "SustainOff"]
+    assert msgs[0].note == midi_file.key_number_to_midi_number(7)
+    assert msgs[1].note == midi_file.key_number_to_midi_number(3)
+    assert len(mod.get_all_midi_messages()) == 6
+    # the packed device trace decodes to the same events
+    from robopianist_amd import engine
+    trace = np.zeros((2, 1, 3, 4), np.uint32)      # [steps, envs, substeps, words]
+    trace[0, 0, 1, 0] = 1 << 3                      # key 3 pressed from substep 1 of step 0
+    trace[0, 0, 2, 0] = 1 << 3
+    trace[1, 0, 0, 0] = 1 << 3
+    trace[1, 0, 1, 2] = 1 << 0                      # key 64 on, key 3 off
+    trace[1, 0, 2, 2] = 1 << 0
+    ev = mm.events_from_trace(trace, sustain=[False, True], times=[0.006, 0.012], physics_timestep=0.002)
+    kinds = [(type(m).__name__, round(m.time, 6)) for m in ev]
+    assert kinds == [("NoteOn", 0.004), ("SustainOn", 0.008), ("NoteOn", 0.01), ("NoteOff", 0.01)]
+    assert ev[0].note == midi_file.key_number_to_midi_number(3)
+    assert ev[2].note == midi_file.key_number_to_midi_number(64)
