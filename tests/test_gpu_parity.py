@@ -188,3 +188,46 @@ def test_teacher_forced_fp64_other_topologies():
         worst, maxcon = teacher_forced(si, 64, ctrl_sequence(si.model, 200, 3))
         print(f"{name}: worst rel dv {worst:.2e}, max contacts {maxcon}, nv {si.model.nv}")
         assert worst < 1e-9, name
+
+
+def test_teacher_forced_fp64_many_contacts(two_hand_scene):
+    """Teacher-forced along the oracle's trajectory of the scripted replay (flailing,
+    self-colliding hands): up to 14 simultaneous contacts incl. hand-hand, i.e. large
+    cross-coupled blocks; every single mj_step must agree to 1e-9."""
+    si = two_hand_scene
+    worst, maxcon = teacher_forced(si, 64, _replay_ctrl(si)[:1200])
+    print(f"fp64 teacher-forced on the replay: worst rel dv {worst:.2e}, max contacts {maxcon}")
+    assert maxcon >= 12
+    assert worst < 1e-9
+
+
+def test_key_trace_matches_oracle_activation(two_hand_scene):
+    """rp_step(key_trace): the per-substep activation bit masks (Piano._update_key_state,
+    piano.py:178-192, evaluated after every substep) against the oracle's key positions."""
+    from robopianist_amd import engine
+    si = two_hand_scene
+    phys, orc = make_pair(si, 64, nenv=2)
+    m = si.model
+    kj = np.asarray(si.key_joint_ids)
+    hi = m.jnt_range[kj, 1]
+    ctrl = key_press_sequence(si, 600)
+    trace = np.zeros((2, 10, 4), np.uint32)
+    pressed_any = 0
+    for t in range(0, 600, 10):
+        # torques on a few keys, switched on and off (piano_with_shadow_hands_test.py:235 style)
+        f = np.zeros(m.nv)
+        if (t // 100) % 2 == 0:
+            f[kj[[5, 40, 41, 70]]] = 3.0
+        phys.set(engine.QFRC_APPLIED, f[None, :])
+        orc.qfrc_applied[:] = f
+        phys.set(engine.CTRL, ctrl[t][None, :])
+        orc.ctrl[:] = ctrl[t]
+        phys.step(10, trace)
+        bits = engine.decode_key_trace(trace)
+        for s in range(10):
+            orc.step(1)
+            q = np.clip(orc.qpos[kj], m.jnt_range[kj, 0], hi)
+            expect = np.abs(q - hi) <= 0.00872665
+            assert (bits[0, s] == expect).all() and (bits[1, s] == expect).all(), (t, s)
+            pressed_any += int(expect.sum())
+    assert pressed_any > 0, "the scripted presses are meant to activate keys"
