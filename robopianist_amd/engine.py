@@ -108,7 +108,8 @@ class BatchedPhysics:
     """`n_envs` copies of one compiled scene stepped on one MI355X."""
 
     def __init__(self, model: mcompile.Model, key_joint_ids: np.ndarray, n_envs: int,
-                 device_id: int = 0, precision: int = 64, blob: Optional[bytes] = None):
+                 device_id: int = 0, precision: int = 64, blob: Optional[bytes] = None,
+                 self_check: Optional[bool] = None):
         self._L = load_library()
         self.model = model
         self.n_envs = int(n_envs)
@@ -131,6 +132,10 @@ class BatchedPhysics:
             TREE_OFFSET: (self.ntree, 3), ACTIVE: (),
         }
         self._int_fields = {NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER, ACTIVE}
+        if self_check is None:
+            self_check = os.environ.get("RP_SKIP_SELF_CHECK", "0") != "1"
+        if self_check:
+            _build_self_check(model, key_joint_ids, self.blob, self.device_id)
 
     def __del__(self):
         try:
@@ -257,6 +262,42 @@ class BatchedPhysics:
     def time(self): return self.get(TIME)
     @property
     def warn_flags(self): return self.get(WARN_FLAGS)
+
+
+_self_checked = set()
+
+
+def _build_self_check(model, key_joint_ids, blob, device_id):
+    """Loud failure instead of silently wrong physics if librp_engine.so was miscompiled.
+
+    The fp64 solver kernel needs ~500 registers per lane; at that pressure hipcc has been
+    seen (round 1, ROCm 7.2) to emit a wrong kernel after a harmless source edit (correct
+    again with `-mllvm -amdgpu-spill-sgpr-to-vgpr=false`, at 2.6x the run time).  The fp32
+    and fp64 builds are separate instantiations, so a few substeps of both on the same input
+    must agree to single precision; once per (library, model, device) and process."""
+    key = (LIB_PATH, hash(blob), device_id)
+    if key in _self_checked:
+        return
+    lo, hi = model.actuator_ctrlrange[:, 0], model.actuator_ctrlrange[:, 1]
+    ctrl = (lo + 0.6 * (hi - lo))[None, :] if model.nu else np.zeros((1, 0))
+    out = {}
+    for prec in (64, 32):
+        e = BatchedPhysics(model, key_joint_ids, 2, device_id=device_id, precision=prec, blob=blob,
+                           self_check=False)
+        if model.nu:
+            e.set(CTRL, ctrl)
+        e.step(6)
+        out[prec] = (e.qpos.astype(np.float64)[0], e.get(QVEL).astype(np.float64)[0])
+        del e
+    dq = np.abs(out[64][0] - out[32][0]).max()
+    dv = np.abs(out[64][1] - out[32][1]).max()
+    vs = max(1.0, np.abs(out[64][1]).max())
+    if not (np.isfinite(dq) and np.isfinite(dv) and dq < 1e-3 and dv < 1e-2 * vs):
+        raise EngineError(
+            f"librp_engine.so failed its build self-check: the fp32 and fp64 kernels disagree after 6 "
+            f"substeps (max |dq| = {dq:.2e}, max |dv| = {dv:.2e}).  The library was most likely "
+            "miscompiled; rebuild it, and see DESIGN.md (toolchain note).")
+    _self_checked.add(key)
 
 
 def decode_key_trace(trace: np.ndarray, n_keys: int = 88) -> np.ndarray:
