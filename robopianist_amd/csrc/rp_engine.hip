@@ -359,7 +359,16 @@ struct Engine : EngineBase {
     if (!w) return fail("rp_set: field is read-only");
     if (!src) { if (f == RP_ACTIVE) { S.active = nullptr; return 0; } return fail("rp_set: null source"); }
     HIP_OK(hipSetDevice(device));
-    if (nb) HIP_OK(hipMemcpyAsync(p, src, nb, hipMemcpyDefault, stream));
+    if (nb) {
+      // Host sources: drain the stream first.  Stream order alone should put this copy after
+      // the kernels already enqueued, but under rocprofv3 --pmc (dispatch interception) a
+      // pending kernel was observed to run after a later host-to-device copy.
+      hipPointerAttribute_t attr;
+      const bool src_on_device = hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeDevice;
+      (void)hipGetLastError();
+      if (!src_on_device) HIP_OK(hipStreamSynchronize(stream));
+      HIP_OK(hipMemcpyAsync(p, src, nb, hipMemcpyDefault, stream));
+    }
     if (f == RP_ACTIVE) S.active = d_active;
     return 0;
   }

@@ -1,5 +1,5 @@
 import warnings; warnings.simplefilter('ignore')
-import sys; sys.path.insert(0,'.')
+import sys; sys.path.insert(0,'/root/repo')
 import numpy as np
 from robopianist_amd import engine
 from robopianist_amd.model import scene
