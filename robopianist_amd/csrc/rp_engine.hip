@@ -272,11 +272,24 @@ struct Engine : EngineBase {
     B.entM = dalloc<int>(E * RPK_NE * 2);
     B.slots = dalloc<int>(E * 64);
     B.keyslot = dalloc<int>(E * (RPK_NKEYS / 4));
+    // hand-over buffers start as NaN / -1 patterns: a read of anything the position kernel
+    // did not write this substep shows up as a bad state instead of silently reusing old data
+    hipMemset(B.RM, 0xFF, sizeof(T) * E * RPK_NL * (RPK_MAXD + 1));
+    hipMemset(B.lanef, 0xFF, sizeof(T) * E * RPK_NLF * 64);
+    hipMemset(B.lanei, 0xFF, sizeof(int) * E * RPK_NLI * 64);
+    hipMemset(B.hdr, 0xFF, sizeof(int) * E * 8);
+    hipMemset(B.entJ, 0xFF, sizeof(T) * E * RPK_NE * 3);
+    hipMemset(B.entM, 0xFF, sizeof(int) * E * RPK_NE * 2);
+    hipMemset(B.slots, 0xFF, sizeof(int) * E * 64);
+    hipMemset(B.keyslot, 0xFF, sizeof(int) * E * (RPK_NKEYS / 4));
     S.key_trace = nullptr;
     S.prof = nullptr;
     d_active = dalloc<int>(E);
     S.active = nullptr;
     S.max_newton = M.iterations; S.max_ls = M.ls_iterations;
+    // The fills and uploads above went through the null stream, which is NOT ordered with the
+    // engine's non-blocking stream: everything must have landed before the first kernel.
+    if (hipDeviceSynchronize() != hipSuccess) throw std::string("hipDeviceSynchronize failed after model upload");
   }
 
   long long* d_prof = nullptr;
@@ -290,7 +303,9 @@ struct Engine : EngineBase {
       HIP_OK(hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost));
       for (int i = 0; i < n && i < RPK_NPROF; i++) out[i] = h[i];
     }
+    HIP_OK(hipStreamSynchronize(stream));  // counters of launches still in flight
     HIP_OK(hipMemset(d_prof, 0, sizeof(long long) * RPK_NPROF));
+    HIP_OK(hipDeviceSynchronize());        // (null-stream fill vs the engine's non-blocking stream)
     S.prof = enable ? d_prof : nullptr;
     return 0;
   }

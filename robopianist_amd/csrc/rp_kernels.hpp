@@ -736,6 +736,13 @@ __global__ __launch_bounds__(64, MODE == 0 ? 2 : 1) void rp_stage_kernel(RpModel
   const int lane = threadIdx.x;
   const int env_active = S.active ? S.active[env] : 1;  // tested after the prologue loads are in flight
   __shared__ Smem<T, MODE> sm;
+#ifdef RPK_POISON_LDS  // debug build: nothing may depend on what a previous workgroup left in LDS
+  {
+    unsigned* w_ = reinterpret_cast<unsigned*>(&sm);
+    for (int i = threadIdx.x; i < (int)(sizeof(sm) / 4); i += 64) w_[i] = 0xFFF4DEADu;
+    WSYNC();
+  }
+#endif
   int warn = 0;
   if (S.prof && env == 0 && lane < RPK_NPROF) sm.prof[lane] = 0;
   long long prof_t = (long long)__builtin_readcyclecounter();
