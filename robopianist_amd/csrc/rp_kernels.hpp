@@ -1619,6 +1619,9 @@ __global__ __launch_bounds__(64, MODE == 0 ? 2 : 1) void rp_stage_kernel(RpModel
           // phi(alpha) and its first two derivatives; the cost itself is only needed at
           // the end points, the Newton iterations on phi' skip that wave reduction
           auto ls_eval = [&](T alpha, T& d1, T& d2, const bool with_cost) -> T {
+#ifdef RPK_LS_COUNTER
+            if (S.prof && env == 0 && lane == 0) sm.prof[26] += 1;  // evaluations (debug counter)
+#endif
             T cst = 0, a = 0, b = 0;
             if (isl && lfloss > 0) {
               T xx = jar.fr + alpha * jv.fr, rf = lflR * lfloss;
