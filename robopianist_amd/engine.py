@@ -274,7 +274,8 @@ def _build_self_check(model, key_joint_ids, blob, device_id):
     seen (round 1, ROCm 7.2) to emit a wrong kernel after a harmless source edit (correct
     again with `-mllvm -amdgpu-spill-sgpr-to-vgpr=false`, at 2.6x the run time).  The fp32
     and fp64 builds are separate instantiations, so a few substeps of both on the same input
-    must agree to single precision; once per (library, model, device) and process."""
+    must agree to single precision (measured: 2e-7 in q, 1e-5 in v; the two bad builds seen so far
+    were off by 5e-4 and 1e-2); once per (library, model, device) and process."""
     key = (LIB_PATH, hash(blob), device_id)
     if key in _self_checked:
         return
@@ -286,15 +287,17 @@ def _build_self_check(model, key_joint_ids, blob, device_id):
                            self_check=False)
         if model.nu:
             e.set(CTRL, ctrl)
-        e.step(6)
+        e.step(10)
         out[prec] = (e.qpos.astype(np.float64)[0], e.get(QVEL).astype(np.float64)[0])
         del e
     dq = np.abs(out[64][0] - out[32][0]).max()
     dv = np.abs(out[64][1] - out[32][1]).max()
     vs = max(1.0, np.abs(out[64][1]).max())
-    if not (np.isfinite(dq) and np.isfinite(dv) and dq < 1e-3 and dv < 1e-2 * vs):
+    if os.environ.get("RP_SELF_CHECK_VERBOSE"):
+        print(f"rp self-check: fp32 vs fp64 after 10 substeps: max|dq| = {dq:.2e}, max|dv| = {dv:.2e}")
+    if not (np.isfinite(dq) and np.isfinite(dv) and dq < 2e-5 and dv < 2e-3 * vs):
         raise EngineError(
-            f"librp_engine.so failed its build self-check: the fp32 and fp64 kernels disagree after 6 "
+            f"librp_engine.so failed its build self-check: the fp32 and fp64 kernels disagree after 10 "
             f"substeps (max |dq| = {dq:.2e}, max |dv| = {dv:.2e}).  The library was most likely "
             "miscompiled; rebuild it, and see DESIGN.md (toolchain note).")
     _self_checked.add(key)
