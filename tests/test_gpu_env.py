@@ -337,3 +337,20 @@ def test_rollouts_are_bitwise_reproducible_and_batch_invariant():
         assert torch.equal(q1, q1[0:1].expand_as(q1)) and torch.equal(v1, v1[0:1].expand_as(v1))
         assert torch.equal(q1, q2) and torch.equal(v1, v2)
         assert torch.equal(q1[:3], q3) and torch.equal(v1[:3], v3)
+
+
+def test_build_self_check_runs_once_and_passes(two_hand_scene, capfd, monkeypatch):
+    """engine._build_self_check: fp32 and fp64 kernels agree to single precision on the
+    shipped library; it is cached per (library, model, device)."""
+    from robopianist_amd import engine
+    monkeypatch.setenv("RP_SELF_CHECK_VERBOSE", "1")
+    monkeypatch.delenv("RP_SKIP_SELF_CHECK", raising=False)
+    engine._self_checked.clear()
+    si = two_hand_scene
+    engine.BatchedPhysics(si.model, si.key_joint_ids, n_envs=3)
+    out = capfd.readouterr().out
+    assert out.count("rp self-check") == 1
+    dq = float(out.split("max|dq| = ")[1].split(",")[0])
+    assert dq < 2e-6
+    engine.BatchedPhysics(si.model, si.key_joint_ids, n_envs=3)   # cached: no second run
+    assert "rp self-check" not in capfd.readouterr().out
