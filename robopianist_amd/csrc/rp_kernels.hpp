@@ -997,12 +997,12 @@ __global__ __launch_bounds__(64, MODE == 0 ? 2 : 1) void rp_stage_kernel(RpModel
         qfs[0] = isl ? (qpas - qbias + qapp[0] + qact) : (T)0;
 #pragma unroll
         for (int s = 0; s < 2; s++) {
-          T f = 0;
-          if (isk[s]) {
-            // passive spring/damper, gravity torque m*g*(hx)*cos(q) about +y, actuator
-            T grav = -kmass[s] * M.gz * khx[s] * kcos[s] - kmass[s] * M.gx * khx[s] * ksin[s];
-            f = -kstiff[s] * (q[1 + s] - ksref[s]) - kdamp[s] * qd[1 + s] + grav + qapp[1 + s];
-            if (kact[s] >= 0) {
+          // passive spring/damper, gravity torque m*g*(hx)*cos(q) about +y, actuator
+          // (all key constants are 0 for lanes without a key: no branch needed)
+          const T grav = -kmass[s] * M.gz * khx[s] * kcos[s] - kmass[s] * M.gx * khx[s] * ksin[s];
+          T f = -kstiff[s] * (q[1 + s] - ksref[s]) - kdamp[s] * qd[1 + s] + grav + qapp[1 + s];
+          {
+            if (isk[s] && kact[s] >= 0) {
               T af = M.act_gain()[kact[s]] * kctrl[s];
               if (M.act_forcelimited()[kact[s]])
                 af = fmin(M.act_forcerange()[2 * kact[s] + 1], fmax(M.act_forcerange()[2 * kact[s]], af));
@@ -1592,11 +1592,13 @@ __global__ __launch_bounds__(64, MODE == 0 ? 2 : 1) void rp_stage_kernel(RpModel
           WSYNC();
 #pragma unroll
           for (int s = 0; s < 2; s++) {
-            search[1 + s] = 0;
-            if (isk[s]) {
-              if (sm.keyslot[kid[s]] >= 0) search[1 + s] = sm.keyvec[0][kid[s]];
-              else search[1 + s] = -grad[1 + s] / (kM[s] + (lim_act[1 + s] ? lim_D[1 + s] : (T)0));
-            }
+            // branch-free on purpose (selects, no divergent region around the key slots: see
+            // the toolchain note in DESIGN.md); kM is 1 for lanes without a key
+            const int kk = isk[s] ? kid[s] : 0;
+            const int ks_ = sm.keyslot[kk];
+            const T via_slot = sm.keyvec[0][kk];
+            const T own = -grad[1 + s] / (kM[s] + (lim_act[1 + s] ? lim_D[1 + s] : (T)0));
+            search[1 + s] = isk[s] ? (ks_ >= 0 ? via_slot : own) : (T)0;
           }
           WSYNC();
           PROF(5);
