@@ -38,6 +38,7 @@ class HandInfo:
     actuator_ids: np.ndarray  # 20 hand actuators then forearm actuators
     fingertip_site_ids: np.ndarray  # th, ff, mf, rf, lf
     root_body_id: int
+    root_site_id: int  # site at the root body's origin (-1 unless build_scene(root_sites=True))
     forearm_geom_ids: np.ndarray
     n_forearm_dofs: int
 
@@ -63,6 +64,7 @@ def build_scene(
     forearm_dofs: Sequence[str] = shadow_hand.DEFAULT_FOREARM_DOFS,
     physics_timestep: float = PHYSICS_TIMESTEP,
     disable_hand_collisions: bool = False,
+    root_sites: bool = False,
 ) -> SceneInfo:
     if hands and not primitive_fingertip_collisions:
         warnings.warn(
@@ -103,6 +105,9 @@ def build_scene(
             hb.set_forearm_tx_range(joint_range)
         if disable_hand_collisions:
             hb.disable_hand_collisions()
+        if root_sites:
+            # origin of the hand's root body, for HandObservables.position (hands/base.py:111-114)
+            hb.root.sites.append(spec.Site(hb._n("forearm_origin_site"), (0.0, 0.0, 0.0)))
         world.add(hb.root)
         scene.tendons.extend(hb.tendons)
         scene.actuators.extend(hb.actuators)
@@ -129,6 +134,7 @@ def build_scene(
             actuator_ids=np.array([n["actuator"].index(a) for a in hb.actuator_names], np.int32),
             fingertip_site_ids=np.array([n["site"].index(s) for s in hb.fingertip_sites], np.int32),
             root_body_id=root_id,
+            root_site_id=(n["site"].index(hb._n("forearm_origin_site")) if root_sites else -1),
             forearm_geom_ids=np.array(
                 [g for g in range(m.ngeom) if m.geom_bodyid[g] == root_id], np.int32),
             n_forearm_dofs=len(hb.forearm_dofs),

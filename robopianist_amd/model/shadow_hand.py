@@ -31,6 +31,7 @@ drops in without touching the engine.
 
 from __future__ import annotations
 
+import enum
 import math
 from typing import Dict, List, Sequence, Tuple
 
@@ -106,6 +107,13 @@ def _mirror_axis(a, left: bool):
 def _mirror_quat(q, left: bool):
     q = tuple(float(x) for x in q)
     return (q[0], q[1], -q[2], -q[3]) if left else q
+
+
+class HandSide(enum.Enum):
+    """Which hand is modelled (robopianist/models/hands/base.py:26-30)."""
+
+    LEFT = enum.auto()
+    RIGHT = enum.auto()
 
 
 class HandBuilder:

@@ -105,6 +105,9 @@ class Environment:
             # HIP task layer (include/rp_task.h): the episode reset of the flagged envs, the
             # key state, after_step, observables, rewards, termination and the step types
             # are one launch after the physics
+            if getattr(task, "needs_host_episode_setup", False):
+                task.prepare_episodes(phys, resetting)  # MIDI augmentations (host; one read-back)
+                fused = task.fused_advance_for(phys)    # (the bank may have been reallocated)
             phys.reset(resetting)
             phys.set_active(resetting)
             phys.forward()

@@ -126,6 +126,7 @@ class Hand:
         self.fingertip_sites = info.fingertip_site_ids
         self.n_forearm_dofs = info.n_forearm_dofs
         self.root_body_id = info.root_body_id
+        self.root_site_id = info.root_site_id
         self.forearm_geom_ids = info.forearm_geom_ids
         self._action_spec = None
 
@@ -187,14 +188,16 @@ class PianoTask(PianoOnlyTask):
                  forearm_dofs: Sequence[str] = hand_model.DEFAULT_FOREARM_DOFS,
                  physics_timestep: float = _PHYSICS_TIMESTEP,
                  control_timestep: float = _CONTROL_TIMESTEP,
-                 disable_hand_collisions: bool = False, _hands=("right", "left")):
+                 disable_hand_collisions: bool = False, _hands=("right", "left"),
+                 _root_sites: bool = False):
         super().__init__(
             add_piano_actuators=False, change_color_on_activation=change_color_on_activation,
             physics_timestep=physics_timestep, control_timestep=control_timestep, _hands=_hands,
             gravity_compensation=gravity_compensation,
             primitive_fingertip_collisions=primitive_fingertip_collisions,
             reduced_action_space=reduced_action_space, attachment_yaw=attachment_yaw,
-            forearm_dofs=forearm_dofs, disable_hand_collisions=disable_hand_collisions)
+            forearm_dofs=forearm_dofs, disable_hand_collisions=disable_hand_collisions,
+            root_sites=_root_sites)
         m = self.scene.model
         self._right_hand = Hand(self.scene.hands["right"], m) if "right" in self.scene.hands else None
         self._left_hand = Hand(self.scene.hands["left"], m) if "left" in self.scene.hands else None

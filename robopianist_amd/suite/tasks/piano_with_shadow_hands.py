@@ -4,6 +4,12 @@ Same constructor arguments, hook order, observation names, reward terms and
 termination rule as robopianist/suite/tasks/piano_with_shadow_hands.py (line
 references below), batched over n_envs.  `midi` may also be a list of MidiFiles:
 env e then plays song e % len(midi) (heterogeneous goal bank, BASELINE config #5).
+
+`augmentations` (suite/variations.py) switch the goal bank to one slot per env: at every
+episode start of env e the variations are applied to that env's initial MIDI on the host
+(reference: _maybe_change_midi, :151-157), its goal / fingering tables are rebuilt and
+uploaded into slot e.  This needs the set of resetting envs on the host, i.e. one small
+device->host read per control step, and ~10 ms of host work per episode start.
 """
 
 from __future__ import annotations
@@ -45,14 +51,13 @@ class PianoWithShadowHands(base.PianoTask):
     ) -> None:
         super().__init__(disable_hand_collisions=disable_hand_collisions, **kwargs)
         del disable_colorization  # cosmetic (:451-474)
-        if augmentations is not None:
-            raise NotImplementedError(
-                "MIDI augmentations (robopianist/suite/variations.py) are a next-row item.")
+        self._augmentations = list(augmentations) if augmentations is not None else None
         midis = list(midi) if isinstance(midi, (list, tuple)) else [midi]
         if trim_silence:
             midis = [m.trim_silence() for m in midis]
         self._midis = midis
         self._midi = midis[0]
+        self._initial_midis = list(midis)  # :104 `_initial_midi`
         self._n_steps_lookahead = n_steps_lookahead
         if n_seconds_lookahead is not None:
             self._n_steps_lookahead = int(np.ceil(n_seconds_lookahead / self.control_timestep))
@@ -100,36 +105,121 @@ class PianoWithShadowHands(base.PianoTask):
         ns = len(trajs)
         goal = np.zeros((ns, tmax, 89), np.float32)
         finger = np.full((ns, tmax, 88), -1, np.int64)
+        self._song_tables = []
         for s, t in enumerate(trajs):
             g, f = t.to_goal_tables()
             goal[s, :len(t)] = g
             finger[s, :len(t)] = f
+            self._song_tables.append((g, f))
         self._goal_bank_np, self._finger_bank_np = goal, finger
         self._song_len_np = np.array([len(t) for t in trajs], np.int64)
 
+    def _tables_for(self, midi):
+        """Goal tables of one (augmented) MIDI (:159-165)."""
+        t = midi_file.NoteTrajectory.from_midi(midi, self.control_timestep)
+        t.add_initial_buffer_time(self._initial_buffer_time)
+        return t.to_goal_tables()
+
+    def _maybe_change_midi(self, mask=None) -> None:
+        """:151-157 for the envs selected by `mask` (None = all): the variations are applied
+        to the env's initial MIDI with the task's RandomState, in env order."""
+        if self._augmentations is None:
+            return
+        E = self._E
+        envs = range(E) if mask is None else np.flatnonzero(mask.detach().cpu().numpy())
+        if len(envs) == 0:
+            return
+        ns = len(self._initial_midis)
+        rows, lens = [], []
+        for e in envs:
+            initial = self._initial_midis[e % ns]
+            midi = initial
+            for var in self._augmentations:
+                midi = var(initial_value=midi, random_state=self._random_state)
+            self._env_midi[e] = midi
+            g, f = self._song_tables[e % ns] if midi is initial else self._tables_for(midi)
+            rows.append((g, f)); lens.append(len(g))
+        need = max(lens)
+        if need > self._goal_bank.shape[1]:
+            self._grow_bank(need + need // 4)
+        cap = self._goal_bank.shape[1]
+        goal = np.zeros((len(rows), cap, 89), np.float32)
+        finger = np.full((len(rows), cap, 88), -1, np.int64)
+        for i, (g, f) in enumerate(rows):
+            goal[i, :len(g)] = g
+            finger[i, :len(g)] = f
+        dev = self._physics_device
+        idx = torch.as_tensor(np.asarray(envs, np.int64), device=dev)
+        self._goal_bank.index_copy_(0, idx, torch.as_tensor(goal, device=dev).to(self._dtype))
+        self._finger_bank.index_copy_(0, idx, torch.as_tensor(finger, device=dev))
+        self._song_len.index_copy_(0, idx, torch.as_tensor(np.asarray(lens, np.int64), device=dev))
+
+    def _grow_bank(self, cap: int) -> None:
+        """Reallocates the per-env bank with `cap` rows (the fused launch arguments hold
+        raw pointers, so they are rebuilt on next use)."""
+        old_g, old_f = self._goal_bank, self._finger_bank
+        n, t = old_g.shape[0], old_g.shape[1]
+        self._goal_bank = torch.zeros((n, cap, 89), device=old_g.device, dtype=old_g.dtype)
+        self._finger_bank = torch.full((n, cap, 88), -1, device=old_f.device, dtype=old_f.dtype)
+        self._goal_bank[:, :t] = old_g
+        self._finger_bank[:, :t] = old_f
+        self._fused_advance = None
+
+    def prepare_episodes(self, physics, mask) -> None:
+        """Host-side part of initialize_episode that the fused device path cannot do:
+        the MIDI augmentations of the envs that start an episode in this step."""
+        del physics
+        if self._augmentations is not None:
+            self._maybe_change_midi(mask)
+
+    @property
+    def needs_host_episode_setup(self) -> bool:
+        return self._augmentations is not None
+
     def bind(self, physics, n_envs, random_state):
         super().bind(physics, n_envs, random_state)
-        dev, E = physics.device, n_envs
+        self._bind_goal_bank()
+        self._bind_hands()
+        self._bind_task_state()
+
+    def _bind_goal_bank(self):
+        dev, E = self._physics_device, self._E
         self._goal_bank = torch.as_tensor(self._goal_bank_np, device=dev, dtype=self._dtype)
         self._finger_bank = torch.as_tensor(self._finger_bank_np, device=dev)
         self._song_len = torch.as_tensor(self._song_len_np, device=dev)
         self._song_id = torch.arange(E, device=dev) % len(self._midis)
-        m = self.scene.model
+        if self._augmentations is not None:
+            # one bank slot per env, initialised with the env's un-augmented song
+            self._goal_bank = self._goal_bank[self._song_id].contiguous()
+            self._finger_bank = self._finger_bank[self._song_id].contiguous()
+            self._song_len = self._song_len[self._song_id].contiguous()
+            self._song_id = torch.arange(E, device=dev)
+            self._env_midi = [self._initial_midis[e % len(self._initial_midis)] for e in range(E)]
+            self._fused_advance = None
+
+    def _bind_hands(self):
+        dev, m = self._physics_device, self.scene.model
         self._rh_act = torch.as_tensor(self.right_hand.actuators, device=dev, dtype=torch.long)
         self._lh_act = torch.as_tensor(self.left_hand.actuators, device=dev, dtype=torch.long)
         self._rh_jnt = torch.as_tensor(self.right_hand.joints, device=dev, dtype=torch.long)
         self._lh_jnt = torch.as_tensor(self.left_hand.joints, device=dev, dtype=torch.long)
         # fingertip sites in fingering-id order: 0-4 right (th..lf), 5-9 left
         self._tip_sites = list(self.right_hand.fingertip_sites) + list(self.left_hand.fingertip_sites)
-        # key geometry for the fingering target (:312-313)
-        kg = self.piano.key_geom_ids
-        kb = m.geom_bodyid[kg]
-        half = m.geom_size[kg]
-        self._key_anchor = torch.as_tensor(m.body_pos[kb] + m.jnt_pos[self.piano.joints],
-                                           device=dev, dtype=self._dtype)
-        self._key_half = torch.as_tensor(half, device=dev, dtype=self._dtype)
+        self._bind_key_geometry()
         self._rfa = torch.as_tensor(self.right_hand.forearm_geom_ids, device=dev, dtype=torch.int32)
         self._lfa = torch.as_tensor(self.left_hand.forearm_geom_ids, device=dev, dtype=torch.int32)
+
+    def _bind_key_geometry(self):
+        """Key hinge positions and box half sizes (fingering target, :312-313)."""
+        dev, m = self._physics_device, self.scene.model
+        kg = self.piano.key_geom_ids
+        kb = m.geom_bodyid[kg]
+        self._key_anchor = torch.as_tensor(m.body_pos[kb] + m.jnt_pos[self.piano.joints],
+                                           device=dev, dtype=self._dtype)
+        self._key_half = torch.as_tensor(m.geom_size[kg], device=dev, dtype=self._dtype)
+
+    def _bind_task_state(self):
+        dev, E = self._physics_device, self._E
         self._reset_quantities_at_episode_init()
         L = self._n_steps_lookahead
         self._goal_state = torch.zeros((E, L + 1, 89), device=dev, dtype=self._dtype)
@@ -157,6 +247,7 @@ class PianoWithShadowHands(base.PianoTask):
     # -- composer-style hooks --------------------------------------------------------
     def initialize_episode(self, physics, mask=None) -> None:
         """:167-174 for the envs selected by `mask` (None = all)."""
+        self._maybe_change_midi(mask)
         self._reset_quantities_at_episode_init(mask)
         self._randomize_initial_hand_positions(physics, mask)
         self.piano.initialize_episode(physics, mask)

@@ -310,6 +310,91 @@ def test_fused_task_advance_matches_torch_hooks(wrong_press):
         assert seen["zero_discount"] >= 1, seen
 
 
+def test_midi_augmentations_fused_path_matches_torch_hooks():
+    """MIDI augmentations (suite/variations.py) on the HIP task layer: per-env goal bank
+    slots are regenerated on the host at every episode start; the fused launch must hand
+    out the same TimeSteps as the torch hooks driven by an identically seeded RandomState."""
+    from robopianist_amd import music, suite
+    from robopianist_amd.suite import variations
+    E = 5
+    def make(fused):
+        augs = [variations.MidiTemporalStretch(prob=0.8, stretch_range=0.4),
+                variations.MidiPitchShift(prob=0.8, shift_range=5)]
+        env = suite.load("RoboPianist-debug-CMajorScaleTwoHands-v0", seed=11, n_envs=E, precision=64,
+                         task_kwargs=dict(control_timestep=0.05, gravity_compensation=True,
+                                          primitive_fingertip_collisions=True, n_steps_lookahead=3,
+                                          augmentations=augs))
+        if not fused:
+            env.task._use_fused_advance = False
+            env.task._use_fused_rewards = False
+        return env
+    fused, ref = make(True), make(False)
+    ts_f, ts_r = fused.reset(), ref.reset()
+    assert fused.task.fused_advance_for(fused.physics) is not None
+    assert torch.equal(fused.task._song_len, ref.task._song_len)
+    assert len(set(fused.task._song_len.tolist())) > 1
+    rng = np.random.RandomState(2)
+    spec = fused.action_spec()
+    n_first = 0
+    for step in range(int(fused.task._song_len.max()) + 40):
+        a = torch.as_tensor(rng.uniform(spec.minimum, spec.maximum, size=(E, spec.shape[0])),
+                            device=fused.physics.device)
+        ts_f, ts_r = fused.step(a), ref.step(a)
+        assert torch.equal(ts_f.step_type, ts_r.step_type), step
+        np.testing.assert_allclose(_np(ts_f.reward), _np(ts_r.reward), rtol=0, atol=1e-12)
+        for k in ts_f.observation:
+            np.testing.assert_allclose(_np(ts_f.observation[k]), _np(ts_r.observation[k]), rtol=0, atol=1e-12,
+                                       err_msg=f"{k} @ {step}")
+        assert torch.equal(fused.task._song_len, ref.task._song_len)
+        assert torch.equal(fused.task._goal_bank[:, :10], ref.task._goal_bank[:, :10])
+        if step > 0:
+            n_first += int((ts_f.step_type == 0).sum())
+    assert n_first >= E, "every env restarted (with a fresh augmentation) at least once"
+
+
+@pytest.mark.parametrize("side", ["right", "left"])
+def test_one_hand_task_on_the_engine(side):
+    """PianoWithOneShadowHand on the HIP engine (single 26-link tree): protocol, observables,
+    and the `position` observable (root body xpos, hands/base.py:111-114) against the
+    closed form for slide joints: body_pos + sum_j R axis_j q_j."""
+    from robopianist_amd import music
+    from robopianist_amd.model import spec
+    from robopianist_amd.suite import environment
+    from robopianist_amd.suite.tasks import PianoWithOneShadowHand
+    E = 4
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        task = PianoWithOneShadowHand(midi=music.load("CMajorScaleTwoHands"), hand_side=side,
+                                      control_timestep=0.05, gravity_compensation=True,
+                                      primitive_fingertip_collisions=True, n_steps_lookahead=2)
+    env = environment.Environment(task, n_envs=E, random_state=3, precision=64)
+    ts = env.reset()
+    hand = task._hand
+    m = task.scene.model
+    name = hand.name
+    spec_a = env.action_spec()
+    assert spec_a.shape == (23,)
+    rng = np.random.RandomState(0)
+    R = spec.quat_to_mat(spec.quat_normalize(m.body_quat[hand.root_body_id]))
+    slide = [int(j) for j in hand.joints[-hand.n_forearm_dofs:]]
+    for step in range(40):
+        a = rng.uniform(spec_a.minimum, spec_a.maximum, size=(E, 23))
+        a[:, :22] = 0.3 * a[:, :22] + 0.7 * np.clip(0.0, spec_a.minimum[:22], spec_a.maximum[:22])
+        ts = env.step(torch.as_tensor(a, device=env.physics.device))
+        q = _np(env.physics.qpos)
+        want = m.body_pos[hand.root_body_id][None, :] + sum(
+            q[:, j:j + 1] * (R @ m.jnt_axis[j])[None, :] for j in slide)
+        np.testing.assert_allclose(_np(ts.observation[f"{name}/position"]), want, rtol=0, atol=1e-12)
+        assert np.isfinite(_np(ts.reward)).all()
+        assert ts.observation["fingering"].shape == (E, 5)
+        assert ts.observation["goal"].shape == (E, 3 * 89)
+    assert int(env.physics.warn.max()) == 0
+    assert np.abs(q[:, slide]).max() > 1e-3, "the forearm did move"
+    terms = task.reward_fn.reward_terms
+    assert set(terms) == {"key_press_reward", "sustain_reward", "energy_reward", "fingering_reward"}
+    assert float(terms["energy_reward"].max()) <= 0.0
+
+
 def test_rollouts_are_bitwise_reproducible_and_batch_invariant():
     """Identical envs stay bitwise identical (the LDS-add reductions of the solver have a
     fixed order), a re-run reproduces the same bits, and an env's trajectory does not depend

@@ -219,3 +219,91 @@ def test_self_actuated_oracle_policy_reward_is_zero():
         if bool(ts.last().all()):
             break
     assert int(env.task._t_idx[0]) == 161
+
+
+# ---- PianoWithOneShadowHand (piano_with_one_shadow_hand.py) ------------------------------------
+def _one_hand_env(side, n_envs=2, midi=None, **kw):
+    from robopianist_amd.suite.tasks import PianoWithOneShadowHand
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        task = PianoWithOneShadowHand(midi=midi or _get_test_midi(dt=0.01), hand_side=side,
+                                      control_timestep=0.01, change_color_on_activation=True, **kw)
+    return environment.Environment(task, n_envs=n_envs, physics=FakePhysics(task.scene, n_envs))
+
+
+@pytest.mark.parametrize("side", ["right", "left"])
+def test_one_hand_observables_action_and_termination(side):
+    from robopianist_amd.model.shadow_hand import HandSide
+    env = _one_hand_env(HandSide.RIGHT if side == "right" else HandSide.LEFT)
+    task = env.task
+    assert task.hand_side == side
+    assert (task.right_hand is None) == (side == "left") and (task.left_hand is None) == (side == "right")
+    assert env.physics.model.nv == 88 + 26 and env.physics.model.nu == 22
+    assert env.action_spec().shape == (23,)
+    assert env.action_spec().minimum[-1] == 0.0 and env.action_spec().maximum[-1] == 1.0
+    ts = env.reset()
+    prefix = "rh" if side == "right" else "lh"
+    assert set(ts.observation) == {f"{prefix}_shadow_hand/joints_pos", f"{prefix}_shadow_hand/position",
+                                   "piano/state", "piano/sustain_state", "goal", "fingering"}
+    assert ts.observation[f"{prefix}_shadow_hand/position"].shape == (2, 3)
+    assert ts.observation["fingering"].shape == (2, 5)
+    spec = env.observation_spec()
+    for k, v in ts.observation.items():
+        assert tuple(v.shape[1:]) == spec[k].shape
+    assert list(task.reward_fn.reward_fns) == ["key_press_reward", "sustain_reward", "energy_reward",
+                                               "fingering_reward"]
+    # action layout: hand first, sustain last (:194-197)
+    a = np.zeros((2, 23)); a[:, :22] = np.linspace(0.01, 0.02, 22); a[:, -1] = 0.7
+    ts = env.step(a)
+    np.testing.assert_array_equal(env.physics.ctrl[:, task._hand.actuators].numpy(), a[:, :22])
+    assert float(task.piano.sustain_state[0, 0]) == 0.7
+    # 3-dt midi => 4 frames => LAST on the 4th step (same rule as the two-hand task)
+    for _ in range(2):
+        ts = env.step(a)
+        assert not bool(ts.last().any())
+    ts = env.step(a)
+    assert bool(ts.last().all()) and float(ts.discount[0]) == 1.0
+
+
+def test_one_hand_fingering_lists_only_this_hands_notes():
+    """:292-311 with the test MIDI: C6 has fingering 1 (right index), G5 fingering 0 (right
+    thumb).  A left hand sees neither; the right hand sees finger 1 for two steps, then 0."""
+    zero = np.zeros((1, 23))
+    env = _one_hand_env("right", n_envs=1)
+    ts = env.reset()
+    seen = [ts.observation["fingering"][0].numpy().copy()]
+    for _ in range(3):
+        seen.append(env.step(zero).observation["fingering"][0].numpy().copy())
+    np.testing.assert_array_equal(np.array(seen), [[0, 1, 0, 0, 0], [0, 1, 0, 0, 0], [1, 0, 0, 0, 0],
+                                                   [0, 0, 0, 0, 0]])
+    env = _one_hand_env("left", n_envs=1)
+    ts = env.reset()
+    assert float(ts.observation["fingering"].sum()) == 0.0
+    for _ in range(3):
+        ts = env.step(zero)
+        assert float(ts.observation["fingering"].sum()) == 0.0
+        assert float(env.task.reward_fn.reward_terms["fingering_reward"][0]) == 0.0
+
+
+def test_one_hand_left_fingers_are_offset_by_five():
+    seq = NoteSequence()
+    seq.notes.add(start_time=0.0, end_time=0.03, velocity=80,
+                  pitch=midi_file.note_name_to_midi_number("C3"), part=7)
+    seq.notes.add(start_time=0.0, end_time=0.03, velocity=80,
+                  pitch=midi_file.note_name_to_midi_number("C6"), part=2)
+    seq.total_time = 0.03
+    seq.tempos.add(qpm=60)
+    midi = midi_file.MidiFile(seq=seq)
+    left = _one_hand_env("left", n_envs=1, midi=midi).reset().observation["fingering"][0].numpy()
+    right = _one_hand_env("right", n_envs=1, midi=midi).reset().observation["fingering"][0].numpy()
+    np.testing.assert_array_equal(left, [0, 0, 1, 0, 0])
+    np.testing.assert_array_equal(right, [0, 0, 1, 0, 0])
+    # the goal still lists both keys for either hand (key press reward is hand-agnostic)
+    env = _one_hand_env("left", n_envs=1, midi=midi)
+    assert float(env.reset().observation["goal"][0, :88].sum()) == 2.0
+
+
+def test_one_hand_invalid_side_raises():
+    from robopianist_amd.suite.tasks import PianoWithOneShadowHand
+    with pytest.raises(ValueError):
+        PianoWithOneShadowHand(midi=_get_test_midi(), hand_side="middle")
