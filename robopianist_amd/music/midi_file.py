@@ -75,11 +75,97 @@ class PianoNote:
                          name=midi_number_to_note_name(number), fingering=fingering)
 
 
-@dataclasses.dataclass(frozen=True)
-class MidiFile:
-    """midi_file.py:171-286 (synthesize/play omitted)."""
+class NoteArrays:
+    """Flat numpy view of a NoteSequence (notes in list order, control changes in list
+    order): what the vectorised goal-table builder consumes.  Time stretches and
+    transpositions act on it with the same IEEE operations as
+    sequence.stretch_note_sequence / transpose_note_sequence."""
 
-    seq: NoteSequence
+    __slots__ = ("start", "end", "pitch", "velocity", "part", "cc_time", "cc_num", "cc_val", "total_time")
+
+    @classmethod
+    def from_sequence(cls, seq: NoteSequence) -> "NoteArrays":
+        a = cls()
+        n = seq.notes
+        a.start = np.array([x.start_time for x in n], np.float64)
+        a.end = np.array([x.end_time for x in n], np.float64)
+        a.pitch = np.array([x.pitch for x in n], np.int64)
+        a.velocity = np.array([x.velocity for x in n], np.int64)
+        a.part = np.array([x.part for x in n], np.int64)
+        c = seq.control_changes
+        a.cc_time = np.array([x.time for x in c], np.float64)
+        a.cc_num = np.array([x.control_number for x in c], np.int64)
+        a.cc_val = np.array([x.control_value for x in c], np.int64)
+        a.total_time = float(seq.total_time)
+        return a
+
+    def stretched(self, factor: float) -> "NoteArrays":
+        if factor == 1.0:
+            return self
+        a = NoteArrays()
+        a.start, a.end, a.cc_time = self.start * factor, self.end * factor, self.cc_time * factor
+        a.pitch, a.velocity, a.part, a.cc_num, a.cc_val = self.pitch, self.velocity, self.part, self.cc_num, self.cc_val
+        a.total_time = self.total_time * factor
+        return a
+
+    def transposed(self, amount: int) -> "NoteArrays":
+        a = NoteArrays()
+        pitch = self.pitch + amount
+        keep = (pitch >= consts.MIN_MIDI_PITCH_PIANO) & (pitch <= consts.MAX_MIDI_PITCH_PIANO)
+        a.start, a.end, a.pitch = self.start[keep], self.end[keep], pitch[keep]
+        a.velocity, a.part = self.velocity[keep], self.part[keep]
+        a.cc_time, a.cc_num, a.cc_val, a.total_time = self.cc_time, self.cc_num, self.cc_val, self.total_time
+        return a
+
+
+class MidiFile:
+    """midi_file.py:171-286 (synthesize/play omitted).
+
+    `stretch` / `transpose` are recorded as pending operations on the source sequence:
+    `.seq` materialises them (sequence.stretch_note_sequence / transpose_note_sequence, in
+    order) on first access, `note_arrays()` applies them to the flat numpy view instead,
+    which is what the per-episode MIDI augmentations of the vectorised tasks use.  The
+    source sequence must not be edited once either view has been requested."""
+
+    def __init__(self, seq: NoteSequence = None, *, _base: NoteSequence = None, _ops: tuple = ()):
+        if (seq is None) == (_base is None):
+            raise TypeError("MidiFile(seq=NoteSequence)")
+        self._base = seq if _base is None else _base
+        self._ops = tuple(_ops)
+        self._seq = seq
+        self._arrays = None
+
+    def __repr__(self) -> str:
+        return f"MidiFile(title={self.title!r}, n_notes={self.n_notes}, duration={self.duration:.3f})"
+
+    @property
+    def seq(self) -> NoteSequence:
+        if self._seq is None:
+            seq = self._base
+            for op, arg in self._ops:
+                if op == "stretch":
+                    seq = seqlib.stretch_note_sequence(seq, arg)
+                else:
+                    seq, _ = seqlib.transpose_note_sequence(
+                        seq, amount=arg, min_allowed_pitch=consts.MIN_MIDI_PITCH_PIANO,
+                        max_allowed_pitch=consts.MAX_MIDI_PITCH_PIANO)
+            self._seq = seq
+        return self._seq
+
+    def note_arrays(self) -> NoteArrays:
+        if self._arrays is None:
+            if self._seq is not None and self._ops:
+                a = NoteArrays.from_sequence(self._seq)  # already materialised: take it as is
+            else:
+                cache = getattr(self._base, "_note_arrays_cache", None)
+                if cache is None or len(cache.pitch) != len(self._base.notes):
+                    cache = NoteArrays.from_sequence(self._base)
+                    self._base._note_arrays_cache = cache
+                a = cache
+                for op, arg in self._ops:
+                    a = a.stretched(arg) if op == "stretch" else a.transposed(arg)
+            self._arrays = a
+        return self._arrays
 
     @classmethod
     def from_file(cls, filename: Union[str, Path]) -> "MidiFile":
@@ -98,14 +184,11 @@ class MidiFile:
     def stretch(self, factor: float) -> "MidiFile":
         if factor <= 0:
             raise ValueError("factor must be positive.")
-        return MidiFile(seq=seqlib.stretch_note_sequence(self.seq, factor))
+        return MidiFile(_base=self._base, _ops=self._ops + (("stretch", float(factor)),))
 
     def transpose(self, amount: int, transpose_chords: bool = True) -> "MidiFile":
         del transpose_chords
-        seq, _ = seqlib.transpose_note_sequence(
-            self.seq, amount=amount, min_allowed_pitch=consts.MIN_MIDI_PITCH_PIANO,
-            max_allowed_pitch=consts.MAX_MIDI_PITCH_PIANO)
-        return MidiFile(seq=seq)
+        return MidiFile(_base=self._base, _ops=self._ops + (("transpose", int(amount)),))
 
     def trim_silence(self) -> "MidiFile":
         seq = seqlib.extract_subsequence(
@@ -114,25 +197,30 @@ class MidiFile:
         return MidiFile(seq=seq)
 
     def has_fingering(self) -> bool:
-        fingerings = set(note.part for note in self.seq.notes)
+        fingerings = set(note.part for note in self._base.notes)  # ops never touch `part`
         non_zero = [f for f in fingerings if f != 0]
         return len(fingerings) > 1 and len(non_zero) > 0
 
+    def pitch_range(self) -> Tuple[int, int]:
+        """(lowest, highest) MIDI pitch of the notes."""
+        p = self.note_arrays().pitch
+        return int(p.min()), int(p.max())
+
     @property
     def duration(self) -> float:
-        return self.seq.total_time
+        return self.note_arrays().total_time if self._seq is None else self._seq.total_time
 
     @property
     def n_notes(self) -> int:
-        return len(self.seq.notes)
+        return len(self.note_arrays().pitch) if self._seq is None else len(self._seq.notes)
 
     @property
     def title(self) -> str:
-        return self.seq.sequence_metadata.title
+        return self._base.sequence_metadata.title
 
     @property
     def artist(self) -> str:
-        return self.seq.sequence_metadata.artist
+        return self._base.sequence_metadata.artist
 
 
 @dataclasses.dataclass
@@ -204,6 +292,62 @@ class NoteTrajectory:
         return frames
 
     # ---- batched-engine view -------------------------------------------------
+    @staticmethod
+    def goal_tables_from_arrays(arrays: "NoteArrays", dt: float, initial_buffer_time: float = 0.0):
+        """`from_midi(midi, dt).add_initial_buffer_time(b).to_goal_tables()` computed from
+        the flat note arrays (same frame arithmetic as piano_roll.sequence_to_pianoroll and
+        seq_to_trajectory above, incl. the repeated-note gap and the sustain latch), without
+        building note objects: goal[T, 89] float32, finger[T, 88] int32.  Returns None when
+        the generic path has to decide (it raises for notes off the 88 keys)."""
+        if initial_buffer_time < 0.0:
+            raise ValueError("initial_buffer_time must be non-negative.")
+        if dt <= 0:
+            raise ValueError("dt must be positive.")
+        a = arrays
+        if len(a.pitch) and (a.pitch.min() < consts.MIN_MIDI_PITCH_PIANO or a.pitch.max() > consts.MAX_MIDI_PITCH_PIANO
+                             or a.velocity.max() > consts.MAX_VELOCITY):
+            return None
+        fps = 1 / dt
+        T = int(a.total_time * fps + 1)
+        nk = consts.NUM_KEYS
+        vel = np.zeros((T, nk), np.float32)
+        onset = np.zeros((T, nk), bool)
+        fing = np.full((T, nk), -1, np.int32)
+        s_frame = (a.start * fps).astype(np.int64)               # int() truncation
+        e_frame = np.maximum(s_frame + 1, np.ceil(a.end * fps).astype(np.int64))
+        key = a.pitch - consts.MIN_MIDI_PITCH_PIANO
+        v32 = a.velocity.astype(np.float64) / consts.MAX_VELOCITY
+        for i in np.argsort(a.start, kind="stable"):             # later notes overwrite earlier ones
+            s0, e0, k = int(s_frame[i]), int(e_frame[i]), int(key[i])
+            vel[s0:e0, k] = v32[i]
+            fing[s0:e0, k] = a.part[i]
+            if s0 < T:
+                onset[s0, k] = True
+        active = vel != 0
+        repeated = np.zeros_like(active)
+        repeated[1:] = active[:-1] & active[1:] & onset[1:]      # seq_to_trajectory's `continue`
+        on = active & ~repeated
+        goal = np.zeros((T, nk + 1), np.float32)
+        goal[:, :nk] = on
+        finger = np.where(on, fing, -1).astype(np.int32)
+        # sustain: last CC64 event of a frame decides, otherwise the previous state holds
+        sel = a.cc_num == consts.SUSTAIN_PEDAL_CC_NUMBER
+        frames = (a.cc_time[sel] * fps).astype(np.int64)
+        vals = a.cc_val[sel] + 1
+        ok = frames < T
+        ev = np.zeros(T, np.int64)
+        ev[frames[ok]] = vals[ok]                                 # in list order: later wins
+        state = np.where(ev >= consts.SUSTAIN_PEDAL_CC_NUMBER + 1, 1, 0)
+        has = (ev >= 1) & (ev <= consts.MAX_CC_VALUE + 1)
+        idx = np.where(has, np.arange(T), -1)
+        np.maximum.accumulate(idx, out=idx)
+        goal[:, nk] = np.where(idx >= 0, state[np.maximum(idx, 0)], 0)
+        nbuf = int(round(initial_buffer_time / dt))
+        if nbuf:
+            goal = np.concatenate([np.zeros((nbuf, nk + 1), np.float32), goal])
+            finger = np.concatenate([np.full((nbuf, nk), -1, np.int32), finger])
+        return goal, finger
+
     def to_goal_tables(self):
         """Dense tables consumed by the vectorised env: goal[T, 89] (keys + sustain),
         finger[T, 88] (fingering id of each goal key or -1)."""

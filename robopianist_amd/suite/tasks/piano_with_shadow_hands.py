@@ -116,6 +116,10 @@ class PianoWithShadowHands(base.PianoTask):
 
     def _tables_for(self, midi):
         """Goal tables of one (augmented) MIDI (:159-165)."""
+        fast = midi_file.NoteTrajectory.goal_tables_from_arrays(
+            midi.note_arrays(), self.control_timestep, self._initial_buffer_time)
+        if fast is not None:
+            return fast
         t = midi_file.NoteTrajectory.from_midi(midi, self.control_timestep)
         t.add_initial_buffer_time(self._initial_buffer_time)
         return t.to_goal_tables()

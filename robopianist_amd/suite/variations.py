@@ -67,9 +67,9 @@ class MidiTemporalStretch(Variation):
 
 def _shift_bounds(midi: midi_file.MidiFile, max_semitones: int):
     """Largest downward / upward shift that keeps every note on the 88 keys."""
-    pitches = [note.pitch for note in midi.seq.notes]
-    low = max(constants.MIN_MIDI_PITCH_PIANO - min(pitches), -max_semitones)
-    high = min(constants.MAX_MIDI_PITCH_PIANO - max(pitches), max_semitones)
+    min_pitch, max_pitch = midi.pitch_range()
+    low = max(constants.MIN_MIDI_PITCH_PIANO - min_pitch, -max_semitones)
+    high = min(constants.MAX_MIDI_PITCH_PIANO - max_pitch, max_semitones)
     return low, high
 
 

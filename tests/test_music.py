@@ -172,3 +172,40 @@ def test_midi_module_edge_detection_matches_reference_semantics():
     assert kinds == [("NoteOn", 0.004), ("SustainOn", 0.008), ("NoteOn", 0.01), ("NoteOff", 0.01)]
     assert ev[0].note == midi_file.key_number_to_midi_number(3)
     assert ev[2].note == midi_file.key_number_to_midi_number(64)
+
+
+def test_goal_tables_from_arrays_equal_the_note_object_path():
+    """The vectorised table builder used for per-episode augmentations must reproduce
+    NoteTrajectory.from_midi(...).to_goal_tables() exactly: all library songs, random
+    stretches / transpositions (lazy MidiFile ops vs materialised sequences), several
+    control timesteps, with and without initial buffer time."""
+    from robopianist_amd.suite import variations
+    rs = np.random.RandomState(0)
+    augs = [variations.MidiTemporalStretch(1.0, 0.4), variations.MidiPitchShift(1.0, 7),
+            variations.MidiOctaveShift(0.5, 2), variations.MidiTemporalStretch(0.5, 0.1)]
+    for name in music.ALL:
+        base = music.load(name)
+        for dt in (0.05, 0.013):
+            for _ in range(4):
+                m = base
+                for v in augs:
+                    m = v(initial_value=m, random_state=rs)
+                for buf in (0.0, 0.5):
+                    fast = midi_file.NoteTrajectory.goal_tables_from_arrays(m.note_arrays(), dt, buf)
+                    t = midi_file.NoteTrajectory.from_midi(m, dt)
+                    t.add_initial_buffer_time(buf)
+                    g, f = t.to_goal_tables()
+                    assert fast is not None
+                    np.testing.assert_array_equal(fast[0], g)
+                    np.testing.assert_array_equal(fast[1], f)
+                assert m.duration == m.seq.total_time and m.n_notes == len(m.seq.notes)
+
+
+def test_goal_tables_from_arrays_defers_off_piano_notes_to_the_generic_path():
+    seq = NoteSequence()
+    seq.notes.add(start_time=0.0, end_time=0.1, velocity=80, pitch=10, part=0)
+    seq.total_time = 0.1
+    m = midi_file.MidiFile(seq=seq)
+    assert midi_file.NoteTrajectory.goal_tables_from_arrays(m.note_arrays(), 0.05) is None
+    with pytest.raises(ValueError):
+        midi_file.NoteTrajectory.from_midi(m, 0.05)
