@@ -63,7 +63,9 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
         if p >= 0:
             parent[i] = lane_of_dof[int(p)]
             depth[i] = depth[parent[i]] + 1
-    assert depth.max(initial=0) < MAX_DEPTH
+    assert depth.max(initial=0) < MAX_DEPTH, (
+        f"kinematic chain of {depth.max(initial=0) + 1} dofs > {MAX_DEPTH} (forearm dofs + 2 wrist joints + "
+        "finger chain; the engine supports at most 2 forearm dofs)")
     tree = m.dof_treeid[link_dofs] if nl else np.zeros(0, np.int32)
     tree_ids = sorted(set(int(x) for x in tree))
     tree_local = np.array([tree_ids.index(int(x)) for x in tree], np.int32)
@@ -83,8 +85,6 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
             # pose of this body in its parent BODY frame; the parent link is the
             # last link of the parent body, whose frame is that body's frame.
             pb = int(m.body_parentid[b])
-            assert m.body_jntnum[pb] > 0 or pb == 0 or m.body_weldid[pb] == 0, \
-                "jointless intermediate bodies are not supported by the engine tables"
             # accumulate static transforms of jointless ancestors (attachment frames)
             pos = m.body_pos[b].copy(); quat = m.body_quat[b].copy()
             while pb != 0 and m.body_jntnum[pb] == 0:
@@ -102,6 +102,43 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
             link_body[i] = b
             body_lane[b] = i
         invw_body[i] = m.body_invweight0[b, 0]
+    # Jointless bodies below a moving body (e.g. the finger segments whose joints
+    # `reduced_action_space` removes, shadow_hand.py:162-171) are welded to it: they are
+    # fused into the link of their nearest jointed ancestor — composite mass / centre /
+    # inertia here, static offsets for their geoms and sites below.  body_weld[b] =
+    # (ancestor body, pos, R) of b's frame in that ancestor's frame.
+    body_weld = {}
+    for b in range(1, m.nbody):
+        if m.body_jntnum[b] > 0 or m.body_weldid[b] == 0:
+            continue
+        pos = m.body_pos[b].copy(); R = spec.quat_to_mat(spec.quat_normalize(m.body_quat[b]))
+        a = int(m.body_parentid[b])
+        while m.body_jntnum[a] == 0:
+            Ra = spec.quat_to_mat(spec.quat_normalize(m.body_quat[a]))
+            pos = m.body_pos[a] + Ra @ pos
+            R = Ra @ R
+            a = int(m.body_parentid[a])
+        if a not in body_lane:
+            continue  # hangs off a key: not a supported layout, caught by the geom checks
+        i = body_lane[a]
+        body_weld[b] = (a, pos, R)
+        body_lane[b] = i
+        assert m.body_gravcomp[b] == m.body_gravcomp[a], "engine requires uniform gravcomp per hand tree"
+        m2 = float(m.body_mass[b])
+        if m2 > 0:
+            c2 = pos + R @ m.body_ipos[b]
+            Ri = R @ spec.quat_to_mat(m.body_iquat[b])
+            I2 = Ri @ np.diag(m.body_inertia[b]) @ Ri.T
+            m1, c1 = float(mass[i]), ipos[i].copy()
+            I1 = np.array([[inertia[i][0], inertia[i][3], inertia[i][4]],
+                           [inertia[i][3], inertia[i][1], inertia[i][5]],
+                           [inertia[i][4], inertia[i][5], inertia[i][2]]])
+            mt = m1 + m2
+            c = (m1 * c1 + m2 * c2) / mt
+            par = lambda mm, d: mm * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+            I = I1 + par(m1, c1 - c) + I2 + par(m2, c2 - c)
+            mass[i] = mt; ipos[i] = c
+            inertia[i] = [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
     # ancestor tables
     anc = np.full((nl, MAX_DEPTH), -1, np.int32)
     ancmask = np.zeros((nl, 2), np.uint32)
@@ -312,6 +349,11 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
                 bb = int(m.body_parentid[bb])
             g_mat[i] = R.reshape(-1)
             t.setdefault("_static_pos", {})[i] = pos
+        elif b in body_weld:
+            _, wp, wR = body_weld[b]
+            g_link[i] = body_lane[b]
+            g_mat[i] = (wR @ spec.quat_to_mat(m.geom_quat[g])).reshape(-1)
+            t.setdefault("_static_pos", {})[i] = wp + wR @ m.geom_pos[g]
         else:
             g_link[i] = body_lane[b]
             g_mat[i] = spec.quat_to_mat(m.geom_quat[g]).reshape(-1)
@@ -425,7 +467,12 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
     hs = [s for s in range(m.nsite) if s_link[s] >= 0]
     t["eng_nsite"] = np.array([len(hs)], np.int32)
     t["eng_site_link"] = s_link[hs] if hs else np.zeros(0, np.int32)
-    t["eng_site_pos"] = m.site_pos[hs] if hs else np.zeros((0, 3))
+    s_pos = m.site_pos.copy()
+    for s_ in hs:
+        b = int(m.site_bodyid[s_])
+        if b in body_weld:
+            s_pos[s_] = body_weld[b][1] + body_weld[b][2] @ m.site_pos[s_]
+    t["eng_site_pos"] = s_pos[hs] if hs else np.zeros((0, 3))
     t["eng_site_modelid"] = np.array(hs, np.int32)
 
     # ---- per-lane topology record: everything a link lane needs about the tree in ONE

@@ -172,8 +172,10 @@ def test_replay_fp32_curve_is_reported(two_hand_scene):
 
 def test_teacher_forced_fp64_other_topologies():
     """Scenes whose trees differ from the benchmark's (two hands, 4-link trunks): one hand
-    only, and hands without forearm dofs (2-link trunks -> the generic, not the
-    trunk-specialised, solver build).  Same 1e-9 teacher-forced bar."""
+    only, hands without forearm dofs (2-link trunks -> the generic, not the
+    trunk-specialised, solver build), the reduced action space (welded finger segments), hinge
+    forearm dofs.  (More than two forearm dofs are rejected by rp_create: the solver's
+    register-blocked trunk holds at most 4 links.)  Same 1e-9 teacher-forced bar."""
     import warnings
     from robopianist_amd.model import scene
     with warnings.catch_warnings():
@@ -183,11 +185,28 @@ def test_teacher_forced_fp64_other_topologies():
                                                  primitive_fingertip_collisions=True),
             "no forearm dofs": scene.build_scene(forearm_dofs=(), gravity_compensation=True,
                                                  primitive_fingertip_collisions=True),
+            # reduced_action_space removes THJ5 / THJ1 / LFJ5 (shadow_hand.py:73-77,162-171): the
+            # engine fuses the now jointless finger segments into their parent links
+            "reduced action space": scene.build_scene(reduced_action_space=True, gravity_compensation=True,
+                                                      primitive_fingertip_collisions=True),
+            "rotational forearm dofs": scene.build_scene(
+                gravity_compensation=True, primitive_fingertip_collisions=True,
+                forearm_dofs=("forearm_roll", "forearm_pitch")),
+            "reduced, left hand, tz + yaw": scene.build_scene(
+                hands=("left",), reduced_action_space=True, gravity_compensation=True,
+                primitive_fingertip_collisions=True, forearm_dofs=("forearm_tz", "forearm_yaw")),
         }
     for name, si in scenes.items():
         worst, maxcon = teacher_forced(si, 64, ctrl_sequence(si.model, 200, 3))
         print(f"{name}: worst rel dv {worst:.2e}, max contacts {maxcon}, nv {si.model.nv}")
         assert worst < 1e-9, name
+    from robopianist_amd import engine
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        si = scene.build_scene(reduced_action_space=True, primitive_fingertip_collisions=True,
+                               forearm_dofs=("forearm_tx", "forearm_ty", "forearm_yaw"))
+    with pytest.raises(engine.EngineError, match="trunk chain"):
+        engine.BatchedPhysics(si.model, si.key_joint_ids, n_envs=1)
 
 
 def test_teacher_forced_fp64_many_contacts(two_hand_scene):

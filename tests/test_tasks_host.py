@@ -307,3 +307,21 @@ def test_one_hand_invalid_side_raises():
     from robopianist_amd.suite.tasks import PianoWithOneShadowHand
     with pytest.raises(ValueError):
         PianoWithOneShadowHand(midi=_get_test_midi(), hand_side="middle")
+
+
+def test_reduced_action_space_is_39_dimensional():
+    """shadow_hand.py:73-79,162-182: three actuators (and their joints) per hand are removed,
+    THJ2's range is cut; the task's action is then 2 x 19 + sustain."""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        task = piano_with_shadow_hands.PianoWithShadowHands(
+            midi=_get_test_midi(), reduced_action_space=True, change_color_on_activation=True)
+    env = environment.Environment(task, n_envs=2, physics=FakePhysics(task.scene, 2))
+    assert env.action_spec().shape == (39,)
+    names = env.action_spec().name.split("\t")
+    assert not any(n.endswith(x) for n in names for x in ("A_THJ5", "A_THJ1", "A_LFJ5"))
+    ts = env.reset()
+    assert ts.observation["rh_shadow_hand/joints_pos"].shape == (2, 23)
+    m = task.scene.model
+    a = m.names["actuator"].index("rh_shadow_hand/rh_A_THJ2")
+    np.testing.assert_allclose(m.actuator_ctrlrange[a], (0.0, 0.698132))
