@@ -1,0 +1,155 @@
+// rp_dense.hpp — dense SPD factor + solve of the cross-coupled block of the Newton
+// Hessian, one row per lane, matrix packed in LDS.
+#pragma once
+#include "rp_wave.hpp"
+
+namespace rpk {
+// 1/sqrt(x) to working precision: hardware estimate + Newton steps (no division on the
+// pivot chain of the dense factorisation).
+template <typename T> __device__ __forceinline__ T rsqrt_nr(T x);
+template <> __device__ __forceinline__ double rsqrt_nr<double>(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  y = y * __builtin_fma(-h * y, y, 1.5);
+  y = y * __builtin_fma(-h * y, y, 1.5);
+  return y;
+}
+template <> __device__ __forceinline__ float rsqrt_nr<float>(float x) {
+  float y = __builtin_amdgcn_rsqf(x);
+  const float h = 0.5f * x;
+  y = y * __builtin_fmaf(-h * y, y, 1.5f);
+  return y;
+}
+
+// Dense solve of the packed lower-triangular SPD system H (n rows, n uniform) with the
+// right-hand side stored as row n of H; returns x_i in lane i < n.
+//   * left-looking L L^T, lane = row, four columns per step (one LDS hand-over per four
+//     pivots; a pair and a single column finish the remainder);
+//   * inner products read the lane's own row and rows j, j+1 (uniform address =
+//     LDS broadcast) with paired 64-bit reads, no v_readlane in the loop;
+//   * the rhs row takes part in the factorisation like any other row, which performs
+//     the forward substitution for free; only the backward pass is a serial chain.
+// Measured on gfx950, one wave per SIMD, n = 20, fp64: 12 k cycles (the first version,
+// one column per step with sqrt/divide/readlane, took 34 k).
+template <typename T>
+__device__ T dense_factor_solve(T* H, int n, int lane, int* warn) {
+  T invd_me = 0;
+  int j = 0;
+  // four columns per step while they last (one LDS hand-over per four pivots) ...
+  // (fp32 only: the fp64 solver kernel is at its register limit and the four-column step
+  // pushes it into scratch spills, measured -7 %)
+  for (; sizeof(T) == 4 && j + 4 <= n; j += 4) {
+    const bool act = lane >= j && lane <= n;
+    const T* ri = H + tri(act ? lane : 0, 0);
+    const T* r0 = H + tri(j, 0);
+    const T* r1 = H + tri(j + 1, 0);
+    const T* r2 = H + tri(j + 2, 0);
+    const T* r3 = H + tri(j + 3, 0);
+    T s0 = ri[j], s1 = ri[j + 1], s2 = ri[j + 2], s3 = ri[j + 3];
+    for (int p = 0; p < j; p += 2) {  // j is a multiple of 4 here; two p per trip keeps the
+#pragma unroll                       // live set small (the fp64 solver is at its register limit)
+      for (int u = 0; u < 2; u++) {
+        const T a = ri[p + u];
+        s0 -= a * r0[p + u]; s1 -= a * r1[p + u]; s2 -= a * r2[p + u]; s3 -= a * r3[p + u];
+      }
+    }
+    T d0 = bcast(s0, j);
+    if (!(d0 >= RPK_MINVAL)) { d0 = RPK_MINVAL; *warn |= 4; }
+    const T q0 = rsqrt_nr(d0);
+    const T l0 = s0 * q0;
+    s1 -= l0 * bcast(l0, j + 1);
+    T d1 = bcast(s1, j + 1);
+    if (!(d1 >= RPK_MINVAL)) { d1 = RPK_MINVAL; *warn |= 4; }
+    const T q1 = rsqrt_nr(d1);
+    const T l1 = s1 * q1;
+    s2 -= l0 * bcast(l0, j + 2); s2 -= l1 * bcast(l1, j + 2);
+    T d2 = bcast(s2, j + 2);
+    if (!(d2 >= RPK_MINVAL)) { d2 = RPK_MINVAL; *warn |= 4; }
+    const T q2 = rsqrt_nr(d2);
+    const T l2 = s2 * q2;
+    s3 -= l0 * bcast(l0, j + 3); s3 -= l1 * bcast(l1, j + 3); s3 -= l2 * bcast(l2, j + 3);
+    T d3 = bcast(s3, j + 3);
+    if (!(d3 >= RPK_MINVAL)) { d3 = RPK_MINVAL; *warn |= 4; }
+    const T q3 = rsqrt_nr(d3);
+    const T l3 = s3 * q3;
+    if (lane == j) invd_me = q0;
+    if (lane == j + 1) invd_me = q1;
+    if (lane == j + 2) invd_me = q2;
+    if (lane == j + 3) invd_me = q3;
+    if (act) H[tri(lane, j)] = l0;
+    if (act && lane > j) H[tri(lane, j + 1)] = l1;
+    if (act && lane > j + 1) H[tri(lane, j + 2)] = l2;
+    if (act && lane > j + 2) H[tri(lane, j + 3)] = l3;
+    WSYNC();
+  }
+  // ... then a pair, then a single column
+  for (; j + 2 <= n; j += 2) {
+    const int j1 = j + 1;
+    const bool act = lane >= j && lane <= n;
+    const T* ri = H + tri(act ? lane : 0, 0);
+    const T* rj = H + tri(j, 0);
+    const T* rk = H + tri(j1, 0);
+    T s = ri[j], t = ri[j1];
+    int p = 0;
+    for (; p + 4 <= j; p += 4) {
+      T a0 = ri[p], a1 = ri[p + 1], a2 = ri[p + 2], a3 = ri[p + 3];
+      T b0 = rj[p], b1 = rj[p + 1], b2 = rj[p + 2], b3 = rj[p + 3];
+      T c0 = rk[p], c1 = rk[p + 1], c2 = rk[p + 2], c3 = rk[p + 3];
+      s -= a0 * b0; t -= a0 * c0; s -= a1 * b1; t -= a1 * c1;
+      s -= a2 * b2; t -= a2 * c2; s -= a3 * b3; t -= a3 * c3;
+    }
+    for (; p < j; p++) { T a0 = ri[p]; s -= a0 * rj[p]; t -= a0 * rk[p]; }
+    T dj = bcast(s, j);
+    if (!(dj >= RPK_MINVAL)) { dj = RPK_MINVAL; *warn |= 4; }
+    const T rs = rsqrt_nr(dj);
+    const T lij = s * rs;               // L[i][j] for lanes > j (lane j: sqrt(dj))
+    const T lkj = bcast(lij, j1);
+    t -= lij * lkj;
+    T dk = bcast(t, j1);
+    if (!(dk >= RPK_MINVAL)) { dk = RPK_MINVAL; *warn |= 4; }
+    const T rs2 = rsqrt_nr(dk);
+    const T lik = t * rs2;
+    if (lane == j) invd_me = rs;
+    if (lane == j1) invd_me = rs2;
+    if (act) H[tri(lane, j)] = lij;
+    if (act && lane > j) H[tri(lane, j1)] = lik;
+    WSYNC();
+  }
+  if (j < n) {
+    const bool act = lane >= j && lane <= n;
+    const T* ri = H + tri(act ? lane : 0, 0);
+    const T* rj = H + tri(j, 0);
+    T s = ri[j];
+    for (int p = 0; p < j; p++) s -= ri[p] * rj[p];
+    T dj = bcast(s, j);
+    if (!(dj >= RPK_MINVAL)) { dj = RPK_MINVAL; *warn |= 4; }
+    const T rs = rsqrt_nr(dj);
+    if (lane == j) invd_me = rs;
+    if (act) H[tri(lane, j)] = s * rs;
+    WSYNC();
+  }
+  // row n now holds y = L^-1 b; backward pass L^T x = y
+  T x = lane < n ? H[tri(n, 0) + lane] : (T)0;
+  int p = n - 1;
+  for (; p - 3 >= 0; p -= 4) {
+    T l0 = H[tri(p, 0) + (lane < p ? lane : 0)], l1 = H[tri(p - 1, 0) + (lane < p - 1 ? lane : 0)];
+    T l2 = H[tri(p - 2, 0) + (lane < p - 2 ? lane : 0)], l3 = H[tri(p - 3, 0) + (lane < p - 3 ? lane : 0)];
+    l0 = lane < p ? l0 : (T)0; l1 = lane < p - 1 ? l1 : (T)0; l2 = lane < p - 2 ? l2 : (T)0; l3 = lane < p - 3 ? l3 : (T)0;
+    if (lane == p) x *= invd_me;
+    x -= l0 * bcast(x, p);
+    if (lane == p - 1) x *= invd_me;
+    x -= l1 * bcast(x, p - 1);
+    if (lane == p - 2) x *= invd_me;
+    x -= l2 * bcast(x, p - 2);
+    if (lane == p - 3) x *= invd_me;
+    x -= l3 * bcast(x, p - 3);
+  }
+  for (; p >= 0; p--) {
+    T l0 = H[tri(p, 0) + (lane < p ? lane : 0)];
+    l0 = lane < p ? l0 : (T)0;
+    if (lane == p) x *= invd_me;
+    x -= l0 * bcast(x, p);
+  }
+  return x;
+}
+}  // namespace rpk

@@ -1,7 +1,7 @@
 // rp_engine.hip — host side of the C ABI declared in include/rp_engine.h.
 // Parses the model blob (robopianist_amd/model/compile.py:to_blob + engine
 // tables), uploads the fixed-topology tables, owns the env-major state arrays and
-// launches rp_step_kernel<T> (rp_kernels.hpp) on a private HIP stream.
+// launches the stage kernels rp_stage_kernel<T, MODE> (rp_kernels.hpp) on the engine's HIP stream.
 #include "rp_kernels.hpp"
 
 #include <hip/hip_runtime.h>

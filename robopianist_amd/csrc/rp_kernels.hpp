@@ -1,493 +1,13 @@
-// rp_kernels.hpp — fixed-topology batched rigid-body step for RoboPianist on gfx950.
-//
-// One environment per 64-lane wavefront (one workgroup = one wave).  Lane roles:
-//   lane i < nlink        : hand link i (= hand dof i; 2 trees x 26 links)
-//   lane k, k+64          : piano keys k and k+64 (closed-form 1-dof hinges)
-//   lane c < ncon         : contact c (4 pyramidal rows) during the solve
-//   lane a < nu           : actuator a during transmission/actuation
-//   lane nlink+s          : solver slot of the s-th key currently touched by a hand
-// Per-dof vectors live in registers of their owner lane; LDS holds link frames,
-// the packed joint-space matrices, contact Jacobians and small staging vectors.
-//
-// What the reference does here: `physics.step()` x n_substeps inside
-// dm_control's composer.Environment.step, configured by
-// /root/reference/robopianist/suite/tasks/base.py:28,31,68-70 and reached from
-// suite/__init__.py:87-93.  The arithmetic follows MuJoCo's documented
-// pipeline; the CPU restatement used as the parity
-// oracle is oracle/rp_oracle.c (a generic, sequential, dense-J formulation).
+// rp_kernels.hpp — the two stage kernels of the batched step (position/velocity stage and
+// constraint-solver stage), their LDS layouts, and the reset kernel.  Lane roles, tables and
+// hand-over buffers: rp_model.hpp.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#define RPK_WAVE 64
-#define RPK_NC 32        // max contacts kept per env (= RP_MAX_CONTACTS; contact c lives in lane c)
-#define RPK_NCOUT 32     // == RP_MAX_CONTACTS
-#define RPK_NE 256      // max contact Jacobian entries (contact, dof) handed to the solver
-#define RPK_NBOXF 26     // boxes covered by the oriented-box prefilter (fits the cdof scratch in fp32)
-#define RPK_HMAX 60      // max rows of the dense cross-coupling block (+1 row for its rhs = one lane each)
-#define RPK_WORK 128     // narrow-phase work list
-#define RPK_MAXD 9       // tree depth levels
-#define RPK_NL 52        // max links
-#define RPK_NKEYS 128    // max keys (2 slots per lane)
-#define RPK_KEYBASE 1000 // work-list / contact encoding of "key k" = RPK_KEYBASE + k
-
-#define JNT_SLIDE_ 2
-#define JNT_HINGE_ 3
-#define GEOM_CAPSULE_ 3
-#define GEOM_BOX_ 6
-
-// All model tables live in TWO device arrays (one of T, one of int) at compile-time
-// offsets (tables are padded to their maximum item counts).  A table access is then
-// `base pointer + immediate`, instead of one kernarg pointer load per table: with ~80
-// tables the pointers do not fit in SGPRs, and every re-load costs an s_waitcnt
-// lgkmcnt(0) that also drains the LDS queue.
-#define RPK_MAXACT 192
-#define RPK_MAXTREE 4
-//      name            items        stride
-#define RPK_FTABLES(X) \
-  X(link_lpos,        RPK_NL,      3) X(link_lmat,       RPK_NL,      9) X(link_axis,      RPK_NL, 3) \
-  X(link_anchor,      RPK_NL,      3) X(link_mass,       RPK_NL,      1) X(link_ipos,      RPK_NL, 3) \
-  X(link_inertia,     RPK_NL,      6) X(link_invw_body,  RPK_NL,      1) X(link_armature,  RPK_NL, 1) \
-  X(link_damping,     RPK_NL,      1) X(link_stiffness,  RPK_NL,      1) X(link_springref, RPK_NL, 1) \
-  X(link_floss,       RPK_NL,      1) X(link_fl_R,       RPK_NL,      1) X(link_fl_B,      RPK_NL, 1) \
-  X(link_range,       RPK_NL,      2) X(link_lim_K,      RPK_NL,      1) X(link_lim_B,     RPK_NL, 1) \
-  X(link_lim_solimp,  RPK_NL,      5) X(link_invw_dof,   RPK_NL,      1) X(link_act_coef,  RPK_NL, 1) \
-  X(link_gscale,      RPK_NL,      1) \
-  X(tree_gscale,      RPK_MAXTREE, 1) X(tree_ref,        RPK_MAXTREE, 3) \
-  X(key_pos,          RPK_NKEYS,   3) X(key_half,        RPK_NKEYS,   3) X(key_mass,       RPK_NKEYS, 1) \
-  X(key_M,            RPK_NKEYS,   1) X(key_stiffness,   RPK_NKEYS,   1) X(key_springref,  RPK_NKEYS, 1) \
-  X(key_damping,      RPK_NKEYS,   1) X(key_range,       RPK_NKEYS,   2) X(key_lim_K,      RPK_NKEYS, 1) \
-  X(key_lim_B,        RPK_NKEYS,   1) X(key_lim_solimp,  RPK_NKEYS,   5) X(key_invw_dof,   RPK_NKEYS, 1) \
-  X(key_invw_body,    RPK_NKEYS,   1) X(key_rbound,      RPK_NKEYS,   1) X(key_cparam,     1,         8) \
-  X(geom_size,        RPK_WAVE,    3) X(geom_pos,        RPK_WAVE,    3) X(geom_mat,       RPK_WAVE,  9) \
-  X(geom_rbound,      RPK_WAVE,    1) X(geom_invw,       RPK_WAVE,    1) X(geom_cparam,    RPK_WAVE,  8) \
-  X(act_coef,         RPK_MAXACT,  2) X(act_gain,        RPK_MAXACT,  1) X(act_bias,       RPK_MAXACT, 3) \
-  X(act_ctrlrange,    RPK_MAXACT,  2) X(act_forcerange,  RPK_MAXACT,  2) X(site_pos,       RPK_WAVE,  3)
-#define RPK_ITABLES(X) \
-  X(lane_topo,    RPK_NL, 16) \
-  X(link_parent,  RPK_NL, 1) X(link_depth,   RPK_NL, 1) X(link_tree,    RPK_NL, 1) X(link_jtype,  RPK_NL, 1) \
-  X(link_dof,     RPK_NL, 1) X(link_sibrank, RPK_NL, 1) X(link_limited, RPK_NL, 1) X(link_act,    RPK_NL, 1) \
-  X(link_ndesc,   RPK_NL, 1) X(link_anc,     RPK_NL, RPK_MAXD) X(link_ancmask, RPK_NL, 2) \
-  X(link_desc,    RPK_NL, RPK_MAXD * 5) X(level_maxrank, 1, RPK_MAXD) \
-  X(tree_base,    RPK_MAXTREE, 1) X(tree_trunk, RPK_MAXTREE, 1) X(chain_first, RPK_MAXTREE, 5) \
-  X(chain_len,    RPK_MAXTREE, 5) \
-  X(key_dof,      RPK_NKEYS, 1) X(key_act,   RPK_NKEYS, 1) X(key_geomid, RPK_NKEYS, 1) \
-  X(geom_link,    RPK_WAVE, 1) X(geom_type,  RPK_WAVE, 1) X(geom_modelid, RPK_WAVE, 1) \
-  X(geom_pairmask, RPK_WAVE, 2) X(geom_iskeycap, RPK_WAVE, 1) \
-  X(act_kind,     RPK_MAXACT, 1) X(act_lane, RPK_MAXACT, 2) X(act_ctrllimited, RPK_MAXACT, 1) \
-  X(act_forcelimited, RPK_MAXACT, 1) X(site_link, RPK_WAVE, 1)
-
-struct RpLayout {
-  enum : int {
-#define X(name, items, stride) F_##name, F_##name##_end = F_##name + (items) * (stride) - 1,
-    RPK_FTABLES(X)
-#undef X
-    F_TOTAL,
-#define X(name, items, stride) I_##name, I_##name##_end = I_##name + (items) * (stride) - 1,
-    RPK_ITABLES(X)
-#undef X
-    I_TOTAL
-  };
-};
-
-template <typename T>
-struct RpModel {
-  int nlink, ntree, maxdepth, nkey, ngeom, nu, nsite, nv;
-  int iterations, ls_iterations;
-  T timestep, gx, gy, gz, tolerance, ls_tolerance, meaninertia, key_zmax;
-  const T* ft;    // RpLayout::F_* offsets
-  const int* it;  // RpLayout::I_* offsets
-#define X(name, items, stride) \
-  __device__ __forceinline__ const T* name() const { return ft + RpLayout::F_##name; }
-  RPK_FTABLES(X)
-#undef X
-#define X(name, items, stride) \
-  __device__ __forceinline__ const int* name() const { return it + RpLayout::I_##name; }
-  RPK_ITABLES(X)
-#undef X
-  __device__ __forceinline__ const unsigned* link_ancmask_u() const {
-    return (const unsigned*)(it + RpLayout::I_link_ancmask);
-  }
-};
-
-template <typename T>
-struct RpState {
-  int nenv;
-  T *qpos, *qvel, *warm, *ctrl, *qfrc_applied, *time, *tree_offset;
-  T *act_force, *act_vel, *site_xpos, *contact_dist;
-  int *ncon, *contact_geoms, *warn, *solver_iter;
-  const int* active;    // may be null: envs with active[e]==0 are left untouched
-  uint32_t* key_trace;  // may be null
-  long long* prof;      // may be null: per-phase cycle counters (env 0)
-  int max_newton, max_ls;
-};
-
-// One workgroup == one wavefront, and a wave's LDS instructions execute in issue
-// order, so cross-lane LDS hand-offs need no s_barrier and no s_waitcnt drain: only
-// the compiler must be kept from reordering LDS accesses across the hand-off.
-#define WSYNC()                                              \
-  do {                                                       \
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
-    __builtin_amdgcn_wave_barrier();                         \
-  } while (0)
-#define RPK_NPROF 32
-// Per-phase shader-clock counters of env 0 (debug aid), accumulated in LDS so a probe
-// costs about one LDS round trip; flushed to global memory once at kernel exit.
-#ifdef RPK_MARK  // static analysis aid: phase boundaries as comments in the ISA listing
-#define PROF(i) asm volatile("; MARK " #i)
-#else
-#define PROF(i)                                                         \
-  do {                                                                  \
-    if (S.prof && env == 0) {                                           \
-      long long t_ = (long long)__builtin_readcyclecounter();           \
-      if (lane == 0) sm.prof[i] += (unsigned)(t_ - prof_t);                       \
-      prof_t = t_;                                                      \
-    }                                                                   \
-  } while (0)
-#endif
-
-// Hand-over between the position/velocity kernel (MODE 0) and the solver kernel
-// (MODE 1): everything `mj_step1` leaves behind for `mj_step2`, per env.  Lives in
-// HBM but is L2 / Infinity-Cache resident (<= 25 KB per env).
-#define RPK_NLF 29  // per-lane float fields
-#define RPK_NLI 12  // per-lane int fields
-template <typename T>
-struct RpStage {
-  T* RM;      // [E][RPK_NL][RPK_MAXD+1] mass-matrix rows
-  T* lanef;   // [E][RPK_NLF][64]
-  int* lanei; // [E][RPK_NLI][64]
-  int* hdr;   // [E][8]: ncon, nkt, dirty mask lo/hi, nent, max entries per contact
-  T* entJ;    // [E][RPK_NE][3]  contact Jacobian entries: d(contact point velocity)/d(qvel of one dof)
-  int* entM;  // [E][RPK_NE][2]  lane | contact<<6 | column<<11 | cross<<15 ; base | count<<8 | rank<<16
-  int* slots; // [E][64]: slotkey[16], slotlink[16], slotmask lo[16], hi[16]
-  int* keyslot; // [E][RPK_NKEYS/4] (packed signed char)
-};
+#include "rp_model.hpp"
+#include "rp_wave.hpp"
+#include "rp_narrow.hpp"
+#include "rp_dense.hpp"
 
 namespace rpk {
-
-template <typename T> struct Num;
-template <> struct Num<float> {
-  static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
-  static __device__ __forceinline__ float abs(float x) { return fabsf(x); }
-  static __device__ __forceinline__ float pow(float x, float y) { return powf(x, y); }
-  static __device__ __forceinline__ void sincos(float x, float* s, float* c) { sincosf(x, s, c); }
-  static __device__ __forceinline__ float eps() { return 1.1920929e-7f; }
-};
-template <> struct Num<double> {
-  static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
-  static __device__ __forceinline__ double abs(double x) { return fabs(x); }
-  static __device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }
-  static __device__ __forceinline__ void sincos(double x, double* s, double* c) { ::sincos(x, s, c); }
-  static __device__ __forceinline__ double eps() { return 2.220446049250313e-16; }
-};
-#define RPK_MINVAL ((T)1e-15)
-
-__device__ __forceinline__ float bcast(float v, int l) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v),
-                                                             __builtin_amdgcn_readfirstlane(l)));
-}
-__device__ __forceinline__ int bcast(int v, int l) {
-  return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l));
-}
-__device__ __forceinline__ double bcast(double v, int l) {
-  long long b = __builtin_bit_cast(long long, v);
-  int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
-  int sl = __builtin_amdgcn_readfirstlane(l);
-  lo = __builtin_amdgcn_readlane(lo, sl);
-  hi = __builtin_amdgcn_readlane(hi, sl);
-  long long r = ((long long)hi << 32) | (unsigned int)lo;
-  return __builtin_bit_cast(double, r);
-}
-// Wave-wide sum, result uniform in every lane.  Four DPP butterfly steps (xor 1, xor 2,
-// half-mirror, mirror) leave each 16-lane row holding its row sum without touching the
-// LDS crossbar; the four row sums are then read with v_readlane and added as scalars.
-template <int CTRL> __device__ __forceinline__ float dpp_move(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-template <int CTRL> __device__ __forceinline__ double dpp_move(double v) {
-  long long b = __builtin_bit_cast(long long, v);
-  int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
-  v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_move<0x141>(v);  // row_half_mirror
-  v += dpp_move<0x140>(v);  // row_mirror
-  return (bcast(v, 0) + bcast(v, 16)) + (bcast(v, 32) + bcast(v, 48));
-}
-template <int CTRL> __device__ __forceinline__ int dpp_move(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
-}
-// integer wave reductions on the same DPP butterfly (uniform result)
-__device__ __forceinline__ int wave_or(int v) {
-  v |= dpp_move<0xB1>(v); v |= dpp_move<0x4E>(v); v |= dpp_move<0x141>(v); v |= dpp_move<0x140>(v);
-  return (bcast(v, 0) | bcast(v, 16)) | (bcast(v, 32) | bcast(v, 48));
-}
-__device__ __forceinline__ int wave_max(int v) {
-  v = max(v, dpp_move<0xB1>(v)); v = max(v, dpp_move<0x4E>(v));
-  v = max(v, dpp_move<0x141>(v)); v = max(v, dpp_move<0x140>(v));
-  return max(max(bcast(v, 0), bcast(v, 16)), max(bcast(v, 32), bcast(v, 48)));
-}
-__device__ __forceinline__ unsigned long long wave_or(unsigned long long v) {
-  unsigned lo = (unsigned)wave_or((int)(v & 0xffffffffull)), hi = (unsigned)wave_or((int)(v >> 32));
-  return ((unsigned long long)hi << 32) | lo;
-}
-template <typename P>
-__device__ __forceinline__ const P* fresh(const P* p) {
-  asm volatile("" : "+s"(p));
-  return p;
-}
-// fire-and-forget LDS accumulate (ds_add_f32 / ds_add_f64): no read-modify-write round trip
-template <typename T> __device__ __forceinline__ void lds_add(T* p, T v) {
-  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-}
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ unsigned long long lanemask_lt(int lane) {
-  return (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-}
-__device__ __forceinline__ int tri(int i, int j) { return (i * (i + 1) >> 1) + j; }
-
-template <typename T> __device__ __forceinline__ T dot3(const T* a, const T* b) {
-  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
-}
-template <typename T> __device__ __forceinline__ void cross3(T* r, const T* a, const T* b) {
-  T x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
-  r[0] = x; r[1] = y; r[2] = z;
-}
-template <typename T> __device__ __forceinline__ void mat_vec(T* r, const T* m, const T* v) {
-  T x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
-  T y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
-  T z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
-  r[0] = x; r[1] = y; r[2] = z;
-}
-template <typename T> __device__ __forceinline__ void matT_vec(T* r, const T* m, const T* v) {
-  T x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2];
-  T y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2];
-  T z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
-  r[0] = x; r[1] = y; r[2] = z;
-}
-template <typename T> __device__ __forceinline__ void mat_mul(T* r, const T* a, const T* b) {
-  T t[9];
-#pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int j = 0; j < 3; j++)
-      t[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
-#pragma unroll
-  for (int i = 0; i < 9; i++) r[i] = t[i];
-}
-// spatial inertia (about the tree reference point) times motion vector
-// I = [Ixx Iyy Izz Ixy Ixz Iyz mdx mdy mdz m]
-template <typename T> __device__ __forceinline__ void mul_inert(T* res, const T* I, const T* v) {
-  T t[3];
-  res[0] = I[0] * v[0] + I[3] * v[1] + I[4] * v[2];
-  res[1] = I[3] * v[0] + I[1] * v[1] + I[5] * v[2];
-  res[2] = I[4] * v[0] + I[5] * v[1] + I[2] * v[2];
-  cross3(t, I + 6, v + 3);
-  res[0] += t[0]; res[1] += t[1]; res[2] += t[2];
-  cross3(t, I + 6, v);
-  res[3] = I[9] * v[3] - t[0]; res[4] = I[9] * v[4] - t[1]; res[5] = I[9] * v[5] - t[2];
-}
-template <typename T> __device__ __forceinline__ T dot6(const T* a, const T* b) {
-  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
-}
-template <typename T> __device__ __forceinline__ void make_frame(const T* n, T* t1, T* t2) {
-  if (Num<T>::abs(n[1]) < (T)0.5) { t1[0] = 0; t1[1] = 1; t1[2] = 0; }
-  else { t1[0] = 0; t1[1] = 0; t1[2] = 1; }
-  T dp = dot3(n, t1);
-  t1[0] -= dp * n[0]; t1[1] -= dp * n[1]; t1[2] -= dp * n[2];
-  T inv = (T)1 / Num<T>::sqrt(dot3(t1, t1));
-  t1[0] *= inv; t1[1] *= inv; t1[2] *= inv;
-  cross3(t2, n, t1);
-}
-template <typename T>
-__device__ __forceinline__ T impedance(const T* solimp, T pos) {  // margin == 0
-  T dmin = fmin((T)0.9999, fmax((T)0.0001, solimp[0]));
-  T dmax = fmin((T)0.9999, fmax((T)0.0001, solimp[1]));
-  T width = fmax(RPK_MINVAL, solimp[2]);
-  T mid = fmin((T)0.9999, fmax((T)0.0001, solimp[3]));
-  T power = fmax((T)1, solimp[4]);
-  if (dmin == dmax || width <= RPK_MINVAL) return (T)0.5 * (dmin + dmax);
-  T x = Num<T>::abs(pos) / width;
-  if (x >= (T)1) return dmax;
-  if (x == (T)0) return dmin;
-  T y;
-  if (power == (T)2) {  // the MuJoCo default; pow(x, 2) is exactly x * x
-    if (x <= mid) y = x * x / mid;
-    else y = (T)1 - ((T)1 - x) * ((T)1 - x) / ((T)1 - mid);
-  } else if (x <= mid) y = Num<T>::pow(x, power) / Num<T>::pow(mid, power - 1);
-  else y = (T)1 - Num<T>::pow((T)1 - x, power) / Num<T>::pow((T)1 - mid, power - 1);
-  return dmin + y * (dmax - dmin);
-}
-
-// ----------------------------------------------------------------- narrow phase
-template <typename T> struct RawCon { T dist, pos[3], n[3]; };
-
-template <typename T>
-__device__ __forceinline__ int sphere_sphere(RawCon<T>* c, const T* c1, T r1, const T* c2, T r2) {
-  T v[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
-  T len = Num<T>::sqrt(dot3(v, v)), dist = len - r1 - r2;
-  if (dist > (T)0) return 0;
-  if (len < RPK_MINVAL) { v[0] = 1; v[1] = 0; v[2] = 0; }
-  else { T inv = (T)1 / len; v[0] *= inv; v[1] *= inv; v[2] *= inv; }
-  c->dist = dist;
-#pragma unroll
-  for (int k = 0; k < 3; k++) { c->n[k] = v[k]; c->pos[k] = c1[k] + v[k] * (r1 + (T)0.5 * dist); }
-  return 1;
-}
-
-// out[n++] = c with a static register index (out[] must never be indexed dynamically,
-// or the compiler places it in scratch memory)
-template <typename T>
-__device__ __forceinline__ void put_con(RawCon<T>* out, int& n, const RawCon<T>& c) {
-#pragma unroll
-  for (int i = 0; i < 3; i++) if (n == i) out[i] = c;
-  n++;
-}
-
-template <typename T>
-__device__ int capsule_capsule(RawCon<T>* out, const T* p1, const T* m1, const T* s1, const T* p2,
-                               const T* m2, const T* s2) {
-  T a1[3] = {m1[2], m1[5], m1[8]}, a2[3] = {m2[2], m2[5], m2[8]};
-  T r1 = s1[0], l1 = s1[1], r2 = s2[0], l2 = s2[1];
-  T dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-  T b = dot3(a1, a2), u = -dot3(a1, dif), v = dot3(a2, dif);
-  T det = (T)1 - b * b;
-  int n = 0;
-  T c1[3], c2[3];
-  if (det > (T)1e-10) {
-    T x1 = (u + b * v) / det, x2 = (v + b * u) / det;
-    if (x1 > l1) { x1 = l1; x2 = v + b * x1; } else if (x1 < -l1) { x1 = -l1; x2 = v + b * x1; }
-    if (x2 > l2) { x2 = l2; x1 = fmin(l1, fmax(-l1, u + b * x2)); }
-    else if (x2 < -l2) { x2 = -l2; x1 = fmin(l1, fmax(-l1, u + b * x2)); }
-#pragma unroll
-    for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * x1; c2[k] = p2[k] + a2[k] * x2; }
-    RawCon<T> rc;
-    if (sphere_sphere(&rc, c1, r1, c2, r2)) put_con(out, n, rc);
-  } else {
-    T sgn = b >= 0 ? (T)1 : (T)-1, mid = u;
-    T lo = fmax(-l1, mid - l2), hi = fmin(l1, mid + l2);
-    if (lo <= hi) {
-      int cnt = (hi - lo > (T)1e-12) ? 2 : 1;
-      for (int q = 0; q < cnt; q++) {
-        T x1 = q == 0 ? lo : hi, x2 = sgn * (x1 - mid);
-#pragma unroll
-        for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * x1; c2[k] = p2[k] + a2[k] * x2; }
-        RawCon<T> rc;
-        if (sphere_sphere(&rc, c1, r1, c2, r2)) put_con(out, n, rc);
-      }
-    } else {
-      T x1 = mid > 0 ? l1 : -l1;
-      T x2 = fmin(l2, fmax(-l2, sgn * (x1 - mid)));
-#pragma unroll
-      for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * x1; c2[k] = p2[k] + a2[k] * x2; }
-      RawCon<T> rc;
-      if (sphere_sphere(&rc, c1, r1, c2, r2)) put_con(out, n, rc);
-    }
-  }
-  return n;
-}
-
-template <typename T>
-__device__ __forceinline__ T seg_box_g(const T* c, const T* a, const T* h, T t) {
-  T g = 0;
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    T p = c[k] + t * a[k];
-    if (p > h[k]) g += a[k] * (p - h[k]); else if (p < -h[k]) g += a[k] * (p + h[k]);
-  }
-  return g;
-}
-
-template <typename T>
-__device__ __forceinline__ int sphere_box_local(RawCon<T>* c, const T* p, T r, const T* h) {
-  T q[3], v[3], d2 = 0;
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    q[k] = p[k] > h[k] ? h[k] : (p[k] < -h[k] ? -h[k] : p[k]);
-    v[k] = p[k] - q[k]; d2 += v[k] * v[k];
-  }
-  T nbs[3], dist;
-  if (d2 > 0) {
-    T dd = Num<T>::sqrt(d2);
-    dist = dd - r;
-    T inv = (T)1 / dd;
-    nbs[0] = v[0] * inv; nbs[1] = v[1] * inv; nbs[2] = v[2] * inv;
-  } else {
-    int ax = 0; T best = (T)-1e30;
-#pragma unroll
-    for (int k = 0; k < 3; k++) { T pen = Num<T>::abs(p[k]) - h[k]; if (pen > best) { best = pen; ax = k; } }
-    nbs[0] = nbs[1] = nbs[2] = 0;
-    T sg = p[ax] >= 0 ? (T)1 : (T)-1;
-    nbs[ax] = sg; q[ax] = sg * h[ax];
-    dist = best - r;
-  }
-  if (dist > 0) return 0;
-  c->dist = dist;
-#pragma unroll
-  for (int k = 0; k < 3; k++) { c->pos[k] = q[k] + nbs[k] * (T)0.5 * dist; c->n[k] = -nbs[k]; }
-  return 1;
-}
-
-// capsule (geom1) vs box (geom2): closest axis point (exact root of the piecewise
-// linear distance derivative) plus both segment ends.
-template <typename T>
-__device__ int capsule_box(RawCon<T>* out, const T* cp, const T* cm, const T* cs, const T* bp,
-                           const T* bm, const T* bs) {
-  T r = cs[0], l = cs[1];
-  T ax[3] = {cm[2], cm[5], cm[8]}, rel[3] = {cp[0] - bp[0], cp[1] - bp[1], cp[2] - bp[2]};
-  T c[3], a[3];
-  matT_vec(c, bm, rel);
-  matT_vec(a, bm, ax);
-  a[0] *= l; a[1] *= l; a[2] *= l;
-  T tstar;
-  T gm = seg_box_g(c, a, bs, (T)-1), gp = seg_box_g(c, a, bs, (T)1);
-  if (gm >= 0) tstar = -1;
-  else if (gp <= 0) tstar = 1;
-  else {
-    T tl = -1, gl = gm, tr = 1, gr = gp;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      if (Num<T>::abs(a[k]) > RPK_MINVAL) {
-#pragma unroll
-        for (int s = 0; s < 2; s++) {
-          T tt = ((s == 0 ? bs[k] : -bs[k]) - c[k]) / a[k];
-          if (tt > -1 && tt < 1) {
-            T g = seg_box_g(c, a, bs, tt);
-            if (g <= 0 && tt > tl) { tl = tt; gl = g; }
-            if (g >= 0 && tt < tr) { tr = tt; gr = g; }
-          }
-        }
-      }
-    }
-    if (tr <= tl) tstar = tl;
-    else if (gr - gl > 0) tstar = tl + (tr - tl) * (-gl) / (gr - gl);
-    else tstar = tl;
-  }
-  int n = 0;
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    T tc = i == 0 ? tstar : (i == 1 ? (T)-1 : (T)1);
-    if (i > 0 && Num<T>::abs(tc - tstar) < (T)1e-9) continue;
-    T p[3] = {c[0] + tc * a[0], c[1] + tc * a[1], c[2] + tc * a[2]};
-    RawCon<T> rc;
-    if (sphere_box_local(&rc, p, r, bs)) {
-      T w[3];
-      RawCon<T> wc;
-      mat_vec(w, bm, rc.pos);
-      wc.pos[0] = bp[0] + w[0]; wc.pos[1] = bp[1] + w[1]; wc.pos[2] = bp[2] + w[2];
-      mat_vec(wc.n, bm, rc.n);
-      wc.dist = rc.dist;
-      put_con(out, n, wc);
-    }
-  }
-  return n;
-}
-
 // ----------------------------------------------------------------- shared memory
 // LDS budget drives occupancy (fp64: 40.5 KB -> 4 workgroups per CU).  Scratch of the
 // position/velocity stage and scratch of the solver are never live together, so they
@@ -557,155 +77,6 @@ struct Smem<T, 1> : SmemShared<T> {
 // rows owned by one lane: friction-loss row of its hand dof, one limit row per dof
 // slot (hand, key, key+64), four pyramidal rows of its contact.
 template <typename T> struct Rows { T fr, lim[3], con[4]; };
-
-// 1/sqrt(x) to working precision: hardware estimate + Newton steps (no division on the
-// pivot chain of the dense factorisation).
-template <typename T> __device__ __forceinline__ T rsqrt_nr(T x);
-template <> __device__ __forceinline__ double rsqrt_nr<double>(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  const double h = 0.5 * x;
-  y = y * __builtin_fma(-h * y, y, 1.5);
-  y = y * __builtin_fma(-h * y, y, 1.5);
-  return y;
-}
-template <> __device__ __forceinline__ float rsqrt_nr<float>(float x) {
-  float y = __builtin_amdgcn_rsqf(x);
-  const float h = 0.5f * x;
-  y = y * __builtin_fmaf(-h * y, y, 1.5f);
-  return y;
-}
-
-// Dense solve of the packed lower-triangular SPD system H (n rows, n uniform) with the
-// right-hand side stored as row n of H; returns x_i in lane i < n.
-//   * left-looking L L^T, lane = row, four columns per step (one LDS hand-over per four
-//     pivots; a pair and a single column finish the remainder);
-//   * inner products read the lane's own row and rows j, j+1 (uniform address =
-//     LDS broadcast) with paired 64-bit reads, no v_readlane in the loop;
-//   * the rhs row takes part in the factorisation like any other row, which performs
-//     the forward substitution for free; only the backward pass is a serial chain.
-// Measured on gfx950, one wave per SIMD, n = 20, fp64: 12 k cycles (the first version,
-// one column per step with sqrt/divide/readlane, took 34 k).
-template <typename T>
-__device__ T dense_factor_solve(T* H, int n, int lane, int* warn) {
-  T invd_me = 0;
-  int j = 0;
-  // four columns per step while they last (one LDS hand-over per four pivots) ...
-  // (fp32 only: the fp64 solver kernel is at its register limit and the four-column step
-  // pushes it into scratch spills, measured -7 %)
-  for (; sizeof(T) == 4 && j + 4 <= n; j += 4) {
-    const bool act = lane >= j && lane <= n;
-    const T* ri = H + tri(act ? lane : 0, 0);
-    const T* r0 = H + tri(j, 0);
-    const T* r1 = H + tri(j + 1, 0);
-    const T* r2 = H + tri(j + 2, 0);
-    const T* r3 = H + tri(j + 3, 0);
-    T s0 = ri[j], s1 = ri[j + 1], s2 = ri[j + 2], s3 = ri[j + 3];
-    for (int p = 0; p < j; p += 2) {  // j is a multiple of 4 here; two p per trip keeps the
-#pragma unroll                       // live set small (the fp64 solver is at its register limit)
-      for (int u = 0; u < 2; u++) {
-        const T a = ri[p + u];
-        s0 -= a * r0[p + u]; s1 -= a * r1[p + u]; s2 -= a * r2[p + u]; s3 -= a * r3[p + u];
-      }
-    }
-    T d0 = bcast(s0, j);
-    if (!(d0 >= RPK_MINVAL)) { d0 = RPK_MINVAL; *warn |= 4; }
-    const T q0 = rsqrt_nr(d0);
-    const T l0 = s0 * q0;
-    s1 -= l0 * bcast(l0, j + 1);
-    T d1 = bcast(s1, j + 1);
-    if (!(d1 >= RPK_MINVAL)) { d1 = RPK_MINVAL; *warn |= 4; }
-    const T q1 = rsqrt_nr(d1);
-    const T l1 = s1 * q1;
-    s2 -= l0 * bcast(l0, j + 2); s2 -= l1 * bcast(l1, j + 2);
-    T d2 = bcast(s2, j + 2);
-    if (!(d2 >= RPK_MINVAL)) { d2 = RPK_MINVAL; *warn |= 4; }
-    const T q2 = rsqrt_nr(d2);
-    const T l2 = s2 * q2;
-    s3 -= l0 * bcast(l0, j + 3); s3 -= l1 * bcast(l1, j + 3); s3 -= l2 * bcast(l2, j + 3);
-    T d3 = bcast(s3, j + 3);
-    if (!(d3 >= RPK_MINVAL)) { d3 = RPK_MINVAL; *warn |= 4; }
-    const T q3 = rsqrt_nr(d3);
-    const T l3 = s3 * q3;
-    if (lane == j) invd_me = q0;
-    if (lane == j + 1) invd_me = q1;
-    if (lane == j + 2) invd_me = q2;
-    if (lane == j + 3) invd_me = q3;
-    if (act) H[tri(lane, j)] = l0;
-    if (act && lane > j) H[tri(lane, j + 1)] = l1;
-    if (act && lane > j + 1) H[tri(lane, j + 2)] = l2;
-    if (act && lane > j + 2) H[tri(lane, j + 3)] = l3;
-    WSYNC();
-  }
-  // ... then a pair, then a single column
-  for (; j + 2 <= n; j += 2) {
-    const int j1 = j + 1;
-    const bool act = lane >= j && lane <= n;
-    const T* ri = H + tri(act ? lane : 0, 0);
-    const T* rj = H + tri(j, 0);
-    const T* rk = H + tri(j1, 0);
-    T s = ri[j], t = ri[j1];
-    int p = 0;
-    for (; p + 4 <= j; p += 4) {
-      T a0 = ri[p], a1 = ri[p + 1], a2 = ri[p + 2], a3 = ri[p + 3];
-      T b0 = rj[p], b1 = rj[p + 1], b2 = rj[p + 2], b3 = rj[p + 3];
-      T c0 = rk[p], c1 = rk[p + 1], c2 = rk[p + 2], c3 = rk[p + 3];
-      s -= a0 * b0; t -= a0 * c0; s -= a1 * b1; t -= a1 * c1;
-      s -= a2 * b2; t -= a2 * c2; s -= a3 * b3; t -= a3 * c3;
-    }
-    for (; p < j; p++) { T a0 = ri[p]; s -= a0 * rj[p]; t -= a0 * rk[p]; }
-    T dj = bcast(s, j);
-    if (!(dj >= RPK_MINVAL)) { dj = RPK_MINVAL; *warn |= 4; }
-    const T rs = rsqrt_nr(dj);
-    const T lij = s * rs;               // L[i][j] for lanes > j (lane j: sqrt(dj))
-    const T lkj = bcast(lij, j1);
-    t -= lij * lkj;
-    T dk = bcast(t, j1);
-    if (!(dk >= RPK_MINVAL)) { dk = RPK_MINVAL; *warn |= 4; }
-    const T rs2 = rsqrt_nr(dk);
-    const T lik = t * rs2;
-    if (lane == j) invd_me = rs;
-    if (lane == j1) invd_me = rs2;
-    if (act) H[tri(lane, j)] = lij;
-    if (act && lane > j) H[tri(lane, j1)] = lik;
-    WSYNC();
-  }
-  if (j < n) {
-    const bool act = lane >= j && lane <= n;
-    const T* ri = H + tri(act ? lane : 0, 0);
-    const T* rj = H + tri(j, 0);
-    T s = ri[j];
-    for (int p = 0; p < j; p++) s -= ri[p] * rj[p];
-    T dj = bcast(s, j);
-    if (!(dj >= RPK_MINVAL)) { dj = RPK_MINVAL; *warn |= 4; }
-    const T rs = rsqrt_nr(dj);
-    if (lane == j) invd_me = rs;
-    if (act) H[tri(lane, j)] = s * rs;
-    WSYNC();
-  }
-  // row n now holds y = L^-1 b; backward pass L^T x = y
-  T x = lane < n ? H[tri(n, 0) + lane] : (T)0;
-  int p = n - 1;
-  for (; p - 3 >= 0; p -= 4) {
-    T l0 = H[tri(p, 0) + (lane < p ? lane : 0)], l1 = H[tri(p - 1, 0) + (lane < p - 1 ? lane : 0)];
-    T l2 = H[tri(p - 2, 0) + (lane < p - 2 ? lane : 0)], l3 = H[tri(p - 3, 0) + (lane < p - 3 ? lane : 0)];
-    l0 = lane < p ? l0 : (T)0; l1 = lane < p - 1 ? l1 : (T)0; l2 = lane < p - 2 ? l2 : (T)0; l3 = lane < p - 3 ? l3 : (T)0;
-    if (lane == p) x *= invd_me;
-    x -= l0 * bcast(x, p);
-    if (lane == p - 1) x *= invd_me;
-    x -= l1 * bcast(x, p - 1);
-    if (lane == p - 2) x *= invd_me;
-    x -= l2 * bcast(x, p - 2);
-    if (lane == p - 3) x *= invd_me;
-    x -= l3 * bcast(x, p - 3);
-  }
-  for (; p >= 0; p--) {
-    T l0 = H[tri(p, 0) + (lane < p ? lane : 0)];
-    l0 = lane < p ? l0 : (T)0;
-    if (lane == p) x *= invd_me;
-    x -= l0 * bcast(x, p);
-  }
-  return x;
-}
 }  // namespace rpk
 
 // physics.reset() for the envs selected by a device-side mask (null = all).
@@ -724,8 +95,10 @@ __global__ void rp_reset_kernel(RpState<T> S, const T* qpos0, const unsigned cha
 }
 
 // ============================================================================
-// The step kernel.  mode 0: n_sub x (acceleration stage, Euler, position/velocity
-// stage).  mode 1: position/velocity stage only (physics.forward()).
+// The stage kernels.  MODE 0: position/velocity stage (mj_step1: kinematics, CRB, collision,
+// constraint rows; also physics.forward()).  MODE 1: acceleration stage (mj_step2: Newton
+// solver + Euler).  FIXED_TL > 0 specialises the solver for trunks of exactly that many links.
+// The host launches  pos, then n_substeps x (sol, pos);  RpStage carries the hand-over.
 // ============================================================================
 template <typename T, int MODE, int FIXED_TL = 0>
 __global__ __launch_bounds__(64, MODE == 0 ? 2 : 1) void rp_stage_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep,

@@ -1,0 +1,164 @@
+// rp_kernels.hpp — fixed-topology batched rigid-body step for RoboPianist on gfx950.
+//
+// One environment per 64-lane wavefront (one workgroup = one wave).  Lane roles:
+//   lane i < nlink        : hand link i (= hand dof i; 2 trees x 26 links)
+//   lane k, k+64          : piano keys k and k+64 (closed-form 1-dof hinges)
+//   lane c < ncon         : contact c (4 pyramidal rows) during the solve
+//   lane a < nu           : actuator a during transmission/actuation
+//   lane nlink+s          : solver slot of the s-th key currently touched by a hand
+// Per-dof vectors live in registers of their owner lane; LDS holds link frames,
+// the packed joint-space matrices, contact Jacobians and small staging vectors.
+//
+// What the reference does here: `physics.step()` x n_substeps inside
+// dm_control's composer.Environment.step, configured by
+// /root/reference/robopianist/suite/tasks/base.py:28,31,68-70 and reached from
+// suite/__init__.py:87-93.  The arithmetic follows MuJoCo's documented
+// pipeline; the CPU restatement used as the parity
+// oracle is oracle/rp_oracle.c (a generic, sequential, dense-J formulation).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RPK_WAVE 64
+#define RPK_NC 32        // max contacts kept per env (= RP_MAX_CONTACTS; contact c lives in lane c)
+#define RPK_NCOUT 32     // == RP_MAX_CONTACTS
+#define RPK_NE 256      // max contact Jacobian entries (contact, dof) handed to the solver
+#define RPK_NBOXF 26     // boxes covered by the oriented-box prefilter (fits the cdof scratch in fp32)
+#define RPK_HMAX 60      // max rows of the dense cross-coupling block (+1 row for its rhs = one lane each)
+#define RPK_WORK 128     // narrow-phase work list
+#define RPK_MAXD 9       // tree depth levels
+#define RPK_NL 52        // max links
+#define RPK_NKEYS 128    // max keys (2 slots per lane)
+#define RPK_KEYBASE 1000 // work-list / contact encoding of "key k" = RPK_KEYBASE + k
+
+#define JNT_SLIDE_ 2
+#define JNT_HINGE_ 3
+#define GEOM_CAPSULE_ 3
+#define GEOM_BOX_ 6
+
+// All model tables live in TWO device arrays (one of T, one of int) at compile-time
+// offsets (tables are padded to their maximum item counts).  A table access is then
+// `base pointer + immediate`, instead of one kernarg pointer load per table: with ~80
+// tables the pointers do not fit in SGPRs, and every re-load costs an s_waitcnt
+// lgkmcnt(0) that also drains the LDS queue.
+#define RPK_MAXACT 192
+#define RPK_MAXTREE 4
+//      name            items        stride
+#define RPK_FTABLES(X) \
+  X(link_lpos,        RPK_NL,      3) X(link_lmat,       RPK_NL,      9) X(link_axis,      RPK_NL, 3) \
+  X(link_anchor,      RPK_NL,      3) X(link_mass,       RPK_NL,      1) X(link_ipos,      RPK_NL, 3) \
+  X(link_inertia,     RPK_NL,      6) X(link_invw_body,  RPK_NL,      1) X(link_armature,  RPK_NL, 1) \
+  X(link_damping,     RPK_NL,      1) X(link_stiffness,  RPK_NL,      1) X(link_springref, RPK_NL, 1) \
+  X(link_floss,       RPK_NL,      1) X(link_fl_R,       RPK_NL,      1) X(link_fl_B,      RPK_NL, 1) \
+  X(link_range,       RPK_NL,      2) X(link_lim_K,      RPK_NL,      1) X(link_lim_B,     RPK_NL, 1) \
+  X(link_lim_solimp,  RPK_NL,      5) X(link_invw_dof,   RPK_NL,      1) X(link_act_coef,  RPK_NL, 1) \
+  X(link_gscale,      RPK_NL,      1) \
+  X(tree_gscale,      RPK_MAXTREE, 1) X(tree_ref,        RPK_MAXTREE, 3) \
+  X(key_pos,          RPK_NKEYS,   3) X(key_half,        RPK_NKEYS,   3) X(key_mass,       RPK_NKEYS, 1) \
+  X(key_M,            RPK_NKEYS,   1) X(key_stiffness,   RPK_NKEYS,   1) X(key_springref,  RPK_NKEYS, 1) \
+  X(key_damping,      RPK_NKEYS,   1) X(key_range,       RPK_NKEYS,   2) X(key_lim_K,      RPK_NKEYS, 1) \
+  X(key_lim_B,        RPK_NKEYS,   1) X(key_lim_solimp,  RPK_NKEYS,   5) X(key_invw_dof,   RPK_NKEYS, 1) \
+  X(key_invw_body,    RPK_NKEYS,   1) X(key_rbound,      RPK_NKEYS,   1) X(key_cparam,     1,         8) \
+  X(geom_size,        RPK_WAVE,    3) X(geom_pos,        RPK_WAVE,    3) X(geom_mat,       RPK_WAVE,  9) \
+  X(geom_rbound,      RPK_WAVE,    1) X(geom_invw,       RPK_WAVE,    1) X(geom_cparam,    RPK_WAVE,  8) \
+  X(act_coef,         RPK_MAXACT,  2) X(act_gain,        RPK_MAXACT,  1) X(act_bias,       RPK_MAXACT, 3) \
+  X(act_ctrlrange,    RPK_MAXACT,  2) X(act_forcerange,  RPK_MAXACT,  2) X(site_pos,       RPK_WAVE,  3)
+#define RPK_ITABLES(X) \
+  X(lane_topo,    RPK_NL, 16) \
+  X(link_parent,  RPK_NL, 1) X(link_depth,   RPK_NL, 1) X(link_tree,    RPK_NL, 1) X(link_jtype,  RPK_NL, 1) \
+  X(link_dof,     RPK_NL, 1) X(link_sibrank, RPK_NL, 1) X(link_limited, RPK_NL, 1) X(link_act,    RPK_NL, 1) \
+  X(link_ndesc,   RPK_NL, 1) X(link_anc,     RPK_NL, RPK_MAXD) X(link_ancmask, RPK_NL, 2) \
+  X(link_desc,    RPK_NL, RPK_MAXD * 5) X(level_maxrank, 1, RPK_MAXD) \
+  X(tree_base,    RPK_MAXTREE, 1) X(tree_trunk, RPK_MAXTREE, 1) X(chain_first, RPK_MAXTREE, 5) \
+  X(chain_len,    RPK_MAXTREE, 5) \
+  X(key_dof,      RPK_NKEYS, 1) X(key_act,   RPK_NKEYS, 1) X(key_geomid, RPK_NKEYS, 1) \
+  X(geom_link,    RPK_WAVE, 1) X(geom_type,  RPK_WAVE, 1) X(geom_modelid, RPK_WAVE, 1) \
+  X(geom_pairmask, RPK_WAVE, 2) X(geom_iskeycap, RPK_WAVE, 1) \
+  X(act_kind,     RPK_MAXACT, 1) X(act_lane, RPK_MAXACT, 2) X(act_ctrllimited, RPK_MAXACT, 1) \
+  X(act_forcelimited, RPK_MAXACT, 1) X(site_link, RPK_WAVE, 1)
+
+struct RpLayout {
+  enum : int {
+#define X(name, items, stride) F_##name, F_##name##_end = F_##name + (items) * (stride) - 1,
+    RPK_FTABLES(X)
+#undef X
+    F_TOTAL,
+#define X(name, items, stride) I_##name, I_##name##_end = I_##name + (items) * (stride) - 1,
+    RPK_ITABLES(X)
+#undef X
+    I_TOTAL
+  };
+};
+
+template <typename T>
+struct RpModel {
+  int nlink, ntree, maxdepth, nkey, ngeom, nu, nsite, nv;
+  int iterations, ls_iterations;
+  T timestep, gx, gy, gz, tolerance, ls_tolerance, meaninertia, key_zmax;
+  const T* ft;    // RpLayout::F_* offsets
+  const int* it;  // RpLayout::I_* offsets
+#define X(name, items, stride) \
+  __device__ __forceinline__ const T* name() const { return ft + RpLayout::F_##name; }
+  RPK_FTABLES(X)
+#undef X
+#define X(name, items, stride) \
+  __device__ __forceinline__ const int* name() const { return it + RpLayout::I_##name; }
+  RPK_ITABLES(X)
+#undef X
+  __device__ __forceinline__ const unsigned* link_ancmask_u() const {
+    return (const unsigned*)(it + RpLayout::I_link_ancmask);
+  }
+};
+
+template <typename T>
+struct RpState {
+  int nenv;
+  T *qpos, *qvel, *warm, *ctrl, *qfrc_applied, *time, *tree_offset;
+  T *act_force, *act_vel, *site_xpos, *contact_dist;
+  int *ncon, *contact_geoms, *warn, *solver_iter;
+  const int* active;    // may be null: envs with active[e]==0 are left untouched
+  uint32_t* key_trace;  // may be null
+  long long* prof;      // may be null: per-phase cycle counters (env 0)
+  int max_newton, max_ls;
+};
+
+// One workgroup == one wavefront, and a wave's LDS instructions execute in issue
+// order, so cross-lane LDS hand-offs need no s_barrier and no s_waitcnt drain: only
+// the compiler must be kept from reordering LDS accesses across the hand-off.
+#define WSYNC()                                              \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+  } while (0)
+#define RPK_NPROF 32
+// Per-phase shader-clock counters of env 0 (debug aid), accumulated in LDS so a probe
+// costs about one LDS round trip; flushed to global memory once at kernel exit.
+#ifdef RPK_MARK  // static analysis aid: phase boundaries as comments in the ISA listing
+#define PROF(i) asm volatile("; MARK " #i)
+#else
+#define PROF(i)                                                         \
+  do {                                                                  \
+    if (S.prof && env == 0) {                                           \
+      long long t_ = (long long)__builtin_readcyclecounter();           \
+      if (lane == 0) sm.prof[i] += (unsigned)(t_ - prof_t);                       \
+      prof_t = t_;                                                      \
+    }                                                                   \
+  } while (0)
+#endif
+
+// Hand-over between the position/velocity kernel (MODE 0) and the solver kernel
+// (MODE 1): everything `mj_step1` leaves behind for `mj_step2`, per env.  Lives in
+// HBM but is L2 / Infinity-Cache resident (<= 25 KB per env).
+#define RPK_NLF 29  // per-lane float fields
+#define RPK_NLI 12  // per-lane int fields
+template <typename T>
+struct RpStage {
+  T* RM;      // [E][RPK_NL][RPK_MAXD+1] mass-matrix rows
+  T* lanef;   // [E][RPK_NLF][64]
+  int* lanei; // [E][RPK_NLI][64]
+  int* hdr;   // [E][8]: ncon, nkt, dirty mask lo/hi, nent, max entries per contact
+  T* entJ;    // [E][RPK_NE][3]  contact Jacobian entries: d(contact point velocity)/d(qvel of one dof)
+  int* entM;  // [E][RPK_NE][2]  lane | contact<<6 | column<<11 | cross<<15 ; base | count<<8 | rank<<16
+  int* slots; // [E][64]: slotkey[16], slotlink[16], slotmask lo[16], hi[16]
+  int* keyslot; // [E][RPK_NKEYS/4] (packed signed char)
+};
