@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--engine-only", action="store_true", help="time rp_step alone (no obs/reward epilogue)")
     ap.add_argument("--dist-backend", default="nccl", help="debug: 'gloo' lets several ranks share one GPU")
     ap.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0")
+    ap.add_argument("--host-io", type=int, default=1,
+                    help="N=1: also time the loop with host-resident actions/TimeSteps (aux.host_io, PCIe inclusive)")
     ap.add_argument("--graph", type=int, default=0,
                     help="replay env.step from a captured hipGraph (wrappers.GraphedStepWrapper)")
     args = ap.parse_args()
@@ -209,8 +211,31 @@ def main():
         finite = bool(np.isfinite(q).all())
         ctrl_seq, _ = load_actions(m)
 
+        # PCIe-inclusive variant (aux only, never `value`): the caller keeps actions and
+        # TimeSteps in host memory -- a [E, 45] numpy action goes up and every TimeStep field
+        # (reward, discount, step type, all observations) comes back to numpy each step
+        host_io = None
+        if args.host_io and world == 1 and not args.engine_only and precision == args.precision:
+            act_host = np.ascontiguousarray(np.broadcast_to(actions[None, :, :], (E,) + actions.shape)
+                                            .transpose(1, 0, 2)).astype(np.float64)
+            n_io = min(40, T - 1)
+            env.reset()
+            barrier()
+            t1 = time.perf_counter()
+            nbytes = 0
+            for t in range(n_io):
+                ts = eager_env.step(act_host[t])
+                host = [ts.reward.cpu().numpy(), ts.discount.cpu().numpy(), ts.step_type.cpu().numpy()]
+                host += [v.cpu().numpy() for v in ts.observation.values()]
+                nbytes = sum(h.nbytes for h in host) + act_host[t].nbytes
+            barrier()
+            dt_io = time.perf_counter() - t1
+            host_io = {"value": E * n_io / dt_io, "unit": "env-steps/s", "steps": n_io,
+                       "bytes_per_step_over_pcie": int(nbytes),
+                       "note": "same env loop with the actions in host numpy arrays and every TimeStep field "
+                               "copied back to numpy (pageable memory, synchronous copies) each step"}
 
-        return dict(dt=dt, kms=kms, nl=nl, sms=sms, snl=snl, warn=warn, finite=finite, phys=phys, m=m,
+        return dict(host_io=host_io, dt=dt, kms=kms, nl=nl, sms=sms, snl=snl, warn=warn, finite=finite, phys=phys, m=m,
                     ctrl_seq=ctrl_seq, E=E, key_ids=base_env.task.scene.key_joint_ids, graphed=bool(use_graph and env.graph_captured))
 
     r = measure(args.precision, args.steps, args.warmup)
@@ -264,13 +289,15 @@ def main():
                       "tests/test_gpu_parity.py::test_replay_fp64_1000_steps; fp32 engine diverges on this "
                       "(chaotic, self-colliding) replay and is reported under aux only",
         }
+        if r.get("host_io"):
+            out.setdefault("aux", {})["host_io"] = r["host_io"]
         if args.aux_fp32 and args.precision == 64 and world == 1:
             del r, phys
             r32 = measure(32, min(args.steps, 80), min(args.warmup, 10))
-            out["aux"] = {"fp32_engine": {
+            out.setdefault("aux", {})["fp32_engine"] = {
                 "value": E * min(args.steps, 80) / r32["dt"], "unit": "env-steps/s", "kernel_avg_ms": r32["kms"],
                 "warn_flags": r32["warn"],
-                "note": "same workload on the fp32 build; meets 1e-4 on smooth key-press scenarios only"}}
+                "note": "same workload on the fp32 build; meets 1e-4 on smooth key-press scenarios only"}
             phys = r32["phys"]
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             from oracle.rp_oracle import Oracle
