@@ -117,3 +117,39 @@ def test_blob_round_trip_and_engine_tables(two_hand_scene):
             for k in desc[i, d]:
                 if k >= 0:
                     assert anc[k][t["eng_link_depth"][i]] == i and t["eng_link_depth"][k] == d
+
+
+def test_welded_bodies_are_fused_into_their_parent_links():
+    """reduced_action_space removes three joints per hand (shadow_hand.py:73-77,162-171): the
+    finger segments that lose their joint stay rigidly attached to their parent.  The engine
+    tables fuse them: link mass / first moment add up to the bodies', every hand geom and site
+    still maps to a link, and geoms of a welded body carry the static offset."""
+    import warnings
+    from robopianist_amd.model import scene, spec
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        si = scene.build_scene(reduced_action_space=True, primitive_fingertip_collisions=True)
+    m = si.model
+    t = engine_tables.build_engine_tables(m, si.key_joint_ids)
+    nl = int(t["eng_nlink"][0])
+    assert nl == 2 * (21 + 2)
+    hand_bodies = [b for b in range(1, m.nbody) if m.body_weldid[b] != 0 and b not in set(si.key_body_ids)]
+    welded = [b for b in hand_bodies if m.body_jntnum[b] == 0]
+    assert len(welded) == 6  # thbase/thhub..., thdistal, lfmetacarpal per hand
+    np.testing.assert_allclose(t["eng_link_mass"].sum(), m.body_mass[hand_bodies].sum(), rtol=1e-14)
+    # every fingertip site still resolves to a link
+    assert int(t["eng_nsite"][0]) >= 10 and (t["eng_site_link"] >= 0).all()
+    # world pose of a welded body's geom through the tables == through the body tree, at qpos0
+    kin = mc.kinematics(m, m.qpos0)
+    checked = 0
+    for i, g in enumerate(t["eng_geom_modelid"]):
+        b = int(m.geom_bodyid[g])
+        if b in welded:
+            a = b
+            while m.body_jntnum[a] == 0:
+                a = int(m.body_parentid[a])
+            want = kin["xpos"][b] + kin["xmat"][b] @ m.geom_pos[g]
+            got = kin["xpos"][a] + kin["xmat"][a] @ t["eng_geom_pos"][i]
+            np.testing.assert_allclose(got, want, atol=1e-14)
+            checked += 1
+    assert checked >= 2  # the fingertip capsules of the welded thumb distal segments
