@@ -317,16 +317,30 @@ def main():
             from robopianist_amd import engine as _eng
             chk = _eng.BatchedPhysics(m, base_key_ids, n_envs=2, precision=args.precision)
             orc.reset()
-            worst = 0.0
+            worst, worst_abs = 0.0, 0.0
+            # dof groups of SURVEY.md 8(d) metric 2: keys (88), forearm joints (2 per hand), fingers+wrists
+            is_key = np.zeros(int(m.nv), bool); is_key[np.asarray(base_key_ids)] = True
+            is_arm = np.array(["forearm" in n for n in m.names["joint"]])
+            groups = {"keys": is_key, "forearms": is_arm & ~is_key, "fingers_and_wrists": ~is_key & ~is_arm}
+            gmax = {k: 0.0 for k in groups}
+            curve = {}
             for i in range(1000):
                 c = ctrl_seq[(i // args.substeps) % ctrl_seq.shape[0]]
                 chk.set(_eng.CTRL, c[None, :]); orc.ctrl[:] = c
                 chk.step(1); orc.step(1)
                 qg = chk.qpos.astype(np.float64)[0]
-                worst = max(worst, float((np.abs(qg - orc.qpos) / np.maximum(np.abs(orc.qpos), 1e-2)).max()))
+                ad = np.abs(qg - orc.qpos)
+                rel = ad / np.maximum(np.abs(orc.qpos), 1e-2)
+                worst = max(worst, float(rel.max())); worst_abs = max(worst_abs, float(ad.max()))
+                for k, sel in groups.items():
+                    gmax[k] = max(gmax[k], float(rel[sel].max()))
+                if i + 1 in (1, 10, 100, 300, 1000):
+                    curve[str(i + 1)] = float(rel.max())
             out["cpu_baseline_parity"] = {
-                "max_rel_qpos_error_1000_mj_steps": worst, "bar": 1e-4,
-                "note": "engine (2 envs, same precision as value) vs the CPU oracle, scripted replay, free running"}
+                "max_rel_qpos_error_1000_mj_steps": worst, "max_abs_qpos_error_1000_mj_steps": worst_abs,
+                "bar": 1e-4, "rel_error_at_mj_step": curve, "max_rel_error_by_dof_group": gmax,
+                "note": "engine (2 envs, same precision as value) vs the CPU oracle, scripted replay, free running; "
+                        "rel = |dq| / max(|q_cpu|, 1e-2)"}
             out["cpu_baseline"] = {
                 "value": nenv_cpu * nstep / args.substeps / secs, "unit": "env-steps/s",
                 "cores": cores, "kind": "port",
