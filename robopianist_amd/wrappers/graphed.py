@@ -14,7 +14,8 @@ Semantics: identical to the wrapped env, with two documented differences --
   * the first `warmup_steps` calls run eagerly (PyTorch needs every kernel loaded before a
     capture), the capture happens on the next call.
 Not capturable (raises): n_envs == 1 (host-side dm_env reset rule), hand-position
-randomisation (host RNG per episode), key-trace recording to a host buffer.
+randomisation and MIDI augmentations (host work per episode), key-trace recording to a host
+buffer.
 """
 
 from __future__ import annotations
@@ -37,6 +38,9 @@ class GraphedStepWrapper:
             raise ValueError("GraphedStepWrapper needs n_envs > 1 (the single-env reset rule reads the host)")
         if getattr(base.task, "_randomize_hand_positions", False):
             raise ValueError("hand-position randomisation draws from the host RNG and cannot be captured")
+        if getattr(base.task, "needs_host_episode_setup", False):
+            raise ValueError("MIDI augmentations regenerate goal tables on the host at episode starts "
+                             "and cannot be captured")
 
     def __getattr__(self, name):
         return getattr(self._environment, name)
