@@ -268,8 +268,8 @@ struct Engine : EngineBase {
     B.lanef = dalloc<T>(E * RPK_NLF * 64);
     B.lanei = dalloc<int>(E * RPK_NLI * 64);
     B.hdr = dalloc<int>(E * 8);
-    B.entJ = dalloc<T>(E * RPK_NE * 3);
-    B.entM = dalloc<int>(E * RPK_NE * 2);
+    B.entJ = dalloc<T>(E * RpCaps<T>::NE * 3);
+    B.entM = dalloc<int>(E * RpCaps<T>::NE * 2);
     B.slots = dalloc<int>(E * 64);
     B.keyslot = dalloc<int>(E * (RPK_NKEYS / 4));
     // hand-over buffers start as NaN / -1 patterns: a read of anything the position kernel
@@ -278,8 +278,8 @@ struct Engine : EngineBase {
     hipMemset(B.lanef, 0xFF, sizeof(T) * E * RPK_NLF * 64);
     hipMemset(B.lanei, 0xFF, sizeof(int) * E * RPK_NLI * 64);
     hipMemset(B.hdr, 0xFF, sizeof(int) * E * 8);
-    hipMemset(B.entJ, 0xFF, sizeof(T) * E * RPK_NE * 3);
-    hipMemset(B.entM, 0xFF, sizeof(int) * E * RPK_NE * 2);
+    hipMemset(B.entJ, 0xFF, sizeof(T) * E * RpCaps<T>::NE * 3);
+    hipMemset(B.entM, 0xFF, sizeof(int) * E * RpCaps<T>::NE * 2);
     hipMemset(B.slots, 0xFF, sizeof(int) * E * 64);
     hipMemset(B.keyslot, 0xFF, sizeof(int) * E * (RPK_NKEYS / 4));
     S.key_trace = nullptr;

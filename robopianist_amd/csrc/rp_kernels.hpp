@@ -63,11 +63,11 @@ struct Smem<T, 1> : SmemShared<T> {
   T R[RPK_WAVE][RPK_MAXD + 1];  // tree factor rows (L), incl. key-leaf rows
   T Dg[RPK_WAVE];               // tree factor diagonal
   T xs[RPK_WAVE];               // solve staging
-  T H[(RPK_HMAX + 1) * (RPK_HMAX + 2) / 2];  // dense block of the cross-coupled rows + rhs row
+  T H[(RpCaps<T>::HMAX + 1) * (RpCaps<T>::HMAX + 2) / 2];  // dense block of the cross-coupled rows + rhs row
   T RM[RPK_NL][RPK_MAXD + 1];   // mass-matrix rows: RM[i][e] = M[i][anc_e(i)]
   T keyvec[2][RPK_NKEYS];
-  T entJ[RPK_NE][3];            // contact Jacobian entries (see RpStage)
-  int entM[RPK_NE][2];
+  T entJ[RpCaps<T>::NE][3];            // contact Jacobian entries (see RpStage)
+  int entM[RpCaps<T>::NE][2];
   T cC[RPK_NC][6];              // per-contact 3x3 weight of the current Newton iteration
   T cv[RPK_NC][3];              // per-contact 3-vector staging (J x, or the contact force)
   T jt[RPK_WAVE];               // J^T f staging, one value per solver row
@@ -101,7 +101,7 @@ __global__ void rp_reset_kernel(RpState<T> S, const T* qpos0, const unsigned cha
 // The host launches  pos, then n_substeps x (sol, pos);  RpStage carries the hand-over.
 // ============================================================================
 template <typename T, int MODE, int FIXED_TL = 0>
-__global__ __launch_bounds__(64, MODE == 0 ? 2 : 1) void rp_stage_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep,
+__global__ __launch_bounds__(64, (MODE == 0 || sizeof(T) == 4) ? 2 : 1) void rp_stage_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep,
                                                      int nsub) {
   using namespace rpk;
   using N = Num<T>;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64, MODE == 0 ? 2 : 1) void rp_stage_kernel(RpModel
           }
         }
         for (int i = lane; i < nent; i += 64) {
-          const size_t e = (size_t)env * RPK_NE + i;
+          const size_t e = (size_t)env * RpCaps<T>::NE + i;
           sm.entJ[i][0] = B.entJ[e * 3]; sm.entJ[i][1] = B.entJ[e * 3 + 1]; sm.entJ[i][2] = B.entJ[e * 3 + 2];
           sm.entM[i][0] = B.entM[e * 2]; sm.entM[i][1] = B.entM[e * 2 + 1];
         }
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(64, MODE == 0 ? 2 : 1) void rp_stage_kernel(RpModel
         WSYNC();
         PROF(21);
         // ---- dense block on the dirty rows (Schur complement + cross-contact terms)
-        if (dm && __popcll(dm) > RPK_HMAX) { warn |= 32; dm = 0; }  // cannot hold the block: drop cross terms
+        if (dm && __popcll(dm) > RpCaps<T>::HMAX) { warn |= 32; dm = 0; }  // cannot hold the block: drop cross terms
         if (dm) {
           T x = (isl || isslot) ? sm.xs[lane] : (T)0;
           WSYNC();
@@ -1643,7 +1643,7 @@ __global__ __launch_bounds__(64, MODE == 0 ? 2 : 1) void rp_stage_kernel(RpModel
       }
       int cnt = __popcll(sup), base = 0;
       for (int c2 = 0; c2 < ncon; c2++) { const int b2 = bcast(cnt, c2); if (c2 < lane) base += b2; }
-      if (lane < ncon && base + cnt > RPK_NE) { cnt = 0; sup = 0; warn |= 2; con_D = 0; }  // dropped
+      if (lane < ncon && base + cnt > RpCaps<T>::NE) { cnt = 0; sup = 0; warn |= 2; con_D = 0; }  // dropped
       const int nent = wave_max(lane < ncon ? base + cnt : 0), maxm = wave_max(cnt);
       LI(10) = base | (cnt << 8);
       if (lane == 0) { B.hdr[env * 8 + 4] = nent; B.hdr[env * 8 + 5] = maxm; }
@@ -1687,7 +1687,7 @@ __global__ __launch_bounds__(64, MODE == 0 ? 2 : 1) void rp_stage_kernel(RpModel
           }
           lds_add(&sm.cv[c][0], j3[0] * xv); lds_add(&sm.cv[c][1], j3[1] * xv); lds_add(&sm.cv[c][2], j3[2] * xv);
           const int rank = __popcll(sc & lanemask_lt(lane));
-          const size_t e = (size_t)env * RPK_NE + cb + rank;
+          const size_t e = (size_t)env * RpCaps<T>::NE + cb + rank;
           B.entJ[e * 3] = j3[0]; B.entJ[e * 3 + 1] = j3[1]; B.entJ[e * 3 + 2] = j3[2];
           B.entM[e * 2] = lane | (c << 6) | (mycol << 11) | (cx << 15);
           B.entM[e * 2 + 1] = cb | (cc << 8) | (rank << 16);

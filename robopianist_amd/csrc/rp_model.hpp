@@ -22,9 +22,9 @@
 #define RPK_WAVE 64
 #define RPK_NC 32        // max contacts kept per env (= RP_MAX_CONTACTS; contact c lives in lane c)
 #define RPK_NCOUT 32     // == RP_MAX_CONTACTS
-#define RPK_NE 256      // max contact Jacobian entries (contact, dof) handed to the solver
+#define RPK_NE 256      // max contact Jacobian entries (contact, dof) handed to the solver (fp64; see RpCaps)
 #define RPK_NBOXF 26     // boxes covered by the oriented-box prefilter (fits the cdof scratch in fp32)
-#define RPK_HMAX 60      // max rows of the dense cross-coupling block (+1 row for its rhs = one lane each)
+#define RPK_HMAX 60      // max rows of the dense cross-coupling block (+1 row for its rhs = one lane each; fp64)
 #define RPK_WORK 128     // narrow-phase work list
 #define RPK_MAXD 9       // tree depth levels
 #define RPK_NL 52        // max links
@@ -88,6 +88,15 @@ struct RpLayout {
 #undef X
     I_TOTAL
   };
+};
+
+// Solver capacities per precision.  The fp32 solver stage is sized to fit two workgroups per
+// SIMD (LDS <= 20 KB, 256 registers): measured 0.50 -> 0.35 ms per launch.  The fp64 stage
+// cannot (40 KB, ~500 registers) and keeps the larger capacities.
+template <typename T>
+struct RpCaps {
+  static constexpr int NE = sizeof(T) == 4 ? 240 : RPK_NE;
+  static constexpr int HMAX = sizeof(T) == 4 ? 56 : RPK_HMAX;
 };
 
 template <typename T>
@@ -157,8 +166,8 @@ struct RpStage {
   T* lanef;   // [E][RPK_NLF][64]
   int* lanei; // [E][RPK_NLI][64]
   int* hdr;   // [E][8]: ncon, nkt, dirty mask lo/hi, nent, max entries per contact
-  T* entJ;    // [E][RPK_NE][3]  contact Jacobian entries: d(contact point velocity)/d(qvel of one dof)
-  int* entM;  // [E][RPK_NE][2]  lane | contact<<6 | column<<11 | cross<<15 ; base | count<<8 | rank<<16
+  T* entJ;    // [E][RpCaps<T>::NE][3]  contact Jacobian entries: d(contact point velocity)/d(qvel of one dof)
+  int* entM;  // [E][RpCaps<T>::NE][2]  lane | contact<<6 | column<<11 | cross<<15 ; base | count<<8 | rank<<16
   int* slots; // [E][64]: slotkey[16], slotlink[16], slotmask lo[16], hi[16]
   int* keyslot; // [E][RPK_NKEYS/4] (packed signed char)
 };
