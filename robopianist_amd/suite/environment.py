@@ -142,6 +142,20 @@ class Environment:
         self._needs_reset.copy_(terminate)  # in place: the step is hipGraph-capturable
         return self._fresh(TimeStep(st, reward, discount, obs))
 
+    # -- checkpoint / resume -----------------------------------------------------------
+    def state_dict(self):
+        """Snapshot from which `load_state_dict` continues the rollout bit for bit: engine
+        state, task / piano episode state, the pending-reset flags and the host RandomState."""
+        return {"physics": self._physics.state_dict(), "task": self._task.state_dict(),
+                "needs_reset": self._needs_reset.detach().clone(),
+                "random_state": self._random_state.get_state()}
+
+    def load_state_dict(self, sd):
+        self._task.load_state_dict(sd["task"])
+        self._physics.load_state_dict(sd["physics"])
+        self._needs_reset.copy_(sd["needs_reset"].to(self._needs_reset.device))
+        self._random_state.set_state(sd["random_state"])
+
     def _fresh(self, ts: TimeStep) -> TimeStep:
         """dm_env hands out arrays the caller may keep; the task state behind them is
         updated in place, so the TimeStep gets its own copies (`copy_outputs=False` hands

@@ -79,6 +79,31 @@ class TorchPhysics:
     def set_active(self, mask: torch.Tensor):
         self._active.copy_(mask.to(torch.int32))
 
+    # -- checkpoint / resume -----------------------------------------------------
+    _STATE_FIELDS = ("qpos", "qvel", "qacc_warmstart", "ctrl", "qfrc_applied", "time", "tree_offset")
+
+    def _state_views(self):
+        if not hasattr(self, "_warm"):
+            self._warm = self.engine.view(eng.QACC_WARMSTART)
+        v = {"qpos": self.qpos, "qvel": self.qvel, "qacc_warmstart": self._warm, "ctrl": self._ctrl,
+             "qfrc_applied": self._qfrc_applied, "time": self.time}
+        if self._tree_offset is not None:
+            v["tree_offset"] = self._tree_offset
+        return v
+
+    def state_dict(self):
+        """Everything mj_step reads: qpos, qvel, qacc_warmstart, ctrl, qfrc_applied, time (and the
+        per-env hand offsets).  Derived arrays (contacts, site positions, actuator velocities) are
+        recomputed by `load_state_dict` with physics.forward()."""
+        return {k: v.detach().clone() for k, v in self._state_views().items()}
+
+    def load_state_dict(self, sd):
+        views = self._state_views()
+        for k, v in views.items():
+            v.copy_(sd[k].to(device=self.device, dtype=v.dtype))
+        self._active.fill_(1)
+        self.engine.forward()
+
     # -- stepping --------------------------------------------------------------
     def reset(self, mask=None):
         if mask is not None:

@@ -86,6 +86,15 @@ class Piano:
             torch.le(torch.abs(self._state - self._qpos_range[:, 1]), _KEY_THRESHOLD, out=self._activation)
         torch.ge(self._sustain_state, _SUSTAIN_THRESHOLD, out=self._sustain_activation)
 
+    _STATE = ("_state", "_sustain_state", "_activation", "_sustain_activation", "_normalized_state")
+
+    def state_dict(self):
+        return {k: getattr(self, k).detach().clone() for k in self._STATE}
+
+    def load_state_dict(self, sd):
+        for k in self._STATE:
+            getattr(self, k).copy_(sd[k].to(getattr(self, k).device))
+
     def apply_sustain(self, sustain):
         self._sustain_state.copy_(sustain.reshape(self._E, 1))
 

@@ -248,6 +248,38 @@ class PianoWithShadowHands(base.PianoTask):
             self._should_terminate.masked_fill_(mask, False)
             self._discount.masked_fill_(mask, 1.0)
 
+    # -- checkpoint / resume ------------------------------------------------------------
+    _STATE = ("_t_idx", "_should_terminate", "_discount", "_goal_state", "_goal_current", "_finger_next",
+              "_finger_current", "_fingering_state", "_failure_termination")
+
+    def state_dict(self):
+        """Episode state of every env (the reference keeps it in Python ints / arrays:
+        piano_with_shadow_hands.py:146-149, piano.py:166-171), incl. the per-env goal bank when
+        MIDI augmentations are on."""
+        sd = {k: getattr(self, k).detach().clone() for k in self._STATE}
+        sd["piano"] = self.piano.state_dict()
+        if self._augmentations is not None:
+            for k in ("_goal_bank", "_finger_bank", "_song_len"):
+                sd[k] = getattr(self, k).detach().clone()
+        if hasattr(self, "_tree_offset"):
+            sd["_tree_offset"] = self._tree_offset.detach().clone()
+        return sd
+
+    def load_state_dict(self, sd):
+        dev = self._physics_device
+        for k in self._STATE:
+            getattr(self, k).copy_(sd[k].to(dev))
+        self.piano.load_state_dict(sd["piano"])
+        if self._augmentations is not None:
+            # the bank may have a different capacity: swap it in (the fused launch holds raw
+            # pointers and is rebuilt on next use)
+            self._goal_bank = sd["_goal_bank"].to(dev).clone()
+            self._finger_bank = sd["_finger_bank"].to(dev).clone()
+            self._song_len.copy_(sd["_song_len"].to(dev))
+            self._fused_advance = None
+        if "_tree_offset" in sd:
+            self._tree_offset = sd["_tree_offset"].to(dev).clone()
+
     # -- composer-style hooks --------------------------------------------------------
     def initialize_episode(self, physics, mask=None) -> None:
         """:167-174 for the envs selected by `mask` (None = all)."""

@@ -79,6 +79,18 @@ class SelfActuatedPiano(base.PianoOnlyTask):
             self._t_idx[mask] = 0
             self._should_terminate[mask] = False
 
+    _STATE = ("_t_idx", "_should_terminate", "_goal_state", "_goal_current")
+
+    def state_dict(self):
+        sd = {k: getattr(self, k).detach().clone() for k in self._STATE}
+        sd["piano"] = self.piano.state_dict()
+        return sd
+
+    def load_state_dict(self, sd):
+        for k in self._STATE:
+            setattr(self, k, sd[k].to(self._physics_device).clone())
+        self.piano.load_state_dict(sd["piano"])
+
     def initialize_episode(self, physics, mask=None):
         self._reset_quantities_at_episode_init(mask)
         self.piano.initialize_episode(physics, mask)

@@ -62,3 +62,11 @@ class FakePhysics:
     def step(self, n, key_trace=None):
         self.n_steps += n
         self.time = self.time + self.active.to(self.dtype) * n * self.timestep
+
+    def state_dict(self):
+        return {"qpos": self.qpos.clone(), "qvel": self.qvel.clone(), "ctrl": self._ctrl.clone(),
+                "time": self.time.clone()}
+
+    def load_state_dict(self, sd):
+        self.qpos.copy_(sd["qpos"]); self.qvel.copy_(sd["qvel"]); self._ctrl.copy_(sd["ctrl"])
+        self.time.copy_(sd["time"])

@@ -395,6 +395,57 @@ def test_one_hand_task_on_the_engine(side):
     assert float(terms["energy_reward"].max()) <= 0.0
 
 
+@pytest.mark.parametrize("augment", [False, True])
+def test_checkpoint_resume_is_bitwise(augment):
+    """Environment.state_dict / load_state_dict (SURVEY.md §5 checkpoint/resume): a second env
+    restored from a mid-episode snapshot continues the rollout bit for bit -- physics state
+    (qpos, qvel, warm start), rewards, observations, across episode ends, with and without
+    per-episode MIDI augmentations (the snapshot carries the per-env goal bank and the host
+    RandomState)."""
+    import os
+    from robopianist_amd import suite
+    from robopianist_amd.suite import variations
+    from robopianist_amd.wrappers import CanonicalSpecWrapper
+    actions = np.load(os.path.join(os.path.dirname(__file__), "golden", "twinkle_twinkle_actions.npy"))
+    E = 6
+
+    def make():
+        augs = [variations.MidiTemporalStretch(prob=1.0, stretch_range=0.3),
+                variations.MidiPitchShift(prob=0.5, shift_range=4)] if augment else None
+        return CanonicalSpecWrapper(suite.load(
+            "RoboPianist-debug-TwinkleTwinkleRousseau-v0", seed=4, n_envs=E, precision=64,
+            task_kwargs=dict(trim_silence=True, control_timestep=0.05, gravity_compensation=True,
+                             primitive_fingertip_collisions=True, n_steps_lookahead=2,
+                             augmentations=augs)))
+    a = make()
+    a.reset()
+    if augment:
+        a.task._t_idx[1] = int(a.task._song_len[1]) - 50   # this env ends (and re-draws) after the snapshot
+    else:
+        a.task._t_idx[1] = 158 - 50
+    dev = a.physics.device
+    act = lambda t: torch.as_tensor(actions[t % len(actions)], device=dev, dtype=torch.float64).expand(E, -1)
+    for t in range(30):
+        a.step(act(t))
+    snap = a.state_dict()
+    b = make()
+    b.reset()
+    b.load_state_dict(snap)
+    n_first = 0
+    for t in range(30, 70):
+        ta, tb = a.step(act(t)), b.step(act(t))
+        assert torch.equal(ta.step_type, tb.step_type), t
+        assert torch.equal(ta.reward, tb.reward), t
+        assert torch.equal(ta.discount, tb.discount), t
+        for k in ta.observation:
+            assert torch.equal(ta.observation[k], tb.observation[k]), (k, t)
+        assert torch.equal(a.physics.qpos, b.physics.qpos) and torch.equal(a.physics.qvel, b.physics.qvel), t
+        n_first += int((ta.step_type == 0).sum())
+    assert n_first >= 1, "an episode boundary was crossed after the restore"
+    if augment:
+        assert torch.equal(a.task._song_len, b.task._song_len)
+
+
 def test_rollouts_are_bitwise_reproducible_and_batch_invariant():
     """Identical envs stay bitwise identical (the LDS-add reductions of the solver have a
     fixed order), a re-run reproduces the same bits, and an env's trajectory does not depend

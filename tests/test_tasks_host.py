@@ -325,3 +325,32 @@ def test_reduced_action_space_is_39_dimensional():
     m = task.scene.model
     a = m.names["actuator"].index("rh_shadow_hand/rh_A_THJ2")
     np.testing.assert_allclose(m.actuator_ctrlrange[a], (0.0, 0.698132))
+
+
+def test_state_dict_round_trip_continues_the_episode_identically():
+    """Checkpoint / resume of the host-side episode state: a fresh env loaded
+    from a snapshot hands out the same TimeSteps as the env that kept running."""
+    midi = music.load("CMajorScaleTwoHands")
+    def make():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            task = piano_with_shadow_hands.PianoWithShadowHands(
+                midi=midi, n_steps_lookahead=3, control_timestep=0.05, change_color_on_activation=True)
+        return environment.Environment(task, n_envs=3, random_state=5, physics=FakePhysics(task.scene, 3))
+    a = make()
+    a.reset()
+    rng = np.random.RandomState(0)
+    acts = rng.uniform(-0.1, 0.1, size=(12, 3, 45))
+    for t in range(6):
+        a.step(acts[t])
+    snap = a.state_dict()
+    b = make()
+    b.reset()
+    b.load_state_dict(snap)
+    for t in range(6, 12):
+        ta, tb = a.step(acts[t]), b.step(acts[t])
+        assert torch.equal(ta.step_type, tb.step_type)
+        assert torch.equal(ta.reward, tb.reward) and torch.equal(ta.discount, tb.discount)
+        for k in ta.observation:
+            assert torch.equal(ta.observation[k], tb.observation[k]), k
+    assert torch.equal(a.task._t_idx, b.task._t_idx) and int(a.task._t_idx[0]) == 12
