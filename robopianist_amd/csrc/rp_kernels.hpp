@@ -1476,7 +1476,9 @@ __global__ __launch_bounds__(64, (MODE == 0 || sizeof(T) == 4) ? 2 : 1) void rp_
         bool has = n > slot;
         unsigned long long mk = __ballot(has);
         int idx = ncon + __popcll(mk & lanemask_lt(lane));
-        if (has && idx < RPK_NC) {
+        // writes this lane's contact `slot` into contact record `at`
+        auto emit = [&](int at) {
+          const int idx = at;
           const T* pA = M.geom_cparam() + 8 * ga;
           T solref0 = (T)0.5 * (pA[0] + pB[0]), solref1 = (T)0.5 * (pA[1] + pB[1]);
           T solimp[5];
@@ -1501,6 +1503,27 @@ __global__ __launch_bounds__(64, (MODE == 0 || sizeof(T) == 4) ? 2 : 1) void rp_
           sm.cB[idx] = gb >= RPK_KEYBASE ? gb : M.geom_link()[gb];
           sm.cgA[idx] = M.geom_modelid()[ga];
           sm.cgB[idx] = gb >= RPK_KEYBASE ? M.key_geomid()[gb - RPK_KEYBASE] : M.geom_modelid()[gb];
+        };
+        if (has && idx < RPK_NC) emit(idx);
+        if (ncon + __popcll(mk) > RPK_NC) {
+          // capacity overflow (rare; RP_WARN_CONTACT_FULL is raised below): keep the deepest
+          // contacts -- one that does not fit replaces the shallowest stored contact if it
+          // penetrates more.  Uniform loop, one overflowing lane at a time.
+          WSYNC();
+          unsigned long long ovm = __ballot(has && idx >= RPK_NC);
+          while (ovm) {
+            const int L = __ffsll((long long)ovm) - 1;
+            ovm &= ovm - 1;
+            const T dL = bcast(rc[slot].dist, L);
+            T worst = sm.cdist[0];
+            int wi = 0;
+            for (int c = 1; c < RPK_NC; c++) {
+              const T d = sm.cdist[c];
+              if (d > worst) { worst = d; wi = c; }
+            }
+            if (dL < worst && lane == L) emit(wi);
+            WSYNC();
+          }
         }
         ncon += __popcll(mk);
       }
