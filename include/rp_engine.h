@@ -58,7 +58,7 @@ typedef enum {
 
 #define RP_WARN_BADSTATE 1     /* NaN / |q|>1e10 in qpos or qvel */
 #define RP_WARN_CONTACT_FULL 2 /* more than 32 simultaneous contacts (or 256 contact Jacobian
-                                  entries; 240 in the fp32 build) in one env; the deepest 32 contacts are kept */
+                                  entries; 240 in the fp32 build) in one env; the deepest contacts are kept */
 #define RP_WARN_HESSIAN 4      /* non-positive pivot in the Newton Hessian */
 #define RP_WARN_KEYSLOT_FULL 8 /* more simultaneously touched keys than solver slots */
 #define RP_WARN_WORK_FULL 16   /* narrow-phase work list overflow */

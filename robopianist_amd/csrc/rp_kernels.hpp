@@ -1664,9 +1664,26 @@ __global__ __launch_bounds__(64, (MODE == 0 || sizeof(T) == 4) ? 2 : 1) void rp_
         sup = con_maskA | con_maskB;
         if (con_slot >= 0) sup |= 1ull << (nl + con_slot);
       }
-      int cnt = __popcll(sup), base = 0;
-      for (int c2 = 0; c2 < ncon; c2++) { const int b2 = bcast(cnt, c2); if (c2 < lane) base += b2; }
-      if (lane < ncon && base + cnt > RpCaps<T>::NE) { cnt = 0; sup = 0; warn |= 2; con_D = 0; }  // dropped
+      int cnt = __popcll(sup), base = 0, tot = 0;
+      for (int c2 = 0; c2 < ncon; c2++) { const int b2 = bcast(cnt, c2); if (c2 < lane) base += b2; tot += b2; }
+      if (tot > RpCaps<T>::NE) {
+        // entry capacity overflow (rare: hand-hand pile-ups, ~14 entries per contact): drop the
+        // shallowest contacts until the rest fits.  Uniform loops.
+        warn |= 2;
+        while (tot > RpCaps<T>::NE) {
+          int wi = 0;
+          T worst = 0;
+          bool any = false;
+          for (int c2 = 0; c2 < ncon; c2++) {
+            const T d2 = bcast(con_dist, c2);
+            if (bcast(cnt, c2) > 0 && (!any || d2 > worst)) { worst = d2; wi = c2; any = true; }
+          }
+          tot -= bcast(cnt, wi);
+          if (lane == wi) { cnt = 0; sup = 0; con_D = 0; }
+        }
+        base = 0;
+        for (int c2 = 0; c2 < ncon; c2++) { const int b2 = bcast(cnt, c2); if (c2 < lane) base += b2; }
+      }
       const int nent = wave_max(lane < ncon ? base + cnt : 0), maxm = wave_max(cnt);
       LI(10) = base | (cnt << 8);
       if (lane == 0) { B.hdr[env * 8 + 4] = nent; B.hdr[env * 8 + 5] = maxm; }
