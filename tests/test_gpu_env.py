@@ -446,6 +446,34 @@ def test_checkpoint_resume_is_bitwise(augment):
         assert torch.equal(a.task._song_len, b.task._song_len)
 
 
+def test_uniformly_random_actions_do_not_diverge():
+    """BASELINE config 3's policy (i.i.d. uniform actions every step) at 8192 envs: hands
+    swing into each other at ~18 rad/s and pile up more contacts / Jacobian entries than the
+    kernels hold.  Capacity overflow keeps the deepest contacts, so no env may diverge (with
+    drop-in-emission-order this very run lost 20 envs), and the overflow path is exercised."""
+    from robopianist_amd import suite
+    from robopianist_amd.wrappers import CanonicalSpecWrapper
+    E = 8192
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        env = CanonicalSpecWrapper(suite.load(
+            "RoboPianist-debug-TwinkleTwinkleRousseau-v0", seed=E, n_envs=E, precision=64,
+            task_kwargs=dict(trim_silence=True, control_timestep=0.05, gravity_compensation=True,
+                             primitive_fingertip_collisions=True)))
+    env.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(E)
+    ever = torch.zeros(E, dtype=torch.int32, device="cuda")
+    for _ in range(120):
+        a = torch.rand((E, 45), generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+        ts = env.step(a)
+        ever |= env.physics.warn
+        assert torch.isfinite(ts.reward).all()
+    assert int((ever & 1).sum()) == 0, "diverged envs"
+    assert int((ever & 4).sum()) == 0, "clamped Hessian pivots"
+    assert int((ever & 2).sum()) > 0, "the capacity-overflow path was meant to be exercised"
+    assert torch.isfinite(env.physics.qpos).all()
+
+
 def test_rollouts_are_bitwise_reproducible_and_batch_invariant():
     """Identical envs stay bitwise identical (the LDS-add reductions of the solver have a
     fixed order), a re-run reproduces the same bits, and an env's trajectory does not depend
