@@ -46,8 +46,7 @@ class SelfActuatedPiano(base.PianoOnlyTask):
                  trim_silence: bool = False, reward_type: RewardType = RewardType.NEGATIVE_L2,
                  augmentations=None, **kwargs) -> None:
         super().__init__(add_piano_actuators=True, **kwargs)
-        if augmentations is not None:
-            raise NotImplementedError("MIDI augmentations are a next-row item.")
+        self._augmentations = list(augmentations) if augmentations is not None else None
         if trim_silence:
             midi = midi.trim_silence()
         self._midi = midi
@@ -62,8 +61,14 @@ class SelfActuatedPiano(base.PianoOnlyTask):
     def bind(self, physics, n_envs, random_state):
         super().bind(physics, n_envs, random_state)
         dev = physics.device
-        self._goal_table = torch.as_tensor(self._goal_np, device=dev, dtype=self._dtype)
-        self._T = self._goal_table.shape[0]
+        # goal bank [n_slots, T, 89]: one shared slot, or one slot per env when MIDI
+        # augmentations re-draw the song at every episode start (:119-125)
+        table = torch.as_tensor(self._goal_np, device=dev, dtype=self._dtype)
+        n_slots = n_envs if self._augmentations is not None else 1
+        self._goal_bank = table[None].expand(n_slots, -1, -1).contiguous()
+        self._slot = (torch.arange(n_envs, device=dev) if self._augmentations is not None
+                      else torch.zeros(n_envs, dtype=torch.long, device=dev))
+        self._len = torch.full((n_slots,), table.shape[0], dtype=torch.long, device=dev)
         L = self._n_steps_lookahead
         self._goal_state = torch.zeros((n_envs, L + 1, 89), device=dev, dtype=self._dtype)
         self._goal_current = torch.zeros((n_envs, 89), device=dev, dtype=self._dtype)
@@ -79,7 +84,7 @@ class SelfActuatedPiano(base.PianoOnlyTask):
             self._t_idx[mask] = 0
             self._should_terminate[mask] = False
 
-    _STATE = ("_t_idx", "_should_terminate", "_goal_state", "_goal_current")
+    _STATE = ("_t_idx", "_should_terminate", "_goal_state", "_goal_current", "_goal_bank", "_len")
 
     def state_dict(self):
         sd = {k: getattr(self, k).detach().clone() for k in self._STATE}
@@ -91,7 +96,38 @@ class SelfActuatedPiano(base.PianoOnlyTask):
             setattr(self, k, sd[k].to(self._physics_device).clone())
         self.piano.load_state_dict(sd["piano"])
 
+    def _maybe_change_midi(self, mask=None):
+        """:119-125 for the envs selected by `mask` (host side, in env order)."""
+        if self._augmentations is None:
+            return
+        envs = range(self._E) if mask is None else np.flatnonzero(mask.detach().cpu().numpy())
+        if len(envs) == 0:
+            return
+        tables = []
+        for _ in envs:
+            midi = self._midi
+            for var in self._augmentations:
+                midi = var(initial_value=midi, random_state=self._random_state)
+            fast = midi_file.NoteTrajectory.goal_tables_from_arrays(midi.note_arrays(), self.control_timestep)
+            if fast is None:
+                fast = midi_file.NoteTrajectory.from_midi(midi, self.control_timestep).to_goal_tables()
+            tables.append(fast[0])
+        need = max(len(g) for g in tables)
+        if need > self._goal_bank.shape[1]:
+            grown = torch.zeros((self._goal_bank.shape[0], need + need // 4, 89),
+                                device=self._goal_bank.device, dtype=self._dtype)
+            grown[:, :self._goal_bank.shape[1]] = self._goal_bank
+            self._goal_bank = grown
+        rows = np.zeros((len(tables), self._goal_bank.shape[1], 89), np.float32)
+        for i, g in enumerate(tables):
+            rows[i, :len(g)] = g
+        dev = self._physics_device
+        idx = torch.as_tensor(np.asarray(envs, np.int64), device=dev)
+        self._goal_bank.index_copy_(0, idx, torch.as_tensor(rows, device=dev).to(self._dtype))
+        self._len.index_copy_(0, idx, torch.as_tensor([len(g) for g in tables], dtype=torch.long, device=dev))
+
     def initialize_episode(self, physics, mask=None):
+        self._maybe_change_midi(mask)
         self._reset_quantities_at_episode_init(mask)
         self.piano.initialize_episode(physics, mask)
 
@@ -110,7 +146,7 @@ class SelfActuatedPiano(base.PianoOnlyTask):
     def after_step(self, physics, active=None):
         inc = torch.ones_like(self._t_idx) if active is None else active.to(torch.long)
         self._t_idx = self._t_idx + inc
-        self._should_terminate = (self._t_idx - 1) == self._T - 1
+        self._should_terminate = (self._t_idx - 1) == self._len[self._slot] - 1
         self._goal_current = self._goal_state[:, 0].clone()
 
     def get_reward(self, physics):
@@ -141,11 +177,12 @@ class SelfActuatedPiano(base.PianoOnlyTask):
         return self._key_press_reward(pred, self._goal_current)
 
     def _update_goal_state(self):
-        live = self._t_idx < self._T
+        T = self._len[self._slot]
+        live = self._t_idx < T
         L = self._n_steps_lookahead
         steps = self._t_idx[:, None] + torch.arange(L + 1, device=self._t_idx.device)[None, :]
-        valid = steps < self._T
-        g = self._goal_table[torch.clamp(steps, max=self._T - 1)]
+        valid = steps < T[:, None]
+        g = self._goal_bank[self._slot[:, None], torch.clamp(steps, max=self._goal_bank.shape[1] - 1)]
         g = torch.where(valid[..., None], g, torch.zeros_like(g))
         self._goal_state = torch.where(live[:, None, None], g, self._goal_state)
 

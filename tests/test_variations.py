@@ -175,3 +175,28 @@ def test_no_augmentation_draw_keeps_the_cached_tables():
     g, _ = _expected_tables(music.load("CMajorScaleTwoHands"), env.task.control_timestep)
     for e in range(3):
         np.testing.assert_array_equal(env.task._goal_bank[e, :len(g)].numpy(), g)
+
+
+def test_self_actuated_piano_applies_augmentations_per_env():
+    """self_actuated_piano.py:119-125 on the vectorised task: one goal-bank slot per env."""
+    from robopianist_amd.suite.tasks import SelfActuatedPiano
+    E = 3
+    augs = [variations.MidiTemporalStretch(prob=1.0, stretch_range=0.4)]
+    base = music.load("TwinkleTwinkleLittleStar")
+    task = SelfActuatedPiano(midi=base, augmentations=augs, control_timestep=0.05,
+                             change_color_on_activation=True)
+    env = environment.Environment(task, n_envs=E, random_state=3, physics=FakePhysics(task.scene, E))
+    ts = env.reset()
+    rs = np.random.RandomState(3)
+    lens = []
+    for e in range(E):
+        midi = augs[0](initial_value=base, random_state=rs)
+        g, _ = _expected_tables(midi, 0.05)
+        lens.append(len(g))
+        np.testing.assert_array_equal(task._goal_bank[e, :len(g)].numpy(), g)
+        np.testing.assert_array_equal(ts.observation["goal"][e].numpy()[:89], g[0])
+    assert task._len.tolist() == lens and len(set(lens)) > 1
+    zero = np.zeros((E,) + env.action_spec().shape)
+    for _ in range(min(lens)):
+        ts = env.step(zero)
+    assert ts.last().tolist() == [l == min(lens) for l in lens]
