@@ -11,10 +11,10 @@ pos=kt[kt.Kernel_Name.str.contains('rp_stage_kernel<double, 0',regex=False)]
 posfull=pos[pos.dur>50000]
 task=kt[kt.Kernel_Name.str.contains('rp_task_',regex=False)]
 other=kt[~kt.Kernel_Name.str.contains('rp_stage_kernel|rp_task_|rp_reset',regex=True)]
-nstep=178
+nstep=max(1,len(task))
 cfg=lambda df:{k:str(df.iloc[0][k]) for k in ['LDS_Block_Size','Scratch_Size','VGPR_Count','Accum_VGPR_Count','SGPR_Count'] if k in df.columns}
 out={"round":1,
- "command":"rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --aux-fp32 0  (fp64 engine, 4096 envs, full env.step, 20 warm-up + 158 timed steps)",
+ "command":"rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --aux-fp32 0 --host-io 0  (fp64 engine, 4096 envs, full env.step, 20 warm-up + 158 timed steps)",
  "kernels":{
   "rp_stage_kernel<double, 1, 4> (solver stage, dominant)":{"launches":int(len(sol)),"avg_us":float(sol.dur.mean()/1e3),"min_us":float(sol.dur.min()/1e3),"max_us":float(sol.dur.max()/1e3),"share_of_gpu_time":float(sol.dur.sum()/kt.dur.sum()),"launch_config":cfg(sol)},
   "rp_stage_kernel<double, 0, 0> (position/velocity stage)":{"launches":int(len(posfull)),"avg_us":float(posfull.dur.mean()/1e3),"masked_forward_launches":int(len(pos)-len(posfull)),"share_of_gpu_time":float(pos.dur.sum()/kt.dur.sum()),"launch_config":cfg(posfull)},
