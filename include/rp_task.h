@@ -44,12 +44,17 @@ typedef struct rp_task_reward_args {
   const void* key_anchor;            /* [88][3] hinge position */
   const void* key_half;              /* [88][3] key box half sizes */
   const int* hand_act; int n_hand_act;      /* actuator ids of both hands (energy term) */
-  const int* tip_site;               /* [10] engine site index of the fingertips, right hand first */
+  const int* tip_site;               /* [10] engine site index of the fingertips, right hand first ([5] with hand_filter) */
   const int* rfa; int n_rfa;         /* right / left forearm geom ids (:251-259) */
   const int* lfa; int n_lfa;
   /* outputs */
   void* terms;                       /* [RP_TASK_N_TERMS][E] */
   void* total;                       /* [E] sum of the enabled terms in the order above */
+  /* PianoWithOneShadowHand (piano_with_one_shadow_hand.py:237-311): 0 = two hands (finger ids 0-9,
+   * tip_site[10], fingering_state [E][10]); 1 = right hand only, 2 = left hand only (tip_site[5],
+   * fingering_state [E][5]; finger_current / finger_next hold the index into this hand's fingertips,
+   * -1 for goal keys fingered by the other hand, and only this hand's keys enter the fingering term) */
+  int hand_filter;
 } rp_task_reward_args;
 
 int rp_task_rewards(const rp_task_reward_args* args, void* hip_stream);
@@ -87,7 +92,7 @@ typedef struct rp_task_advance_args {
   void* discount_state;              /* [E] */
   void* goal_state;                  /* [E][L+1][89] */
   long long* finger_next;            /* [E][88] */
-  void* fingering_state;             /* [E][10] */
+  void* fingering_state;             /* [E][10] ([E][5] with rw.hand_filter) */
   unsigned char* needs_reset;        /* [E] in/out */
   /* outputs */
   void* discount;                    /* [E] */

@@ -32,7 +32,7 @@ __device__ __forceinline__ T reward_env(const rp_task_reward_args& a, int env, i
   const T* sites = (const T*)a.site_xpos + (size_t)env * a.n_sites * 3;
   const T kclose = (T)a.key_close, fclose = (T)a.finger_close;
   T kp_sum = 0, fg_sum = 0;
-  int n_on = 0, false_pos = 0;
+  int n_on = 0, n_fg = 0, false_pos = 0;
 #pragma unroll
   for (int s = 0; s < 2; s++) {
     const int k = lane + 64 * s;
@@ -41,9 +41,12 @@ __device__ __forceinline__ T reward_env(const rp_task_reward_args& a, int env, i
       if (g > (T)0) {
         n_on++;
         kp_sum += tol_gauss(g - kv.nstate[s], kclose, kclose * (T)10);
-        if (a.use_fingering) {
-          const long long f = kv.finger[s];
-          const int fid = f < 0 ? 4 : (int)f;  // a note without fingering counts as finger 4 (:401-412)
+        // two hands: a note without fingering counts as finger 4 (:401-412); one hand: only the
+        // notes fingered by this hand take part (finger holds the local index or -1)
+        const long long f = kv.finger[s];
+        if (a.use_fingering && (a.hand_filter == 0 || f >= 0)) {
+          const int fid = f < 0 ? 4 : (int)f;
+          n_fg++;
           const T* tip = sites + (size_t)a.tip_site[fid] * 3;
           const T* an = (const T*)a.key_anchor + 3 * k;
           const T* hf = (const T*)a.key_half + 3 * k;
@@ -78,14 +81,14 @@ __device__ __forceinline__ T reward_env(const rp_task_reward_args& a, int env, i
     }
   }
   kp_sum = wsum(kp_sum); fg_sum = wsum(fg_sum); en = wsum(en);
-  const int non = (int)wsum((float)n_on);
+  const int non = (int)wsum((float)n_on), nfg = (int)wsum((float)n_fg);
   const bool fpos = __ballot(false_pos) != 0ull, fhit = __ballot(hit) != 0ull;
   T tot = 0;
   if (lane == 0) {
     const T key_press = (non > 0 ? (T)0.5 * kp_sum / (T)non : (T)0) + (T)0.5 * (fpos ? (T)0 : (T)1);
     const T sustain = tol_gauss(kv.goal_sustain - (kv.sustain_on ? (T)1 : (T)0), kclose, kclose * (T)10);
     const T energy = -(T)a.energy_coef * en;
-    const T fingering = a.use_fingering ? (non > 0 ? fg_sum / (T)non : (T)0) : (T)0;
+    const T fingering = a.use_fingering ? (nfg > 0 ? fg_sum / (T)nfg : (T)0) : (T)0;
     const T forearm = a.use_forearm ? (fhit ? (T)0 : (T)0.5) : (T)0;
     T* t = (T*)a.terms;
     t[0 * E + env] = key_press; t[1 * E + env] = sustain; t[2 * E + env] = energy;
@@ -182,14 +185,18 @@ __global__ __launch_bounds__(64) void rp_task_advance_kernel(rp_task_advance_arg
       const int k = lane + 64 * s;
       if (k < RP_TASK_N_KEYS) {
         const bool gn = ((const T*)p.goal_bank)[((size_t)song * p.bank_len + bi) * 89 + k] > (T)0;
-        const long long f = gn ? p.finger_bank[((size_t)song * p.bank_len + bi) * 88 + k] : -1;
+        long long f = gn ? p.finger_bank[((size_t)song * p.bank_len + bi) * 88 + k] : -1;
+        bool mine = gn;
+        if (a.hand_filter == 1) { mine = gn && f < 5; f = mine ? (f < 0 ? 4 : f) : -1; }        // :299-303
+        else if (a.hand_filter == 2) { mine = gn && f >= 5; f = mine ? f - 5 : -1; }           // :304-306
         p.finger_next[(size_t)env * 88 + k] = f;
-        if (gn) fbits |= 1u << (f < 0 ? 4 : (int)f);
+        if (mine) fbits |= 1u << (f < 0 ? 4 : (int)f);
       }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) fbits |= __shfl_xor(fbits, off, 64);
-    if (lane < 10) ((T*)p.fingering_state)[(size_t)env * 10 + lane] = (fbits >> lane) & 1u ? (T)1 : (T)0;
+    const int nfingers = a.hand_filter ? 5 : 10;
+    if (lane < nfingers) ((T*)p.fingering_state)[(size_t)env * nfingers + lane] = (fbits >> lane) & 1u ? (T)1 : (T)0;
   }
 
   // ---- rewards, termination, discount, step type
@@ -226,6 +233,7 @@ int rp_task_rewards(const rp_task_reward_args* a, void* hip_stream) {
   if (!a) { g_task_err = "rp_task_rewards: null args"; return -1; }
   if (a->precision != 32 && a->precision != 64) { g_task_err = "rp_task_rewards: precision must be 32 or 64"; return -1; }
   if (a->n_envs <= 0) { g_task_err = "rp_task_rewards: n_envs must be positive"; return -1; }
+  if (a->hand_filter < 0 || a->hand_filter > 2) { g_task_err = "rp_task_rewards: hand_filter must be 0, 1 or 2"; return -1; }
   if (!a->qpos || !a->act_force || !a->act_vel || !a->site_xpos || !a->contact_geoms || !a->goal_current ||
       !a->key_norm_state || !a->key_activation || !a->sustain_activation || !a->finger_current || !a->key_qadr ||
       !a->key_anchor || !a->key_half || !a->hand_act || !a->tip_site || !a->terms || !a->total) {
@@ -245,6 +253,7 @@ int rp_task_advance(const rp_task_advance_args* p, void* hip_stream) {
   const rp_task_reward_args* a = &p->rw;
   if (a->precision != 32 && a->precision != 64) { g_task_err = "rp_task_advance: precision must be 32 or 64"; return -1; }
   if (a->n_envs <= 0 || p->n_lookahead < 0 || p->bank_len <= 0) { g_task_err = "rp_task_advance: bad sizes"; return -1; }
+  if (a->hand_filter < 0 || a->hand_filter > 2) { g_task_err = "rp_task_advance: hand_filter must be 0, 1 or 2"; return -1; }
   if (!a->qpos || !a->act_force || !a->act_vel || !a->site_xpos || !a->contact_geoms || !a->goal_current ||
       !a->key_norm_state || !a->key_activation || !a->sustain_activation || !a->finger_current || !a->key_qadr ||
       !a->key_anchor || !a->key_half || !a->hand_act || !a->tip_site || !a->terms || !a->total || !p->warn ||

@@ -14,7 +14,8 @@ a single 26-link tree).  Differences to the two-hand task, all taken from the re
   * observables: the hand's `joints_pos` and `position` (root body xpos), piano state,
     sustain state, goal, fingering                                       (:313-352)
 
-The task hooks run as torch ops (the fused HIP task kernels cover the two-hand task).
+On the HIP engine the hooks run as the fused task kernels in their one-hand mode
+(`rp_task_reward_args.hand_filter`); the torch methods below are the definition / cross-check.
 """
 
 from __future__ import annotations
@@ -95,10 +96,24 @@ class PianoWithOneShadowHand(two_hands.PianoWithShadowHands):
         self._fingering_state = torch.zeros((self._E, 5), device=self._physics_device, dtype=self._dtype)
 
     def _fused_rewards_for(self, physics):
-        return None
-
-    def fused_advance_for(self, physics):
-        return None
+        """The fused HIP task kernels (include/rp_task.h) in their one-hand mode."""
+        if not self._use_fused_rewards or not getattr(physics, "device", None) or physics.device.type != "cuda":
+            return None
+        want = ("key_press_reward", "sustain_reward", "energy_reward") + (
+            ("fingering_reward",) if not self._disable_fingering_reward else ())
+        if tuple(self._reward_fn.reward_fns) != want:
+            return None  # customised reward set: torch path
+        if self._fused_rewards is None:
+            from robopianist_amd import task_kernels
+            self._fused_rewards = task_kernels.FusedRewards(
+                physics, n_envs=self._E, key_qadr=[int(j) for j in self.piano.joints],
+                key_anchor=self._key_anchor, key_half=self._key_half, hand_act=list(self._hand.actuators),
+                tip_site=[physics._site_modelid[int(s)] for s in self._tip_sites], rfa=[], lfa=[],
+                use_fingering=not self._disable_fingering_reward, use_forearm=False,
+                energy_coef=_ENERGY_PENALTY_COEF, key_close=_KEY_CLOSE_ENOUGH_TO_PRESSED,
+                finger_close=_FINGER_CLOSE_ENOUGH_TO_KEY,
+                hand_filter=1 if self._hand_side == "right" else 2)
+        return self._fused_rewards
 
     @property
     def hand_side(self) -> str:
@@ -145,6 +160,10 @@ class PianoWithOneShadowHand(two_hands.PianoWithShadowHands):
     def get_observation(self, physics):
         """Enabled observables (:313-352) in the reference's update order."""
         self._update_goal_state()
+        self._update_fingering_state()
+        return self._observation_dict(physics)
+
+    def _observation_dict(self, physics):
         name = self._hand.name
         obs = {
             f"{name}/joints_pos": physics.qpos[:, self._jnt],
@@ -153,7 +172,6 @@ class PianoWithOneShadowHand(two_hands.PianoWithShadowHands):
             "piano/sustain_state": self.piano.sustain_state,
             "goal": self._goal_state.reshape(self._E, -1),
         }
-        self._update_fingering_state()
         if not self._disable_fingering_reward:
             obs["fingering"] = self._fingering_state
         return obs

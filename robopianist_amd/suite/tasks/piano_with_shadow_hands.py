@@ -392,16 +392,7 @@ class PianoWithShadowHands(base.PianoTask):
         for i, name in enumerate(task_kernels.TERM_NAMES):
             if name in self._reward_fn.reward_fns:
                 self._reward_fn.reward_terms[name] = terms[i]
-        obs = {
-            f"{self.right_hand.name}/joints_pos": physics.qpos[:, self._rh_jnt],
-            f"{self.left_hand.name}/joints_pos": physics.qpos[:, self._lh_jnt],
-            "piano/state": pn.normalized_state,
-            "piano/sustain_state": pn.sustain_state,
-            "goal": self._goal_state.reshape(self._E, -1),
-        }
-        if not self._disable_fingering_reward:
-            obs["fingering"] = self._fingering_state
-        return st, total, disc, obs
+        return st, total, disc, self._observation_dict(physics)
 
     def get_discount(self, physics=None):
         return self._discount
@@ -465,6 +456,10 @@ class PianoWithShadowHands(base.PianoTask):
     def get_observation(self, physics):
         """Enabled observables (:414-449), evaluated once per control step."""
         self._update_goal_state()
+        self._update_fingering_state()
+        return self._observation_dict(physics)
+
+    def _observation_dict(self, physics):
         obs = {
             f"{self.right_hand.name}/joints_pos": physics.qpos[:, self._rh_jnt],
             f"{self.left_hand.name}/joints_pos": physics.qpos[:, self._lh_jnt],
@@ -472,7 +467,6 @@ class PianoWithShadowHands(base.PianoTask):
             "piano/sustain_state": self.piano.sustain_state,
             "goal": self._goal_state.reshape(self._E, -1),
         }
-        self._update_fingering_state()
         if not self._disable_fingering_reward:
             obs["fingering"] = self._fingering_state
         return obs

@@ -34,6 +34,7 @@ class RewardArgs(ctypes.Structure):
         ("rfa", ctypes.c_void_p), ("n_rfa", ctypes.c_int),
         ("lfa", ctypes.c_void_p), ("n_lfa", ctypes.c_int),
         ("terms", ctypes.c_void_p), ("total", ctypes.c_void_p),
+        ("hand_filter", ctypes.c_int),
     ]
 
 
@@ -76,7 +77,7 @@ class FusedRewards:
     """All reward terms of PianoWithShadowHands for every env in one launch."""
 
     def __init__(self, physics, *, n_envs, key_qadr, key_anchor, key_half, hand_act, tip_site, rfa, lfa,
-                 use_fingering, use_forearm, energy_coef, key_close, finger_close):
+                 use_fingering, use_forearm, energy_coef, key_close, finger_close, hand_filter=0):
         self._L = _lib()
         dev, dt = physics.device, physics.dtype
         self._phys, self._E, self._dt = physics, int(n_envs), dt
@@ -106,6 +107,9 @@ class FusedRewards:
         a.rfa, a.n_rfa = self._rfa.data_ptr(), int(self._rfa.numel())
         a.lfa, a.n_lfa = self._lfa.data_ptr(), int(self._lfa.numel())
         a.terms, a.total = self.terms.data_ptr(), self.total.data_ptr()
+        a.hand_filter = int(hand_filter)
+        if len(tip_site) != (5 if a.hand_filter else 10):
+            raise engine.EngineError("fused task kernel: tip_site must list 10 fingertips (5 for one hand)")
         self._args = a
 
     def compute(self, *, goal_current, key_norm_state, key_activation, sustain_activation, finger_current):
@@ -173,7 +177,7 @@ class FusedAdvance:
         p.discount_state = _chk(discount_state, dt, (E,))
         p.goal_state = _chk(goal_state, dt, (E, L + 1, 89))
         p.finger_next = _chk(finger_next, torch.int64, (E, 88))
-        p.fingering_state = _chk(fingering_state, dt, (E, 10))
+        p.fingering_state = _chk(fingering_state, dt, (E, 5 if a.hand_filter else 10))
         p.needs_reset = _chk(needs_reset, torch.bool, (E,))
         stream = torch.cuda.current_stream(self._rw._phys.device).cuda_stream
         if self._L.rp_task_advance(ctypes.byref(p), ctypes.c_void_p(stream)) != 0:

@@ -446,6 +446,69 @@ def test_checkpoint_resume_is_bitwise(augment):
         assert torch.equal(a.task._song_len, b.task._song_len)
 
 
+@pytest.mark.parametrize("side", ["right", "left"])
+def test_one_hand_fused_task_kernels_match_torch_hooks(side):
+    """rp_task_advance in its one-hand mode (rp_task_reward_args.hand_filter) against the torch
+    restatement of piano_with_one_shadow_hand.py: every TimeStep field and the persistent task
+    state, across episode ends and wrong-press terminations."""
+    from robopianist_amd import music
+    from robopianist_amd.suite import environment
+    from robopianist_amd.suite.tasks import PianoWithOneShadowHand
+    E = 5
+    def make(fused):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            task = PianoWithOneShadowHand(midi=music.load("CMajorScaleTwoHands"), hand_side=side,
+                                          control_timestep=0.05, gravity_compensation=True,
+                                          primitive_fingertip_collisions=True, n_steps_lookahead=3,
+                                          wrong_press_termination=True)
+        if not fused:
+            task._use_fused_advance = False
+            task._use_fused_rewards = False
+        return environment.Environment(task, n_envs=E, random_state=3, precision=64)
+    fused, ref = make(True), make(False)
+    fused.reset(); ref.reset()
+    assert fused.task.fused_advance_for(fused.physics) is not None
+    assert ref.task.fused_advance_for(ref.physics) is None
+    spec = fused.action_spec()
+    rng = np.random.RandomState(1)
+    seen = dict(first=0, last=0, fingering=0.0)
+    kj = torch.as_tensor(fused.task.piano.joints, device=fused.physics.device, dtype=torch.long)
+    for step in range(220):
+        a = rng.uniform(spec.minimum, spec.maximum, size=(E, spec.shape[0]))
+        a[:, :22] = 0.3 * a[:, :22]
+        if step % 37 == 20:   # a wrong key goes down in env 2: failure termination
+            for env in (fused, ref):
+                f = torch.zeros((E, env.physics.model.nv), device=env.physics.device, dtype=torch.float64)
+                f[2, kj[3]] = 3.0
+                env.physics.set_qfrc_applied(f)
+        if step % 37 == 24:
+            for env in (fused, ref):
+                env.physics.set_qfrc_applied(torch.zeros((E, env.physics.model.nv), device=env.physics.device,
+                                                         dtype=torch.float64))
+        at = torch.as_tensor(a, device=fused.physics.device)
+        ts_f, ts_r = fused.step(at), ref.step(at)
+        assert torch.equal(ts_f.step_type, ts_r.step_type), step
+        np.testing.assert_allclose(_np(ts_f.reward), _np(ts_r.reward), rtol=0, atol=1e-12, err_msg=str(step))
+        np.testing.assert_allclose(_np(ts_f.discount), _np(ts_r.discount), rtol=0, atol=0)
+        assert ts_f.observation.keys() == ts_r.observation.keys()
+        for k in ts_f.observation:
+            np.testing.assert_allclose(_np(ts_f.observation[k]), _np(ts_r.observation[k]), rtol=0, atol=1e-12,
+                                       err_msg=f"{k} @ {step}")
+        tf, tr = fused.task, ref.task
+        for name in ("_t_idx", "_should_terminate", "_failure_termination", "_discount", "_goal_current",
+                     "_finger_current", "_finger_next", "_fingering_state", "_goal_state"):
+            assert torch.equal(getattr(tf, name), getattr(tr, name)), f"{name} @ {step}"
+        for name in ("fingering_reward", "energy_reward", "key_press_reward", "sustain_reward"):
+            np.testing.assert_allclose(_np(tf.reward_fn.reward_terms[name]), _np(tr.reward_fn.reward_terms[name]),
+                                       rtol=0, atol=1e-12, err_msg=name)
+        seen["first"] += int((ts_f.step_type == 0).sum())
+        seen["last"] += int((ts_f.step_type == 2).sum())
+        seen["fingering"] = max(seen["fingering"], float(tf.reward_fn.reward_terms["fingering_reward"].max()))
+    assert seen["last"] >= E and seen["first"] >= E, seen
+    assert seen["fingering"] > 0.0, "this hand's notes did enter the fingering term"
+
+
 def test_uniformly_random_actions_do_not_diverge():
     """BASELINE config 3's policy (i.i.d. uniform actions every step) at 8192 envs: hands
     swing into each other at ~18 rad/s and pile up more contacts / Jacobian entries than the
