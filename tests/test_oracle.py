@@ -162,3 +162,51 @@ def test_capsule_box_contact_geometry(two_hand_scene):
         n = row[4:7]
         assert np.linalg.norm(n) == pytest.approx(1.0)
         assert row[0] < 0
+
+
+def test_gravity_bias_is_the_gradient_of_the_potential_energy(two_hand_scene):
+    """RNE at zero velocity: qfrc_bias = dU/dq with U = -sum_b m_b g . com_b (central finite
+    differences through the kinematics of model/compile.py), on a random hand pose."""
+    m = two_hand_scene.model
+    o = _oracle(two_hand_scene)
+    rng = np.random.default_rng(5)
+    q = np.zeros(m.nv)
+    q[88:] = rng.uniform(-0.4, 0.4, m.nv - 88)
+    q = np.clip(q, m.jnt_range[:, 0], m.jnt_range[:, 1])
+
+    def potential(qq):
+        kin = mc.kinematics(m, qq)
+        u = 0.0
+        for b in range(1, m.nbody):
+            com = kin["xpos"][b] + kin["xmat"][b] @ m.body_ipos[b]
+            u -= m.body_mass[b] * float(np.dot(m.opt_gravity, com))
+        return u
+
+    o.qpos[:] = q
+    o.qvel[:] = 0
+    o.forward()
+    bias = o.qfrc_bias.copy()
+    eps = 1e-6
+    for j in list(range(88, m.nv, 5)) + [3, 40]:
+        dq = np.zeros(m.nv); dq[j] = eps
+        fd = (potential(q + dq) - potential(q - dq)) / (2 * eps)
+        assert abs(bias[j] - fd) < 1e-7 * max(1.0, abs(fd)), (j, bias[j], fd)
+
+
+def test_unconstrained_acceleration_solves_m_qacc_equals_qfrc_smooth(two_hand_scene):
+    """qacc_smooth = M^-1 (passive + actuator + applied - bias), checked as a residual with the
+    dense mass matrix on a moving random pose."""
+    m = two_hand_scene.model
+    o = _oracle(two_hand_scene)
+    rng = np.random.default_rng(6)
+    o.qpos[88:] = rng.uniform(-0.3, 0.3, m.nv - 88)
+    o.qvel[:] = rng.uniform(-2, 2, m.nv)
+    lo, hi = m.actuator_ctrlrange[:, 0], m.actuator_ctrlrange[:, 1]
+    o.ctrl[:] = lo + rng.uniform(0.1, 0.9, m.nu) * (hi - lo)
+    o.forward()
+    M = o.qM.reshape(m.nv, m.nv)
+    np.testing.assert_allclose(o.qfrc_smooth, o.qfrc_passive + o.qfrc_actuator + o.qfrc_applied - o.qfrc_bias,
+                               atol=1e-12)
+    res = M @ o.qacc_smooth - o.qfrc_smooth
+    assert np.abs(res).max() < 1e-9 * max(1.0, np.abs(o.qfrc_smooth).max())
+    assert np.allclose(M, M.T) and np.linalg.eigvalsh(M).min() > 0
