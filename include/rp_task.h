@@ -97,6 +97,16 @@ typedef struct rp_task_advance_args {
   /* outputs */
   void* discount;                    /* [E] */
   int* step_type;                    /* [E] 0 FIRST, 1 MID, 2 LAST */
+  /* optional (eval_sums == NULL: off): MidiEvaluationWrapper (wrappers/evaluation.py:67-177) as a
+   * device reduction.  Per simulated step: precision / recall / F1 (sklearn "binary",
+   * zero_division=1) of the key activations against the goal row of that step, and of the sustain
+   * activation against the goal sustain; accumulated per env, and at LAST the episode mean goes into
+   * a ring of the last `eval_deque` episodes.  Always double. */
+  double* eval_sums;                 /* [E][6] running sums: key P, R, F1, sustain P, R, F1 */
+  double* eval_count;                /* [E]    steps accumulated */
+  double* eval_hist;                 /* [E][eval_deque][6] episode means */
+  long long* eval_nfinished;         /* [E]    episodes finished */
+  int eval_deque;
 } rp_task_advance_args;
 
 int rp_task_advance(const rp_task_advance_args* args, void* hip_stream);

@@ -21,6 +21,15 @@ template <typename T> __device__ __forceinline__ T tol_gauss(T x, T upper, T mar
   return exp((T)-0.5 * z * z);
 }
 
+// precision / recall / F1 with sklearn's average="binary", zero_division=1 conventions
+__device__ __forceinline__ void prf(int tp, int fp, int fn, double* out) {
+  const double p = tp + fp > 0 ? (double)tp / (double)(tp + fp) : 1.0;
+  const double r = tp + fn > 0 ? (double)tp / (double)(tp + fn) : 1.0;
+  double f = p + r > 0.0 ? 2.0 * p * r / (p + r) : 0.0;
+  if (tp + fp + fn == 0) f = 1.0;
+  out[0] = p; out[1] = r; out[2] = f;
+}
+
 // Per-lane view of the task state the reward terms read: lane k owns keys k and k + 64.
 template <typename T> struct KeyView { T goal[2], nstate[2]; bool pressed[2]; long long finger[2]; T goal_sustain; bool sustain_on; };
 
@@ -160,6 +169,15 @@ __global__ __launch_bounds__(64) void rp_task_advance_kernel(rp_task_advance_arg
   const bool sus_on = ((const T*)p.sustain_state)[env] >= (T)p.sustain_threshold;
   kv.goal_sustain = gsus; kv.sustain_on = sus_on;
   const bool failure = __ballot(fail) != 0ull;
+  // MidiEvaluationWrapper counts (goal row of the simulated step vs the new activations)
+  int e_tp = 0, e_fp = 0, e_fn = 0;
+  if (p.eval_sums) {
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const bool on = kv.goal[s] > (T)0, pr = kv.pressed[s];   // (lanes beyond key 87 hold goal 0 / not pressed)
+      e_tp += __popcll(__ballot(on && pr)); e_fp += __popcll(__ballot(!on && pr)); e_fn += __popcll(__ballot(on && !pr));
+    }
+  }
   t += active ? 1 : 0;
   bool term = t == slen;                                       // (t_idx - 1) == len - 1
   if (lane == 0) {
@@ -221,6 +239,27 @@ __global__ __launch_bounds__(64) void rp_task_advance_kernel(rp_task_advance_arg
     p.failure_termination[env] = failure;
     ((T*)p.discount_state)[env] = dstate;
     p.needs_reset[env] = terminate;
+    if (p.eval_sums) {
+      double* sums = p.eval_sums + (size_t)env * 6;
+      double cnt = p.eval_count[env];
+      if (active) {
+        double v[6];
+        prf(e_tp, e_fp, e_fn, v);
+        const bool st_ = gsus > (T)0;
+        prf(st_ && sus_on, !st_ && sus_on, st_ && !sus_on, v + 3);
+        for (int i = 0; i < 6; i++) sums[i] += v[i];
+        cnt += 1.0;
+      }
+      if (terminate) {
+        const long long nf = p.eval_nfinished[env];
+        double* h = p.eval_hist + ((size_t)env * p.eval_deque + (size_t)(nf % p.eval_deque)) * 6;
+        const double den = cnt > 1.0 ? cnt : 1.0;
+        for (int i = 0; i < 6; i++) { h[i] = sums[i] / den; sums[i] = 0.0; }
+        p.eval_nfinished[env] = nf + 1;
+        cnt = 0.0;
+      }
+      p.eval_count[env] = cnt;
+    }
   }
 }
 }  // namespace
@@ -254,6 +293,10 @@ int rp_task_advance(const rp_task_advance_args* p, void* hip_stream) {
   if (a->precision != 32 && a->precision != 64) { g_task_err = "rp_task_advance: precision must be 32 or 64"; return -1; }
   if (a->n_envs <= 0 || p->n_lookahead < 0 || p->bank_len <= 0) { g_task_err = "rp_task_advance: bad sizes"; return -1; }
   if (a->hand_filter < 0 || a->hand_filter > 2) { g_task_err = "rp_task_advance: hand_filter must be 0, 1 or 2"; return -1; }
+  if (p->eval_sums && (!p->eval_count || !p->eval_hist || !p->eval_nfinished || p->eval_deque <= 0)) {
+    g_task_err = "rp_task_advance: incomplete evaluation buffers";
+    return -1;
+  }
   if (!a->qpos || !a->act_force || !a->act_vel || !a->site_xpos || !a->contact_geoms || !a->goal_current ||
       !a->key_norm_state || !a->key_activation || !a->sustain_activation || !a->finger_current || !a->key_qadr ||
       !a->key_anchor || !a->key_half || !a->hand_act || !a->tip_site || !a->terms || !a->total || !p->warn ||

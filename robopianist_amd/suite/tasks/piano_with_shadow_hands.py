@@ -374,7 +374,16 @@ class PianoWithShadowHands(base.PianoTask):
                 wrong_press_termination=self._wrong_press_termination,
                 key_threshold=_base._KEY_THRESHOLD, sustain_threshold=_base._SUSTAIN_THRESHOLD,
                 key_qrange=self.piano._qpos_range)
+            if getattr(self, "_eval_buffers", None) is not None:
+                self._fused_advance.set_evaluation_buffers(*self._eval_buffers)
         return self._fused_advance
+
+    def set_evaluation_buffers(self, buffers) -> None:
+        """(sums, count, hist, n_finished) of a MidiEvaluationWrapper, or None: the fused launch
+        then performs the wrapper's reduction (include/rp_task.h `eval_*`)."""
+        self._eval_buffers = buffers
+        if self._fused_advance is not None:
+            self._fused_advance.set_evaluation_buffers(*(buffers or (None, None, None, None)))
 
     def fused_advance(self, physics, needs_reset):
         """Runs rp_task_advance; returns (step_type, reward, discount, observation)."""

@@ -52,6 +52,8 @@ class AdvanceArgs(ctypes.Structure):
         ("discount_state", ctypes.c_void_p), ("goal_state", ctypes.c_void_p), ("finger_next", ctypes.c_void_p),
         ("fingering_state", ctypes.c_void_p), ("needs_reset", ctypes.c_void_p),
         ("discount", ctypes.c_void_p), ("step_type", ctypes.c_void_p),
+        ("eval_sums", ctypes.c_void_p), ("eval_count", ctypes.c_void_p), ("eval_hist", ctypes.c_void_p),
+        ("eval_nfinished", ctypes.c_void_p), ("eval_deque", ctypes.c_int),
     ]
 
 
@@ -157,6 +159,22 @@ class FusedAdvance:
         p.discount, p.step_type = self.discount.data_ptr(), self.step_type.data_ptr()
         self._p = p
         self._L_lookahead = int(n_lookahead)
+
+    def set_evaluation_buffers(self, sums, count, hist, n_finished):
+        """Turns on the MidiEvaluationWrapper reduction inside the launch (None: off)."""
+        p, E = self._p, self._E
+        if sums is None:
+            p.eval_sums = p.eval_count = p.eval_hist = p.eval_nfinished = None
+            p.eval_deque = 0
+            self._eval = None
+            return
+        D = int(hist.shape[1])
+        p.eval_sums = _chk(sums, torch.float64, (E, 6))
+        p.eval_count = _chk(count, torch.float64, (E,))
+        p.eval_hist = _chk(hist, torch.float64, (E, D, 6))
+        p.eval_nfinished = _chk(n_finished, torch.int64, (E,))
+        p.eval_deque = D
+        self._eval = (sums, count, hist, n_finished)  # keep alive
 
     def advance(self, *, needs_reset, key_state, key_norm_state, key_activation, sustain_state, sustain_activation,
                 t_idx, should_terminate, failure_termination, discount_state, goal_state, goal_current,

@@ -1,6 +1,8 @@
 """MidiEvaluationWrapper: per-episode precision / recall / F1 of key presses and of the
 sustain pedal against the MIDI goal (mirror of robopianist/wrappers/evaluation.py:40-177),
-computed as batched device reductions instead of sklearn calls.
+computed as batched device reductions instead of sklearn calls.  On the HIP task layer the
+reduction runs inside the `rp_task_advance` launch (include/rp_task.h, `eval_*` buffers); the
+torch code below is the definition and the fallback.
 
 Per step and env: precision/recall/F1 of activation vs the goal row of that step with
 sklearn's `average="binary", zero_division=1` convention, averaged over the episode."""
@@ -39,6 +41,8 @@ class MidiEvaluationWrapper:
         self._hist = torch.zeros((E, deque_size, 6), dtype=torch.float64, device=dev)
         self._n_finished = torch.zeros(E, dtype=torch.long, device=dev)
         self._deque_size = deque_size
+        self._fused_with = None  # the FusedAdvance object our buffers are registered with
+        self._use_fused = True
 
     def __getattr__(self, name):
         return getattr(self._environment, name)
@@ -48,7 +52,24 @@ class MidiEvaluationWrapper:
         self._count.zero_()
         return self._environment.reset()
 
+    def _fused(self) -> bool:
+        """True when the task's fused launch does the reduction (our buffers registered)."""
+        task, phys = self._environment.task, self._environment.physics
+        if not self._use_fused or not hasattr(task, "set_evaluation_buffers"):
+            return False
+        if task.fused_advance_for(phys) is None:
+            if self._fused_with is not None:
+                task.set_evaluation_buffers(None)
+                self._fused_with = None
+            return False
+        if self._fused_with is None:
+            task.set_evaluation_buffers((self._sums, self._count, self._hist, self._n_finished))
+            self._fused_with = task
+        return True
+
     def step(self, action):
+        if self._fused():
+            return self._environment.step(action)
         task = self._environment.task
         # goal row of the step about to be simulated = goal_state[:, 0]
         goal = task._goal_state[:, 0].clone()
@@ -68,8 +89,8 @@ class MidiEvaluationWrapper:
         self._hist[torch.arange(self._hist.shape[0], device=slot.device), slot] = torch.where(
             last[:, None], mean, cur)
         self._n_finished += last.long()
-        self._sums = torch.where(last[:, None], torch.zeros_like(self._sums), self._sums)
-        self._count = torch.where(last, torch.zeros_like(self._count), self._count)
+        self._sums.copy_(torch.where(last[:, None], torch.zeros_like(self._sums), self._sums))
+        self._count.copy_(torch.where(last, torch.zeros_like(self._count), self._count))
         return timestep
 
     def get_musical_metrics(self) -> Dict[str, float]:

@@ -509,6 +509,54 @@ def test_one_hand_fused_task_kernels_match_torch_hooks(side):
     assert seen["fingering"] > 0.0, "this hand's notes did enter the fingering term"
 
 
+def test_evaluation_wrapper_fused_reduction_matches_torch():
+    """MidiEvaluationWrapper (wrappers/evaluation.py:67-177): the reduction inside the
+    rp_task_advance launch against the torch definition -- running sums, episode history ring
+    and the reported metrics, over several episodes incl. keys pressed by applied torques."""
+    from robopianist_amd import suite
+    from robopianist_amd.wrappers import CanonicalSpecWrapper, MidiEvaluationWrapper
+    E = 6
+    def make(fused):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            env = suite.load("RoboPianist-debug-CMajorChordProgressionTwoHands-v0", seed=2, n_envs=E, precision=64,
+                             task_kwargs=dict(control_timestep=0.05, gravity_compensation=True,
+                                              primitive_fingertip_collisions=True))
+        w = MidiEvaluationWrapper(CanonicalSpecWrapper(env), deque_size=2)
+        w._use_fused = fused
+        return w
+    a, b = make(True), make(False)
+    a.reset(); b.reset()
+    assert a._fused() and not b._fused()
+    rng = np.random.RandomState(0)
+    dev = a.physics.device
+    kj = torch.as_tensor(a.task.piano.joints, device=dev, dtype=torch.long)
+    n_last = 0
+    for step in range(260):
+        act = torch.as_tensor(0.3 * rng.uniform(-1, 1, size=(E, 45)), device=dev)
+        act[:, -1] = float(rng.uniform(-1, 1))   # sustain pedal toggles
+        if step % 9 == 0:   # press the goal keys of env 0..2 (and a wrong key in env 3) with torques
+            for w in (a, b):
+                f = torch.zeros((E, w.physics.model.nv), device=dev, dtype=torch.float64)
+                goal = w.task._goal_state[:, 0, :88] > 0
+                for e in range(3):
+                    f[e, kj[goal[e]]] = 3.0
+                f[3, kj[10]] = 3.0
+                w.physics.set_qfrc_applied(f)
+        ta, tb = a.step(act), b.step(act)
+        assert torch.equal(ta.step_type, tb.step_type)
+        assert torch.equal(a._count, b._count), step
+        np.testing.assert_allclose(_np(a._sums), _np(b._sums), rtol=0, atol=1e-12, err_msg=str(step))
+        np.testing.assert_allclose(_np(a._hist), _np(b._hist), rtol=0, atol=1e-12, err_msg=str(step))
+        assert torch.equal(a._n_finished, b._n_finished)
+        n_last += int(ta.last().sum())
+    assert n_last >= 2 * E
+    ma, mb = a.get_musical_metrics(), b.get_musical_metrics()
+    for k in ma:
+        assert abs(ma[k] - mb[k]) < 1e-12, k
+    assert 0.0 < ma["f1"] < 1.0 and ma["recall"] > 0.0, ma
+
+
 def test_uniformly_random_actions_do_not_diverge():
     """BASELINE config 3's policy (i.i.d. uniform actions every step) at 8192 envs: hands
     swing into each other at ~18 rad/s and pile up more contacts / Jacobian entries than the
