@@ -62,3 +62,47 @@ def test_key_trace_decoding():
     assert bits.shape == (1, 2, 88)
     assert bits[0, 0].nonzero()[0].tolist() == [0, 2]
     assert bits[0, 1].nonzero()[0].tolist() == [67]
+
+
+def test_task_abi_rejects_bad_arguments_without_a_device():
+    """include/rp_task.h: argument errors are reported through the return code /
+    rp_task_last_error before anything is launched."""
+    from robopianist_amd import task_kernels as tk
+    L = tk._lib()
+    assert L.rp_task_advance(None, None) == -1 and b"null args" in L.rp_task_last_error()
+    assert L.rp_task_rewards(None, None) == -1
+    a = tk.RewardArgs()
+    a.n_envs, a.precision = 4, 16
+    assert L.rp_task_rewards(ctypes.byref(a), None) == -1 and b"precision" in L.rp_task_last_error()
+    a.precision, a.n_envs = 64, 0
+    assert L.rp_task_rewards(ctypes.byref(a), None) == -1 and b"n_envs" in L.rp_task_last_error()
+    a.n_envs, a.hand_filter = 4, 3
+    assert L.rp_task_rewards(ctypes.byref(a), None) == -1 and b"hand_filter" in L.rp_task_last_error()
+    a.hand_filter = 0
+    assert L.rp_task_rewards(ctypes.byref(a), None) == -1 and b"null array" in L.rp_task_last_error()
+    p = tk.AdvanceArgs()
+    p.rw = a
+    p.bank_len = 0
+    assert L.rp_task_advance(ctypes.byref(p), None) == -1 and b"bad sizes" in L.rp_task_last_error()
+
+
+def test_task_abi_struct_layout_matches_the_header():
+    """The ctypes mirrors in task_kernels.py must list the header's fields in order (a
+    mismatch would silently shift every pointer after it)."""
+    from robopianist_amd import task_kernels as tk
+    src = open(os.path.join(ROOT, "include", "rp_task.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+
+    def fields(struct):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), src, flags=re.S).group(1)
+        names = []
+        for stmt in body.split(";"):
+            stmt = stmt.strip()
+            if not stmt:
+                continue
+            for part in stmt.split(","):
+                names.append(re.findall(r"[A-Za-z_][A-Za-z_0-9]*", part)[-1])
+        return names
+
+    assert fields("rp_task_reward_args") == [f[0] for f in tk.RewardArgs._fields_]
+    assert fields("rp_task_advance_args") == [f[0] for f in tk.AdvanceArgs._fields_]
