@@ -3,6 +3,7 @@ without a GPU the product path fails loudly (no CPU fallback)."""
 import ctypes
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -106,3 +107,49 @@ def test_task_abi_struct_layout_matches_the_header():
 
     assert fields("rp_task_reward_args") == [f[0] for f in tk.RewardArgs._fields_]
     assert fields("rp_task_advance_args") == [f[0] for f in tk.AdvanceArgs._fields_]
+
+
+def _build_c_demo(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "c_abi_demo")
+    csrc = os.path.join(ROOT, "robopianist_amd", "csrc")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_abi_demo.c"), "-o", exe,
+                           "-L" + csrc, "-lrp_engine", "-Wl,-rpath," + csrc])
+    blob = str(tmp_path / "scene.blob")
+    subprocess.check_call([sys.executable, "-m", "robopianist_amd.tools.dump_blob", blob, "--gravity_compensation"],
+                          cwd=ROOT)
+    return exe, blob
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_plain_c_host_links_against_the_abi_and_fails_loudly_without_a_gpu(tmp_path):
+    """examples/c_abi_demo.c uses include/rp_engine.h only (gcc, no torch, no Python at run
+    time): the boundary is a plain C ABI."""
+    import subprocess
+    exe, blob = _build_c_demo(tmp_path)
+    r = subprocess.run([exe, blob, "4", "2"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_plain_c_host_reproduces_the_python_binding_bitwise(tmp_path):
+    import subprocess
+    import warnings
+    import numpy as np
+    from robopianist_amd.model import scene
+    exe, blob = _build_c_demo(tmp_path)
+    r = subprocess.run([exe, blob, "8", "5"], capture_output=True, text=True, check=True)
+    lines = r.stdout.strip().split("\n")
+    assert lines[0].startswith("nv 140 nu 44 envs 8 steps 5 warn 0")
+    q_c = np.array([float(x) for x in lines[1].split()])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=True)
+    phys = engine.BatchedPhysics(si.model, si.key_joint_ids, n_envs=8, precision=64)
+    ctrl = (0.2 + 0.01 * (np.arange(8 * 44) % 44)).reshape(8, 44)
+    phys.reset()
+    phys.set(engine.CTRL, ctrl)
+    for _ in range(5):
+        phys.step(10)
+    assert np.array_equal(phys.qpos[0].astype(np.float64), q_c)
