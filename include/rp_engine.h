@@ -97,7 +97,8 @@ int rp_forward(rp_engine* e);
 int rp_set_solver_limits(rp_engine* e, int max_newton_iter, int max_ls_iter);
 
 /* Newton termination tolerance / line-search tolerance (defaults: model opt.tolerance,
- * opt.ls_tolerance; values <= 0 leave the current setting). */
+ * opt.ls_tolerance; the fp32 build raises a default tolerance below 1e-6 to 1e-6, the resolution
+ * of single precision; values <= 0 leave the current setting). */
 int rp_set_solver_tolerance(rp_engine* e, double tolerance, double ls_tolerance);
 int rp_sync(rp_engine* e);
 int rp_get_stream(rp_engine* e, void** hip_stream);

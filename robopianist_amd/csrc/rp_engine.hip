@@ -166,6 +166,10 @@ struct Engine : EngineBase {
     auto g = b.f("opt_gravity");
     M.gx = (T)g[0]; M.gy = (T)g[1]; M.gz = (T)g[2];
     M.tolerance = (T)b.f1("opt_tolerance"); M.ls_tolerance = (T)b.f1("opt_ls_tolerance");
+    // single precision cannot resolve MuJoCo's default 1e-8: iterating below 1e-6 only chases
+    // rounding noise (measured: same accuracy against the fp64 engine, 5 % fewer iterations);
+    // rp_set_solver_tolerance overrides this
+    if (sizeof(T) == 4 && M.tolerance < (T)1e-6) M.tolerance = (T)1e-6;
     M.meaninertia = (T)b.f1("stat_meaninertia");
     // ---- pack every model table into the two device arrays (RpLayout offsets)
     std::vector<double> ft((size_t)RpLayout::F_TOTAL, 0.0);
