@@ -67,6 +67,20 @@ def _pmc_traffic(E, precision):
         return None
 
 
+def _issue_roofline(value, substeps):
+    """Issue-slot ceiling of the present instruction streams from the committed SQ counters
+    (profiles/r01_sq_instruction_mix.json: SQ_ACTIVE_INST_ANY per wave, in units of 4 cycles):
+    every SIMD issues for one wave at a time, 1024 SIMDs at 2.4 GHz."""
+    try:
+        k = json.load(open(os.path.join(ROOT, "profiles", "r01_sq_instruction_mix.json")))["kernels"]
+        act = sum(v["per_wave"]["SQ_ACTIVE_INST_ANY"] for v in k.values())
+    except Exception:
+        return None
+    ceiling = 1024 * 2.4e9 / (substeps * 4.0 * act)
+    return {"bound": "instruction issue", "achieved": value, "peak": ceiling, "unit": "env-steps/s",
+            "frac": value / ceiling, "source": "profiles/r01_sq_instruction_mix.json (fp64 kernels)"}
+
+
 def load_actions(m):
     a = np.load(os.path.join(ROOT, "tests", "golden", "twinkle_twinkle_actions.npy")).astype(np.float64)
     hands = a[:, :-1]
@@ -283,6 +297,7 @@ def main():
                         "The path is instruction-issue / latency bound (one wave per env; the fp64 solver runs one "
                         "wave per SIMD, the position kernel two), not HBM bound: see DESIGN.md 6",
             },
+            "issue_roofline": _issue_roofline(value / world, args.substeps) if args.precision == 64 else None,
             "sanity": {"warn_flags": warn, "finite": finite},
             "parity": "fp64 engine: max rel |dq| vs CPU oracle over 1000 mj_steps of this replay < 1e-4 "
                       "(measured live under cpu_baseline_parity when the CPU leg runs), "
