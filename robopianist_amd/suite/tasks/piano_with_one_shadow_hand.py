@@ -174,6 +174,7 @@ class PianoWithOneShadowHand(two_hands.PianoWithShadowHands):
         }
         if not self._disable_fingering_reward:
             obs["fingering"] = self._fingering_state
+        self._add_optional_observables(physics, obs)
         return obs
 
     def observation_spec(self):
@@ -187,6 +188,7 @@ class PianoWithOneShadowHand(two_hands.PianoWithShadowHands):
         }
         if not self._disable_fingering_reward:
             out["fingering"] = specs.Array((5,), d)
+        self._add_optional_specs(out)
         return out
 
     def steps_left(self):

@@ -478,7 +478,63 @@ class PianoWithShadowHands(base.PianoTask):
         }
         if not self._disable_fingering_reward:
             obs["fingering"] = self._fingering_state
+        self._add_optional_observables(physics, obs)
         return obs
+
+    # -- optional observables ------------------------------------------------------------------
+    # The reference's entities define more observables than the task enables
+    # (models/hands/base.py:75-114, shadow_hand.py:390-432, models/piano/piano.py:286-336); a user
+    # switches them on with `entity.observables.<name>.enabled = True`.  Here:
+    # `task.enable_observable("rh_shadow_hand/joints_vel")`.
+    _HAND_OBSERVABLES = ("joints_vel", "joints_pos_cos_sin", "actuators_force", "actuators_velocity",
+                         "actuators_power", "fingertip_positions")
+    _PIANO_OBSERVABLES = ("joints_pos", "activation", "sustain_activation")
+
+    def _present_hands(self):
+        return [h for h in (self.right_hand, self.left_hand) if h is not None]
+
+    def available_observables(self):
+        names = [f"{h.name}/{o}" for h in self._present_hands() for o in self._HAND_OBSERVABLES]
+        return names + [f"piano/{o}" for o in self._PIANO_OBSERVABLES]
+
+    def enable_observable(self, name: str, enabled: bool = True) -> None:
+        if name not in self.available_observables():
+            raise KeyError(f"Unknown observable {name!r}; optional observables: {self.available_observables()} "
+                           "(torque / touch sensors are not implemented)")
+        extra = getattr(self, "_extra_observables", [])
+        if enabled and name not in extra:
+            extra = extra + [name]
+        if not enabled:
+            extra = [n for n in extra if n != name]
+        self._extra_observables = extra
+
+    def _optional_observable(self, physics, name):
+        owner, what = name.split("/")
+        if owner == "piano":
+            if what == "joints_pos":
+                return physics.qpos[:, self.piano._jidx]
+            act = self.piano.activation if what == "activation" else self.piano.sustain_activation
+            return act.to(self._dtype)
+        hand = next(h for h in self._present_hands() if h.name == owner)
+        dev = self._physics_device
+        jnt = torch.as_tensor(hand.joints, device=dev, dtype=torch.long)
+        act = torch.as_tensor(hand.actuators, device=dev, dtype=torch.long)
+        if what == "joints_vel":
+            return physics.qvel[:, jnt]
+        if what == "joints_pos_cos_sin":
+            q = physics.qpos[:, jnt]
+            return torch.cat([torch.cos(q), torch.sin(q)], dim=1)
+        if what == "actuators_force":
+            return physics.act_force[:, act]
+        if what == "actuators_velocity":
+            return physics.act_vel[:, act]
+        if what == "actuators_power":
+            return physics.act_force[:, act].abs() * physics.act_vel[:, act].abs()
+        return physics.site_xpos(list(hand.fingertip_sites)).reshape(self._E, -1)  # fingertip_positions
+
+    def _add_optional_observables(self, physics, obs) -> None:
+        for name in getattr(self, "_extra_observables", ()):
+            obs[name] = self._optional_observable(physics, name)
 
     def observation_spec(self):
         L = self._n_steps_lookahead
@@ -492,7 +548,19 @@ class PianoWithShadowHands(base.PianoTask):
         }
         if not self._disable_fingering_reward:
             out["fingering"] = specs.Array((10,), d)
+        self._add_optional_specs(out)
         return out
+
+    def _add_optional_specs(self, out) -> None:
+        for name in getattr(self, "_extra_observables", ()):
+            owner, what = name.split("/")
+            if owner == "piano":
+                n = 88 if what != "sustain_activation" else 1
+            else:
+                hand = next(h for h in self._present_hands() if h.name == owner)
+                n = {"joints_vel": len(hand.joints), "joints_pos_cos_sin": 2 * len(hand.joints),
+                     "fingertip_positions": 15}.get(what, len(hand.actuators))
+            out[name] = specs.Array((n,), np.float64)
 
     # -- rewards ------------------------------------------------------------------------------
     def _compute_forearm_reward(self, physics):

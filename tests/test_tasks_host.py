@@ -354,3 +354,33 @@ def test_state_dict_round_trip_continues_the_episode_identically():
         for k in ta.observation:
             assert torch.equal(ta.observation[k], tb.observation[k]), k
     assert torch.equal(a.task._t_idx, b.task._t_idx) and int(a.task._t_idx[0]) == 12
+
+
+def test_optional_observables_can_be_enabled():
+    """The observables the reference's entities define but the task leaves disabled
+    (hands/base.py:75-114, shadow_hand.py:390-432, piano.py:286-336)."""
+    env = _get_env(n_envs=2)
+    task = env.task
+    assert "rh_shadow_hand/joints_vel" in task.available_observables()
+    with pytest.raises(KeyError):
+        task.enable_observable("rh_shadow_hand/joints_torque")
+    for name in ("rh_shadow_hand/joints_vel", "lh_shadow_hand/joints_pos_cos_sin", "rh_shadow_hand/actuators_power",
+                 "lh_shadow_hand/fingertip_positions", "piano/activation", "piano/joints_pos"):
+        task.enable_observable(name)
+    env.physics.qvel[:] = 0.5
+    env.physics.qpos[:, task._lh_jnt] = 0.25
+    ts = env.reset()
+    spec = env.observation_spec()
+    for k, v in ts.observation.items():
+        assert tuple(v.shape[1:]) == spec[k].shape, k
+    env.physics.qvel[:] = 0.5
+    env.physics.qpos[:, task._lh_jnt] = 0.25
+    obs = task.get_observation(env.physics)
+    assert obs["rh_shadow_hand/joints_vel"].shape == (2, 26) and float(obs["rh_shadow_hand/joints_vel"][0, 0]) == 0.5
+    cs = obs["lh_shadow_hand/joints_pos_cos_sin"]
+    assert cs.shape == (2, 52)
+    np.testing.assert_allclose(cs[0, :26].numpy(), np.cos(0.25)); np.testing.assert_allclose(cs[0, 26:].numpy(), np.sin(0.25))
+    assert obs["lh_shadow_hand/fingertip_positions"].shape == (2, 15)
+    assert obs["piano/activation"].shape == (2, 88)
+    task.enable_observable("piano/activation", False)
+    assert "piano/activation" not in task.get_observation(env.physics)
