@@ -123,8 +123,10 @@ class FusedRewards:
         a.key_activation = _chk(key_activation, torch.bool, (E, 88))
         a.sustain_activation = _chk(sustain_activation, torch.bool, (E, 1))
         a.finger_current = _chk(finger_current, torch.int64, (E, 88))
-        stream = torch.cuda.current_stream(self._phys.device).cuda_stream
-        if self._L.rp_task_rewards(ctypes.byref(a), ctypes.c_void_p(stream)) != 0:
+        with torch.cuda.device(self._phys.device):  # the launch must see the stream's device as current
+            stream = torch.cuda.current_stream(self._phys.device).cuda_stream
+            rc = self._L.rp_task_rewards(ctypes.byref(a), ctypes.c_void_p(stream))
+        if rc != 0:
             raise engine.EngineError(self._L.rp_task_last_error().decode())
         return self.total, self.terms
 
@@ -197,7 +199,9 @@ class FusedAdvance:
         p.finger_next = _chk(finger_next, torch.int64, (E, 88))
         p.fingering_state = _chk(fingering_state, dt, (E, 5 if a.hand_filter else 10))
         p.needs_reset = _chk(needs_reset, torch.bool, (E,))
-        stream = torch.cuda.current_stream(self._rw._phys.device).cuda_stream
-        if self._L.rp_task_advance(ctypes.byref(p), ctypes.c_void_p(stream)) != 0:
+        with torch.cuda.device(self._rw._phys.device):
+            stream = torch.cuda.current_stream(self._rw._phys.device).cuda_stream
+            rc = self._L.rp_task_advance(ctypes.byref(p), ctypes.c_void_p(stream))
+        if rc != 0:
             raise engine.EngineError(self._L.rp_task_last_error().decode())
         return self.step_type, self._rw.total, self.discount, self._rw.terms
