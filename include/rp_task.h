@@ -83,7 +83,7 @@ typedef struct rp_task_advance_args {
   const void* key_qrange;            /* [88][2] */
   const void* goal_bank; const long long* finger_bank;
   const long long* song_len;         /* [n_songs] */
-  const long long* song_id;          /* [E] */
+  long long* song_id;                /* [E] (written only in prefetch mode, see next_ready) */
   /* piano state */
   void* key_state;                   /* [E][88] clipped joint position */
   const void* sustain_state;         /* [E]     latched by before_step */
@@ -107,6 +107,15 @@ typedef struct rp_task_advance_args {
   double* eval_hist;                 /* [E][eval_deque][6] episode means */
   long long* eval_nfinished;         /* [E]    episodes finished */
   int eval_deque;
+  /* optional (next_ready == NULL: off): double-buffered goal bank for per-episode MIDI
+   * augmentations without a host round trip.  Env e owns bank slots 2e and 2e+1; the host keeps
+   * the slot the env is not playing filled with the tables of its next episode and sets
+   * next_ready[e].  When env e starts an episode and next_ready[e] is set, the launch switches
+   * song_id[e] to the other slot, clears next_ready[e] and raises consumed[e] (the host polls that
+   * asynchronously, refills the freed slot, clears it).  If the host is late the env replays its
+   * current tables. */
+  unsigned char* next_ready;         /* [E] in/out */
+  unsigned char* consumed;           /* [E] out (sticky) */
 } rp_task_advance_args;
 
 int rp_task_advance(const rp_task_advance_args* args, void* hip_stream);

@@ -137,7 +137,12 @@ __global__ __launch_bounds__(64) void rp_task_advance_kernel(rp_task_advance_arg
   long long t = p.t_idx[env];
   T dstate = ((T*)p.discount_state)[env];
   if (resetting) { t = 0; dstate = (T)1; }  // _reset_quantities_at_episode_init (:146-149)
-  const long long song = p.song_id[env], slen = p.song_len[song];
+  long long song = p.song_id[env];
+  if (resetting && p.next_ready && p.next_ready[env]) {  // prefetch mode: switch to the prepared slot
+    song ^= 1;
+    if (lane == 0) { p.song_id[env] = song; p.next_ready[env] = 0; p.consumed[env] = 1; }
+  }
+  const long long slen = p.song_len[song];
   const T* qpos = (const T*)a.qpos + (size_t)env * a.nv;
   T* gstate = (T*)p.goal_state + (size_t)env * (p.n_lookahead + 1) * 89;
 
@@ -293,6 +298,7 @@ int rp_task_advance(const rp_task_advance_args* p, void* hip_stream) {
   if (a->precision != 32 && a->precision != 64) { g_task_err = "rp_task_advance: precision must be 32 or 64"; return -1; }
   if (a->n_envs <= 0 || p->n_lookahead < 0 || p->bank_len <= 0) { g_task_err = "rp_task_advance: bad sizes"; return -1; }
   if (a->hand_filter < 0 || a->hand_filter > 2) { g_task_err = "rp_task_advance: hand_filter must be 0, 1 or 2"; return -1; }
+  if (p->next_ready && !p->consumed) { g_task_err = "rp_task_advance: next_ready without consumed"; return -1; }
   if (p->eval_sums && (!p->eval_count || !p->eval_hist || !p->eval_nfinished || p->eval_deque <= 0)) {
     g_task_err = "rp_task_advance: incomplete evaluation buffers";
     return -1;

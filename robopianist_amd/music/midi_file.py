@@ -317,12 +317,23 @@ class NoteTrajectory:
         e_frame = np.maximum(s_frame + 1, np.ceil(a.end * fps).astype(np.int64))
         key = a.pitch - consts.MIN_MIDI_PITCH_PIANO
         v32 = a.velocity.astype(np.float64) / consts.MAX_VELOCITY
-        for i in np.argsort(a.start, kind="stable"):             # later notes overwrite earlier ones
-            s0, e0, k = int(s_frame[i]), int(e_frame[i]), int(key[i])
-            vel[s0:e0, k] = v32[i]
-            fing[s0:e0, k] = a.part[i]
-            if s0 < T:
-                onset[s0, k] = True
+        # rasterise all notes at once: one (frame, key) index pair per covered frame, notes in
+        # start order -- NumPy assigns repeated indices in order, so later notes overwrite
+        # earlier ones exactly like the per-note slice assignments of the piano roll
+        order = np.argsort(a.start, kind="stable")
+        s_o = np.minimum(s_frame[order], T)
+        e_o = np.minimum(e_frame[order], T)
+        n_fr = np.maximum(e_o - s_o, 0)
+        total = int(n_fr.sum())
+        if total:
+            note = np.repeat(np.arange(len(order)), n_fr)
+            first = np.cumsum(n_fr) - n_fr
+            frame = np.arange(total) - first[note] + s_o[note]
+            kcol = key[order][note]
+            vel[frame, kcol] = v32[order][note].astype(np.float32)
+            fing[frame, kcol] = a.part[order][note].astype(np.int32)
+        starts_in = s_frame[order] < T
+        onset[s_frame[order][starts_in], key[order][starts_in]] = True
         active = vel != 0
         repeated = np.zeros_like(active)
         repeated[1:] = active[:-1] & active[1:] & onset[1:]      # seq_to_trajectory's `continue`

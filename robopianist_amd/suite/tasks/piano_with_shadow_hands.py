@@ -9,7 +9,11 @@ env e then plays song e % len(midi) (heterogeneous goal bank, BASELINE config #5
 episode start of env e the variations are applied to that env's initial MIDI on the host
 (reference: _maybe_change_midi, :151-157), its goal / fingering tables are rebuilt and
 uploaded into slot e.  This needs the set of resetting envs on the host, i.e. one small
-device->host read per control step, and ~10 ms of host work per episode start.
+device->host read per control step, and ~0.2 ms of host work per episode start.
+`augmentation_prefetch=True` (an extension) removes the read: every env owns two bank slots, the host
+keeps the idle one filled with the tables of the env's next episode, the fused launch switches slots
+when an episode starts and raises a flag the host polls asynchronously
+(include/rp_task.h `next_ready` / `consumed`).  Draws then happen ahead of time, in refill order.
 """
 
 from __future__ import annotations
@@ -47,9 +51,13 @@ class PianoWithShadowHands(base.PianoTask):
         augmentations=None,
         energy_penalty_coef: float = _ENERGY_PENALTY_COEF,
         randomize_hand_positions: bool = False,
+        augmentation_prefetch: bool = False,
         **kwargs,
     ) -> None:
         super().__init__(disable_hand_collisions=disable_hand_collisions, **kwargs)
+        # extension (not in the reference): keep the tables of every env's NEXT episode ready in a
+        # second bank slot, so that augmentations need no device->host read per step
+        self._prefetch = bool(augmentation_prefetch) and augmentations is not None
         del disable_colorization  # cosmetic (:451-474)
         self._augmentations = list(augmentations) if augmentations is not None else None
         midis = list(midi) if isinstance(midi, (list, tuple)) else [midi]
@@ -129,20 +137,35 @@ class PianoWithShadowHands(base.PianoTask):
         to the env's initial MIDI with the task's RandomState, in env order."""
         if self._augmentations is None:
             return
+        if self._prefetch:
+            if mask is not None:
+                raise RuntimeError("augmentation_prefetch runs on the fused HIP task path only")
+            self._prefetch_full_reset()
+            return
         E = self._E
         envs = range(E) if mask is None else np.flatnonzero(mask.detach().cpu().numpy())
         if len(envs) == 0:
             return
+        rows = self._draw_tables(envs)
+        self._upload_tables(np.asarray(envs, np.int64), rows)
+
+    def _draw_tables(self, envs):
+        """Applies the variations to the initial MIDI of each env in `envs` (task RandomState, in
+        that order) and returns their (goal, finger) tables."""
         ns = len(self._initial_midis)
-        rows, lens = [], []
+        rows = []
         for e in envs:
             initial = self._initial_midis[e % ns]
             midi = initial
             for var in self._augmentations:
                 midi = var(initial_value=midi, random_state=self._random_state)
             self._env_midi[e] = midi
-            g, f = self._song_tables[e % ns] if midi is initial else self._tables_for(midi)
-            rows.append((g, f)); lens.append(len(g))
+            rows.append(self._song_tables[e % ns] if midi is initial else self._tables_for(midi))
+        return rows
+
+    def _upload_tables(self, slots, rows) -> None:
+        """Writes `rows` into the bank slots `slots` (grows the bank if a song is longer)."""
+        lens = [len(g) for g, _ in rows]
         need = max(lens)
         if need > self._goal_bank.shape[1]:
             self._grow_bank(need + need // 4)
@@ -153,10 +176,44 @@ class PianoWithShadowHands(base.PianoTask):
             goal[i, :len(g)] = g
             finger[i, :len(g)] = f
         dev = self._physics_device
-        idx = torch.as_tensor(np.asarray(envs, np.int64), device=dev)
+        idx = torch.as_tensor(np.asarray(slots, np.int64), device=dev)
         self._goal_bank.index_copy_(0, idx, torch.as_tensor(goal, device=dev).to(self._dtype))
         self._finger_bank.index_copy_(0, idx, torch.as_tensor(finger, device=dev))
         self._song_len.index_copy_(0, idx, torch.as_tensor(np.asarray(lens, np.int64), device=dev))
+
+    # -- prefetch mode ---------------------------------------------------------------------
+    def _prefetch_full_reset(self) -> None:
+        """Environment.reset(): current tables into slot 2e, next episode's into 2e+1."""
+        E = self._E
+        envs = np.arange(E, dtype=np.int64)
+        self._upload_tables(2 * envs, self._draw_tables(envs))
+        self._upload_tables(2 * envs + 1, self._draw_tables(envs))
+        self._song_id.copy_(torch.as_tensor(2 * envs, device=self._physics_device))
+        self._host_parity = np.zeros(E, np.int64)
+        self._next_ready.fill_(1)
+        self._consumed.zero_()
+        self._poll_event = None
+        self.prefetch_refills = 0
+
+    def _prefetch_poll(self) -> None:
+        """Non-blocking: if the last snapshot of the `consumed` flags has arrived, refill the
+        freed slots, then request the next snapshot."""
+        ev = self._poll_event
+        if ev is not None and not ev.query():
+            return
+        if ev is not None:
+            envs = np.flatnonzero(self._consumed_host.numpy())
+            if len(envs):
+                self._host_parity[envs] ^= 1                       # those envs switched slots
+                free = 2 * envs + (self._host_parity[envs] ^ 1)
+                self._upload_tables(free, self._draw_tables(envs))
+                idx = torch.as_tensor(envs, device=self._physics_device)
+                self._consumed.index_fill_(0, idx, 0)              # (stream-ordered after the upload)
+                self._next_ready.index_fill_(0, idx, 1)
+                self.prefetch_refills += len(envs)
+        self._consumed_host.copy_(self._consumed, non_blocking=True)
+        self._poll_event = torch.cuda.Event()
+        self._poll_event.record(torch.cuda.current_stream(self._physics_device))
 
     def _grow_bank(self, cap: int) -> None:
         """Reallocates the per-env bank with `cap` rows (the fused launch arguments hold
@@ -173,7 +230,11 @@ class PianoWithShadowHands(base.PianoTask):
         """Host-side part of initialize_episode that the fused device path cannot do:
         the MIDI augmentations of the envs that start an episode in this step."""
         del physics
-        if self._augmentations is not None:
+        if self._augmentations is None:
+            return
+        if self._prefetch:
+            self._prefetch_poll()
+        else:
             self._maybe_change_midi(mask)
 
     @property
@@ -200,6 +261,19 @@ class PianoWithShadowHands(base.PianoTask):
             self._song_id = torch.arange(E, device=dev)
             self._env_midi = [self._initial_midis[e % len(self._initial_midis)] for e in range(E)]
             self._fused_advance = None
+            if self._prefetch:
+                if dev.type != "cuda":
+                    raise ValueError("augmentation_prefetch needs the HIP task path (a GPU)")
+                self._goal_bank = self._goal_bank.repeat_interleave(2, dim=0).contiguous()
+                self._finger_bank = self._finger_bank.repeat_interleave(2, dim=0).contiguous()
+                self._song_len = self._song_len.repeat_interleave(2).contiguous()
+                self._song_id = 2 * torch.arange(E, device=dev)
+                self._next_ready = torch.zeros(E, dtype=torch.uint8, device=dev)
+                self._consumed = torch.zeros(E, dtype=torch.uint8, device=dev)
+                self._consumed_host = torch.zeros(E, dtype=torch.uint8).pin_memory()
+                self._host_parity = np.zeros(E, np.int64)
+                self._poll_event = None
+                self.prefetch_refills = 0
 
     def _bind_hands(self):
         dev, m = self._physics_device, self.scene.model
@@ -261,6 +335,11 @@ class PianoWithShadowHands(base.PianoTask):
         if self._augmentations is not None:
             for k in ("_goal_bank", "_finger_bank", "_song_len"):
                 sd[k] = getattr(self, k).detach().clone()
+        if self._prefetch:
+            torch.cuda.synchronize(self._physics_device)
+            for k in ("_song_id", "_next_ready", "_consumed"):
+                sd[k] = getattr(self, k).detach().clone()
+            sd["_host_parity"] = self._host_parity.copy()
         if hasattr(self, "_tree_offset"):
             sd["_tree_offset"] = self._tree_offset.detach().clone()
         return sd
@@ -277,6 +356,11 @@ class PianoWithShadowHands(base.PianoTask):
             self._finger_bank = sd["_finger_bank"].to(dev).clone()
             self._song_len.copy_(sd["_song_len"].to(dev))
             self._fused_advance = None
+        if self._prefetch:
+            for k in ("_song_id", "_next_ready", "_consumed"):
+                getattr(self, k).copy_(sd[k].to(dev))
+            self._host_parity = np.array(sd["_host_parity"], np.int64)
+            self._poll_event = None  # a pending snapshot belongs to the old state
         if "_tree_offset" in sd:
             self._tree_offset = sd["_tree_offset"].to(dev).clone()
 
@@ -376,6 +460,8 @@ class PianoWithShadowHands(base.PianoTask):
                 key_qrange=self.piano._qpos_range)
             if getattr(self, "_eval_buffers", None) is not None:
                 self._fused_advance.set_evaluation_buffers(*self._eval_buffers)
+            if self._prefetch:
+                self._fused_advance.set_prefetch_buffers(self._next_ready, self._consumed)
         return self._fused_advance
 
     def set_evaluation_buffers(self, buffers) -> None:

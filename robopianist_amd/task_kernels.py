@@ -54,6 +54,7 @@ class AdvanceArgs(ctypes.Structure):
         ("discount", ctypes.c_void_p), ("step_type", ctypes.c_void_p),
         ("eval_sums", ctypes.c_void_p), ("eval_count", ctypes.c_void_p), ("eval_hist", ctypes.c_void_p),
         ("eval_nfinished", ctypes.c_void_p), ("eval_deque", ctypes.c_int),
+        ("next_ready", ctypes.c_void_p), ("consumed", ctypes.c_void_p),
     ]
 
 
@@ -161,6 +162,19 @@ class FusedAdvance:
         p.discount, p.step_type = self.discount.data_ptr(), self.step_type.data_ptr()
         self._p = p
         self._L_lookahead = int(n_lookahead)
+
+    def set_prefetch_buffers(self, next_ready, consumed):
+        """Double-buffered goal bank (include/rp_task.h `next_ready` / `consumed`); None: off."""
+        p, E = self._p, self._E
+        if next_ready is None:
+            p.next_ready = p.consumed = None
+            self._prefetch = None
+            return
+        if int(self._goal_bank.shape[0]) != 2 * E:
+            raise engine.EngineError("prefetch mode needs two bank slots per env")
+        p.next_ready = _chk(next_ready, torch.uint8, (E,))
+        p.consumed = _chk(consumed, torch.uint8, (E,))
+        self._prefetch = (next_ready, consumed)
 
     def set_evaluation_buffers(self, sums, count, hist, n_finished):
         """Turns on the MidiEvaluationWrapper reduction inside the launch (None: off)."""

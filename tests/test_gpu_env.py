@@ -557,6 +557,60 @@ def test_evaluation_wrapper_fused_reduction_matches_torch():
     assert 0.0 < ma["f1"] < 1.0 and ma["recall"] > 0.0, ma
 
 
+def test_augmentation_prefetch_switches_bank_slots_without_host_reads():
+    """`augmentation_prefetch=True`: every env owns two goal-bank slots; the fused launch
+    switches to the prepared slot when an episode starts (include/rp_task.h next_ready /
+    consumed) and the host refills the freed slot from an asynchronous snapshot of the flags.
+    Checks: slots stay inside the env's pair, every episode start finds a table the host
+    uploaded for that env, songs change from episode to episode, refills keep up."""
+    from robopianist_amd import suite
+    from robopianist_amd.suite import variations
+    E = 16
+    augs = [variations.MidiTemporalStretch(prob=1.0, stretch_range=0.3),
+            variations.MidiPitchShift(prob=1.0, shift_range=6)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        env = suite.load("RoboPianist-debug-CMajorScaleOneHand-v0", seed=9, n_envs=E, precision=64,
+                         task_kwargs=dict(control_timestep=0.05, gravity_compensation=True,
+                                          primitive_fingertip_collisions=True, augmentations=augs,
+                                          augmentation_prefetch=True))
+    task = env.task
+    uploads = {}
+    orig = task._upload_tables
+    def recording_upload(slots, rows):
+        for sl, (g, _) in zip(slots, rows):
+            uploads[int(sl)] = g.copy()
+        orig(slots, rows)
+    task._upload_tables = recording_upload
+    env.reset()
+    assert task.fused_advance_for(env.physics) is not None and task._goal_bank.shape[0] == 2 * E
+    zero = torch.zeros((E, 45), device=env.physics.device, dtype=torch.float64)
+    lens_seen = [set() for _ in range(E)]
+    starts = np.zeros(E, int)
+    stale = 0
+    prev_slot = task._song_id.clone().cpu().numpy()
+    for step in range(700):
+        ts = env.step(zero)
+        first = ts.first().cpu().numpy()
+        if first.any():
+            sid = task._song_id.cpu().numpy()
+            assert (sid // 2 == np.arange(E)).all()
+            for e in np.flatnonzero(first):
+                g = uploads[int(sid[e])]
+                n = int(task._song_len[sid[e]])
+                assert n == len(g)
+                np.testing.assert_array_equal(_np(task._goal_bank[sid[e], :n]), g)
+                np.testing.assert_array_equal(_np(ts.observation["goal"][e][:89]), g[0])
+                lens_seen[e].add(n)
+                starts[e] += 1
+                stale += int(sid[e] == prev_slot[e])   # host was late: the env replays its tables
+            prev_slot = sid.copy()
+    assert starts.min() >= 3
+    assert sum(len(s) >= 2 for s in lens_seen) >= E - 2, lens_seen
+    assert stale == 0, "the refills did not keep up"
+    assert task.prefetch_refills >= starts.sum() - 2 * E
+
+
 def test_uniformly_random_actions_do_not_diverge():
     """BASELINE config 3's policy (i.i.d. uniform actions every step) at 8192 envs: hands
     swing into each other at ~18 rad/s and pile up more contacts / Jacobian entries than the
