@@ -119,6 +119,38 @@ typedef struct rp_task_advance_args {
 } rp_task_advance_args;
 
 int rp_task_advance(const rp_task_advance_args* args, void* hip_stream);
+
+/* rp_task_rasterize: goal / fingering tables of augmented songs, built on the device.
+ * What the reference does on the host at every episode start when `augmentations` are given
+ * (suite/tasks/piano_with_shadow_hands.py:151-165): MidiFile.stretch / transpose
+ * (music/midi_file.py:214-243), sequence_to_pianoroll (music/piano_roll.py:59-204, onset window 0)
+ * and NoteTrajectory.seq_to_trajectory incl. the repeated-note gap and the sustain latch
+ * (music/midi_file.py:315-362), then the tables the vectorised task reads.  One workgroup per job
+ * (= one bank slot); a job names a base song and an ordered list of operations. */
+typedef struct rp_task_raster_args {
+  int n_jobs, precision;
+  int n_songs, bank_len, max_ops, n_buffer;   /* n_buffer: rows of silence in front (initial_buffer_time) */
+  double fps;                                 /* 1 / control_timestep */
+  /* base songs: notes stably sorted by start time, CC64 (sustain) events in file order */
+  const long long* note_ofs;                  /* [n_songs + 1] */
+  const double* note_start; const double* note_end;
+  const int* note_pitch; const int* note_velocity; const int* note_part;
+  const long long* cc_ofs;                    /* [n_songs + 1] */
+  const double* cc_time; const int* cc_value;
+  const double* total_time;                   /* [n_songs] */
+  /* jobs */
+  const long long* job_slot;                  /* [n_jobs] bank slot to fill */
+  const int* job_song;                        /* [n_jobs] base song */
+  const int* op_kind;                         /* [n_jobs][max_ops] 0 = none, 1 = stretch, 2 = transpose */
+  const double* op_value;                     /* [n_jobs][max_ops] factor / semitones */
+  /* outputs */
+  void* goal_bank;                            /* [n_slots][bank_len][89] */
+  long long* finger_bank;                     /* [n_slots][bank_len][88] */
+  long long* song_len;                        /* [n_slots] */
+  int* status;                                /* [n_jobs] 0 = done, 1 = does not fit in bank_len rows (slot untouched) */
+} rp_task_raster_args;
+
+int rp_task_rasterize(const rp_task_raster_args* args, void* hip_stream);
 const char* rp_task_last_error(void);
 
 #ifdef __cplusplus

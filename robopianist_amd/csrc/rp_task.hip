@@ -267,6 +267,82 @@ __global__ __launch_bounds__(64) void rp_task_advance_kernel(rp_task_advance_arg
     }
   }
 }
+// ---- goal tables of augmented songs -----------------------------------------------------------
+// thread k < 88 owns piano key k of the job's slot, thread 88 the sustain column
+#define RP_ONSET_BIT (1ll << 40)
+template <typename T>
+__global__ __launch_bounds__(128) void rp_task_raster_kernel(rp_task_raster_args a) {
+  const int job = blockIdx.x, tid = threadIdx.x;
+  const int song = a.job_song[job];
+  const long long slot = a.job_slot[job];
+  const int* kinds = a.op_kind + (size_t)job * a.max_ops;
+  const double* vals = a.op_value + (size_t)job * a.max_ops;
+  double total = a.total_time[song];
+  for (int o = 0; o < a.max_ops; o++)
+    if (kinds[o] == 1 && vals[o] != 1.0) total *= vals[o];
+  const long long Tn = (long long)(total * a.fps + 1.0), nb = a.n_buffer;
+  if (Tn + nb > a.bank_len) {  // uniform: the host grows the bank and retries
+    if (tid == 0) a.status[job] = 1;
+    return;
+  }
+  T* goal = (T*)a.goal_bank + (size_t)slot * a.bank_len * 89;
+  long long* fing = a.finger_bank + (size_t)slot * a.bank_len * 88;
+  for (long long i = tid; i < (long long)a.bank_len * 89; i += blockDim.x) goal[i] = (T)0;
+  for (long long i = tid; i < (long long)a.bank_len * 88; i += blockDim.x) fing[i] = -1;
+  __syncthreads();
+  if (tid < 88) {
+    const int k = tid;
+    // rows of this song hold (part + 1) | onset flag while the notes are laid down
+    for (long long t = 0; t < Tn; t++) fing[(nb + t) * 88 + k] = 0;
+    for (long long i = a.note_ofs[song]; i < a.note_ofs[song + 1]; i++) {
+      double st = a.note_start[i], en = a.note_end[i];
+      long long pitch = a.note_pitch[i];
+      bool kept = true;
+      for (int o = 0; o < a.max_ops && kept; o++) {
+        if (kinds[o] == 1) { if (vals[o] != 1.0) { st *= vals[o]; en *= vals[o]; } }
+        else if (kinds[o] == 2) { pitch += (long long)vals[o]; kept = pitch >= 21 && pitch <= 108; }  // out of range: deleted
+      }
+      if (!kept || pitch - 21 != k) continue;
+      const long long s0 = (long long)(st * a.fps);
+      long long e0 = (long long)ceil(en * a.fps);
+      if (e0 < s0 + 1) e0 = s0 + 1;                      // every note fills at least one frame
+      const T on = a.note_velocity[i] != 0 ? (T)1 : (T)0;
+      const long long code = (long long)a.note_part[i] + 1;
+      for (long long t = s0; t < e0 && t < Tn; t++) {
+        goal[(nb + t) * 89 + k] = on;                     // later notes overwrite earlier ones
+        long long* f = &fing[(nb + t) * 88 + k];
+        *f = code | (*f & RP_ONSET_BIT) | (t == s0 ? RP_ONSET_BIT : 0);
+      }
+    }
+    // repeated note: a key that is held and struck again in the same frame is released for that frame
+    for (long long t = Tn - 1; t >= 0; t--) {
+      const long long c = fing[(nb + t) * 88 + k];
+      const bool act = goal[(nb + t) * 89 + k] != (T)0;
+      const bool rep = t > 0 && act && goal[(nb + t - 1) * 89 + k] != (T)0 && (c & RP_ONSET_BIT);
+      const bool on = act && !rep;
+      goal[(nb + t) * 89 + k] = on ? (T)1 : (T)0;
+      fing[(nb + t) * 88 + k] = on ? (c & 0xffffffffll) - 1 : -1;
+    }
+  } else if (tid == 88) {
+    for (long long i = a.cc_ofs[song]; i < a.cc_ofs[song + 1]; i++) {
+      double tm = a.cc_time[i];
+      for (int o = 0; o < a.max_ops; o++)
+        if (kinds[o] == 1 && vals[o] != 1.0) tm *= vals[o];
+      const long long fr = (long long)(tm * a.fps);
+      if (fr < Tn) goal[(nb + fr) * 89 + 88] = (T)(a.cc_value[i] + 1);   // last event of a frame decides
+    }
+    T prev = 0;
+    for (long long t = 0; t < Tn; t++) {
+      const int ev = (int)goal[(nb + t) * 89 + 88];
+      T sus = prev;
+      if (ev >= 1 && ev <= 64) sus = 0;
+      else if (ev >= 65 && ev <= 128) sus = 1;
+      goal[(nb + t) * 89 + 88] = sus;
+      prev = sus;
+    }
+  }
+  if (tid == 0) { a.song_len[slot] = Tn + nb; a.status[job] = 0; }
+}
 }  // namespace
 
 extern "C" {
@@ -317,6 +393,28 @@ int rp_task_advance(const rp_task_advance_args* p, void* hip_stream) {
   else hipLaunchKernelGGL(rp_task_advance_kernel<double>, dim3(a->n_envs), dim3(64), 0, s, *p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { g_task_err = std::string("rp_task_advance: ") + hipGetErrorString(e); return -2; }
+  return 0;
+}
+
+int rp_task_rasterize(const rp_task_raster_args* a, void* hip_stream) {
+  if (!a) { g_task_err = "rp_task_rasterize: null args"; return -1; }
+  if (a->precision != 32 && a->precision != 64) { g_task_err = "rp_task_rasterize: precision must be 32 or 64"; return -1; }
+  if (a->n_jobs < 0 || a->n_songs <= 0 || a->bank_len <= 0 || a->max_ops < 0 || a->n_buffer < 0 || !(a->fps > 0)) {
+    g_task_err = "rp_task_rasterize: bad sizes";
+    return -1;
+  }
+  if (!a->note_ofs || !a->note_start || !a->note_end || !a->note_pitch || !a->note_velocity || !a->note_part ||
+      !a->cc_ofs || !a->total_time || !a->job_slot || !a->job_song || !a->goal_bank || !a->finger_bank ||
+      !a->song_len || !a->status || (a->max_ops > 0 && (!a->op_kind || !a->op_value))) {
+    g_task_err = "rp_task_rasterize: null array pointer";
+    return -1;
+  }
+  if (a->n_jobs == 0) return 0;
+  hipStream_t s = (hipStream_t)hip_stream;
+  if (a->precision == 32) hipLaunchKernelGGL(rp_task_raster_kernel<float>, dim3(a->n_jobs), dim3(128), 0, s, *a);
+  else hipLaunchKernelGGL(rp_task_raster_kernel<double>, dim3(a->n_jobs), dim3(128), 0, s, *a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { g_task_err = std::string("rp_task_rasterize: ") + hipGetErrorString(e); return -2; }
   return 0;
 }
 

@@ -13,7 +13,7 @@ import torch
 
 from robopianist_amd import engine
 
-EXPORTED_SYMBOLS = ("rp_task_rewards", "rp_task_advance", "rp_task_last_error")
+EXPORTED_SYMBOLS = ("rp_task_rewards", "rp_task_advance", "rp_task_rasterize", "rp_task_last_error")
 TERM_NAMES = ("key_press_reward", "sustain_reward", "energy_reward", "fingering_reward", "forearm_reward")
 
 
@@ -58,6 +58,22 @@ class AdvanceArgs(ctypes.Structure):
     ]
 
 
+class RasterArgs(ctypes.Structure):
+    _fields_ = [
+        ("n_jobs", ctypes.c_int), ("precision", ctypes.c_int),
+        ("n_songs", ctypes.c_int), ("bank_len", ctypes.c_int), ("max_ops", ctypes.c_int), ("n_buffer", ctypes.c_int),
+        ("fps", ctypes.c_double),
+        ("note_ofs", ctypes.c_void_p), ("note_start", ctypes.c_void_p), ("note_end", ctypes.c_void_p),
+        ("note_pitch", ctypes.c_void_p), ("note_velocity", ctypes.c_void_p), ("note_part", ctypes.c_void_p),
+        ("cc_ofs", ctypes.c_void_p), ("cc_time", ctypes.c_void_p), ("cc_value", ctypes.c_void_p),
+        ("total_time", ctypes.c_void_p),
+        ("job_slot", ctypes.c_void_p), ("job_song", ctypes.c_void_p), ("op_kind", ctypes.c_void_p),
+        ("op_value", ctypes.c_void_p),
+        ("goal_bank", ctypes.c_void_p), ("finger_bank", ctypes.c_void_p), ("song_len", ctypes.c_void_p),
+        ("status", ctypes.c_void_p),
+    ]
+
+
 def _lib():
     L = engine.load_library()
     if not getattr(L, "_rp_task_ready", False):
@@ -65,6 +81,8 @@ def _lib():
         L.rp_task_rewards.restype = ctypes.c_int
         L.rp_task_advance.argtypes = [ctypes.POINTER(AdvanceArgs), ctypes.c_void_p]
         L.rp_task_advance.restype = ctypes.c_int
+        L.rp_task_rasterize.argtypes = [ctypes.POINTER(RasterArgs), ctypes.c_void_p]
+        L.rp_task_rasterize.restype = ctypes.c_int
         L.rp_task_last_error.restype = ctypes.c_char_p
         L._rp_task_ready = True
     return L
@@ -219,3 +237,73 @@ class FusedAdvance:
         if rc != 0:
             raise engine.EngineError(self._L.rp_task_last_error().decode())
         return self.step_type, self._rw.total, self.discount, self._rw.terms
+
+
+class Rasterizer:
+    """rp_task_rasterize: goal / fingering tables of stretched / transposed songs built on the
+    device.  `songs` are music.midi_file.NoteArrays of the base songs (pitches on the piano,
+    velocities <= 127: the caller checks); a job = (bank slot, base song, ordered ops)."""
+
+    MAX_OPS = 8
+    KIND = {"stretch": 1, "transpose": 2}
+
+    def __init__(self, device, dtype, songs, control_timestep, initial_buffer_time):
+        import numpy as np
+        self._L = _lib()
+        self._dev, self._dt = device, dtype
+        order = [np.argsort(a.start, kind="stable") for a in songs]
+        cat = lambda xs, dt: torch.as_tensor(np.concatenate(xs) if xs else np.zeros(0), dtype=dt, device=device).contiguous()
+        ofs = lambda ns: torch.as_tensor(np.concatenate([[0], np.cumsum(ns)]), dtype=torch.int64, device=device)
+        self._note_ofs = ofs([len(a.start) for a in songs])
+        self._start = cat([a.start[o] for a, o in zip(songs, order)], torch.float64)
+        self._end = cat([a.end[o] for a, o in zip(songs, order)], torch.float64)
+        self._pitch = cat([a.pitch[o] for a, o in zip(songs, order)], torch.int32)
+        self._vel = cat([a.velocity[o] for a, o in zip(songs, order)], torch.int32)
+        self._part = cat([a.part[o] for a, o in zip(songs, order)], torch.int32)
+        sus = [a.cc_num == 64 for a in songs]
+        self._cc_ofs = ofs([int(m.sum()) for m in sus])
+        self._cc_time = cat([a.cc_time[m] for a, m in zip(songs, sus)], torch.float64)
+        self._cc_val = cat([a.cc_val[m] for a, m in zip(songs, sus)], torch.int32)
+        self._total = torch.as_tensor([a.total_time for a in songs], dtype=torch.float64, device=device)
+        p = RasterArgs()
+        p.precision = 64 if dtype == torch.float64 else 32
+        p.n_songs, p.max_ops = len(songs), self.MAX_OPS
+        p.fps = 1 / control_timestep
+        p.n_buffer = int(round(initial_buffer_time / control_timestep))
+        p.note_ofs, p.note_start, p.note_end = self._note_ofs.data_ptr(), self._start.data_ptr(), self._end.data_ptr()
+        p.note_pitch, p.note_velocity, p.note_part = self._pitch.data_ptr(), self._vel.data_ptr(), self._part.data_ptr()
+        p.cc_ofs, p.cc_time, p.cc_value = self._cc_ofs.data_ptr(), self._cc_time.data_ptr(), self._cc_val.data_ptr()
+        p.total_time = self._total.data_ptr()
+        self._p = p
+        self._keep = None
+
+    def rasterize(self, goal_bank, finger_bank, song_len, slots, songs, ops):
+        """Enqueues the launch on torch's current stream; returns the per-job status tensor
+        (0 = done, 1 = does not fit in the bank's rows).  ops[j] = [("stretch", f) | ("transpose", k), ...]."""
+        import numpy as np
+        n = len(slots)
+        kind = np.zeros((n, self.MAX_OPS), np.int32)
+        val = np.zeros((n, self.MAX_OPS), np.float64)
+        for j, seq in enumerate(ops):
+            for o, (k, v) in enumerate(seq):
+                kind[j, o] = self.KIND[k]; val[j, o] = v
+        dev = self._dev
+        t_slot = torch.as_tensor(np.asarray(slots, np.int64), device=dev)
+        t_song = torch.as_tensor(np.asarray(songs, np.int32), device=dev)
+        t_kind, t_val = torch.as_tensor(kind, device=dev), torch.as_tensor(val, device=dev)
+        status = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        p = self._p
+        p.n_jobs, p.bank_len = n, int(goal_bank.shape[1])
+        p.job_slot, p.job_song = t_slot.data_ptr(), t_song.data_ptr()
+        p.op_kind, p.op_value = t_kind.data_ptr(), t_val.data_ptr()
+        S = int(goal_bank.shape[0])
+        p.goal_bank = _chk(goal_bank, self._dt, (S, p.bank_len, 89))
+        p.finger_bank = _chk(finger_bank, torch.int64, (S, p.bank_len, 88))
+        p.song_len = _chk(song_len, torch.int64, (S,))
+        p.status = status.data_ptr()
+        with torch.cuda.device(dev):
+            rc = self._L.rp_task_rasterize(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise engine.EngineError(self._L.rp_task_last_error().decode())
+        self._keep = (t_slot, t_song, t_kind, t_val, status)  # alive until the launch has run
+        return status

@@ -107,6 +107,7 @@ def test_task_abi_struct_layout_matches_the_header():
 
     assert fields("rp_task_reward_args") == [f[0] for f in tk.RewardArgs._fields_]
     assert fields("rp_task_advance_args") == [f[0] for f in tk.AdvanceArgs._fields_]
+    assert fields("rp_task_raster_args") == [f[0] for f in tk.RasterArgs._fields_]
 
 
 def _build_c_demo(tmp_path):

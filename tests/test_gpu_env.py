@@ -576,13 +576,14 @@ def test_augmentation_prefetch_switches_bank_slots_without_host_reads():
                                           augmentation_prefetch=True))
     task = env.task
     uploads = {}
-    orig = task._upload_tables
-    def recording_upload(slots, rows):
-        for sl, (g, _) in zip(slots, rows):
-            uploads[int(sl)] = g.copy()
-        orig(slots, rows)
-    task._upload_tables = recording_upload
+    orig = task._fill_slots
+    def recording_fill(slots, envs):
+        orig(slots, envs)
+        for sl, e in zip(slots, envs):   # expected table: the host path on the MIDI just drawn for e
+            uploads[int(sl)] = task._tables_for(task._env_midi[e])[0]
+    task._fill_slots = recording_fill
     env.reset()
+    assert task._device_rasterizer() is not None
     assert task.fused_advance_for(env.physics) is not None and task._goal_bank.shape[0] == 2 * E
     zero = torch.zeros((E, 45), device=env.physics.device, dtype=torch.float64)
     lens_seen = [set() for _ in range(E)]
@@ -609,6 +610,57 @@ def test_augmentation_prefetch_switches_bank_slots_without_host_reads():
     assert sum(len(s) >= 2 for s in lens_seen) >= E - 2, lens_seen
     assert stale == 0, "the refills did not keep up"
     assert task.prefetch_refills >= starts.sum() - 2 * E
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+def test_device_rasterizer_matches_the_host_tables(precision):
+    """rp_task_rasterize against NoteTrajectory.from_midi(...).to_goal_tables() (the note-object
+    path that restates midi_file.py:315-362 / piano_roll.py:59-204): every library song, random
+    stretch / transpose chains, two control timesteps, with and without initial buffer time --
+    goal rows, fingering rows and lengths bit-equal."""
+    from robopianist_amd import music, task_kernels
+    from robopianist_amd.music import midi_file
+    from robopianist_amd.suite import variations
+    dev = torch.device("cuda", 0)
+    dt_t = torch.float64 if precision == 64 else torch.float32
+    bases = [music.load(n) for n in music.ALL]
+    rs = np.random.RandomState(1)
+    augs = [variations.MidiTemporalStretch(1.0, 0.4), variations.MidiPitchShift(1.0, 9),
+            variations.MidiOctaveShift(0.5, 2), variations.MidiTemporalStretch(0.5, 0.1)]
+    for dt, buf in ((0.05, 0.0), (0.013, 0.5)):
+        r = task_kernels.Rasterizer(dev, dt_t, [b.note_arrays() for b in bases], dt, buf)
+        jobs = []
+        for rep in range(3):
+            for si, base in enumerate(bases):
+                m = base
+                for v in augs:
+                    m = v(initial_value=m, random_state=rs)
+                assert m._base is base._base
+                jobs.append((si, m))
+        want = []
+        for si, m in jobs:
+            t = midi_file.NoteTrajectory.from_midi(m, dt)
+            t.add_initial_buffer_time(buf)
+            want.append(t.to_goal_tables())
+        cap = max(len(g) for g, _ in want) + 3
+        n = len(jobs)
+        goal = torch.full((n, cap, 89), 7.0, device=dev, dtype=dt_t)      # garbage: the kernel must overwrite
+        finger = torch.full((n, cap, 88), 5, device=dev, dtype=torch.int64)
+        lens = torch.zeros(n, dtype=torch.int64, device=dev)
+        ops = [list(m._ops[len(bases[si]._ops):]) for si, m in jobs]
+        st = r.rasterize(goal, finger, lens, np.arange(n), [si for si, _ in jobs], ops)
+        assert st.tolist() == [0] * n
+        for j, (g, f) in enumerate(want):
+            L = len(g)
+            assert int(lens[j]) == L, (j, int(lens[j]), L)
+            np.testing.assert_array_equal(_np(goal[j, :L]), g, err_msg=f"goal of job {j}")
+            np.testing.assert_array_equal(_np(finger[j, :L]), f, err_msg=f"finger of job {j}")
+            assert float(goal[j, L:].abs().sum()) == 0.0 and int((finger[j, L:] != -1).sum()) == 0
+        # a bank that is too short is reported, not overrun
+        small = torch.zeros((n, 8, 89), device=dev, dtype=dt_t)
+        st = r.rasterize(small, torch.zeros((n, 8, 88), device=dev, dtype=torch.int64), lens,
+                         np.arange(n), [si for si, _ in jobs], ops)
+        assert st.tolist() == [1] * n and float(small.abs().sum()) == 0.0
 
 
 def test_uniformly_random_actions_do_not_diverge():
