@@ -123,7 +123,7 @@ int rp_task_advance(const rp_task_advance_args* args, void* hip_stream);
 /* rp_task_rasterize: goal / fingering tables of augmented songs, built on the device.
  * What the reference does on the host at every episode start when `augmentations` are given
  * (suite/tasks/piano_with_shadow_hands.py:151-165): MidiFile.stretch / transpose
- * (music/midi_file.py:214-243), sequence_to_pianoroll (music/piano_roll.py:59-204, onset window 0)
+ * (music/midi_file.py:204-229), sequence_to_pianoroll (music/piano_roll.py:59-204, onset window 0)
  * and NoteTrajectory.seq_to_trajectory incl. the repeated-note gap and the sustain latch
  * (music/midi_file.py:315-362), then the tables the vectorised task reads.  One workgroup per job
  * (= one bank slot); a job names a base song and an ordered list of operations. */
