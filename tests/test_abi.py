@@ -85,6 +85,14 @@ def test_task_abi_rejects_bad_arguments_without_a_device():
     p.rw = a
     p.bank_len = 0
     assert L.rp_task_advance(ctypes.byref(p), None) == -1 and b"bad sizes" in L.rp_task_last_error()
+    r = tk.RasterArgs()
+    assert L.rp_task_rasterize(None, None) == -1
+    r.precision = 8
+    assert L.rp_task_rasterize(ctypes.byref(r), None) == -1 and b"precision" in L.rp_task_last_error()
+    r.precision, r.n_songs, r.bank_len, r.fps = 64, 1, 16, 0.0
+    assert L.rp_task_rasterize(ctypes.byref(r), None) == -1 and b"bad sizes" in L.rp_task_last_error()
+    r.fps = 20.0
+    assert L.rp_task_rasterize(ctypes.byref(r), None) == -1 and b"null array" in L.rp_task_last_error()
 
 
 def test_task_abi_struct_layout_matches_the_header():
