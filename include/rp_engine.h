@@ -100,6 +100,13 @@ int rp_set_solver_limits(rp_engine* e, int max_newton_iter, int max_ls_iter);
  * opt.ls_tolerance; the fp32 build raises a default tolerance below 1e-6 to 1e-6, the resolution
  * of single precision; values <= 0 leave the current setting). */
 int rp_set_solver_tolerance(rp_engine* e, double tolerance, double ls_tolerance);
+/* rp_step starts with a position/velocity stage for the incoming state (the caller may have
+ * changed it).  With the lazy mode on, that leading stage is skipped for every env whose stage data
+ * is still the one of its current state: computed by the previous rp_step / rp_forward, and no
+ * rp_reset / rp_set(RP_QPOS | RP_QVEL | RP_TREE_OFFSET) since.  The engine cannot see writes through
+ * rp_field_ptr views: a caller that writes state through a view must call rp_forward (or rp_set)
+ * before the next rp_step.  Default: off.  Results are bit-identical either way. */
+int rp_set_lazy_position_stage(rp_engine* e, int on);
 int rp_sync(rp_engine* e);
 int rp_get_stream(rp_engine* e, void** hip_stream);
 /* Makes the engine enqueue on a caller-owned HIP stream (e.g. PyTorch's current stream),

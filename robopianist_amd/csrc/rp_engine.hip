@@ -17,6 +17,17 @@
 
 namespace {
 
+// Bookkeeping of the lazy position stage (rp_set_lazy_position_stage): which envs' hand-over
+// (RpStage) still matches their state.
+__global__ void rp_lead_mask_kernel(int* lead, const int* active, const unsigned char* valid, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) lead[e] = ((active ? active[e] != 0 : true) && !valid[e]) ? 1 : 0;
+}
+__global__ void rp_mark_valid_kernel(unsigned char* valid, const int* active, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n && (!active || active[e] != 0)) valid[e] = 1;
+}
+
 thread_local std::string g_err;
 int fail(const std::string& s) { g_err = s; return -1; }
 #define HIP_OK(x)                                                                  \
@@ -95,6 +106,7 @@ struct EngineBase {
   virtual int step(int nsub, uint32_t* trace, int mode) = 0;
   virtual void limits(int newton, int ls) = 0;
   virtual void tolerances(double tol, double ls_tol) = 0;
+  bool lazy_position = false;
   virtual int field_ptr(rp_field f, void** p, size_t* bytes) = 0;
   bool own_stream = true;
   virtual int profile(long long* out, int n, int enable) = 0;
@@ -290,6 +302,8 @@ struct Engine : EngineBase {
     S.prof = nullptr;
     d_active = dalloc<int>(E);
     S.active = nullptr;
+    d_lead = dalloc<int>(E);
+    d_valid = dalloc<unsigned char>(E);  // (zero-filled: nothing is valid yet)
     S.max_newton = M.iterations; S.max_ls = M.ls_iterations;
     // The fills and uploads above went through the null stream, which is NOT ordered with the
     // engine's non-blocking stream: everything must have landed before the first kernel.
@@ -298,6 +312,8 @@ struct Engine : EngineBase {
 
   long long* d_prof = nullptr;
   int* d_active = nullptr;
+  int* d_lead = nullptr;            // lazy position stage: active && !valid
+  unsigned char* d_valid = nullptr; // hand-over of env e matches its state
   int profile(long long* out, int n, int enable) override {
     HIP_OK(hipSetDevice(device));
     if (!d_prof) { d_prof = dalloc<long long>(RPK_NPROF); }
@@ -338,7 +354,7 @@ struct Engine : EngineBase {
         dmask = d_mask;
       }
     }
-    hipLaunchKernelGGL(rp_reset_kernel<T>, dim3(nenv), dim3(64), 0, stream, S, d_qpos0, dmask, nv, nu);
+    hipLaunchKernelGGL(rp_reset_kernel<T>, dim3(nenv), dim3(64), 0, stream, S, d_qpos0, dmask, nv, nu, d_valid);
     HIP_OK(hipGetLastError());
     return 0;
   }
@@ -389,6 +405,8 @@ struct Engine : EngineBase {
       HIP_OK(hipMemcpyAsync(p, src, nb, hipMemcpyDefault, stream));
     }
     if (f == RP_ACTIVE) S.active = d_active;
+    // state the position stage depends on changed: every env's hand-over is stale
+    if (f == RP_QPOS || f == RP_QVEL || f == RP_TREE_OFFSET) HIP_OK(hipMemsetAsync(d_valid, 0, (size_t)nenv, stream));
     return 0;
   }
   int get(rp_field f, void* dst) override {
@@ -431,7 +449,16 @@ struct Engine : EngineBase {
     // mj_step1 for the current state, then n_sub x (mj_step2; mj_step1): dm_control's legacy
     // order.  Two small kernels per substep instead of one fused launch: each half fits in
     // registers, and the hand-over (RpStage) stays in L2 / Infinity Cache.
-    hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(nenv), dim3(64), 0, stream, M, s, B, -1, nsub);
+    const int hb = (nenv + 255) / 256;
+    if (lazy_position && mode == 0) {
+      // skip the leading stage for envs whose hand-over is still the one of their current state
+      RpState<T> lead = s;
+      hipLaunchKernelGGL(rp_lead_mask_kernel, dim3(hb), dim3(256), 0, stream, d_lead, s.active, d_valid, nenv);
+      lead.active = d_lead;
+      hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(nenv), dim3(64), 0, stream, M, lead, B, -1, nsub);
+    } else {
+      hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(nenv), dim3(64), 0, stream, M, s, B, -1, nsub);
+    }
     if (mode == 0) {
       for (int k = 0; k < nsub; k++) {
         const bool probe = timeit && k == nsub / 2;
@@ -443,6 +470,7 @@ struct Engine : EngineBase {
         hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
       }
     }
+    hipLaunchKernelGGL(rp_mark_valid_kernel, dim3(hb), dim3(256), 0, stream, d_valid, s.active, nenv);
     HIP_OK(hipGetLastError());
     if (timeit) { HIP_OK(hipEventRecord(ev1[slot], stream)); ev_pending[slot] = true; }
     if (trace && mode == 0)
@@ -518,6 +546,11 @@ int rp_profile(rp_engine* e, long long* out, int n, int enable) {
 int rp_set_solver_tolerance(rp_engine* e, double tolerance, double ls_tolerance) {
   if (!e) return fail("null engine");
   E(e)->tolerances(tolerance, ls_tolerance);
+  return 0;
+}
+int rp_set_lazy_position_stage(rp_engine* e, int on) {
+  if (!e) return fail("null engine");
+  E(e)->lazy_position = on != 0;
   return 0;
 }
 int rp_sync(rp_engine* e) {

@@ -81,9 +81,11 @@ template <typename T> struct Rows { T fr, lim[3], con[4]; };
 
 // physics.reset() for the envs selected by a device-side mask (null = all).
 template <typename T>
-__global__ void rp_reset_kernel(RpState<T> S, const T* qpos0, const unsigned char* mask, int nv, int nu) {
+__global__ void rp_reset_kernel(RpState<T> S, const T* qpos0, const unsigned char* mask, int nv, int nu,
+                                unsigned char* stage_valid) {
   const int env = blockIdx.x;
   if (mask && !mask[env]) return;
+  if (threadIdx.x == 0) stage_valid[env] = 0;  // the hand-over of this env no longer matches its state
   for (int i = threadIdx.x; i < nv; i += blockDim.x) {
     S.qpos[(size_t)env * nv + i] = qpos0[i];
     S.qvel[(size_t)env * nv + i] = 0;

@@ -34,7 +34,7 @@ WARN_WORK_FULL = 16
 
 EXPORTED_SYMBOLS = (
     "rp_create", "rp_destroy", "rp_reset", "rp_set", "rp_get", "rp_step", "rp_forward",
-    "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
+    "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_set_lazy_position_stage", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
     "rp_n_envs", "rp_dim",
     "rp_kernel_time", "rp_solver_kernel_time", "rp_profile", "rp_last_error",
 )
@@ -70,6 +70,7 @@ def load_library(path: str = LIB_PATH):
     L.rp_set_solver_limits.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     L.rp_sync.argtypes = [ctypes.c_void_p]
     L.rp_set_solver_tolerance.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]
+    L.rp_set_lazy_position_stage.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.rp_get_stream.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
     L.rp_n_envs.argtypes = [ctypes.c_void_p]
     L.rp_dim.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
@@ -223,6 +224,11 @@ class BatchedPhysics:
 
     def set_solver_limits(self, max_newton_iter=0, max_ls_iter=0):
         self._check(self._L.rp_set_solver_limits(self._h, max_newton_iter, max_ls_iter))
+
+    def set_lazy_position_stage(self, on: bool = True):
+        """rp_step skips its leading position/velocity stage for envs whose stage data is still
+        valid (see include/rp_engine.h); state written through views then needs forward()."""
+        self._check(self._L.rp_set_lazy_position_stage(self._h, int(bool(on))))
 
     def set_solver_tolerance(self, tolerance=0.0, ls_tolerance=0.0):
         self._check(self._L.rp_set_solver_tolerance(self._h, float(tolerance), float(ls_tolerance)))

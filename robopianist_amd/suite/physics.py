@@ -43,6 +43,10 @@ class TorchPhysics:
         self._tree_offset = e.view(eng.TREE_OFFSET) if e.ntree else None
         self._active = e.view(eng.ACTIVE)
         self._active.fill_(1)
+        # The env layer changes qpos / qvel only through reset() and load_state_dict(), both
+        # followed by forward(): rp_step may skip its leading position stage for untouched envs.
+        # Code that writes `physics.qpos` / `qvel` through the views must call forward() itself.
+        e.set_lazy_position_stage(True)
         from robopianist_amd.model import engine_tables
         t = engine_tables.build_engine_tables(self.model, scene_info.key_joint_ids)
         self._site_modelid = {int(s): i for i, s in enumerate(t["eng_site_modelid"])}

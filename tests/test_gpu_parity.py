@@ -250,3 +250,50 @@ def test_key_trace_matches_oracle_activation(two_hand_scene):
             assert (bits[0, s] == expect).all() and (bits[1, s] == expect).all(), (t, s)
             pressed_any += int(expect.sum())
     assert pressed_any > 0, "the scripted presses are meant to activate keys"
+
+
+def test_lazy_position_stage_is_bit_identical(two_hand_scene):
+    """rp_set_lazy_position_stage: skipping the leading position/velocity stage of rp_step for
+    envs whose stage data is still valid changes nothing -- same bits as the eager engine through
+    steps, masked resets, rp_set of the state (which must invalidate) and rp_forward."""
+    from robopianist_amd import engine
+    si = two_hand_scene
+    m = si.model
+    E = 6
+    a = engine.BatchedPhysics(m, si.key_joint_ids, n_envs=E, precision=64)
+    b = engine.BatchedPhysics(m, si.key_joint_ids, n_envs=E, precision=64)
+    b.set_lazy_position_stage(True)
+    ctrl = _replay_ctrl(si)
+    rng = np.random.default_rng(0)
+    act_a, act_b = a.view(engine.ACTIVE), b.view(engine.ACTIVE)
+    act_a.fill_(1); act_b.fill_(1)
+    for t in range(60):
+        c = np.tile(ctrl[10 * t], (E, 1)) * (1 + 0.05 * rng.standard_normal((E, 1)))
+        for p in (a, b):
+            p.set(engine.CTRL, c)
+        if t == 20:     # masked reset of two envs, position stage for them only, then step everybody
+            mask = np.zeros(E, np.uint8); mask[[1, 4]] = 1
+            for p, act in ((a, act_a), (b, act_b)):
+                p.reset(mask)
+                act.copy_(torch_i32(mask)); p.forward(); act.fill_(1)
+        if t == 35:     # state written through the ABI: must invalidate the stage data
+            q = a.qpos.copy(); q[:, 88:] += 0.01
+            for p in (a, b):
+                p.set(engine.QPOS, q)
+        if t == 45:     # some envs sit a step out
+            mask = np.ones(E, np.int32); mask[2] = 0
+            for act in (act_a, act_b):
+                act.copy_(torch_i32(mask))
+        if t == 46:
+            act_a.fill_(1); act_b.fill_(1)
+        a.step(10); b.step(10)
+        assert np.array_equal(a.qpos, b.qpos) and np.array_equal(a.qvel, b.qvel), t
+        assert np.array_equal(a.get(engine.NCON), b.get(engine.NCON))
+        assert np.array_equal(a.get(engine.ACT_VELOCITY), b.get(engine.ACT_VELOCITY))
+        assert np.array_equal(a.get(engine.SITE_XPOS), b.get(engine.SITE_XPOS))
+    assert a.warn_flags.max() == 0
+
+
+def torch_i32(x):
+    import torch
+    return torch.as_tensor(np.asarray(x, np.int32), device="cuda")
