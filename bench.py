@@ -1,20 +1,30 @@
 #!/usr/bin/env python
 """Benchmark of the hot path (BASELINE.json: env-steps/sec at 4096 envs/GPU).
 
-One "step" = one control step (= 10 physics substeps, base.py:28,31) of ALL envs
-on this rank.  Workload: BASELINE.json configs[1] — PianoWithShadowHands,
-TwinkleTwinkle scripted replay (tests/golden/twinkle_twinkle_actions.npy mapped
-canonical -> ctrlrange), 4096 envs per GPU, inputs resident in HBM.
+One "step" = one control step (= 10 physics substeps, base.py:28,31) of ALL envs on this
+rank.  `--config` selects the BASELINE.json workload:
 
-Prints ONE JSON line (rank 0).  See DESIGN.md §Measurement for the definitions
-of `roofline` (algorithmic bytes / step-kernel time from HIP events) and
-`cpu_baseline` (the fp64 C oracle timed on the host cores on a bounded sample).
+  2 (default, the headline)  PianoWithShadowHands-TwinkleTwinkle, 4096 envs, every env replays
+                             tests/golden/twinkle_twinkle_actions.npy through the canonical map
+  3                          same model, uniformly random policy, default_rng(12345 + 1000 rank)
+  4                          RoboPianist-debug-CMajorScaleTwoHands, 8192 envs, random policy
+  5                          150 distinct goal tables (mixed songs), 2048 envs, random policy
+
+`--gpus N` with N > 1 and no torchrun environment SPAWNS the N ranks itself (one process per GPU,
+torch.distributed.run on 127.0.0.1) and fails loudly if fewer devices are visible; under torchrun
+it checks WORLD_SIZE == N.  `n_gpus` in the output is the world size the process group reports.
+
+Prints ONE JSON line (rank 0).  See DESIGN.md 6 for the definitions of `roofline` (algorithmic
+bytes / solver-kernel time from HIP events) and `cpu_baseline` (the fp64 C oracle timed on the
+host cores on a bounded sample).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 import warnings
@@ -24,18 +34,24 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# Algorithmic bytes of ONE launch of the dominant kernel (rp_stage_kernel<T,1>, the mj_step2 /
-# constraint-solver stage of one substep) per env, in elements of T:
-#   in : qpos qvel qacc_warmstart qfrc_applied (4 nv) + ctrl (nu)
-#   out: qpos qvel qacc_warmstart (3 nv) + actuator_force (nu) + time (1)
-# = 7*140 + 2*44 + 1 = 1069 elements -> 4276 B (fp32), 8552 B (fp64).  SURVEY/BASELINE §2.3
-# quote 4352 B per fused env-step; that figure assumed one 10-substep kernel and is reported
-# under roofline.note for reference.
-def algo_bytes_per_solver_launch(nv, nu, precision):
-    return (7 * nv + 2 * nu + 1) * (8 if precision == 64 else 4)
-
-
 HBM_PEAK_GBS = 8000.0
+NOTEBOOK_KW = dict(control_timestep=0.05, gravity_compensation=True, primitive_fingertip_collisions=True,
+                   reduced_action_space=False, n_steps_lookahead=10)
+CONFIGS = {
+    2: dict(envs=4096, policy="replay", name="PianoWithShadowHands-TwinkleTwinkle scripted replay (BASELINE configs[1])"),
+    3: dict(envs=4096, policy="random", name="PianoWithShadowHands-TwinkleTwinkle random policy (BASELINE configs[2])"),
+    4: dict(envs=8192, policy="random", name="RoboPianist-debug-CMajorScaleTwoHands random policy (BASELINE configs[3])"),
+    5: dict(envs=2048, policy="random", name="mixed batch of 150 goal tables, random policy (BASELINE configs[4]; "
+                                             "the licence-gated PIG repertoire is replaced by the 8 in-tree songs + "
+                                             "stretch / pitch-shift variants)"),
+}
+
+
+# SURVEY.md 8(d) / BASELINE 2.3, un-fused upper bound: per mj_step and env the state makes one
+# round trip through HBM -- read qpos qvel qacc_warmstart (3 nv) + ctrl (nu), write qpos qvel
+# qacc_warmstart (3 nv) = 884 elements for nv = 140, nu = 44 -> 3536 B (fp32), 7072 B (fp64).
+def algo_bytes_per_mj_step(nv, nu, precision):
+    return (6 * nv + nu) * (8 if precision == 64 else 4)
 
 
 def _usable_cores():
@@ -54,31 +70,22 @@ def _usable_cores():
     return n
 
 
+def _profile_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+
+
 def _pmc_traffic(E, precision):
     """HBM-side bytes per solver-kernel launch from the committed rocprofv3 --pmc passes
-    (profiles/traffic_r01.json); null if not collected for this
-    env count / precision."""
-    p = os.path.join(ROOT, "profiles", "traffic_r01.json")
-    try:
-        d = json.load(open(p))
-        ok = int(d["envs"]) == int(E) and int(d["precision"]) == int(precision)
-        return d["solver_kernel_bytes_per_launch"] if ok else None
-    except Exception:
-        return None
-
-
-def _issue_roofline(value, substeps):
-    """Issue-slot ceiling of the present instruction streams from the committed SQ counters
-    (profiles/r01_sq_instruction_mix.json: SQ_ACTIVE_INST_ANY per wave, in units of 4 cycles):
-    every SIMD issues for one wave at a time, 1024 SIMDs at 2.4 GHz."""
-    try:
-        k = json.load(open(os.path.join(ROOT, "profiles", "r01_sq_instruction_mix.json")))["kernels"]
-        act = sum(v["per_wave"]["SQ_ACTIVE_INST_ANY"] for v in k.values())
-    except Exception:
-        return None
-    ceiling = 1024 * 2.4e9 / (substeps * 4.0 * act)
-    return {"bound": "instruction issue", "achieved": value, "peak": ceiling, "unit": "env-steps/s",
-            "frac": value / ceiling, "source": "profiles/r01_sq_instruction_mix.json (fp64 kernels)"}
+    (newest profiles/traffic_rNN.json); null if not collected for this env
+    count / precision."""
+    for name in ("traffic_r02.json", "traffic_r01.json"):
+        d = _profile_json(name)
+        if d and int(d.get("envs", -1)) == int(E) and int(d.get("precision", -1)) == int(precision):
+            return d.get("solver_kernel_bytes_per_launch")
+    return None
 
 
 def load_actions(m):
@@ -91,102 +98,189 @@ def load_actions(m):
     return ctrl, a[:, -1]
 
 
+def mixed_song_bank(n=150):
+    """Config 5: >= 150 distinct goal tables from the in-tree songs (library.py:544-553) and
+    MidiTemporalStretch / MidiPitchShift variants (variations.py:49-133), RandomState(0)."""
+    from robopianist_amd import music
+    from robopianist_amd.suite import variations
+    songs = [music.load(name) for name in music.ALL]
+    rs = np.random.RandomState(0)
+    bank = list(songs)
+    aug = [variations.MidiTemporalStretch(1.0, 0.2), variations.MidiPitchShift(1.0, 5)]
+    while len(bank) < n:
+        m = songs[len(bank) % len(songs)]
+        for v in aug:
+            m = v(initial_value=m, random_state=rs)
+        bank.append(m)
+    return bank
+
+
+def build_env(config, E, rank, dev, precision):
+    from robopianist_amd import suite
+    from robopianist_amd import distributed as rpd
+    from robopianist_amd.suite import environment
+    from robopianist_amd.suite.tasks import PianoWithShadowHands
+    seed = rpd.rank_seed(12345, rank)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        if config in (2, 3):
+            # notebook cell 15 kwargs (SURVEY.md 3.5); capsule fingertips (no mesh assets here)
+            return suite.load("RoboPianist-debug-TwinkleTwinkleRousseau-v0", seed=seed, n_envs=E, device_id=dev,
+                              precision=precision, task_kwargs=dict(trim_silence=True, **NOTEBOOK_KW))
+        if config == 4:
+            return suite.load("RoboPianist-debug-CMajorScaleTwoHands-v0", seed=seed, n_envs=E, device_id=dev,
+                              precision=precision, task_kwargs=dict(**NOTEBOOK_KW))
+        task = PianoWithShadowHands(midi=mixed_song_bank(150), **NOTEBOOK_KW)
+        return environment.Environment(task, n_envs=E, random_state=seed, device_id=dev, precision=precision)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args, argv):
+    """`bench.py --gpus N` outside torchrun: launch the N ranks (one per GPU) and relay rank 0's line."""
+    import torch
+    have = torch.cuda.device_count()
+    if not args.same_device and have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} requested but only {have} HIP device(s) are visible\n")
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=158)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--steps", type=int, default=474, help="timed control steps (default: 3 Twinkle episodes)")
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the config's BASELINE value)")
     ap.add_argument("--precision", type=int, default=64, choices=(32, 64),
-                    help="64 (default) is the precision that meets the 1e-4 parity bar on this replay")
+                    help="64 (default) is the precision that meets the 1e-4 parity bar on the replay")
     ap.add_argument("--aux-fp32", type=int, default=1, help="also time the fp32 engine (reported under aux)")
     ap.add_argument("--substeps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", type=int, default=1, help="all-gather trajectory slab when gpus>1")
-    ap.add_argument("--engine-only", action="store_true", help="time rp_step alone (no obs/reward epilogue)")
+    ap.add_argument("--gather", type=int, default=1, help="all-gather the trajectory slab when gpus > 1")
+    ap.add_argument("--engine-only", action="store_true", help="config 2: time rp_step alone (no obs/reward epilogue)")
     ap.add_argument("--dist-backend", default="nccl", help="debug: 'gloo' lets several ranks share one GPU")
     ap.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0")
     ap.add_argument("--host-io", type=int, default=1,
-                    help="N=1: also time the loop with host-resident actions/TimeSteps (aux.host_io, PCIe inclusive)")
-    ap.add_argument("--graph", type=int, default=0,
-                    help="replay env.step from a captured hipGraph (wrappers.GraphedStepWrapper)")
+                    help="N=1, config 2: also time the loop with host-resident actions/TimeSteps (aux.host_io)")
+    ap.add_argument("--graph", type=int, default=0, help="replay env.step from a captured hipGraph")
+    ap.add_argument("--stagger", type=int, default=1,
+                    help="config 2: every env at its own episode time (env e starts at replay row e mod 158), so any "
+                         "timed window samples the whole episode; 0 = all envs in lockstep")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    in_torchrun = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not in_torchrun:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if in_torchrun else 1
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks\n")
+        sys.exit(2)
     import torch
     dist = None
+    if not torch.cuda.is_available():
+        sys.stderr.write("bench.py: no HIP device visible (the engine has no CPU fallback)\n")
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.same_device:
             local_rank = 0
+        elif torch.cuda.device_count() <= local_rank:
+            sys.stderr.write(f"bench.py: rank {rank} has no device cuda:{local_rank} "
+                             f"({torch.cuda.device_count()} visible)\n")
+            sys.exit(2)
         torch.cuda.set_device(local_rank)
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.dist_backend)
-    dev = local_rank if torch.cuda.is_available() else 0
+        world = dist.get_world_size()  # what the process group actually reports
+    dev = local_rank
+    cfg = CONFIGS[args.config]
+    E = args.envs or cfg["envs"]
 
     def measure(precision, steps, warmup):
-        from robopianist_amd import engine, suite
         from robopianist_amd import distributed as rpd
         from robopianist_amd.wrappers import CanonicalSpecWrapper, GraphedStepWrapper
 
-        E = args.envs
         device = torch.device("cuda", dev)
         tdt = torch.float32 if precision == 32 else torch.float64
-        actions = np.load(os.path.join(ROOT, "tests", "golden", "twinkle_twinkle_actions.npy"))
-        T = actions.shape[0]
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            # notebook cell 15 kwargs; capsule fingertips (no meshes available)
-            base_env = suite.load(
-                "RoboPianist-debug-TwinkleTwinkleRousseau-v0", seed=rpd.rank_seed(12345, rank), n_envs=E,
-                device_id=dev, precision=precision,
-                task_kwargs=dict(trim_silence=True, control_timestep=0.05, gravity_compensation=True,
-                                 primitive_fingertip_collisions=True, reduced_action_space=False,
-                                 n_steps_lookahead=10))
+        base_env = build_env(args.config, E, rank, dev, precision)
         eager_env = CanonicalSpecWrapper(base_env)
         use_graph = bool(args.graph) and not args.engine_only
         env = GraphedStepWrapper(eager_env, warmup_steps=2) if use_graph else eager_env
         phys = base_env.physics.engine
         m = base_env.task.scene.model
         assert base_env.task.physics_steps_per_control_step == args.substeps == 10
-        # all envs replay the same action stream (config #2); rows pre-expanded on device
-        act_dev = torch.as_tensor(actions, dtype=tdt, device=device)
-        state = {"t": 0}
+        A = env.action_spec().shape[0]
+        replay = cfg["policy"] == "replay"
+        stagger = bool(args.stagger) and replay and not args.engine_only
+        state = {"t": 0, "sim": torch.zeros((), dtype=torch.long, device=device)}
+        if replay:
+            actions = np.load(os.path.join(ROOT, "tests", "golden", "twinkle_twinkle_actions.npy"))
+            T = actions.shape[0]
+            act_dev = torch.as_tensor(actions, dtype=tdt, device=device)
+            idx = torch.zeros(E, dtype=torch.long, device=device)  # replay row of every env
+        else:
+            # a ~ U(spec.min, spec.max) i.i.d. per env and step (canonical: U(-1, 1)), sustain ~ U(0, 1);
+            # np.random.default_rng(12345 + 1000 rank).  Slabs are drawn on the host before the
+            # timed region and live in HBM; they are reused cyclically after `nslab` steps.
+            rng = np.random.default_rng(rpd.rank_seed(12345, rank))
+            nslab = min(steps + warmup, 128)
+            slab = rng.uniform(-1.0, 1.0, size=(nslab, E, A))
+            # the canonical wrapper maps [-1, 1] -> [0, 1] for the sustain channel: uniform stays uniform
+            act_dev = torch.as_tensor(slab, dtype=tdt, device=device)
+            T = None
 
         def one_step(_):
             t = state["t"]
             if args.engine_only:
                 lo = torch.as_tensor(m.actuator_ctrlrange[:, 0], dtype=tdt, device=device)
                 hi = torch.as_tensor(m.actuator_ctrlrange[:, 1], dtype=tdt, device=device)
-                c = lo + (act_dev[t, :-1] + 1) * 0.5 * (hi - lo)
+                c = lo + (act_dev[t % T, :-1] + 1) * 0.5 * (hi - lo)
                 base_env.physics.set_ctrl(c.expand(E, -1))
                 phys.step(args.substeps)
-                ts_last = (t + 1 == T)
-            else:
-                ts = env.step(act_dev[t].expand(E, -1))
-                ts_last = (t + 1 == T)
-                if world > 1 and args.gather:
-                    rec = rpd.pack_trajectory_record(
-                        base_env.physics.qpos, ts.reward, ts.discount, ts.step_type,
-                        base_env.task.piano.activation)
-                    # enqueue only: the all-gather of step t overlaps the physics of step t+1
-                    if state.get("gather") is not None:
-                        state["gather"][1].wait()
-                    state["gather"] = rpd.gather_trajectories(rec, async_op=True, out=state.get("gather_buf"))
-                    state["gather_buf"] = state["gather"][0]
-            state["t"] = t + 1
-            if ts_last:  # episode boundary: reset (not counted as a step, but timed)
-                if args.engine_only:
+                state["sim"] += E
+                state["t"] = t + 1
+                if (t + 1) % T == 0:
                     phys.sync(); phys.reset()
-                else:
-                    env.reset()
-                state["t"] = 0
+                return
+            if replay:
+                ts = env.step(act_dev.index_select(0, idx))
+                first = ts.step_type == 0
+                # dm_env: the step after LAST resets the env and returns FIRST without simulating
+                idx.copy_(torch.where(first, torch.zeros_like(idx), torch.clamp(idx + 1, max=T - 1)))
+            else:
+                ts = env.step(act_dev[t % act_dev.shape[0]])
+                first = ts.step_type == 0
+            state["sim"] += (~first).sum()
+            if world > 1 and args.gather:
+                rec = rpd.pack_trajectory_record(
+                    base_env.physics.qpos, ts.reward, ts.discount, ts.step_type, base_env.task.piano.activation)
+                # enqueue only: the all-gather of step t overlaps the physics of step t+1
+                if state.get("gather") is not None:
+                    state["gather"][1].wait()
+                state["gather"] = rpd.gather_trajectories(rec, async_op=True, out=state.get("gather_buf"))
+                state["gather_buf"] = state["gather"][0]
+            state["t"] = t + 1
 
         def barrier():
             if state.get("gather") is not None and state["gather"][1] is not None:
@@ -198,38 +292,60 @@ def main():
                 torch.cuda.synchronize()
 
         env.reset()
+        n_spread = 0
+        if stagger:
+            # untimed prologue: env e is restarted at prologue step T-1-(e mod T), so that after T
+            # steps it is (e mod T) steps into its episode; from then on every env auto-resets at
+            # its own time and each control step holds every phase of the episode
+            phase = torch.arange(E, device=device) % T
+            for j in range(T):
+                base_env.request_reset(phase == (T - 1 - j))
+                one_step(j)
+            n_spread = T
         for t in range(warmup):
             one_step(t)
         barrier()
         phys.solver_kernel_time(); phys.kernel_time()  # reset the event-timer statistics
+        state["sim"].zero_()
+        if base_env.physics.warn is not None:
+            base_env.physics.warn.zero_()
         t0 = time.perf_counter()
         for t in range(steps):
             one_step(warmup + t)
         barrier()
         dt = time.perf_counter() - t0
+        sim = int(state["sim"].item())
         if dist is not None:
             tt = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
+            ss = torch.tensor([sim], dtype=torch.float64, device=device)
+            dist.all_reduce(ss, op=dist.ReduceOp.SUM)
+            sim_all = int(ss.item())
+        else:
+            sim_all = sim
         if use_graph:
             # launches inside a replayed hipGraph cannot carry per-kernel events: sample the
             # kernel times on 16 eager steps of the same rollout right after the timed region
             phys.solver_kernel_time(); phys.kernel_time()
             for i in range(16):
-                eager_env.step(act_dev[(state["t"] + i) % T].expand(E, -1))
+                a = act_dev.index_select(0, idx) if replay else act_dev[i % act_dev.shape[0]]
+                eager_env.step(a)
             barrier()
         sms, snl = phys.solver_kernel_time()
         kms, nl = phys.kernel_time()
-        warn = int(phys.warn_flags.max())
+        wf = base_env.physics.warn
+        warn_or = int(torch.bitwise_or(wf, torch.zeros_like(wf)).max().item()) if wf is not None else 0
+        events = {"capacity_overflow_episodes": int(base_env.task.overflow_terminations())
+                  if hasattr(base_env.task, "overflow_terminations") else None}
         q = phys.qpos
         finite = bool(np.isfinite(q).all())
-        ctrl_seq, _ = load_actions(m)
 
         # PCIe-inclusive variant (aux only, never `value`): the caller keeps actions and
         # TimeSteps in host memory -- a [E, 45] numpy action goes up and every TimeStep field
         # (reward, discount, step type, all observations) comes back to numpy each step
         host_io = None
-        if args.host_io and world == 1 and not args.engine_only and precision == args.precision:
+        if args.host_io and world == 1 and replay and not args.engine_only and precision == args.precision:
             act_host = np.ascontiguousarray(np.broadcast_to(actions[None, :, :], (E,) + actions.shape)
                                             .transpose(1, 0, 2)).astype(np.float64)
             n_io = min(40, T - 1)
@@ -249,17 +365,18 @@ def main():
                        "note": "same env loop with the actions in host numpy arrays and every TimeStep field "
                                "copied back to numpy (pageable memory, synchronous copies) each step"}
 
-        return dict(host_io=host_io, dt=dt, kms=kms, nl=nl, sms=sms, snl=snl, warn=warn, finite=finite, phys=phys, m=m,
-                    ctrl_seq=ctrl_seq, E=E, key_ids=base_env.task.scene.key_joint_ids, graphed=bool(use_graph and env.graph_captured))
+        return dict(host_io=host_io, dt=dt, kms=kms, nl=nl, sms=sms, snl=snl, warn=warn_or, finite=finite, phys=phys,
+                    m=m, E=E, key_ids=base_env.task.scene.key_joint_ids, sim=sim_all, n_spread=n_spread, events=events,
+                    graphed=bool(use_graph and env.graph_captured), stagger=stagger)
 
     r = measure(args.precision, args.steps, args.warmup)
-    dt, kms, nl, sms, snl, warn, finite, phys, m, ctrl_seq, E = (
-        r[k] for k in ('dt', 'kms', 'nl', 'sms', 'snl', 'warn', 'finite', 'phys', 'm', 'ctrl_seq', 'E'))
-    base_key_ids = r['key_ids']
+    dt, kms, nl, sms, snl, phys, m = (r[k] for k in ("dt", "kms", "nl", "sms", "snl", "phys", "m"))
+    base_key_ids = r["key_ids"]
 
     if rank == 0:
-        value = world * E * args.steps / dt
-        algo = algo_bytes_per_solver_launch(int(m.nv), int(m.nu), args.precision) * E
+        # simulated env-steps only: a FIRST step (the dm_env reset after LAST) advances no physics
+        value = r["sim"] / dt
+        algo = algo_bytes_per_mj_step(int(m.nv), int(m.nu), args.precision) * E
         achieved = algo / (sms * 1e-3) / 1e9 if sms > 0 else 0.0
         tname = "double" if args.precision == 64 else "float"
         out = {
@@ -274,11 +391,18 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.precision == 32 else "f64",
-            "data": "synthetic (scripted twinkle_twinkle_actions.npy replay on the stand-in hand model)",
+            "data": "synthetic (%s; stand-in hand model)" % (
+                "scripted twinkle_twinkle_actions.npy replay" if cfg["policy"] == "replay"
+                else "uniformly random actions, np.random.default_rng(12345 + 1000 rank)"),
             "config": {
-                "workload": "PianoWithShadowHands-TwinkleTwinkle scripted replay (BASELINE configs[1]), " + ("engine-level rp_step only" if args.engine_only else "full vectorised env.step (obs + rewards)"),
+                "workload": cfg["name"] + ", " + ("engine-level rp_step only" if args.engine_only
+                                                  else "full vectorised env.step (obs + rewards)"),
+                "baseline_config": args.config,
                 "envs_per_gpu": E, "substeps_per_step": args.substeps, "nv": int(m.nv), "nu": int(m.nu),
                 "fingertips": "capsule (primitive) stand-in", "mj_steps_per_s": value * args.substeps,
+                "simulated_env_steps": r["sim"], "reset_steps_not_counted": world * E * args.steps - r["sim"],
+                "episode_phase": ("staggered: env e is (e mod 158) steps into its episode, auto-reset per env "
+                                  "(untimed %d-step prologue)" % r["n_spread"]) if r["stagger"] else "lockstep",
                 "trajectory_gather": bool(world > 1 and args.gather), "hipgraph_step": r["graphed"],
             },
             "roofline": {
@@ -287,84 +411,114 @@ def main():
                 "kernel": "rp_stage_kernel<%s, 1> (mj_step2: constraint solver + Euler, one substep of all envs)" % tname,
                 "kernel_avg_ms": sms, "kernel_launches_sampled": snl,
                 "algorithmic_bytes_per_launch": algo,
+                "algorithmic_bytes_per_mj_step_per_env": algo // E,
                 "step_sequence_avg_ms": kms, "step_sequences": nl,
                 "kernel_timing": ("HIP events on 16 eager env steps of the same rollout right after the timed region "
                                   "(the timed region replays a captured hipGraph)") if r["graphed"] else
-                                 "HIP events over the timed region",
-                "note": "one rp_step = 1 + 2*substeps launches (rp_stage_kernel<T,0> position/velocity stage, "
-                        "<T,1> solver stage); kernel_avg_ms is the solver launch of the middle substep of every step "
-                        "(HIP events on the engine stream), step_sequence_avg_ms the whole 21-launch sequence. "
-                        "The path is instruction-issue / latency bound (one wave per env; the fp64 solver runs one "
-                        "wave per SIMD, the position kernel two), not HBM bound: see DESIGN.md 6",
+                                 "HIP events on the engine stream over the timed region; the probed substep rotates "
+                                 "(substep = step index mod n_substeps), so the average is the all-substep mean",
+                "note": "algorithmic bytes = SURVEY 8(d) un-fused figure (qpos qvel qacc_warmstart in + out, ctrl in) "
+                        "x envs per launch; one rp_step = 1 + 2*substeps launches (rp_stage_kernel<T,0> "
+                        "position/velocity stage, <T,1> solver stage).  The path is instruction-issue / latency bound "
+                        "(one wave per env), not HBM bound: see DESIGN.md 6",
             },
-            "issue_roofline": _issue_roofline(value / world, args.substeps) if args.precision == 64 else None,
-            "sanity": {"warn_flags": warn, "finite": finite},
-            "parity": "fp64 engine: max rel |dq| vs CPU oracle over 1000 mj_steps of this replay < 1e-4 "
-                      "(measured live under cpu_baseline_parity when the CPU leg runs), "
-                      "tests/test_gpu_parity.py::test_replay_fp64_1000_steps; fp32 engine diverges on this "
-                      "(chaotic, self-colliding) replay and is reported under aux only",
+            "sanity": {"warn_flags_or": r["warn"], "finite": r["finite"], **(r["events"] or {})},
+            "parity": "fp64 engine vs the CPU oracle: see cpu_baseline_parity (measured live when the CPU leg runs) and "
+                      "tests/test_gpu_parity.py; the fp32 engine diverges on the chaotic replay and is aux only",
         }
         if r.get("host_io"):
             out.setdefault("aux", {})["host_io"] = r["host_io"]
-        if args.aux_fp32 and args.precision == 64 and world == 1:
+        if args.aux_fp32 and args.precision == 64 and world == 1 and args.config == 2:
             del r, phys
-            r32 = measure(32, min(args.steps, 80), min(args.warmup, 10))
+            s32, w32 = min(args.steps, 80), min(args.warmup, 10)
+            r32 = measure(32, s32, w32)
             out.setdefault("aux", {})["fp32_engine"] = {
-                "value": E * min(args.steps, 80) / r32["dt"], "unit": "env-steps/s", "kernel_avg_ms": r32["kms"],
-                "warn_flags": r32["warn"],
+                "value": r32["sim"] / r32["dt"], "unit": "env-steps/s", "kernel_avg_ms": r32["kms"],
+                "warn_flags_or": r32["warn"],
                 "note": "same workload on the fp32 build; meets 1e-4 on smooth key-press scenarios only"}
             phys = r32["phys"]
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            from oracle.rp_oracle import Oracle
-            orc = Oracle(m, phys.blob)
-            cores = _usable_cores()
-            # bounded sample of the same workload, sized for ~15 s of host work: many short
-            # rollouts from reset (the transient, contact-changing part of an episode), each
-            # env holding a different row of the scripted replay
-            nenv_cpu = cores * 160
-            nstep = 400
-            rows = (40 + 7 * np.arange(nenv_cpu)) % ctrl_seq.shape[0]
-            cc = np.ascontiguousarray(ctrl_seq[rows])
-            secs, _ = orc.bench(nenv_cpu, nstep, cc, cores)
-            # same leg: the second half of BASELINE.json's metric, measured here -- the engine
-            # (precision of the headline run) against the CPU oracle on this very replay,
-            # free running, 1000 mj_steps, rel = |dq| / max(|q|, 1e-2)
-            from robopianist_amd import engine as _eng
-            chk = _eng.BatchedPhysics(m, base_key_ids, n_envs=2, precision=args.precision)
-            orc.reset()
-            worst, worst_abs = 0.0, 0.0
-            # dof groups of SURVEY.md 8(d) metric 2: keys (88), forearm joints (2 per hand), fingers+wrists
-            is_key = np.zeros(int(m.nv), bool); is_key[np.asarray(base_key_ids)] = True
-            is_arm = np.array(["forearm" in n for n in m.names["joint"]])
-            groups = {"keys": is_key, "forearms": is_arm & ~is_key, "fingers_and_wrists": ~is_key & ~is_arm}
-            gmax = {k: 0.0 for k in groups}
-            curve = {}
-            for i in range(1000):
-                c = ctrl_seq[(i // args.substeps) % ctrl_seq.shape[0]]
-                chk.set(_eng.CTRL, c[None, :]); orc.ctrl[:] = c
-                chk.step(1); orc.step(1)
-                qg = chk.qpos.astype(np.float64)[0]
-                ad = np.abs(qg - orc.qpos)
-                rel = ad / np.maximum(np.abs(orc.qpos), 1e-2)
-                worst = max(worst, float(rel.max())); worst_abs = max(worst_abs, float(ad.max()))
-                for k, sel in groups.items():
-                    gmax[k] = max(gmax[k], float(rel[sel].max()))
-                if i + 1 in (1, 10, 100, 300, 1000):
-                    curve[str(i + 1)] = float(rel.max())
-            out["cpu_baseline_parity"] = {
-                "max_rel_qpos_error_1000_mj_steps": worst, "max_abs_qpos_error_1000_mj_steps": worst_abs,
-                "bar": 1e-4, "rel_error_at_mj_step": curve, "max_rel_error_by_dof_group": gmax,
-                "note": "engine (2 envs, same precision as value) vs the CPU oracle, scripted replay, free running; "
-                        "rel = |dq| / max(|q_cpu|, 1e-2)"}
-            out["cpu_baseline"] = {
-                "value": nenv_cpu * nstep / args.substeps / secs, "unit": "env-steps/s",
-                "cores": cores, "kind": "port",
-                "sample": f"{nenv_cpu} envs x {nstep} mj_steps from reset ({secs:.1f} s of host time), fp64 C oracle (CPU restatement, not MuJoCo), OpenMP {cores} threads, each env holds one row of the scripted replay as ctrl",
-                "mj_steps_per_s": nenv_cpu * nstep / secs,
-            }
+            out.update(cpu_leg(args, m, phys, base_key_ids, cfg))
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_leg(args, m, phys, key_ids, cfg):
+    """cpu_baseline (the fp64 C oracle on the host cores, bounded sample of the same workload) and
+    cpu_baseline_parity (engine vs oracle on the config's own action stream)."""
+    from oracle.rp_oracle import Oracle
+    from robopianist_amd import engine as _eng
+    out = {}
+    orc = Oracle(m, phys.blob)
+    cores = _usable_cores()
+    lo, hi = m.actuator_ctrlrange[:, 0], m.actuator_ctrlrange[:, 1]
+    replay = cfg["policy"] == "replay"
+    if replay:
+        ctrl_seq, _ = load_actions(m)
+    else:
+        rng = np.random.default_rng(12345)
+        ctrl_seq = lo + rng.uniform(0, 1, size=(1000, m.nu)) * (hi - lo)
+    # bounded sample sized for ~15 s of host work: many short rollouts from reset (the transient,
+    # contact-changing part of an episode), each env holding a different row of the action stream
+    nenv_cpu = cores * 160
+    nstep = 400
+    rows = (40 + 7 * np.arange(nenv_cpu)) % ctrl_seq.shape[0]
+    cc = np.ascontiguousarray(ctrl_seq[rows])
+    secs, _ = orc.bench(nenv_cpu, nstep, cc, cores)
+    out["cpu_baseline"] = {
+        "value": nenv_cpu * nstep / args.substeps / secs, "unit": "env-steps/s", "cores": cores, "kind": "port",
+        "sample": f"{nenv_cpu} envs x {nstep} mj_steps from reset ({secs:.1f} s of host time), fp64 C oracle (CPU "
+                  f"restatement, not MuJoCo), OpenMP {cores} threads, each env holds one row of the config's action "
+                  "stream as ctrl",
+        "mj_steps_per_s": nenv_cpu * nstep / secs,
+    }
+    # ---- parity on this config's own action stream (2 envs, precision of `value`)
+    chk = _eng.BatchedPhysics(m, key_ids, n_envs=2, precision=args.precision)
+    is_key = np.zeros(int(m.nv), bool); is_key[np.asarray(key_ids)] = True
+    is_arm = np.array(["forearm" in n for n in m.names["joint"]])
+    groups = {"keys": is_key, "forearms": is_arm & ~is_key, "fingers_and_wrists": ~is_key & ~is_arm}
+    # (1) free running, 1000 mj_steps (BASELINE metric 2): rel = |dq| / max(|q_cpu|, 1e-2)
+    orc.reset()
+    worst, worst_abs, gmax, curve = 0.0, 0.0, {k: 0.0 for k in groups}, {}
+    for i in range(1000):
+        c = ctrl_seq[(i // args.substeps) % ctrl_seq.shape[0]]
+        chk.set(_eng.CTRL, c[None, :]); orc.ctrl[:] = c
+        chk.step(1); orc.step(1)
+        qg = chk.qpos.astype(np.float64)[0]
+        ad = np.abs(qg - orc.qpos)
+        rel = ad / np.maximum(np.abs(orc.qpos), 1e-2)
+        worst = max(worst, float(rel.max())); worst_abs = max(worst_abs, float(ad.max()))
+        for k, sel in groups.items():
+            gmax[k] = max(gmax[k], float(rel[sel].max()))
+        if i + 1 in (1, 10, 100, 300, 1000):
+            curve[str(i + 1)] = float(rel.max())
+    # (2) teacher forced along the oracle's trajectory of the same stream: every mj_step restarts
+    # from the oracle's state, i.e. the per-step discrepancy free of the trajectory's own sensitivity
+    orc.reset()
+    tf_worst, ncon_max, ncon_mismatch = 0.0, 0, 0
+    for i in range(300):
+        c = ctrl_seq[(i // args.substeps) % ctrl_seq.shape[0]]
+        chk.set(_eng.QPOS, orc.qpos[None, :]); chk.set(_eng.QVEL, orc.qvel[None, :])
+        chk.set(_eng.QACC_WARMSTART, orc.qacc_warmstart[None, :])
+        chk.set(_eng.CTRL, c[None, :]); orc.ctrl[:] = c
+        v0 = orc.qvel.copy()
+        chk.step(1); orc.step(1)
+        dv = np.abs(chk.qvel[0].astype(np.float64) - orc.qvel).max()
+        tf_worst = max(tf_worst, float(dv / max(np.abs(orc.qvel - v0).max(), 1e-9)))
+        ncon_mismatch += int(chk.get(_eng.NCON)[0] != orc.ncon)
+        ncon_max = max(ncon_max, int(orc.ncon))
+    out["cpu_baseline_parity"] = {
+        "max_rel_qpos_error_1000_mj_steps": worst, "max_abs_qpos_error_1000_mj_steps": worst_abs,
+        "bar": 1e-4, "rel_error_at_mj_step": curve, "max_rel_error_by_dof_group": gmax,
+        "teacher_forced_worst_rel_dv_300_mj_steps": tf_worst, "teacher_forced_bar": 1e-9 if args.precision == 64 else 5e-3,
+        "teacher_forced_contact_count_mismatches": ncon_mismatch, "teacher_forced_max_contacts": ncon_max,
+        "note": "engine (2 envs, same precision as value) vs the CPU oracle on this config's action stream; free "
+                "running: rel = |dq| / max(|q_cpu|, 1e-2) (random policies are chaotic: the free-running figure is "
+                "reported, the bar applies to the scripted replay); teacher forced: every mj_step restarts from the "
+                "oracle state, error relative to the step's largest velocity change"}
+    return out
 
 
 if __name__ == "__main__":

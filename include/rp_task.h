@@ -24,7 +24,10 @@ extern "C" {
 typedef struct rp_task_reward_args {
   int n_envs, precision;
   int nv, nu, n_sites, n_contacts;   /* row lengths of qpos, act_*, site_xpos, contact_geoms */
-  int use_fingering, use_forearm;    /* disabled terms are written as 0 and not summed */
+  int use_fingering, use_forearm;    /* disabled terms are written as 0 and not summed.  use_fingering: 1 = the
+                                      * MIDI's fingering (:300-331); 2 = the optimal-transport term (:333-369):
+                                      * minimum-cost assignment between the fingertips and the keys to press
+                                      * (scipy.optimize.linear_sum_assignment in the reference), term slot 3 */
   double energy_coef;                /* _ENERGY_PENALTY_COEF (:24) */
   double key_close, finger_close;    /* _KEY_CLOSE_ENOUGH_TO_PRESSED, _FINGER_CLOSE_ENOUGH_TO_KEY (:22-23) */
   /* engine state: rp_field_ptr views */
@@ -116,6 +119,10 @@ typedef struct rp_task_advance_args {
    * current tables. */
   unsigned char* next_ready;         /* [E] in/out */
   unsigned char* consumed;           /* [E] out (sticky) */
+  /* engine warn bits that end the episode with reward 0 / discount 0 (0 = RP_WARN_BADSTATE only);
+   * fatal_count (optional) counts those episodes per env */
+  int warn_fatal_mask;
+  long long* fatal_count;            /* [E] or NULL */
 } rp_task_advance_args;
 
 int rp_task_advance(const rp_task_advance_args* args, void* hip_stream);

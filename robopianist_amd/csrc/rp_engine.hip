@@ -88,8 +88,10 @@ struct EngineBase {
   bool ev_pending[kRing] = {};
   int ev_next = 0;
   double kernel_ms = 0; int kernel_launches = 0;
-  // second ring: one solver-kernel (mj_step2) launch per rp_step call, the middle substep
+  // second ring: one solver-kernel (mj_step2) launch per rp_step call; the probed substep rotates
+  // with the call count, so the running average is the mean over all substeps by construction
   hipEvent_t sv0[kRing] = {}, sv1[kRing] = {};
+  unsigned step_calls = 0;
   double solver_ms = 0; int solver_launches = 0;
   void harvest(int i, bool wait) {
     if (!ev_pending[i]) return;
@@ -461,7 +463,7 @@ struct Engine : EngineBase {
     }
     if (mode == 0) {
       for (int k = 0; k < nsub; k++) {
-        const bool probe = timeit && k == nsub / 2;
+        const bool probe = timeit && k == (int)(step_calls % (unsigned)nsub);
         if (probe) HIP_OK(hipEventRecord(sv0[slot], stream));
         // solver stage; the build specialised for "every tree has a 4-link trunk" when it applies
         if (trunk4) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 4>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
@@ -472,6 +474,7 @@ struct Engine : EngineBase {
     }
     hipLaunchKernelGGL(rp_mark_valid_kernel, dim3(hb), dim3(256), 0, stream, d_valid, s.active, nenv);
     HIP_OK(hipGetLastError());
+    if (mode == 0) step_calls++;
     if (timeit) { HIP_OK(hipEventRecord(ev1[slot], stream)); ev_pending[slot] = true; }
     if (trace && mode == 0)
       HIP_OK(hipMemcpyAsync(trace, d_trace, need * sizeof(uint32_t), hipMemcpyDefault, stream));

@@ -30,6 +30,86 @@ __device__ __forceinline__ void prf(int tp, int fp, int fn, double* out) {
   out[0] = p; out[1] = r; out[2] = f;
 }
 
+// Optimal-transport fingering term (piano_with_shadow_hands.py:333-369): minimum-cost assignment
+// between the 10 fingertips and the keys to press (scipy.optimize.linear_sum_assignment in the
+// reference), mean tolerance of the assigned distances.  One wavefront; shortest augmenting paths
+// with potentials (Kuhn-Munkres), rows = the smaller side (<= 10), columns over lanes (two per
+// lane).  Always in double.  cost[r * m + c]; returns the mean tolerance in every lane.
+struct OtScratch {
+  double cost[10 * RP_TASK_N_KEYS];
+  double u[11];
+  int p[RP_TASK_N_KEYS + 1], way[RP_TASK_N_KEYS + 1];   // 1-based columns, 0 = the virtual start column
+};
+__device__ __forceinline__ double ot_assign_mean_tolerance(OtScratch& S, int n, int m, int lane, double fclose) {
+  const double INF = 1e300;
+  double v[2] = {0, 0}, minv[2];
+  bool used[2];
+  for (int j = lane; j <= m; j += 64) S.p[j] = 0;
+  if (lane <= n) S.u[lane] = 0;
+  __syncthreads();
+  for (int i = 1; i <= n; i++) {
+    if (lane == 0) S.p[0] = i;
+    minv[0] = minv[1] = INF; used[0] = used[1] = false;
+    int j0 = 0;
+    __syncthreads();
+    while (true) {
+#pragma unroll
+      for (int s = 0; s < 2; s++) if (j0 == lane + 64 * s + 1) used[s] = true;
+      const int i0 = S.p[j0];
+      const double ui0 = S.u[i0];
+      double best = INF;
+      int bj = 0x7fffffff;
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const int j = lane + 64 * s + 1;
+        if (j <= m && !used[s]) {
+          const double cur = S.cost[(size_t)(i0 - 1) * m + (j - 1)] - ui0 - v[s];
+          if (cur < minv[s]) { minv[s] = cur; S.way[j] = j0; }
+          if (minv[s] < best) { best = minv[s]; bj = j; }
+        }
+      }
+      // wave argmin (ties: smallest column, as a sequential scan would pick)
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const double ob = __shfl_xor(best, off, 64);
+        const int oj = __shfl_xor(bj, off, 64);
+        if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+      }
+      const double delta = best;
+      const int j1 = bj;
+      __syncthreads();  // every lane has read u[i0] / p[j0] before the potentials move
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const int j = lane + 64 * s + 1;
+        if (j <= m) {
+          if (used[s]) { S.u[S.p[j]] += delta; v[s] -= delta; }   // distinct rows: no conflict
+          else minv[s] -= delta;
+        }
+      }
+      if (lane == 0) S.u[i] += delta;   // the virtual column holds row i
+      j0 = j1;
+      __syncthreads();
+      if (S.p[j0] == 0) break;
+    }
+    // augment along the alternating path (uniform; lane 0 writes)
+    __syncthreads();
+    if (lane == 0) {
+      int j = j0;
+      while (j) { const int jn = S.way[j]; S.p[j] = S.p[jn]; j = jn; }
+    }
+    __syncthreads();
+  }
+  double sum = 0;
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const int j = lane + 64 * s + 1;
+    if (j <= m && S.p[j] != 0) sum += tol_gauss(S.cost[(size_t)(S.p[j] - 1) * m + (j - 1)], fclose, fclose * 10.0);
+  }
+  sum = wsum(sum);
+  __syncthreads();
+  return sum / (double)n;
+}
+
 // Per-lane view of the task state the reward terms read: lane k owns keys k and k + 64.
 template <typename T> struct KeyView { T goal[2], nstate[2]; bool pressed[2]; long long finger[2]; T goal_sustain; bool sustain_on; };
 
@@ -42,6 +122,9 @@ __device__ __forceinline__ T reward_env(const rp_task_reward_args& a, int env, i
   const T kclose = (T)a.key_close, fclose = (T)a.finger_close;
   T kp_sum = 0, fg_sum = 0;
   int n_on = 0, n_fg = 0, false_pos = 0;
+  const bool ot = a.use_fingering == 2;
+  T tgt[2][3] = {{0, 0, 0}, {0, 0, 0}};   // fingertip target of this lane's goal keys
+  bool on[2] = {false, false};
 #pragma unroll
   for (int s = 0; s < 2; s++) {
     const int k = lane + 64 * s;
@@ -49,26 +132,57 @@ __device__ __forceinline__ T reward_env(const rp_task_reward_args& a, int env, i
       const T g = kv.goal[s];
       if (g > (T)0) {
         n_on++;
+        on[s] = true;
         kp_sum += tol_gauss(g - kv.nstate[s], kclose, kclose * (T)10);
-        // two hands: a note without fingering counts as finger 4 (:401-412); one hand: only the
-        // notes fingered by this hand take part (finger holds the local index or -1)
-        const long long f = kv.finger[s];
-        if (a.use_fingering && (a.hand_filter == 0 || f >= 0)) {
-          const int fid = f < 0 ? 4 : (int)f;
-          n_fg++;
-          const T* tip = sites + (size_t)a.tip_site[fid] * 3;
+        if (a.use_fingering) {
           const T* an = (const T*)a.key_anchor + 3 * k;
           const T* hf = (const T*)a.key_half + 3 * k;
           const T q = qpos[a.key_qadr[k]];
           const T hx = hf[0];
           // key geom centre + (0.35 size_x, 0, 0.5 size_z)  (:311-313)
-          const T tx = an[0] + hx * cos(q) + (T)0.35 * hx;
-          const T ty = an[1];
-          const T tz = an[2] - hx * sin(q) + (T)0.5 * hf[2];
-          const T dx = tx - tip[0], dy = ty - tip[1], dz = tz - tip[2];
+          tgt[s][0] = an[0] + hx * cos(q) + (T)0.35 * hx;
+          tgt[s][1] = an[1];
+          tgt[s][2] = an[2] - hx * sin(q) + (T)0.5 * hf[2];
+        }
+        // two hands: a note without fingering counts as finger 4 (:401-412); one hand: only the
+        // notes fingered by this hand take part (finger holds the local index or -1)
+        const long long f = kv.finger[s];
+        if (a.use_fingering == 1 && (a.hand_filter == 0 || f >= 0)) {
+          const int fid = f < 0 ? 4 : (int)f;
+          n_fg++;
+          const T* tip = sites + (size_t)a.tip_site[fid] * 3;
+          const T dx = tgt[s][0] - tip[0], dy = tgt[s][1] - tip[1], dz = tgt[s][2] - tip[2];
           fg_sum += tol_gauss(sqrt(dx * dx + dy * dy + dz * dz), fclose, fclose * (T)10);
         }
       } else if (kv.pressed[s]) false_pos = 1;
+    }
+  }
+  // OT fingering (:333-369): assignment between the fingertips and the keys to press
+  T ot_rew = (T)1;  // no key to press
+  if (ot) {
+    __shared__ OtScratch ots;
+    const unsigned long long m0 = __ballot(on[0]), m1 = __ballot(on[1]);
+    const int k0 = __popcll(m0), nk = k0 + __popcll(m1);   // uniform
+    if (nk > 0) {
+      const int ntip = a.hand_filter ? 5 : 10;
+      const bool tips_are_rows = nk >= ntip;   // rows = the smaller side
+      const int n = tips_are_rows ? ntip : nk, m = tips_are_rows ? nk : ntip;
+      const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        if (on[s]) {
+          const int kc = (s == 0 ? 0 : k0) + __popcll((s == 0 ? m0 : m1) & below);  // compact key index
+          for (int f = 0; f < ntip; f++) {
+            const T* tip = sites + (size_t)a.tip_site[f] * 3;
+            const double dx = (double)tgt[s][0] - (double)tip[0], dy = (double)tgt[s][1] - (double)tip[1],
+                         dz = (double)tgt[s][2] - (double)tip[2];
+            const double d = sqrt(dx * dx + dy * dy + dz * dz);
+            if (tips_are_rows) ots.cost[(size_t)f * m + kc] = d; else ots.cost[(size_t)kc * m + f] = d;
+          }
+        }
+      }
+      __syncthreads();
+      ot_rew = (T)ot_assign_mean_tolerance(ots, n, m, lane, (double)a.finger_close);
     }
   }
   // energy: |actuatorfrc| * |actuatorvel| over the hand actuators
@@ -97,7 +211,7 @@ __device__ __forceinline__ T reward_env(const rp_task_reward_args& a, int env, i
     const T key_press = (non > 0 ? (T)0.5 * kp_sum / (T)non : (T)0) + (T)0.5 * (fpos ? (T)0 : (T)1);
     const T sustain = tol_gauss(kv.goal_sustain - (kv.sustain_on ? (T)1 : (T)0), kclose, kclose * (T)10);
     const T energy = -(T)a.energy_coef * en;
-    const T fingering = a.use_fingering ? (nfg > 0 ? fg_sum / (T)nfg : (T)0) : (T)0;
+    const T fingering = ot ? ot_rew : (a.use_fingering ? (nfg > 0 ? fg_sum / (T)nfg : (T)0) : (T)0);
     const T forearm = a.use_forearm ? (fhit ? (T)0 : (T)0.5) : (T)0;
     T* t = (T*)a.terms;
     t[0 * E + env] = key_press; t[1 * E + env] = sustain; t[2 * E + env] = energy;
@@ -225,14 +339,20 @@ __global__ __launch_bounds__(64) void rp_task_advance_kernel(rp_task_advance_arg
   // ---- rewards, termination, discount, step type
   T reward = reward_env<T>(a, env, lane, kv);
   if (lane == 0) {
+    // composer.Environment.step reads get_discount BEFORE should_terminate_episode (:213-220 then
+    // sets task._discount = 0): the LAST TimeStep of a wrong press still carries the old discount
+    T disc = dstate;
     if (p.wrong_press_termination) {
       if (failure && !term) dstate = (T)0;
       term = term || failure;
     }
     bool terminate = term && active;
-    const bool bad = (p.warn[env] & 1) != 0 && active;       // physics divergence ends the episode
+    // physics divergence ends the episode (PhysicsError semantics); so do the engine's capacity
+    // overflows selected by warn_fatal_mask (dropped contacts / cross terms: wrong physics from here on)
+    const int fatal = p.warn_fatal_mask ? p.warn_fatal_mask : 1;
+    const bool bad = (p.warn[env] & fatal) != 0 && active;
+    if (bad && p.fatal_count) p.fatal_count[env] += 1;
     terminate = terminate || bad;
-    T disc = dstate;
     if (bad) { reward = (T)0; disc = (T)0; }
     int st = terminate ? 2 : 1;
     if (resetting) { st = 0; reward = (T)0; disc = (T)1; }

@@ -31,6 +31,7 @@ WARN_CONTACT_FULL = 2
 WARN_HESSIAN = 4
 WARN_KEYSLOT_FULL = 8
 WARN_WORK_FULL = 16
+WARN_DENSE_FULL = 32
 
 EXPORTED_SYMBOLS = (
     "rp_create", "rp_destroy", "rp_reset", "rp_set", "rp_get", "rp_step", "rp_forward",

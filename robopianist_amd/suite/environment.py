@@ -90,7 +90,14 @@ class Environment:
         obs = self._task.get_observation(self._physics)
         st = torch.full((self._n_envs,), int(StepType.FIRST), dtype=torch.int32,
                         device=self._physics.device)
-        return TimeStep(st, None, None, obs)
+        # (own copies, like step(): a FIRST observation kept by the caller must survive the next step)
+        return self._fresh(TimeStep(st, None, None, obs))
+
+    def request_reset(self, mask) -> None:
+        """Extension: flags the envs selected by the boolean device tensor `mask` for a reset at
+        the next step() (they return FIRST there and are not simulated), exactly as if their episode
+        had just ended.  Device-side, no synchronisation."""
+        self._needs_reset.logical_or_(mask.to(device=self._needs_reset.device, dtype=torch.bool))
 
     def step(self, action) -> TimeStep:
         """Fully asynchronous for n_envs > 1: resets are applied through device-side
@@ -100,6 +107,10 @@ class Environment:
         if self._n_envs == 1 and bool(resetting.all()):
             return self.reset()  # dm_env: step after LAST == reset (reward None)
         active = ~resetting
+        # the action of an env that is being reset is discarded (dm_env): it must not leak into ctrl /
+        # the sustain latch, which the FIRST observation reports as 0 after reset()
+        action = torch.as_tensor(action, device=phys.device, dtype=phys.dtype).reshape(self._n_envs, -1)
+        action = action * active[:, None].to(action.dtype)
         fused = task.fused_advance_for(phys) if hasattr(task, "fused_advance_for") else None
         if fused is not None:
             # HIP task layer (include/rp_task.h): the episode reset of the flagged envs, the
@@ -128,10 +139,16 @@ class Environment:
         task.after_step(phys, active)
         obs = task.get_observation(phys)
         reward = task.get_reward(phys)
+        # composer.Environment.step reads the discount BEFORE should_terminate_episode: the LAST
+        # TimeStep of a wrong-press termination carries discount 1, only task._discount drops to 0
+        # (which is what the reference's test asserts, piano_with_shadow_hands_test.py:228-242)
+        discount = task.get_discount(phys).clone()
         terminate = task.should_terminate_episode(phys) & active
-        discount = task.get_discount(phys)
-        # physics divergence terminates the episode (dm_control PhysicsError semantics)
-        bad = (phys.warn & 1).bool() & active
+        # physics divergence terminates the episode (dm_control PhysicsError semantics); so does a
+        # capacity overflow of the engine (dropped contacts / cross terms = wrong physics from here on)
+        bad = (phys.warn & int(getattr(task, "fatal_warn_mask", 1))).bool() & active
+        if hasattr(task, "count_fatal"):
+            task.count_fatal(phys.warn, active)
         terminate = terminate | bad
         reward = torch.where(bad, torch.zeros_like(reward), reward)
         discount = torch.where(bad, torch.zeros_like(discount), discount)

@@ -52,6 +52,7 @@ class PianoWithShadowHands(base.PianoTask):
         energy_penalty_coef: float = _ENERGY_PENALTY_COEF,
         randomize_hand_positions: bool = False,
         augmentation_prefetch: bool = False,
+        overflow_termination: bool = True,
         **kwargs,
     ) -> None:
         super().__init__(disable_hand_collisions=disable_hand_collisions, **kwargs)
@@ -77,6 +78,13 @@ class PianoWithShadowHands(base.PianoTask):
         self._disable_hand_collisions = disable_hand_collisions
         self._energy_penalty_coef = energy_penalty_coef
         self._randomize_hand_positions = randomize_hand_positions
+        # extension: an engine capacity overflow (contacts / Jacobian entries / key slots / dense rows
+        # dropped: the physics of that env is wrong from there on) ends the episode like a diverged
+        # state does -- reward 0, discount 0 -- instead of stepping on with silently altered dynamics
+        from robopianist_amd import engine as _eng
+        self.fatal_warn_mask = _eng.WARN_BADSTATE | (
+            (_eng.WARN_CONTACT_FULL | _eng.WARN_KEYSLOT_FULL | _eng.WARN_DENSE_FULL) if overflow_termination else 0)
+        self._fatal_count = None
         self._use_fused_rewards = True   # set False to force the torch reward functions
         self._fused_rewards = None
         self._use_fused_advance = True   # set False to force the torch task hooks
@@ -298,6 +306,22 @@ class PianoWithShadowHands(base.PianoTask):
         self._bind_goal_bank()
         self._bind_hands()
         self._bind_task_state()
+        self._fatal_count = torch.zeros(n_envs, device=physics.device, dtype=torch.long)
+        if self._prefetch:
+            # both slots of every env are filled before the first step, whether or not the caller
+            # starts with an explicit reset()
+            self._prefetch_full_reset()
+
+    def count_fatal(self, warn, active) -> None:
+        """Torch path: counts the episodes ended by an engine warn flag (see fatal_warn_mask)."""
+        self._fatal_count.add_(((warn & self.fatal_warn_mask) != 0) & active)
+
+    def overflow_terminations(self) -> int:
+        """Episodes ended by a warn flag so far (bad state or capacity overflow), all envs."""
+        n = int(self._fatal_count.sum().item()) if self._fatal_count is not None else 0
+        if self._fused_advance is not None:
+            n += int(self._fused_advance.fatal_count.sum().item())
+        return n
 
     def _bind_goal_bank(self):
         dev, E = self._physics_device, self._E
@@ -464,8 +488,8 @@ class PianoWithShadowHands(base.PianoTask):
             goal_current=self._goal_current, key_norm_state=self.piano.normalized_state,
             key_activation=self.piano.activation, sustain_activation=self.piano.sustain_activation,
             finger_current=self._finger_current)
-        from robopianist_amd import task_kernels
-        for i, name in enumerate(task_kernels.TERM_NAMES):
+        for i in range(len(terms)):
+            name = self._term_name(i)
             if name in self._reward_fn.reward_fns:
                 self._reward_fn.reward_terms[name] = terms[i]
         return total
@@ -475,10 +499,12 @@ class PianoWithShadowHands(base.PianoTask):
             return None
         names = tuple(self._reward_fn.reward_fns)
         std = ("key_press_reward", "sustain_reward", "energy_reward")
-        want = std + (("fingering_reward",) if not self._disable_fingering_reward else ()) + \
-            (("forearm_reward",) if not self._disable_forearm_reward else ())
+        fing = "fingering_reward" if not self._disable_fingering_reward else "ot_fingering_reward"
+        if fing == "ot_fingering_reward" and not self._ot_term_on_device():
+            return None
+        want = std + (fing,) + (("forearm_reward",) if not self._disable_forearm_reward else ())
         if names != want or self.piano._add_actuators:
-            return None  # customised reward set (or the OT fingering term): torch path
+            return None  # customised reward set: torch path
         if self._fused_rewards is None:
             from robopianist_amd import task_kernels
             tips = [physics._site_modelid[int(s)] for s in self._tip_sites]
@@ -487,10 +513,20 @@ class PianoWithShadowHands(base.PianoTask):
                 key_anchor=self._key_anchor, key_half=self._key_half,
                 hand_act=list(self.right_hand.actuators) + list(self.left_hand.actuators), tip_site=tips,
                 rfa=self.right_hand.forearm_geom_ids, lfa=self.left_hand.forearm_geom_ids,
-                use_fingering=not self._disable_fingering_reward, use_forearm=not self._disable_forearm_reward,
+                use_fingering=1 if not self._disable_fingering_reward else 2,  # 2: the OT assignment term
+                use_forearm=not self._disable_forearm_reward,
                 energy_coef=self._energy_penalty_coef, key_close=_KEY_CLOSE_ENOUGH_TO_PRESSED,
                 finger_close=_FINGER_CLOSE_ENOUGH_TO_KEY)
         return self._fused_rewards
+
+    def _ot_term_on_device(self) -> bool:
+        """The OT fingering term (:333-369) as a wave-per-env assignment kernel (two-hand task)."""
+        return getattr(self, "_use_device_ot", True) and self.right_hand is not None and self.left_hand is not None
+
+    def _term_name(self, i):
+        from robopianist_amd import task_kernels
+        name = task_kernels.TERM_NAMES[i]
+        return "ot_fingering_reward" if (name == "fingering_reward" and self._disable_fingering_reward) else name
 
     def fused_advance_for(self, physics):
         """The one-launch replacement of after_substeps .. TimeStep assembly
@@ -509,7 +545,7 @@ class PianoWithShadowHands(base.PianoTask):
                 finger_bank=self._finger_bank, song_len=self._song_len, song_id=self._song_id,
                 wrong_press_termination=self._wrong_press_termination,
                 key_threshold=_base._KEY_THRESHOLD, sustain_threshold=_base._SUSTAIN_THRESHOLD,
-                key_qrange=self.piano._qpos_range)
+                key_qrange=self.piano._qpos_range, warn_fatal_mask=self.fatal_warn_mask)
             if getattr(self, "_eval_buffers", None) is not None:
                 self._fused_advance.set_evaluation_buffers(*self._eval_buffers)
             if self._prefetch:
@@ -536,7 +572,8 @@ class PianoWithShadowHands(base.PianoTask):
             discount_state=self._discount, goal_state=self._goal_state, goal_current=self._goal_current,
             finger_next=self._finger_next, finger_current=self._finger_current,
             fingering_state=self._fingering_state)
-        for i, name in enumerate(task_kernels.TERM_NAMES):
+        for i in range(len(terms)):
+            name = self._term_name(i)
             if name in self._reward_fn.reward_fns:
                 self._reward_fn.reward_terms[name] = terms[i]
         return st, total, disc, self._observation_dict(physics)
@@ -763,7 +800,9 @@ class PianoWithShadowHands(base.PianoTask):
 
     def _compute_ot_fingering_reward(self, physics):
         """:333-369 — optimal assignment of the 10 fingertips (left first) to the keys to
-        press.  Runs scipy's Hungarian solver per env on the host."""
+        press.  This is the DEFINITION (scipy's solver per env on the host, as the reference); on the
+        HIP engine the term runs inside the fused task kernels (include/rp_task.h, use_fingering = 2)
+        and this function is the cross-check of tests/test_gpu_env.py."""
         from scipy.optimize import linear_sum_assignment
         tips = torch.cat([physics.site_xpos(list(self.left_hand.fingertip_sites)),
                           physics.site_xpos(list(self.right_hand.fingertip_sites))], dim=1)

@@ -77,12 +77,22 @@ class SelfActuatedPiano(base.PianoOnlyTask):
 
     def _reset_quantities_at_episode_init(self, mask=None):
         dev, E = self._physics_device, self._E
-        if mask is None or not hasattr(self, "_t_idx"):
+        # allocated once, updated in place: a captured hipGraph (GraphedStepWrapper) replays
+        # against these very buffers
+        if not hasattr(self, "_t_idx"):
             self._t_idx = torch.zeros(E, device=dev, dtype=torch.long)
             self._should_terminate = torch.zeros(E, device=dev, dtype=torch.bool)
+        elif mask is None:
+            self._t_idx.zero_()
+            self._should_terminate.zero_()
         else:
-            self._t_idx[mask] = 0
-            self._should_terminate[mask] = False
+            self._t_idx.masked_fill_(mask, 0)
+            self._should_terminate.masked_fill_(mask, False)
+
+    @property
+    def needs_host_episode_setup(self) -> bool:
+        """MIDI augmentations re-draw the song on the host at every episode start (not capturable)."""
+        return self._augmentations is not None
 
     _STATE = ("_t_idx", "_should_terminate", "_goal_state", "_goal_current", "_goal_bank", "_len")
 
@@ -93,7 +103,11 @@ class SelfActuatedPiano(base.PianoOnlyTask):
 
     def load_state_dict(self, sd):
         for k in self._STATE:
-            setattr(self, k, sd[k].to(self._physics_device).clone())
+            cur, new = getattr(self, k), sd[k].to(self._physics_device)
+            if cur.shape == new.shape:
+                cur.copy_(new)
+            else:  # (the goal bank may have grown)
+                setattr(self, k, new.clone())
         self.piano.load_state_dict(sd["piano"])
 
     def _maybe_change_midi(self, mask=None):
@@ -135,9 +149,7 @@ class SelfActuatedPiano(base.PianoOnlyTask):
         """:143-151 — Piano.apply_action: ctrl = action[:-1], sustain = action[-1]."""
         action = torch.as_tensor(action, device=self._physics_device, dtype=self._dtype)
         action = action.reshape(self._E, -1)
-        ctrl = physics.ctrl.clone()
-        ctrl[:, self._aidx] = action[:, :-1]
-        physics.set_ctrl(ctrl)
+        physics.ctrl[:, self._aidx] = action[:, :-1]  # (zero-copy view of the engine's ctrl array)
         self.piano.apply_sustain(action[:, -1])
 
     def after_substeps(self, physics):
@@ -145,9 +157,9 @@ class SelfActuatedPiano(base.PianoOnlyTask):
 
     def after_step(self, physics, active=None):
         inc = torch.ones_like(self._t_idx) if active is None else active.to(torch.long)
-        self._t_idx = self._t_idx + inc
-        self._should_terminate = (self._t_idx - 1) == self._len[self._slot] - 1
-        self._goal_current = self._goal_state[:, 0].clone()
+        self._t_idx.add_(inc)
+        torch.eq(self._t_idx, self._len[self._slot], out=self._should_terminate)  # (t_idx - 1) == len - 1
+        self._goal_current.copy_(self._goal_state[:, 0])
 
     def get_reward(self, physics):
         return self._reward_fn.compute(physics)
@@ -184,7 +196,7 @@ class SelfActuatedPiano(base.PianoOnlyTask):
         valid = steps < T[:, None]
         g = self._goal_bank[self._slot[:, None], torch.clamp(steps, max=self._goal_bank.shape[1] - 1)]
         g = torch.where(valid[..., None], g, torch.zeros_like(g))
-        self._goal_state = torch.where(live[:, None, None], g, self._goal_state)
+        self._goal_state.copy_(torch.where(live[:, None, None], g, self._goal_state))
 
     def get_observation(self, physics):
         self._update_goal_state()

@@ -55,6 +55,7 @@ class AdvanceArgs(ctypes.Structure):
         ("eval_sums", ctypes.c_void_p), ("eval_count", ctypes.c_void_p), ("eval_hist", ctypes.c_void_p),
         ("eval_nfinished", ctypes.c_void_p), ("eval_deque", ctypes.c_int),
         ("next_ready", ctypes.c_void_p), ("consumed", ctypes.c_void_p),
+        ("warn_fatal_mask", ctypes.c_int), ("fatal_count", ctypes.c_void_p),
     ]
 
 
@@ -114,7 +115,8 @@ class FusedRewards:
         a.n_envs, a.precision = self._E, 64 if dt == torch.float64 else 32
         a.nv, a.nu = int(physics.qpos.shape[1]), int(physics.act_force.shape[1])
         a.n_sites, a.n_contacts = int(physics.site_xpos_eng.shape[1]), int(physics.contact_geoms.shape[1])
-        a.use_fingering, a.use_forearm = int(bool(use_fingering)), int(bool(use_forearm))
+        # use_fingering: False / True, or 2 = the optimal-transport term (include/rp_task.h)
+        a.use_fingering, a.use_forearm = int(use_fingering), int(bool(use_forearm))
         a.energy_coef, a.key_close, a.finger_close = float(energy_coef), float(key_close), float(finger_close)
         E = self._E
         a.qpos = _chk(physics.qpos, dt, (E, a.nv))
@@ -156,7 +158,7 @@ class FusedAdvance:
     are the task's persistent buffers and are updated in place."""
 
     def __init__(self, rewards: FusedRewards, *, n_lookahead, goal_bank, finger_bank, song_len, song_id,
-                 wrong_press_termination, key_threshold, sustain_threshold, key_qrange):
+                 wrong_press_termination, key_threshold, sustain_threshold, key_qrange, warn_fatal_mask=1):
         self._L = _lib()
         self._rw = rewards
         E, dt, dev = rewards._E, rewards._dt, rewards._phys.device
@@ -178,6 +180,9 @@ class FusedAdvance:
         p.goal_bank, p.finger_bank = self._goal_bank.data_ptr(), self._finger_bank.data_ptr()
         p.song_len, p.song_id = self._song_len.data_ptr(), self._song_id.data_ptr()
         p.discount, p.step_type = self.discount.data_ptr(), self.step_type.data_ptr()
+        p.warn_fatal_mask = int(warn_fatal_mask)
+        self.fatal_count = torch.zeros((E,), device=dev, dtype=torch.int64)
+        p.fatal_count = self.fatal_count.data_ptr()
         self._p = p
         self._L_lookahead = int(n_lookahead)
 

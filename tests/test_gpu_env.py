@@ -65,7 +65,9 @@ def test_failure_termination_with_applied_force():
     env.physics.set_qfrc_applied(f)
     ts = env.step(np.zeros((3,) + env.action_spec().shape))
     assert bool(ts.last().all())
-    np.testing.assert_array_equal(_np(ts.discount), 0.0)
+    assert bool(task.should_terminate_episode(env.physics).all())
+    # "Failure, so discount should be 0.0": the reference asserts the task's discount
+    np.testing.assert_array_equal(_np(task.get_discount(env.physics)), 0.0)
 
 
 def test_env_step_matches_oracle_and_key_trace():
@@ -303,7 +305,7 @@ def test_fused_task_advance_matches_torch_hooks(wrong_press):
         assert torch.equal(fused._needs_reset, ref._needs_reset)
         seen["first"] += int((ts_f.step_type == 0).sum())
         seen["last"] += int((ts_f.step_type == 2).sum())
-        seen["zero_discount"] += int(((ts_f.discount == 0) & (ts_f.step_type == 2)).sum())
+        seen["zero_discount"] += int(((tf._discount == 0) & (ts_f.step_type == 2)).sum())
     # the scenario did exercise the interesting branches
     assert seen["last"] >= 2 and seen["first"] >= 2, seen
     if wrong_press:

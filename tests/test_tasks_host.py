@@ -149,7 +149,37 @@ def test_wrong_press_sets_discount_zero_and_terminates():
     env.physics.qpos[1, env.task.piano.joints[0]] = 1.0
     ts = env.step(zero)
     assert ts.step_type.tolist() == [1, 2, 1]
-    np.testing.assert_array_equal(ts.discount.numpy(), [1.0, 0.0, 1.0])
+    # the reference asserts the TASK's discount (piano_with_shadow_hands_test.py:228-242);
+    # composer.Environment.step reads get_discount before should_terminate_episode zeroes it,
+    # so the LAST TimeStep itself still carries 1.0
+    np.testing.assert_array_equal(env.task.get_discount(env.physics).numpy(), [1.0, 0.0, 1.0])
+    np.testing.assert_array_equal(ts.discount.numpy(), [1.0, 1.0, 1.0])
+
+
+def test_first_observation_survives_the_next_step():
+    """reset() hands out its own copies (dm_env): a kept FIRST observation is not overwritten."""
+    env = _get_env(n_envs=2)
+    ts0 = env.reset()
+    kept = {k: v.clone() for k, v in ts0.observation.items()}
+    a = np.zeros((2,) + env.action_spec().shape)
+    a[:, -1] = 0.9  # sustain
+    env.physics.qpos[:, env.task.piano.joints[3]] = 0.05
+    env.step(a)
+    for k, v in kept.items():
+        assert torch.equal(ts0.observation[k], v), k
+
+
+def test_discarded_action_of_a_resetting_env_does_not_leak():
+    """The step that resets an env ignores its action: ctrl / sustain of the FIRST observation are 0."""
+    env = _get_env(n_envs=2)
+    env.reset()
+    env.request_reset(torch.tensor([False, True]))
+    a = np.full((2,) + env.action_spec().shape, 0.7)
+    ts = env.step(a)
+    assert ts.step_type.tolist() == [1, 0]
+    assert float(ts.observation["piano/sustain_state"][1]) == 0.0
+    assert float(ts.observation["piano/sustain_state"][0]) == 0.7
+    assert float(env.physics.ctrl[1].abs().max()) == 0.0
 
 
 def test_rewards_as_functions_of_state():
