@@ -176,10 +176,29 @@ class MidiFile:
             except (RuntimeError, IndexError, KeyError) as e:
                 raise RuntimeError(f"Could not parse MIDI file {filename}.") from e
         elif filename.suffix == ".proto":
-            raise ValueError("NoteSequence .proto files need note_seq, which is unavailable.")
+            # serialized note_seq NoteSequence (the PIG repertoire; fingering in note.part)
+            from robopianist_amd.music import note_seq_proto
+            with open(filename, "rb") as f:
+                try:
+                    seq = note_seq_proto.parse(f.read())
+                except ValueError as e:
+                    raise RuntimeError(f"Could not parse NoteSequence file {filename}.") from e
         else:
             raise ValueError(f"Unsupported file extension {filename.suffix}.")
         return cls(seq=seq)
+
+    def save(self, filename: Union[str, Path]) -> None:
+        """Saves the song as a serialized NoteSequence (`.proto`); midi_file.py:191-201.  Writing
+        Standard MIDI files is not implemented (nothing on the path consumes them)."""
+        filename = Path(filename)
+        if filename.suffix == ".proto":
+            from robopianist_amd.music import note_seq_proto
+            with open(filename, "wb") as f:
+                f.write(note_seq_proto.serialize(self.seq))
+        elif filename.suffix == ".mid":
+            raise NotImplementedError("writing .mid files is not supported; save as .proto")
+        else:
+            raise ValueError(f"Unsupported file extension {filename.suffix}.")
 
     def stretch(self, factor: float) -> "MidiFile":
         if factor <= 0:

@@ -153,3 +153,75 @@ def test_welded_bodies_are_fused_into_their_parent_links():
             np.testing.assert_allclose(got, want, atol=1e-14)
             checked += 1
     assert checked >= 2  # the fingertip capsules of the welded thumb distal segments
+
+
+# ---- pin of "the piano half is exact": the in-tree piano against what the REFERENCE's own builder
+# builds (tests/golden/piano_layout.json, produced by running robopianist/models/piano/piano_mjcf.py
+# against a recording mjcf stand-in: tests/golden/make_piano_golden.py)
+def _golden_piano():
+    import json, os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "piano_layout.json")))
+
+
+def test_piano_golden_is_current_when_the_reference_is_present():
+    import os, subprocess, sys
+    if not os.path.isdir(os.environ.get("RP_REFERENCE", "/root/reference")):
+        pytest.skip("reference checkout not present (GPU box)")
+    script = os.path.join(os.path.dirname(__file__), "golden", "make_piano_golden.py")
+    assert subprocess.run([sys.executable, script, "--check"]).returncode == 0
+
+
+def test_every_piano_constant_matches_the_reference():
+    g = _golden_piano()
+    ours = {k: v for k, v in vars(piano).items() if k.isupper()}
+    alias = {"WHITE_KEY_SPRINGREF": "KEY_SPRINGREF_DEG", "BLACK_KEY_SPRINGREF": "KEY_SPRINGREF_DEG",
+             "WHITE_KEY_STIFFNESS": "KEY_STIFFNESS", "BLACK_KEY_STIFFNESS": "KEY_STIFFNESS",
+             "WHITE_JOINT_DAMPING": "KEY_DAMPING", "BLACK_JOINT_DAMPING": "KEY_DAMPING",
+             "WHITE_JOINT_ARMATURE": "KEY_ARMATURE", "BLACK_JOINT_ARMATURE": "KEY_ARMATURE"}
+    cosmetic = {"WHITE_KEY_COLOR", "BLACK_KEY_COLOR", "BASE_COLOR", "ACTUATOR_DYNPRM", "ACTUATOR_GAINPRM"}
+    checked = 0
+    for name, ref in g["piano_constants"].items():
+        if name in cosmetic:
+            continue
+        mine = ours[alias.get(name, name)]
+        assert np.array_equal(np.asarray(mine, float), np.asarray(ref, float)), name   # bit-equal
+        checked += 1
+    assert checked >= 35
+    from robopianist_amd.music import constants as mconst
+    for name, ref in g["music_constants"].items():
+        assert getattr(mconst, name) == ref, name
+    assert mconst.NOTES == g["music_notes"]
+
+
+@pytest.mark.parametrize("actuated", [False, True])
+def test_compiled_piano_equals_the_reference_builders_output(actuated):
+    g = _golden_piano()["piano_with_actuators" if actuated else "piano"]
+    assert g["compiler"] == {"angle": "radian", "autolimits": True}
+    base, keys, acts = piano.build(add_actuators=actuated)
+    gb = g["bodies"]
+    assert len(gb) == 89 and gb[0]["name"] == "base"
+    assert np.array_equal(np.asarray(base.pos, float), np.asarray(gb[0]["pos"], float))
+    assert np.array_equal(np.asarray(base.geoms[0].size, float), np.asarray(gb[0]["geom"]["size"], float))
+    assert (base.geoms[0].contype, base.geoms[0].conaffinity) == (gb[0]["geom"]["contype"], gb[0]["geom"]["conaffinity"])
+    for k, (mine, ref) in enumerate(zip(keys, gb[1:])):
+        assert mine.name == "piano/" + ref["name"], k          # key id order == sorted body order
+        eq = lambda a, b: np.array_equal(np.asarray(a, float), np.asarray(b, float))
+        assert eq(mine.pos, ref["pos"]), (k, mine.pos, ref["pos"])
+        gm, gr = mine.geoms[0], ref["geom"]
+        assert gm.name == "piano/" + gr["name"] and gr["type"] == "box" and gm.type == spec.GEOM_BOX
+        assert eq(gm.size, gr["size"]) and gm.mass == gr["mass"]
+        assert (gm.contype, gm.conaffinity) == (gr["contype"], gr["conaffinity"])
+        jm, jr = mine.joints[0], ref["joint"]
+        assert jm.name == "piano/" + jr["name"] and jr["type"] == "hinge" and jm.type == spec.JNT_HINGE
+        for field in ("pos", "axis", "range"):
+            assert eq(getattr(jm, field), jr[field]), (k, field)
+        for field in ("stiffness", "springref", "damping", "armature"):
+            assert float(getattr(jm, field)) == float(jr[field]), (k, field)
+        assert mine.sites[0].name == "piano/" + ref["site"]["name"]
+    if actuated:
+        assert len(acts) == 88 == len(g["actuators"])
+        for am, ar in zip(acts, g["actuators"]):
+            assert am.name == "piano/" + ar["name"] and am.joint == "piano/" + ar["joint"]
+            assert ar["gaintype"] == "fixed" and ar["biastype"] == "none" and ar["dyntype"] == "none"
+            assert am.gain == ar["gainprm"][0] and tuple(am.bias) == tuple(float(x) for x in ar["biasprm"])
+            assert np.array_equal(np.asarray(am.ctrlrange, float), np.asarray(ar["ctrlrange"], float))

@@ -209,3 +209,92 @@ def test_goal_tables_from_arrays_defers_off_piano_notes_to_the_generic_path():
     assert midi_file.NoteTrajectory.goal_tables_from_arrays(m.note_arrays(), 0.05) is None
     with pytest.raises(ValueError):
         midi_file.NoteTrajectory.from_midi(m, 0.05)
+
+
+# ---------------------------------------------------------------- NoteSequence .proto files
+def _music_pb2_like():
+    """A google.protobuf message class for the NoteSequence subset, built at run time from the
+    field numbers note_seq_proto.py documents (no generated music_pb2 exists in this image)."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    fd = descriptor_pb2.FileDescriptorProto(name="rp_music_subset.proto", package="rp_test", syntax="proto3")
+    T = descriptor_pb2.FieldDescriptorProto
+
+    def msg(name, fields):
+        m = fd.message_type.add(name=name)
+        for fname, num, typ, rep, tname in fields:
+            f = m.field.add(name=fname, number=num, type=typ,
+                            label=T.LABEL_REPEATED if rep else T.LABEL_OPTIONAL)
+            if tname:
+                f.type_name = ".rp_test." + tname
+    msg("Note", [("pitch", 1, T.TYPE_INT32, 0, None), ("velocity", 2, T.TYPE_INT32, 0, None),
+                 ("start_time", 3, T.TYPE_DOUBLE, 0, None), ("end_time", 4, T.TYPE_DOUBLE, 0, None),
+                 ("instrument", 7, T.TYPE_INT32, 0, None), ("part", 10, T.TYPE_INT32, 0, None)])
+    msg("Tempo", [("time", 1, T.TYPE_DOUBLE, 0, None), ("qpm", 2, T.TYPE_DOUBLE, 0, None)])
+    msg("ControlChange", [("time", 1, T.TYPE_DOUBLE, 0, None), ("control_number", 2, T.TYPE_INT32, 0, None),
+                          ("control_value", 3, T.TYPE_INT32, 0, None)])
+    msg("SequenceMetadata", [("title", 1, T.TYPE_STRING, 0, None), ("artist", 2, T.TYPE_STRING, 0, None)])
+    msg("NoteSequence", [("id", 1, T.TYPE_STRING, 0, None), ("ticks_per_quarter", 4, T.TYPE_INT32, 0, None),
+                         ("tempos", 7, T.TYPE_MESSAGE, 1, "Tempo"), ("notes", 8, T.TYPE_MESSAGE, 1, "Note"),
+                         ("total_time", 9, T.TYPE_DOUBLE, 0, None),
+                         ("control_changes", 11, T.TYPE_MESSAGE, 1, "ControlChange"),
+                         ("sequence_metadata", 19, T.TYPE_MESSAGE, 0, "SequenceMetadata")])
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    return message_factory.GetMessageClass(pool.FindMessageTypeByName("rp_test.NoteSequence"))
+
+
+def test_note_sequence_proto_round_trip_and_wire_compatibility(tmp_path):
+    from robopianist_amd import music
+    from robopianist_amd.music import midi_file, note_seq_proto
+    song = music.load("TwinkleTwinkleRousseau")
+    path = tmp_path / "twinkle.proto"
+    song.save(path)
+    back = midi_file.MidiFile.from_file(path)
+    a, b = song.seq, back.seq
+    assert [(n.pitch, n.velocity, n.start_time, n.end_time, n.part) for n in a.notes] == \
+           [(n.pitch, n.velocity, n.start_time, n.end_time, n.part) for n in b.notes]
+    assert [(c.time, c.control_number, c.control_value) for c in a.control_changes] == \
+           [(c.time, c.control_number, c.control_value) for c in b.control_changes]
+    assert a.total_time == b.total_time and back.has_fingering()
+    assert (back.title, back.artist) == (song.title, song.artist)
+    # identical goal tables through the .proto detour
+    ta = midi_file.NoteTrajectory.from_midi(song, 0.05).to_goal_tables()
+    tb = midi_file.NoteTrajectory.from_midi(back, 0.05).to_goal_tables()
+    np.testing.assert_array_equal(ta[0], tb[0]); np.testing.assert_array_equal(ta[1], tb[1])
+    # google.protobuf parses what we write ...
+    NoteSequence = _music_pb2_like()
+    pb = NoteSequence()
+    pb.ParseFromString(path.read_bytes())
+    assert len(pb.notes) == len(a.notes) and pb.total_time == a.total_time
+    assert [(n.pitch, n.part, n.start_time) for n in pb.notes] == [(n.pitch, n.part, n.start_time) for n in a.notes]
+    assert pb.sequence_metadata.title == song.title
+    # ... and we parse what google.protobuf writes (incl. an unknown field, a negative int, defaults)
+    pb.id = "some/id"
+    pb.notes.add(pitch=60, velocity=0, start_time=0.0, end_time=1.5, part=-1, instrument=3)
+    ours = note_seq_proto.parse(pb.SerializeToString())
+    assert len(ours.notes) == len(a.notes) + 1
+    last = ours.notes[-1]
+    assert (last.pitch, last.velocity, last.start_time, last.end_time, last.part) == (60, 0, 0.0, 1.5, -1)
+    with pytest.raises(RuntimeError):
+        bad = tmp_path / "bad.proto"
+        bad.write_bytes(b"\x42\xff\xff")   # length-delimited field running past the end
+        midi_file.MidiFile.from_file(bad)
+
+
+def test_pig_directory_is_picked_up_from_the_environment(tmp_path):
+    """music/__init__.py:33-56: the repertoire names come from globbing *.proto files."""
+    import importlib, os, subprocess, sys
+    from robopianist_amd import music
+    d = tmp_path / "pig"
+    d.mkdir()
+    music.load("CMajorScaleTwoHands").save(d / "nocturne_op_9_no_2-1.proto")
+    music.load("TwinkleTwinkleRousseau").save(d / "golliwogg's_cakewalk-1.proto")
+    code = ("from robopianist_amd import music, suite\n"
+            "assert music.PIG_MIDIS == ['GolliwoggsCakewalk', 'NocturneOp9No2'], music.PIG_MIDIS\n"
+            "assert 'GolliwoggsCakewalk' in music.ETUDE_MIDIS\n"
+            "assert 'RoboPianist-repertoire-150-NocturneOp9No2-v0' in suite.ALL\n"
+            "m = music.load('NocturneOp9No2', stretch=1.0, shift=0)\n"
+            "assert m.n_notes == 30 and m.has_fingering()\n")
+    env = dict(os.environ, ROBOPIANIST_PIG_DIR=str(d))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, cwd=root)
