@@ -19,7 +19,8 @@ from robopianist_amd.model import compile as mcompile
 from robopianist_amd.model import engine_tables
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librp_engine.so")
+# RP_ENGINE_LIB selects another build of the same library (perf experiments: scratch/run_variants.py)
+LIB_PATH = os.environ.get("RP_ENGINE_LIB") or os.path.join(_HERE, "csrc", "librp_engine.so")
 
 # rp_field
 QPOS, QVEL, QACC_WARMSTART, CTRL, QFRC_APPLIED, ACT_FORCE, ACT_VELOCITY, SITE_XPOS, \

@@ -1,0 +1,83 @@
+"""bench.py's launcher contract (no GPU needed): `--gpus N` must never silently run fewer ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env=None, timeout=300):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=e, timeout=timeout, cwd=ROOT)
+
+
+def test_gpus_n_without_enough_devices_fails_loudly():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box really has two devices")
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 2
+    assert "--gpus 2 requested but only" in r.stderr
+    assert r.stdout.strip() == ""      # no JSON line that could be mistaken for a result
+
+
+def test_world_size_mismatch_is_an_error():
+    r = _run(["--gpus", "4", "--steps", "1"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_single_rank_without_a_device_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    r = _run(["--steps", "1", "--warmup", "0"])
+    assert r.returncode == 2 and "no HIP device" in r.stderr
+
+
+def test_config_definitions_follow_the_survey():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert {k: v["envs"] for k, v in bench.CONFIGS.items()} == {2: 4096, 3: 4096, 4: 8192, 5: 2048}
+    assert bench.algo_bytes_per_mj_step(140, 44, 64) == 7072 and bench.algo_bytes_per_mj_step(140, 44, 32) == 3536
+    bank = bench.mixed_song_bank(150)
+    assert len(bank) == 150
+    from robopianist_amd.music import midi_file
+    tables = {midi_file.NoteTrajectory.from_midi(m, 0.05).to_goal_tables()[0].tobytes() for m in bank}
+    assert len(tables) >= 140   # (distinct goal tables; a few stretch / shift draws may coincide)
+
+
+@pytest.mark.gpu
+def test_bench_spawns_two_ranks_on_one_gpu():
+    """`--gpus 2` outside torchrun starts two ranks (here both on cuda:0 over gloo) and reports n_gpus = 2."""
+    r = _run(["--gpus", "2", "--same-device", "--dist-backend", "gloo", "--envs", "64", "--steps", "12", "--warmup", "2",
+              "--config", "3", "--no-cpu-baseline"], timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["trajectory_gather"] is True
+    assert out["config"]["simulated_env_steps"] == 2 * 64 * 12 and out["value"] > 0
+    assert out["sanity"]["finite"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", [2, 3, 4, 5])
+def test_bench_configs_emit_the_contract_line(config):
+    r = _run(["--config", str(config), "--envs", "128", "--steps", "6", "--warmup", "1", "--aux-fp32", "0",
+              "--host-io", "0", "--no-cpu-baseline"], timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in out
+    assert out["config"]["baseline_config"] == config and out["dtype"] == "f64" and out["n_gpus"] == 1
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["kernel_launches_sampled"] >= 1
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["algorithmic_bytes_per_launch"] == 7072 * 128

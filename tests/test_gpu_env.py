@@ -737,3 +737,75 @@ def test_build_self_check_runs_once_and_passes(two_hand_scene, capfd, monkeypatc
     assert dq < 2e-6
     engine.BatchedPhysics(si.model, si.key_joint_ids, n_envs=3)   # cached: no second run
     assert "rp self-check" not in capfd.readouterr().out
+
+
+def test_ot_fingering_reward_on_device_matches_scipy():
+    """include/rp_task.h use_fingering = 2: the optimal-transport fingering term
+    (piano_with_shadow_hands.py:333-369) as a wave-per-env assignment kernel against the host
+    definition (scipy.optimize.linear_sum_assignment per env), incl. more keys than fingers, one
+    key, no key, and through the fused advance on a rollout."""
+    from robopianist_amd import suite
+    from robopianist_amd.wrappers import CanonicalSpecWrapper
+    name = "RoboPianist-debug-CMajorChordProgressionTwoHands-v0"
+    E = 64
+    env = CanonicalSpecWrapper(suite.load(
+        name, seed=5, n_envs=E, precision=64,
+        task_kwargs=dict(control_timestep=0.05, gravity_compensation=True, primitive_fingertip_collisions=True,
+                         disable_fingering_reward=True)))
+    task = env.task
+    assert "ot_fingering_reward" in task.reward_fn.reward_fns
+    env.reset()
+    rng = np.random.RandomState(0)
+    dev = env.physics.device
+    A = env.action_spec().shape[0]
+    # (1) through the rollout: fused advance vs the host definition on the same state
+    for t in range(12):
+        ts = env.step(torch.as_tensor(rng.uniform(-1, 1, size=(E, A)), device=dev))
+        assert task._fused_advance is not None
+        fused = task.reward_fn.reward_terms["ot_fingering_reward"].clone()
+        ref = task._compute_ot_fingering_reward(env.physics)
+        np.testing.assert_allclose(_np(fused), _np(ref), rtol=0, atol=1e-12, err_msg=str(t))
+    # (2) synthetic goal sets of every size 0..30 keys, random key states / hand poses
+    fr = task._fused_rewards_for(env.physics)
+    sizes = [0, 1, 2, 3, 5, 9, 10, 11, 12, 17, 30, 88]
+    for trial in range(3):
+        goal = torch.zeros((E, 89), device=dev, dtype=torch.float64)
+        for e in range(E):
+            k = sizes[(e + trial) % len(sizes)]
+            idx = rng.choice(88, size=k, replace=False)
+            goal[e, torch.as_tensor(idx, device=dev, dtype=torch.long)] = 1.0
+        task._goal_current.copy_(goal)
+        env.step(torch.as_tensor(rng.uniform(-1, 1, size=(E, A)), device=dev))  # new hand poses
+        task._goal_current.copy_(goal)
+        total, terms = fr.compute(goal_current=task._goal_current, key_norm_state=task.piano.normalized_state,
+                                  key_activation=task.piano.activation, sustain_activation=task.piano.sustain_activation,
+                                  finger_current=task._finger_current)
+        ref = task._compute_ot_fingering_reward(env.physics)
+        np.testing.assert_allclose(_np(terms[3]), _np(ref), rtol=0, atol=1e-12)
+        assert float(ref[goal[:, :88].sum(1) == 0].min()) == 1.0 if bool((goal[:, :88].sum(1) == 0).any()) else True
+
+
+def test_capacity_overflow_ends_the_episode():
+    """An engine capacity overflow (RP_WARN_CONTACT_FULL etc.) ends the episode with reward 0 /
+    discount 0 like a diverged state, on the fused path and on the torch hooks alike; with
+    overflow_termination=False the env steps on (round-1 behaviour)."""
+    from robopianist_amd import engine
+    fused, ref = _load_pair(4, 64)
+    loose, _ = _load_pair(4, 64, overflow_termination=False)
+    dev = fused.physics.device
+    A = fused.action_spec().shape[0]
+    a = torch.zeros((4, A), device=dev, dtype=torch.float64)
+    for env in (fused, ref, loose):
+        env.reset()
+        env.step(a)
+        env.physics.warn[2] |= engine.WARN_CONTACT_FULL      # as the position stage would raise it
+        env.physics.warn[3] |= engine.WARN_HESSIAN           # not fatal: a clamped pivot is reported only
+    ts_f, ts_r, ts_l = fused.step(a), ref.step(a), loose.step(a)
+    for ts in (ts_f, ts_r):
+        assert ts.step_type.tolist() == [1, 1, 2, 1]
+        assert float(ts.reward[2]) == 0.0 and float(ts.discount[2]) == 0.0
+    assert ts_l.step_type.tolist() == [1, 1, 1, 1]
+    assert fused.task.overflow_terminations() == 1 and ref.task.overflow_terminations() == 1
+    ts_f = fused.step(a)
+    assert ts_f.step_type.tolist() == [1, 1, 0, 1]          # auto-reset clears the flag
+    assert int(fused.physics.warn[2]) == 0

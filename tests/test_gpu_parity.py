@@ -297,3 +297,40 @@ def test_lazy_position_stage_is_bit_identical(two_hand_scene):
 def torch_i32(x):
     import torch
     return torch.as_tensor(np.asarray(x, np.int32), device="cuda")
+
+
+# ---- BASELINE configs 3 and 4: the random policy's own trajectory, teacher forced ---------------
+def _random_policy_ctrl(m, n_control_steps, seed=12345, substeps=10):
+    """bench.py --config 3/4: a ~ U(spec.min, spec.max) per control step, held for 10 mj_steps."""
+    rng = np.random.default_rng(seed)
+    lo, hi = m.actuator_ctrlrange[:, 0], m.actuator_ctrlrange[:, 1]
+    a = lo + rng.uniform(0.0, 1.0, size=(n_control_steps, m.nu)) * (hi - lo)
+    return np.repeat(a, substeps, axis=0)
+
+
+@pytest.mark.parametrize("config", [3, 4])
+def test_teacher_forced_fp64_along_the_random_policy_trajectory(two_hand_scene, config):
+    """Per-step parity (1e-9, same contact counts) along the trajectory the CPU oracle follows under
+    the uniformly random policy of BASELINE configs 3 / 4 (same model and ctrl distribution; the
+    songs only differ in the goal tables, which do not enter the physics): 400 mj_steps of flailing
+    hands, hand-hand and finger-key contacts."""
+    ctrl = _random_policy_ctrl(two_hand_scene.model, 40, seed=12345 + (0 if config == 3 else 4))
+    worst, maxcon = teacher_forced(two_hand_scene, 64, ctrl)
+    print(f"config {config}: fp64 teacher-forced along the random-policy trajectory: worst rel dv {worst:.2e}, "
+          f"max contacts {maxcon}")
+    assert maxcon >= 3
+    assert worst < 1e-9
+
+
+def test_replay_teacher_forced_fp64(two_hand_scene):
+    """The scripted Twinkle replay (BASELINE config 2), teacher forced along the oracle's own
+    trajectory for 1000 mj_steps: the per-step discrepancy, free of the trajectory's chaotic
+    amplification -- the robust companion of the free-running 1e-4 check."""
+    import os
+    a = np.load(os.path.join(os.path.dirname(__file__), "golden", "twinkle_twinkle_actions.npy")).astype(np.float64)
+    m = two_hand_scene.model
+    lo, hi = m.actuator_ctrlrange[:, 0], m.actuator_ctrlrange[:, 1]
+    ctrl = np.repeat(lo + (np.clip(a[:100, :-1], -1, 1) + 1.0) * 0.5 * (hi - lo), 10, axis=0)
+    worst, maxcon = teacher_forced(two_hand_scene, 64, ctrl)
+    print(f"replay: fp64 teacher-forced worst rel dv {worst:.2e}, max contacts {maxcon}")
+    assert worst < 1e-9
