@@ -49,9 +49,15 @@ typedef enum {
   RP_CONTACT_DIST = 13, /* [E][RP_MAX_CONTACTS] */
   RP_TREE_OFFSET = 14,  /* [E][ntree][3] per-env root-body translation (hand.shift_pose,
                            piano_with_shadow_hands.py:491-499) */
-  RP_ACTIVE = 15        /* [E] int32, write-only: envs with 0 are skipped by rp_step/rp_forward
+  RP_ACTIVE = 15,       /* [E] int32, write-only: envs with 0 are skipped by rp_step/rp_forward
                            (rp_set(RP_ACTIVE, NULL) re-enables all).  Needed because dm_env's
                            step-after-LAST is a reset, not a physics step. */
+  RP_SENSOR_TORQUE = 16,/* [E][nv]    `torque` sensors at every hand joint's body origin projected on the
+                           joint axis = the `joints_torque` observable  shadow_hand.py:209-226, hands/base.py:101-109
+                           (key dofs: 0).  Needs rp_set_acc_sensors(e, 1). */
+  RP_SENSOR_TOUCH = 17  /* [E][nsite] `touch` sensors (sum of the normal forces of the contacts whose force ray
+                           hits the site's sphere), non-zero for the fingertip sites = the `fingertip_force`
+                           observable  shadow_hand.py:248-270,425-432.  Needs rp_set_acc_sensors(e, 1). */
 } rp_field;
 
 #define RP_MAX_CONTACTS 32
@@ -107,6 +113,19 @@ int rp_set_solver_tolerance(rp_engine* e, double tolerance, double ls_tolerance)
  * rp_field_ptr views: a caller that writes state through a view must call rp_forward (or rp_set)
  * before the next rp_step.  Default: off.  Results are bit-identical either way. */
 int rp_set_lazy_position_stage(rp_engine* e, int on);
+/* Cost-ordered launch: every stage kernel processes the envs in descending order of what their last
+ * solver stage needed (Newton iterations x coupled rows, contact count), re-sorted on the device after
+ * every solver stage (longest-processing-time-first).  One wave steps one env and a SIMD runs its
+ * envs one after the other, so in a heterogeneous batch (random policies, envs at different episode
+ * times) a heavy env that happens to start last is the tail of the whole launch.  Results are
+ * bit-identical either way (envs are independent); default: off. */
+int rp_set_cost_ordered_launch(rp_engine* e, int on);
+/* Acceleration-stage sensors (mj_sensorAcc: `torque`, `touch`).  When on, the last substep of every
+ * rp_step is followed by one extra launch (the sensor stage: position / velocity stage of the state
+ * before that substep's Euler step + mj_rnePostConstraint), which fills RP_SENSOR_TORQUE and
+ * RP_SENSOR_TOUCH with the values MuJoCo's sensordata holds after the step.  Default: off (the task's
+ * default observables and rewards do not read them). */
+int rp_set_acc_sensors(rp_engine* e, int on);
 int rp_sync(rp_engine* e);
 int rp_get_stream(rp_engine* e, void** hip_stream);
 /* Makes the engine enqueue on a caller-owned HIP stream (e.g. PyTorch's current stream),

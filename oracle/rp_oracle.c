@@ -78,6 +78,7 @@ struct rpo_model {
       *geom_solref, *geom_solimp, *geom_solmix, *geom_margin, *geom_gap;
   const int32_t* site_bodyid;
   const double* site_pos;
+  const double* site_touch_radius; /* > 0: the site is the zone of a touch sensor (sphere); may be NULL */
   const int32_t *tendon_adr, *tendon_num, *wrap_objid;
   const double* wrap_prm;
   const int32_t *actuator_trntype, *actuator_trnid, *actuator_ctrllimited,
@@ -153,7 +154,10 @@ rpo_model* rpo_model_load(const void* blob, size_t nbytes) {
     m->geom_solimp = BF("geom_solimp"); m->geom_solmix = BF("geom_solmix");
     m->geom_margin = BF("geom_margin"); m->geom_gap = BF("geom_gap");
   }
-  if (m->nsite) { m->site_bodyid = BI("site_bodyid"); m->site_pos = BF("site_pos"); }
+  if (m->nsite) {
+    m->site_bodyid = BI("site_bodyid"); m->site_pos = BF("site_pos");
+    m->site_touch_radius = blob_find(m, "site_touch_radius") ? BF("site_touch_radius") : NULL;
+  }
   if (m->ntendon) {
     m->tendon_adr = BI("tendon_adr"); m->tendon_num = BI("tendon_num");
     m->wrap_objid = BI("wrap_objid"); m->wrap_prm = BF("wrap_prm");
@@ -211,6 +215,9 @@ struct rpo_data {
   double *Ma, *grad, *Mgrad, *search, *Mv, *H, *tmp;
   int* act_idx;
   int solver_iter, warnings;
+  /* acceleration-stage sensors [MJ: mj_rnePostConstraint, mj_sensorAcc] */
+  int first_con_row;
+  double *cfrc_ext, *cfrc_int, *cacc_post, *sens_torque, *sens_touch;
 };
 
 static double* dalloc(size_t n) { return (double*)calloc(n ? n : 1, sizeof(double)); }
@@ -252,6 +259,8 @@ rpo_data* rpo_data_new(const rpo_model* m) {
   d->Ma = dalloc(nv); d->grad = dalloc(nv); d->Mgrad = dalloc(nv); d->search = dalloc(nv);
   d->Mv = dalloc(nv); d->H = dalloc((size_t)nv * nv); d->tmp = dalloc(nv);
   d->act_idx = (int*)calloc(nv ? nv : 1, sizeof(int));
+  d->cfrc_ext = dalloc(6 * nb); d->cfrc_int = dalloc(6 * nb); d->cacc_post = dalloc(6 * nb);
+  d->sens_torque = dalloc(nv); d->sens_touch = dalloc(m->nsite);
   return d;
 }
 
@@ -266,7 +275,8 @@ void rpo_data_free(rpo_data* d) {
     &d->qfrc_constraint, &d->qacc_smooth, &d->contact_out, &d->efc_J, &d->efc_pos,
     &d->efc_margin, &d->efc_floss, &d->efc_diagApprox, &d->efc_K, &d->efc_B, &d->efc_imp,
     &d->efc_D, &d->efc_R, &d->efc_vel, &d->efc_aref, &d->efc_force, &d->efc_jar, &d->efc_jv,
-    &d->Ma, &d->grad, &d->Mgrad, &d->search, &d->Mv, &d->H, &d->tmp};
+    &d->Ma, &d->grad, &d->Mgrad, &d->search, &d->Mv, &d->H, &d->tmp,
+    &d->cfrc_ext, &d->cfrc_int, &d->cacc_post, &d->sens_torque, &d->sens_touch};
   for (size_t i = 0; i < sizeof(ps) / sizeof(ps[0]); i++) free(*ps[i]);
   free(d->contact); free(d->efc_type); free(d->efc_state); free(d->act_idx);
   free(d);
@@ -795,6 +805,7 @@ static void make_constraint(const rpo_model* m, rpo_data* d) {
     }
   }
   free(jd);
+  d->first_con_row = first_con_row;
   d->nefc = ne;
   /* R, D  [MJ: mj_makeImpedance]; pyramidal rows share Rpy = 2 mu^2 R(first row) */
   for (int i = 0; i < ne; i++) {
@@ -1141,6 +1152,85 @@ static void step1(const rpo_model* m, rpo_data* d) { /* position + velocity */
   rne(m, d);
 }
 
+/* ------------------------------------------------ acceleration-stage sensors
+ * [MJ: mj_rnePostConstraint + mj_sensorAcc, the two sensor types the hands declare at
+ * robopianist/models/hands/shadow_hand.py:209-226 (torque) and :248-270 (touch)].
+ *   cfrc_ext : contact forces on each body, as spatial force about the tree's subtree_com;
+ *   cfrc_int : interaction force between a body and its parent = sum over the subtree of
+ *              (I cacc + cvel x* I cvel - cfrc_ext), cacc from the CONSTRAINED qacc;
+ *   torque sensor of joint j (a site at the origin of the joint's body, shadow_hand.py:211-219):
+ *              cfrc_int of that body moved to the body origin, rotated into the body frame; the
+ *              observable projects it on the joint axis (hands/base.py:101-109), so the oracle
+ *              reports sens_torque[j] = (xmat_b jnt_axis_j) . torque directly;
+ *   touch sensor of a site: sum of the normal forces of the contacts of the site's body whose
+ *              force ray from the contact point hits the site's sphere. */
+static void sensor_acc(const rpo_model* m, rpo_data* d) {
+  int nb = m->nbody, nv = m->nv;
+  memset(d->cfrc_ext, 0, sizeof(double) * 6 * nb);
+  memset(d->sens_touch, 0, sizeof(double) * (m->nsite ? m->nsite : 1));
+  for (int ic = 0; ic < d->ncon; ic++) {
+    const contact_t* c = d->contact + ic;
+    const double* f = d->efc_force + d->first_con_row + 4*ic;
+    /* [MJ: mju_decodePyramid] */
+    double fn = f[0] + f[1] + f[2] + f[3];
+    double f1 = c->friction[0] * (f[0] - f[1]), f2 = c->friction[1] * (f[2] - f[3]);
+    double F[3];
+    for (int k = 0; k < 3; k++) F[k] = fn*c->frame[k] + f1*c->frame[3+k] + f2*c->frame[6+k];
+    int body[2] = {m->geom_bodyid[c->geom1], m->geom_bodyid[c->geom2]};
+    for (int side = 0; side < 2; side++) {  /* the force acts on geom2's body, its reaction on geom1's */
+      int b = body[side];
+      if (b == 0) continue;
+      double sg = side ? 1.0 : -1.0;
+      const double* ref = d->subtree_com + 3*m->body_rootid[b];
+      double r[3] = {c->pos[0]-ref[0], c->pos[1]-ref[1], c->pos[2]-ref[2]}, t[3];
+      cross3(t, r, F);
+      for (int k = 0; k < 3; k++) { d->cfrc_ext[6*b+k] += sg*t[k]; d->cfrc_ext[6*b+3+k] += sg*F[k]; }
+    }
+    if (fn <= 0 || !m->site_touch_radius) continue;
+    for (int s = 0; s < m->nsite; s++) {
+      double rad = m->site_touch_radius[s];
+      int sb = m->site_bodyid[s];
+      if (rad <= 0 || (sb != body[0] && sb != body[1])) continue;
+      /* ray from the contact point along the normal force (flipped when the sensor is on body 2)
+       * against the sphere [MJ: mju_rayGeom, sphere] */
+      double sg = (sb == body[1]) ? -1.0 : 1.0;
+      double o[3] = {c->pos[0]-d->site_xpos[3*s], c->pos[1]-d->site_xpos[3*s+1], c->pos[2]-d->site_xpos[3*s+2]};
+      double bq = sg * dot3(o, c->frame), cq = dot3(o, o) - rad*rad;
+      double det = bq*bq - cq;
+      if (det < 1e-15) continue;
+      if (-bq + sqrt(det) >= 0) d->sens_touch[s] += fn;
+    }
+  }
+  for (int k = 0; k < 3; k++) { d->cacc_post[k] = 0; d->cacc_post[3+k] = -m->gravity[k]; }
+  memset(d->cfrc_int, 0, sizeof(double) * 6);
+  for (int b = 1; b < nb; b++) {
+    double ca[6];
+    memcpy(ca, d->cacc_post + 6*m->body_parentid[b], sizeof ca);
+    for (int j = m->body_jntadr[b]; j < m->body_jntadr[b] + m->body_jntnum[b]; j++)
+      for (int k = 0; k < 6; k++) ca[k] += d->cdof_dot[6*j+k] * d->qvel[j] + d->cdof[6*j+k] * d->qacc[j];
+    memcpy(d->cacc_post + 6*b, ca, sizeof ca);
+    double f1[6], iv[6], f2[6];
+    mul_inert(f1, d->cinert + 10*b, ca);
+    mul_inert(iv, d->cinert + 10*b, d->cvel + 6*b);
+    cross_force(f2, d->cvel + 6*b, iv);
+    for (int k = 0; k < 6; k++) d->cfrc_int[6*b+k] = f1[k] + f2[k] - d->cfrc_ext[6*b+k];
+  }
+  for (int b = nb - 1; b >= 1; b--) {
+    int p = m->body_parentid[b];
+    if (p > 0) for (int k = 0; k < 6; k++) d->cfrc_int[6*p+k] += d->cfrc_int[6*b+k];
+  }
+  for (int j = 0; j < nv; j++) {
+    int b = m->jnt_bodyid[j];
+    const double* ref = d->subtree_com + 3*m->body_rootid[b];
+    const double* fi = d->cfrc_int + 6*b;
+    /* moment about the body origin: M_p = M_ref + (ref - p) x F  [MJ: mju_transformSpatial, force] */
+    double r[3] = {ref[0]-d->xpos[3*b], ref[1]-d->xpos[3*b+1], ref[2]-d->xpos[3*b+2]}, t[3], ax[3];
+    cross3(t, r, fi + 3);
+    mat_vec(ax, d->xmat + 9*b, m->jnt_axis + 3*j);
+    d->sens_torque[j] = (fi[0]+t[0])*ax[0] + (fi[1]+t[1])*ax[1] + (fi[2]+t[2])*ax[2];
+  }
+}
+
 static void acceleration_stage(const rpo_model* m, rpo_data* d) {
   int nv = m->nv;
   actuation(m, d);
@@ -1150,6 +1240,7 @@ static void acceleration_stage(const rpo_model* m, rpo_data* d) {
   solve_ld(m, d->qLD, d->qacc_smooth);
   solve_newton(m, d);
   memcpy(d->qacc_warmstart, d->qacc, sizeof(double)*nv);
+  sensor_acc(m, d);
 }
 
 static void euler(const rpo_model* m, rpo_data* d) {
@@ -1213,6 +1304,10 @@ double* rpo_get_ptr(const rpo_model* m, rpo_data* d, int field) {
       return d->contact_out;
     case RPO_TIME: return &d->time;
     case RPO_BODY_POS: return ((rpo_model*)m)->body_pos;
+    case RPO_SENSOR_TORQUE: return d->sens_torque;
+    case RPO_SENSOR_TOUCH: return d->sens_touch;
+    case RPO_CFRC_INT: return d->cfrc_int;
+    case RPO_SUBTREE_COM: return d->subtree_com;
   }
   return NULL;
 }

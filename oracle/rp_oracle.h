@@ -39,7 +39,10 @@ enum {
   RPO_QFRC_SMOOTH, RPO_QACC_SMOOTH, RPO_QFRC_CONSTRAINT,
   RPO_EFC_FORCE, RPO_EFC_AREF, RPO_EFC_D, RPO_EFC_POS, RPO_EFC_J,
   RPO_CONTACT /* ncon * 16: dist,pos[3],frame[9],geom1,geom2,mu */,
-  RPO_TIME, RPO_BODY_POS /* model, writable: nbody*3 */
+  RPO_TIME, RPO_BODY_POS /* model, writable: nbody*3 */,
+  RPO_SENSOR_TORQUE /* nv: joint-axis projection of the torque sensor at each joint's body origin */,
+  RPO_SENSOR_TOUCH /* nsite: touch sensor reading of the sites with site_touch_radius > 0 */,
+  RPO_CFRC_INT /* nbody*6 */, RPO_SUBTREE_COM /* nbody*3 */
 };
 
 rpo_model* rpo_model_load(const void* blob, size_t nbytes);

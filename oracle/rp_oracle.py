@@ -21,7 +21,7 @@ FIELDS = dict(
     geom_xpos=11, geom_xmat=12, site_xpos=13, qM=14, qfrc_bias=15, qfrc_passive=16,
     qfrc_actuator=17, qfrc_smooth=18, qacc_smooth=19, qfrc_constraint=20,
     efc_force=21, efc_aref=22, efc_D=23, efc_pos=24, efc_J=25, contact=26, time=27,
-    body_pos=28,
+    body_pos=28, sensor_torque=29, sensor_touch=30, cfrc_int=31, subtree_com=32,
 )
 
 
@@ -93,7 +93,8 @@ class Oracle:
             qfrc_smooth=m.nv, qacc_smooth=m.nv, qfrc_constraint=m.nv,
             efc_force=self.nefc, efc_aref=self.nefc, efc_D=self.nefc,
             efc_pos=self.nefc, efc_J=self.nefc * m.nv, contact=16 * self.ncon, time=1,
-            body_pos=3 * m.nbody,
+            body_pos=3 * m.nbody, sensor_torque=m.nv, sensor_touch=m.nsite, cfrc_int=6 * m.nbody,
+            subtree_com=3 * m.nbody,
         )[name]
 
     def view(self, name) -> np.ndarray:

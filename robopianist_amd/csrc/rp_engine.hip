@@ -28,6 +28,34 @@ __global__ void rp_mark_valid_kernel(unsigned char* valid, const int* active, in
   if (e < n && (!active || active[e] != 0)) valid[e] = 1;
 }
 
+// Launch order of the envs for the next stage kernels: descending predicted cost (counting sort on
+// a small integer key), one workgroup of 1024 threads.  Predictor = what the env needed in its last
+// solver stage: Newton iterations x (rows of the dense block + touched keys + a constant), plus its
+// contact count (the position stage's cost).  Inactive envs go last.
+#define RP_ORDER_BUCKETS 512
+__global__ __launch_bounds__(1024) void rp_order_kernel(int* order, const int* solver_iter, const int* ncon,
+                                                        const int* active, int n) {
+  __shared__ int hist[RP_ORDER_BUCKETS];
+  __shared__ int base[RP_ORDER_BUCKETS];
+  for (int i = threadIdx.x; i < RP_ORDER_BUCKETS; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  auto key_of = [&](int e) -> int {
+    if (active && active[e] == 0) return 0;
+    const int si = solver_iter[e];
+    const int it = si & 255, nd = (si >> 8) & 255, nk = (si >> 16) & 255;
+    int k = 1 + it * (6 + (nd >> 1) + nk) + ncon[e];
+    return k < RP_ORDER_BUCKETS ? k : RP_ORDER_BUCKETS - 1;
+  };
+  for (int e = threadIdx.x; e < n; e += blockDim.x) atomicAdd(&hist[key_of(e)], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {  // descending: the largest key first
+    int acc = 0;
+    for (int b = RP_ORDER_BUCKETS - 1; b >= 0; b--) { base[b] = acc; acc += hist[b]; }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n; e += blockDim.x) order[atomicAdd(&base[key_of(e)], 1)] = e;
+}
+
 thread_local std::string g_err;
 int fail(const std::string& s) { g_err = s; return -1; }
 #define HIP_OK(x)                                                                  \
@@ -109,6 +137,8 @@ struct EngineBase {
   virtual void limits(int newton, int ls) = 0;
   virtual void tolerances(double tol, double ls_tol) = 0;
   bool lazy_position = false;
+  bool cost_order = false;   // rp_set_cost_ordered_launch
+  virtual int acc_sensors(int on) = 0;
   virtual int field_ptr(rp_field f, void** p, size_t* bytes) = 0;
   bool own_stream = true;
   virtual int profile(long long* out, int n, int enable) = 0;
@@ -263,6 +293,8 @@ struct Engine : EngineBase {
     PF(act_coef, "eng_act_coef"); PF(act_gain, "eng_act_gain"); PF(act_bias, "eng_act_bias");
     PF(act_ctrlrange, "eng_act_ctrlrange"); PF(act_forcerange, "eng_act_forcerange");
     PI(site_link, "eng_site_link"); PF(site_pos, "eng_site_pos");
+    if (b.has("eng_site_touch_radius")) PF(site_touch_radius, "eng_site_touch_radius");
+    if (b.has("eng_link_bodylink")) PI(link_bodylink, "eng_link_bodylink");
 #undef PF
 #undef PI
     M.ft = upF(ft);
@@ -305,6 +337,7 @@ struct Engine : EngineBase {
     d_active = dalloc<int>(E);
     S.active = nullptr;
     d_lead = dalloc<int>(E);
+    d_order = dalloc<int>(E);
     d_valid = dalloc<unsigned char>(E);  // (zero-filled: nothing is valid yet)
     S.max_newton = M.iterations; S.max_ls = M.ls_iterations;
     // The fills and uploads above went through the null stream, which is NOT ordered with the
@@ -314,6 +347,26 @@ struct Engine : EngineBase {
 
   long long* d_prof = nullptr;
   int* d_active = nullptr;
+  int* d_order = nullptr;           // cost-ordered launch: workgroup -> env
+  // acceleration-stage sensors (rp_set_acc_sensors): state before the last Euler step, outputs
+  bool sensors_on = false;
+  T *d_qpos_prev = nullptr, *d_qvel_prev = nullptr, *d_con_force = nullptr, *d_sens_torque = nullptr,
+    *d_sens_touch = nullptr;
+  int acc_sensors(int on) override {
+    if (on && !d_qpos_prev) {
+      HIP_OK(hipSetDevice(device));
+      try {
+        size_t E = (size_t)nenv;
+        d_qpos_prev = dalloc<T>(E * nv); d_qvel_prev = dalloc<T>(E * nv);
+        d_con_force = dalloc<T>(E * RPK_NC * 4);
+        d_sens_torque = dalloc<T>(E * nv); d_sens_touch = dalloc<T>(E * (nsite ? nsite : 1));
+      } catch (const std::string& s) { return fail("rp_set_acc_sensors: " + s); }
+      HIP_OK(hipDeviceSynchronize());  // (null-stream fills vs the engine's stream)
+    }
+    sensors_on = on != 0;
+    S.con_force = sensors_on ? d_con_force : nullptr;
+    return 0;
+  }
   int* d_lead = nullptr;            // lazy position stage: active && !valid
   unsigned char* d_valid = nullptr; // hand-over of env e matches its state
   int profile(long long* out, int n, int enable) override {
@@ -381,12 +434,14 @@ struct Engine : EngineBase {
       case RP_CONTACT_DIST: *p = S.contact_dist; *bytes = sizeof(T) * E * RPK_NCOUT; return true;
       case RP_ACTIVE: *p = d_active; *bytes = sizeof(int) * E; *writable = true; return true;
       case RP_TREE_OFFSET: *p = S.tree_offset; *bytes = sizeof(T) * E * ntree * 3; *writable = true; return true;
+      case RP_SENSOR_TORQUE: if (!d_sens_torque) return false; *p = d_sens_torque; *bytes = sizeof(T) * E * nv; return true;
+      case RP_SENSOR_TOUCH: if (!d_sens_touch) return false; *p = d_sens_touch; *bytes = sizeof(T) * E * nsite; return true;
     }
     return false;
   }
   int field_ptr(rp_field f, void** p, size_t* bytes) override {
     bool w;
-    if (!field(f, p, bytes, &w)) return fail("rp_field_ptr: unknown field");
+    if (!field(f, p, bytes, &w)) return fail("rp_field_ptr: unknown field (sensor fields need rp_set_acc_sensors first)");
     if (f == RP_ACTIVE) S.active = d_active;  // a caller that maps the mask uses it
     return 0;
   }
@@ -452,6 +507,11 @@ struct Engine : EngineBase {
     // order.  Two small kernels per substep instead of one fused launch: each half fits in
     // registers, and the hand-over (RpStage) stays in L2 / Infinity Cache.
     const int hb = (nenv + 255) / 256;
+    // cost-ordered launch: heaviest envs (by what their last solver stage needed) first
+    auto reorder = [&]() {
+      hipLaunchKernelGGL(rp_order_kernel, dim3(1), dim3(1024), 0, stream, d_order, S.solver_iter, S.ncon, s.active, nenv);
+    };
+    if (cost_order && mode == 0) { reorder(); s.order = d_order; }
     if (lazy_position && mode == 0) {
       // skip the leading stage for envs whose hand-over is still the one of their current state
       RpState<T> lead = s;
@@ -464,11 +524,26 @@ struct Engine : EngineBase {
     if (mode == 0) {
       for (int k = 0; k < nsub; k++) {
         const bool probe = timeit && k == (int)(step_calls % (unsigned)nsub);
+        const bool sense = sensors_on && k == nsub - 1;
+        if (sense) {  // the state this substep's forces belong to (the solver stage integrates in place)
+          HIP_OK(hipMemcpyAsync(d_qpos_prev, S.qpos, sizeof(T) * (size_t)nenv * nv, hipMemcpyDeviceToDevice, stream));
+          HIP_OK(hipMemcpyAsync(d_qvel_prev, S.qvel, sizeof(T) * (size_t)nenv * nv, hipMemcpyDeviceToDevice, stream));
+        }
         if (probe) HIP_OK(hipEventRecord(sv0[slot], stream));
         // solver stage; the build specialised for "every tree has a 4-link trunk" when it applies
         if (trunk4) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 4>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
         else hipLaunchKernelGGL((rp_stage_kernel<T, 1>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
         if (probe) HIP_OK(hipEventRecord(sv1[slot], stream));
+        if (sense) {
+          // sensor stage: position / velocity stage of the saved state + mj_rnePostConstraint with the
+          // constrained qacc (S.warm) and the contact row forces the solver stage just stored
+          RpState<T> ss = s;
+          ss.qpos = d_qpos_prev; ss.qvel = d_qvel_prev;
+          ss.sens_torque = d_sens_torque; ss.sens_touch = d_sens_touch;
+          ss.key_trace = nullptr; ss.prof = nullptr;
+          hipLaunchKernelGGL((rp_stage_kernel<T, 2>), dim3(nenv), dim3(64), 0, stream, M, ss, B, -1, nsub);
+        }
+        if (cost_order && k + 1 < nsub) reorder();
         hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
       }
     }
@@ -554,6 +629,12 @@ int rp_set_solver_tolerance(rp_engine* e, double tolerance, double ls_tolerance)
 int rp_set_lazy_position_stage(rp_engine* e, int on) {
   if (!e) return fail("null engine");
   E(e)->lazy_position = on != 0;
+  return 0;
+}
+int rp_set_acc_sensors(rp_engine* e, int on) { return e ? E(e)->acc_sensors(on) : fail("null engine"); }
+int rp_set_cost_ordered_launch(rp_engine* e, int on) {
+  if (!e) return fail("null engine");
+  E(e)->cost_order = on != 0;
   return 0;
 }
 int rp_sync(rp_engine* e) {

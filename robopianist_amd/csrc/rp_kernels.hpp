@@ -57,6 +57,13 @@ struct Smem<T, 0> : SmemShared<T> {
   T keyvec[1][RPK_NKEYS];
   int cA[RPK_NC], cB[RPK_NC], cgA[RPK_NC], cgB[RPK_NC];
 };
+// ---- sensor stage (MODE 2): the position / velocity stage of the state BEFORE the last Euler
+// step, plus what the acceleration-stage sensors need (mj_rnePostConstraint, mj_sensorAcc)
+template <typename T>
+struct Smem<T, 2> : Smem<T, 0> {
+  T fext[RPK_NL][6];   // contact forces on each link: spatial force about the tree reference point
+  T touch[RPK_WAVE];   // touch sensor sums per engine site
+};
 // ---- acceleration stage (mj_step2: constraint solver + Euler)
 template <typename T>
 struct Smem<T, 1> : SmemShared<T> {
@@ -103,11 +110,11 @@ __global__ void rp_reset_kernel(RpState<T> S, const T* qpos0, const unsigned cha
 // The host launches  pos, then n_substeps x (sol, pos);  RpStage carries the hand-over.
 // ============================================================================
 template <typename T, int MODE, int FIXED_TL = 0>
-__global__ __launch_bounds__(64, (MODE == 0 || sizeof(T) == 4) ? 2 : 1) void rp_stage_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep,
+__global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_stage_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep,
                                                      int nsub) {
   using namespace rpk;
   using N = Num<T>;
-  const int env = blockIdx.x;
+  const int env = S.order ? S.order[blockIdx.x] : blockIdx.x;
   const int lane = threadIdx.x;
   const int env_active = S.active ? S.active[env] : 1;  // tested after the prologue loads are in flight
   __shared__ Smem<T, MODE> sm;
@@ -1079,6 +1086,12 @@ __global__ __launch_bounds__(64, (MODE == 0 || sizeof(T) == 4) ? 2 : 1) void rp_
       }
 #pragma unroll
       for (int s = 0; s < 3; s++) qw[s] = qa[s];
+      // forces of the pyramidal contact rows, for the acceleration-stage sensors (MODE 2)
+      if (S.con_force && lane < RPK_NC) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          S.con_force[((size_t)env * RPK_NC + lane) * 4 + r] = (anyrow && lane < ncon) ? frc.con[r] : (T)0;
+      }
 
       PROF(8);
       // ---- Euler with implicit joint damping [MJ: mj_Euler, eulerdamp]
@@ -1106,7 +1119,7 @@ __global__ __launch_bounds__(64, (MODE == 0 || sizeof(T) == 4) ? 2 : 1) void rp_
     // ======================================================================
     // MODE 0: POSITION + VELOCITY STAGE  (mj_step1)
     // ======================================================================
-    if constexpr (MODE == 0) {
+    if constexpr (MODE != 1) {
     {
       bool bad = !(N::abs(q[0]) < (T)1e10) || !(N::abs(q[1]) < (T)1e10) || !(N::abs(q[2]) < (T)1e10) ||
                  !(N::abs(qd[0]) < (T)1e10) || !(N::abs(qd[1]) < (T)1e10) || !(N::abs(qd[2]) < (T)1e10);
@@ -1156,7 +1169,7 @@ __global__ __launch_bounds__(64, (MODE == 0 || sizeof(T) == 4) ? 2 : 1) void rp_
       }
       WSYNC();
     }
-    if (lane < M.nsite) {  // site positions of this state
+    if (MODE == 0 && lane < M.nsite) {  // site positions of this state
       int sl = M.site_link()[lane];
       T t[3];
       mat_vec(t, sm.xmat[sl], M.site_pos() + 3 * lane);
@@ -1589,6 +1602,11 @@ __global__ __launch_bounds__(64, (MODE == 0 || sizeof(T) == 4) ? 2 : 1) void rp_
     // chains of the two bodies as they are (a dof on both chains moves both bodies: its
     // Jacobian column is the difference, i.e. exactly zero)
     const unsigned long long omA = con_maskA, omB = con_maskB;
+    const int bodyA = con_A, bodyB = con_B;   // (the nested-contact collapse below edits con_A / con_B)
+    T con_pos[3] = {0, 0, 0};
+    if constexpr (MODE == 2) {
+      if (lane < ncon) { con_pos[0] = sm.cpos[lane][0]; con_pos[1] = sm.cpos[lane][1]; con_pos[2] = sm.cpos[lane][2]; }
+    }
     {
       int cross = 0;
       if (lane < ncon) {
@@ -1687,8 +1705,10 @@ __global__ __launch_bounds__(64, (MODE == 0 || sizeof(T) == 4) ? 2 : 1) void rp_
         for (int c2 = 0; c2 < ncon; c2++) { const int b2 = bcast(cnt, c2); if (c2 < lane) base += b2; }
       }
       const int nent = wave_max(lane < ncon ? base + cnt : 0), maxm = wave_max(cnt);
-      LI(10) = base | (cnt << 8);
-      if (lane == 0) { B.hdr[env * 8 + 4] = nent; B.hdr[env * 8 + 5] = maxm; }
+      if constexpr (MODE == 0) {
+        LI(10) = base | (cnt << 8);
+        if (lane == 0) { B.hdr[env * 8 + 4] = nent; B.hdr[env * 8 + 5] = maxm; }
+      }
       WSYNC();
       const int mycol = isl ? depth : sdepth + 1;
       T ax_[3] = {0, 0, 0}, an_[3] = {0, 0, 0}, xv = 0, khx_ = 0, khz_ = 0;
@@ -1729,10 +1749,12 @@ __global__ __launch_bounds__(64, (MODE == 0 || sizeof(T) == 4) ? 2 : 1) void rp_
           }
           lds_add(&sm.cv[c][0], j3[0] * xv); lds_add(&sm.cv[c][1], j3[1] * xv); lds_add(&sm.cv[c][2], j3[2] * xv);
           const int rank = __popcll(sc & lanemask_lt(lane));
-          const size_t e = (size_t)env * RpCaps<T>::NE + cb + rank;
-          B.entJ[e * 3] = j3[0]; B.entJ[e * 3 + 1] = j3[1]; B.entJ[e * 3 + 2] = j3[2];
-          B.entM[e * 2] = lane | (c << 6) | (mycol << 11) | (cx << 15);
-          B.entM[e * 2 + 1] = cb | (cc << 8) | (rank << 16);
+          if constexpr (MODE == 0) {
+            const size_t e = (size_t)env * RpCaps<T>::NE + cb + rank;
+            B.entJ[e * 3] = j3[0]; B.entJ[e * 3 + 1] = j3[1]; B.entJ[e * 3 + 2] = j3[2];
+            B.entM[e * 2] = lane | (c << 6) | (mycol << 11) | (cx << 15);
+            B.entM[e * 2 + 1] = cb | (cc << 8) | (rank << 16);
+          }
         }
       }
       WSYNC();
@@ -1845,7 +1867,7 @@ __global__ __launch_bounds__(64, (MODE == 0 || sizeof(T) == 4) ? 2 : 1) void rp_
 
     PROF(16);
     // ---- per-substep key activation trace (Piano._update_key_state, piano.py:178-192)
-    if (S.key_trace && substep >= 0) {
+    if (MODE == 0 && S.key_trace && substep >= 0) {
       unsigned long long b0 = __ballot(isk[0] && (fmin(hi[1], fmax(lo[1], q[1])) >= hi[1] - (T)0.00872665));
       unsigned long long b1 = __ballot(isk[1] && (fmin(hi[2], fmax(lo[2], q[2])) >= hi[2] - (T)0.00872665));
       if (lane == 0) {
@@ -1854,7 +1876,7 @@ __global__ __launch_bounds__(64, (MODE == 0 || sizeof(T) == 4) ? 2 : 1) void rp_
       }
     }
     // ---- hand over to the solver kernel
-    {
+    if constexpr (MODE == 0) {
       LF(0) = qbias; LF(1) = alen; LF(2) = avel;
       LF(3) = ksin[0]; LF(4) = ksin[1]; LF(5) = kcos[0]; LF(6) = kcos[1];
       LF(7) = fr_aref;
@@ -1886,6 +1908,122 @@ __global__ __launch_bounds__(64, (MODE == 0 || sizeof(T) == 4) ? 2 : 1) void rp_
         B.hdr[env * 8 + 2] = (int)(dirty_mask & 0xffffffffu); B.hdr[env * 8 + 3] = (int)(dirty_mask >> 32);
       }
     }
+
+    // ======================================================================
+    // MODE 2: ACCELERATION-STAGE SENSORS  [MJ: mj_rnePostConstraint, mj_sensorAcc]
+    // torque sensors at every hand joint's body origin, projected on the joint axis
+    // (robopianist/models/hands/shadow_hand.py:209-226, hands/base.py:101-109) and the
+    // fingertip touch sensors (:248-270), from the constrained qacc (S.warm holds it) and the
+    // contact row forces the solver stage stored (S.con_force).
+    // ======================================================================
+    if constexpr (MODE == 2) {
+      if (isl) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) sm.fext[lane][k] = 0;
+      }
+      sm.touch[lane] = 0;
+      WSYNC();
+      if (lane < ncon) {
+        T f[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) f[r] = S.con_force[((size_t)env * RPK_NC + lane) * 4 + r];
+        // [MJ: mju_decodePyramid] normal force and the two friction components
+        const T fn = f[0] + f[1] + f[2] + f[3];
+        const T f1 = con_mu * (f[0] - f[1]), f2 = con_mu * (f[2] - f[3]);
+        T F[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) F[k] = fn * con_n[k] + f1 * con_t1[k] + f2 * con_t2[k];
+        // the force acts on body B (geom 2), its reaction on body A; keys carry no sensors
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+          const int l = side ? bodyB : bodyA;
+          if (l >= 0 && l < RPK_KEYBASE) {
+            const T sg = side ? (T)1 : (T)-1;
+            const T* tr = M.tree_ref() + 3 * M.link_tree()[l];
+            const T r[3] = {con_pos[0] - tr[0], con_pos[1] - tr[1], con_pos[2] - tr[2]};
+            T t[3];
+            cross3(t, r, F);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { lds_add(&sm.fext[l][k], sg * t[k]); lds_add(&sm.fext[l][3 + k], sg * F[k]); }
+          }
+        }
+        if (fn > (T)0) {
+          for (int st = 0; st < M.nsite; st++) {
+            const T rad = M.site_touch_radius()[st];
+            const int sl = M.site_link()[st];
+            if (rad > (T)0 && (sl == bodyA || sl == bodyB)) {
+              // ray from the contact point along the normal force (flipped when the sensor is on
+              // body B) against the site's sphere [MJ: mju_rayGeom]
+              T sp[3];
+              mat_vec(sp, sm.xmat[sl], M.site_pos() + 3 * st);
+              const T o[3] = {con_pos[0] - sm.xpos[sl][0] - sp[0], con_pos[1] - sm.xpos[sl][1] - sp[1],
+                              con_pos[2] - sm.xpos[sl][2] - sp[2]};
+              const T bq = (sl == bodyB ? (T)-1 : (T)1) * dot3(o, con_n), cq = dot3(o, o) - rad * rad;
+              const T det = bq * bq - cq;
+              if (det >= (T)1e-15 && -bq + N::sqrt(det) >= (T)0) lds_add(&sm.touch[st], fn);
+            }
+          }
+        }
+      }
+      WSYNC();
+      // spatial accelerations with the constrained qacc, by tree level
+      const T qacc = qw[0];
+      T ca2[6] = {0, 0, 0, 0, 0, 0};
+      for (int d = 0; d < M.maxdepth; d++) {
+        if (isl && depth == d) {
+          // (gravity is NOT scaled here: gravity compensation is a joint-space passive force in
+          // MuJoCo, the body-level accelerations see the full gravity)
+          T pa[6] = {0, 0, 0, -M.gx, -M.gy, -M.gz};
+          if (parent >= 0) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) pa[k] = sm.vel[parent][k];
+          }
+#pragma unroll
+          for (int k = 0; k < 6; k++) ca2[k] = pa[k] + cdd[k] * qd[0] + cdofr[k] * qacc;
+        }
+        WSYNC();
+        if (isl && depth == d) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) sm.vel[lane][k] = ca2[k];
+        }
+        WSYNC();
+      }
+      {
+        T f1[6], iv[6], f2[6], t1[3], t2[3];
+        mul_inert(f1, cin, ca2);
+        mul_inert(iv, cin, cv);
+        cross3(t1, cv, iv); cross3(t2, cv + 3, iv + 3);
+        f2[0] = t1[0] + t2[0]; f2[1] = t1[1] + t2[1]; f2[2] = t1[2] + t2[2];
+        cross3(f2 + 3, cv, iv + 3);
+        if (isl) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) sm.acc[lane][k] = f1[k] + f2[k] - sm.fext[lane][k];
+        }
+      }
+      WSYNC();
+      for (int d = M.maxdepth - 1; d >= 1; d--) {
+        int mr = M.level_maxrank()[d];
+        for (int r = 0; r < mr; r++) {
+          if (isl && depth == d && sibrank == r) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) sm.acc[parent][k] += sm.acc[lane][k];
+          }
+          WSYNC();
+        }
+      }
+      if (isl && S.sens_torque) {
+        // interaction force of my body with its parent = my subtree force (the massless virtual links
+        // of a multi-joint body carry the same one); moment about the body origin, on the joint axis
+        const int bl = M.link_bodylink()[L];
+        T axb[3], t[3];
+        mat_vec(axb, sm.xmat[bl], laxis);
+        const T r[3] = {tref[0] - sm.xpos[bl][0], tref[1] - sm.xpos[bl][1], tref[2] - sm.xpos[bl][2]};
+        const T* fi = sm.acc[lane];
+        cross3(t, r, fi + 3);
+        S.sens_torque[eo + ldof] = (fi[0] + t[0]) * axb[0] + (fi[1] + t[1]) * axb[1] + (fi[2] + t[2]) * axb[2];
+      }
+      if (lane < M.nsite && S.sens_touch) S.sens_touch[(size_t)env * M.nsite + lane] = sm.touch[lane];
+    }
     }  // MODE 0
   }
 
@@ -1904,7 +2042,7 @@ __global__ __launch_bounds__(64, (MODE == 0 || sizeof(T) == 4) ? 2 : 1) void rp_
     S.contact_dist[(size_t)env * RPK_NCOUT + lane] = v ? con_dist : (T)0;
   }
   }
-  {
+  if constexpr (MODE != 2) {
     int w = warn;
     w = wave_or(w);
     if (lane == 0) {

@@ -62,7 +62,8 @@
   X(geom_size,        RPK_WAVE,    3) X(geom_pos,        RPK_WAVE,    3) X(geom_mat,       RPK_WAVE,  9) \
   X(geom_rbound,      RPK_WAVE,    1) X(geom_invw,       RPK_WAVE,    1) X(geom_cparam,    RPK_WAVE,  8) \
   X(act_coef,         RPK_MAXACT,  2) X(act_gain,        RPK_MAXACT,  1) X(act_bias,       RPK_MAXACT, 3) \
-  X(act_ctrlrange,    RPK_MAXACT,  2) X(act_forcerange,  RPK_MAXACT,  2) X(site_pos,       RPK_WAVE,  3)
+  X(act_ctrlrange,    RPK_MAXACT,  2) X(act_forcerange,  RPK_MAXACT,  2) X(site_pos,       RPK_WAVE,  3) \
+  X(site_touch_radius, RPK_WAVE,   1)
 #define RPK_ITABLES(X) \
   X(lane_topo,    RPK_NL, 16) \
   X(link_parent,  RPK_NL, 1) X(link_depth,   RPK_NL, 1) X(link_tree,    RPK_NL, 1) X(link_jtype,  RPK_NL, 1) \
@@ -75,7 +76,7 @@
   X(geom_link,    RPK_WAVE, 1) X(geom_type,  RPK_WAVE, 1) X(geom_modelid, RPK_WAVE, 1) \
   X(geom_pairmask, RPK_WAVE, 2) X(geom_iskeycap, RPK_WAVE, 1) \
   X(act_kind,     RPK_MAXACT, 1) X(act_lane, RPK_MAXACT, 2) X(act_ctrllimited, RPK_MAXACT, 1) \
-  X(act_forcelimited, RPK_MAXACT, 1) X(site_link, RPK_WAVE, 1)
+  X(act_forcelimited, RPK_MAXACT, 1) X(site_link, RPK_WAVE, 1) X(link_bodylink, RPK_NL, 1)
 
 struct RpLayout {
   enum : int {
@@ -129,6 +130,13 @@ struct RpState {
   uint32_t* key_trace;  // may be null
   long long* prof;      // may be null: per-phase cycle counters (env 0)
   int max_newton, max_ls;
+  // acceleration-stage sensors (all may be null): contact row forces written by the solver stage,
+  // joint torque / touch sensors written by the sensor stage (MODE 2)
+  T *con_force, *sens_torque, *sens_touch;
+  // may be null: workgroup b processes env order[b].  The host keeps it sorted by descending
+  // predicted cost (longest-processing-time-first: with one wave per env and four sequential
+  // rounds per SIMD, a heavy env that starts last is the tail of the whole launch)
+  const int* order;
 };
 
 // One workgroup == one wavefront, and a wave's LDS instructions execute in issue

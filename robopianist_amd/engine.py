@@ -24,7 +24,8 @@ LIB_PATH = os.environ.get("RP_ENGINE_LIB") or os.path.join(_HERE, "csrc", "librp
 
 # rp_field
 QPOS, QVEL, QACC_WARMSTART, CTRL, QFRC_APPLIED, ACT_FORCE, ACT_VELOCITY, SITE_XPOS, \
-    TIME, NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER, CONTACT_DIST, TREE_OFFSET, ACTIVE = range(16)
+    TIME, NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER, CONTACT_DIST, TREE_OFFSET, ACTIVE, \
+    SENSOR_TORQUE, SENSOR_TOUCH = range(18)
 MAX_CONTACTS = 32
 
 WARN_BADSTATE = 1
@@ -36,7 +37,7 @@ WARN_DENSE_FULL = 32
 
 EXPORTED_SYMBOLS = (
     "rp_create", "rp_destroy", "rp_reset", "rp_set", "rp_get", "rp_step", "rp_forward",
-    "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_set_lazy_position_stage", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
+    "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_set_lazy_position_stage", "rp_set_cost_ordered_launch", "rp_set_acc_sensors", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
     "rp_n_envs", "rp_dim",
     "rp_kernel_time", "rp_solver_kernel_time", "rp_profile", "rp_last_error",
 )
@@ -73,6 +74,8 @@ def load_library(path: str = LIB_PATH):
     L.rp_sync.argtypes = [ctypes.c_void_p]
     L.rp_set_solver_tolerance.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]
     L.rp_set_lazy_position_stage.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.rp_set_cost_ordered_launch.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.rp_set_acc_sensors.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.rp_get_stream.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
     L.rp_n_envs.argtypes = [ctypes.c_void_p]
     L.rp_dim.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
@@ -132,7 +135,7 @@ class BatchedPhysics:
             QFRC_APPLIED: (self.nv,), ACT_FORCE: (self.nu,), ACT_VELOCITY: (self.nu,),
             SITE_XPOS: (self.nsite, 3), TIME: (), NCON: (), CONTACT_GEOMS: (MAX_CONTACTS, 2),
             WARN_FLAGS: (), SOLVER_ITER: (), CONTACT_DIST: (MAX_CONTACTS,),
-            TREE_OFFSET: (self.ntree, 3), ACTIVE: (),
+            TREE_OFFSET: (self.ntree, 3), ACTIVE: (), SENSOR_TORQUE: (self.nv,), SENSOR_TOUCH: (self.nsite,),
         }
         self._int_fields = {NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER, ACTIVE}
         if self_check is None:
@@ -231,6 +234,15 @@ class BatchedPhysics:
         """rp_step skips its leading position/velocity stage for envs whose stage data is still
         valid (see include/rp_engine.h); state written through views then needs forward()."""
         self._check(self._L.rp_set_lazy_position_stage(self._h, int(bool(on))))
+
+    def set_acc_sensors(self, on: bool = True):
+        """Torque / touch sensors (SENSOR_TORQUE, SENSOR_TOUCH) after every step(): one extra launch per
+        rp_step (include/rp_engine.h)."""
+        self._check(self._L.rp_set_acc_sensors(self._h, int(bool(on))))
+
+    def set_cost_ordered_launch(self, on: bool = True):
+        """Stage kernels process the envs heaviest-first (include/rp_engine.h); bit-identical results."""
+        self._check(self._L.rp_set_cost_ordered_launch(self._h, int(bool(on))))
 
     def set_solver_tolerance(self, tolerance=0.0, ls_tolerance=0.0):
         self._check(self._L.rp_set_solver_tolerance(self._h, float(tolerance), float(ls_tolerance)))

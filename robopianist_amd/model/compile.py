@@ -152,7 +152,7 @@ def compile_scene(scene: spec.Scene) -> Model:
     geom = dict(type=[], bodyid=[], pos=[], quat=[], size=[], contype=[],
                 conaffinity=[], condim=[], friction=[], solref=[], solimp=[],
                 solmix=[], margin=[], gap=[], priority=[])
-    site_bodyid, site_pos = [], []
+    site_bodyid, site_pos, site_touch = [], [], []
 
     for i, b in enumerate(bodies):
         names["body"].append(b.name)
@@ -211,6 +211,7 @@ def compile_scene(scene: spec.Scene) -> Model:
             names["site"].append(s.name)
             site_bodyid.append(i)
             site_pos.append(s.pos)
+            site_touch.append(float(getattr(s, "touch_radius", 0.0)))
 
     njnt = len(jnt["type"])
     m["njnt"] = njnt
@@ -309,6 +310,7 @@ def compile_scene(scene: spec.Scene) -> Model:
     m["nsite"] = len(site_bodyid)
     m["site_bodyid"] = arr(site_bodyid, np.int32)
     m["site_pos"] = arr(site_pos, shape=(len(site_bodyid), 3))
+    m["site_touch_radius"] = arr(site_touch)
 
     # Tendons (fixed).
     ten_adr, ten_num, wrap_jnt, wrap_coef = [], [], [], []

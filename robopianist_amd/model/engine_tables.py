@@ -256,6 +256,13 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
     t["eng_tree_trunk"] = tree_trunk
     t["eng_chain_first"] = chain_first
     t["eng_chain_len"] = chain_len
+    # last link of the body each link's joint belongs to (its frame is the body frame): the torque
+    # sensors sit at the body origin and the observable projects on the joint axis in that frame
+    bodylink = np.arange(nl, dtype=np.int32)
+    for i, j in enumerate(link_dofs):
+        b = int(m.jnt_bodyid[j])
+        bodylink[i] = lane_of_dof[int(m.body_jntadr[b] + m.body_jntnum[b] - 1)]
+    t["eng_link_bodylink"] = bodylink
     t["eng_link_lpos"] = lpos; t["eng_link_lquat"] = lquat
     t["eng_link_axis"] = axis; t["eng_link_anchor"] = anchor
     t["eng_link_mass"] = mass; t["eng_link_ipos"] = ipos; t["eng_link_inertia"] = inertia
@@ -474,6 +481,9 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
             s_pos[s_] = body_weld[b][1] + body_weld[b][2] @ m.site_pos[s_]
     t["eng_site_pos"] = s_pos[hs] if hs else np.zeros((0, 3))
     t["eng_site_modelid"] = np.array(hs, np.int32)
+    # zones of the touch sensors (spheres at the fingertip sites, shadow_hand.py:248-270)
+    tr = m.site_touch_radius if "site_touch_radius" in m else np.zeros(m.nsite)
+    t["eng_site_touch_radius"] = tr[hs] if hs else np.zeros(0)
 
     # ---- per-lane topology record: everything a link lane needs about the tree in ONE
     # 64-byte read (the kernels' prologues are otherwise chains of dependent table reads)

@@ -46,6 +46,7 @@ FINGERTIP_BODIES = ("thdistal", "ffdistal", "mfdistal", "rfdistal", "lfdistal")
 
 _FINGERTIP_OFFSET = 0.026  # shadow_hand.py:81
 _THUMBTIP_OFFSET = 0.0275  # shadow_hand.py:82
+_TOUCH_RADIUS = 0.01       # shadow_hand.py:261
 
 # shadow_hand.py:41-69. (type, axis, stiffness, range, reflect)
 FOREARM_DOFS: Dict[str, tuple] = {
@@ -218,7 +219,9 @@ class HandBuilder:
         di.joints.append(self._joint(f.upper() + "J1", "middle_distal"))
         # Stand-in for mesh `f_distal_pst` in primitive (capsule) mode.
         di.geoms.append(self._capsule(f + "distal_pst", 0.0075, 0.0065, (0, 0, 0.012)))
-        di.sites.append(spec.Site(self._n(f + "distal_site"), (0, 0, _FINGERTIP_OFFSET)))
+        # fingertip site (shadow_hand.py:192-207) and, at the same place, the r = 0.01 zone of the
+        # fingertip's touch sensor (:248-270)
+        di.sites.append(spec.Site(self._n(f + "distal_site"), (0, 0, _FINGERTIP_OFFSET), touch_radius=_TOUCH_RADIUS))
 
     def _build(self) -> spec.Body:
         fa = self._body("forearm", (0, 0, 0), 3.0, (0, 0, 0.09), (1, 0, 0, 0),
@@ -289,7 +292,7 @@ class HandBuilder:
                                quat=(1, 0, 0, -1)))
         td.joints.append(self._joint("THJ1", "thdistal"))
         td.geoms.append(self._capsule("thdistal_pst", 0.009, 0.005, (0, 0, 0.0135)))
-        td.sites.append(spec.Site(self._n("thdistal_site"), (0, 0, _THUMBTIP_OFFSET)))
+        td.sites.append(spec.Site(self._n("thdistal_site"), (0, 0, _THUMBTIP_OFFSET), touch_radius=_TOUCH_RADIUS))
 
         # Joint order as PyMJCF's find_all("joint") returns it (document order;
         # forearm joints are appended to the root body AFTER its child bodies, so

@@ -79,6 +79,9 @@ class Geom:
 class Site:
     name: str
     pos: Sequence[float] = (0.0, 0.0, 0.0)
+    # > 0: the site is also the (spherical) zone of a touch sensor of this radius
+    # (robopianist/models/hands/shadow_hand.py:248-270: r = 0.01 at every fingertip)
+    touch_radius: float = 0.0
 
 
 @dataclasses.dataclass

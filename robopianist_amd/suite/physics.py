@@ -9,6 +9,8 @@ HIP stream with no host synchronisation and no staging copies.
 
 from __future__ import annotations
 
+import os
+
 import torch
 
 from robopianist_amd import engine as eng
@@ -47,11 +49,29 @@ class TorchPhysics:
         # followed by forward(): rp_step may skip its leading position stage for untouched envs.
         # Code that writes `physics.qpos` / `qvel` through the views must call forward() itself.
         e.set_lazy_position_stage(True)
+        # heterogeneous batches (random policies, envs at their own episode times): heaviest envs first
+        e.set_cost_ordered_launch(os.environ.get("RP_COST_ORDER", "1") != "0")
         from robopianist_amd.model import engine_tables
         t = engine_tables.build_engine_tables(self.model, scene_info.key_joint_ids)
         self._site_modelid = {int(s): i for i, s in enumerate(t["eng_site_modelid"])}
         self._site_index_cache = {}
         self.timestep = float(self.model.opt_timestep)
+
+    # -- acceleration-stage sensors ------------------------------------------------
+    def enable_acc_sensors(self):
+        """Turns on the `torque` / `touch` sensors (one extra engine launch per step) and maps their
+        arrays: `sens_torque` [E, nv] (joint-axis projection at every hand joint = joints_torque),
+        `sens_touch` [E, n_engine_sites] (fingertip_force at the fingertip sites)."""
+        if getattr(self, "sens_torque", None) is None:
+            self.engine.set_acc_sensors(True)
+            self.sens_torque = self.engine.view(eng.SENSOR_TORQUE)
+            self.sens_touch = self.engine.view(eng.SENSOR_TOUCH)
+
+    def site_touch(self, model_site_ids):
+        """Touch sensor readings of the given model sites, [E, len(ids)]."""
+        self.enable_acc_sensors()
+        idx = torch.as_tensor([self._site_modelid[int(s)] for s in model_site_ids], dtype=torch.long, device=self.device)
+        return self.sens_touch.index_select(1, idx)
 
     # -- reads -----------------------------------------------------------------
     def refresh(self):

@@ -662,7 +662,7 @@ class PianoWithShadowHands(base.PianoTask):
     # switches them on with `entity.observables.<name>.enabled = True`.  Here:
     # `task.enable_observable("rh_shadow_hand/joints_vel")`.
     _HAND_OBSERVABLES = ("joints_vel", "joints_pos_cos_sin", "actuators_force", "actuators_velocity",
-                         "actuators_power", "fingertip_positions")
+                         "actuators_power", "fingertip_positions", "joints_torque", "fingertip_force")
     _PIANO_OBSERVABLES = ("joints_pos", "activation", "sustain_activation")
 
     def _present_hands(self):
@@ -674,8 +674,7 @@ class PianoWithShadowHands(base.PianoTask):
 
     def enable_observable(self, name: str, enabled: bool = True) -> None:
         if name not in self.available_observables():
-            raise KeyError(f"Unknown observable {name!r}; optional observables: {self.available_observables()} "
-                           "(torque / touch sensors are not implemented)")
+            raise KeyError(f"Unknown observable {name!r}; optional observables: {self.available_observables()}")
         extra = getattr(self, "_extra_observables", [])
         if enabled and name not in extra:
             extra = extra + [name]
@@ -705,6 +704,14 @@ class PianoWithShadowHands(base.PianoTask):
             return physics.act_vel[:, act]
         if what == "actuators_power":
             return physics.act_force[:, act].abs() * physics.act_vel[:, act].abs()
+        if what == "joints_torque":
+            # torque sensors at each joint's body origin projected on the joint axis
+            # (hands/base.py:101-109); the engine's sensor stage delivers the projection
+            physics.enable_acc_sensors()
+            return physics.sens_torque[:, jnt]
+        if what == "fingertip_force":
+            # touch sensors at the fingertips (shadow_hand.py:425-432)
+            return physics.site_touch(list(hand.fingertip_sites))
         return physics.site_xpos(list(hand.fingertip_sites)).reshape(self._E, -1)  # fingertip_positions
 
     def _add_optional_observables(self, physics, obs) -> None:
@@ -734,7 +741,8 @@ class PianoWithShadowHands(base.PianoTask):
             else:
                 hand = next(h for h in self._present_hands() if h.name == owner)
                 n = {"joints_vel": len(hand.joints), "joints_pos_cos_sin": 2 * len(hand.joints),
-                     "fingertip_positions": 15}.get(what, len(hand.actuators))
+                     "fingertip_positions": 15, "joints_torque": len(hand.joints),
+                     "fingertip_force": 5}.get(what, len(hand.actuators))
             out[name] = specs.Array((n,), np.float64)
 
     # -- rewards ------------------------------------------------------------------------------

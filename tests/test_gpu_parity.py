@@ -334,3 +334,71 @@ def test_replay_teacher_forced_fp64(two_hand_scene):
     worst, maxcon = teacher_forced(two_hand_scene, 64, ctrl)
     print(f"replay: fp64 teacher-forced worst rel dv {worst:.2e}, max contacts {maxcon}")
     assert worst < 1e-9
+
+
+def test_torque_and_touch_sensors_match_the_oracle(two_hand_scene):
+    """rp_set_acc_sensors: the sensor stage (mj_rnePostConstraint + mj_sensorAcc restated on the GPU)
+    against the oracle, teacher forced through a contact-rich rollout: joints_torque for all 52 hand
+    joints and fingertip_force at the 10 fingertip sites, after one and after ten substeps."""
+    from robopianist_amd import engine
+    from robopianist_amd.model import engine_tables
+    si = two_hand_scene
+    m = si.model
+    phys, orc = make_pair(si, 64, nenv=3)
+    phys.set_acc_sensors(True)
+    t = engine_tables.build_engine_tables(m, si.key_joint_ids)
+    site_ids = t["eng_site_modelid"]
+    hand = np.array([j for j in range(m.nv) if j not in set(int(k) for k in si.key_joint_ids)])
+    ctrl = ctrl_sequence(m, 240, 7)
+    worst_t, worst_f, touched, scale = 0.0, 0.0, 0, 0.0
+    for i, c in enumerate(ctrl):
+        nsub = 10 if i % 40 == 39 else 1
+        phys.set(engine.QPOS, orc.qpos[None, :]); phys.set(engine.QVEL, orc.qvel[None, :])
+        phys.set(engine.QACC_WARMSTART, orc.qacc_warmstart[None, :])
+        phys.set(engine.CTRL, c[None, :]); orc.ctrl[:] = c
+        phys.step(nsub); orc.step(nsub)
+        tq = phys.get(engine.SENSOR_TORQUE).astype(np.float64)
+        tc = phys.get(engine.SENSOR_TOUCH).astype(np.float64)
+        assert np.abs(tq - tq[:1]).max() == 0.0 and np.abs(tc - tc[:1]).max() == 0.0   # identical envs
+        if nsub == 1:
+            want_t, want_f = orc.sensor_torque[hand], orc.sensor_touch[site_ids]
+            worst_t = max(worst_t, np.abs(tq[0, hand] - want_t).max())
+            worst_f = max(worst_f, np.abs(tc[0] - want_f).max())
+            scale = max(scale, np.abs(want_t).max())
+            touched += int((want_f > 0).sum())
+            assert np.abs(tq[0, np.asarray(si.key_joint_ids)]).max() == 0.0
+        else:  # free-running ten substeps: same sensors to the trajectory's own sensitivity
+            np.testing.assert_allclose(tq[0, hand], orc.sensor_torque[hand], rtol=0, atol=1e-6 * max(1.0, scale))
+    print(f"sensors: worst |d torque| {worst_t:.2e} (scale {scale:.2f} N m), worst |d touch| {worst_f:.2e} N, "
+          f"{touched} fingertip touches")
+    assert scale > 0.05 and touched >= 3
+    assert worst_t < 1e-9 * max(1.0, scale) and worst_f < 1e-9
+
+
+def test_joints_torque_and_fingertip_force_observables():
+    """The two optional observables the reference derives from these sensors (hands/base.py:101-109,
+    shadow_hand.py:425-432) through the vectorised task."""
+    import warnings
+    from robopianist_amd import suite
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        env = suite.load("RoboPianist-debug-TwinkleTwinkleRousseau-v0", seed=1, n_envs=4,
+                         task_kwargs=dict(primitive_fingertip_collisions=True, gravity_compensation=True))
+    task = env.task
+    for name in ("rh_shadow_hand/joints_torque", "lh_shadow_hand/joints_torque", "rh_shadow_hand/fingertip_force",
+                 "lh_shadow_hand/fingertip_force"):
+        task.enable_observable(name)
+    env.reset()
+    spec = env.action_spec()
+    a = np.tile(0.5 * (spec.minimum + spec.maximum), (4, 1))
+    a[:, [i for i, n in enumerate(spec.name.split("\t")) if n.endswith("J3") and "TH" not in n]] = 1.4  # curl onto the keys
+    force = 0.0
+    for _ in range(25):
+        ts = env.step(a)
+        obs, ospec = ts.observation, env.observation_spec()
+        for k in ("rh_shadow_hand/joints_torque", "lh_shadow_hand/fingertip_force"):
+            assert tuple(obs[k].shape[1:]) == ospec[k].shape
+        assert obs["rh_shadow_hand/joints_torque"].shape == (4, 26) and obs["lh_shadow_hand/fingertip_force"].shape == (4, 5)
+        force = max(force, float(obs["rh_shadow_hand/fingertip_force"].max()), float(obs["lh_shadow_hand/fingertip_force"].max()))
+    assert float(obs["rh_shadow_hand/joints_torque"].abs().max()) > 1e-3
+    assert force > 0.0, "curled fingers must press on the keys"

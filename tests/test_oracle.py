@@ -210,3 +210,77 @@ def test_unconstrained_acceleration_solves_m_qacc_equals_qfrc_smooth(two_hand_sc
     res = M @ o.qacc_smooth - o.qfrc_smooth
     assert np.abs(res).max() < 1e-9 * max(1.0, np.abs(o.qfrc_smooth).max())
     assert np.allclose(M, M.T) and np.linalg.eigvalsh(M).min() > 0
+
+
+# ---- acceleration-stage sensors (mj_rnePostConstraint / mj_sensorAcc restated) -------------------
+def _contact_rich_state(si, steps=80, seed=3):
+    m = si.model
+    o = _oracle(si)
+    rng = np.random.default_rng(seed)
+    lo, hi = m.actuator_ctrlrange[:, 0], m.actuator_ctrlrange[:, 1]
+    for s in range(steps):
+        if s % 20 == 0:
+            o.ctrl[:] = lo + rng.uniform(0.1, 0.9, m.nu) * (hi - lo)
+        o.step(1)
+    # after a step the acceleration-stage quantities (qacc, efc_force, sensors) belong to the state
+    # BEFORE the Euler update while the position-stage ones were recomputed for the new state;
+    # forward() makes everything refer to the current state
+    o.forward()
+    return o
+
+
+def test_torque_sensor_equals_the_joint_space_force_balance(two_hand_scene):
+    """Known answer tying cfrc_int (body-level Newton-Euler with the constrained qacc and the contact
+    forces) to the joint-space dynamics: for a hinge whose anchor is its body's origin, the sensed
+    torque about the joint axis is everything the joint itself transmits,
+        passive + actuator + applied + (friction-loss and limit rows of that dof) - armature * qacc,
+    because M qacc + bias = those + J_contact^T f and M = CRB + armature."""
+    m = two_hand_scene.model
+    o = _contact_rich_state(two_hand_scene)
+    assert o.ncon >= 3
+    nv, nefc = m.nv, o.nefc
+    J = o.efc_J.reshape(nefc, nv).copy()
+    f = o.efc_force.copy()
+    ncon_rows = 4 * o.ncon
+    joint_rows = J[:nefc - ncon_rows].T @ f[:nefc - ncon_rows]      # friction loss + limits (unit rows)
+    expect = o.qfrc_passive + o.qfrc_actuator + o.qfrc_applied + joint_rows - m.dof_armature * o.qacc
+    tau = o.sensor_torque.copy()
+    sel = [j for j in range(88, nv) if m.jnt_type[j] == 3 and np.allclose(m.jnt_pos[j], 0)]
+    assert len(sel) >= 40
+    np.testing.assert_allclose(tau[sel], expect[sel], rtol=0, atol=1e-9 * max(1.0, np.abs(expect[sel]).max()))
+    assert np.abs(tau[sel]).max() > 1e-3     # (a non-trivial state)
+    # and the full balance closes: M qacc + bias - (all forces) = 0
+    M = o.qM.reshape(nv, nv)
+    res = M @ o.qacc + o.qfrc_bias - o.qfrc_passive - o.qfrc_actuator - o.qfrc_applied - J.T @ f
+    assert np.abs(res).max() < 1e-7
+
+
+def test_touch_sensor_sums_the_normal_forces_inside_the_fingertip_zone(two_hand_scene):
+    """Independent numpy restatement from the oracle's contact list and row forces."""
+    m = two_hand_scene.model
+    hits = 0
+    for seed in (3, 4, 5):
+        o = _contact_rich_state(two_hand_scene, steps=120, seed=seed)
+        con = o.contact.reshape(-1, 16).copy()
+        f = o.efc_force.copy()[o.nefc - 4 * o.ncon:].reshape(-1, 4)
+        want = np.zeros(m.nsite)
+        sx = o.site_xpos.reshape(-1, 3)
+        for c, fr in zip(con, f):
+            fn = fr.sum()
+            if fn <= 0:
+                continue
+            pos, n = c[1:4], c[4:7]
+            b1, b2 = m.geom_bodyid[int(c[13])], m.geom_bodyid[int(c[14])]
+            for s in np.flatnonzero(m.site_touch_radius > 0):
+                sb = m.site_bodyid[s]
+                if sb not in (b1, b2):
+                    continue
+                ray = -n if sb == b2 else n
+                oc = pos - sx[s]
+                bq, cq = oc @ ray, oc @ oc - m.site_touch_radius[s] ** 2
+                det = bq * bq - cq
+                if det >= 1e-15 and -bq + np.sqrt(det) >= 0:
+                    want[s] += fn
+        np.testing.assert_allclose(o.sensor_touch, want, rtol=1e-12, atol=1e-12)
+        hits += int((want > 0).sum())
+    assert hits >= 1, "no fingertip touched anything in these rollouts"

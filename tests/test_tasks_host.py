@@ -392,8 +392,10 @@ def test_optional_observables_can_be_enabled():
     env = _get_env(n_envs=2)
     task = env.task
     assert "rh_shadow_hand/joints_vel" in task.available_observables()
+    assert "rh_shadow_hand/joints_torque" in task.available_observables()     # torque / touch sensors
+    assert "lh_shadow_hand/fingertip_force" in task.available_observables()
     with pytest.raises(KeyError):
-        task.enable_observable("rh_shadow_hand/joints_torque")
+        task.enable_observable("rh_shadow_hand/no_such_observable")
     for name in ("rh_shadow_hand/joints_vel", "lh_shadow_hand/joints_pos_cos_sin", "rh_shadow_hand/actuators_power",
                  "lh_shadow_hand/fingertip_positions", "piano/activation", "piano/joints_pos"):
         task.enable_observable(name)
