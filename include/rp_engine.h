@@ -55,6 +55,8 @@ typedef enum {
   RP_SENSOR_TORQUE = 16,/* [E][nv]    `torque` sensors at every hand joint's body origin projected on the
                            joint axis = the `joints_torque` observable  shadow_hand.py:209-226, hands/base.py:101-109
                            (key dofs: 0).  Needs rp_set_acc_sensors(e, 1). */
+  RP_ENV_COST = 18,     /* [E] int32  shader-clock cycles >> 8 of the env's last solver-stage wave (diagnostic; the
+                           predictor of rp_set_cost_ordered_launch) */
   RP_SENSOR_TOUCH = 17  /* [E][nsite] `touch` sensors (sum of the normal forces of the contacts whose force ray
                            hits the site's sphere), non-zero for the fingertip sites = the `fingertip_force`
                            observable  shadow_hand.py:248-270,425-432.  Needs rp_set_acc_sensors(e, 1). */

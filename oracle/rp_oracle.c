@@ -602,9 +602,13 @@ static int sphere_box_local(rawcon* c, const double* p, double r, const double* 
   return 1;
 }
 
-/* capsule (geom1) vs box (geom2). Own algorithm (MuJoCo's mjc_CapsuleBox is not
- * restated): contact candidates are the axis point closest to the box (exact
- * piecewise-linear root of the distance derivative) and both segment ends. */
+/* capsule (geom1) vs box (geom2).  Contract of MuJoCo's mjc_CapsuleBox [MEM: engine_collision_box.c;
+ * the routine itself is not available here]: at most TWO contacts, both sphere-vs-box tests at
+ * points of the capsule's axis -- the first at the axis point closest to the box, the second further
+ * along the axis where the capsule still bears on the box.  Restated as: first contact at the exact
+ * minimiser t* of the segment-box distance (root of the piecewise-linear derivative), second contact
+ * at the segment END that lies deeper in / closer to the box (skipped when it coincides with t*).
+ * The way MuJoCo picks its second point in edge / corner configurations is NOT reproduced. */
 static int capsule_box(rawcon* out, const double* cp, const double* cm, const double* cs,
                        const double* bp, const double* bm, const double* bs, double margin) {
   double r = cs[0], l = cs[1];
@@ -638,9 +642,18 @@ static int capsule_box(rawcon* out, const double* cp, const double* cm, const do
     else if (gr - gl > 0) tstar = tl + (tr - tl) * (-gl) / (gr - gl);
     else tstar = tl;
   }
-  double cand[3] = {tstar, -1, 1};
+  /* the deeper end: compare the two ends' sphere-box distances (ties: the -1 end) */
+  double dend[2];
+  for (int e = 0; e < 2; e++) {
+    double te = e ? 1.0 : -1.0, p[3] = {c[0]+te*a[0], c[1]+te*a[1], c[2]+te*a[2]};
+    rawcon rc;
+    dend[e] = sphere_box_local(&rc, p, r, bs, 1e300) ? rc.dist : 1e300;
+  }
+  double tend = dend[0] <= dend[1] ? -1.0 : 1.0;
+  if (fabs(tend - tstar) < 1e-9) tend = -tend;
+  double cand[2] = {tstar, tend};
   int n = 0;
-  for (int i = 0; i < 3; i++) {
+  for (int i = 0; i < 2; i++) {
     if (i > 0 && fabs(cand[i] - tstar) < 1e-9) continue;
     double p[3] = {c[0]+cand[i]*a[0], c[1]+cand[i]*a[1], c[2]+cand[i]*a[2]};
     rawcon rc;
@@ -653,6 +666,178 @@ static int capsule_box(rawcon* out, const double* cp, const double* cm, const do
       n++;
     }
   }
+  return n;
+}
+
+
+/* box (geom1) vs box (geom2).  Contract of MuJoCo's mjc_BoxBox [MEM; source not available]: separating-
+ * axis test over the 15 axes; if the least-penetration axis is a face normal, the contact points are
+ * the part of the other box's incident face inside the reference face's prism (vertices, reference
+ * corners, edge crossings: up to 8 points), all with that face normal; if it is an edge-edge axis,
+ * one contact at the closest points of the two edges.  Contact position = midway between the
+ * surfaces, dist = -penetration, normal from geom1 to geom2.  Capacity: the RPO_BOXBOX_MAX deepest
+ * points are kept (the engine has three contact slots per geom pair). */
+#define RPO_BOXBOX_MAX 3
+static void bb_keep(rawcon* out, int* n, const double* pos, const double* nrm, double dist) {
+  /* keep the deepest RPO_BOXBOX_MAX candidates, sorted by dist ascending (ties: first come) */
+  int at = *n;
+  for (int i = 0; i < *n; i++) if (dist < out[i].dist) { at = i; break; }
+  if (at >= RPO_BOXBOX_MAX) return;
+  int last = *n < RPO_BOXBOX_MAX ? *n : RPO_BOXBOX_MAX - 1;
+  for (int i = last; i > at; i--) out[i] = out[i-1];
+  out[at].dist = dist;
+  memcpy(out[at].pos, pos, 3*sizeof(double)); memcpy(out[at].normal, nrm, 3*sizeof(double));
+  if (*n < RPO_BOXBOX_MAX) (*n)++;
+}
+
+static int box_box(rawcon* out, const double* p1, const double* m1, const double* s1,
+                   const double* p2, const double* m2, const double* s2, double margin) {
+  /* R[i][j] = A_i . B_j, t = centre of B in A's frame */
+  double R[3][3], Q[3][3], d[3] = {p2[0]-p1[0], p2[1]-p1[1], p2[2]-p1[2]}, t[3];
+  for (int i = 0; i < 3; i++) {
+    t[i] = m1[i]*d[0] + m1[3+i]*d[1] + m1[6+i]*d[2];
+    for (int j = 0; j < 3; j++) {
+      R[i][j] = m1[i]*m2[j] + m1[3+i]*m2[3+j] + m1[6+i]*m2[6+j];
+      Q[i][j] = fabs(R[i][j]) + 1e-12;
+    }
+  }
+  double tb[3];
+  for (int j = 0; j < 3; j++) tb[j] = t[0]*R[0][j] + t[1]*R[1][j] + t[2]*R[2][j];   /* same in B's frame */
+  double best = -1e300; int code = -1; double sgn = 1;
+  /* face axes of A (codes 0-2) and of B (3-5): separation = |t.L| - rA - rB */
+  for (int i = 0; i < 3; i++) {
+    double sep = fabs(t[i]) - (s1[i] + s2[0]*Q[i][0] + s2[1]*Q[i][1] + s2[2]*Q[i][2]);
+    if (sep > margin) return 0;
+    if (sep > best) { best = sep; code = i; sgn = t[i] >= 0 ? 1 : -1; }
+  }
+  for (int j = 0; j < 3; j++) {
+    double sep = fabs(tb[j]) - (s2[j] + s1[0]*Q[0][j] + s1[1]*Q[1][j] + s1[2]*Q[2][j]);
+    if (sep > margin) return 0;
+    if (sep > best) { best = sep; code = 3 + j; sgn = tb[j] >= 0 ? 1 : -1; }
+  }
+  /* edge axes A_i x B_j (codes 6..14); normalised; a face axis wins unless the edge axis is
+   * clearly better (5 % + 1e-9 bias), as is customary */
+  double ebest = -1e300; int ecode = -1; double esgn = 1, eaxis[3] = {0, 0, 0};
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    int i1 = (i+1)%3, i2 = (i+2)%3, j1 = (j+1)%3, j2 = (j+2)%3;
+    /* L = A_i x B_j in A's frame: components along A_i1, A_i2 are -R[i2][j], R[i1][j] */
+    double l2 = R[i1][j]*R[i1][j] + R[i2][j]*R[i2][j];
+    if (l2 < 1e-12) continue;   /* parallel edges: covered by the face axes */
+    double inv = 1.0 / sqrt(l2);
+    double tl = (t[i2]*R[i1][j] - t[i1]*R[i2][j]) * inv;
+    double ra = (s1[i1]*Q[i2][j] + s1[i2]*Q[i1][j]) * inv;
+    double rb = (s2[j1]*Q[i][j2] + s2[j2]*Q[i][j1]) * inv;
+    double sep = fabs(tl) - ra - rb;
+    if (sep > margin) return 0;
+    if (sep > ebest) {
+      ebest = sep; ecode = 6 + 3*i + j; esgn = tl >= 0 ? 1 : -1;
+      /* world axis = (A_i x B_j) / |.| */
+      double Ai[3] = {m1[i], m1[3+i], m1[6+i]}, Bj[3] = {m2[j], m2[3+j], m2[6+j]};
+      cross3(eaxis, Ai, Bj);
+      for (int k = 0; k < 3; k++) eaxis[k] *= inv;
+    }
+  }
+  int n = 0;
+  if (ecode >= 0 && ebest > best + 1e-9 + 0.05*fabs(best)) {
+    /* ---- edge-edge: closest points of the edge of A (parallel to A_i) and of B (parallel to B_j)
+     * that face each other along the axis */
+    int i = (ecode - 6) / 3, j = (ecode - 6) % 3;
+    double nrm[3] = {esgn*eaxis[0], esgn*eaxis[1], esgn*eaxis[2]};   /* from A to B */
+    double pa[3] = {p1[0], p1[1], p1[2]}, pb[3] = {p2[0], p2[1], p2[2]};
+    for (int k = 0; k < 3; k++) {
+      if (k != i) {
+        double ak[3] = {m1[k], m1[3+k], m1[6+k]};
+        double sg = dot3(nrm, ak) >= 0 ? 1 : -1;
+        for (int c = 0; c < 3; c++) pa[c] += sg * s1[k] * ak[c];
+      }
+      if (k != j) {
+        double bk[3] = {m2[k], m2[3+k], m2[6+k]};
+        double sg = dot3(nrm, bk) >= 0 ? -1 : 1;
+        for (int c = 0; c < 3; c++) pb[c] += sg * s2[k] * bk[c];
+      }
+    }
+    double ua[3] = {m1[i], m1[3+i], m1[6+i]}, ub[3] = {m2[j], m2[3+j], m2[6+j]};
+    double w[3] = {pb[0]-pa[0], pb[1]-pa[1], pb[2]-pa[2]};
+    double uaub = dot3(ua, ub), q1 = dot3(ua, w), q2 = -dot3(ub, w), den = 1 - uaub*uaub;
+    double alpha = 0, beta = 0;
+    if (den > 1e-12) { alpha = (q1 + uaub*q2) / den; beta = (uaub*q1 + q2) / den; }
+    alpha = fmin(s1[i], fmax(-s1[i], alpha)); beta = fmin(s2[j], fmax(-s2[j], beta));
+    double pos[3];
+    for (int c = 0; c < 3; c++) pos[c] = 0.5 * ((pa[c] + alpha*ua[c]) + (pb[c] + beta*ub[c]));
+    bb_keep(out, &n, pos, nrm, ebest);
+    return n;
+  }
+  /* ---- face contact: reference box = owner of the axis */
+  int refA = code < 3, ax = code % 3;
+  const double *pr = refA ? p1 : p2, *mr = refA ? m1 : m2, *sr = refA ? s1 : s2;
+  const double *pi = refA ? p2 : p1, *mi = refA ? m2 : m1, *si = refA ? s2 : s1;
+  /* outward normal of the reference face: towards the other box */
+  double fs = refA ? sgn : -sgn;               /* sign of the reference axis pointing at the incident box */
+  int u = (ax+1)%3, v = (ax+2)%3;
+  /* incident box in the reference frame: centre ci, axes E[k] (column k of Rri) */
+  double ci[3], E[3][3], dd[3] = {pi[0]-pr[0], pi[1]-pr[1], pi[2]-pr[2]};
+  for (int a = 0; a < 3; a++) {
+    ci[a] = mr[a]*dd[0] + mr[3+a]*dd[1] + mr[6+a]*dd[2];
+    for (int k = 0; k < 3; k++) E[k][a] = mr[a]*mi[k] + mr[3+a]*mi[3+k] + mr[6+a]*mi[6+k];
+  }
+  /* incident face: the face of the incident box most anti-parallel to the reference normal */
+  int ia = 0; double bestd = -1;
+  for (int k = 0; k < 3; k++) { double c = fabs(E[k][ax]); if (c > bestd) { bestd = c; ia = k; } }
+  double isg = (E[ia][ax] * fs > 0) ? -1 : 1;   /* the face whose outward normal opposes fs * axis */
+  int iu = (ia+1)%3, iv = (ia+2)%3;
+  double fc[3];
+  for (int a = 0; a < 3; a++) fc[a] = ci[a] + isg * si[ia] * E[ia][a];      /* face centre */
+  double q[4][3];
+  for (int c = 0; c < 4; c++) {
+    double su = (c == 0 || c == 3) ? -1 : 1, sv = (c < 2) ? -1 : 1;          /* (-,-) (+,-) (+,+) (-,+) */
+    for (int a = 0; a < 3; a++) q[c][a] = fc[a] + su*si[iu]*E[iu][a] + sv*si[iv]*E[iv][a];
+  }
+  double h = sr[ax], hu = sr[u], hv = sr[v];
+  double nrm_ref[3] = {fs*mr[ax], fs*mr[3+ax], fs*mr[6+ax]};                 /* world, reference -> incident */
+  double nrm[3];
+  for (int k = 0; k < 3; k++) nrm[k] = refA ? nrm_ref[k] : -nrm_ref[k];      /* geom1 -> geom2 */
+  /* a candidate at reference-plane coordinates (cu, cv) with signed height z along fs*axis */
+#define BB_EMIT(cu, cv, zz) do {                                                          \
+    double depth_ = h - (zz);                                                             \
+    if (-depth_ <= margin) {                                                              \
+      double loc_[3]; loc_[ax] = fs * ((zz) + 0.5*depth_); loc_[u] = (cu); loc_[v] = (cv); \
+      double pos_[3];                                                                     \
+      for (int k_ = 0; k_ < 3; k_++) pos_[k_] = pr[k_] + mr[3*k_+0]*loc_[0] + mr[3*k_+1]*loc_[1] + mr[3*k_+2]*loc_[2]; \
+      bb_keep(out, &n, pos_, nrm, -depth_);                                               \
+    } } while (0)
+  /* (a) incident vertices inside the reference face's prism */
+  for (int c = 0; c < 4; c++)
+    if (fabs(q[c][u]) <= hu && fabs(q[c][v]) <= hv) BB_EMIT(q[c][u], q[c][v], fs*q[c][ax]);
+  /* incident face as a parallelogram in (u, v): P = f0 + a e1 + b e2, a,b in [-1,1] */
+  double f0[2] = {fc[u], fc[v]}, e1[2] = {si[iu]*E[iu][u], si[iu]*E[iu][v]}, e2[2] = {si[iv]*E[iv][u], si[iv]*E[iv][v]};
+  double det = e1[0]*e2[1] - e1[1]*e2[0];
+  double z0 = fs*fc[ax], z1 = fs*si[iu]*E[iu][ax], z2 = fs*si[iv]*E[iv][ax];
+  if (fabs(det) > 1e-14) {
+    /* (b) reference corners inside the incident parallelogram */
+    for (int c = 0; c < 4; c++) {
+      double cu = ((c == 0 || c == 3) ? -hu : hu), cv = (c < 2 ? -hv : hv);
+      double ru = cu - f0[0], rv = cv - f0[1];
+      double a = (ru*e2[1] - rv*e2[0]) / det, b = (e1[0]*rv - e1[1]*ru) / det;
+      if (fabs(a) <= 1 && fabs(b) <= 1) BB_EMIT(cu, cv, z0 + a*z1 + b*z2);
+    }
+  }
+  /* (c) crossings of the incident face's edges with the reference rectangle's edges */
+  for (int c = 0; c < 4; c++) {
+    const double *qa = q[c], *qb = q[(c+1)%4];
+    for (int side = 0; side < 4; side++) {
+      int cax = side < 2 ? u : v, oax = side < 2 ? v : u;
+      double lim = (side & 1) ? (side < 2 ? hu : hv) : -(side < 2 ? hu : hv);
+      double ho = side < 2 ? hv : hu;
+      double da = qa[cax] - lim, db = qb[cax] - lim;
+      if ((da < 0) == (db < 0) || da == db) continue;
+      double tt = da / (da - db);
+      double oc = qa[oax] + tt*(qb[oax] - qa[oax]);
+      if (fabs(oc) > ho) continue;
+      double zz = fs * (qa[ax] + tt*(qb[ax] - qa[ax]));
+      if (side < 2) BB_EMIT(lim, oc, zz); else BB_EMIT(oc, lim, zz);
+    }
+  }
+#undef BB_EMIT
   return n;
 }
 
@@ -674,6 +859,9 @@ static void collision(const rpo_model* m, rpo_data* d) {
     else if (t1 == GEOM_CAPSULE && t2 == GEOM_BOX)
       n = capsule_box(rc, p1, d->geom_xmat + 9*g1, m->geom_size + 3*g1, p2,
                       d->geom_xmat + 9*g2, m->geom_size + 3*g2, margin);
+    else if (t1 == GEOM_BOX && t2 == GEOM_BOX)
+      n = box_box(rc, p1, d->geom_xmat + 9*g1, m->geom_size + 3*g1, p2,
+                  d->geom_xmat + 9*g2, m->geom_size + 3*g2, margin);
     else continue;
     for (int i = 0; i < n; i++) {
       if (d->ncon >= MAXCON) { d->warnings |= 2; return; }

@@ -28,32 +28,46 @@ __global__ void rp_mark_valid_kernel(unsigned char* valid, const int* active, in
   if (e < n && (!active || active[e] != 0)) valid[e] = 1;
 }
 
-// Launch order of the envs for the next stage kernels: descending predicted cost (counting sort on
-// a small integer key), one workgroup of 1024 threads.  Predictor = what the env needed in its last
-// solver stage: Newton iterations x (rows of the dense block + touched keys + a constant), plus its
-// contact count (the position stage's cost).  Inactive envs go last.
-#define RP_ORDER_BUCKETS 512
-__global__ __launch_bounds__(1024) void rp_order_kernel(int* order, const int* solver_iter, const int* ncon,
-                                                        const int* active, int n) {
-  __shared__ int hist[RP_ORDER_BUCKETS];
-  __shared__ int base[RP_ORDER_BUCKETS];
-  for (int i = threadIdx.x; i < RP_ORDER_BUCKETS; i += blockDim.x) hist[i] = 0;
+// Launch order of the envs for the solver stage that follows a position stage: descending predicted
+// cost (counting sort on a small integer key), one workgroup of 1024 threads.  With one wave per env
+// and every SIMD running its envs one after the other, a heavy env that starts late is the tail of
+// the whole launch; the hardware dispatches workgroups in index order to whichever slot frees up, so
+// sorting the heaviest first is longest-processing-time-first list scheduling.
+//   * predictor: the structure of the system the solver is about to solve, read from the hand-over
+//     the position stage just wrote -- contacts, touched keys, rows of the dense (cross-chain) block --
+//     with a typical Newton iteration count.  Measured (profiles/r02_cost_order.md): the per-env solver
+//     time is 26 k + it * (30 k + 1.2 k nd + 5 nd^2 + 2 k nk) + 2.7 k ncon cycles (R^2 0.99), and the
+//     iteration count of the next solve is nearly unpredictable from the last ones (correlation 0.37),
+//     so a constant does better than the previous count.
+//   * XCD affinity: workgroup b runs on XCD b mod 8, and an env's state / hand-over should stay in
+//     that XCD's L2, so the sort is done within each residue class: order[8 r + x] = the r-th
+//     heaviest env among those with index = x (mod 8).  Inactive envs go last in their class.
+#define RP_ORDER_BUCKETS 256
+#define RP_ORDER_CLASSES 8
+__global__ __launch_bounds__(1024) void rp_order_kernel(int* order, const int* hdr, const int* active, int n) {
+  __shared__ int hist[RP_ORDER_CLASSES][RP_ORDER_BUCKETS];
+  for (int i = threadIdx.x; i < RP_ORDER_CLASSES * RP_ORDER_BUCKETS; i += blockDim.x) (&hist[0][0])[i] = 0;
   __syncthreads();
   auto key_of = [&](int e) -> int {
     if (active && active[e] == 0) return 0;
-    const int si = solver_iter[e];
-    const int it = si & 255, nd = (si >> 8) & 255, nk = (si >> 16) & 255;
-    int k = 1 + it * (6 + (nd >> 1) + nk) + ncon[e];
+    const int nc = hdr[e * 8], nk = hdr[e * 8 + 1];
+    const int nd = __popc((unsigned)hdr[e * 8 + 2]) + __popc((unsigned)hdr[e * 8 + 3]);
+    if (nc < 0 || nk < 0) return 1;   // (hand-over not written yet)
+    // k cycles / 4, five Newton iterations
+    const int k = 1 + (26 + 5 * (30 + nd + (nd >> 2) + nd * nd / 200 + 2 * nk) + 3 * nc) / 4;
     return k < RP_ORDER_BUCKETS ? k : RP_ORDER_BUCKETS - 1;
   };
-  for (int e = threadIdx.x; e < n; e += blockDim.x) atomicAdd(&hist[key_of(e)], 1);
+  for (int e = threadIdx.x; e < n; e += blockDim.x) atomicAdd(&hist[e & 7][key_of(e)], 1);
   __syncthreads();
-  if (threadIdx.x == 0) {  // descending: the largest key first
+  if (threadIdx.x < RP_ORDER_CLASSES) {  // descending exclusive prefix per class
     int acc = 0;
-    for (int b = RP_ORDER_BUCKETS - 1; b >= 0; b--) { base[b] = acc; acc += hist[b]; }
+    for (int b = RP_ORDER_BUCKETS - 1; b >= 0; b--) { const int c = hist[threadIdx.x][b]; hist[threadIdx.x][b] = acc; acc += c; }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < n; e += blockDim.x) order[atomicAdd(&base[key_of(e)], 1)] = e;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    const int r = atomicAdd(&hist[e & 7][key_of(e)], 1);
+    order[8 * r + (e & 7)] = e;
+  }
 }
 
 thread_local std::string g_err;
@@ -155,6 +169,8 @@ struct Engine : EngineBase {
   uint32_t* d_trace = nullptr; size_t trace_cap = 0;
   uint8_t* d_mask = nullptr;
   bool trunk4 = false;  // every tree has a 4-link trunk: launch the specialised solver build
+  bool deep = false;    // a trunk of 5..8 links (more than two forearm dofs): the RPK_MAXD_DEEP builds
+  int md() const { return deep ? RPK_MAXD_DEEP : RPK_MAXD; }
 
   ~Engine() override {
     hipSetDevice(device);
@@ -194,12 +210,12 @@ struct Engine : EngineBase {
     M.maxdepth = b.i1("eng_maxdepth"); M.nkey = nkey = b.i1("eng_nkey");
     M.ngeom = b.i1("eng_ngeom");
     M.nu = nu = b.i1("eng_nu"); M.nsite = nsite = b.i1("eng_nsite"); M.nv = nv = b.i1("nv");
-    if (M.nlink > RPK_NL) throw std::string("too many hand dofs for the engine (max 52)");
+    if (M.nlink > RPK_NL_DEEP) throw std::string("too many hand dofs for the engine (max 60)");
     if (M.nkey > RPK_NKEYS) throw std::string("too many keys (max 128)");
     if (M.ngeom > RPK_WAVE) throw std::string("too many collision geoms (max 64)");
     if (M.nu > RPK_MAXACT) throw std::string("too many actuators");
     if (M.nsite > RPK_WAVE) throw std::string("too many sites (max 64)");
-    if (M.maxdepth > RPK_MAXD) throw std::string("tree too deep (max 9 levels)");
+    if (M.maxdepth > RPK_MAXD_DEEP) throw std::string("tree too deep (max 13 levels: 8 trunk links + 5 finger links)");
     {
       std::vector<int> kind = b.i("eng_act_kind");
       for (int a = 0; a < nu; a++)
@@ -238,9 +254,11 @@ struct Engine : EngineBase {
     {
       auto tt = b.i("eng_tree_trunk");
       trunk4 = M.ntree > 0;
+      deep = M.maxdepth > RPK_MAXD || M.nlink > RPK_NL;
       for (int t = 0; t < M.ntree && t < (int)tt.size(); t++) {
-        if (tt[t] > 4 || tt[t] < 1) throw std::string("the solver needs a trunk chain of 1..4 links per articulated tree");
+        if (tt[t] > 8 || tt[t] < 1) throw std::string("the solver needs a trunk chain of 1..8 links per articulated tree");
         if (tt[t] != 4) trunk4 = false;
+        if (tt[t] > 4) deep = true;   // (the register-blocked trunk of the default build holds 4 links)
       }
     }
     for (int v : b.i("eng_chain_len")) if (v > 5) throw std::string("finger chain longer than 5 links is not supported by the solver");
@@ -255,7 +273,7 @@ struct Engine : EngineBase {
         o[3] = 2 * (x * y + w * z); o[4] = 1 - 2 * (x * x + z * z); o[5] = 2 * (y * z - w * x);
         o[6] = 2 * (x * z - w * y); o[7] = 2 * (y * z + w * x); o[8] = 1 - 2 * (x * x + y * y);
       }
-      putF(RpLayout::F_link_lmat, RPK_NL * 9, m, "link_lmat");
+      putF(RpLayout::F_link_lmat, RPK_NL_DEEP * 9, m, "link_lmat");
     }
     PF(link_axis, "eng_link_axis"); PF(link_anchor, "eng_link_anchor"); PF(link_mass, "eng_link_mass");
     PF(link_ipos, "eng_link_ipos"); PF(link_inertia, "eng_link_inertia"); PF(link_invw_body, "eng_link_invw_body");
@@ -314,7 +332,7 @@ struct Engine : EngineBase {
     S.contact_dist = dalloc<T>(E * RPK_NCOUT);
     S.ncon = dalloc<int>(E); S.contact_geoms = dalloc<int>(E * RPK_NCOUT * 2);
     S.warn = dalloc<int>(E); S.solver_iter = dalloc<int>(E);
-    B.RM = dalloc<T>(E * RPK_NL * (RPK_MAXD + 1));
+    B.RM = dalloc<T>(E * RPK_NLX(md()) * (md() + 1));
     B.lanef = dalloc<T>(E * RPK_NLF * 64);
     B.lanei = dalloc<int>(E * RPK_NLI * 64);
     B.hdr = dalloc<int>(E * 8);
@@ -324,7 +342,7 @@ struct Engine : EngineBase {
     B.keyslot = dalloc<int>(E * (RPK_NKEYS / 4));
     // hand-over buffers start as NaN / -1 patterns: a read of anything the position kernel
     // did not write this substep shows up as a bad state instead of silently reusing old data
-    hipMemset(B.RM, 0xFF, sizeof(T) * E * RPK_NL * (RPK_MAXD + 1));
+    hipMemset(B.RM, 0xFF, sizeof(T) * E * RPK_NLX(md()) * (md() + 1));
     hipMemset(B.lanef, 0xFF, sizeof(T) * E * RPK_NLF * 64);
     hipMemset(B.lanei, 0xFF, sizeof(int) * E * RPK_NLI * 64);
     hipMemset(B.hdr, 0xFF, sizeof(int) * E * 8);
@@ -338,6 +356,12 @@ struct Engine : EngineBase {
     S.active = nullptr;
     d_lead = dalloc<int>(E);
     d_order = dalloc<int>(E);
+    {
+      std::vector<int> id(E);
+      for (size_t i = 0; i < E; i++) id[i] = (int)i;
+      hipMemcpy(d_order, id.data(), E * sizeof(int), hipMemcpyHostToDevice);
+    }
+    S.cost_pos = dalloc<int>(E); S.cost_sol = dalloc<int>(E);
     d_valid = dalloc<unsigned char>(E);  // (zero-filled: nothing is valid yet)
     S.max_newton = M.iterations; S.max_ls = M.ls_iterations;
     // The fills and uploads above went through the null stream, which is NOT ordered with the
@@ -434,6 +458,7 @@ struct Engine : EngineBase {
       case RP_CONTACT_DIST: *p = S.contact_dist; *bytes = sizeof(T) * E * RPK_NCOUT; return true;
       case RP_ACTIVE: *p = d_active; *bytes = sizeof(int) * E; *writable = true; return true;
       case RP_TREE_OFFSET: *p = S.tree_offset; *bytes = sizeof(T) * E * ntree * 3; *writable = true; return true;
+      case RP_ENV_COST: *p = S.cost_sol; *bytes = sizeof(int) * E; return true;
       case RP_SENSOR_TORQUE: if (!d_sens_torque) return false; *p = d_sens_torque; *bytes = sizeof(T) * E * nv; return true;
       case RP_SENSOR_TOUCH: if (!d_sens_touch) return false; *p = d_sens_touch; *bytes = sizeof(T) * E * nsite; return true;
     }
@@ -478,6 +503,10 @@ struct Engine : EngineBase {
     if (!on_device) HIP_OK(hipStreamSynchronize(stream));  // device destinations stay stream-ordered
     return 0;
   }
+  void launch_pos(const RpState<T>& st, int k, int nsub) {
+    if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP>), dim3(nenv), dim3(64), 0, stream, M, st, B, k, nsub);
+    else hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(nenv), dim3(64), 0, stream, M, st, B, k, nsub);
+  }
   int step(int nsub, uint32_t* trace, int mode) override {
     HIP_OK(hipSetDevice(device));
     if (mode == 0 && nsub <= 0) return fail("rp_step: n_substeps must be positive");
@@ -509,29 +538,31 @@ struct Engine : EngineBase {
     const int hb = (nenv + 255) / 256;
     // cost-ordered launch: heaviest envs (by what their last solver stage needed) first
     auto reorder = [&]() {
-      hipLaunchKernelGGL(rp_order_kernel, dim3(1), dim3(1024), 0, stream, d_order, S.solver_iter, S.ncon, s.active, nenv);
+      hipLaunchKernelGGL(rp_order_kernel, dim3(1), dim3(1024), 0, stream, d_order, B.hdr, s.active, nenv);
     };
-    if (cost_order && mode == 0) { reorder(); s.order = d_order; }
+    if (cost_order && mode == 0) s.order = d_order;   // (initialised to the identity; refreshed below)
     if (lazy_position && mode == 0) {
       // skip the leading stage for envs whose hand-over is still the one of their current state
       RpState<T> lead = s;
       hipLaunchKernelGGL(rp_lead_mask_kernel, dim3(hb), dim3(256), 0, stream, d_lead, s.active, d_valid, nenv);
       lead.active = d_lead;
-      hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(nenv), dim3(64), 0, stream, M, lead, B, -1, nsub);
+      launch_pos(lead, -1, nsub);
     } else {
-      hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(nenv), dim3(64), 0, stream, M, s, B, -1, nsub);
+      launch_pos(s, -1, nsub);
     }
     if (mode == 0) {
       for (int k = 0; k < nsub; k++) {
         const bool probe = timeit && k == (int)(step_calls % (unsigned)nsub);
         const bool sense = sensors_on && k == nsub - 1;
+        if (cost_order) reorder();   // from the hand-over the position stage just wrote
         if (sense) {  // the state this substep's forces belong to (the solver stage integrates in place)
           HIP_OK(hipMemcpyAsync(d_qpos_prev, S.qpos, sizeof(T) * (size_t)nenv * nv, hipMemcpyDeviceToDevice, stream));
           HIP_OK(hipMemcpyAsync(d_qvel_prev, S.qvel, sizeof(T) * (size_t)nenv * nv, hipMemcpyDeviceToDevice, stream));
         }
         if (probe) HIP_OK(hipEventRecord(sv0[slot], stream));
         // solver stage; the build specialised for "every tree has a 4-link trunk" when it applies
-        if (trunk4) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 4>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
+        if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 0, RPK_MAXD_DEEP>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
+        else if (trunk4) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 4>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
         else hipLaunchKernelGGL((rp_stage_kernel<T, 1>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
         if (probe) HIP_OK(hipEventRecord(sv1[slot], stream));
         if (sense) {
@@ -541,10 +572,10 @@ struct Engine : EngineBase {
           ss.qpos = d_qpos_prev; ss.qvel = d_qvel_prev;
           ss.sens_torque = d_sens_torque; ss.sens_touch = d_sens_touch;
           ss.key_trace = nullptr; ss.prof = nullptr;
-          hipLaunchKernelGGL((rp_stage_kernel<T, 2>), dim3(nenv), dim3(64), 0, stream, M, ss, B, -1, nsub);
+          if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 2, 0, RPK_MAXD_DEEP>), dim3(nenv), dim3(64), 0, stream, M, ss, B, -1, nsub);
+          else hipLaunchKernelGGL((rp_stage_kernel<T, 2>), dim3(nenv), dim3(64), 0, stream, M, ss, B, -1, nsub);
         }
-        if (cost_order && k + 1 < nsub) reorder();
-        hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
+        launch_pos(s, k, nsub);
       }
     }
     hipLaunchKernelGGL(rp_mark_valid_kernel, dim3(hb), dim3(256), 0, stream, d_valid, s.active, nenv);

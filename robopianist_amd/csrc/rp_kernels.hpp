@@ -27,21 +27,21 @@ struct SmemShared {  // used by both stages
   char occ_pad[RPK_OCC_TEST];
 #endif
 };
-template <typename T, int MODE> struct Smem;
+template <typename T, int MODE, int MD = RPK_MAXD> struct Smem;
 // ---- position / velocity stage (mj_step1)
-template <typename T>
-struct Smem<T, 0> : SmemShared<T> {
-  T xpos[RPK_NL][3];
-  T xmat[RPK_NL][9];
-  T xaxis[RPK_NL][3];
-  T xanchor[RPK_NL][3];
+template <typename T, int MD>
+struct Smem<T, 0, MD> : SmemShared<T> {
+  T xpos[RPK_NLX(MD)][3];
+  T xmat[RPK_NLX(MD)][9];
+  T xaxis[RPK_NLX(MD)][3];
+  T xanchor[RPK_NLX(MD)][3];
   union {
-    T cdof[RPK_NL][6];  // until the mass-matrix rows are built
-    T vel[RPK_NL][6];   // velocity stage: spatial velocities / accelerations
+    T cdof[RPK_NLX(MD)][6];  // until the mass-matrix rows are built
+    T vel[RPK_NLX(MD)][6];   // velocity stage: spatial velocities / accelerations
     float gbox[RPK_NBOXF][12];  // in between (collision): world frame + half sizes of the boxes
   };
   union {
-    T acc[RPK_NL][10];  // composite inertias, then subtree forces
+    T acc[RPK_NLX(MD)][10];  // composite inertias, then subtree forces
     struct {            // in between (collision .. contact Jacobians):
       float gax[RPK_WAVE][4];  // fp32 capsule axes for the candidate prefilter: world axis, half-length
       float grr[RPK_WAVE];     // radius (bounding radius for boxes)
@@ -59,19 +59,19 @@ struct Smem<T, 0> : SmemShared<T> {
 };
 // ---- sensor stage (MODE 2): the position / velocity stage of the state BEFORE the last Euler
 // step, plus what the acceleration-stage sensors need (mj_rnePostConstraint, mj_sensorAcc)
-template <typename T>
-struct Smem<T, 2> : Smem<T, 0> {
-  T fext[RPK_NL][6];   // contact forces on each link: spatial force about the tree reference point
+template <typename T, int MD>
+struct Smem<T, 2, MD> : Smem<T, 0, MD> {
+  T fext[RPK_NLX(MD)][6];   // contact forces on each link: spatial force about the tree reference point
   T touch[RPK_WAVE];   // touch sensor sums per engine site
 };
 // ---- acceleration stage (mj_step2: constraint solver + Euler)
-template <typename T>
-struct Smem<T, 1> : SmemShared<T> {
-  T R[RPK_WAVE][RPK_MAXD + 1];  // tree factor rows (L), incl. key-leaf rows
+template <typename T, int MD>
+struct Smem<T, 1, MD> : SmemShared<T> {
+  T R[RPK_WAVE][MD + 1];  // tree factor rows (L), incl. key-leaf rows
   T Dg[RPK_WAVE];               // tree factor diagonal
   T xs[RPK_WAVE];               // solve staging
   T H[(RpCaps<T>::HMAX + 1) * (RpCaps<T>::HMAX + 2) / 2];  // dense block of the cross-coupled rows + rhs row
-  T RM[RPK_NL][RPK_MAXD + 1];   // mass-matrix rows: RM[i][e] = M[i][anc_e(i)]
+  T RM[RPK_NLX(MD)][MD + 1];   // mass-matrix rows: RM[i][e] = M[i][anc_e(i)]
   T keyvec[2][RPK_NKEYS];
   T entJ[RpCaps<T>::NE][3];            // contact Jacobian entries (see RpStage)
   int entM[RpCaps<T>::NE][2];
@@ -109,7 +109,7 @@ __global__ void rp_reset_kernel(RpState<T> S, const T* qpos0, const unsigned cha
 // solver + Euler).  FIXED_TL > 0 specialises the solver for trunks of exactly that many links.
 // The host launches  pos, then n_substeps x (sol, pos);  RpStage carries the hand-over.
 // ============================================================================
-template <typename T, int MODE, int FIXED_TL = 0>
+template <typename T, int MODE, int FIXED_TL = 0, int MD = RPK_MAXD>
 __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_stage_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep,
                                                      int nsub) {
   using namespace rpk;
@@ -117,7 +117,9 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
   const int env = S.order ? S.order[blockIdx.x] : blockIdx.x;
   const int lane = threadIdx.x;
   const int env_active = S.active ? S.active[env] : 1;  // tested after the prologue loads are in flight
-  __shared__ Smem<T, MODE> sm;
+  __shared__ Smem<T, MODE, MD> sm;
+  constexpr int TC = MD > MD ? 8 : 4;          // trunk links the chain-blocked solver holds
+  constexpr int NT = TC * (TC + 1) / 2, NREC = NT + TC;  // packed trunk block / per-chain record
 #ifdef RPK_POISON_LDS  // debug build: nothing may depend on what a previous workgroup left in LDS
   {
     unsigned* w_ = reinterpret_cast<unsigned*>(&sm);
@@ -128,6 +130,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
   int warn = 0;
   if (S.prof && env == 0 && lane < RPK_NPROF) sm.prof[lane] = 0;
   long long prof_t = (long long)__builtin_readcyclecounter();
+  const long long kernel_t0 = prof_t;
   const int nl = M.nlink, nk = M.nkey, nv = M.nv, nu = M.nu;
   const T h = M.timestep;
 
@@ -282,9 +285,9 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
   // values produced by the position/velocity stage and consumed by the next
   // acceleration stage
   T cdofr[6], qbias = 0, alen = 0, avel = 0;
-  T Mr[RPK_MAXD + 1];  // this link's mass-matrix row over its ancestors (diag at [depth])
+  T Mr[MD + 1];  // this link's mass-matrix row over its ancestors (diag at [depth])
 #pragma unroll
-  for (int e = 0; e <= RPK_MAXD; e++) Mr[e] = 0;
+  for (int e = 0; e <= MD; e++) Mr[e] = 0;
   int tree_ok = 1;     // all contacts lie on single root-to-leaf paths (uniform)
   int sdepth = -1;  // solver-slot lanes: anchor link depth
   // Lanes are numbered in preorder (trunk chain, then the leaf chains), so the ancestor
@@ -337,8 +340,8 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
         sdepth = LI(9);
         if (isl) {
 #pragma unroll
-          for (int e = 0; e <= RPK_MAXD; e++) {
-            Mr[e] = B.RM[((size_t)env * RPK_NL + lane) * (RPK_MAXD + 1) + e];
+          for (int e = 0; e <= MD; e++) {
+            Mr[e] = B.RM[((size_t)env * RPK_NLX(MD) + lane) * (MD + 1) + e];
             sm.RM[lane][e] = Mr[e];
           }
         }
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
         // trunk length of this lane's tree; a compile-time constant in the FIXED_TL build
         // (every predicate on it folds: -20 % instructions in the chain elimination)
         const int TLX = FIXED_TL > 0 ? FIXED_TL : TL;
-        // Chain-blocked elimination.  Each tree is a trunk chain (<= 4 links) carrying up
+        // Chain-blocked elimination.  Each tree is a trunk chain (<= TC links) carrying up
         // to five leaf chains (<= 5 links).  The first lane of every chain ("leader")
         // gathers its chain's rows and eliminates the clean links, deepest first, entirely
         // in registers; what that leaves on the trunk is summed per trunk row, the trunk
@@ -428,14 +431,14 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
           if (isslot) {
             T Dk = (T)1;
 #pragma unroll
-            for (int e = 0; e <= RPK_MAXD; e++) if (e == mydiag) Dk = Rr[e];
+            for (int e = 0; e <= MD; e++) if (e == mydiag) Dk = Rr[e];
             if (!dirty) {
               if (!(Dk >= RPK_MINVAL)) { Dk = RPK_MINVAL; warn |= 4; }
               Dslot = Dk;
             }
             const T inv = dirty ? (T)1 : (T)1 / Dk;
 #pragma unroll
-            for (int e = 0; e <= RPK_MAXD; e++) if (e <= mydiag) sm.R[lane][e] = e < mydiag ? Rr[e] * inv : Rr[e];
+            for (int e = 0; e <= MD; e++) if (e <= mydiag) sm.R[lane][e] = e < mydiag ? Rr[e] * inv : Rr[e];
             sm.Dg[lane] = Dk;
             sm.xs[lane] = rhs;
           }
@@ -443,14 +446,14 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
           if (isl) {
             for (int sidx = 0; sidx < nslots; sidx++) {
               const T* Lk = sm.R[nl + sidx];
-              T lrow[RPK_MAXD + 1];
+              T lrow[MD + 1];
 #pragma unroll
-              for (int e = 0; e <= RPK_MAXD; e++) lrow[e] = Lk[e];
+              for (int e = 0; e <= MD; e++) lrow[e] = Lk[e];
               const T lk = Lk[depth], dk = sm.Dg[nl + sidx], xk = sm.xs[nl + sidx];
               if (((sm.slotmask[sidx] >> lane) & 1) && !((dm >> (nl + sidx)) & 1)) {
                 const T t = lk * dk;
 #pragma unroll
-                for (int e = 0; e <= RPK_MAXD; e++) if (e <= depth) Rr[e] -= t * lrow[e];
+                for (int e = 0; e <= MD; e++) if (e <= depth) Rr[e] -= t * lrow[e];
                 rhs -= lk * xk;
               }
             }
@@ -458,22 +461,22 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
         }
         if (isl && depth >= TLX) {
 #pragma unroll
-          for (int e = 0; e <= RPK_MAXD; e++) if (e <= depth) sm.R[lane][e] = Rr[e];
+          for (int e = 0; e <= MD; e++) if (e <= depth) sm.R[lane][e] = Rr[e];
           sm.xs[lane] = rhs;
         }
         WSYNC();
         PROF(20);
-        // ---- chain leaders: local variables 0..3 = trunk, 4..8 = my chain (depth order)
+        // ---- chain leaders: local variables 0..TC-1 = trunk, TC..TC+4 = my chain (depth order)
         const bool leader = isl && depth == TLX && TLX > 0;
         const int clen = chain_end - TLX;
-        T Ac[5][9];   // Ac[ci][j]: chain link ci vs local variable j <= 4+ci
+        T Ac[5][TC + 5];   // Ac[ci][j]: chain link ci vs local variable j <= TC+ci
         T rc_[5], inv_[5];
-        T dT[10], drT[4];  // what the eliminated links leave on the trunk block / rhs
+        T dT[NT], drT[TC];  // what the eliminated links leave on the trunk block / rhs
         int mc[5];
 #pragma unroll
-        for (int k = 0; k < 10; k++) dT[k] = 0;
+        for (int k = 0; k < NT; k++) dT[k] = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) drT[k] = 0;
+        for (int k = 0; k < TC; k++) drT[k] = 0;
         if (leader) {
 #pragma unroll
           for (int ci = 0; ci < 5; ci++) {
@@ -484,43 +487,43 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
             const T xr_ = sm.xs[lane + ci];
             rc_[ci] = pi ? xr_ : (T)0;
 #pragma unroll
-            for (int j = 0; j < 9; j++) {
-              if (j <= 4 + ci) {
-                const bool pj = j < 4 ? j < TLX : (j - 4) < clen;
-                const T raw = j < 4 ? row[j] : rowc[j - 4];
-                Ac[ci][j] = (pi && pj) ? raw : (j == 4 + ci ? (T)1 : (T)0);
+            for (int j = 0; j < TC + 5; j++) {
+              if (j <= TC + ci) {
+                const bool pj = j < TC ? j < TLX : (j - TC) < clen;
+                const T raw = j < TC ? row[j] : rowc[j - TC];
+                Ac[ci][j] = (pi && pj) ? raw : (j == TC + ci ? (T)1 : (T)0);
               }
             }
           }
 #pragma unroll
           for (int ci = 4; ci >= 0; ci--) {
-            const int v = 4 + ci;
+            const int v = TC + ci;
             T dv = Ac[ci][v];
             if (mc[ci] && !(dv >= RPK_MINVAL)) { dv = RPK_MINVAL; warn |= 4; }
             const T iv = mc[ci] ? (T)1 / dv : (T)0;
             inv_[ci] = iv;
-            T l[8];
+            T l[TC + 4];
 #pragma unroll
-            for (int i = 0; i < 8; i++) if (i < v) l[i] = Ac[ci][i] * iv;
+            for (int i = 0; i < TC + 4; i++) if (i < v) l[i] = Ac[ci][i] * iv;
             // chain rows above me
 #pragma unroll
             for (int ci2 = 0; ci2 < 4; ci2++) {
               if (ci2 < ci) {
-                const int i = 4 + ci2;
+                const int i = TC + ci2;
 #pragma unroll
-                for (int j = 0; j < 9; j++) if (j <= i) Ac[ci2][j] -= l[i] * Ac[ci][j];
+                for (int j = 0; j < TC + 5; j++) if (j <= i) Ac[ci2][j] -= l[i] * Ac[ci][j];
                 rc_[ci2] -= l[i] * rc_[ci];
               }
             }
             // trunk block
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < TC; i++) {
 #pragma unroll
-              for (int j = 0; j < 4; j++) if (j <= i) dT[i * (i + 1) / 2 + j] -= l[i] * Ac[ci][j];
+              for (int j = 0; j < TC; j++) if (j <= i) dT[i * (i + 1) / 2 + j] -= l[i] * Ac[ci][j];
               drT[i] -= l[i] * rc_[ci];
             }
 #pragma unroll
-            for (int i = 0; i < 8; i++) if (i < v && mc[ci]) Ac[ci][i] = l[i];
+            for (int i = 0; i < TC + 4; i++) if (i < v && mc[ci]) Ac[ci][i] = l[i];
           }
           // rows / rhs of the links I did not eliminate go back for the dense block (the
           // LDS rows of eliminated links are dead, so every present row is stored)
@@ -530,18 +533,18 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
               T* row = sm.R[lane + ci];
               T* rowc = row + TLX;
 #pragma unroll
-              for (int j = 0; j < 4; j++) if (j < TLX) row[j] = Ac[ci][j];
+              for (int j = 0; j < TC; j++) if (j < TLX) row[j] = Ac[ci][j];
 #pragma unroll
-              for (int j = 4; j < 9; j++) if (j <= 4 + ci) rowc[j - 4] = Ac[ci][j];
+              for (int j = TC; j < TC + 5; j++) if (j <= TC + ci) rowc[j - TC] = Ac[ci][j];
               sm.xs[lane + ci] = rc_[ci];
             }
           }
-          // trunk deltas, one 14-entry record per chain (the dense block is not live yet)
-          T* rec = sm.H + (size_t)(ltree * 5 + mychain) * 14;
+          // trunk deltas, one NREC-entry record per chain (the dense block is not live yet)
+          T* rec = sm.H + (size_t)(ltree * 5 + mychain) * NREC;
 #pragma unroll
-          for (int k = 0; k < 10; k++) rec[k] = dT[k];
+          for (int k = 0; k < NT; k++) rec[k] = dT[k];
 #pragma unroll
-          for (int k = 0; k < 4; k++) rec[10 + k] = drT[k];
+          for (int k = 0; k < TC; k++) rec[NT + k] = drT[k];
         }
         WSYNC();
         // ---- trunk rows collect the chains' contributions (fixed order: deterministic)
@@ -549,34 +552,34 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
           const int tro = depth * (depth + 1) / 2;
 #pragma unroll
           for (int c = 0; c < 5; c++) {
-            const T* rec = sm.H + (size_t)(ltree * 5 + c) * 14;
-            T dv[4];
+            const T* rec = sm.H + (size_t)(ltree * 5 + c) * NREC;
+            T dv[TC];
 #pragma unroll
-            for (int e = 0; e < 4; e++) dv[e] = rec[tro + e < 10 ? tro + e : 9];
-            const T dr = rec[10 + depth];
+            for (int e = 0; e < TC; e++) dv[e] = rec[tro + e < NT ? tro + e : NT - 1];
+            const T dr = rec[NT + depth];
             const bool has = (chainmask >> c) & 1;
 #pragma unroll
-            for (int e = 0; e < 4; e++) if (has && e <= depth) Rr[e] += dv[e];
+            for (int e = 0; e < TC; e++) if (has && e <= depth) Rr[e] += dv[e];
             if (has) rhs += dr;
           }
 #pragma unroll
-          for (int e = 0; e < 4; e++) if (e <= depth) sm.R[lane][e] = Rr[e];
+          for (int e = 0; e < TC; e++) if (e <= depth) sm.R[lane][e] = Rr[e];
           sm.xs[lane] = rhs;
         }
         WSYNC();
         // ---- trunk leader eliminates the clean trunk links (deepest first)
         const bool tleader = isl && depth == 0;
-        T At[4][4], rt[4], invt[4];
-        int mt[4];
+        T At[TC][TC], rt[TC], invt[TC];
+        int mt[TC];
         if (tleader) {
 #pragma unroll
-          for (int i = 0; i < 4; i++) {
+          for (int i = 0; i < TC; i++) {
             const bool pi = i < TLX;
             mt[i] = pi && !((dm >> (lane + i)) & 1);
             const T xin = sm.xs[lane + i];
             rt[i] = pi ? xin : (T)0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < TC; j++) {
               if (j <= i) {
                 const T raw = sm.R[lane + i][j];
                 At[i][j] = pi ? raw : (j == i ? (T)1 : (T)0);
@@ -584,30 +587,30 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
             }
           }
 #pragma unroll
-          for (int v = 3; v >= 0; v--) {
+          for (int v = TC - 1; v >= 0; v--) {
             T dv = At[v][v];
             if (mt[v] && !(dv >= RPK_MINVAL)) { dv = RPK_MINVAL; warn |= 4; }
             const T iv = mt[v] ? (T)1 / dv : (T)0;
             invt[v] = iv;
-            T l[3];
+            T l[TC - 1];
 #pragma unroll
-            for (int i = 0; i < 3; i++) if (i < v) l[i] = At[v][i] * iv;
+            for (int i = 0; i < TC - 1; i++) if (i < v) l[i] = At[v][i] * iv;
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
+            for (int i = 0; i < TC - 1; i++) {
               if (i < v) {
 #pragma unroll
-                for (int j = 0; j < 3; j++) if (j <= i) At[i][j] -= l[i] * At[v][j];
+                for (int j = 0; j < TC - 1; j++) if (j <= i) At[i][j] -= l[i] * At[v][j];
                 rt[i] -= l[i] * rt[v];
               }
             }
 #pragma unroll
-            for (int i = 0; i < 3; i++) if (i < v && mt[v]) At[v][i] = l[i];
+            for (int i = 0; i < TC - 1; i++) if (i < v && mt[v]) At[v][i] = l[i];
           }
 #pragma unroll
-          for (int i = 0; i < 4; i++) {
+          for (int i = 0; i < TC; i++) {
             if (i < TLX) {  // (rows of eliminated links are dead: store them all)
 #pragma unroll
-              for (int j = 0; j < 4; j++) if (j <= i) sm.R[lane + i][j] = At[i][j];
+              for (int j = 0; j < TC; j++) if (j <= i) sm.R[lane + i][j] = At[i][j];
               sm.xs[lane + i] = rt[i];
             }
           }
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
             } else {
               sm.H[tri(ci, ci)] = sm.R[lane][mydiag];
 #pragma unroll
-              for (int e = 0; e < RPK_MAXD; e++) {
+              for (int e = 0; e < MD; e++) {
                 if (e <= sdepth) {
                   const int a_ = anc_of(salink, sdepth, sTL, sTB, e);
                   if ((dm >> a_) & 1) sm.H[tri(ci, cidx(a_))] = sm.R[lane][e];
@@ -656,31 +659,31 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
         PROF(25);
         // ---- back-substitution: trunk leader, then chain leaders, then key leaves
         if (tleader) {
-          T xt[4];
+          T xt[TC];
 #pragma unroll
-          for (int v = 0; v < 4; v++) xt[v] = sm.xs[lane + v];
+          for (int v = 0; v < TC; v++) xt[v] = sm.xs[lane + v];
 #pragma unroll
-          for (int v = 0; v < 4; v++) {
+          for (int v = 0; v < TC; v++) {
             T xv = rt[v] * invt[v];
 #pragma unroll
-            for (int i = 0; i < 3; i++) if (i < v) xv -= At[v][i] * xt[i];
+            for (int i = 0; i < TC - 1; i++) if (i < v) xv -= At[v][i] * xt[i];
             xt[v] = mt[v] ? xv : (v < TLX ? xt[v] : (T)0);
             if (v < TLX) sm.xs[lane + v] = xt[v];
           }
         }
         WSYNC();
         if (leader) {
-          T xl[9];
+          T xl[TC + 5];
 #pragma unroll
-          for (int j = 0; j < 4; j++) { const T xin = sm.xs[tbase + j]; xl[j] = j < TLX ? xin : (T)0; }
+          for (int j = 0; j < TC; j++) { const T xin = sm.xs[tbase + j]; xl[j] = j < TLX ? xin : (T)0; }
 #pragma unroll
-          for (int ci = 0; ci < 5; ci++) xl[4 + ci] = sm.xs[lane + ci];
+          for (int ci = 0; ci < 5; ci++) xl[TC + ci] = sm.xs[lane + ci];
 #pragma unroll
           for (int ci = 0; ci < 5; ci++) {
-            const int v = 4 + ci;
+            const int v = TC + ci;
             T xv = rc_[ci] * inv_[ci];
 #pragma unroll
-            for (int i = 0; i < 8; i++) if (i < v) xv -= Ac[ci][i] * xl[i];
+            for (int i = 0; i < TC + 4; i++) if (i < v) xv -= Ac[ci][i] * xl[i];
             xl[v] = mc[ci] ? xv : (ci < clen ? xl[v] : (T)0);
             if (ci < clen) sm.xs[lane + ci] = xl[v];
           }
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
           if (!dirty) {
             x = rhs / Dslot;
 #pragma unroll
-            for (int e = 0; e < RPK_MAXD; e++)
+            for (int e = 0; e < MD; e++)
               if (e <= sdepth) x -= sm.R[lane][e] * sm.xs[anc_of(salink, sdepth, sTL, sTB, e)];
           }
         }
@@ -702,9 +705,9 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
       auto no_cross = [&](auto&&) {};
       // ---- qacc_smooth = M^-1 qfrc_smooth (M is always tree-sparse)
       {
-        T Rr[RPK_MAXD + 1];
+        T Rr[MD + 1];
 #pragma unroll
-        for (int e = 0; e <= RPK_MAXD; e++) Rr[e] = Mr[e];
+        for (int e = 0; e <= MD; e++) Rr[e] = Mr[e];
         qs[0] = tree_solve(Rr, qfs[0], 0, 0ull, no_cross);
       }
 
@@ -822,7 +825,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
         T y = 0;
         if (isl) {
 #pragma unroll
-          for (int e = 0; e <= RPK_MAXD; e++) if (e <= depth) y += Mr[e] * sm.xs[anc_at(e)];
+          for (int e = 0; e <= MD; e++) if (e <= depth) y += Mr[e] * sm.xs[anc_at(e)];
           for (int j = 1; j <= ndesc; j++) y += sm.RM[lane + j][depth] * sm.xs[lane + j];
         }
         out[0] = y;
@@ -912,10 +915,10 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
             }
             if (isl) {
 #pragma unroll
-              for (int e = 0; e <= RPK_MAXD; e++) if (e <= depth) sm.R[lane][e] = Mr[e] + (e == depth ? mydiag_add : (T)0);
+              for (int e = 0; e <= MD; e++) if (e <= depth) sm.R[lane][e] = Mr[e] + (e == depth ? mydiag_add : (T)0);
             } else if (isslot) {
 #pragma unroll
-              for (int e = 0; e <= RPK_MAXD; e++) if (e <= sdepth + 1) sm.R[lane][e] = e == sdepth + 1 ? slotdiag : (T)0;
+              for (int e = 0; e <= MD; e++) if (e <= sdepth + 1) sm.R[lane][e] = e == sdepth + 1 ? slotdiag : (T)0;
             }
             WSYNC();
             // ... + J^T C J of every contact.  Entry lane a of contact c holds u = C_c J_a and
@@ -959,9 +962,9 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
             };
             contact_terms(false, [](int) { return 0; });
             WSYNC();
-            T Rr[RPK_MAXD + 1];
+            T Rr[MD + 1];
 #pragma unroll
-            for (int e = 0; e <= RPK_MAXD; e++) Rr[e] = sm.R[lane][e];
+            for (int e = 0; e <= MD; e++) Rr[e] = sm.R[lane][e];
             WSYNC();
             // cross-chain contacts go into the dense block of the dirty rows
             auto cross_fn = [&](auto&& cidx) { contact_terms(true, cidx); };
@@ -1097,9 +1100,9 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
       // ---- Euler with implicit joint damping [MJ: mj_Euler, eulerdamp]
       T qe[3];
       {
-        T Rr[RPK_MAXD + 1];
+        T Rr[MD + 1];
 #pragma unroll
-        for (int e = 0; e <= RPK_MAXD; e++) Rr[e] = Mr[e] + ((isl && e == depth) ? h * ldamp : (T)0);
+        for (int e = 0; e <= MD; e++) Rr[e] = Mr[e] + ((isl && e == depth) ? h * ldamp : (T)0);
         qe[0] = tree_solve(Rr, qfs[0] + qfc[0], 0, 0ull, no_cross);
       }
 #pragma unroll
@@ -1236,7 +1239,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
       for (int k = 0; k < 10; k++) crb[k] = sm.acc[lane][k];
       mul_inert(buf, crb, cdofr);
 #pragma unroll
-      for (int k = 0; k < RPK_MAXD; k++) {
+      for (int k = 0; k < MD; k++) {
         if (k <= depth) {
           int a = anc_at(k);
           T v = dot6(sm.cdof[a], buf);
@@ -1350,13 +1353,25 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
         const int g = __ffsll((long long)near_mask) - 1;
         near_mask &= near_mask - 1;
         const float cx = bcast(fcx, g), cy = bcast(fcy, g), cz = bcast(fcz, g), rb = bcast(frb, g);
+        // extents along world x, y, z: the bounding radius for capsules, the oriented box's own
+        // axis-aligned extents for boxes (a palm box hovering over the keyboard is no candidate)
+        float ex_ = rb, ey_ = rb, ez_ = rb;
+        {
+          const int bi_ = g - ncap;
+          if (bi_ >= 0 && bi_ < RPK_NBOXF) {
+            const float* gb_ = sm.gbox[bi_];
+            ex_ = fabsf(gb_[0]) * gb_[9] + fabsf(gb_[1]) * gb_[10] + fabsf(gb_[2]) * gb_[11] + 1e-4f;
+            ey_ = fabsf(gb_[3]) * gb_[9] + fabsf(gb_[4]) * gb_[10] + fabsf(gb_[5]) * gb_[11] + 1e-4f;
+            ez_ = fabsf(gb_[6]) * gb_[9] + fabsf(gb_[7]) * gb_[10] + fabsf(gb_[8]) * gb_[11] + 1e-4f;
+          }
+        }
 #pragma unroll
         for (int s = 0; s < 2; s++) {
           const float dx = kx[s] - cx, dy = kpy[s] - cy, dz = kz[s] - cz, rr = rb + krb_[s];
           // bounding spheres, then a conservative box test (the key only rotates about
           // y, so its y-extent is exact; x/z get a 1 cm allowance)
-          const bool hit = isk[s] && dx * dx + dy * dy + dz * dz <= rr * rr && fabsf(dy) <= khy_[s] + rb &&
-                           fabsf(cx - kpx[s]) <= khx_[s] + rb && cz - rb <= ktop[s];
+          const bool hit = isk[s] && dx * dx + dy * dy + dz * dz <= rr * rr && fabsf(dy) <= khy_[s] + ey_ &&
+                           fabsf(cx - kpx[s]) <= khx_[s] + ex_ && cz - ez_ <= ktop[s];
           if (s == 0) remK0 |= hit ? (1ull << g) : 0ull; else remK1 |= hit ? (1ull << g) : 0ull;
         }
       }
@@ -1412,6 +1427,42 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
                 sep = sep || (fabsf(ck) - fhl * fabsf(ak) > gb[9 + k] + reach2);
               }
               has = has && !sep;
+              // box against box: the full 15-axis separating-axis test in fp32 (0.1 mm allowance), so
+              // that the fp64 box-box routine only ever runs for boxes that really touch
+              const int ai = lane - ncap;
+              if (ai >= 0 && ai < RPK_NBOXF && __builtin_amdgcn_ballot_w64(has) != 0ull) {
+                const float* ga_ = sm.gbox[ai];
+                float Rf[3][3], Qf[3][3], tf[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                  tf[i] = -(ga_[i] * rx + ga_[3 + i] * ry + ga_[6 + i] * rz);   // (B centre - A centre) in A's frame
+#pragma unroll
+                  for (int j = 0; j < 3; j++) {
+                    Rf[i][j] = ga_[i] * gb[j] + ga_[3 + i] * gb[3 + j] + ga_[6 + i] * gb[6 + j];
+                    Qf[i][j] = fabsf(Rf[i][j]) + 1e-6f;
+                  }
+                }
+                bool sp = false;
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                  sp = sp || fabsf(tf[i]) > ga_[9 + i] + gb[9] * Qf[i][0] + gb[10] * Qf[i][1] + gb[11] * Qf[i][2] + 1e-4f;
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                  sp = sp || fabsf(tf[0] * Rf[0][j] + tf[1] * Rf[1][j] + tf[2] * Rf[2][j]) >
+                                 gb[9 + j] + ga_[9] * Qf[0][j] + ga_[10] * Qf[1][j] + ga_[11] * Qf[2][j] + 1e-4f;
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+#pragma unroll
+                  for (int j = 0; j < 3; j++) {
+                    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+                    const float tl = fabsf(tf[i2] * Rf[i1][j] - tf[i1] * Rf[i2][j]);
+                    const float ra = ga_[9 + i1] * Qf[i2][j] + ga_[9 + i2] * Qf[i1][j];
+                    const float rb = gb[9 + j1] * Qf[i][j2] + gb[9 + j2] * Qf[i][j1];
+                    sp = sp || tl > ra + rb + 1e-4f;   // (unnormalised axis: both sides scale alike; the
+                  }                                    //  allowance only makes the test more conservative)
+                }
+                has = has && !sp;
+              }
             }
           }
           const unsigned long long mk = __ballot(has);
@@ -1464,7 +1515,10 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
           T hx = M.key_half()[3 * k];
           T bp[3] = {M.key_pos()[3 * k] - hx + hx * c, M.key_pos()[3 * k + 1], M.key_pos()[3 * k + 2] - hx * s};
           T bm[9] = {c, 0, s, 0, 1, 0, -s, 0, c};
-          n = capsule_box(rc, posA, mA, M.geom_size() + 3 * ga, bp, bm, M.key_half() + 3 * k);
+          if (M.geom_type()[ga] == GEOM_CAPSULE_)
+            n = capsule_box(rc, posA, mA, M.geom_size() + 3 * ga, bp, bm, M.key_half() + 3 * k);
+          else
+            n = box_box(rc, posA, mA, M.geom_size() + 3 * ga, bp, bm, M.key_half() + 3 * k);
 #pragma unroll
           for (int e = 0; e < 8; e++) pB[e] = M.key_cparam()[e];
           invw += M.key_invw_body()[k];
@@ -1478,8 +1532,10 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
           }
           if (M.geom_type()[gb] == GEOM_CAPSULE_)
             n = capsule_capsule(rc, posA, mA, M.geom_size() + 3 * ga, posB, mB, M.geom_size() + 3 * gb);
-          else
+          else if (M.geom_type()[ga] == GEOM_CAPSULE_)
             n = capsule_box(rc, posA, mA, M.geom_size() + 3 * ga, posB, mB, M.geom_size() + 3 * gb);
+          else
+            n = box_box(rc, posA, mA, M.geom_size() + 3 * ga, posB, mB, M.geom_size() + 3 * gb);
 #pragma unroll
           for (int e = 0; e < 8; e++) pB[e] = M.geom_cparam()[8 * gb + e];
           invw += M.geom_invw()[gb];
@@ -1895,7 +1951,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
       LI(11) = salink | (sTL << 8) | (sTB << 16);
       if (isl) {
 #pragma unroll
-        for (int e = 0; e <= RPK_MAXD; e++) B.RM[((size_t)env * RPK_NL + lane) * (RPK_MAXD + 1) + e] = Mr[e];
+        for (int e = 0; e <= MD; e++) B.RM[((size_t)env * RPK_NLX(MD) + lane) * (MD + 1) + e] = Mr[e];
       }
       if (lane < 16) {
         int* sl = B.slots + (size_t)env * 64;
@@ -2057,6 +2113,10 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
   if (S.prof && env == 0 && lane < RPK_NPROF) {
     WSYNC();
     atomicAdd((unsigned long long*)&S.prof[lane], (unsigned long long)sm.prof[lane]);
+  }
+  if constexpr (MODE != 2) {
+    int* cost = MODE == 0 ? S.cost_pos : S.cost_sol;
+    if (cost && lane == 0) cost[env] = (int)(((long long)__builtin_readcyclecounter() - kernel_t0) >> 8);
   }
 #undef LF
 #undef LI

@@ -26,8 +26,11 @@
 #define RPK_NBOXF 26     // boxes covered by the oriented-box prefilter (fits the cdof scratch in fp32)
 #define RPK_HMAX 60      // max rows of the dense cross-coupling block (+1 row for its rhs = one lane each; fp64)
 #define RPK_WORK 128     // narrow-phase work list
-#define RPK_MAXD 9       // tree depth levels
-#define RPK_NL 52        // max links
+#define RPK_MAXD 9       // tree depth levels held by the default kernel builds (trunk <= 4 links + chain <= 5)
+#define RPK_MAXD_DEEP 13 // ... by the deep builds (trunk <= 8 links: every subset of the six forearm dofs)
+#define RPK_NL 52        // max links held by the default kernel builds (two hands x (24 + 2 forearm dofs))
+#define RPK_NL_DEEP 60   // ... by the deep builds (two hands x (24 + 6)); also the table capacity
+#define RPK_NLX(MD) ((MD) > RPK_MAXD ? RPK_NL_DEEP : RPK_NL)
 #define RPK_NKEYS 128    // max keys (2 slots per lane)
 #define RPK_KEYBASE 1000 // work-list / contact encoding of "key k" = RPK_KEYBASE + k
 
@@ -45,14 +48,14 @@
 #define RPK_MAXTREE 4
 //      name            items        stride
 #define RPK_FTABLES(X) \
-  X(link_lpos,        RPK_NL,      3) X(link_lmat,       RPK_NL,      9) X(link_axis,      RPK_NL, 3) \
-  X(link_anchor,      RPK_NL,      3) X(link_mass,       RPK_NL,      1) X(link_ipos,      RPK_NL, 3) \
-  X(link_inertia,     RPK_NL,      6) X(link_invw_body,  RPK_NL,      1) X(link_armature,  RPK_NL, 1) \
-  X(link_damping,     RPK_NL,      1) X(link_stiffness,  RPK_NL,      1) X(link_springref, RPK_NL, 1) \
-  X(link_floss,       RPK_NL,      1) X(link_fl_R,       RPK_NL,      1) X(link_fl_B,      RPK_NL, 1) \
-  X(link_range,       RPK_NL,      2) X(link_lim_K,      RPK_NL,      1) X(link_lim_B,     RPK_NL, 1) \
-  X(link_lim_solimp,  RPK_NL,      5) X(link_invw_dof,   RPK_NL,      1) X(link_act_coef,  RPK_NL, 1) \
-  X(link_gscale,      RPK_NL,      1) \
+  X(link_lpos,        RPK_NL_DEEP,      3) X(link_lmat,       RPK_NL_DEEP,      9) X(link_axis,      RPK_NL_DEEP, 3) \
+  X(link_anchor,      RPK_NL_DEEP,      3) X(link_mass,       RPK_NL_DEEP,      1) X(link_ipos,      RPK_NL_DEEP, 3) \
+  X(link_inertia,     RPK_NL_DEEP,      6) X(link_invw_body,  RPK_NL_DEEP,      1) X(link_armature,  RPK_NL_DEEP, 1) \
+  X(link_damping,     RPK_NL_DEEP,      1) X(link_stiffness,  RPK_NL_DEEP,      1) X(link_springref, RPK_NL_DEEP, 1) \
+  X(link_floss,       RPK_NL_DEEP,      1) X(link_fl_R,       RPK_NL_DEEP,      1) X(link_fl_B,      RPK_NL_DEEP, 1) \
+  X(link_range,       RPK_NL_DEEP,      2) X(link_lim_K,      RPK_NL_DEEP,      1) X(link_lim_B,     RPK_NL_DEEP, 1) \
+  X(link_lim_solimp,  RPK_NL_DEEP,      5) X(link_invw_dof,   RPK_NL_DEEP,      1) X(link_act_coef,  RPK_NL_DEEP, 1) \
+  X(link_gscale,      RPK_NL_DEEP,      1) \
   X(tree_gscale,      RPK_MAXTREE, 1) X(tree_ref,        RPK_MAXTREE, 3) \
   X(key_pos,          RPK_NKEYS,   3) X(key_half,        RPK_NKEYS,   3) X(key_mass,       RPK_NKEYS, 1) \
   X(key_M,            RPK_NKEYS,   1) X(key_stiffness,   RPK_NKEYS,   1) X(key_springref,  RPK_NKEYS, 1) \
@@ -65,18 +68,18 @@
   X(act_ctrlrange,    RPK_MAXACT,  2) X(act_forcerange,  RPK_MAXACT,  2) X(site_pos,       RPK_WAVE,  3) \
   X(site_touch_radius, RPK_WAVE,   1)
 #define RPK_ITABLES(X) \
-  X(lane_topo,    RPK_NL, 16) \
-  X(link_parent,  RPK_NL, 1) X(link_depth,   RPK_NL, 1) X(link_tree,    RPK_NL, 1) X(link_jtype,  RPK_NL, 1) \
-  X(link_dof,     RPK_NL, 1) X(link_sibrank, RPK_NL, 1) X(link_limited, RPK_NL, 1) X(link_act,    RPK_NL, 1) \
-  X(link_ndesc,   RPK_NL, 1) X(link_anc,     RPK_NL, RPK_MAXD) X(link_ancmask, RPK_NL, 2) \
-  X(link_desc,    RPK_NL, RPK_MAXD * 5) X(level_maxrank, 1, RPK_MAXD) \
+  X(lane_topo,    RPK_NL_DEEP, 16) \
+  X(link_parent,  RPK_NL_DEEP, 1) X(link_depth,   RPK_NL_DEEP, 1) X(link_tree,    RPK_NL_DEEP, 1) X(link_jtype,  RPK_NL_DEEP, 1) \
+  X(link_dof,     RPK_NL_DEEP, 1) X(link_sibrank, RPK_NL_DEEP, 1) X(link_limited, RPK_NL_DEEP, 1) X(link_act,    RPK_NL_DEEP, 1) \
+  X(link_ndesc,   RPK_NL_DEEP, 1) X(link_anc,     RPK_NL_DEEP, RPK_MAXD_DEEP) X(link_ancmask, RPK_NL_DEEP, 2) \
+  X(link_desc,    RPK_NL_DEEP, RPK_MAXD_DEEP * 5) X(level_maxrank, 1, RPK_MAXD_DEEP) \
   X(tree_base,    RPK_MAXTREE, 1) X(tree_trunk, RPK_MAXTREE, 1) X(chain_first, RPK_MAXTREE, 5) \
   X(chain_len,    RPK_MAXTREE, 5) \
   X(key_dof,      RPK_NKEYS, 1) X(key_act,   RPK_NKEYS, 1) X(key_geomid, RPK_NKEYS, 1) \
   X(geom_link,    RPK_WAVE, 1) X(geom_type,  RPK_WAVE, 1) X(geom_modelid, RPK_WAVE, 1) \
   X(geom_pairmask, RPK_WAVE, 2) X(geom_iskeycap, RPK_WAVE, 1) \
   X(act_kind,     RPK_MAXACT, 1) X(act_lane, RPK_MAXACT, 2) X(act_ctrllimited, RPK_MAXACT, 1) \
-  X(act_forcelimited, RPK_MAXACT, 1) X(site_link, RPK_WAVE, 1) X(link_bodylink, RPK_NL, 1)
+  X(act_forcelimited, RPK_MAXACT, 1) X(site_link, RPK_WAVE, 1) X(link_bodylink, RPK_NL_DEEP, 1)
 
 struct RpLayout {
   enum : int {
@@ -137,6 +140,9 @@ struct RpState {
   // predicted cost (longest-processing-time-first: with one wave per env and four sequential
   // rounds per SIMD, a heavy env that starts last is the tail of the whole launch)
   const int* order;
+  // may be null: shader-clock cycles (>> 8) every env's wave spent in its last position stage /
+  // solver stage -- the cost predictor of the ordered launch
+  int *cost_pos, *cost_sol;
 };
 
 // One workgroup == one wavefront, and a wave's LDS instructions execute in issue
@@ -170,7 +176,7 @@ struct RpState {
 #define RPK_NLI 12  // per-lane int fields
 template <typename T>
 struct RpStage {
-  T* RM;      // [E][RPK_NL][RPK_MAXD+1] mass-matrix rows
+  T* RM;      // [E][RPK_NLX(MD)][MD+1] mass-matrix rows (MD = RPK_MAXD or RPK_MAXD_DEEP, the build in use)
   T* lanef;   // [E][RPK_NLF][64]
   int* lanei; // [E][RPK_NLI][64]
   int* hdr;   // [E][8]: ncon, nkt, dirty mask lo/hi, nent, max entries per contact

@@ -113,8 +113,23 @@ __device__ __forceinline__ int sphere_box_local(RawCon<T>* c, const T* p, T r, c
   return 1;
 }
 
-// capsule (geom1) vs box (geom2): closest axis point (exact root of the piecewise
-// linear distance derivative) plus both segment ends.
+// signed distance of a sphere (local centre p, radius r) to the box of half sizes h
+template <typename T>
+__device__ __forceinline__ T sphere_box_dist(const T* p, T r, const T* h) {
+  T d2 = 0, best = (T)-1e30;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const T q = p[k] > h[k] ? h[k] : (p[k] < -h[k] ? -h[k] : p[k]);
+    d2 += (p[k] - q) * (p[k] - q);
+    const T pen = Num<T>::abs(p[k]) - h[k];
+    if (pen > best) best = pen;
+  }
+  return (d2 > 0 ? Num<T>::sqrt(d2) : best) - r;
+}
+
+// capsule (geom1) vs box (geom2), at most two contacts [MJ: mjc_CapsuleBox's contract]: the axis point
+// closest to the box (exact root of the piecewise linear distance derivative), then the segment end
+// that lies deeper in / closer to the box.
 template <typename T>
 __device__ int capsule_box(RawCon<T>* out, const T* cp, const T* cm, const T* cs, const T* bp,
                            const T* bm, const T* bs) {
@@ -148,10 +163,20 @@ __device__ int capsule_box(RawCon<T>* out, const T* cp, const T* cm, const T* cs
     else if (gr - gl > 0) tstar = tl + (tr - tl) * (-gl) / (gr - gl);
     else tstar = tl;
   }
+  // the deeper end (ties: the -1 end); if it is t* itself, the other one
+  T dend[2];
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const T te = e ? (T)1 : (T)-1;
+    T p[3] = {c[0] + te * a[0], c[1] + te * a[1], c[2] + te * a[2]};
+    dend[e] = sphere_box_dist(p, r, bs);
+  }
+  T tend = dend[0] <= dend[1] ? (T)-1 : (T)1;
+  if (Num<T>::abs(tend - tstar) < (T)1e-9) tend = -tend;
   int n = 0;
 #pragma unroll
-  for (int i = 0; i < 3; i++) {
-    T tc = i == 0 ? tstar : (i == 1 ? (T)-1 : (T)1);
+  for (int i = 0; i < 2; i++) {
+    T tc = i == 0 ? tstar : tend;
     if (i > 0 && Num<T>::abs(tc - tstar) < (T)1e-9) continue;
     T p[3] = {c[0] + tc * a[0], c[1] + tc * a[1], c[2] + tc * a[2]};
     RawCon<T> rc;
@@ -163,6 +188,210 @@ __device__ int capsule_box(RawCon<T>* out, const T* cp, const T* cm, const T* cs
       mat_vec(wc.n, bm, rc.n);
       wc.dist = rc.dist;
       put_con(out, n, wc);
+    }
+  }
+  return n;
+}
+// ---------------------------------------------------------------------------------------------
+// box (geom1) vs box (geom2) [MJ: mjc_BoxBox's contract]: separating-axis test over the 15 axes; a
+// face axis of least penetration -> the part of the other box's facing face inside the reference
+// face's prism (its vertices, the reference corners under it, the edge crossings), all with the face
+// normal; an edge-edge axis -> one contact at the closest points of the two edges.  Position midway
+// between the surfaces, dist = -penetration, normal from geom1 to geom2.  The three deepest points
+// are kept (contact slots per geom pair).  Not inlined: the position kernel is register-bound and
+// box-box pairs are rare; nothing here indexes a register array dynamically.
+template <typename T> __device__ __forceinline__ T pick3(T a0, T a1, T a2, int i) { return i == 0 ? a0 : (i == 1 ? a1 : a2); }
+
+template <typename T>
+__device__ __forceinline__ void bb_keep(RawCon<T>* out, int& n, const T* pos, const T* nrm, T dist) {
+  RawCon<T> c;
+  c.dist = dist;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { c.pos[k] = pos[k]; c.n[k] = nrm[k]; }
+  // sorted insertion into (out[0] <= out[1] <= out[2]) by dist, first come first on ties
+  const bool v0 = n > 0, v1 = n > 1, v2 = n > 2;
+  if (!v0 || c.dist < out[0].dist) { out[2] = out[1]; out[1] = out[0]; out[0] = c; }
+  else if (!v1 || c.dist < out[1].dist) { out[2] = out[1]; out[1] = c; }
+  else if (!v2 || c.dist < out[2].dist) { out[2] = c; }
+  if (n < 3) n++;
+}
+
+template <typename T>
+__device__ __noinline__ int box_box(RawCon<T>* out, const T* p1, const T* m1, const T* s1, const T* p2,
+                                    const T* m2, const T* s2) {
+  using N = Num<T>;
+  T R[3][3], Q[3][3], t[3], tb[3];
+  const T d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    t[i] = m1[i] * d[0] + m1[3 + i] * d[1] + m1[6 + i] * d[2];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      R[i][j] = m1[i] * m2[j] + m1[3 + i] * m2[3 + j] + m1[6 + i] * m2[6 + j];
+      Q[i][j] = N::abs(R[i][j]) + (T)1e-12;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++) tb[j] = t[0] * R[0][j] + t[1] * R[1][j] + t[2] * R[2][j];
+  T best = (T)-1e30, sgn = 1;
+  int code = -1;
+  bool separated = false;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const T sep = N::abs(t[i]) - (s1[i] + s2[0] * Q[i][0] + s2[1] * Q[i][1] + s2[2] * Q[i][2]);
+    separated = separated || sep > (T)0;
+    if (sep > best) { best = sep; code = i; sgn = t[i] >= 0 ? (T)1 : (T)-1; }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const T sep = N::abs(tb[j]) - (s2[j] + s1[0] * Q[0][j] + s1[1] * Q[1][j] + s1[2] * Q[2][j]);
+    separated = separated || sep > (T)0;
+    if (sep > best) { best = sep; code = 3 + j; sgn = tb[j] >= 0 ? (T)1 : (T)-1; }
+  }
+  T ebest = (T)-1e30, esgn = 1, einv = 0;
+  int ecode = -1;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      constexpr int dummy = 0; (void)dummy;
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const T l2 = R[i1][j] * R[i1][j] + R[i2][j] * R[i2][j];
+      const bool ok = l2 >= (T)1e-12;            // parallel edges are covered by the face axes
+      const T inv = (T)1 / N::sqrt(ok ? l2 : (T)1);
+      const T tl = (t[i2] * R[i1][j] - t[i1] * R[i2][j]) * inv;
+      const T ra = (s1[i1] * Q[i2][j] + s1[i2] * Q[i1][j]) * inv;
+      const T rb = (s2[j1] * Q[i][j2] + s2[j2] * Q[i][j1]) * inv;
+      const T sep = N::abs(tl) - ra - rb;
+      separated = separated || (ok && sep > (T)0);
+      if (ok && sep > ebest) { ebest = sep; ecode = 3 * i + j; esgn = tl >= 0 ? (T)1 : (T)-1; einv = inv; }
+    }
+  }
+  if (separated) return 0;
+  int n = 0;
+  // a face axis wins unless the edge axis is clearly better (5 % bias, as is customary)
+  if (ecode >= 0 && ebest > best + (T)1e-9 + (T)0.05 * N::abs(best)) {
+    const int i = ecode / 3, j = ecode - 3 * i;
+    const T ua[3] = {pick3(m1[0], m1[1], m1[2], i), pick3(m1[3], m1[4], m1[5], i), pick3(m1[6], m1[7], m1[8], i)};
+    const T ub[3] = {pick3(m2[0], m2[1], m2[2], j), pick3(m2[3], m2[4], m2[5], j), pick3(m2[6], m2[7], m2[8], j)};
+    T nrm[3];
+    cross3(nrm, ua, ub);
+#pragma unroll
+    for (int k = 0; k < 3; k++) nrm[k] *= esgn * einv;    // from geom1 to geom2
+    T pa[3] = {p1[0], p1[1], p1[2]}, pb[3] = {p2[0], p2[1], p2[2]};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const T ak[3] = {m1[k], m1[3 + k], m1[6 + k]}, bk[3] = {m2[k], m2[3 + k], m2[6 + k]};
+      const T sa = k != i ? (dot3(nrm, ak) >= 0 ? s1[k] : -s1[k]) : (T)0;
+      const T sb = k != j ? (dot3(nrm, bk) >= 0 ? -s2[k] : s2[k]) : (T)0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) { pa[c] += sa * ak[c]; pb[c] += sb * bk[c]; }
+    }
+    const T w[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+    const T uaub = dot3(ua, ub), q1 = dot3(ua, w), q2 = -dot3(ub, w), den = (T)1 - uaub * uaub;
+    T alpha = 0, beta = 0;
+    if (den > (T)1e-12) { alpha = (q1 + uaub * q2) / den; beta = (uaub * q1 + q2) / den; }
+    const T la = pick3(s1[0], s1[1], s1[2], i), lb = pick3(s2[0], s2[1], s2[2], j);
+    alpha = fmin(la, fmax(-la, alpha)); beta = fmin(lb, fmax(-lb, beta));
+    T pos[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) pos[c] = (T)0.5 * ((pa[c] + alpha * ua[c]) + (pb[c] + beta * ub[c]));
+    bb_keep(out, n, pos, nrm, ebest);
+    return n;
+  }
+  // ---- face contact.  Reference frame (zr = fs * face axis towards the other box, ur, vr) and the
+  // incident box (centre ci, scaled axes) are built with selects, never with dynamic indices.
+  const bool refA = code < 3;
+  const int ax = refA ? code : code - 3;
+  const T* pr = refA ? p1 : p2; const T* mr = refA ? m1 : m2; const T* sr = refA ? s1 : s2;
+  const T* pi = refA ? p2 : p1; const T* mi = refA ? m2 : m1; const T* si = refA ? s2 : s1;
+  const T fs = refA ? sgn : -sgn;
+  const int au = (ax + 1) % 3, av = (ax + 2) % 3;
+  T zr[3], ur[3], vr[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    zr[c] = fs * pick3(mr[3 * c], mr[3 * c + 1], mr[3 * c + 2], ax);
+    ur[c] = pick3(mr[3 * c], mr[3 * c + 1], mr[3 * c + 2], au);
+    vr[c] = pick3(mr[3 * c], mr[3 * c + 1], mr[3 * c + 2], av);
+  }
+  const T h = pick3(sr[0], sr[1], sr[2], ax), hu = pick3(sr[0], sr[1], sr[2], au), hv = pick3(sr[0], sr[1], sr[2], av);
+  const T dd[3] = {pi[0] - pr[0], pi[1] - pr[1], pi[2] - pr[2]};
+  const T ci[3] = {dot3(ur, dd), dot3(vr, dd), dot3(zr, dd)};   // (u, v, z) of the incident centre
+  // incident box axes in (u, v, z), scaled by the half sizes
+  T E[3][3];
+  T zabs[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const T ek[3] = {mi[k], mi[3 + k], mi[6 + k]};
+    E[k][0] = si[k] * dot3(ur, ek); E[k][1] = si[k] * dot3(vr, ek); E[k][2] = si[k] * dot3(zr, ek);
+    zabs[k] = N::abs(dot3(zr, ek));
+  }
+  // incident face: the face most anti-parallel to zr (first maximum)
+  const int ia = (zabs[0] >= zabs[1] && zabs[0] >= zabs[2]) ? 0 : (zabs[1] >= zabs[2] ? 1 : 2);
+  const int iu = (ia + 1) % 3, iv = (ia + 2) % 3;
+  T Ea[3], Eu[3], Ev[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    Ea[c] = pick3(E[0][c], E[1][c], E[2][c], ia);
+    Eu[c] = pick3(E[0][c], E[1][c], E[2][c], iu);
+    Ev[c] = pick3(E[0][c], E[1][c], E[2][c], iv);
+  }
+  const T isg = Ea[2] > 0 ? (T)-1 : (T)1;       // the face whose outward normal opposes zr
+  const T fc[3] = {ci[0] + isg * Ea[0], ci[1] + isg * Ea[1], ci[2] + isg * Ea[2]};
+  T nrm[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) nrm[k] = refA ? zr[k] : -zr[k];
+  auto emit = [&](T cu, T cv, T zz) {
+    const T depth = h - zz;
+    if (depth >= (T)0) {
+      const T zc = zz + (T)0.5 * depth;
+      T pos[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) pos[k] = pr[k] + ur[k] * cu + vr[k] * cv + zr[k] * zc;
+      bb_keep(out, n, pos, nrm, -depth);
+    }
+  };
+  T q[4][3];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const T su = (c == 0 || c == 3) ? (T)-1 : (T)1, sv = c < 2 ? (T)-1 : (T)1;
+#pragma unroll
+    for (int a = 0; a < 3; a++) q[c][a] = fc[a] + su * Eu[a] + sv * Ev[a];
+  }
+  // (a) incident vertices inside the reference face's prism
+#pragma unroll
+  for (int c = 0; c < 4; c++)
+    if (N::abs(q[c][0]) <= hu && N::abs(q[c][1]) <= hv) emit(q[c][0], q[c][1], q[c][2]);
+  // (b) reference corners under the incident face (a parallelogram in (u, v))
+  const T det = Eu[0] * Ev[1] - Eu[1] * Ev[0];
+  if (N::abs(det) > (T)1e-14) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const T cu = (c == 0 || c == 3) ? -hu : hu, cv = c < 2 ? -hv : hv;
+      const T ru = cu - fc[0], rv = cv - fc[1];
+      const T a = (ru * Ev[1] - rv * Ev[0]) / det, b = (Eu[0] * rv - Eu[1] * ru) / det;
+      if (N::abs(a) <= (T)1 && N::abs(b) <= (T)1) emit(cu, cv, fc[2] + a * Eu[2] + b * Ev[2]);
+    }
+  }
+  // (c) crossings of the incident face's edges with the reference rectangle's edges
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const T* qa = q[c];
+    const T* qb = q[(c + 1) % 4];
+#pragma unroll
+    for (int side = 0; side < 4; side++) {
+      const int cax = side < 2 ? 0 : 1, oax = 1 - cax;
+      const T hh = side < 2 ? hu : hv, ho = side < 2 ? hv : hu;
+      const T lim = (side & 1) ? hh : -hh;
+      const T da = qa[cax] - lim, db = qb[cax] - lim;
+      if ((da < 0) != (db < 0) && da != db) {
+        const T tt = da / (da - db);
+        const T oc = qa[oax] + tt * (qb[oax] - qa[oax]);
+        if (N::abs(oc) <= ho) {
+          const T zz = qa[2] + tt * (qb[2] - qa[2]);
+          if (side < 2) emit(lim, oc, zz); else emit(oc, lim, zz);
+        }
+      }
     }
   }
   return n;

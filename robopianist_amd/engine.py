@@ -25,7 +25,7 @@ LIB_PATH = os.environ.get("RP_ENGINE_LIB") or os.path.join(_HERE, "csrc", "librp
 # rp_field
 QPOS, QVEL, QACC_WARMSTART, CTRL, QFRC_APPLIED, ACT_FORCE, ACT_VELOCITY, SITE_XPOS, \
     TIME, NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER, CONTACT_DIST, TREE_OFFSET, ACTIVE, \
-    SENSOR_TORQUE, SENSOR_TOUCH = range(18)
+    SENSOR_TORQUE, SENSOR_TOUCH, ENV_COST = range(19)
 MAX_CONTACTS = 32
 
 WARN_BADSTATE = 1
@@ -136,8 +136,9 @@ class BatchedPhysics:
             SITE_XPOS: (self.nsite, 3), TIME: (), NCON: (), CONTACT_GEOMS: (MAX_CONTACTS, 2),
             WARN_FLAGS: (), SOLVER_ITER: (), CONTACT_DIST: (MAX_CONTACTS,),
             TREE_OFFSET: (self.ntree, 3), ACTIVE: (), SENSOR_TORQUE: (self.nv,), SENSOR_TOUCH: (self.nsite,),
+            ENV_COST: (),
         }
-        self._int_fields = {NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER, ACTIVE}
+        self._int_fields = {NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER, ACTIVE, ENV_COST}
         if self_check is None:
             self_check = os.environ.get("RP_SKIP_SELF_CHECK", "0") != "1"
         if self_check:

@@ -417,9 +417,6 @@ def compile_scene(scene: spec.Scene) -> Model:
             a, b = g1, g2
             if m.geom_type[a] > m.geom_type[b]:
                 a, b = b, a
-            if m.geom_type[a] == spec.GEOM_BOX and m.geom_type[b] == spec.GEOM_BOX:
-                dropped_boxbox += 1
-                continue
             pairs.append((min(b1, b2), max(b1, b2), a, b))
     pairs.sort()
     m["pair_geom"] = np.asarray([(p[2], p[3]) for p in pairs], np.int32).reshape(-1, 2)

@@ -174,8 +174,9 @@ def test_teacher_forced_fp64_other_topologies():
     """Scenes whose trees differ from the benchmark's (two hands, 4-link trunks): one hand
     only, hands without forearm dofs (2-link trunks -> the generic, not the
     trunk-specialised, solver build), the reduced action space (welded finger segments), hinge
-    forearm dofs.  (More than two forearm dofs are rejected by rp_create: the solver's
-    register-blocked trunk holds at most 4 links.)  Same 1e-9 teacher-forced bar."""
+    forearm dofs, and more than two forearm dofs -- up to all six of
+    robopianist/models/hands/shadow_hand.py:41-69, i.e. trunks of 5..8 links, which run on the deep
+    (RPK_MAXD_DEEP) kernel builds.  Same 1e-9 teacher-forced bar."""
     import warnings
     from robopianist_amd.model import scene
     with warnings.catch_warnings():
@@ -195,18 +196,20 @@ def test_teacher_forced_fp64_other_topologies():
             "reduced, left hand, tz + yaw": scene.build_scene(
                 hands=("left",), reduced_action_space=True, gravity_compensation=True,
                 primitive_fingertip_collisions=True, forearm_dofs=("forearm_tz", "forearm_yaw")),
+            "three forearm dofs, reduced": scene.build_scene(
+                reduced_action_space=True, gravity_compensation=True, primitive_fingertip_collisions=True,
+                forearm_dofs=("forearm_tx", "forearm_ty", "forearm_yaw")),
+            "all six forearm dofs": scene.build_scene(
+                gravity_compensation=True, primitive_fingertip_collisions=True,
+                forearm_dofs=("forearm_tx", "forearm_ty", "forearm_tz", "forearm_roll", "forearm_pitch", "forearm_yaw")),
+            "left hand, five forearm dofs": scene.build_scene(
+                hands=("left",), gravity_compensation=True, primitive_fingertip_collisions=True,
+                forearm_dofs=("forearm_ty", "forearm_tz", "forearm_roll", "forearm_pitch", "forearm_yaw")),
         }
     for name, si in scenes.items():
         worst, maxcon = teacher_forced(si, 64, ctrl_sequence(si.model, 200, 3))
         print(f"{name}: worst rel dv {worst:.2e}, max contacts {maxcon}, nv {si.model.nv}")
         assert worst < 1e-9, name
-    from robopianist_amd import engine
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        si = scene.build_scene(reduced_action_space=True, primitive_fingertip_collisions=True,
-                               forearm_dofs=("forearm_tx", "forearm_ty", "forearm_yaw"))
-    with pytest.raises(engine.EngineError, match="trunk chain"):
-        engine.BatchedPhysics(si.model, si.key_joint_ids, n_envs=1)
 
 
 def test_teacher_forced_fp64_many_contacts(two_hand_scene):
@@ -402,3 +405,46 @@ def test_joints_torque_and_fingertip_force_observables():
         force = max(force, float(obs["rh_shadow_hand/fingertip_force"].max()), float(obs["lh_shadow_hand/fingertip_force"].max()))
     assert float(obs["rh_shadow_hand/joints_torque"].abs().max()) > 1e-3
     assert force > 0.0, "curled fingers must press on the keys"
+
+
+def test_teacher_forced_fp64_with_box_box_contacts(two_hand_scene):
+    """Box-box narrow phase (forearm box on the own palm's boxes, palm on palm when the hands are
+    driven into each other) in the engine against the oracle: same contact counts, 1e-9 per step."""
+    from robopianist_amd import engine
+    from robopianist_amd.model import spec
+    si = two_hand_scene
+    m = si.model
+    names = m.names["actuator"]
+    lo, hi = m.actuator_ctrlrange[:, 0], m.actuator_ctrlrange[:, 1]
+    rng = np.random.default_rng(11)
+
+    def ctrl_for(txr, txl, wr):
+        c = np.clip(0.0, lo, hi)
+        for a, n in enumerate(names):
+            s = n.split("/")[-1]
+            if s == "forearm_tx":
+                c[a] = txr if n.startswith("rh") else txl
+            elif s == "forearm_ty":
+                c[a] = 0.03
+            elif s.endswith("WRJ2") or s.endswith("WRJ1"):
+                c[a] = np.clip(wr * (1 if n.startswith("rh") else -1), lo[a], hi[a])
+        return c
+    phases = [ctrl_for(-0.3, 0.0, 0.0)] * 120 + [ctrl_for(-0.15, 0.15, 0.4)] * 120 + [ctrl_for(-0.05, 0.25, -0.3)] * 120
+    phys, orc = make_pair(si, 64)
+    worst, boxbox, maxcon = 0.0, 0, 0
+    for c in phases:
+        c = np.clip(c + rng.normal(0, 0.02, m.nu) * (hi - lo), lo, hi)
+        phys.set(engine.QPOS, orc.qpos[None, :]); phys.set(engine.QVEL, orc.qvel[None, :])
+        phys.set(engine.QACC_WARMSTART, orc.qacc_warmstart[None, :])
+        phys.set(engine.CTRL, c[None, :]); orc.ctrl[:] = c
+        v0 = orc.qvel.copy()
+        phys.step(1); orc.step(1)
+        dv = np.abs(phys.qvel[0].astype(np.float64) - orc.qvel).max()
+        worst = max(worst, dv / max(np.abs(orc.qvel - v0).max(), 1e-9))
+        assert phys.get(engine.NCON)[0] == orc.ncon
+        con = orc.contact.reshape(-1, 16)
+        boxbox += sum(1 for cc in con if m.geom_type[int(cc[13])] == spec.GEOM_BOX and m.geom_type[int(cc[14])] == spec.GEOM_BOX)
+        maxcon = max(maxcon, orc.ncon)
+    print(f"box-box: {boxbox} box-box contacts over {len(phases)} steps, max contacts {maxcon}, worst rel dv {worst:.2e}")
+    assert boxbox >= 50 and (phys.warn_flags.max() & ~engine.WARN_CONTACT_FULL) == 0
+    assert worst < 1e-9

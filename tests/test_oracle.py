@@ -284,3 +284,81 @@ def test_touch_sensor_sums_the_normal_forces_inside_the_fingertip_zone(two_hand_
         np.testing.assert_allclose(o.sensor_touch, want, rtol=1e-12, atol=1e-12)
         hits += int((want > 0).sum())
     assert hits >= 1, "no fingertip touched anything in these rollouts"
+
+
+# ---- box-box narrow phase (known answers on a two-box scene) ---------------------------------------
+def _two_box_scene(top_quat=(1, 0, 0, 0), hinges=()):
+    """A 4 x 4 x 2 cm box on a vertical slide (plus optional hinges) above a static 10 x 10 x 2 cm box."""
+    from robopianist_amd.model import spec
+    world = spec.Body(name="world")
+    world.geoms.append(spec.Geom("floor_box", spec.GEOM_BOX, (0.05, 0.05, 0.01), pos=(0, 0, 0.01)))
+    joints = [spec.Joint("z", type=spec.JNT_SLIDE, axis=(0, 0, 1), damping=0.5)]
+    for i, ax in enumerate(hinges):
+        joints.append(spec.Joint(f"h{i}", type=spec.JNT_HINGE, axis=ax, damping=0.01))
+    top = spec.Body(name="top", pos=(0, 0, 0.05), quat=top_quat, joints=joints,
+                    geoms=[spec.Geom("top_box", spec.GEOM_BOX, (0.02, 0.02, 0.01), mass=0.1)])
+    world.add(top)
+    sc = spec.Scene(world=world)
+    m = mc.compile_scene(sc)
+    return m, Oracle(m, mc.to_blob(m))
+
+
+def test_box_on_box_face_contact_settles():
+    m, o = _two_box_scene()
+    assert m.npair == 1
+    o.step(600)
+    con = o.contact.reshape(-1, 16)
+    assert o.ncon == 3                                    # deepest three of the four face corners
+    np.testing.assert_allclose(con[:, 4:7], np.tile([0, 0, 1.0], (3, 1)), atol=1e-12)   # floor (geom1) -> top
+    # rest: top box centre at 0.02 + 0.01 - penetration, a soft-contact penetration of well under 1 mm
+    z = 0.05 + o.qpos[0]
+    assert 0.0290 < z < 0.0300 and abs(o.qvel[0]) < 1e-6
+    np.testing.assert_allclose(con[:, 0], z - 0.03, atol=1e-12)      # dist = -penetration
+    assert set(map(tuple, np.round(np.abs(con[:, 1:3]), 12))) == {(0.02, 0.02)}      # corners of the small face
+    np.testing.assert_allclose(con[:, 3], 0.02 + 0.5 * (z - 0.03), atol=1e-12)       # midway between the surfaces
+    # static balance: the contact normal forces carry the weight
+    f = o.efc_force[o.nefc - 4 * o.ncon:].sum()
+    assert f == pytest.approx(0.1 * 9.81, rel=1e-3)
+
+
+def test_box_box_rotated_face_and_edge_edge_cases():
+    # (1) top box turned 45 degrees about z: its four corners still lie inside the floor face
+    c, s_ = np.cos(np.pi / 8), np.sin(np.pi / 8)
+    m, o = _two_box_scene(top_quat=(c, 0, 0, s_))
+    o.qpos[0] = -0.0205; o.forward()
+    con = o.contact.reshape(-1, 16)
+    assert o.ncon == 3 and np.allclose(con[:, 0], -0.0005)
+    r = np.hypot(con[:, 1], con[:, 2])
+    np.testing.assert_allclose(r, 0.02 * np.sqrt(2), atol=1e-12)
+    # (2) a big top face over a small floor: the reference corners / crossings come from the other box
+    m, o = _two_box_scene(hinges=((1, 0, 0),))
+    o.qpos[0] = -0.0202; o.qpos[1] = 0.3; o.forward()       # tilted about x: one edge of the top box digs in
+    con = o.contact.reshape(-1, 16)
+    assert 1 <= o.ncon <= 3 and np.all(con[:, 0] <= 0)
+    np.testing.assert_allclose(con[:, 4:7], np.tile([0, 0, 1.0], (o.ncon, 1)), atol=1e-12)
+    assert np.all(con[:, 2] < 0)                              # the lowered edge is on the -y side
+    # (3) edge against edge: top box rolled 45 deg about x and yawed 90 deg - its lowest edge (along x
+    # after the yaw... along y) crosses the floor's top edge region -> single contact, normal = +-(e1 x e2)
+    from robopianist_amd.model import spec
+    world = spec.Body(name="world")
+    world.geoms.append(spec.Geom("floor_box", spec.GEOM_BOX, (0.05, 0.05, 0.01), pos=(0, 0, 0.01),
+                                 quat=tuple(spec.axis_angle_to_quat(np.array([0.0, 1.0, 0.0]), np.pi / 4))))
+    xr = -0.04 / np.sqrt(2)      # world x of the floor box's top ridge (it runs along y)
+    top = spec.Body(name="top", pos=(xr, 0, 0.05), mass=0.1, inertia=(1e-4, 1e-4, 1e-4),
+                    joints=[spec.Joint("z", type=spec.JNT_SLIDE, axis=(0, 0, 1))],
+                    geoms=[spec.Geom("top_box", spec.GEOM_BOX, (0.02, 0.02, 0.01),
+                                     quat=tuple(spec.axis_angle_to_quat(np.array([1.0, 0.0, 0.0]), np.pi / 4)))])
+    world.add(top)
+    m = mc.compile_scene(spec.Scene(world=world))
+    o = Oracle(m, mc.to_blob(m))
+    # floor box rotated about y: its top ridge runs along y at height 0.01 + (0.05 + 0.01)/sqrt(2); the top
+    # box's lowest ridge runs along x at 0.05 + q - (0.02 + 0.01)/sqrt(2)
+    ridge = 0.01 + 0.06 / np.sqrt(2)
+    low0 = 0.05 - 0.03 / np.sqrt(2)
+    o.qpos[0] = ridge - low0 - 0.001; o.forward()            # 1 mm of penetration, ridge on ridge
+    con = o.contact.reshape(-1, 16)
+    assert o.ncon == 1
+    np.testing.assert_allclose(con[0, 0], -0.001, atol=1e-12)
+    np.testing.assert_allclose(con[0, 4:7], [0, 0, 1.0], atol=1e-12)
+    # the top box's lowest ridge runs along x at world y = -0.01 / sqrt(2)
+    np.testing.assert_allclose(con[0, 1:4], [xr, -0.01 / np.sqrt(2), ridge - 0.0005], atol=1e-12)
