@@ -122,7 +122,7 @@ struct Blob {
 struct EngineBase {
   virtual ~EngineBase() {}
   int nenv = 0, device = 0, precision = 32;
-  int nv = 0, nu = 0, nsite = 0, ntree = 0, nkey = 0, nlink = 0;
+  int nv = 0, nu = 0, nsite = 0, ntree = 0, nkey = 0, nlink = 0, maxdepth = 0;
   hipStream_t stream = nullptr;
   // ring of HIP event pairs bracketing every step-kernel launch on `stream`
   static const int kRing = 128;
@@ -207,7 +207,7 @@ struct Engine : EngineBase {
   void build(const Blob& b, int n_envs) {
     nenv = n_envs;
     M.nlink = nlink = b.i1("eng_nlink"); M.ntree = ntree = b.i1("eng_ntree");
-    M.maxdepth = b.i1("eng_maxdepth"); M.nkey = nkey = b.i1("eng_nkey");
+    M.maxdepth = maxdepth = b.i1("eng_maxdepth"); M.nkey = nkey = b.i1("eng_nkey");
     M.ngeom = b.i1("eng_ngeom");
     M.nu = nu = b.i1("eng_nu"); M.nsite = nsite = b.i1("eng_nsite"); M.nv = nv = b.i1("nv");
     if (M.nlink > RPK_NL_DEEP) throw std::string("too many hand dofs for the engine (max 60)");
@@ -260,6 +260,7 @@ struct Engine : EngineBase {
         if (tt[t] != 4) trunk4 = false;
         if (tt[t] > 4) deep = true;   // (the register-blocked trunk of the default build holds 4 links)
       }
+      if (getenv("RP_FORCE_DEEP")) { deep = true; trunk4 = false; }   // test hook: deep builds on any scene
     }
     for (int v : b.i("eng_chain_len")) if (v > 5) throw std::string("finger chain longer than 5 links is not supported by the solver");
     PF(link_lpos, "eng_link_lpos");
@@ -459,6 +460,7 @@ struct Engine : EngineBase {
       case RP_ACTIVE: *p = d_active; *bytes = sizeof(int) * E; *writable = true; return true;
       case RP_TREE_OFFSET: *p = S.tree_offset; *bytes = sizeof(T) * E * ntree * 3; *writable = true; return true;
       case RP_ENV_COST: *p = S.cost_sol; *bytes = sizeof(int) * E; return true;
+      case RP_DEBUG_MASS_ROWS: *p = B.RM; *bytes = sizeof(T) * E * RPK_NLX(md()) * (md() + 1); return true;
       case RP_SENSOR_TORQUE: if (!d_sens_torque) return false; *p = d_sens_torque; *bytes = sizeof(T) * E * nv; return true;
       case RP_SENSOR_TOUCH: if (!d_sens_touch) return false; *p = d_sens_touch; *bytes = sizeof(T) * E * nsite; return true;
     }
@@ -704,6 +706,7 @@ int rp_dim(const rp_engine* e, const char* name) {
   if (!strcmp(name, "ntree")) return b->ntree;
   if (!strcmp(name, "nkey")) return b->nkey;
   if (!strcmp(name, "nlink")) return b->nlink;
+  if (!strcmp(name, "maxdepth")) return b->maxdepth;
   if (!strcmp(name, "precision")) return b->precision;
   return -1;
 }

@@ -7,6 +7,19 @@
 #include "rp_narrow.hpp"
 #include "rp_dense.hpp"
 
+#ifdef RPK_NO_BOXBOX   // perf experiment: what the box-box routine costs the position kernel
+#define RPK_BOXBOX(...) 0
+#else
+// (the box-box routine is a real call: its arguments and result live in memory, so they are copies --
+// the capsule paths' own arrays stay in registers)
+#define RPK_BOXBOX(rc_, pA_, mA_, sA_, pB_, mB_, sB_) [&]() -> int {                            \
+    T a_[15], b_[15]; RawCon<T> o_[3];                                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < 3; i_++) { a_[i_] = (pA_)[i_]; b_[i_] = (pB_)[i_]; a_[12 + i_] = (sA_)[i_]; b_[12 + i_] = (sB_)[i_]; } \
+    _Pragma("unroll") for (int i_ = 0; i_ < 9; i_++) { a_[3 + i_] = (mA_)[i_]; b_[3 + i_] = (mB_)[i_]; }                     \
+    const int n_ = box_box(o_, a_, a_ + 3, a_ + 12, b_, b_ + 3, b_ + 12);                       \
+    (rc_)[0] = o_[0]; (rc_)[1] = o_[1]; (rc_)[2] = o_[2];                                       \
+    return n_; }()
+#endif
 namespace rpk {
 // ----------------------------------------------------------------- shared memory
 // LDS budget drives occupancy (fp64: 40.5 KB -> 4 workgroups per CU).  Scratch of the
@@ -118,7 +131,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
   const int lane = threadIdx.x;
   const int env_active = S.active ? S.active[env] : 1;  // tested after the prologue loads are in flight
   __shared__ Smem<T, MODE, MD> sm;
-  constexpr int TC = MD > MD ? 8 : 4;          // trunk links the chain-blocked solver holds
+  constexpr int TC = MD > 9 ? 8 : 4;            // trunk links the chain-blocked solver holds
   constexpr int NT = TC * (TC + 1) / 2, NREC = NT + TC;  // packed trunk block / per-chain record
 #ifdef RPK_POISON_LDS  // debug build: nothing may depend on what a previous workgroup left in LDS
   {
@@ -1518,7 +1531,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
           if (M.geom_type()[ga] == GEOM_CAPSULE_)
             n = capsule_box(rc, posA, mA, M.geom_size() + 3 * ga, bp, bm, M.key_half() + 3 * k);
           else
-            n = box_box(rc, posA, mA, M.geom_size() + 3 * ga, bp, bm, M.key_half() + 3 * k);
+            n = RPK_BOXBOX(rc, posA, mA, M.geom_size() + 3 * ga, bp, bm, M.key_half() + 3 * k);
 #pragma unroll
           for (int e = 0; e < 8; e++) pB[e] = M.key_cparam()[e];
           invw += M.key_invw_body()[k];
@@ -1535,7 +1548,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
           else if (M.geom_type()[ga] == GEOM_CAPSULE_)
             n = capsule_box(rc, posA, mA, M.geom_size() + 3 * ga, posB, mB, M.geom_size() + 3 * gb);
           else
-            n = box_box(rc, posA, mA, M.geom_size() + 3 * ga, posB, mB, M.geom_size() + 3 * gb);
+            n = RPK_BOXBOX(rc, posA, mA, M.geom_size() + 3 * ga, posB, mB, M.geom_size() + 3 * gb);
 #pragma unroll
           for (int e = 0; e < 8; e++) pB[e] = M.geom_cparam()[8 * gb + e];
           invw += M.geom_invw()[gb];

@@ -216,8 +216,11 @@ __device__ __forceinline__ void bb_keep(RawCon<T>* out, int& n, const T* pos, co
   if (n < 3) n++;
 }
 
+#ifndef RPK_BOXBOX_INLINE
+#define RPK_BOXBOX_INLINE __noinline__
+#endif
 template <typename T>
-__device__ __noinline__ int box_box(RawCon<T>* out, const T* p1, const T* m1, const T* s1, const T* p2,
+__device__ RPK_BOXBOX_INLINE int box_box(RawCon<T>* out, const T* p1, const T* m1, const T* s1, const T* p2,
                                     const T* m2, const T* s2) {
   using N = Num<T>;
   T R[3][3], Q[3][3], t[3], tb[3];
@@ -341,14 +344,15 @@ __device__ __noinline__ int box_box(RawCon<T>* out, const T* p1, const T* m1, co
   T nrm[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) nrm[k] = refA ? zr[k] : -zr[k];
+  // candidates are reduced on the fly to the three deepest (depth, u, v); ties: first come
+  T bd[3] = {(T)-1, (T)-1, (T)-1}, bu[3] = {0, 0, 0}, bv[3] = {0, 0, 0};
   auto emit = [&](T cu, T cv, T zz) {
     const T depth = h - zz;
     if (depth >= (T)0) {
-      const T zc = zz + (T)0.5 * depth;
-      T pos[3];
-#pragma unroll
-      for (int k = 0; k < 3; k++) pos[k] = pr[k] + ur[k] * cu + vr[k] * cv + zr[k] * zc;
-      bb_keep(out, n, pos, nrm, -depth);
+      const bool g0 = depth > bd[0], g1 = depth > bd[1], g2 = depth > bd[2];
+      bd[2] = g1 ? bd[1] : (g2 ? depth : bd[2]); bu[2] = g1 ? bu[1] : (g2 ? cu : bu[2]); bv[2] = g1 ? bv[1] : (g2 ? cv : bv[2]);
+      bd[1] = g0 ? bd[0] : (g1 ? depth : bd[1]); bu[1] = g0 ? bu[0] : (g1 ? cu : bu[1]); bv[1] = g0 ? bv[0] : (g1 ? cv : bv[1]);
+      bd[0] = g0 ? depth : bd[0]; bu[0] = g0 ? cu : bu[0]; bv[0] = g0 ? cv : bv[0];
     }
   };
   T q[4][3];
@@ -365,33 +369,50 @@ __device__ __noinline__ int box_box(RawCon<T>* out, const T* p1, const T* m1, co
   // (b) reference corners under the incident face (a parallelogram in (u, v))
   const T det = Eu[0] * Ev[1] - Eu[1] * Ev[0];
   if (N::abs(det) > (T)1e-14) {
+    const T idet = (T)1 / det;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
       const T cu = (c == 0 || c == 3) ? -hu : hu, cv = c < 2 ? -hv : hv;
       const T ru = cu - fc[0], rv = cv - fc[1];
-      const T a = (ru * Ev[1] - rv * Ev[0]) / det, b = (Eu[0] * rv - Eu[1] * ru) / det;
+      const T a = (ru * Ev[1] - rv * Ev[0]) * idet, b = (Eu[0] * rv - Eu[1] * ru) * idet;
       if (N::abs(a) <= (T)1 && N::abs(b) <= (T)1) emit(cu, cv, fc[2] + a * Eu[2] + b * Ev[2]);
     }
   }
-  // (c) crossings of the incident face's edges with the reference rectangle's edges
+  // (c) crossings of the incident face's edges with the reference rectangle's edges (one
+  // reciprocal per edge and axis)
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     const T* qa = q[c];
     const T* qb = q[(c + 1) % 4];
 #pragma unroll
-    for (int side = 0; side < 4; side++) {
-      const int cax = side < 2 ? 0 : 1, oax = 1 - cax;
-      const T hh = side < 2 ? hu : hv, ho = side < 2 ? hv : hu;
-      const T lim = (side & 1) ? hh : -hh;
-      const T da = qa[cax] - lim, db = qb[cax] - lim;
-      if ((da < 0) != (db < 0) && da != db) {
-        const T tt = da / (da - db);
-        const T oc = qa[oax] + tt * (qb[oax] - qa[oax]);
-        if (N::abs(oc) <= ho) {
-          const T zz = qa[2] + tt * (qb[2] - qa[2]);
-          if (side < 2) emit(lim, oc, zz); else emit(oc, lim, zz);
+    for (int cax = 0; cax < 2; cax++) {
+      const int oax = 1 - cax;
+      const T hh = cax == 0 ? hu : hv, ho = cax == 0 ? hv : hu;
+      const T dq = qb[cax] - qa[cax];
+      const T idq = (T)1 / (dq != (T)0 ? dq : (T)1);
+#pragma unroll
+      for (int sd = 0; sd < 2; sd++) {
+        const T lim = sd ? hh : -hh;
+        const T da = qa[cax] - lim, db = qb[cax] - lim;
+        if ((da < 0) != (db < 0) && dq != (T)0) {
+          const T tt = -da * idq;
+          const T oc = qa[oax] + tt * (qb[oax] - qa[oax]);
+          if (N::abs(oc) <= ho) {
+            const T zz = qa[2] + tt * (qb[2] - qa[2]);
+            if (cax == 0) emit(lim, oc, zz); else emit(oc, lim, zz);
+          }
         }
       }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    if (bd[i] >= (T)0) {
+      const T zc = h - (T)0.5 * bd[i];     // midway between the surfaces
+#pragma unroll
+      for (int k = 0; k < 3; k++) { out[i].pos[k] = pr[k] + ur[k] * bu[i] + vr[k] * bv[i] + zr[k] * zc; out[i].n[k] = nrm[k]; }
+      out[i].dist = -bd[i];
+      n = i + 1;
     }
   }
   return n;

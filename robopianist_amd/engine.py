@@ -25,7 +25,7 @@ LIB_PATH = os.environ.get("RP_ENGINE_LIB") or os.path.join(_HERE, "csrc", "librp
 # rp_field
 QPOS, QVEL, QACC_WARMSTART, CTRL, QFRC_APPLIED, ACT_FORCE, ACT_VELOCITY, SITE_XPOS, \
     TIME, NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER, CONTACT_DIST, TREE_OFFSET, ACTIVE, \
-    SENSOR_TORQUE, SENSOR_TOUCH, ENV_COST = range(19)
+    SENSOR_TORQUE, SENSOR_TOUCH, ENV_COST, DEBUG_MASS_ROWS = range(20)
 MAX_CONTACTS = 32
 
 WARN_BADSTATE = 1
@@ -138,6 +138,8 @@ class BatchedPhysics:
             TREE_OFFSET: (self.ntree, 3), ACTIVE: (), SENSOR_TORQUE: (self.nv,), SENSOR_TOUCH: (self.nsite,),
             ENV_COST: (),
         }
+        deep = self.dim("nlink") > 52 or self.dim("maxdepth") > 9
+        self._shapes[DEBUG_MASS_ROWS] = ((60, 14) if deep else (52, 10))
         self._int_fields = {NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER, ACTIVE, ENV_COST}
         if self_check is None:
             self_check = os.environ.get("RP_SKIP_SELF_CHECK", "0") != "1"
