@@ -679,9 +679,10 @@ static int capsule_box(rawcon* out, const double* cp, const double* cm, const do
  * points are kept (the engine has three contact slots per geom pair). */
 #define RPO_BOXBOX_MAX 3
 static void bb_keep(rawcon* out, int* n, const double* pos, const double* nrm, double dist) {
-  /* keep the deepest RPO_BOXBOX_MAX candidates, sorted by dist ascending (ties: first come) */
+  /* keep the deepest RPO_BOXBOX_MAX candidates, sorted by dist ascending; the corners of a face
+   * resting flat tie exactly, so depths within 1e-10 count as equal and the first comer wins */
   int at = *n;
-  for (int i = 0; i < *n; i++) if (dist < out[i].dist) { at = i; break; }
+  for (int i = 0; i < *n; i++) if (dist < out[i].dist - 1e-10) { at = i; break; }
   if (at >= RPO_BOXBOX_MAX) return;
   int last = *n < RPO_BOXBOX_MAX ? *n : RPO_BOXBOX_MAX - 1;
   for (int i = last; i > at; i--) out[i] = out[i-1];
@@ -713,7 +714,8 @@ static int box_box(rawcon* out, const double* p1, const double* m1, const double
   for (int j = 0; j < 3; j++) {
     double sep = fabs(tb[j]) - (s2[j] + s1[0]*Q[0][j] + s1[1]*Q[1][j] + s1[2]*Q[2][j]);
     if (sep > margin) return 0;
-    if (sep > best) { best = sep; code = 3 + j; sgn = tb[j] >= 0 ? 1 : -1; }
+    /* parallel faces tie exactly: geom1's face stays the reference unless geom2's is clearly better */
+    if (sep > best + 1e-10) { best = sep; code = 3 + j; sgn = tb[j] >= 0 ? 1 : -1; }
   }
   /* edge axes A_i x B_j (codes 6..14); normalised; a face axis wins unless the edge axis is
    * clearly better (5 % + 1e-9 bias), as is customary */

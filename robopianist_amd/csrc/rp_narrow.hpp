@@ -249,7 +249,8 @@ __device__ RPK_BOXBOX_INLINE int box_box(RawCon<T>* out, const T* p1, const T* m
   for (int j = 0; j < 3; j++) {
     const T sep = N::abs(tb[j]) - (s2[j] + s1[0] * Q[0][j] + s1[1] * Q[1][j] + s1[2] * Q[2][j]);
     separated = separated || sep > (T)0;
-    if (sep > best) { best = sep; code = 3 + j; sgn = tb[j] >= 0 ? (T)1 : (T)-1; }
+    // (parallel faces tie exactly: geom1's face stays the reference unless geom2's is clearly better)
+    if (sep > best + (T)1e-10) { best = sep; code = 3 + j; sgn = tb[j] >= 0 ? (T)1 : (T)-1; }
   }
   T ebest = (T)-1e30, esgn = 1, einv = 0;
   int ecode = -1;
@@ -349,7 +350,8 @@ __device__ RPK_BOXBOX_INLINE int box_box(RawCon<T>* out, const T* p1, const T* m
   auto emit = [&](T cu, T cv, T zz) {
     const T depth = h - zz;
     if (depth >= (T)0) {
-      const bool g0 = depth > bd[0], g1 = depth > bd[1], g2 = depth > bd[2];
+      // (the corners of a face resting flat tie exactly: depths within 1e-10 count as equal)
+      const bool g0 = depth > bd[0] + (T)1e-10, g1 = depth > bd[1] + (T)1e-10, g2 = depth > bd[2] + (T)1e-10;
       bd[2] = g1 ? bd[1] : (g2 ? depth : bd[2]); bu[2] = g1 ? bu[1] : (g2 ? cu : bu[2]); bv[2] = g1 ? bv[1] : (g2 ? cv : bv[2]);
       bd[1] = g0 ? bd[0] : (g1 ? depth : bd[1]); bu[1] = g0 ? bu[0] : (g1 ? cu : bu[1]); bv[1] = g0 ? bv[0] : (g1 ? cv : bv[1]);
       bd[0] = g0 ? depth : bd[0]; bu[0] = g0 ? cu : bu[0]; bv[0] = g0 ? cv : bv[0];
