@@ -42,6 +42,7 @@
 #define JNT_HINGE 3
 #define GEOM_CAPSULE 3
 #define GEOM_BOX 6
+#define GEOM_MESH 7
 #define TRN_JOINT 0
 #define TRN_TENDON 3
 
@@ -76,6 +77,8 @@ struct rpo_model {
   const int32_t *geom_type, *geom_bodyid, *geom_condim, *geom_priority;
   const double *geom_pos, *geom_quat, *geom_size, *geom_rbound, *geom_friction,
       *geom_solref, *geom_solimp, *geom_solmix, *geom_margin, *geom_gap;
+  const int32_t *geom_vertadr, *geom_vertnum;   /* GEOM_MESH: hull vertices (geom frame) */
+  const double* mesh_vert;
   const int32_t* site_bodyid;
   const double* site_pos;
   const double* site_touch_radius; /* > 0: the site is the zone of a touch sensor (sphere); may be NULL */
@@ -153,6 +156,10 @@ rpo_model* rpo_model_load(const void* blob, size_t nbytes) {
     m->geom_friction = BF("geom_friction"); m->geom_solref = BF("geom_solref");
     m->geom_solimp = BF("geom_solimp"); m->geom_solmix = BF("geom_solmix");
     m->geom_margin = BF("geom_margin"); m->geom_gap = BF("geom_gap");
+    if (blob_find(m, "geom_vertadr")) {
+      m->geom_vertadr = BI("geom_vertadr"); m->geom_vertnum = BI("geom_vertnum");
+      m->mesh_vert = blob_find(m, "mesh_vert") ? BF("mesh_vert") : NULL;
+    }
   }
   if (m->nsite) {
     m->site_bodyid = BI("site_bodyid"); m->site_pos = BF("site_pos");
@@ -843,6 +850,136 @@ static int box_box(rawcon* out, const double* p1, const double* m1, const double
   return n;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Convex pairs that involve a hull (GEOM_MESH).  MuJoCo sends these to libccd's Minkowski Portal
+ * Refinement [MEM: mjc_Convex -> ccdMPRPenetration; neither source is available here]: ONE contact per
+ * pair -- penetration depth, direction and a position from the portal's witness points.  Restated as a
+ * plain MPR (XenoCollide): portal discovery from the centre-to-centre ray, refinement until the
+ * support point in the portal's direction is within `CCD_TOL` of the portal, then
+ * depth = distance of the origin to the portal plane along its normal, normal = that direction (from
+ * geom1 to geom2), position = midpoint of the two witness points combined with the barycentric
+ * weights of the origin's ray through the portal.  Tolerance / iteration cap: MuJoCo's defaults
+ * (1e-6, 50). */
+#define CCD_TOL 1e-6
+#define CCD_ITER 50
+typedef struct { int type; const double *pos, *mat, *size; const double* vert; int nvert; } cgeom;
+typedef struct { double v[3], p1[3], p2[3]; } mpoint;   /* point of B - A, its witnesses on A and B */
+
+static void geom_support(const cgeom* g, const double* d, double* out) {   /* d: unit, world */
+  if (g->type == GEOM_CAPSULE) {
+    double ax[3] = {g->mat[2], g->mat[5], g->mat[8]}, sg = dot3(ax, d) >= 0 ? 1.0 : -1.0;
+    for (int k = 0; k < 3; k++) out[k] = g->pos[k] + sg*g->size[1]*ax[k] + g->size[0]*d[k];
+  } else if (g->type == GEOM_BOX) {
+    for (int k = 0; k < 3; k++) out[k] = g->pos[k];
+    for (int a = 0; a < 3; a++) {
+      double ax[3] = {g->mat[a], g->mat[3+a], g->mat[6+a]}, sg = dot3(ax, d) >= 0 ? 1.0 : -1.0;
+      for (int k = 0; k < 3; k++) out[k] += sg*g->size[a]*ax[k];
+    }
+  } else {
+    double dl[3]; matT_vec(dl, g->mat, d);
+    int best = 0; double bv = -1e300;
+    for (int i = 0; i < g->nvert; i++) { double v = dot3(dl, g->vert + 3*i); if (v > bv) { bv = v; best = i; } }
+    double w[3]; mat_vec(w, g->mat, g->vert + 3*best);
+    for (int k = 0; k < 3; k++) out[k] = g->pos[k] + w[k];
+  }
+}
+static void mpr_support(const cgeom* A, const cgeom* B, const double* d, mpoint* o) {
+  double nd[3] = {-d[0], -d[1], -d[2]};
+  geom_support(A, nd, o->p1); geom_support(B, d, o->p2);
+  for (int k = 0; k < 3; k++) o->v[k] = o->p2[k] - o->p1[k];
+}
+static int normalize3(double* v) { double n = norm3(v); if (n < 1e-14) return 0; v[0] /= n; v[1] /= n; v[2] /= n; return 1; }
+
+/* returns 1 and fills (dist <= 0, pos, normal) if A and B overlap */
+static int mpr_penetration(const cgeom* A, const cgeom* B, rawcon* out) {
+  mpoint v0, v1, v2, v3, v4;
+  double dir[3], t1[3], t2[3];
+  for (int k = 0; k < 3; k++) { v0.p1[k] = A->pos[k]; v0.p2[k] = B->pos[k]; v0.v[k] = B->pos[k] - A->pos[k]; }
+  if (norm3(v0.v) < 1e-10) v0.v[0] = 1e-5;
+  /* ---- portal discovery */
+  for (int k = 0; k < 3; k++) dir[k] = -v0.v[k];
+  normalize3(dir);
+  mpr_support(A, B, dir, &v1);
+  if (dot3(v1.v, dir) <= 0) return 0;
+  cross3(dir, v0.v, v1.v);
+  if (!normalize3(dir)) {
+    /* the origin lies on the ray v0 -> v1: penetration along that ray */
+    double n[3] = {v1.v[0] - v0.v[0], v1.v[1] - v0.v[1], v1.v[2] - v0.v[2]};
+    normalize3(n);
+    out->dist = -dot3(v1.v, n);
+    for (int k = 0; k < 3; k++) { out->normal[k] = -n[k]; out->pos[k] = 0.5*(v1.p1[k] + v1.p2[k]); }
+    return out->dist <= 0;
+  }
+  mpr_support(A, B, dir, &v2);
+  if (dot3(v2.v, dir) <= 0) return 0;
+  for (int k = 0; k < 3; k++) { t1[k] = v1.v[k] - v0.v[k]; t2[k] = v2.v[k] - v0.v[k]; }
+  cross3(dir, t1, t2); normalize3(dir);
+  if (dot3(dir, v0.v) > 0) { mpoint tmp = v1; v1 = v2; v2 = tmp; for (int k = 0; k < 3; k++) dir[k] = -dir[k]; }
+  for (int it = 0; ; it++) {
+    if (it > CCD_ITER) return 0;
+    mpr_support(A, B, dir, &v3);
+    if (dot3(v3.v, dir) <= 0) return 0;
+    cross3(t1, v1.v, v3.v);
+    if (dot3(t1, v0.v) < 0) {           /* origin outside (v1, v0, v3): replace v2 */
+      v2 = v3;
+      for (int k = 0; k < 3; k++) { t1[k] = v1.v[k] - v0.v[k]; t2[k] = v3.v[k] - v0.v[k]; }
+      cross3(dir, t1, t2); normalize3(dir);
+      continue;
+    }
+    cross3(t1, v3.v, v2.v);
+    if (dot3(t1, v0.v) < 0) {           /* origin outside (v3, v0, v2): replace v1 */
+      v1 = v3;
+      for (int k = 0; k < 3; k++) { t1[k] = v3.v[k] - v0.v[k]; t2[k] = v2.v[k] - v0.v[k]; }
+      cross3(dir, t1, t2); normalize3(dir);
+      continue;
+    }
+    break;
+  }
+  /* ---- portal refinement */
+  int hit = 0;
+  for (int it = 0; it <= CCD_ITER; it++) {
+    for (int k = 0; k < 3; k++) { t1[k] = v2.v[k] - v1.v[k]; t2[k] = v3.v[k] - v1.v[k]; }
+    cross3(dir, t1, t2);
+    if (!normalize3(dir)) return 0;
+    if (dot3(dir, v1.v) >= 0) hit = 1;   /* the origin is inside the portal */
+    mpr_support(A, B, dir, &v4);
+    double reach = dot3(v4.v, dir) - dot3(v1.v, dir);
+    if (!hit && dot3(v4.v, dir) < 0) return 0;             /* the origin lies beyond the support plane */
+    if (reach <= CCD_TOL || it == CCD_ITER) {
+      if (!hit) return 0;
+      /* penetration: depth along the portal normal, witnesses weighted by the origin's ray */
+      double depth = dot3(v1.v, dir);
+      double b[4], c[3];
+      cross3(c, v1.v, v2.v); b[0] = dot3(c, v3.v);
+      cross3(c, v3.v, v2.v); b[1] = dot3(c, v0.v);
+      cross3(c, v0.v, v1.v); b[2] = dot3(c, v3.v);
+      cross3(c, v2.v, v1.v); b[3] = dot3(c, v0.v);
+      double sum = b[0] + b[1] + b[2] + b[3];
+      if (sum <= 0) {
+        b[0] = 0;
+        cross3(c, v2.v, v3.v); b[1] = dot3(c, dir);
+        cross3(c, v3.v, v1.v); b[2] = dot3(c, dir);
+        cross3(c, v1.v, v2.v); b[3] = dot3(c, dir);
+        sum = b[1] + b[2] + b[3];
+      }
+      const mpoint* P[4] = {&v0, &v1, &v2, &v3};
+      double inv = 1.0 / sum;
+      for (int k = 0; k < 3; k++) {
+        double acc = 0;
+        for (int i = 0; i < 4; i++) acc += b[i] * 0.5 * (P[i]->p1[k] + P[i]->p2[k]);
+        out->pos[k] = acc * inv; out->normal[k] = -dir[k];   /* (the portal faces away from B - A's centre: geom1 -> geom2 is -dir) */
+      }
+      out->dist = -depth;
+      return 1;
+    }
+    /* expand the portal with v4 */
+    cross3(t1, v4.v, v0.v);
+    if (dot3(v1.v, t1) > 0) { if (dot3(v2.v, t1) > 0) v1 = v4; else v3 = v4; }
+    else { if (dot3(v3.v, t1) > 0) v2 = v4; else v1 = v4; }
+  }
+  return 0;
+}
+
 static void collision(const rpo_model* m, rpo_data* d) {
   d->ncon = 0;
   for (int ip = 0; ip < m->npair; ip++) {
@@ -864,6 +1001,12 @@ static void collision(const rpo_model* m, rpo_data* d) {
     else if (t1 == GEOM_BOX && t2 == GEOM_BOX)
       n = box_box(rc, p1, d->geom_xmat + 9*g1, m->geom_size + 3*g1, p2,
                   d->geom_xmat + 9*g2, m->geom_size + 3*g2, margin);
+    else if (t2 == GEOM_MESH && m->mesh_vert) {
+      cgeom A = {t1, p1, d->geom_xmat + 9*g1, m->geom_size + 3*g1,
+                 t1 == GEOM_MESH ? m->mesh_vert + 3*m->geom_vertadr[g1] : NULL, t1 == GEOM_MESH ? m->geom_vertnum[g1] : 0};
+      cgeom B = {t2, p2, d->geom_xmat + 9*g2, m->geom_size + 3*g2, m->mesh_vert + 3*m->geom_vertadr[g2], m->geom_vertnum[g2]};
+      n = mpr_penetration(&A, &B, rc);
+    }
     else continue;
     for (int i = 0; i < n; i++) {
       if (d->ncon >= MAXCON) { d->warnings |= 2; return; }

@@ -151,7 +151,8 @@ def compile_scene(scene: spec.Scene) -> Model:
                solref=[], solimp=[], fsolref=[], fsolimp=[], margin=[])
     geom = dict(type=[], bodyid=[], pos=[], quat=[], size=[], contype=[],
                 conaffinity=[], condim=[], friction=[], solref=[], solimp=[],
-                solmix=[], margin=[], gap=[], priority=[])
+                solmix=[], margin=[], gap=[], priority=[], vertadr=[], vertnum=[])
+    mesh_vert = []
     site_bodyid, site_pos, site_touch = [], [], []
 
     for i, b in enumerate(bodies):
@@ -203,6 +204,14 @@ def compile_scene(scene: spec.Scene) -> Model:
             geom["pos"].append(g.pos)
             geom["quat"].append(spec.quat_normalize(g.quat))
             size = list(g.size) + [0.0] * (3 - len(g.size))
+            if g.type == spec.GEOM_MESH:
+                v = np.asarray(g.vertices, float).reshape(-1, 3)
+                assert len(v) >= 4, "a hull needs at least four vertices"
+                size = list(np.abs(v).max(axis=0))          # half extents of the hull's box in the geom frame
+                geom["vertadr"].append(len(mesh_vert)); geom["vertnum"].append(len(v))
+                mesh_vert.extend(v.tolist())
+            else:
+                geom["vertadr"].append(-1); geom["vertnum"].append(0)
             geom["size"].append(size)
             for k in ("contype", "conaffinity", "condim", "friction", "solref",
                       "solimp", "solmix", "margin", "gap", "priority"):
@@ -284,6 +293,11 @@ def compile_scene(scene: spec.Scene) -> Model:
     m["geom_pos"] = arr(geom["pos"], shape=(ngeom, 3))
     m["geom_quat"] = arr(geom["quat"], shape=(ngeom, 4))
     m["geom_size"] = arr(geom["size"], shape=(ngeom, 3))
+    # convex hulls (GEOM_MESH): vertices in the geom frame
+    m["geom_vertadr"] = arr(geom["vertadr"], np.int32)
+    m["geom_vertnum"] = arr(geom["vertnum"], np.int32)
+    m["mesh_vert"] = arr(mesh_vert, shape=(len(mesh_vert), 3))
+    m["nmeshvert"] = len(mesh_vert)
     m["geom_contype"] = arr(geom["contype"], np.int32)
     m["geom_conaffinity"] = arr(geom["conaffinity"], np.int32)
     m["geom_condim"] = arr(geom["condim"], np.int32)
@@ -303,6 +317,9 @@ def compile_scene(scene: spec.Scene) -> Model:
             rb[g] = s[0] + s[1]
         elif t == spec.GEOM_BOX:
             rb[g] = np.linalg.norm(s)
+        elif t == spec.GEOM_MESH:
+            a, n_ = geom["vertadr"][g], geom["vertnum"][g]
+            rb[g] = np.linalg.norm(np.asarray(mesh_vert[a:a + n_]), axis=1).max()
         else:
             raise ValueError(f"unsupported geom type {t}")
     m["geom_rbound"] = rb
@@ -429,7 +446,7 @@ def compile_scene(scene: spec.Scene) -> Model:
 # Blob serialisation: header + table of named arrays (float64 / int32).
 # ---------------------------------------------------------------------------
 
-_SCALARS_I = ["nbody", "njnt", "nv", "nq", "ngeom", "nsite", "ntendon", "nu",
+_SCALARS_I = ["nbody", "njnt", "nv", "nq", "ngeom", "nsite", "ntendon", "nu", "nmeshvert",
               "npair", "ntree", "opt_iterations", "opt_ls_iterations", "opt_refsafe"]
 _SCALARS_F = ["opt_timestep", "opt_tolerance", "opt_ls_tolerance", "opt_impratio",
               "stat_meaninertia"]

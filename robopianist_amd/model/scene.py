@@ -68,9 +68,9 @@ def build_scene(
 ) -> SceneInfo:
     if hands and not primitive_fingertip_collisions:
         warnings.warn(
-            "Mesh fingertip colliders are unavailable (mujoco_menagerie is not "
-            "vendored in the reference checkout): using capsule fingertips, i.e. "
-            "primitive_fingertip_collisions=True semantics.",
+            "The menagerie fingertip meshes are not available (mujoco_menagerie is not vendored in the "
+            "reference checkout): the fingertips collide through a stand-in convex hull (the 26-vertex "
+            "polytope inscribed in the capsule that primitive_fingertip_collisions=True uses).",
             stacklevel=2,
         )
     world = spec.Body(name="world")
@@ -87,6 +87,7 @@ def build_scene(
         hb = shadow_hand.HandBuilder(
             side=side, forearm_dofs=forearm_dofs,
             reduced_action_space=reduced_action_space,
+            primitive_fingertip_collisions=primitive_fingertip_collisions,
         )
         position = RIGHT_HAND_POSITION if side == "right" else LEFT_HAND_POSITION
         quaternion = RIGHT_HAND_QUATERNION if side == "right" else LEFT_HAND_QUATERNION

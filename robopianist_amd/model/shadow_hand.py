@@ -126,8 +126,10 @@ class HandBuilder:
         forearm_dofs: Sequence[str] = DEFAULT_FOREARM_DOFS,
         restrict_wrist_yaw_range: bool = False,
         reduced_action_space: bool = False,
+        primitive_fingertip_collisions: bool = True,
     ):
         assert side in ("right", "left")
+        self.primitive_fingertips = bool(primitive_fingertip_collisions)
         for d in forearm_dofs:
             if d not in FOREARM_DOFS:
                 # Same error behaviour as shadow_hand.py:283-287.
@@ -189,6 +191,28 @@ class HandBuilder:
             **_PLASTIC,
         )
 
+    def _fingertip(self, name, radius, half, pos):
+        """Collision geom of a distal phalanx (`*distal_pst`).  The reference's default is the
+        menagerie mesh, collided through its convex hull; `primitive_fingertip_collisions=True`
+        turns it into the capsule MuJoCo fits to the mesh (shadow_hand.py:105-107,144-152).  The mesh
+        is not available here: the stand-in hull is the 26-vertex polytope inscribed in that same
+        capsule (poles, one ring on each cap at 45 degrees, the two rings of the cylinder; 6 azimuths),
+        so the two modes describe the same fingertip with the two collision pipelines."""
+        if self.primitive_fingertips:
+            return self._capsule(name, radius, half, pos)
+        verts = [(0.0, 0.0, half + radius), (0.0, 0.0, -half - radius)]
+        c45 = math.sqrt(0.5)
+        for k in range(6):
+            a = 2 * math.pi * k / 6
+            ca, sa = math.cos(a), math.sin(a)
+            verts += [(radius * ca, radius * sa, half), (radius * ca, radius * sa, -half),
+                      (radius * c45 * ca, radius * c45 * sa, half + radius * c45),
+                      (radius * c45 * ca, radius * c45 * sa, -half - radius * c45)]
+        if self.left:  # mirrored hand: mirror the hull like every other position
+            verts = [tuple(_mirror_vec(v, True)) for v in verts]
+        return spec.Geom(self._n(name), spec.GEOM_MESH, (radius, radius, half + radius),
+                         pos=_mirror_vec(pos, self.left), vertices=verts, **_PLASTIC)
+
     def _box(self, name, size, pos=(0, 0, 0), quat=(1, 0, 0, 0)):
         return spec.Geom(
             self._n(name), spec.GEOM_BOX, size,
@@ -218,7 +242,7 @@ class HandBuilder:
                                (1, 0, 0, 1), (1.28092e-06, 1.12092e-06, 5.3e-07)))
         di.joints.append(self._joint(f.upper() + "J1", "middle_distal"))
         # Stand-in for mesh `f_distal_pst` in primitive (capsule) mode.
-        di.geoms.append(self._capsule(f + "distal_pst", 0.0075, 0.0065, (0, 0, 0.012)))
+        di.geoms.append(self._fingertip(f + "distal_pst", 0.0075, 0.0065, (0, 0, 0.012)))
         # fingertip site (shadow_hand.py:192-207) and, at the same place, the r = 0.01 zone of the
         # fingertip's touch sensor (:248-270)
         di.sites.append(spec.Site(self._n(f + "distal_site"), (0, 0, _FINGERTIP_OFFSET), touch_radius=_TOUCH_RADIUS))
@@ -291,7 +315,7 @@ class HandBuilder:
                                (1, 0, 0, 1), (2.37794e-06, 2.27794e-06, 1e-06),
                                quat=(1, 0, 0, -1)))
         td.joints.append(self._joint("THJ1", "thdistal"))
-        td.geoms.append(self._capsule("thdistal_pst", 0.009, 0.005, (0, 0, 0.0135)))
+        td.geoms.append(self._fingertip("thdistal_pst", 0.009, 0.005, (0, 0, 0.0135)))
         td.sites.append(spec.Site(self._n("thdistal_site"), (0, 0, _THUMBTIP_OFFSET), touch_radius=_TOUCH_RADIUS))
 
         # Joint order as PyMJCF's find_all("joint") returns it (document order;

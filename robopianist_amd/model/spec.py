@@ -23,6 +23,7 @@ GEOM_PLANE = 0
 GEOM_SPHERE = 2
 GEOM_CAPSULE = 3
 GEOM_BOX = 6
+GEOM_MESH = 7  # a convex hull given by its vertices (MuJoCo collides meshes through their hulls)
 
 JNT_SLIDE = 2  # mjJNT_SLIDE
 JNT_HINGE = 3  # mjJNT_HINGE
@@ -73,6 +74,7 @@ class Geom:
     gap: float = 0.0
     priority: int = 0
     mass: Optional[float] = None  # If set, contributes to the body inertia.
+    vertices: Optional[Sequence[Sequence[float]]] = None  # GEOM_MESH: hull vertices in the geom frame
 
 
 @dataclasses.dataclass

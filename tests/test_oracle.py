@@ -362,3 +362,96 @@ def test_box_box_rotated_face_and_edge_edge_cases():
     np.testing.assert_allclose(con[0, 4:7], [0, 0, 1.0], atol=1e-12)
     # the top box's lowest ridge runs along x at world y = -0.01 / sqrt(2)
     np.testing.assert_allclose(con[0, 1:4], [xr, -0.01 / np.sqrt(2), ridge - 0.0005], atol=1e-12)
+
+
+# ---- convex hulls (GEOM_MESH) through MPR -------------------------------------------------------------
+def _hull_scene(verts, floor="box"):
+    from robopianist_amd.model import spec
+    world = spec.Body(name="world")
+    if floor == "box":
+        world.geoms.append(spec.Geom("floor", spec.GEOM_BOX, (0.05, 0.05, 0.01), pos=(0, 0, 0.01)))
+    else:
+        world.geoms.append(spec.Geom("floor", spec.GEOM_CAPSULE, (0.01, 0.05, 0.0), pos=(0, 0, 0.01),
+                                     quat=tuple(spec.axis_angle_to_quat(np.array([0.0, 1.0, 0.0]), np.pi / 2))))
+    top = spec.Body(name="top", pos=(0, 0, 0.05), mass=0.1, inertia=(1e-4, 1e-4, 1e-4),
+                    joints=[spec.Joint("z", type=spec.JNT_SLIDE, axis=(0, 0, 1), damping=0.5),
+                            spec.Joint("x", type=spec.JNT_SLIDE, axis=(1, 0, 0), damping=0.5)],
+                    geoms=[spec.Geom("hull", spec.GEOM_MESH, (0, 0, 0), vertices=verts)])
+    world.add(top)
+    m = mc.compile_scene(spec.Scene(world=world))
+    return m, Oracle(m, mc.to_blob(m))
+
+
+def _octahedron(r):
+    return [(r, 0, 0), (-r, 0, 0), (0, r, 0), (0, -r, 0), (0, 0, r), (0, 0, -r)]
+
+
+def test_hull_on_box_known_answers():
+    # (1) a cube-shaped hull resting on the box: one contact, straight up, carrying the weight
+    h = 0.02
+    cube = [(sx * h, sy * h, sz * 0.01) for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]
+    m, o = _hull_scene(cube)
+    assert m.npair == 1 and m.geom_rbound[1] == pytest.approx(np.sqrt(2 * h * h + 1e-4))
+    o.step(600)
+    con = o.contact.reshape(-1, 16)
+    assert o.ncon == 1
+    np.testing.assert_allclose(con[0, 4:7], [0, 0, 1.0], atol=1e-9)          # box (geom1) -> hull
+    z = 0.05 + o.qpos[0]
+    assert 0.0290 < z < 0.0300
+    np.testing.assert_allclose(con[0, 0], z - 0.03, atol=1e-9)
+    f = o.efc_force[o.nefc - 4:].sum()
+    assert f == pytest.approx(0.1 * 9.81, rel=1e-3)
+    # (2) an octahedron pressed 1 mm into the face, vertex first: depth, normal and position are exact
+    m, o = _hull_scene(_octahedron(0.015))
+    o.qpos[0] = 0.02 + 0.015 - 0.001 - 0.05; o.qpos[1] = 0.004; o.forward()
+    con = o.contact.reshape(-1, 16)
+    assert o.ncon == 1
+    np.testing.assert_allclose(con[0, 0], -0.001, atol=1e-6)                 # (the MPR tolerance)
+    np.testing.assert_allclose(con[0, 4:7], [0, 0, 1.0], atol=1e-6)
+    np.testing.assert_allclose(con[0, 1:4], [0.004, 0, 0.02 - 0.0005], atol=2e-4)   # ~midway, under the vertex (witness blend)
+    # (3) clear of the box by 0.1 mm: no contact
+    o.qpos[0] += 0.0011; o.forward()
+    assert o.ncon == 0
+
+
+def test_hull_against_capsule_matches_the_sphere_case():
+    """Vertex-down octahedron on a lying capsule (r = 1 cm): the contact is the vertex against the
+    cylinder, as for a point: depth = r - height of the vertex above the axis."""
+    m, o = _hull_scene(_octahedron(0.015), floor="capsule")
+    assert m.geom_type.tolist() == [3, 7] and m.npair == 1
+    o.qpos[0] = (0.01 + 0.01 + 0.015 - 0.0007) - 0.05; o.forward()      # vertex 0.7 mm inside the cylinder
+    con = o.contact.reshape(-1, 16)
+    assert o.ncon == 1
+    np.testing.assert_allclose(con[0, 0], -0.0007, atol=2e-6)
+    np.testing.assert_allclose(con[0, 4:7], [0, 0, 1.0], atol=2e-2)   # (curved surface: the portal normal is good to sqrt(tol / r))
+
+
+def test_hull_fingertips_build_and_press_keys():
+    """primitive_fingertip_collisions=False: the ten distal phalanges collide as 26-vertex hulls
+    (the reference's default mesh mode, shadow_hand.py:105-107), one contact per fingertip-key pair."""
+    from robopianist_amd import engine
+    from robopianist_amd.model import spec
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        si = scene.build_scene(primitive_fingertip_collisions=False, gravity_compensation=True)
+    m = si.model
+    assert int((m.geom_type == spec.GEOM_MESH).sum()) == 10 and m.nmeshvert == 260
+    o = Oracle(m, engine.make_blob(m, si.key_joint_ids))
+    lo, hi = m.actuator_ctrlrange[:, 0], m.actuator_ctrlrange[:, 1]
+    c = np.clip(0.0, lo, hi)
+    for a, n in enumerate(m.names["actuator"]):
+        short = n.split("/")[-1]
+        if short.endswith("J3") and "TH" not in short:
+            c[a] = min(hi[a], 1.4)
+        if short.endswith("J0"):
+            c[a] = 0.6
+    o.ctrl[:] = c
+    mesh_key = 0
+    for _ in range(300):
+        o.step(1)
+        for cc in o.contact.reshape(-1, 16):
+            g1, g2 = int(cc[13]), int(cc[14])
+            if m.geom_type[g2] == spec.GEOM_MESH and m.names["geom"][g1].startswith("piano"):
+                mesh_key += 1
+    assert o.warnings == 0 and mesh_key > 50
+    assert np.abs(o.qpos[:88]).max() > 0.01      # keys went down
