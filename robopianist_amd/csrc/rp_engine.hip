@@ -169,6 +169,7 @@ struct Engine : EngineBase {
   uint32_t* d_trace = nullptr; size_t trace_cap = 0;
   uint8_t* d_mask = nullptr;
   bool trunk4 = false;  // every tree has a 4-link trunk: launch the specialised solver build
+  bool mesh = false;    // the model has convex-hull geoms: position / sensor stages with MPR
   bool deep = false;    // a trunk of 5..8 links (more than two forearm dofs): the RPK_MAXD_DEEP builds
   int md() const { return deep ? RPK_MAXD_DEEP : RPK_MAXD; }
 
@@ -314,6 +315,11 @@ struct Engine : EngineBase {
     PI(site_link, "eng_site_link"); PF(site_pos, "eng_site_pos");
     if (b.has("eng_site_touch_radius")) PF(site_touch_radius, "eng_site_touch_radius");
     if (b.has("eng_link_bodylink")) PI(link_bodylink, "eng_link_bodylink");
+    if (b.has("eng_mesh_vert")) {
+      PF(mesh_vert, "eng_mesh_vert"); PI(geom_vertadr, "eng_geom_vertadr"); PI(geom_vertnum, "eng_geom_vertnum");
+      for (int t : b.i("eng_geom_type")) if (t == GEOM_MESH_) mesh = true;
+    }
+    if (mesh && deep) throw std::string("hull geoms together with more than two forearm dofs are not built (no such kernel variant)");
 #undef PF
 #undef PI
     M.ft = upF(ft);
@@ -507,6 +513,7 @@ struct Engine : EngineBase {
   }
   void launch_pos(const RpState<T>& st, int k, int nsub) {
     if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP>), dim3(nenv), dim3(64), 0, stream, M, st, B, k, nsub);
+    else if (mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD, 1>), dim3(nenv), dim3(64), 0, stream, M, st, B, k, nsub);
     else hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(nenv), dim3(64), 0, stream, M, st, B, k, nsub);
   }
   int step(int nsub, uint32_t* trace, int mode) override {
@@ -575,6 +582,7 @@ struct Engine : EngineBase {
           ss.sens_torque = d_sens_torque; ss.sens_touch = d_sens_touch;
           ss.key_trace = nullptr; ss.prof = nullptr;
           if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 2, 0, RPK_MAXD_DEEP>), dim3(nenv), dim3(64), 0, stream, M, ss, B, -1, nsub);
+          else if (mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 2, 0, RPK_MAXD, 1>), dim3(nenv), dim3(64), 0, stream, M, ss, B, -1, nsub);
           else hipLaunchKernelGGL((rp_stage_kernel<T, 2>), dim3(nenv), dim3(64), 0, stream, M, ss, B, -1, nsub);
         }
         launch_pos(s, k, nsub);

@@ -20,6 +20,21 @@
     (rc_)[0] = o_[0]; (rc_)[1] = o_[1]; (rc_)[2] = o_[2];                                       \
     return n_; }()
 #endif
+// convex pair with a hull: arguments copied into memory-resident geom records (a real call)
+#define RPK_CONVEX(rc_, tA_, pA_, mA_, sA_, gA_, tB_, pB_, mB_, sB_, gB_) [&]() -> int {      \
+    CGeom<T> a_, b_; RawCon<T> o_;                                                              \
+    a_.type = (tA_); b_.type = (tB_);                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < 3; i_++) { a_.pos[i_] = (pA_)[i_]; b_.pos[i_] = (pB_)[i_]; a_.size[i_] = (sA_)[i_]; b_.size[i_] = (sB_)[i_]; } \
+    _Pragma("unroll") for (int i_ = 0; i_ < 9; i_++) { a_.mat[i_] = (mA_)[i_]; b_.mat[i_] = (mB_)[i_]; }                     \
+    a_.nvert = (gA_) >= 0 ? M.geom_vertnum()[(gA_) >= 0 ? (gA_) : 0] : 0;                       \
+    b_.nvert = (gB_) >= 0 ? M.geom_vertnum()[(gB_) >= 0 ? (gB_) : 0] : 0;                       \
+    a_.vert = M.mesh_vert() + 3 * ((gA_) >= 0 ? M.geom_vertadr()[(gA_) >= 0 ? (gA_) : 0] : 0); \
+    b_.vert = M.mesh_vert() + 3 * ((gB_) >= 0 ? M.geom_vertadr()[(gB_) >= 0 ? (gB_) : 0] : 0); \
+    if (a_.type != GEOM_MESH_) { a_.nvert = 0; a_.vert = M.mesh_vert(); }                       \
+    if (b_.type != GEOM_MESH_) { b_.nvert = 0; b_.vert = M.mesh_vert(); }                       \
+    const int n_ = convex_mpr(&o_, &a_, &b_);                                                   \
+    (rc_)[0] = o_;                                                                              \
+    return n_; }()
 namespace rpk {
 // ----------------------------------------------------------------- shared memory
 // LDS budget drives occupancy (fp64: 40.5 KB -> 4 workgroups per CU).  Scratch of the
@@ -122,7 +137,7 @@ __global__ void rp_reset_kernel(RpState<T> S, const T* qpos0, const unsigned cha
 // solver + Euler).  FIXED_TL > 0 specialises the solver for trunks of exactly that many links.
 // The host launches  pos, then n_substeps x (sol, pos);  RpStage carries the hand-over.
 // ============================================================================
-template <typename T, int MODE, int FIXED_TL = 0, int MD = RPK_MAXD>
+template <typename T, int MODE, int FIXED_TL = 0, int MD = RPK_MAXD, int MESH = 0>
 __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_stage_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep,
                                                      int nsub) {
   using namespace rpk;
@@ -1530,7 +1545,12 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
           T bm[9] = {c, 0, s, 0, 1, 0, -s, 0, c};
           if (M.geom_type()[ga] == GEOM_CAPSULE_)
             n = capsule_box(rc, posA, mA, M.geom_size() + 3 * ga, bp, bm, M.key_half() + 3 * k);
-          else
+          else if (MESH && M.geom_type()[ga] == GEOM_MESH_) {
+            // (box, hull) in geom-type order: the key is geom 1 of the pair; the engine keeps the hand
+            // geom as side A of the contact, so the normal is turned around
+            n = RPK_CONVEX(rc, GEOM_BOX_, bp, bm, M.key_half() + 3 * k, -1, GEOM_MESH_, posA, mA, M.geom_size() + 3 * ga, ga);
+            rc[0].n[0] = -rc[0].n[0]; rc[0].n[1] = -rc[0].n[1]; rc[0].n[2] = -rc[0].n[2];
+          } else
             n = RPK_BOXBOX(rc, posA, mA, M.geom_size() + 3 * ga, bp, bm, M.key_half() + 3 * k);
 #pragma unroll
           for (int e = 0; e < 8; e++) pB[e] = M.key_cparam()[e];
@@ -1545,6 +1565,8 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
           }
           if (M.geom_type()[gb] == GEOM_CAPSULE_)
             n = capsule_capsule(rc, posA, mA, M.geom_size() + 3 * ga, posB, mB, M.geom_size() + 3 * gb);
+          else if (MESH && M.geom_type()[gb] == GEOM_MESH_)
+            n = RPK_CONVEX(rc, M.geom_type()[ga], posA, mA, M.geom_size() + 3 * ga, ga, GEOM_MESH_, posB, mB, M.geom_size() + 3 * gb, gb);
           else if (M.geom_type()[ga] == GEOM_CAPSULE_)
             n = capsule_box(rc, posA, mA, M.geom_size() + 3 * ga, posB, mB, M.geom_size() + 3 * gb);
           else

@@ -23,7 +23,7 @@
 #define RPK_NC 32        // max contacts kept per env (= RP_MAX_CONTACTS; contact c lives in lane c)
 #define RPK_NCOUT 32     // == RP_MAX_CONTACTS
 #define RPK_NE 256      // max contact Jacobian entries (contact, dof) handed to the solver (fp64; see RpCaps)
-#define RPK_NBOXF 26     // boxes covered by the oriented-box prefilter (fits the cdof scratch in fp32)
+#define RPK_NBOXF 32     // boxes / hull boxes covered by the oriented-box prefilter
 #define RPK_HMAX 60      // max rows of the dense cross-coupling block (+1 row for its rhs = one lane each; fp64)
 #define RPK_WORK 128     // narrow-phase work list
 #define RPK_MAXD 9       // tree depth levels held by the default kernel builds (trunk <= 4 links + chain <= 5)
@@ -38,6 +38,8 @@
 #define JNT_HINGE_ 3
 #define GEOM_CAPSULE_ 3
 #define GEOM_BOX_ 6
+#define GEOM_MESH_ 7   // convex hull (vertices in the geom frame)
+#define RPK_MAXMESHV 320 // hull vertices of all hull geoms together
 
 // All model tables live in TWO device arrays (one of T, one of int) at compile-time
 // offsets (tables are padded to their maximum item counts).  A table access is then
@@ -66,7 +68,7 @@
   X(geom_rbound,      RPK_WAVE,    1) X(geom_invw,       RPK_WAVE,    1) X(geom_cparam,    RPK_WAVE,  8) \
   X(act_coef,         RPK_MAXACT,  2) X(act_gain,        RPK_MAXACT,  1) X(act_bias,       RPK_MAXACT, 3) \
   X(act_ctrlrange,    RPK_MAXACT,  2) X(act_forcerange,  RPK_MAXACT,  2) X(site_pos,       RPK_WAVE,  3) \
-  X(site_touch_radius, RPK_WAVE,   1)
+  X(site_touch_radius, RPK_WAVE,   1) X(mesh_vert, RPK_MAXMESHV, 3)
 #define RPK_ITABLES(X) \
   X(lane_topo,    RPK_NL_DEEP, 16) \
   X(link_parent,  RPK_NL_DEEP, 1) X(link_depth,   RPK_NL_DEEP, 1) X(link_tree,    RPK_NL_DEEP, 1) X(link_jtype,  RPK_NL_DEEP, 1) \
@@ -79,7 +81,8 @@
   X(geom_link,    RPK_WAVE, 1) X(geom_type,  RPK_WAVE, 1) X(geom_modelid, RPK_WAVE, 1) \
   X(geom_pairmask, RPK_WAVE, 2) X(geom_iskeycap, RPK_WAVE, 1) \
   X(act_kind,     RPK_MAXACT, 1) X(act_lane, RPK_MAXACT, 2) X(act_ctrllimited, RPK_MAXACT, 1) \
-  X(act_forcelimited, RPK_MAXACT, 1) X(site_link, RPK_WAVE, 1) X(link_bodylink, RPK_NL_DEEP, 1)
+  X(act_forcelimited, RPK_MAXACT, 1) X(site_link, RPK_WAVE, 1) X(link_bodylink, RPK_NL_DEEP, 1) \
+  X(geom_vertadr, RPK_WAVE, 1) X(geom_vertnum, RPK_WAVE, 1)
 
 struct RpLayout {
   enum : int {

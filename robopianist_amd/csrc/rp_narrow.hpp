@@ -419,4 +419,147 @@ __device__ RPK_BOXBOX_INLINE int box_box(RawCon<T>* out, const T* p1, const T* m
   }
   return n;
 }
+// ---------------------------------------------------------------------------------------------
+// Convex pairs with a hull (GEOM_MESH_) [MJ: mjc_Convex -> libccd MPR; restated, see the oracle]:
+// Minkowski Portal Refinement on B - A, one contact: depth along the final portal's normal,
+// normal from A to B, position = witness midpoints blended with the origin ray's barycentric
+// weights.  Tolerance 1e-6, at most 50 refinement steps.  Not inlined (register-bound caller).
+template <typename T> struct CGeom { int type, nvert; T pos[3], mat[9], size[3]; const T* vert; };
+template <typename T> struct MPoint { T v[3], p1[3], p2[3]; };
+
+template <typename T>
+__device__ __forceinline__ void geom_support(const CGeom<T>& g, const T* d, T* out) {
+  if (g.type == GEOM_CAPSULE_) {
+    const T ax[3] = {g.mat[2], g.mat[5], g.mat[8]};
+    const T sl = dot3(ax, d) >= 0 ? g.size[1] : -g.size[1];
+#pragma unroll
+    for (int k = 0; k < 3; k++) out[k] = g.pos[k] + sl * ax[k] + g.size[0] * d[k];
+  } else if (g.type == GEOM_BOX_) {
+    T o[3] = {g.pos[0], g.pos[1], g.pos[2]};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const T ax[3] = {g.mat[a], g.mat[3 + a], g.mat[6 + a]};
+      const T sh = dot3(ax, d) >= 0 ? g.size[a] : -g.size[a];
+#pragma unroll
+      for (int k = 0; k < 3; k++) o[k] += sh * ax[k];
+    }
+    out[0] = o[0]; out[1] = o[1]; out[2] = o[2];
+  } else {
+    T dl[3];
+    matT_vec(dl, g.mat, d);
+    T bv = (T)-1e30, b0 = 0, b1 = 0, b2 = 0;
+    for (int i = 0; i < g.nvert; i++) {       // first maximum wins
+      const T x = g.vert[3 * i], y = g.vert[3 * i + 1], z = g.vert[3 * i + 2];
+      const T v = dl[0] * x + dl[1] * y + dl[2] * z;
+      if (v > bv) { bv = v; b0 = x; b1 = y; b2 = z; }
+    }
+    const T bl[3] = {b0, b1, b2};
+    T w[3];
+    mat_vec(w, g.mat, bl);
+    out[0] = g.pos[0] + w[0]; out[1] = g.pos[1] + w[1]; out[2] = g.pos[2] + w[2];
+  }
+}
+template <typename T>
+__device__ __forceinline__ void mpr_support(const CGeom<T>& A, const CGeom<T>& B, const T* d, MPoint<T>& o) {
+  const T nd[3] = {-d[0], -d[1], -d[2]};
+  geom_support(A, nd, o.p1);
+  geom_support(B, d, o.p2);
+#pragma unroll
+  for (int k = 0; k < 3; k++) o.v[k] = o.p2[k] - o.p1[k];
+}
+template <typename T> __device__ __forceinline__ bool normalize3(T* v) {
+  const T n = Num<T>::sqrt(dot3(v, v));
+  if (n < (T)1e-14) return false;
+  const T inv = (T)1 / n;
+  v[0] *= inv; v[1] *= inv; v[2] *= inv;
+  return true;
+}
+template <typename T> __device__ __forceinline__ void portal_dir(T* dir, const MPoint<T>& a, const MPoint<T>& b, const MPoint<T>& o) {
+  const T t1[3] = {a.v[0] - o.v[0], a.v[1] - o.v[1], a.v[2] - o.v[2]};
+  const T t2[3] = {b.v[0] - o.v[0], b.v[1] - o.v[1], b.v[2] - o.v[2]};
+  cross3(dir, t1, t2);
+}
+
+template <typename T>
+__device__ __noinline__ int convex_mpr(RawCon<T>* out, const CGeom<T>* Ap, const CGeom<T>* Bp) {
+  const CGeom<T>& A = *Ap; const CGeom<T>& B = *Bp;
+  MPoint<T> v0, v1, v2, v3, v4;
+  T dir[3], t1[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { v0.p1[k] = A.pos[k]; v0.p2[k] = B.pos[k]; v0.v[k] = B.pos[k] - A.pos[k]; }
+  if (Num<T>::sqrt(dot3(v0.v, v0.v)) < (T)1e-10) v0.v[0] = (T)1e-5;
+  // ---- portal discovery
+  dir[0] = -v0.v[0]; dir[1] = -v0.v[1]; dir[2] = -v0.v[2];
+  normalize3(dir);
+  mpr_support(A, B, dir, v1);
+  if (dot3(v1.v, dir) <= 0) return 0;
+  cross3(dir, v0.v, v1.v);
+  if (!normalize3(dir)) {   // the origin lies on the ray v0 -> v1
+    T n[3] = {v1.v[0] - v0.v[0], v1.v[1] - v0.v[1], v1.v[2] - v0.v[2]};
+    normalize3(n);
+    out->dist = -dot3(v1.v, n);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { out->n[k] = -n[k]; out->pos[k] = (T)0.5 * (v1.p1[k] + v1.p2[k]); }
+    return out->dist <= 0 ? 1 : 0;
+  }
+  mpr_support(A, B, dir, v2);
+  if (dot3(v2.v, dir) <= 0) return 0;
+  portal_dir(dir, v1, v2, v0);
+  normalize3(dir);
+  if (dot3(dir, v0.v) > 0) {
+    const MPoint<T> tmp = v1; v1 = v2; v2 = tmp;
+    dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2];
+  }
+  for (int it = 0;; it++) {
+    if (it > 50) return 0;
+    mpr_support(A, B, dir, v3);
+    if (dot3(v3.v, dir) <= 0) return 0;
+    cross3(t1, v1.v, v3.v);
+    if (dot3(t1, v0.v) < 0) { v2 = v3; portal_dir(dir, v1, v3, v0); normalize3(dir); continue; }
+    cross3(t1, v3.v, v2.v);
+    if (dot3(t1, v0.v) < 0) { v1 = v3; portal_dir(dir, v3, v2, v0); normalize3(dir); continue; }
+    break;
+  }
+  // ---- refinement
+  bool hit = false;
+  for (int it = 0; it <= 50; it++) {
+    portal_dir(dir, v2, v3, v1);
+    if (!normalize3(dir)) return 0;
+    if (dot3(dir, v1.v) >= 0) hit = true;   // the origin is inside the portal
+    mpr_support(A, B, dir, v4);
+    const T reach = dot3(v4.v, dir) - dot3(v1.v, dir);
+    if (!hit && dot3(v4.v, dir) < 0) return 0;
+    if (reach <= (T)1e-6 || it == 50) {
+      if (!hit) return 0;
+      const T depth = dot3(v1.v, dir);
+      T b[4], c[3];
+      cross3(c, v1.v, v2.v); b[0] = dot3(c, v3.v);
+      cross3(c, v3.v, v2.v); b[1] = dot3(c, v0.v);
+      cross3(c, v0.v, v1.v); b[2] = dot3(c, v3.v);
+      cross3(c, v2.v, v1.v); b[3] = dot3(c, v0.v);
+      T sum = b[0] + b[1] + b[2] + b[3];
+      if (sum <= 0) {
+        b[0] = 0;
+        cross3(c, v2.v, v3.v); b[1] = dot3(c, dir);
+        cross3(c, v3.v, v1.v); b[2] = dot3(c, dir);
+        cross3(c, v1.v, v2.v); b[3] = dot3(c, dir);
+        sum = b[1] + b[2] + b[3];
+      }
+      const T inv = (T)1 / sum;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const T acc = b[0] * (T)0.5 * (v0.p1[k] + v0.p2[k]) + b[1] * (T)0.5 * (v1.p1[k] + v1.p2[k]) +
+                      b[2] * (T)0.5 * (v2.p1[k] + v2.p2[k]) + b[3] * (T)0.5 * (v3.p1[k] + v3.p2[k]);
+        out->pos[k] = acc * inv;
+        out->n[k] = -dir[k];   // (the portal faces away from the centre of B - A: A -> B is -dir)
+      }
+      out->dist = -depth;
+      return 1;
+    }
+    cross3(t1, v4.v, v0.v);
+    if (dot3(v1.v, t1) > 0) { if (dot3(v2.v, t1) > 0) v1 = v4; else v3 = v4; }
+    else { if (dot3(v3.v, t1) > 0) v2 = v4; else v1 = v4; }
+  }
+  return 0;
+}
 }  // namespace rpk

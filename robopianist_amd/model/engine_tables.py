@@ -380,6 +380,17 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
         [m.geom_solref[egeoms], m.geom_solimp[egeoms], m.geom_friction[egeoms][:, :1]],
         axis=1) if ng else np.zeros((0, 8)))
     t["eng_geom_modelid"] = np.array(egeoms, np.int32)
+    # convex hulls: vertices (geom frame; welded bodies are handled through geom_pos / geom_mat)
+    if ng and "geom_vertnum" in m and int(np.sum(m.geom_vertnum[egeoms])) > 0:
+        vadr, vnum, verts = np.full(ng, -1, np.int32), np.zeros(ng, np.int32), []
+        for i, g in enumerate(egeoms):
+            if m.geom_type[g] == spec.GEOM_MESH:
+                vadr[i] = len(verts); vnum[i] = int(m.geom_vertnum[g])
+                a = int(m.geom_vertadr[g])
+                verts.extend(m.mesh_vert[a:a + vnum[i]].tolist())
+        assert len(verts) <= 320, "too many hull vertices for the engine (RPK_MAXMESHV)"
+        t["eng_geom_vertadr"] = vadr; t["eng_geom_vertnum"] = vnum
+        t["eng_mesh_vert"] = np.asarray(verts, float).reshape(-1, 3)
 
     # static pairs (neither geom is a key) and the capsule-x-all-keys family
     spairs = []
@@ -390,7 +401,7 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
         assert not (ka and kb)
         if ka or kb:
             h = b if ka else a
-            assert m.geom_type[h] in (spec.GEOM_CAPSULE, spec.GEOM_BOX), "capsule- / box-vs-key pairs only"
+            assert m.geom_type[h] in (spec.GEOM_CAPSULE, spec.GEOM_BOX, spec.GEOM_MESH), "capsule- / box- / hull-vs-key pairs only"
             keycount[h] = keycount.get(h, 0) + 1
         else:
             spairs.append((eidx[a], eidx[b]))

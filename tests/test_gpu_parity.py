@@ -55,6 +55,30 @@ def key_press_sequence(si, nsteps):
     return out
 
 
+def wrist_press_sequence(si, nsteps):
+    """Fingertips onto the keys and off again: the wrist flexes (WRJ1 -> 0.35 rad) with half-curled
+    fingers, period 200 steps, while the forearms slide a little.  (The hands' root sits 13 cm above the
+    keyboard, base.py:34-39: without wrist flexion the stand-in's fingers only graze the keys.)"""
+    m = si.model
+    out = np.zeros((nsteps, m.nu))
+    for s in range(nsteps):
+        press = 0.5 - 0.5 * np.cos(2 * np.pi * (s % 200) / 200.0)
+        for a, n in enumerate(m.names["actuator"]):
+            short = n.split("/")[-1]
+            lo, hi = m.actuator_ctrlrange[a]
+            v = 0.0
+            if short.endswith("WRJ1"):
+                v = 0.35 * press
+            elif short.endswith("J3") and "TH" not in short:
+                v = 0.8
+            elif short == "forearm_tx":
+                v = 0.01 * np.sin(2 * np.pi * s / 400.0)
+            elif short == "forearm_ty":
+                v = 0.02
+            out[s, a] = min(hi, max(lo, v))
+    return out
+
+
 def make_pair(si, precision, nenv=2):
     from robopianist_amd import engine
     from oracle.rp_oracle import Oracle
@@ -501,3 +525,39 @@ def test_teacher_forced_fp64_with_box_box_contacts(two_hand_scene):
     print(f"box-box: {boxbox} box-box contacts over {len(phases)} steps, max contacts {maxcon}, worst rel dv {worst:.2e}")
     assert boxbox >= 50 and (phys.warn_flags.max() & ~engine.WARN_CONTACT_FULL) == 0
     assert worst < 1e-9
+
+
+def test_teacher_forced_fp64_hull_fingertips():
+    """primitive_fingertip_collisions=False (the reference's default, shadow_hand.py:105-107): the distal
+    phalanges collide as convex hulls through MPR, in the engine (MESH kernel builds) as in the oracle.
+    Teacher forced through key presses and random targets: same contact counts, 1e-9 per step (both
+    sides run the same portal refinement, so its 1e-6 tolerance cancels)."""
+    import warnings
+    from robopianist_amd import engine
+    from robopianist_amd.model import scene, spec
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=False)
+    m = si.model
+    assert int((m.geom_type == spec.GEOM_MESH).sum()) == 10
+    ctrl = np.concatenate([wrist_press_sequence(si, 400), ctrl_sequence(m, 200, 5)])
+    phys, orc = make_pair(si, 64)
+    worst, hull_contacts, maxcon, borderline = 0.0, 0, 0, 0
+    for c in ctrl:
+        phys.set(engine.QPOS, orc.qpos[None, :]); phys.set(engine.QVEL, orc.qvel[None, :])
+        phys.set(engine.QACC_WARMSTART, orc.qacc_warmstart[None, :])
+        phys.set(engine.CTRL, c[None, :]); orc.ctrl[:] = c
+        v0 = orc.qvel.copy()
+        phys.step(1); orc.step(1)
+        con = orc.contact.reshape(-1, 16)
+        hull_contacts += sum(1 for cc in con if m.geom_type[int(cc[14])] == spec.GEOM_MESH)
+        maxcon = max(maxcon, orc.ncon)
+        if int(phys.get(engine.NCON)[0]) != orc.ncon:
+            borderline += 1          # (an MPR pair within its tolerance of touching)
+            continue
+        dv = np.abs(phys.qvel[0].astype(np.float64) - orc.qvel).max()
+        worst = max(worst, dv / max(np.abs(orc.qvel - v0).max(), 1e-9))
+    print(f"hull fingertips: {hull_contacts} hull contacts, max contacts {maxcon}, worst rel dv {worst:.2e}, "
+          f"{borderline} steps with a borderline pair")
+    assert hull_contacts >= 200 and borderline <= 5
+    assert phys.warn_flags.max() == 0 and worst < 1e-9

@@ -437,17 +437,10 @@ def test_hull_fingertips_build_and_press_keys():
     m = si.model
     assert int((m.geom_type == spec.GEOM_MESH).sum()) == 10 and m.nmeshvert == 260
     o = Oracle(m, engine.make_blob(m, si.key_joint_ids))
-    lo, hi = m.actuator_ctrlrange[:, 0], m.actuator_ctrlrange[:, 1]
-    c = np.clip(0.0, lo, hi)
-    for a, n in enumerate(m.names["actuator"]):
-        short = n.split("/")[-1]
-        if short.endswith("J3") and "TH" not in short:
-            c[a] = min(hi[a], 1.4)
-        if short.endswith("J0"):
-            c[a] = 0.6
-    o.ctrl[:] = c
+    from test_gpu_parity import wrist_press_sequence      # scripted fingertips-onto-the-keys sequence
     mesh_key = 0
-    for _ in range(300):
+    for c in wrist_press_sequence(si, 300):
+        o.ctrl[:] = c
         o.step(1)
         for cc in o.contact.reshape(-1, 16):
             g1, g2 = int(cc[13]), int(cc[14])
