@@ -1275,6 +1275,12 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
           Mr[k] = v;
         }
       }
+      // handed over right away: the rows are not needed again in this kernel, and the collision
+      // phase that follows is the register-hungriest part of it
+      if constexpr (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e <= MD; e++) B.RM[((size_t)env * RPK_NLX(MD) + lane) * (MD + 1) + e] = Mr[e];
+      }
     }
     PROF(11);
     // ---- key poses, geom centres
@@ -1984,10 +1990,6 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
       LI(7) = (int)(con_maskB & 0xffffffffu); LI(8) = (int)(con_maskB >> 32);
       LI(9) = sdepth;
       LI(11) = salink | (sTL << 8) | (sTB << 16);
-      if (isl) {
-#pragma unroll
-        for (int e = 0; e <= MD; e++) B.RM[((size_t)env * RPK_NLX(MD) + lane) * (MD + 1) + e] = Mr[e];
-      }
       if (lane < 16) {
         int* sl = B.slots + (size_t)env * 64;
         sl[lane] = sm.slotkey[lane]; sl[16 + lane] = sm.slotlink[lane];

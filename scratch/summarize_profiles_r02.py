@@ -32,7 +32,7 @@ for name, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
         x = df[df.Kernel_Name.str.contains(pat, regex=False)]
         if tag == "position": x = x[x.Counter_Value > x.Counter_Value.max() * 0.05]
         pm[f"{name}_KB_per_launch_{tag}"] = float(x.Counter_Value.mean()); pm[f"n_{name}_{tag}"] = int(len(x))
-if pm:
+if "FETCH_SIZE_KB_per_launch_solver" in pm and "WRITE_SIZE_KB_per_launch_solver" in pm:
     sol_b = pm["FETCH_SIZE_KB_per_launch_solver"] * 1024 * 2 + pm["WRITE_SIZE_KB_per_launch_solver"] * 1024
     pos_b = pm["FETCH_SIZE_KB_per_launch_position"] * 1024 * 2 + pm["WRITE_SIZE_KB_per_launch_position"] * 1024
     pm["note"] = ("separate --pmc passes (bench.py --steps 20 --warmup 5 each).  Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 "
@@ -42,6 +42,8 @@ if pm:
     out["pmc"] = pm
     json.dump({"envs": 4096, "precision": 64, "solver_kernel_bytes_per_launch": sol_b, "position_kernel_bytes_per_launch": pos_b},
               open(os.path.join(OUT, "traffic_r02.json"), "w"))
+elif pm:
+    out["pmc_partial"] = pm
 sq = {}
 for d in ("sq1", "sq2"):
     f = sorted(glob.glob(f"{R}/{d}/*/*counter_collection.csv"))
