@@ -1365,7 +1365,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
         }
       }
     }
-    // allowed pairs only (the pair mask is upper-triangular and empty beyond ngeom)
+    // allowed pairs this lane owns (engine_tables.py deals every static pair to one of its two lanes)
     unsigned long long remA = (((unsigned long long)hithi << 32) | hitlo) & gpm;
     // keys: capsules that reach down to the keyboard, against this lane's two keys
     unsigned long long remK0 = 0, remK1 = 0;
@@ -1508,7 +1508,8 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
 #endif
           const int idx = nwork + __popcll(mk & lanemask_lt(lane));
           if (has) {
-            if (gen_phase == 0) { sm.work[idx][0] = (short)lane; sm.work[idx][1] = (short)bit; }
+            // (a static pair is owned by either of its lanes: geom 1 of the pair is the lower one)
+            if (gen_phase == 0) { sm.work[idx][0] = (short)(lane < bit ? lane : bit); sm.work[idx][1] = (short)(lane < bit ? bit : lane); }
             else { sm.work[idx][0] = (short)bit; sm.work[idx][1] = (short)(RPK_KEYBASE + (gen_phase == 1 ? kid[0] : kid[1])); }
           }
           nwork += __popcll(mk);

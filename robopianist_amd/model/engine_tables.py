@@ -416,11 +416,21 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
     t["eng_nkeycap"] = np.array([len(kcaps)], np.int32)
     t["eng_keycap"] = np.array(kcaps, np.int32)
     # per-geom partner masks (bit j of row i: static pair (i, j), j > i) and key-capsule flags
+    # Every static pair is OWNED by one of its two lanes (bit `other` in the owner's mask): the broad
+    # phase drains one candidate per lane and round, so the number of rounds is the largest number of
+    # sphere-overlapping partners any one lane owns.  Pairs of different geom types stay with the lower
+    # (capsule-side) lane, whose prefilter is the sharper one; same-type pairs are dealt out greedily to
+    # the endpoint that owns fewer so far -- the piano's base box (bounding radius 0.61 m: it overlaps
+    # every hand box) would otherwise own twenty pairs and cost twenty rounds every substep.
     pmask = np.zeros((max(ng, 1), 2), np.uint32)
+    owned = np.zeros(max(ng, 1), np.int64)
     for a, b in spairs:
         lo_, hi_ = min(a, b), max(a, b)
         assert m.geom_type[egeoms[lo_]] <= m.geom_type[egeoms[hi_]]
-        pmask[lo_, hi_ // 32] |= np.uint32(1 << (hi_ % 32))
+        same = m.geom_type[egeoms[lo_]] == m.geom_type[egeoms[hi_]]
+        own, oth = (hi_, lo_) if (same and owned[hi_] < owned[lo_]) else (lo_, hi_)
+        owned[own] += 1
+        pmask[own, oth // 32] |= np.uint32(1 << (oth % 32))
     t["eng_geom_pairmask"] = pmask.view(np.int32)
     iskc = np.zeros(max(ng, 1), np.int32)
     iskc[kcaps] = 1
