@@ -77,14 +77,16 @@ def _profile_json(name):
         return None
 
 
-def _pmc_traffic(E, precision):
+def _pmc_traffic(E, precision, envs_per_launch=None):
     """HBM-side bytes per solver-kernel launch from the committed rocprofv3 --pmc passes
-    (newest profiles/traffic_rNN.json); null if not collected for this env
-    count / precision."""
+    (newest profiles/traffic_rNN.json, see DESIGN.md 6), scaled to the envs one launch covers;
+    null if not collected for this env count / precision."""
     for name in ("traffic_r02.json", "traffic_r01.json"):
         d = _profile_json(name)
         if d and int(d.get("envs", -1)) == int(E) and int(d.get("precision", -1)) == int(precision):
-            return d.get("solver_kernel_bytes_per_launch")
+            b = d.get("solver_kernel_bytes_per_launch")
+            n = float(d.get("envs_per_launch", d["envs"]))
+            return None if b is None else b * float(envs_per_launch or n) / n
     return None
 
 
@@ -333,6 +335,7 @@ def main():
                 eager_env.step(a)
             barrier()
         sms, snl = phys.solver_kernel_time()
+        senvs = phys.solver_kernel_envs() or float(E)   # a launch covers the batch or one slice of it
         kms, nl = phys.kernel_time()
         wf = base_env.physics.warn
         warn_or = int(torch.bitwise_or(wf, torch.zeros_like(wf)).max().item()) if wf is not None else 0
@@ -365,7 +368,7 @@ def main():
                        "note": "same env loop with the actions in host numpy arrays and every TimeStep field "
                                "copied back to numpy (pageable memory, synchronous copies) each step"}
 
-        return dict(host_io=host_io, dt=dt, kms=kms, nl=nl, sms=sms, snl=snl, warn=warn_or, finite=finite, phys=phys,
+        return dict(host_io=host_io, dt=dt, kms=kms, nl=nl, sms=sms, snl=snl, senvs=senvs, warn=warn_or, finite=finite, phys=phys,
                     m=m, E=E, key_ids=base_env.task.scene.key_joint_ids, sim=sim_all, n_spread=n_spread, events=events,
                     graphed=bool(use_graph and env.graph_captured), stagger=stagger)
 
@@ -376,7 +379,8 @@ def main():
     if rank == 0:
         # simulated env-steps only: a FIRST step (the dm_env reset after LAST) advances no physics
         value = r["sim"] / dt
-        algo = algo_bytes_per_mj_step(int(m.nv), int(m.nu), args.precision) * E
+        per_env = algo_bytes_per_mj_step(int(m.nv), int(m.nu), args.precision)
+        algo = per_env * r["senvs"]
         achieved = algo / (sms * 1e-3) / 1e9 if sms > 0 else 0.0
         tname = "double" if args.precision == 64 else "float"
         out = {
@@ -407,19 +411,21 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(E, args.precision),
+                "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(E, args.precision, r["senvs"]),
                 "kernel": "rp_stage_kernel<%s, 1> (mj_step2: constraint solver + Euler, one substep of all envs)" % tname,
                 "kernel_avg_ms": sms, "kernel_launches_sampled": snl,
+                "envs_per_launch": r["senvs"],
                 "algorithmic_bytes_per_launch": algo,
-                "algorithmic_bytes_per_mj_step_per_env": algo // E,
+                "algorithmic_bytes_per_mj_step_per_env": per_env,
                 "step_sequence_avg_ms": kms, "step_sequences": nl,
                 "kernel_timing": ("HIP events on 16 eager env steps of the same rollout right after the timed region "
                                   "(the timed region replays a captured hipGraph)") if r["graphed"] else
                                  "HIP events on the engine stream over the timed region; the probed substep rotates "
                                  "(substep = step index mod n_substeps), so the average is the all-substep mean",
                 "note": "algorithmic bytes = SURVEY 8(d) un-fused figure (qpos qvel qacc_warmstart in + out, ctrl in) "
-                        "x envs per launch; one rp_step = 1 + 2*substeps launches (rp_stage_kernel<T,0> "
-                        "position/velocity stage, <T,1> solver stage).  The path is instruction-issue / latency bound "
+                        "x envs per launch (the batch, or half of it when the engine steps two slices on two streams: "
+                        "envs_per_launch is the mean over the sampled launches); one rp_step = 1 + 2*substeps launches "
+                        "per slice (rp_stage_kernel<T,0> position/velocity stage, <T,1> solver stage).  The path is instruction-issue / latency bound "
                         "(one wave per env), not HBM bound: see DESIGN.md 6",
             },
             "sanity": {"warn_flags_or": r["warn"], "finite": r["finite"], **(r["events"] or {})},
@@ -434,6 +440,7 @@ def main():
             rl = measure(args.precision, 158, 5, stagger_on=False)
             out.setdefault("aux", {})["lockstep_full_episode"] = {
                 "value": rl["sim"] / rl["dt"], "unit": "env-steps/s", "steps": 158, "kernel_avg_ms": rl["sms"],
+                "envs_per_launch": rl["senvs"],
                 "step_sequence_avg_ms": rl["kms"],
                 "note": "same workload with every env on the same replay row (one full 158-step episode)"}
             del rl

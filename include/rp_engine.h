@@ -123,6 +123,14 @@ int rp_set_lazy_position_stage(rp_engine* e, int on);
  * times) a heavy env that happens to start last is the tail of the whole launch.  Results are
  * bit-identical either way (envs are independent); default: off. */
 int rp_set_cost_ordered_launch(rp_engine* e, int on);
+/* Stream slices (0, 1, 2 or 4; default 1): with n > 1, rp_step runs n slices of the batch as n
+ * independent kernel chains (the caller's stream and internal ones, forked / joined with events
+ * inside the call), so that the tail of one slice's launch overlaps another slice's next kernel:
+ * faster for heterogeneous batches (two slices: +3 %; four: slower again), slower for uniform ones
+ * (-6 %).  0 = automatic: the engine times one and two slices on 8 of every 64 steps (its own HIP
+ * events, never waited on) and runs the rest with the faster.  Same results in every mode; batches
+ * of fewer than 1024 envs and stream captures run as one slice. */
+int rp_set_stream_slices(rp_engine* e, int n);
 /* Acceleration-stage sensors (mj_sensorAcc: `torque`, `touch`).  When on, the last substep of every
  * rp_step is followed by one extra launch (the sensor stage: position / velocity stage of the state
  * before that substep's Euler step + mj_rnePostConstraint), which fills RP_SENSOR_TORQUE and
@@ -149,6 +157,9 @@ int rp_kernel_time(rp_engine* e, double* avg_ms, int* n_launches);
  * every rp_step call, HIP events on the engine stream.  Call before rp_kernel_time
  * if both are wanted for the same interval. */
 int rp_solver_kernel_time(rp_engine* e, double* avg_ms, int* n_launches);
+/* Average number of envs one timed solver-stage launch covered, over the launches the last
+ * rp_solver_kernel_time call reported (the whole batch, or one slice of it: rp_set_stream_slices). */
+int rp_solver_kernel_envs(rp_engine* e, double* avg_envs);
 /* Debug aid: per-phase shader-clock counters of env 0 (see rp_kernels.hpp PROF).
  * Reads and clears the counters (out may be NULL), then enables/disables them. */
 int rp_profile(rp_engine* e, long long* out, int n, int enable);

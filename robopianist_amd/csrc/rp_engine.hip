@@ -44,7 +44,9 @@ __global__ void rp_mark_valid_kernel(unsigned char* valid, const int* active, in
 //     heaviest env among those with index = x (mod 8).  Inactive envs go last in their class.
 #define RP_ORDER_BUCKETS 256
 #define RP_ORDER_CLASSES 8
-__global__ __launch_bounds__(1024) void rp_order_kernel(int* order, const int* hdr, const int* active, int n) {
+__global__ __launch_bounds__(1024) void rp_order_kernel(int* order_all, const int* hdr, const int* active, int base, int n) {
+  // (sorts the envs base .. base + n - 1 into order_all[base .. base + n - 1]; base is a multiple of 8)
+  int* order = order_all + base;
   __shared__ int hist[RP_ORDER_CLASSES][RP_ORDER_BUCKETS];
   for (int i = threadIdx.x; i < RP_ORDER_CLASSES * RP_ORDER_BUCKETS; i += blockDim.x) (&hist[0][0])[i] = 0;
   __syncthreads();
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(1024) void rp_order_kernel(int* order, const int* h
     const int k = 1 + (26 + 5 * (30 + nd + (nd >> 2) + nd * nd / 200 + 2 * nk) + 3 * nc) / 4;
     return k < RP_ORDER_BUCKETS ? k : RP_ORDER_BUCKETS - 1;
   };
-  for (int e = threadIdx.x; e < n; e += blockDim.x) atomicAdd(&hist[e & 7][key_of(e)], 1);
+  for (int e = threadIdx.x; e < n; e += blockDim.x) atomicAdd(&hist[e & 7][key_of(base + e)], 1);
   __syncthreads();
   if (threadIdx.x < RP_ORDER_CLASSES) {  // descending exclusive prefix per class
     int acc = 0;
@@ -65,8 +67,8 @@ __global__ __launch_bounds__(1024) void rp_order_kernel(int* order, const int* h
   }
   __syncthreads();
   for (int e = threadIdx.x; e < n; e += blockDim.x) {
-    const int r = atomicAdd(&hist[e & 7][key_of(e)], 1);
-    order[8 * r + (e & 7)] = e;
+    const int r = atomicAdd(&hist[e & 7][key_of(base + e)], 1);
+    order[8 * r + (e & 7)] = base + e;
   }
 }
 
@@ -135,13 +137,25 @@ struct EngineBase {
   hipEvent_t sv0[kRing] = {}, sv1[kRing] = {};
   unsigned step_calls = 0;
   double solver_ms = 0; int solver_launches = 0;
+  int sv_envs[kRing] = {};            // envs the probed solver launch of that slot covered (a slice or the batch)
+  double solver_envs = 0, last_solver_envs = 0;
+  // stream slices, automatic choice (n_slices == 0): the first 8 steps of every 64 run with one and two
+  // slices in the order 1 2 2 1 1 2 2 1 (a linear drift of the workload cancels); the mode with the lower
+  // mean step time (event ring; sums decay by 1/2 per 64 steps; 1 % hysteresis) runs the other 56
+  int ev_trial[kRing] = {};           // 0 = not a trial step, else the slice count it ran with
+  double trial_ms[3] = {0, 0, 0}, trial_n[3] = {0, 0, 0};
+  int auto_slices = 1; unsigned auto_pos = 0;
   void harvest(int i, bool wait) {
     if (!ev_pending[i]) return;
     if (wait) hipEventSynchronize(ev1[i]);
     else if (hipEventQuery(ev1[i]) != hipSuccess) return;
     float ms = 0;
-    if (hipEventElapsedTime(&ms, ev0[i], ev1[i]) == hipSuccess) { kernel_ms += ms; kernel_launches++; }
-    if (hipEventElapsedTime(&ms, sv0[i], sv1[i]) == hipSuccess) { solver_ms += ms; solver_launches++; }
+    if (hipEventElapsedTime(&ms, ev0[i], ev1[i]) == hipSuccess) {
+      kernel_ms += ms; kernel_launches++;
+      if (ev_trial[i]) { trial_ms[ev_trial[i]] += ms; trial_n[ev_trial[i]]++; }
+    }
+    ev_trial[i] = 0;
+    if (hipEventElapsedTime(&ms, sv0[i], sv1[i]) == hipSuccess) { solver_ms += ms; solver_launches++; solver_envs += sv_envs[i]; }
     ev_pending[i] = false;
   }
   virtual int reset(const uint8_t* mask) = 0;
@@ -152,6 +166,10 @@ struct EngineBase {
   virtual void tolerances(double tol, double ls_tol) = 0;
   bool lazy_position = false;
   bool cost_order = false;   // rp_set_cost_ordered_launch
+  int n_slices = 1;          // rp_set_stream_slices (0 = automatic)
+  static const int kMaxSlices = 4;
+  hipStream_t xstream[kMaxSlices] = {};   // [0] unused: slice 0 runs on the caller's stream
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxSlices] = {};
   virtual int acc_sensors(int on) = 0;
   virtual int field_ptr(rp_field f, void** p, size_t* bytes) = 0;
   bool own_stream = true;
@@ -185,6 +203,11 @@ struct Engine : EngineBase {
       if (sv1[i]) hipEventDestroy(sv1[i]);
     }
     if (stream && own_stream) hipStreamDestroy(stream);
+    for (int i = 1; i < kMaxSlices; i++) {
+      if (xstream[i]) hipStreamDestroy(xstream[i]);
+      if (ev_join[i]) hipEventDestroy(ev_join[i]);
+    }
+    if (ev_fork) hipEventDestroy(ev_fork);
   }
   template <typename U> U* dalloc(size_t n) {
     void* p = nullptr;
@@ -511,11 +534,6 @@ struct Engine : EngineBase {
     if (!on_device) HIP_OK(hipStreamSynchronize(stream));  // device destinations stay stream-ordered
     return 0;
   }
-  void launch_pos(const RpState<T>& st, int k, int nsub) {
-    if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP>), dim3(nenv), dim3(64), 0, stream, M, st, B, k, nsub);
-    else if (mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD, 1>), dim3(nenv), dim3(64), 0, stream, M, st, B, k, nsub);
-    else hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(nenv), dim3(64), 0, stream, M, st, B, k, nsub);
-  }
   int step(int nsub, uint32_t* trace, int mode) override {
     HIP_OK(hipSetDevice(device));
     if (mode == 0 && nsub <= 0) return fail("rp_step: n_substeps must be positive");
@@ -545,49 +563,94 @@ struct Engine : EngineBase {
     // order.  Two small kernels per substep instead of one fused launch: each half fits in
     // registers, and the hand-over (RpStage) stays in L2 / Infinity Cache.
     const int hb = (nenv + 255) / 256;
-    // cost-ordered launch: heaviest envs (by what their last solver stage needed) first
-    auto reorder = [&]() {
-      hipLaunchKernelGGL(rp_order_kernel, dim3(1), dim3(1024), 0, stream, d_order, B.hdr, s.active, nenv);
-    };
-    if (cost_order && mode == 0) s.order = d_order;   // (initialised to the identity; refreshed below)
-    if (lazy_position && mode == 0) {
-      // skip the leading stage for envs whose hand-over is still the one of their current state
-      RpState<T> lead = s;
-      hipLaunchKernelGGL(rp_lead_mask_kernel, dim3(hb), dim3(256), 0, stream, d_lead, s.active, d_valid, nenv);
-      lead.active = d_lead;
-      launch_pos(lead, -1, nsub);
-    } else {
-      launch_pos(s, -1, nsub);
-    }
-    if (mode == 0) {
-      for (int k = 0; k < nsub; k++) {
-        const bool probe = timeit && k == (int)(step_calls % (unsigned)nsub);
-        const bool sense = sensors_on && k == nsub - 1;
-        if (cost_order) reorder();   // from the hand-over the position stage just wrote
-        if (sense) {  // the state this substep's forces belong to (the solver stage integrates in place)
-          HIP_OK(hipMemcpyAsync(d_qpos_prev, S.qpos, sizeof(T) * (size_t)nenv * nv, hipMemcpyDeviceToDevice, stream));
-          HIP_OK(hipMemcpyAsync(d_qvel_prev, S.qvel, sizeof(T) * (size_t)nenv * nv, hipMemcpyDeviceToDevice, stream));
+    // Slices: the batch may be stepped as two halves on two streams.  Within a half the kernels are
+    // ordered (solver -> position -> solver ...), between the halves they are not, so the tail of one
+    // half's launch (a few heavy envs still running, most SIMDs idle) is filled by the other half's
+    // next kernel instead of waiting for a launch boundary.
+    int want = n_slices;
+    if (n_slices == 0 && mode == 0 && !capturing && nenv >= 1024) {
+      const unsigned pos = auto_pos++ % 64u;
+      if (pos < 8) { want = 1 + (int)(((pos + 1u) >> 1) & 1u); ev_trial[slot] = want; }
+      else {
+        if (pos == 40) {  // the trial steps finished long ago: read them without waiting
+          for (int i = 0; i < kRing; i++) if (ev_trial[i]) harvest(i, false);
+          if (trial_n[1] >= 3 && trial_n[2] >= 3) {
+            const double m1 = trial_ms[1] / trial_n[1], m2 = trial_ms[2] / trial_n[2];
+            if (auto_slices == 1 ? m2 < 0.99 * m1 : m1 < 0.99 * m2) auto_slices = 3 - auto_slices;
+          }
+          for (int k = 1; k <= 2; k++) { trial_ms[k] *= 0.5; trial_n[k] *= 0.5; }
         }
-        if (probe) HIP_OK(hipEventRecord(sv0[slot], stream));
+        want = auto_slices;
+      }
+    }
+    int nsl = (mode == 0 && want > 1 && nenv >= 1024 && !capturing) ? (want >= 4 ? 4 : 2) : 1;
+    if (nsl > 1 && !ev_fork && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev_fork = nullptr; nsl = 1; }
+    for (int i = 1; i < nsl; i++) {
+      if (xstream[i]) continue;
+      if (hipStreamCreateWithFlags(&xstream[i], hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); xstream[i] = nullptr; nsl = 1; break; }
+    }
+    // slice sl covers the envs [bound(sl), bound(sl + 1)); bounds are multiples of 8 (XCD classes of the order)
+    auto bound = [&](int sl) { return sl >= nsl ? nenv : (int)(((long long)nenv * sl / nsl + 7) / 8 * 8); };
+    if (cost_order && mode == 0) s.order = d_order;   // (initialised to the identity; refreshed below)
+    if (lazy_position && mode == 0)
+      hipLaunchKernelGGL(rp_lead_mask_kernel, dim3(hb), dim3(256), 0, stream, d_lead, s.active, d_valid, nenv);
+    if (nsl > 1) {
+      HIP_OK(hipEventRecord(ev_fork, stream));
+      for (int i = 1; i < nsl; i++) HIP_OK(hipStreamWaitEvent(xstream[i], ev_fork, 0));
+    }
+    for (int sl = 0; sl < nsl; sl++) {
+      hipStream_t st = sl == 0 ? stream : xstream[sl];
+      const int base = bound(sl), cnt = bound(sl + 1) - base;
+      RpState<T> ss = s;
+      ss.env_base = base;
+      auto launch_pos_on = [&](const RpState<T>& q, int k) {
+        if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
+        else if (mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD, 1>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
+        else hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
+      };
+      // mj_step1 for the current state ...
+      if (lazy_position && mode == 0) {
+        // ... skipped for envs whose hand-over is still the one of their current state
+        RpState<T> lead = ss;
+        lead.active = d_lead;
+        launch_pos_on(lead, -1);
+      } else {
+        launch_pos_on(ss, -1);
+      }
+      if (mode != 0) continue;
+      // ... then n_sub x (mj_step2; mj_step1): dm_control's legacy order.  Two kernels per substep instead
+      // of one fused launch: each half fits in registers, the hand-over (RpStage) stays in L2 / Infinity Cache.
+      for (int k = 0; k < nsub; k++) {
+        const bool probe = timeit && sl == 0 && k == (int)(step_calls % (unsigned)nsub);
+        const bool sense = sensors_on && k == nsub - 1;
+        // cost-ordered launch: heaviest envs first, from the hand-over the position stage just wrote
+        if (cost_order) hipLaunchKernelGGL(rp_order_kernel, dim3(1), dim3(1024), 0, st, d_order, B.hdr, s.active, base, cnt);
+        if (sense) {  // the state this substep's forces belong to (the solver stage integrates in place)
+          HIP_OK(hipMemcpyAsync(d_qpos_prev + (size_t)base * nv, S.qpos + (size_t)base * nv, sizeof(T) * (size_t)cnt * nv, hipMemcpyDeviceToDevice, st));
+          HIP_OK(hipMemcpyAsync(d_qvel_prev + (size_t)base * nv, S.qvel + (size_t)base * nv, sizeof(T) * (size_t)cnt * nv, hipMemcpyDeviceToDevice, st));
+        }
+        if (probe) { HIP_OK(hipEventRecord(sv0[slot], st)); sv_envs[slot] = cnt; }
         // solver stage; the build specialised for "every tree has a 4-link trunk" when it applies
-        if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 0, RPK_MAXD_DEEP>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
-        else if (trunk4) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 4>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
-        else hipLaunchKernelGGL((rp_stage_kernel<T, 1>), dim3(nenv), dim3(64), 0, stream, M, s, B, k, nsub);
-        if (probe) HIP_OK(hipEventRecord(sv1[slot], stream));
+        if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 0, RPK_MAXD_DEEP>), dim3(cnt), dim3(64), 0, st, M, ss, B, k, nsub);
+        else if (trunk4) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 4>), dim3(cnt), dim3(64), 0, st, M, ss, B, k, nsub);
+        else hipLaunchKernelGGL((rp_stage_kernel<T, 1>), dim3(cnt), dim3(64), 0, st, M, ss, B, k, nsub);
+        if (probe) HIP_OK(hipEventRecord(sv1[slot], st));
         if (sense) {
           // sensor stage: position / velocity stage of the saved state + mj_rnePostConstraint with the
           // constrained qacc (S.warm) and the contact row forces the solver stage just stored
-          RpState<T> ss = s;
-          ss.qpos = d_qpos_prev; ss.qvel = d_qvel_prev;
-          ss.sens_torque = d_sens_torque; ss.sens_touch = d_sens_touch;
-          ss.key_trace = nullptr; ss.prof = nullptr;
-          if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 2, 0, RPK_MAXD_DEEP>), dim3(nenv), dim3(64), 0, stream, M, ss, B, -1, nsub);
-          else if (mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 2, 0, RPK_MAXD, 1>), dim3(nenv), dim3(64), 0, stream, M, ss, B, -1, nsub);
-          else hipLaunchKernelGGL((rp_stage_kernel<T, 2>), dim3(nenv), dim3(64), 0, stream, M, ss, B, -1, nsub);
+          RpState<T> sq = ss;
+          sq.qpos = d_qpos_prev; sq.qvel = d_qvel_prev;
+          sq.sens_torque = d_sens_torque; sq.sens_touch = d_sens_touch;
+          sq.key_trace = nullptr; sq.prof = nullptr;
+          if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 2, 0, RPK_MAXD_DEEP>), dim3(cnt), dim3(64), 0, st, M, sq, B, -1, nsub);
+          else if (mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 2, 0, RPK_MAXD, 1>), dim3(cnt), dim3(64), 0, st, M, sq, B, -1, nsub);
+          else hipLaunchKernelGGL((rp_stage_kernel<T, 2>), dim3(cnt), dim3(64), 0, st, M, sq, B, -1, nsub);
         }
-        launch_pos(s, k, nsub);
+        launch_pos_on(ss, k);
       }
     }
+    for (int i = 1; i < nsl; i++) { HIP_OK(hipEventRecord(ev_join[i], xstream[i])); HIP_OK(hipStreamWaitEvent(stream, ev_join[i], 0)); }
     hipLaunchKernelGGL(rp_mark_valid_kernel, dim3(hb), dim3(256), 0, stream, d_valid, s.active, nenv);
     HIP_OK(hipGetLastError());
     if (mode == 0) step_calls++;
@@ -673,6 +736,12 @@ int rp_set_lazy_position_stage(rp_engine* e, int on) {
   return 0;
 }
 int rp_set_acc_sensors(rp_engine* e, int on) { return e ? E(e)->acc_sensors(on) : fail("null engine"); }
+int rp_set_stream_slices(rp_engine* e, int n) {
+  if (!e) return fail("null engine");
+  if (n != 0 && n != 1 && n != 2 && n != 4) return fail("rp_set_stream_slices: 0 (automatic), 1, 2 or 4");
+  E(e)->n_slices = n;
+  return 0;
+}
 int rp_set_cost_ordered_launch(rp_engine* e, int on) {
   if (!e) return fail("null engine");
   E(e)->cost_order = on != 0;
@@ -737,8 +806,14 @@ int rp_solver_kernel_time(rp_engine* e, double* avg_ms, int* n_launches) {
   for (int i = 0; i < EngineBase::kRing; i++) b->harvest(i, true);
   if (avg_ms) *avg_ms = b->solver_launches ? b->solver_ms / b->solver_launches : 0.0;
   if (n_launches) *n_launches = b->solver_launches;
-  b->solver_ms = 0; b->solver_launches = 0;
+  b->last_solver_envs = b->solver_launches ? b->solver_envs / b->solver_launches : 0.0;
+  b->solver_ms = 0; b->solver_launches = 0; b->solver_envs = 0;
   (void)km; (void)kl;
+  return 0;
+}
+int rp_solver_kernel_envs(rp_engine* e, double* avg_envs) {
+  if (!e) return fail("null engine");
+  if (avg_envs) *avg_envs = E(e)->last_solver_envs;
   return 0;
 }
 

@@ -138,11 +138,14 @@ __global__ void rp_reset_kernel(RpState<T> S, const T* qpos0, const unsigned cha
 // The host launches  pos, then n_substeps x (sol, pos);  RpStage carries the hand-over.
 // ============================================================================
 template <typename T, int MODE, int FIXED_TL = 0, int MD = RPK_MAXD, int MESH = 0>
-__global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_stage_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep,
+#ifndef RPK_SOL64_WAVES
+#define RPK_SOL64_WAVES 1
+#endif
+__global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_WAVES) void rp_stage_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep,
                                                      int nsub) {
   using namespace rpk;
   using N = Num<T>;
-  const int env = S.order ? S.order[blockIdx.x] : blockIdx.x;
+  const int env = S.order ? S.order[S.env_base + blockIdx.x] : S.env_base + (int)blockIdx.x;
   const int lane = threadIdx.x;
   const int env_active = S.active ? S.active[env] : 1;  // tested after the prologue loads are in flight
   __shared__ Smem<T, MODE, MD> sm;
@@ -355,16 +358,18 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
         fr_aref = LF(7);
 #pragma unroll
         for (int k = 0; k < 3; k++) { lim_D[k] = LF(8 + k); lim_aref[k] = LF(11 + k); }
-        con_D = LF(14); con_mu = LF(15);
+        if (lane < ncon) {  // the contact lanes' fields: only those lanes' cache lines cross (other lanes: the defaults)
+          con_D = LF(14); con_mu = LF(15);
 #pragma unroll
-        for (int k = 0; k < 3; k++) { con_n[k] = LF(16 + k); con_t1[k] = LF(19 + k); con_t2[k] = LF(22 + k); }
+          for (int k = 0; k < 3; k++) { con_n[k] = LF(16 + k); con_t1[k] = LF(19 + k); con_t2[k] = LF(22 + k); }
 #pragma unroll
-        for (int k = 0; k < 4; k++) con_aref[k] = LF(25 + k);
+          for (int k = 0; k < 4; k++) con_aref[k] = LF(25 + k);
+          con_A = LI(1); con_B = LI(2); con_slot = LI(3); con_cross = LI(4);
+          con_maskA = ((unsigned long long)(unsigned)LI(6) << 32) | (unsigned)LI(5);
+          con_maskB = ((unsigned long long)(unsigned)LI(8) << 32) | (unsigned)LI(7);
+        }
         int ls = LI(0);
         lim_sign[0] = (ls & 3) - 1; lim_sign[1] = ((ls >> 2) & 3) - 1; lim_sign[2] = ((ls >> 4) & 3) - 1;
-        con_A = LI(1); con_B = LI(2); con_slot = LI(3); con_cross = LI(4);
-        con_maskA = ((unsigned long long)(unsigned)LI(6) << 32) | (unsigned)LI(5);
-        con_maskB = ((unsigned long long)(unsigned)LI(8) << 32) | (unsigned)LI(7);
         sdepth = LI(9);
         if (isl) {
 #pragma unroll
@@ -1980,15 +1985,17 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : 1) void rp_
       LF(7) = fr_aref;
 #pragma unroll
       for (int k = 0; k < 3; k++) { LF(8 + k) = lim_D[k]; LF(11 + k) = lim_aref[k]; }
-      LF(14) = con_D; LF(15) = con_mu;
+      if (lane < ncon) {  // (the solver stage reads these for lanes < ncon only)
+        LF(14) = con_D; LF(15) = con_mu;
 #pragma unroll
-      for (int k = 0; k < 3; k++) { LF(16 + k) = con_n[k]; LF(19 + k) = con_t1[k]; LF(22 + k) = con_t2[k]; }
+        for (int k = 0; k < 3; k++) { LF(16 + k) = con_n[k]; LF(19 + k) = con_t1[k]; LF(22 + k) = con_t2[k]; }
 #pragma unroll
-      for (int k = 0; k < 4; k++) LF(25 + k) = con_aref[k];
+        for (int k = 0; k < 4; k++) LF(25 + k) = con_aref[k];
+        LI(1) = con_A; LI(2) = con_B; LI(3) = con_slot; LI(4) = con_cross;
+        LI(5) = (int)(con_maskA & 0xffffffffu); LI(6) = (int)(con_maskA >> 32);
+        LI(7) = (int)(con_maskB & 0xffffffffu); LI(8) = (int)(con_maskB >> 32);
+      }
       LI(0) = (lim_sign[0] + 1) | ((lim_sign[1] + 1) << 2) | ((lim_sign[2] + 1) << 4);
-      LI(1) = con_A; LI(2) = con_B; LI(3) = con_slot; LI(4) = con_cross;
-      LI(5) = (int)(con_maskA & 0xffffffffu); LI(6) = (int)(con_maskA >> 32);
-      LI(7) = (int)(con_maskB & 0xffffffffu); LI(8) = (int)(con_maskB >> 32);
       LI(9) = sdepth;
       LI(11) = salink | (sTL << 8) | (sTB << 16);
       if (lane < 16) {

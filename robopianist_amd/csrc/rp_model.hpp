@@ -22,9 +22,13 @@
 #define RPK_WAVE 64
 #define RPK_NC 32        // max contacts kept per env (= RP_MAX_CONTACTS; contact c lives in lane c)
 #define RPK_NCOUT 32     // == RP_MAX_CONTACTS
+#ifndef RPK_NE
 #define RPK_NE 256      // max contact Jacobian entries (contact, dof) handed to the solver (fp64; see RpCaps)
+#endif
 #define RPK_NBOXF 32     // boxes / hull boxes covered by the oriented-box prefilter
+#ifndef RPK_HMAX
 #define RPK_HMAX 60      // max rows of the dense cross-coupling block (+1 row for its rhs = one lane each; fp64)
+#endif
 #define RPK_WORK 128     // narrow-phase work list
 #define RPK_MAXD 9       // tree depth levels held by the default kernel builds (trunk <= 4 links + chain <= 5)
 #define RPK_MAXD_DEEP 13 // ... by the deep builds (trunk <= 8 links: every subset of the six forearm dofs)
@@ -143,6 +147,7 @@ struct RpState {
   // predicted cost (longest-processing-time-first: with one wave per env and four sequential
   // rounds per SIMD, a heavy env that starts last is the tail of the whole launch)
   const int* order;
+  int env_base;   // workgroup b of a launch stands for position env_base + b (a launch may cover a slice of the batch)
   // may be null: shader-clock cycles (>> 8) every env's wave spent in its last position stage /
   // solver stage -- the cost predictor of the ordered launch
   int *cost_pos, *cost_sol;

@@ -37,9 +37,9 @@ WARN_DENSE_FULL = 32
 
 EXPORTED_SYMBOLS = (
     "rp_create", "rp_destroy", "rp_reset", "rp_set", "rp_get", "rp_step", "rp_forward",
-    "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_set_lazy_position_stage", "rp_set_cost_ordered_launch", "rp_set_acc_sensors", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
+    "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_set_lazy_position_stage", "rp_set_cost_ordered_launch", "rp_set_stream_slices", "rp_set_acc_sensors", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
     "rp_n_envs", "rp_dim",
-    "rp_kernel_time", "rp_solver_kernel_time", "rp_profile", "rp_last_error",
+    "rp_kernel_time", "rp_solver_kernel_time", "rp_solver_kernel_envs", "rp_profile", "rp_last_error",
 )
 
 _lib = None
@@ -76,6 +76,7 @@ def load_library(path: str = LIB_PATH):
     L.rp_set_lazy_position_stage.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.rp_set_cost_ordered_launch.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.rp_set_acc_sensors.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.rp_set_stream_slices.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.rp_get_stream.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
     L.rp_n_envs.argtypes = [ctypes.c_void_p]
     L.rp_dim.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
@@ -83,6 +84,7 @@ def load_library(path: str = LIB_PATH):
                                  ctypes.POINTER(ctypes.c_int)]
     L.rp_solver_kernel_time.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_int)]
+    L.rp_solver_kernel_envs.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
     L.rp_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     L.rp_set_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.rp_field_ptr.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
@@ -243,6 +245,10 @@ class BatchedPhysics:
         rp_step (include/rp_engine.h)."""
         self._check(self._L.rp_set_acc_sensors(self._h, int(bool(on))))
 
+    def set_stream_slices(self, n: int = 0):
+        """rp_step steps the batch as `n` (1 or 2; 0 = the engine picks) kernel chains (include/rp_engine.h)."""
+        self._check(self._L.rp_set_stream_slices(self._h, int(n)))
+
     def set_cost_ordered_launch(self, on: bool = True):
         """Stage kernels process the envs heaviest-first (include/rp_engine.h); bit-identical results."""
         self._check(self._L.rp_set_cost_ordered_launch(self._h, int(bool(on))))
@@ -261,6 +267,12 @@ class BatchedPhysics:
         ms = ctypes.c_double(); n = ctypes.c_int()
         self._check(self._L.rp_solver_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
+
+    def solver_kernel_envs(self):
+        """Average envs per launch over the launches the last solver_kernel_time() reported."""
+        v = ctypes.c_double()
+        self._check(self._L.rp_solver_kernel_envs(self._h, ctypes.byref(v)))
+        return v.value
 
     def profile(self, enable=True):
         """Reads+clears the per-phase cycle counters of env 0, then (dis)enables them."""

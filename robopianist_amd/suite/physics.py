@@ -51,6 +51,9 @@ class TorchPhysics:
         e.set_lazy_position_stage(True)
         # heterogeneous batches (random policies, envs at their own episode times): heaviest envs first
         e.set_cost_ordered_launch(os.environ.get("RP_COST_ORDER", "1") != "0")
+        # two halves of the batch on two streams (one half's launch tail overlaps the other half's next
+        # kernel) when the engine measures that to be faster: heterogeneous batches
+        e.set_stream_slices(int(os.environ.get("RP_STREAM_SLICES", "0")))
         from robopianist_amd.model import engine_tables
         t = engine_tables.build_engine_tables(self.model, scene_info.key_joint_ids)
         self._site_modelid = {int(s): i for i, s in enumerate(t["eng_site_modelid"])}
