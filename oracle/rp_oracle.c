@@ -1316,6 +1316,69 @@ static double ls_eval(const rpo_data* d, const double* quadGauss, double alpha, 
   return cost;
 }
 
+/* One point of the line search [MJ: mjPrimalPnt]: phi and its first two derivatives at alpha. */
+typedef struct { double alpha, cost, d0, d1; } ls_pnt;
+
+static ls_pnt ls_point(const rpo_data* d, const double* quadGauss, double alpha, int* evals) {
+  ls_pnt p;
+  p.alpha = alpha;
+  p.cost = ls_eval(d, quadGauss, alpha, &p.d0, &p.d1);
+  (*evals)++;
+  return p;
+}
+
+/* [MJ: updateBracket] move one end of the bracket to the candidate on the same side of the root
+ * whose slope is closest to zero; if it moved, its Newton successor is evaluated into *pnext. */
+static int ls_update_bracket(const rpo_data* d, const double* quadGauss, ls_pnt* p, const ls_pnt cand[3],
+                             ls_pnt* pnext, int* evals) {
+  int flag = 0;
+  for (int i = 0; i < 3; i++) {
+    if (p->d0 < 0 && cand[i].d0 < 0 && p->d0 < cand[i].d0) { *p = cand[i]; flag = 1; }
+    else if (p->d0 > 0 && cand[i].d0 > 0 && p->d0 > cand[i].d0) { *p = cand[i]; flag = 2; }
+  }
+  if (flag) *pnext = ls_point(d, quadGauss, p->alpha - p->d0 / p->d1, evals);
+  return flag;
+}
+
+/* Exact line search along `search` [MJ: engine_solver.c PrimalSearch, restated]: a Newton step from
+ * alpha = 0; Newton steps on phi' while the slope keeps its sign (one-sided phase); once the root
+ * of phi' is bracketed, each round evaluates the midpoint and the Newton successors of both
+ * bracket ends, returns the best candidate whose |phi'| < gtol, otherwise tightens the bracket.
+ * Returns alpha (0 = no improvement). */
+static double primal_search(const rpo_model* m, const rpo_data* d, const double* quadGauss, double gtol) {
+  int evals = 0;
+  ls_pnt p0 = ls_point(d, quadGauss, 0, &evals);
+  if (!(p0.d1 > 0)) return 0;
+  ls_pnt p1 = ls_point(d, quadGauss, p0.alpha - p0.d0 / p0.d1, &evals);   /* always one Newton step */
+  if (p0.cost < p1.cost) p1 = p0;
+  if (fabs(p1.d0) < gtol) return p1.alpha;
+  int dir = p1.d0 < 0 ? 1 : -1;
+  ls_pnt p2 = p1;
+  int p2update = 0;
+  while (p1.d0 * dir <= -gtol && evals < m->ls_iterations) {               /* one-sided search */
+    p2 = p1; p2update = 1;
+    p1 = ls_point(d, quadGauss, p1.alpha - p1.d0 / p1.d1, &evals);
+    if (fabs(p1.d0) < gtol) return p1.alpha;
+  }
+  if (evals >= m->ls_iterations || !p2update) return p1.alpha;             /* failed to bracket */
+  ls_pnt p2next = p1;
+  ls_pnt p1next = ls_point(d, quadGauss, p1.alpha - p1.d0 / p1.d1, &evals);
+  while (evals < m->ls_iterations) {                                        /* bracketed search */
+    ls_pnt pmid = ls_point(d, quadGauss, 0.5 * (p1.alpha + p2.alpha), &evals);
+    ls_pnt cand[3] = {p1next, p2next, pmid};
+    int best = -1;
+    for (int i = 0; i < 3; i++)
+      if (fabs(cand[i].d0) < gtol && (best < 0 || cand[i].cost < cand[best].cost)) best = i;
+    if (best >= 0) return cand[best].alpha;
+    int b1 = ls_update_bracket(d, quadGauss, &p1, cand, &p1next, &evals);
+    int b2 = ls_update_bracket(d, quadGauss, &p2, cand, &p2next, &evals);
+    if (!b1 && !b2) return pmid.alpha;                                      /* numerical accuracy reached */
+  }
+  if (p1.cost <= p2.cost && p1.cost < p0.cost) return p1.alpha;
+  if (p2.cost <= p1.cost && p2.cost < p0.cost) return p2.alpha;
+  return 0;
+}
+
 static void mul_J(const rpo_model* m, const rpo_data* d, double* res, const double* v) {
   int nv = m->nv;
   for (int i = 0; i < d->nefc; i++) {
@@ -1422,26 +1485,10 @@ static void solve_newton(const rpo_model* m, rpo_data* d) {
       quadGauss[1] += d->search[j] * (d->Ma[j] - d->qfrc_smooth[j]);
       quadGauss[2] += 0.5 * d->search[j] * d->Mv[j];
     }
-    /* exact line search: safeguarded Newton on phi'(alpha) (monotone, piecewise linear) */
+    /* exact line search [MJ: PrimalSearch]; gtol = tolerance * ls_tolerance * |search| * meaninertia * max(1, nv) */
     double gtol = m->tolerance * m->ls_tolerance * snorm / scale;
-    double f0, h0, f, h;
-    double c0 = ls_eval(d, quadGauss, 0, &f0, &h0);
-    double alpha = 0;
-    if (f0 < 0 && h0 > 0) {
-      double lo = 0, hi = INFINITY;
-      alpha = -f0 / h0;
-      for (int it = 0; it < m->ls_iterations; it++) {
-        ls_eval(d, quadGauss, alpha, &f, &h);
-        if (fabs(f) < gtol) break;
-        if (f < 0) lo = alpha; else hi = alpha;
-        double an = alpha - f / h;
-        if (!(an > lo && an < hi)) an = isinf(hi) ? 2*alpha : 0.5*(lo + hi);
-        alpha = an;
-      }
-      double c1 = ls_eval(d, quadGauss, alpha, &f, &h);
-      if (c1 > c0) alpha = 0;
-    }
-    if (alpha == 0) break;
+    double alpha = primal_search(m, d, quadGauss, gtol);
+    if (!(alpha > 0)) break;   /* no improvement */
     for (int j = 0; j < nv; j++) { d->qacc[j] += alpha*d->search[j]; d->Ma[j] += alpha*d->Mv[j]; }
     for (int i = 0; i < ne; i++) d->efc_jar[i] += alpha * d->efc_jv[i];
     double oldcost = cost;

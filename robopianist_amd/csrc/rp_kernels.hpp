@@ -1035,38 +1035,66 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
           }
           g0 = (T)0.5 * wave_sum(g0); g1 = wave_sum(g1); g2 = (T)0.5 * wave_sum(g2);
           PROF(6);
-          // ---- exact line search: safeguarded Newton on phi'(alpha)
-          // phi(alpha) and its first two derivatives; the cost itself is only needed at
-          // the end points, the Newton iterations on phi' skip that wave reduction
+          // ---- exact line search [MJ: PrimalSearch]
+          // [MJ: PrimalPrepare] along the search direction every row's cost is a quadratic in alpha while
+          // the row stays in one zone: q0 + alpha q1 + alpha^2 q2 with q = D (jar^2/2, jar jv, jv^2/2).
+          // The coefficients are formed once per Newton iteration; an evaluation then only tests each
+          // row's zone at alpha and sums the coefficients of the active rows [MJ: PrimalEval].  Rows a
+          // lane does not own get zero coefficients.
+          T qfr[3] = {0, 0, 0}, qfl[2] = {0, 0}, frf = -1;   // friction row: quadratic zone, linear zones (+-), zone bound R f
+          if (isl && lfloss > 0) {
+            frf = lflR * lfloss;
+            qfr[0] = (T)0.5 * lflD * jar.fr * jar.fr; qfr[1] = lflD * jar.fr * jv.fr; qfr[2] = (T)0.5 * lflD * jv.fr * jv.fr;
+            qfl[0] = -(T)0.5 * frf * lfloss; qfl[1] = lfloss * jar.fr;   // linear zones: qfl[0] -+ qfl[1], slope -+ lfloss jv
+          }
+          const T frs = lfloss * jv.fr;
+          T qlim[3][3], qcon[4][3];
+#pragma unroll
+          for (int s = 0; s < 3; s++) {
+            const T Dp = lim_sign[s] != 0 ? lim_D[s] : (T)0;
+            qlim[s][0] = (T)0.5 * Dp * jar.lim[s] * jar.lim[s]; qlim[s][1] = Dp * jar.lim[s] * jv.lim[s];
+            qlim[s][2] = (T)0.5 * Dp * jv.lim[s] * jv.lim[s];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const T Dp = hascon ? con_D : (T)0;
+            qcon[r][0] = (T)0.5 * Dp * jar.con[r] * jar.con[r]; qcon[r][1] = Dp * jar.con[r] * jv.con[r];
+            qcon[r][2] = (T)0.5 * Dp * jv.con[r] * jv.con[r];
+          }
+          const bool any_con = ncon > 0;
+          // phi(alpha) and its first two derivatives; the one-sided Newton iterations on phi' never
+          // read the cost and skip that wave reduction
           auto ls_eval = [&](T alpha, T& d1, T& d2, const bool with_cost) -> T {
 #ifdef RPK_LS_COUNTER
             if (S.prof && env == 0 && lane == 0) sm.prof[26] += 1;  // evaluations (debug counter)
 #endif
-            T cst = 0, a = 0, b = 0;
-            if (isl && lfloss > 0) {
-              T xx = jar.fr + alpha * jv.fr, rf = lflR * lfloss;
-              if (xx <= -rf) { cst += -(T)0.5 * rf * lfloss - lfloss * xx; a += -lfloss * jv.fr; }
-              else if (xx >= rf) { cst += -(T)0.5 * rf * lfloss + lfloss * xx; a += lfloss * jv.fr; }
-              else { cst += (T)0.5 * lflD * xx * xx; a += lflD * xx * jv.fr; b += lflD * jv.fr * jv.fr; }
+            T s0 = 0, s1 = 0, s2 = 0;
+            {
+              const T xx = jar.fr + alpha * jv.fr;
+              const bool lo_ = xx <= -frf, hi_ = xx >= frf;   // (frf < 0 on lanes without the row: both true, zero coefficients)
+              s0 = lo_ ? qfl[0] - qfl[1] : (hi_ ? qfl[0] + qfl[1] : qfr[0]);
+              s1 = lo_ ? -frs : (hi_ ? frs : qfr[1]);
+              s2 = (lo_ || hi_) ? (T)0 : qfr[2];
+              if (frf < 0) { s0 = 0; s1 = 0; }
             }
 #pragma unroll
-            for (int s = 0; s < 3; s++) if (lim_sign[s] != 0) {
-              T xx = jar.lim[s] + alpha * jv.lim[s];
-              if (xx < 0) { cst += (T)0.5 * lim_D[s] * xx * xx; a += lim_D[s] * xx * jv.lim[s]; b += lim_D[s] * jv.lim[s] * jv.lim[s]; }
+            for (int s = 0; s < 3; s++) {
+              const T xx = jar.lim[s] + alpha * jv.lim[s];
+              if (xx < 0) { s0 += qlim[s][0]; s1 += qlim[s][1]; s2 += qlim[s][2]; }
             }
-            if (hascon) {
+            if (any_con) {
 #pragma unroll
               for (int r = 0; r < 4; r++) {
-                T xx = jar.con[r] + alpha * jv.con[r];
-                if (xx < 0) { cst += (T)0.5 * con_D * xx * xx; a += con_D * xx * jv.con[r]; b += con_D * jv.con[r] * jv.con[r]; }
+                const T xx = jar.con[r] + alpha * jv.con[r];
+                if (xx < 0) { s0 += qcon[r][0]; s1 += qcon[r][1]; s2 += qcon[r][2]; }
               }
             }
-            a = wave_sum(a); b = wave_sum(b);
-            d1 = a + (T)2 * alpha * g2 + g1;
-            d2 = b + (T)2 * g2;
+            s1 = wave_sum(s1) + g1; s2 = wave_sum(s2) + g2;
+            d1 = s1 + (T)2 * alpha * s2;
+            d2 = (T)2 * s2;
             if (!with_cost) return (T)0;
-            cst = wave_sum(cst);
-            return cst + alpha * alpha * g2 + alpha * g1 + g0;
+            s0 = wave_sum(s0) + g0;
+            return s0 + alpha * (s1 + alpha * s2);
           };
           T gtol = M.tolerance * M.ls_tolerance * snorm / scale;
           // phi at alpha = 0 needs no row evaluation: phi(0) is the current cost,
@@ -1075,29 +1103,73 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
           // Newton step alpha = 1.
           // (fp64 only: in fp32 the cost carried over from the last update and the cost
           // formula of ls_eval differ by more than the improvements being compared.)
-          T f, hh, f0, h0, c0;
+          T f0, h0, c0;
           if constexpr (sizeof(T) == 8) {
             f0 = wave_sum(grad[0] * search[0] + grad[1] * search[1] + grad[2] * search[2]);
             h0 = -f0; c0 = cost;
           } else {
             c0 = ls_eval((T)0, f0, h0, true);
           }
+          // [MJ: engine_solver.c PrimalSearch, restated; the oracle's primal_search is the same
+          // procedure written sequentially]  All of this is wave-uniform scalar control flow; a
+          // point's cost is only reduced where the procedure reads it.  (Measured alternatives with
+          // fewer inlined copies of ls_eval -- a state machine around one evaluation site, a to-do
+          // list around two -- were 1 ... 4 % slower than this straight transcription.)
+          struct LsPnt { T a, c, d0, d1; };
+          auto ls_point = [&](T al, const bool with_cost) -> LsPnt {
+            LsPnt p; p.a = al; p.c = ls_eval(al, p.d0, p.d1, with_cost); return p;
+          };
           T alpha = 0;
-          if (f0 < 0 && h0 > 0) {
-            T lo_ = 0, hi_ = (T)-1;  // hi_<0: unbounded
-            alpha = -f0 / h0;
-            for (int it = 0; it < S.max_ls; it++) {
-              ls_eval(alpha, f, hh, false);
-              if (N::abs(f) < gtol) break;
-              if (f < 0) lo_ = alpha; else hi_ = alpha;
-              T an = alpha - f / hh;
-              bool inside = an > lo_ && (hi_ < 0 || an < hi_);
-              if (!inside) an = hi_ < 0 ? (T)2 * alpha : (T)0.5 * (lo_ + hi_);
-              if (N::abs(an - alpha) <= (T)4 * N::eps() * N::abs(alpha)) { alpha = an; break; }
-              alpha = an;
+          if (h0 > 0) {
+            const int max_ls = S.max_ls;
+            int evals = 2;                       // (alpha = 0 and the first Newton point)
+            const LsPnt p0 = {(T)0, c0, f0, h0};
+            LsPnt p1 = ls_point(-f0 / h0, true);  // always one Newton step
+            if (p0.c < p1.c) p1 = p0;
+            alpha = p1.a;
+            if (!(N::abs(p1.d0) < gtol)) {
+              const T dir = p1.d0 < 0 ? (T)1 : (T)-1;
+              LsPnt p2 = p1;
+              bool p2update = false, converged = false;
+              while (p1.d0 * dir <= -gtol && evals < max_ls) {   // one-sided search
+                p2 = p1; p2update = true;
+                p1 = ls_point(p1.a - p1.d0 / p1.d1, false); evals++;
+                if (N::abs(p1.d0) < gtol) { converged = true; break; }
+              }
+              alpha = p1.a;   // converged, or failed to bracket
+              if (!converged && evals < max_ls && p2update) {     // bracketed search
+                LsPnt p2next = p1;   // (its cost is never read: it is not converged, and the costs of the bracket ends are re-evaluated below)
+                LsPnt p1next = ls_point(p1.a - p1.d0 / p1.d1, true); evals++;
+                // [MJ: updateBracket] the candidate on p's side of the root whose slope is closest to zero
+                auto update_bracket = [&](LsPnt& p, const LsPnt& ca, const LsPnt& cb, const LsPnt& cc, LsPnt& pnext) -> bool {
+                  bool moved = false;
+                  auto consider = [&](const LsPnt& c) {
+                    if ((p.d0 < 0 && c.d0 < 0 && p.d0 < c.d0) || (p.d0 > 0 && c.d0 > 0 && p.d0 > c.d0)) { p = c; moved = true; }
+                  };
+                  consider(ca); consider(cb); consider(cc);
+                  if (moved) { pnext = ls_point(p.a - p.d0 / p.d1, true); evals++; }
+                  return moved;
+                };
+                bool settled = false;
+                while (evals < max_ls) {
+                  const LsPnt pmid = ls_point((T)0.5 * (p1.a + p2.a), true); evals++;
+                  const LsPnt ca = p1next, cb = p2next;   // this round's candidates: ca, cb, pmid
+                  T bestc = 0; bool found = false;
+                  if (N::abs(ca.d0) < gtol) { found = true; bestc = ca.c; alpha = ca.a; }
+                  if (N::abs(cb.d0) < gtol && (!found || cb.c < bestc)) { found = true; bestc = cb.c; alpha = cb.a; }
+                  if (N::abs(pmid.d0) < gtol && (!found || pmid.c < bestc)) { found = true; alpha = pmid.a; }
+                  if (found) { settled = true; break; }
+                  const bool b1 = update_bracket(p1, ca, cb, pmid, p1next);
+                  const bool b2 = update_bracket(p2, ca, cb, pmid, p2next);
+                  if (!b1 && !b2) { alpha = pmid.a; settled = true; break; }   // numerical accuracy reached
+                }
+                if (!settled) {   // evaluations exhausted: the better end of the bracket, if it beats alpha = 0
+                  T t1, t2;
+                  const T c1 = ls_eval(p1.a, t1, t2, true), c2 = ls_eval(p2.a, t1, t2, true);
+                  alpha = (c1 <= c2 && c1 < p0.c) ? p1.a : ((c2 <= c1 && c2 < p0.c) ? p2.a : (T)0);
+                }
+              }
             }
-            T c1 = ls_eval(alpha, f, hh, true);
-            if (c1 > c0) alpha = 0;
           }
           PROF(7);
           if (!(alpha > 0)) break;

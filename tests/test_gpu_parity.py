@@ -374,6 +374,48 @@ def test_lazy_position_stage_is_bit_identical(two_hand_scene):
     assert a.warn_flags.max() == 0
 
 
+@pytest.mark.gpu
+def test_stream_slices_and_cost_order_are_bit_identical(two_hand_scene):
+    """rp_set_stream_slices / rp_set_cost_ordered_launch only change WHEN an env's kernels run
+    (which stream, which workgroup index): 1100 envs on different controls, with sensors on,
+    masked resets and envs sitting out -- same bits as the plain engine in every mode."""
+    from robopianist_amd import engine
+    si = two_hand_scene
+    m = si.model
+    E = 1100   # (slices need >= 1024 envs; not a multiple of the slice rounding)
+    ctrl = _replay_ctrl(si)
+    rng = np.random.default_rng(1)
+    gain = 1 + 0.1 * rng.standard_normal((E, 1))
+    ref = engine.BatchedPhysics(m, si.key_joint_ids, n_envs=E, precision=64)
+    ref.set_acc_sensors(True)
+    modes = []
+    for slices, order in ((2, False), (4, True), (0, True)):
+        p = engine.BatchedPhysics(m, si.key_joint_ids, n_envs=E, precision=64)
+        p.set_stream_slices(slices); p.set_cost_ordered_launch(order); p.set_acc_sensors(True)
+        modes.append(p)
+    for t in range(24):
+        c = ctrl[10 * (t + 20)][None, :] * gain
+        mask = None
+        if t == 8:
+            mask = np.zeros(E, np.uint8); mask[::7] = 1
+        for p in [ref] + modes:
+            p.set(engine.CTRL, c)
+            if mask is not None:
+                p.reset(mask)
+            if t == 12:
+                act = np.ones(E, np.int32); act[5::11] = 0
+                p.view(engine.ACTIVE).copy_(torch_i32(act))
+            if t == 13:
+                p.view(engine.ACTIVE).fill_(1)
+            p.step(10)
+        for p in modes:
+            assert np.array_equal(ref.qpos, p.qpos) and np.array_equal(ref.qvel, p.qvel), t
+            assert np.array_equal(ref.get(engine.NCON), p.get(engine.NCON))
+            assert np.array_equal(ref.get(engine.SENSOR_TORQUE), p.get(engine.SENSOR_TORQUE))
+            assert np.array_equal(ref.get(engine.SENSOR_TOUCH), p.get(engine.SENSOR_TOUCH))
+    assert ref.get(engine.NCON).max() > 0
+
+
 def torch_i32(x):
     import torch
     return torch.as_tensor(np.asarray(x, np.int32), device="cuda")
