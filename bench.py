@@ -424,7 +424,9 @@ def main():
                                  "(substep = step index mod n_substeps), so the average is the all-substep mean",
                 "note": "algorithmic bytes = SURVEY 8(d) un-fused figure (qpos qvel qacc_warmstart in + out, ctrl in) "
                         "x envs per launch (the batch, or half of it when the engine steps two slices on two streams: "
-                        "envs_per_launch is the mean over the sampled launches); one rp_step = 1 + 2*substeps launches "
+                        "envs_per_launch is the mean over the sampled launches; a slice's launch shares the GPU with the other slice's "
+                        "kernels, so its duration is not exclusive and achieved/frac drop when slices are on although the step "
+                        "gets faster -- compare step_sequence_avg_ms); one rp_step = 1 + 2*substeps launches "
                         "per slice (rp_stage_kernel<T,0> position/velocity stage, <T,1> solver stage).  The path is instruction-issue / latency bound "
                         "(one wave per env), not HBM bound: see DESIGN.md 6",
             },

@@ -353,11 +353,18 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
         ncon = B.hdr[env * 8]; nkt = B.hdr[env * 8 + 1];
         dirty_mask = ((unsigned long long)(unsigned)B.hdr[env * 8 + 3] << 32) | (unsigned)B.hdr[env * 8 + 2];
         nent = B.hdr[env * 8 + 4]; maxm = B.hdr[env * 8 + 5];
-        qbias = LF(0); alen = LF(1); avel = LF(2);
-        ksin[0] = LF(3); ksin[1] = LF(4); kcos[0] = LF(5); kcos[1] = LF(6);
+        // (fields only some lanes own cross for those lanes only: fewer cache lines per env)
+        qbias = LF(0);
+        if (lane < nu) { alen = LF(1); avel = LF(2); }
+        ksin[0] = LF(3); kcos[0] = LF(5);
+        if (isk[1]) { ksin[1] = LF(4); kcos[1] = LF(6); }
         fr_aref = LF(7);
+        {
+          const int ls = LI(0);
+          lim_sign[0] = (ls & 3) - 1; lim_sign[1] = ((ls >> 2) & 3) - 1; lim_sign[2] = ((ls >> 4) & 3) - 1;
+        }
 #pragma unroll
-        for (int k = 0; k < 3; k++) { lim_D[k] = LF(8 + k); lim_aref[k] = LF(11 + k); }
+        for (int k = 0; k < 3; k++) if (lim_sign[k] != 0) { lim_D[k] = LF(8 + k); lim_aref[k] = LF(11 + k); }
         if (lane < ncon) {  // the contact lanes' fields: only those lanes' cache lines cross (other lanes: the defaults)
           con_D = LF(14); con_mu = LF(15);
 #pragma unroll
@@ -368,8 +375,6 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
           con_maskA = ((unsigned long long)(unsigned)LI(6) << 32) | (unsigned)LI(5);
           con_maskB = ((unsigned long long)(unsigned)LI(8) << 32) | (unsigned)LI(7);
         }
-        int ls = LI(0);
-        lim_sign[0] = (ls & 3) - 1; lim_sign[1] = ((ls >> 2) & 3) - 1; lim_sign[2] = ((ls >> 4) & 3) - 1;
         sdepth = LI(9);
         if (isl) {
 #pragma unroll
@@ -2052,11 +2057,13 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
     }
     // ---- hand over to the solver kernel
     if constexpr (MODE == 0) {
-      LF(0) = qbias; LF(1) = alen; LF(2) = avel;
-      LF(3) = ksin[0]; LF(4) = ksin[1]; LF(5) = kcos[0]; LF(6) = kcos[1];
+      LF(0) = qbias;
+      if (lane < nu) { LF(1) = alen; LF(2) = avel; }
+      LF(3) = ksin[0]; LF(5) = kcos[0];
+      if (isk[1]) { LF(4) = ksin[1]; LF(6) = kcos[1]; }
       LF(7) = fr_aref;
 #pragma unroll
-      for (int k = 0; k < 3; k++) { LF(8 + k) = lim_D[k]; LF(11 + k) = lim_aref[k]; }
+      for (int k = 0; k < 3; k++) if (lim_sign[k] != 0) { LF(8 + k) = lim_D[k]; LF(11 + k) = lim_aref[k]; }
       if (lane < ncon) {  // (the solver stage reads these for lanes < ncon only)
         LF(14) = con_D; LF(15) = con_mu;
 #pragma unroll
