@@ -179,24 +179,25 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
       tp[4 * q] = v.x; tp[4 * q + 1] = v.y; tp[4 * q + 2] = v.z; tp[4 * q + 3] = v.w;
     }
   }
-  const int parent = isl ? tp[0] : -1;
-  const int depth = isl ? tp[1] : -1;
-  const int jtype = isl ? tp[2] : 0;
-  const int sibrank = isl ? tp[3] : 0;
-  const int ltree = isl ? tp[4] : 0;
-  const int ldof = isl ? tp[5] : 0;
+  // (not const: the position stage re-reads the record after the collision phase instead of carrying
+  // fourteen integers through it -- it is register-bound there)
+  int parent = isl ? tp[0] : -1;
+  int depth = isl ? tp[1] : -1;
+  int jtype = isl ? tp[2] : 0;
+  int sibrank = isl ? tp[3] : 0;
+  int ltree = isl ? tp[4] : 0;
+  int ldof = isl ? tp[5] : 0;
   // chain structure (lanes are in preorder: trunk chain, then up to 5 leaf chains)
-  const int tbase = isl ? tp[6] : 0, TL = isl ? tp[7] : 0;
-  const int ndesc = isl ? tp[8] : 0;
+  int tbase = isl ? tp[6] : 0, TL = isl ? tp[7] : 0;
+  int ndesc = isl ? tp[8] : 0;
   // chain lanes: first depth past the end of my chain / chain index; bit c of chainmask:
   // leaf chain c of my tree exists
   const int chain_end = isl ? tp[11] : 0, mychain = isl ? tp[12] : 0, chainmask = isl ? tp[13] : 0;
   // lane of my ancestor at depth e (e <= depth)
   auto anc_at = [&](int e) -> int { return e < TL ? tbase + e : lane - (depth - e); };
-  const int llimited = isl ? tp[9] : 0;
-  const int lact = isl ? tp[10] : -1;
+  int llimited = isl ? tp[9] : 0;
+  int lact = isl ? tp[10] : -1;
   const T lactcoef = isl ? M.link_act_coef()[L] : (T)0;
-  const T gscale = (isl && nl) ? M.link_gscale()[L] : (T)0;
   int hasdof[3];
   hasdof[0] = isl && llimited; hasdof[1] = lane < nk; hasdof[2] = lane + 64 < nk;
   const bool isk[2] = {lane < nk, lane + 64 < nk};
@@ -281,8 +282,6 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
   // actuator owned by this lane (hand actuators only; key actuators live with the key)
   const bool isa = lane < nu && M.act_kind()[lane < nu ? lane : 0] == 0;
   const int A = lane < nu ? lane : 0;
-  const int alane0 = isa ? M.act_lane()[2 * A] : -1, alane1 = isa ? M.act_lane()[2 * A + 1] : -1;
-  const T acoef0 = isa ? M.act_coef()[2 * A] : (T)0, acoef1 = isa ? M.act_coef()[2 * A + 1] : (T)0;
 
   // ------------------------------------------------------------------- state
   const size_t eo = (size_t)env * nv;
@@ -1738,6 +1737,29 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
     if (ncon > RPK_NC) { warn |= 2; ncon = RPK_NC; }
     WSYNC();
 
+    // The position / velocity stages are register-bound around the narrow phase: the state is re-read here
+    // (L2 hits) instead of being carried -- that is: spilled to scratch and reloaded -- across the collision.
+    if constexpr (MODE != 1) {
+      {
+        const int4* rec = (const int4*)(fresh(M.lane_topo()) + 16 * L);
+        const int4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+        parent = isl ? r0.x : -1; depth = isl ? r0.y : -1; jtype = isl ? r0.z : 0; sibrank = isl ? r0.w : 0;
+        ltree = isl ? r1.x : 0; ldof = isl ? r1.y : 0; tbase = isl ? r1.z : 0; TL = isl ? r1.w : 0;
+        ndesc = isl ? r2.x : 0; llimited = isl ? r2.y : 0; lact = isl ? r2.z : -1;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+          kdof[s] = isk[s] ? fresh(M.key_dof())[kid[s]] : 0;
+          kact[s] = isk[s] ? fresh(M.key_act())[kid[s]] : -1;
+        }
+      }
+      const T *p_q = fresh(S.qpos), *p_v = fresh(S.qvel);
+      q[0] = isl ? p_q[eo + ldof] : (T)0; qd[0] = isl ? p_v[eo + ldof] : (T)0;
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        q[1 + s] = isk[s] ? p_q[eo + kdof[s]] : (T)0;
+        qd[1 + s] = isk[s] ? p_v[eo + kdof[s]] : (T)0;
+      }
+    }
     PROF(13);
     // ---- solver slots for touched keys
     {
@@ -1953,6 +1975,24 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
     // VELOCITY STAGE
     // ======================================================================
     // ---- spatial velocities, axis derivatives [MJ: mj_comVel]
+    if constexpr (MODE != 1) {
+      // the motion axis about the tree reference point again, from the link frames in LDS (same arithmetic
+      // as in mj_comPos above: same bits), instead of six more registers carried across the collision
+      if (isl) {
+        const T* p_tref = fresh(M.tree_ref());
+        const T axw[3] = {sm.xaxis[lane][0], sm.xaxis[lane][1], sm.xaxis[lane][2]};
+        if (jtype == JNT_SLIDE_) {
+          cdofr[0] = cdofr[1] = cdofr[2] = 0;
+          cdofr[3] = axw[0]; cdofr[4] = axw[1]; cdofr[5] = axw[2];
+        } else {
+          T off[3];
+#pragma unroll
+          for (int k = 0; k < 3; k++) off[k] = p_tref[3 * ltree + k] - sm.xanchor[lane][k];
+          cdofr[0] = axw[0]; cdofr[1] = axw[1]; cdofr[2] = axw[2];
+          cross3(cdofr + 3, axw, off);
+        }
+      }
+    }
     T cv[6] = {0, 0, 0, 0, 0, 0}, cdd[6] = {0, 0, 0, 0, 0, 0};
     for (int d = 0; d < M.maxdepth; d++) {
       if (isl && depth == d) {
@@ -1974,6 +2014,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
     T ca[6] = {0, 0, 0, 0, 0, 0};
     for (int d = 0; d < M.maxdepth; d++) {
       if (isl && depth == d) {
+        const T gscale = fresh(M.link_gscale())[L];
         T pa[6] = {0, 0, 0, -M.gx * gscale, -M.gy * gscale, -M.gz * gscale};
         if (parent >= 0) {
 #pragma unroll
@@ -2020,6 +2061,9 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
     if (isk[1]) sm.keyvec[0][kid[1]] = qd[2];
     WSYNC();
     if (isa) {
+      // (read here, not in the prologue: nothing else needs them and the stage is register-bound)
+      const int alane0 = fresh(M.act_lane())[2 * A], alane1 = fresh(M.act_lane())[2 * A + 1];
+      const T acoef0 = fresh(M.act_coef())[2 * A], acoef1 = fresh(M.act_coef())[2 * A + 1];
       alen = acoef0 * sm.vec[0][alane0] + (alane1 >= 0 ? acoef1 * sm.vec[0][alane1] : (T)0);
       avel = acoef0 * sm.vec[1][alane0] + (alane1 >= 0 ? acoef1 * sm.vec[1][alane1] : (T)0);
     }
