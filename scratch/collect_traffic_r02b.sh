@@ -1,0 +1,24 @@
+#!/bin/bash
+# Refresh of the bench lines + the two HBM-traffic PMC passes (after the position-stage spill diet).
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT/gpurun_out/prof_r02c
+rm -rf $R; mkdir -p $R
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests -m gpu -x -q > $R/pytest_gpu.log 2>&1; tail -2 $R/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $R/smoke.log 2>&1; tail -1 $R/smoke.log
+timeout 900 python bench.py > $R/bench_plain.json 2> $R/bench_plain.err
+for c in 3 4 5; do timeout 600 python bench.py --config $c --steps 150 > $R/bench_c$c.json 2> $R/bench_c$c.err; done
+cd /tmp
+BENCH="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --aux-fp32 0 --host-io 0"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/stats -- $BENCH --steps 158 --warmup 20 > $R/stats.log 2>&1
+SHORT="$BENCH --stagger 0 --steps 4 --warmup 1"
+export RP_STREAM_SLICES=1
+timeout 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/fetch -- $SHORT > $R/fetch.log 2>&1
+timeout 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/write -- $SHORT > $R/write.log 2>&1
+timeout 500 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $R/sq1 -- $SHORT > $R/sq1.log 2>&1
+timeout 500 rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM_RD --output-format csv -d $R/sq2 -- $SHORT > $R/sq2.log 2>&1
+unset RP_STREAM_SLICES
+cd $GRAFT_REPO_ROOT
+python scratch/summarize_profiles_r02b.py $R 2>&1 | grep -A12 '"pmc"'
+for d in stats fetch write sq1 sq2; do rm -rf $R/$d; done
+du -sh $R
