@@ -71,7 +71,7 @@ typedef enum {
 #define RP_WARN_HESSIAN 4      /* non-positive pivot in the Newton Hessian */
 #define RP_WARN_KEYSLOT_FULL 8 /* more simultaneously touched keys than solver slots */
 #define RP_WARN_WORK_FULL 16   /* narrow-phase work list overflow */
-#define RP_WARN_DENSE_FULL 32  /* more than 60 (fp32 build: 56) cross-coupled rows; cross terms dropped */
+#define RP_WARN_DENSE_FULL 32  /* more than 57 (fp32 build: 53; deep builds: 52 / 47) cross-coupled rows; cross terms dropped */
 
 /* Builds an engine for `n_envs` copies of the model in `model_blob`
  * (robopianist_amd.model.compile.to_blob + engine tables) on HIP device

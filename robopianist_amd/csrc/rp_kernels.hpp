@@ -151,6 +151,9 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
   __shared__ Smem<T, MODE, MD> sm;
   constexpr int TC = MD > 9 ? 8 : 4;            // trunk links the chain-blocked solver holds
   constexpr int NT = TC * (TC + 1) / 2, NREC = NT + TC;  // packed trunk block / per-chain record
+  // the chain records of the tree elimination live at the end of the dense block's LDS (sm.H); the
+  // packed block (rows + its rhs row) may grow up to there
+  constexpr int HSIZE = (RpCaps<T>::HMAX + 1) * (RpCaps<T>::HMAX + 2) / 2;
 #ifdef RPK_POISON_LDS  // debug build: nothing may depend on what a previous workgroup left in LDS
   {
     unsigned* w_ = reinterpret_cast<unsigned*>(&sm);
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
   long long prof_t = (long long)__builtin_readcyclecounter();
   const long long kernel_t0 = prof_t;
   const int nl = M.nlink, nk = M.nkey, nv = M.nv, nu = M.nu;
+  const int HREC0 = HSIZE - M.ntree * 5 * NREC;   // first chain record in sm.H = capacity of the packed dense block
   const T h = M.timestep;
 
   // ------------------------------------------------------------ lane constants
@@ -444,8 +448,9 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
       // `dm` ("clean") only couple to their ancestors and are eliminated leaf-to-root
       // with no fill-in.  The rows in `dm` ("dirty": supports of cross-chain contacts,
       // an ancestor-closed set) receive the Schur complement and are solved with a
-      // small dense Cholesky; `cross_fn(cidx)` adds the cross-contact blocks to it.
-      auto tree_solve = [&](T* Rr, T rhs, int nslots, unsigned long long dm, auto&& cross_fn) -> T {
+      // small dense Cholesky.  The caller has already put the cross-contact blocks into the packed
+      // block sm.H (zeroed + accumulated during the Hessian assembly); the Schur rows are added here.
+      auto tree_solve = [&](T* Rr, T rhs, int nslots, unsigned long long dm) -> T {
         // trunk length of this lane's tree; a compile-time constant in the FIXED_TL build
         // (every predicate on it folds: -20 % instructions in the chain elimination)
         const int TLX = FIXED_TL > 0 ? FIXED_TL : TL;
@@ -576,8 +581,9 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
               sm.xs[lane + ci] = rc_[ci];
             }
           }
-          // trunk deltas, one NREC-entry record per chain (the dense block is not live yet)
-          T* rec = sm.H + (size_t)(ltree * 5 + mychain) * NREC;
+          // trunk deltas, one NREC-entry record per chain, at the end of the dense block's storage (the
+          // block itself already holds the cross-contact terms; its capacity check leaves this room)
+          T* rec = sm.H + HREC0 + (size_t)(ltree * 5 + mychain) * NREC;
 #pragma unroll
           for (int k = 0; k < NT; k++) rec[k] = dT[k];
 #pragma unroll
@@ -589,7 +595,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
           const int tro = depth * (depth + 1) / 2;
 #pragma unroll
           for (int c = 0; c < 5; c++) {
-            const T* rec = sm.H + (size_t)(ltree * 5 + c) * NREC;
+            const T* rec = sm.H + HREC0 + (size_t)(ltree * 5 + c) * NREC;
             T dv[TC];
 #pragma unroll
             for (int e = 0; e < TC; e++) dv[e] = rec[tro + e < NT ? tro + e : NT - 1];
@@ -655,33 +661,29 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
         WSYNC();
         PROF(21);
         // ---- dense block on the dirty rows (Schur complement + cross-contact terms)
-        if (dm && __popcll(dm) > RpCaps<T>::HMAX) { warn |= 32; dm = 0; }  // cannot hold the block: drop cross terms
-        if (dm) {
+        if (dm) {   // (the caller passes dm = 0 when the block would not fit: RP_WARN_DENSE_FULL)
           T x = (isl || isslot) ? sm.xs[lane] : (T)0;
           WSYNC();
           const int nD = __popcll(dm);
           auto cidx = [&](int l) -> int { return __popcll(dm & lanemask_lt(l)); };
           const int ci = cidx(lane);
-          for (int i = lane; i < tri(nD, 0); i += 64) sm.H[i] = 0;
-          WSYNC();
+          // every (row, ancestor) element has exactly one owner lane: plain read-modify-write
           if (dirty) {
             if (isl) {
-              for (int e = 0; e <= depth; e++) sm.H[tri(ci, cidx(anc_at(e)))] = sm.R[lane][e];
+              for (int e = 0; e <= depth; e++) sm.H[tri(ci, cidx(anc_at(e)))] += sm.R[lane][e];
             } else {
-              sm.H[tri(ci, ci)] = sm.R[lane][mydiag];
+              sm.H[tri(ci, ci)] += sm.R[lane][mydiag];
 #pragma unroll
               for (int e = 0; e < MD; e++) {
                 if (e <= sdepth) {
                   const int a_ = anc_of(salink, sdepth, sTL, sTB, e);
-                  if ((dm >> a_) & 1) sm.H[tri(ci, cidx(a_))] = sm.R[lane][e];
+                  if ((dm >> a_) & 1) sm.H[tri(ci, cidx(a_))] += sm.R[lane][e];
                 }
               }
             }
           }
           WSYNC();
           PROF(22);
-          cross_fn(cidx);
-          WSYNC();
           PROF(23);
           // the rhs of compact row r (owned by a dirty lane) is row nD of the packed block
           if (dirty) sm.H[tri(nD, 0) + ci] = x;
@@ -739,13 +741,12 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
         WSYNC();
         return x;
       };
-      auto no_cross = [&](auto&&) {};
       // ---- qacc_smooth = M^-1 qfrc_smooth (M is always tree-sparse)
       {
         T Rr[MD + 1];
 #pragma unroll
         for (int e = 0; e <= MD; e++) Rr[e] = Mr[e];
-        qs[0] = tree_solve(Rr, qfs[0], 0, 0ull, no_cross);
+        qs[0] = tree_solve(Rr, qfs[0], 0, 0ull);
       }
 
       PROF(2);
@@ -961,8 +962,18 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
             // ... + J^T C J of every contact.  Entry lane a of contact c holds u = C_c J_a and
             // walks the entries b <= a of its contact (dofs in lane order: b is an ancestor
             // of a, or the same dof): single-chain contacts add u.J_b to row(a)[col(b)] of the
-            // tree rows, cross-chain contacts to the dense block of the dirty rows.
-            auto contact_terms = [&](const bool cross_pass, auto&& cidx) {
+            // tree rows, cross-chain contacts to the packed dense block of the dirty rows (zeroed
+            // here; tree_solve adds the Schur complement of the clean rows to it) -- one pass over
+            // the entries for both destinations.
+            unsigned long long dmx = dirty_mask;
+            if (dmx && tri(__popcll(dmx) + 1, 0) > HREC0) { warn |= 32; dmx = 0; }  // cannot hold the block: drop cross terms
+            if (dmx) {
+              const int nD = __popcll(dmx);
+              for (int i = lane; i < tri(nD, 0); i += 64) sm.H[i] = 0;
+            }
+            auto cidx = [&](int l) -> int { return __popcll(dmx & lanemask_lt(l)); };
+            WSYNC();
+            {
               for (int e0 = 0; e0 < nent; e0 += 64) {
                 const bool valid = e0 + lane < nent;
                 const int e = valid ? e0 + lane : nent - 1;
@@ -975,8 +986,9 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
                 const T u0 = C0 * ja0 + C3 * ja1 + C4 * ja2;
                 const T u1 = C3 * ja0 + C1 * ja1 + C5 * ja2;
                 const T u2 = C4 * ja0 + C5 * ja1 + C2 * ja2;
-                const bool mine = valid && (((m0 >> 15) & 1) != 0) == cross_pass;
-                const int cia = cross_pass ? cidx(ln) : 0;
+                const bool cross = ((m0 >> 15) & 1) != 0;
+                const bool mine = valid && (!cross || dmx != 0);
+                const int cia = cross ? cidx(ln) : 0;
                 for (int k0 = 0; k0 < maxm; k0 += 4) {
                   // four entries per trip: the twelve LDS reads go out together
                   int mb[4];
@@ -990,23 +1002,20 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
 #pragma unroll
                   for (int u = 0; u < 4; u++) {
                     if (mine && k0 + u <= rank) {
-                      T* dst = cross_pass ? &sm.H[tri(cia, cidx(mb[u] & 63))] : &sm.R[ln][(mb[u] >> 11) & 15];
+                      T* dst = cross ? &sm.H[tri(cia, cidx(mb[u] & 63))] : &sm.R[ln][(mb[u] >> 11) & 15];
                       lds_add(dst, val[u]);
                     }
                   }
                 }
               }
-            };
-            contact_terms(false, [](int) { return 0; });
+            }
             WSYNC();
             T Rr[MD + 1];
 #pragma unroll
             for (int e = 0; e <= MD; e++) Rr[e] = sm.R[lane][e];
             WSYNC();
-            // cross-chain contacts go into the dense block of the dirty rows
-            auto cross_fn = [&](auto&& cidx) { contact_terms(true, cidx); };
             PROF(4);
-            x = tree_solve(Rr, rhs, nkt, dirty_mask, cross_fn);
+            x = tree_solve(Rr, rhs, nkt, dmx);
           }
           T search[3];
           search[0] = isl ? -x : (T)0;
@@ -1212,7 +1221,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
         T Rr[MD + 1];
 #pragma unroll
         for (int e = 0; e <= MD; e++) Rr[e] = Mr[e] + ((isl && e == depth) ? h * ldamp : (T)0);
-        qe[0] = tree_solve(Rr, qfs[0] + qfc[0], 0, 0ull, no_cross);
+        qe[0] = tree_solve(Rr, qfs[0] + qfc[0], 0, 0ull);
       }
 #pragma unroll
       for (int s = 0; s < 2; s++) qe[1 + s] = (qfs[1 + s] + qfc[1 + s]) / (kM[s] + h * kdamp[s]);

@@ -60,6 +60,14 @@ def load_library(path: str = LIB_PATH):
             "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
             "There is no CPU fallback."
         )
+    # torch bundles its own libamdhip64; it has to be in the process BEFORE this library pulls in the
+    # system one (same soname: the loader then binds us to torch's copy and the two share one runtime,
+    # which is what makes rp_field_ptr views and stream sharing work).  The other order leaves torch
+    # with "No HIP GPUs are available" at its first CUDA call.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # plain ctypes use without torch is fine
+        pass
     L = ctypes.CDLL(path)
     L.rp_last_error.restype = ctypes.c_char_p
     L.rp_create.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,

@@ -162,3 +162,25 @@ def test_plain_c_host_reproduces_the_python_binding_bitwise(tmp_path):
     for _ in range(5):
         phys.step(10)
     assert np.array_equal(phys.qpos[0].astype(np.float64), q_c)
+
+
+@pytest.mark.gpu
+def test_engine_created_before_torch_touches_the_gpu():
+    """A fresh process that builds the engine first and uses torch's GPU side afterwards: torch's bundled
+    HIP runtime must be the one the engine binds to (robopianist_amd/engine.py: load_library)."""
+    import subprocess
+    import sys
+    code = (
+        "import warnings; warnings.simplefilter('ignore')\n"
+        "from robopianist_amd import engine\n"
+        "from robopianist_amd.model import scene\n"
+        "si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=True)\n"
+        "p = engine.BatchedPhysics(si.model, si.key_joint_ids, n_envs=4, precision=64)\n"
+        "p.step(2)\n"
+        "import torch\n"
+        "v = p.view(engine.QPOS)\n"
+        "assert v.is_cuda and bool(torch.isfinite(v).all()) and float(torch.ones(3, device='cuda').sum()) == 3.0\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-1500:]
