@@ -1345,33 +1345,37 @@ static int ls_update_bracket(const rpo_data* d, const double* quadGauss, ls_pnt*
  * of phi' is bracketed, each round evaluates the midpoint and the Newton successors of both
  * bracket ends, returns the best candidate whose |phi'| < gtol, otherwise tightens the bracket.
  * Returns alpha (0 = no improvement). */
+static double primal_search_n(int ls_iterations, const rpo_data* d, const double* quadGauss, double gtol, int* pev);
 static double primal_search(const rpo_model* m, const rpo_data* d, const double* quadGauss, double gtol) {
   int evals = 0;
-  ls_pnt p0 = ls_point(d, quadGauss, 0, &evals);
+  return primal_search_n(m->ls_iterations, d, quadGauss, gtol, &evals);
+}
+static double primal_search_n(int ls_iterations, const rpo_data* d, const double* quadGauss, double gtol, int* pev) {
+  ls_pnt p0 = ls_point(d, quadGauss, 0, pev);
   if (!(p0.d1 > 0)) return 0;
-  ls_pnt p1 = ls_point(d, quadGauss, p0.alpha - p0.d0 / p0.d1, &evals);   /* always one Newton step */
+  ls_pnt p1 = ls_point(d, quadGauss, p0.alpha - p0.d0 / p0.d1, pev);   /* always one Newton step */
   if (p0.cost < p1.cost) p1 = p0;
   if (fabs(p1.d0) < gtol) return p1.alpha;
   int dir = p1.d0 < 0 ? 1 : -1;
   ls_pnt p2 = p1;
   int p2update = 0;
-  while (p1.d0 * dir <= -gtol && evals < m->ls_iterations) {               /* one-sided search */
+  while (p1.d0 * dir <= -gtol && (*pev) < ls_iterations) {               /* one-sided search */
     p2 = p1; p2update = 1;
-    p1 = ls_point(d, quadGauss, p1.alpha - p1.d0 / p1.d1, &evals);
+    p1 = ls_point(d, quadGauss, p1.alpha - p1.d0 / p1.d1, pev);
     if (fabs(p1.d0) < gtol) return p1.alpha;
   }
-  if (evals >= m->ls_iterations || !p2update) return p1.alpha;             /* failed to bracket */
+  if ((*pev) >= ls_iterations || !p2update) return p1.alpha;             /* failed to bracket */
   ls_pnt p2next = p1;
-  ls_pnt p1next = ls_point(d, quadGauss, p1.alpha - p1.d0 / p1.d1, &evals);
-  while (evals < m->ls_iterations) {                                        /* bracketed search */
-    ls_pnt pmid = ls_point(d, quadGauss, 0.5 * (p1.alpha + p2.alpha), &evals);
+  ls_pnt p1next = ls_point(d, quadGauss, p1.alpha - p1.d0 / p1.d1, pev);
+  while ((*pev) < ls_iterations) {                                        /* bracketed search */
+    ls_pnt pmid = ls_point(d, quadGauss, 0.5 * (p1.alpha + p2.alpha), pev);
     ls_pnt cand[3] = {p1next, p2next, pmid};
     int best = -1;
     for (int i = 0; i < 3; i++)
       if (fabs(cand[i].d0) < gtol && (best < 0 || cand[i].cost < cand[best].cost)) best = i;
     if (best >= 0) return cand[best].alpha;
-    int b1 = ls_update_bracket(d, quadGauss, &p1, cand, &p1next, &evals);
-    int b2 = ls_update_bracket(d, quadGauss, &p2, cand, &p2next, &evals);
+    int b1 = ls_update_bracket(d, quadGauss, &p1, cand, &p1next, pev);
+    int b2 = ls_update_bracket(d, quadGauss, &p2, cand, &p2next, pev);
     if (!b1 && !b2) return pmid.alpha;                                      /* numerical accuracy reached */
   }
   if (p1.cost <= p2.cost && p1.cost < p0.cost) return p1.alpha;
@@ -1721,4 +1725,19 @@ double rpo_bench(const rpo_model* m, int nenv, int nstep, const double* ctrl, in
   }
   free(ds);
   return t1 - t0;
+}
+
+/* ---- test hook (rp_oracle.h): PrimalSearch on a hand-made one-dimensional problem */
+double rpo_debug_line_search(int n, const int* type, const double* jar, const double* jv, const double* D,
+                             const double* floss, const double* R, const double quad[3], double gtol,
+                             int ls_iterations, int* evals) {
+  rpo_data d;
+  memset(&d, 0, sizeof d);
+  d.nefc = n;
+  d.efc_type = (int*)type; d.efc_jar = (double*)jar; d.efc_jv = (double*)jv; d.efc_D = (double*)D;
+  d.efc_floss = (double*)floss; d.efc_R = (double*)R;
+  int ev = 0;
+  const double a = primal_search_n(ls_iterations, &d, quad, gtol, &ev);
+  if (evals) *evals = ev;
+  return a;
 }

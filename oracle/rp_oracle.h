@@ -72,6 +72,14 @@ int rpo_warnings(const rpo_data* d);
 double rpo_bench(const rpo_model* m, int nenv, int nstep, const double* ctrl,
                  int nthreads, double* qpos_out /* [nenv][nq] or NULL */);
 
+/* Test hook: the line search of the Newton solver (PrimalSearch as restated in rp_oracle.c) on a
+ * hand-made one-dimensional problem  phi(alpha) = q0 + q1 alpha + q2 alpha^2 + sum_i row_i(jar_i + alpha jv_i)
+ * with n rows of type[i] (0 friction-loss: D, floss, R used; 1 / 2 limit / contact: quadratic D x^2 / 2 on
+ * x < 0).  Returns alpha; *evals = number of evaluations of phi it used. */
+double rpo_debug_line_search(int n, const int* type, const double* jar, const double* jv, const double* D,
+                             const double* floss, const double* R, const double quad[3], double gtol,
+                             int ls_iterations, int* evals);
+
 #ifdef __cplusplus
 }
 #endif

@@ -448,3 +448,100 @@ def test_hull_fingertips_build_and_press_keys():
                 mesh_key += 1
     assert o.warnings == 0 and mesh_key > 50
     assert np.abs(o.qpos[:88]).max() > 0.01      # keys went down
+
+
+# ---- the line search (PrimalSearch as restated in oracle/rp_oracle.c) on hand-made problems ------------
+def _line_search(rows, quad, gtol, ls_iterations=50):
+    """rows: list of (type, jar, jv, D, floss, R); type 0 friction loss, 1 limit, 2 contact."""
+    import ctypes
+    from oracle import rp_oracle
+    L = rp_oracle.lib()
+    n = len(rows)
+    I = (ctypes.c_int * max(n, 1))(*[int(r[0]) for r in rows])
+    cols = [(ctypes.c_double * max(n, 1))(*[float(r[k]) for r in rows]) for k in range(1, 6)]
+    q = (ctypes.c_double * 3)(*quad)
+    ev = ctypes.c_int(0)
+    L.rpo_debug_line_search.restype = ctypes.c_double
+    a = L.rpo_debug_line_search(n, I, cols[0], cols[1], cols[2], cols[3], cols[4], q, ctypes.c_double(gtol),
+                                int(ls_iterations), ctypes.byref(ev))
+    return a, ev.value
+
+
+def _phi(rows, quad, a):
+    """phi and phi' of the same problem, written independently of the C code."""
+    c = quad[0] + quad[1] * a + quad[2] * a * a
+    g = quad[1] + 2 * quad[2] * a
+    for t, jar, jv, D, f, R in rows:
+        x = jar + a * jv
+        if t == 0:
+            if x <= -R * f:
+                c += -0.5 * R * f * f - f * x; g += -f * jv
+            elif x >= R * f:
+                c += -0.5 * R * f * f + f * x; g += f * jv
+            else:
+                c += 0.5 * D * x * x; g += D * x * jv
+        elif x < 0:
+            c += 0.5 * D * x * x; g += D * x * jv
+    return c, g
+
+
+def test_line_search_pure_quadratic_is_one_newton_step():
+    # phi = 3 - 4 a + 2 a^2: minimum at a = 1, found by the first Newton point (2 evaluations: 0 and 1)
+    a, ev = _line_search([], (3.0, -4.0, 2.0), 1e-10)
+    assert a == 1.0 and ev == 2
+    # ... also with rows that stay in one zone: an active contact row adds D (jar + a jv)^2 / 2
+    rows = [(2, -1.0, 0.25, 8.0, 0, 0)]
+    a, ev = _line_search(rows, (0.0, -1.0, 1.0), 1e-12)
+    # phi' = -1 + 2a + 8 (−1 + a/4)/4 = -3 + 2.5 a  ->  a = 1.2 (row still active there: -1 + 0.3 < 0)
+    assert abs(a - 1.2) < 1e-14 and ev == 2
+
+
+def test_line_search_finds_the_minimum_across_zone_changes():
+    """Random piecewise-quadratic line costs (limit / contact rows switching on and off, friction-loss rows
+    crossing their three zones): the result satisfies PrimalSearch's own stopping rule, |phi'(alpha)| < gtol,
+    never costs more than alpha = 0, and agrees with a bisection on phi' (which is monotone) to the accuracy
+    gtol implies."""
+    rng = np.random.default_rng(5)
+    reached_bracket = 0
+    for trial in range(300):
+        n = int(rng.integers(1, 12))
+        rows = []
+        for _ in range(n):
+            t = int(rng.integers(0, 3))
+            D = float(10 ** rng.uniform(-1, 3))
+            R = 1.0 / D
+            rows.append((t, float(rng.normal()), float(rng.normal()), D, float(10 ** rng.uniform(-2, 0)), R))
+        q2 = float(10 ** rng.uniform(-2, 1))
+        # a descent direction: phi'(0) < 0
+        c0, g0 = _phi(rows, (0.0, 0.0, q2), 0.0)
+        q1 = -abs(float(rng.normal())) - max(0.0, g0) - 0.1
+        quad = (0.0, q1, q2)
+        gtol = 1e-9
+        a, ev = _line_search(rows, quad, gtol)
+        c, g = _phi(rows, quad, a)
+        assert a > 0 and abs(g) < gtol, (trial, a, g)
+        assert c <= _phi(rows, quad, 0.0)[0]
+        assert ev <= 50
+        reached_bracket += ev > 4
+        # bisection on the monotone phi'
+        lo, hi = 0.0, 1.0
+        while _phi(rows, quad, hi)[1] < 0:
+            hi *= 2
+        for _ in range(200):
+            mid = 0.5 * (lo + hi)
+            if _phi(rows, quad, mid)[1] < 0:
+                lo = mid
+            else:
+                hi = mid
+        # |phi'| < gtol and phi'' >= 2 q2 bound the distance to the root
+        assert abs(a - 0.5 * (lo + hi)) <= gtol / (2 * q2) + 1e-12, (trial, a, lo, hi)
+    assert reached_bracket > 30   # (the bracketed phase is exercised, not only the first Newton steps)
+
+
+def test_line_search_respects_the_evaluation_limit():
+    rows = [(2, -1.0 + 0.01 * k, 1.0, 50.0 * (k + 1), 0, 0) for k in range(10)]
+    quad = (0.0, -5.0, 0.01)
+    a_full, ev_full = _line_search(rows, quad, 1e-13)
+    a_cut, ev_cut = _line_search(rows, quad, 1e-13, ls_iterations=3)
+    assert ev_cut <= 4 and ev_full >= ev_cut     # (the limit is checked between evaluations, as in MuJoCo)
+    assert _phi(rows, quad, a_cut)[0] <= _phi(rows, quad, 0.0)[0]
