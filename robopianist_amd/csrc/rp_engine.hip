@@ -61,9 +61,20 @@ __global__ __launch_bounds__(1024) void rp_order_kernel(int* order_all, const in
   };
   for (int e = threadIdx.x; e < n; e += blockDim.x) atomicAdd(&hist[e & 7][key_of(base + e)], 1);
   __syncthreads();
-  if (threadIdx.x < RP_ORDER_CLASSES) {  // descending exclusive prefix per class
-    int acc = 0;
-    for (int b = RP_ORDER_BUCKETS - 1; b >= 0; b--) { const int c = hist[threadIdx.x][b]; hist[threadIdx.x][b] = acc; acc += c; }
+  // descending exclusive prefix per class: wave c scans class c, lane l owns the four buckets
+  // 255 - 4 l ... 252 - 4 l (the serial scan by eight threads was 2 of this kernel's 10.5 us)
+  static_assert(RP_ORDER_BUCKETS == 256 && RP_ORDER_CLASSES * 64 <= 1024, "scan layout");
+  if (threadIdx.x < 64 * RP_ORDER_CLASSES) {
+    const int c = threadIdx.x >> 6, l = threadIdx.x & 63;
+    int v[4], tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = hist[c][RP_ORDER_BUCKETS - 1 - 4 * l - k]; tot += v[k]; }
+    int incl = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (l >= d) incl += t; }
+    int acc = incl - tot;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { hist[c][RP_ORDER_BUCKETS - 1 - 4 * l - k] = acc; acc += v[k]; }
   }
   __syncthreads();
   for (int e = threadIdx.x; e < n; e += blockDim.x) {
