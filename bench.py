@@ -117,22 +117,24 @@ def mixed_song_bank(n=150):
     return bank
 
 
-def build_env(config, E, rank, dev, precision):
+def build_env(config, E, rank, dev, precision, fingertips="primitive"):
     from robopianist_amd import suite
     from robopianist_amd import distributed as rpd
     from robopianist_amd.suite import environment
     from robopianist_amd.suite.tasks import PianoWithShadowHands
     seed = rpd.rank_seed(12345, rank)
+    kw = dict(NOTEBOOK_KW, primitive_fingertip_collisions=(fingertips == "primitive"))
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         if config in (2, 3):
-            # notebook cell 15 kwargs; capsule fingertips (no mesh assets here)
+            # notebook cell 15 kwargs; fingertips: capsules (`primitive_fingertip_collisions=True`)
+            # or the stand-in convex hulls collided through MPR (the notebook's own setting, meshes)
             return suite.load("RoboPianist-debug-TwinkleTwinkleRousseau-v0", seed=seed, n_envs=E, device_id=dev,
-                              precision=precision, task_kwargs=dict(trim_silence=True, **NOTEBOOK_KW))
+                              precision=precision, task_kwargs=dict(trim_silence=True, **kw))
         if config == 4:
             return suite.load("RoboPianist-debug-CMajorScaleTwoHands-v0", seed=seed, n_envs=E, device_id=dev,
-                              precision=precision, task_kwargs=dict(**NOTEBOOK_KW))
-        task = PianoWithShadowHands(midi=mixed_song_bank(150), **NOTEBOOK_KW)
+                              precision=precision, task_kwargs=dict(**kw))
+        task = PianoWithShadowHands(midi=mixed_song_bank(150), **kw)
         return environment.Environment(task, n_envs=E, random_state=seed, device_id=dev, precision=precision)
 
 
@@ -178,6 +180,11 @@ def main():
     ap.add_argument("--host-io", type=int, default=1,
                     help="N=1, config 2: also time the loop with host-resident actions/TimeSteps (aux.host_io)")
     ap.add_argument("--graph", type=int, default=0, help="replay env.step from a captured hipGraph")
+    ap.add_argument("--fingertips", default="primitive", choices=("primitive", "hull"),
+                    help="fingertip colliders of `value`: capsules (primitive_fingertip_collisions=True) or the "
+                         "stand-in convex hulls through MPR (the notebook's mesh setting); config 2 reports the other "
+                         "one under aux")
+    ap.add_argument("--aux-fingertips", type=int, default=1, help="config 2: also time the other fingertip mode (aux)")
     ap.add_argument("--stagger", type=int, default=1,
                     help="config 2: every env at its own episode time (env e starts at replay row e mod 158), so any "
                          "timed window samples the whole episode; 0 = all envs in lockstep")
@@ -219,13 +226,13 @@ def main():
     cfg = CONFIGS[args.config]
     E = args.envs or cfg["envs"]
 
-    def measure(precision, steps, warmup, stagger_on=None):
+    def measure(precision, steps, warmup, stagger_on=None, fingertips=None):
         from robopianist_amd import distributed as rpd
         from robopianist_amd.wrappers import CanonicalSpecWrapper, GraphedStepWrapper
 
         device = torch.device("cuda", dev)
         tdt = torch.float32 if precision == 32 else torch.float64
-        base_env = build_env(args.config, E, rank, dev, precision)
+        base_env = build_env(args.config, E, rank, dev, precision, fingertips or args.fingertips)
         eager_env = CanonicalSpecWrapper(base_env)
         use_graph = bool(args.graph) and not args.engine_only
         env = GraphedStepWrapper(eager_env, warmup_steps=2) if use_graph else eager_env
@@ -403,7 +410,9 @@ def main():
                                                   else "full vectorised env.step (obs + rewards)"),
                 "baseline_config": args.config,
                 "envs_per_gpu": E, "substeps_per_step": args.substeps, "nv": int(m.nv), "nu": int(m.nu),
-                "fingertips": "capsule (primitive) stand-in", "mj_steps_per_s": value * args.substeps,
+                "fingertips": ("capsule (primitive_fingertip_collisions=True) stand-in" if args.fingertips == "primitive"
+                               else "26-vertex convex-hull stand-in for the f_distal_pst mesh, MPR narrow phase "
+                                    "(primitive_fingertip_collisions=False, the notebook's setting)"), "mj_steps_per_s": value * args.substeps,
                 "simulated_env_steps": r["sim"], "reset_steps_not_counted": world * E * args.steps - r["sim"],
                 "episode_phase": ("staggered: env e is (e mod 158) steps into its episode, auto-reset per env "
                                   "(untimed %d-step prologue)" % r["n_spread"]) if r["stagger"] else "lockstep",
@@ -446,6 +455,18 @@ def main():
                 "step_sequence_avg_ms": rl["kms"],
                 "note": "same workload with every env on the same replay row (one full 158-step episode)"}
             del rl
+        if args.aux_fingertips and args.config == 2 and world == 1 and r["stagger"] and not args.engine_only:
+            # config 2 is run with both fingertip colliders
+            other = "hull" if args.fingertips == "primitive" else "primitive"
+            rh = measure(args.precision, 158, 10, fingertips=other)
+            out.setdefault("aux", {})[other + "_fingertips"] = {
+                "value": rh["sim"] / rh["dt"], "unit": "env-steps/s", "steps": 158, "kernel_avg_ms": rh["sms"],
+                "envs_per_launch": rh["senvs"], "step_sequence_avg_ms": rh["kms"],
+                "sanity": {"warn_flags_or": rh["warn"], "finite": rh["finite"], **(rh["events"] or {})},
+                "note": "same staggered workload with the other fingertip collider ("
+                        + ("the stand-in convex hulls through MPR: the notebook's mesh setting" if other == "hull"
+                           else "capsules: primitive_fingertip_collisions=True") + ")"}
+            del rh
         if args.aux_fp32 and args.precision == 64 and world == 1 and args.config == 2:
             del r, phys
             s32, w32 = min(args.steps, 80), min(args.warmup, 10)

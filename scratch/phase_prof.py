@@ -6,7 +6,7 @@ from robopianist_amd.model import scene
 from bench import load_actions
 prec = int(sys.argv[1]) if len(sys.argv)>1 else 32
 E = int(sys.argv[2]) if len(sys.argv)>2 else 4096
-si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=True)
+si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=(len(sys.argv) <= 3 or sys.argv[3] != "hull"))
 m = si.model
 phys = engine.BatchedPhysics(m, si.key_joint_ids, n_envs=E, precision=prec)
 ctrl,_ = load_actions(m)
