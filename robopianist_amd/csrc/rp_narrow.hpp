@@ -448,10 +448,22 @@ __device__ __forceinline__ void geom_support(const CGeom<T>& g, const T* d, T* o
     T dl[3];
     matT_vec(dl, g.mat, d);
     T bv = (T)-1e30, b0 = 0, b1 = 0, b2 = 0;
-    for (int i = 0; i < g.nvert; i++) {       // first maximum wins
-      const T x = g.vert[3 * i], y = g.vert[3 * i + 1], z = g.vert[3 * i + 2];
-      const T v = dl[0] * x + dl[1] * y + dl[2] * z;
-      if (v > bv) { bv = v; b0 = x; b1 = y; b2 = z; }
+    // first maximum wins.  Four vertices per trip: the twelve loads go out together (one lane walks
+    // this loop while the rest of the wave waits, so the load latency is all there is to hide); the
+    // tail repeats the last vertex, which cannot win a strict comparison against itself.
+    const int last = g.nvert - 1;
+    for (int i = 0; i < g.nvert; i += 4) {
+      T x[4], y[4], z[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int iu = i + u < last ? i + u : last;
+        x[u] = g.vert[3 * iu]; y[u] = g.vert[3 * iu + 1]; z[u] = g.vert[3 * iu + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const T v = dl[0] * x[u] + dl[1] * y[u] + dl[2] * z[u];
+        if (v > bv) { bv = v; b0 = x[u]; b1 = y[u]; b2 = z[u]; }
+      }
     }
     const T bl[3] = {b0, b1, b2};
     T w[3];
