@@ -1623,6 +1623,13 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
       RawCon<T> rc[3];
       int n = 0, ga = 0, gb = 0;
       T pB[8], invw = 0;
+      // MESH builds: both kinds of hull pair (key box vs hull, hand geom vs hull) collect their arguments
+      // here and meet at ONE call of the MPR routine below -- with a call in each branch a pass that holds
+      // both kinds walks the (serial, one-lane-at-a-time) routine twice
+      bool mpr = false, mpr_flip = false;
+      int mpr_tA = 0, mpr_gA = -1, mpr_gB = -1;
+      T mpr_pA[3] = {0, 0, 0}, mpr_mA[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, mpr_sA[3] = {0, 0, 0};
+      T mpr_pB[3] = {0, 0, 0}, mpr_mB[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, mpr_sB[3] = {0, 0, 0};
       if (w < nproc) {
         ga = sm.work[w][0]; gb = sm.work[w][1];
         int la = M.geom_link()[ga];
@@ -1633,6 +1640,12 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
           for (int k = 0; k < 9; k++) mA[k] = M.geom_mat()[9 * ga + k];
         }
         invw = M.geom_invw()[ga];
+        // the partner is a box (a key, or a box geom) and geom ga a capsule or a box: both branches hand
+        // the box over and meet at one capsule-box / box-box call (a pass that holds key pairs and
+        // hand-hand pairs would otherwise walk each routine twice)
+        bool boxside = false;
+        T bxp[3] = {0, 0, 0}, bxm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        const T* bxs = M.geom_size();
         if (gb >= RPK_KEYBASE) {
           int k = gb - RPK_KEYBASE;
           T s, c;
@@ -1640,15 +1653,21 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
           T hx = M.key_half()[3 * k];
           T bp[3] = {M.key_pos()[3 * k] - hx + hx * c, M.key_pos()[3 * k + 1], M.key_pos()[3 * k + 2] - hx * s};
           T bm[9] = {c, 0, s, 0, 1, 0, -s, 0, c};
-          if (M.geom_type()[ga] == GEOM_CAPSULE_)
-            n = capsule_box(rc, posA, mA, M.geom_size() + 3 * ga, bp, bm, M.key_half() + 3 * k);
-          else if (MESH && M.geom_type()[ga] == GEOM_MESH_) {
+          if (MESH && M.geom_type()[ga] == GEOM_MESH_) {
             // (box, hull) in geom-type order: the key is geom 1 of the pair; the engine keeps the hand
             // geom as side A of the contact, so the normal is turned around
-            n = RPK_CONVEX(rc, GEOM_BOX_, bp, bm, M.key_half() + 3 * k, -1, GEOM_MESH_, posA, mA, M.geom_size() + 3 * ga, ga);
-            rc[0].n[0] = -rc[0].n[0]; rc[0].n[1] = -rc[0].n[1]; rc[0].n[2] = -rc[0].n[2];
-          } else
-            n = RPK_BOXBOX(rc, posA, mA, M.geom_size() + 3 * ga, bp, bm, M.key_half() + 3 * k);
+            mpr = true; mpr_flip = true; mpr_tA = GEOM_BOX_; mpr_gA = -1; mpr_gB = ga;
+#pragma unroll
+            for (int i = 0; i < 3; i++) { mpr_pA[i] = bp[i]; mpr_sA[i] = M.key_half()[3 * k + i]; mpr_pB[i] = posA[i]; mpr_sB[i] = M.geom_size()[3 * ga + i]; }
+#pragma unroll
+            for (int i = 0; i < 9; i++) { mpr_mA[i] = bm[i]; mpr_mB[i] = mA[i]; }
+          } else {
+            boxside = true; bxs = M.key_half() + 3 * k;
+#pragma unroll
+            for (int i = 0; i < 3; i++) bxp[i] = bp[i];
+#pragma unroll
+            for (int i = 0; i < 9; i++) bxm[i] = bm[i];
+          }
 #pragma unroll
           for (int e = 0; e < 8; e++) pB[e] = M.key_cparam()[e];
           invw += M.key_invw_body()[k];
@@ -1662,15 +1681,32 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
           }
           if (M.geom_type()[gb] == GEOM_CAPSULE_)
             n = capsule_capsule(rc, posA, mA, M.geom_size() + 3 * ga, posB, mB, M.geom_size() + 3 * gb);
-          else if (MESH && M.geom_type()[gb] == GEOM_MESH_)
-            n = RPK_CONVEX(rc, M.geom_type()[ga], posA, mA, M.geom_size() + 3 * ga, ga, GEOM_MESH_, posB, mB, M.geom_size() + 3 * gb, gb);
-          else if (M.geom_type()[ga] == GEOM_CAPSULE_)
-            n = capsule_box(rc, posA, mA, M.geom_size() + 3 * ga, posB, mB, M.geom_size() + 3 * gb);
-          else
-            n = RPK_BOXBOX(rc, posA, mA, M.geom_size() + 3 * ga, posB, mB, M.geom_size() + 3 * gb);
+          else if (MESH && M.geom_type()[gb] == GEOM_MESH_) {
+            mpr = true; mpr_tA = M.geom_type()[ga]; mpr_gA = ga; mpr_gB = gb;
+#pragma unroll
+            for (int i = 0; i < 3; i++) { mpr_pA[i] = posA[i]; mpr_sA[i] = M.geom_size()[3 * ga + i]; mpr_pB[i] = posB[i]; mpr_sB[i] = M.geom_size()[3 * gb + i]; }
+#pragma unroll
+            for (int i = 0; i < 9; i++) { mpr_mA[i] = mA[i]; mpr_mB[i] = mB[i]; }
+          } else {
+            boxside = true; bxs = M.geom_size() + 3 * gb;
+#pragma unroll
+            for (int i = 0; i < 3; i++) bxp[i] = posB[i];
+#pragma unroll
+            for (int i = 0; i < 9; i++) bxm[i] = mB[i];
+          }
 #pragma unroll
           for (int e = 0; e < 8; e++) pB[e] = M.geom_cparam()[8 * gb + e];
           invw += M.geom_invw()[gb];
+        }
+        if (boxside) {
+          if (M.geom_type()[ga] == GEOM_CAPSULE_) n = capsule_box(rc, posA, mA, M.geom_size() + 3 * ga, bxp, bxm, bxs);
+          else n = RPK_BOXBOX(rc, posA, mA, M.geom_size() + 3 * ga, bxp, bxm, bxs);
+        }
+      }
+      if constexpr (MESH != 0) {
+        if (mpr) {
+          n = RPK_CONVEX(rc, mpr_tA, mpr_pA, mpr_mA, mpr_sA, mpr_gA, GEOM_MESH_, mpr_pB, mpr_mB, mpr_sB, mpr_gB);
+          if (mpr_flip) { rc[0].n[0] = -rc[0].n[0]; rc[0].n[1] = -rc[0].n[1]; rc[0].n[2] = -rc[0].n[2]; }
         }
       }
       PROF(13);
