@@ -11,7 +11,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 900 python bench.py > $R/bench_plain.json 2> $R/bench_plain.err
 for c in 3 4 5; do timeout 600 python bench.py --config $c --steps 150 > $R/bench_c$c.json 2> $R/bench_c$c.err; done
 cd /tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --aux-fp32 0 --host-io 0"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --aux-fp32 0 --host-io 0 --aux-fingertips 0"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/stats -- $BENCH --steps 158 --warmup 20 > $R/stats.log 2>&1
 SHORT="$BENCH --stagger 0 --steps 4 --warmup 1"
 export RP_STREAM_SLICES=1

@@ -26,7 +26,7 @@ try:
         return res
     posfull = pos[pos.dur > 30000]
     out.update({
-        "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --aux-fp32 0 --host-io 0 --steps 158 --warmup 20  (fp64, config 2, 4096 envs, staggered episode phases, full env.step, stream slices chosen by the engine; the trace also holds the untimed prologue and the lockstep aux leg)",
+        "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --aux-fp32 0 --host-io 0 --aux-fingertips 0 --steps 158 --warmup 20  (fp64, config 2, 4096 envs, staggered episode phases, full env.step, stream slices chosen by the engine; the trace also holds the untimed prologue and the lockstep aux leg)",
         "kernels": {
             "rp_stage_kernel<double, 1, 4, 9> (solver stage, dominant)": {"launches": int(len(sol)), "avg_us": float(sol.dur.mean() / 1e3), "min_us": float(sol.dur.min() / 1e3), "max_us": float(sol.dur.max() / 1e3), "share_of_gpu_time": float(sol.dur.sum() / kt.dur.sum()), "by_launch_size": by_grid(sol), "launch_config": cfg(sol)},
             "rp_stage_kernel<double, 0, 0, 9> (position/velocity stage)": {"launches": int(len(posfull)), "avg_us": float(posfull.dur.mean() / 1e3), "masked_forward_launches": int(len(pos) - len(posfull)), "share_of_gpu_time": float(pos.dur.sum() / kt.dur.sum()), "by_launch_size": by_grid(posfull), "launch_config": cfg(posfull)},
