@@ -81,3 +81,16 @@ def test_bench_configs_emit_the_contract_line(config):
     assert rf["bound"] == "hbm" and rf["kernel_launches_sampled"] >= 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["algorithmic_bytes_per_launch"] == 7072 * 128
+
+
+@pytest.mark.gpu
+def test_bench_config2_reports_both_fingertip_colliders():
+    """config 2 runs with the notebook's mesh-fingertip setting (stand-in hulls through MPR) and
+    with primitive_fingertip_collisions=True; `--fingertips` picks which one is `value`, the other is aux."""
+    r = _run(["--config", "2", "--envs", "128", "--steps", "4", "--warmup", "1", "--aux-fp32", "0", "--host-io", "0",
+              "--no-cpu-baseline", "--fingertips", "hull"], timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert "hull" in out["config"]["fingertips"] and out["value"] > 0 and out["sanity"]["finite"]
+    other = out["aux"]["primitive_fingertips"]
+    assert other["value"] > 0 and other["sanity"]["finite"] and other["sanity"]["warn_flags_or"] == 0
