@@ -21,6 +21,24 @@ template <> __device__ __forceinline__ float rsqrt_nr<float>(float x) {
   return y;
 }
 
+// 1/x to working precision for the pivots of the tree elimination (x > 0, normal range): hardware
+// estimate + Newton steps instead of the IEEE division sequence (v_div_scale / v_div_fmas / v_div_fixup:
+// twice the dependent chain, and the pivot chain is what the chain leaders wait on).
+template <typename T> __device__ __forceinline__ T rcp_nr(T x);
+template <> __device__ __forceinline__ double rcp_nr<double>(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  return y;
+}
+template <> __device__ __forceinline__ float rcp_nr<float>(float x) {
+  float y = __builtin_amdgcn_rcpf(x);
+  const float e = __builtin_fmaf(-x, y, 1.0f);
+  return __builtin_fmaf(y, e, y);
+}
+
 // Dense solve of the packed lower-triangular SPD system H (n rows, n uniform) with the
 // right-hand side stored as row n of H; returns x_i in lane i < n.
 //   * left-looking L L^T, lane = row, four columns per step (one LDS hand-over per four

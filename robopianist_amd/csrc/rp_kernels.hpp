@@ -478,7 +478,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
               if (!(Dk >= RPK_MINVAL)) { Dk = RPK_MINVAL; warn |= 4; }
               Dslot = Dk;
             }
-            const T inv = dirty ? (T)1 : (T)1 / Dk;
+            const T inv = dirty ? (T)1 : rcp_nr(Dk);
 #pragma unroll
             for (int e = 0; e <= MD; e++) if (e <= mydiag) sm.R[lane][e] = e < mydiag ? Rr[e] * inv : Rr[e];
             sm.Dg[lane] = Dk;
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
             const int v = TC + ci;
             T dv = Ac[ci][v];
             if (mc[ci] && !(dv >= RPK_MINVAL)) { dv = RPK_MINVAL; warn |= 4; }
-            const T iv = mc[ci] ? (T)1 / dv : (T)0;
+            const T iv = mc[ci] ? rcp_nr(dv) : (T)0;
             inv_[ci] = iv;
             T l[TC + 4];
 #pragma unroll
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
           for (int v = TC - 1; v >= 0; v--) {
             T dv = At[v][v];
             if (mt[v] && !(dv >= RPK_MINVAL)) { dv = RPK_MINVAL; warn |= 4; }
-            const T iv = mt[v] ? (T)1 / dv : (T)0;
+            const T iv = mt[v] ? rcp_nr(dv) : (T)0;
             invt[v] = iv;
             T l[TC - 1];
 #pragma unroll
