@@ -1540,8 +1540,9 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
             has = has && (ex * ex + ey * ey + ez * ez <= reach * reach);
             // boxes: separating-axis test on the three box axes (capsule = segment + radius)
             const int bi = bit - ncap;
-            if (bi >= 0 && bi < RPK_NBOXF) {
-              const float* gb = sm.gbox[bi];
+            const bool bbox = bi >= 0 && bi < RPK_NBOXF;
+            const float* gb = sm.gbox[bbox ? bi : 0];
+            if (bbox) {
               const float reach2 = frr + 1e-4f;
               bool sep = false;
 #pragma unroll
@@ -1551,10 +1552,14 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
                 sep = sep || (fabsf(ck) - fhl * fabsf(ak) > gb[9 + k] + reach2);
               }
               has = has && !sep;
+            }
+            {
               // box against box: the full 15-axis separating-axis test in fp32 (0.1 mm allowance), so
-              // that the fp64 box-box routine only ever runs for boxes that really touch
+              // that the fp64 box-box routine only ever runs for boxes that really touch.  (The vote is
+              // taken by the whole wave, in uniform control flow; the test itself runs on the box-box lanes.)
               const int ai = lane - ncap;
-              if (ai >= 0 && ai < RPK_NBOXF && __builtin_amdgcn_ballot_w64(has) != 0ull) {
+              const bool abox = bbox && ai >= 0 && ai < RPK_NBOXF;
+              if (__builtin_amdgcn_ballot_w64(abox && has) != 0ull && abox) {
                 const float* ga_ = sm.gbox[ai];
                 float Rf[3][3], Qf[3][3], tf[3];
 #pragma unroll

@@ -76,9 +76,14 @@ __device__ __forceinline__ unsigned long long wave_or(unsigned long long v) {
   unsigned lo = (unsigned)wave_or((int)(v & 0xffffffffull)), hi = (unsigned)wave_or((int)(v >> 32));
   return ((unsigned long long)hi << 32) | lo;
 }
+// (RPK_SREG_CONSTRAINT: "+s" = keep the pointer in SGPRs; the CPU wave emulator of tests/wavesim
+// compiles this file for the host and overrides it)
+#ifndef RPK_SREG_CONSTRAINT
+#define RPK_SREG_CONSTRAINT "+s"
+#endif
 template <typename P>
 __device__ __forceinline__ const P* fresh(const P* p) {
-  asm volatile("" : "+s"(p));
+  asm volatile("" : RPK_SREG_CONSTRAINT(p));
   return p;
 }
 // fire-and-forget LDS accumulate (ds_add_f32 / ds_add_f64): no read-modify-write round trip

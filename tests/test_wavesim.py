@@ -1,0 +1,37 @@
+"""The engine's OWN kernel sources (robopianist_amd/csrc/*.hpp, rp_engine.hip), compiled for the CPU wave
+emulator in tests/wavesim and stepped against the oracle: a no-GPU check of the HIP code paths themselves
+(lane roles, LDS hand-overs, DPP / readlane reductions, the solver) at the teacher-forced 1e-9 bar.
+Test infrastructure only -- the product never loads the emulator build (engine.load_library opens
+csrc/librp_engine.so; this test points RP_ENGINE_LIB at the emulator build in a subprocess)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+WS = os.path.join(HERE, "wavesim")
+
+
+@pytest.fixture(scope="module")
+def wavesim_lib():
+    subprocess.check_call([os.path.join(WS, "build.sh")], stdout=subprocess.DEVNULL)
+    return os.path.join(WS, "_build", "librp_engine_wavesim.so")
+
+
+def _run(lib, *args):
+    env = dict(os.environ, RP_ENGINE_LIB=lib, WAVESIM_SITE="0")
+    out = subprocess.run([sys.executable, os.path.join(WS, "run_parity.py"), *args], env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    m = re.search(r"worst rel dv ([0-9.e+-]+), max contacts (\d+)", out.stdout)
+    assert m, out.stdout
+    return float(m.group(1)), int(m.group(2))
+
+
+@pytest.mark.parametrize("scenario,nsteps,mincon", [("random", 80, 4), ("wrist", 120, 6)])
+def test_kernels_on_the_wave_emulator_match_the_oracle(wavesim_lib, scenario, nsteps, mincon):
+    worst, maxcon = _run(wavesim_lib, str(nsteps), scenario)
+    assert maxcon >= mincon, maxcon
+    assert worst < 1e-9, worst
