@@ -58,6 +58,8 @@ typedef enum {
   RP_ENV_COST = 18,     /* [E] int32  shader-clock cycles >> 8 of the env's last solver-stage wave (diagnostic; the
                            predictor of rp_set_cost_ordered_launch) */
   RP_DEBUG_MASS_ROWS = 19, /* [E][52 or 60][10 or 14] hand-over: row i = M[link i][its ancestors by depth] (tests) */
+  RP_DEBUG_HANDOVER_HDR = 20, /* [E][8] int32 hand-over header of the last position stage: contacts, touched keys,
+                           dirty-row mask lo / hi, contact Jacobian entries, max entries per contact (diagnostics) */
   RP_SENSOR_TOUCH = 17  /* [E][nsite] `touch` sensors (sum of the normal forces of the contacts whose force ray
                            hits the site's sphere), non-zero for the fingertip sites = the `fingertip_force`
                            observable  shadow_hand.py:248-270,425-432.  Needs rp_set_acc_sensors(e, 1). */

@@ -501,6 +501,7 @@ struct Engine : EngineBase {
       case RP_TREE_OFFSET: *p = S.tree_offset; *bytes = sizeof(T) * E * ntree * 3; *writable = true; return true;
       case RP_ENV_COST: *p = S.cost_sol; *bytes = sizeof(int) * E; return true;
       case RP_DEBUG_MASS_ROWS: *p = B.RM; *bytes = sizeof(T) * E * RPK_NLX(md()) * (md() + 1); return true;
+      case RP_DEBUG_HANDOVER_HDR: *p = B.hdr; *bytes = sizeof(int) * E * 8; return true;
       case RP_SENSOR_TORQUE: if (!d_sens_torque) return false; *p = d_sens_torque; *bytes = sizeof(T) * E * nv; return true;
       case RP_SENSOR_TOUCH: if (!d_sens_touch) return false; *p = d_sens_touch; *bytes = sizeof(T) * E * nsite; return true;
     }

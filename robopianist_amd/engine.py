@@ -25,7 +25,7 @@ LIB_PATH = os.environ.get("RP_ENGINE_LIB") or os.path.join(_HERE, "csrc", "librp
 # rp_field
 QPOS, QVEL, QACC_WARMSTART, CTRL, QFRC_APPLIED, ACT_FORCE, ACT_VELOCITY, SITE_XPOS, \
     TIME, NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER, CONTACT_DIST, TREE_OFFSET, ACTIVE, \
-    SENSOR_TORQUE, SENSOR_TOUCH, ENV_COST, DEBUG_MASS_ROWS = range(20)
+    SENSOR_TORQUE, SENSOR_TOUCH, ENV_COST, DEBUG_MASS_ROWS, DEBUG_HANDOVER_HDR = range(21)
 MAX_CONTACTS = 32
 
 WARN_BADSTATE = 1
@@ -146,11 +146,11 @@ class BatchedPhysics:
             SITE_XPOS: (self.nsite, 3), TIME: (), NCON: (), CONTACT_GEOMS: (MAX_CONTACTS, 2),
             WARN_FLAGS: (), SOLVER_ITER: (), CONTACT_DIST: (MAX_CONTACTS,),
             TREE_OFFSET: (self.ntree, 3), ACTIVE: (), SENSOR_TORQUE: (self.nv,), SENSOR_TOUCH: (self.nsite,),
-            ENV_COST: (),
+            ENV_COST: (), DEBUG_HANDOVER_HDR: (8,),
         }
         deep = self.dim("nlink") > 52 or self.dim("maxdepth") > 9
         self._shapes[DEBUG_MASS_ROWS] = ((60, 14) if deep else (52, 10))
-        self._int_fields = {NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER, ACTIVE, ENV_COST}
+        self._int_fields = {NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER, ACTIVE, ENV_COST, DEBUG_HANDOVER_HDR}
         if self_check is None:
             self_check = os.environ.get("RP_SKIP_SELF_CHECK", "0") != "1"
         if self_check:
