@@ -125,6 +125,14 @@ int rp_set_lazy_position_stage(rp_engine* e, int on);
  * times) a heavy env that happens to start last is the tail of the whole launch.  Results are
  * bit-identical either way (envs are independent); default: off. */
 int rp_set_cost_ordered_launch(rp_engine* e, int on);
+/* Capacity classes of the solver stage (on by default for the fp64 engine on scenes with <= 2 forearm dofs per
+ * hand; RP_LEAN=0 in the environment turns the default off).  on: envs whose constraint system of the substep
+ * fits the light class (<= 24 contacts, <= 160 contact Jacobian entries, <= 36 cross-coupled rows, <= 12 touched
+ * keys) are stepped by the lean build of the solver stage (two waves per SIMD), the others by the full-capacity
+ * build; results do not depend on the class to more than rounding.  No counterpart in the reference (MuJoCo
+ * allocates its constraint arrays per step). */
+int rp_set_lean_solver(rp_engine* e, int on);
+
 /* Stream slices (0, 1, 2 or 4; default 1): with n > 1, rp_step runs n slices of the batch as n
  * independent kernel chains (the caller's stream and internal ones, forked / joined with events
  * inside the call), so that the tail of one slice's launch overlaps another slice's next kernel:

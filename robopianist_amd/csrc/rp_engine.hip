@@ -182,6 +182,7 @@ struct EngineBase {
   hipStream_t xstream[kMaxSlices] = {};   // [0] unused: slice 0 runs on the caller's stream
   hipEvent_t ev_fork = nullptr, ev_join[kMaxSlices] = {};
   virtual int acc_sensors(int on) = 0;
+  virtual int lean_solver(int on) = 0;
   virtual int field_ptr(rp_field f, void** p, size_t* bytes) = 0;
   bool own_stream = true;
   virtual int profile(long long* out, int n, int enable) = 0;
@@ -200,6 +201,12 @@ struct Engine : EngineBase {
   bool trunk4 = false;  // every tree has a 4-link trunk: launch the specialised solver build
   bool mesh = false;    // the model has convex-hull geoms: position / sensor stages with MPR
   bool deep = false;    // a trunk of 5..8 links (more than two forearm dofs): the RPK_MAXD_DEEP builds
+  bool lean = false;    // light envs are stepped by rp_lean_solver_kernel (rp_solver2.hpp), the others by the full build
+  int lean_solver(int on) override {
+    if (on && (deep || sizeof(T) != 8)) return fail("rp_set_lean_solver: the lean solver stage exists for the fp64 default builds only");
+    lean = on != 0; S.lean = lean ? 1 : 0;
+    return 0;
+  }
   int md() const { return deep ? RPK_MAXD_DEEP : RPK_MAXD; }
 
   ~Engine() override {
@@ -405,6 +412,11 @@ struct Engine : EngineBase {
     S.cost_pos = dalloc<int>(E); S.cost_sol = dalloc<int>(E);
     d_valid = dalloc<unsigned char>(E);  // (zero-filled: nothing is valid yet)
     S.max_newton = M.iterations; S.max_ls = M.ls_iterations;
+    {
+      const char* le = getenv("RP_LEAN");
+      lean = sizeof(T) == 8 && !deep && !(le && le[0] == '0');
+      S.lean = lean ? 1 : 0;
+    }
     // The fills and uploads above went through the null stream, which is NOT ordered with the
     // engine's non-blocking stream: everything must have landed before the first kernel.
     if (hipDeviceSynchronize() != hipSuccess) throw std::string("hipDeviceSynchronize failed after model upload");
@@ -621,15 +633,13 @@ struct Engine : EngineBase {
         else if (mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD, 1>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
         else hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
       };
-      // mj_step1 for the current state ...
-      if (lazy_position && mode == 0) {
-        // ... skipped for envs whose hand-over is still the one of their current state
-        RpState<T> lead = ss;
-        lead.active = d_lead;
-        launch_pos_on(lead, -1);
-      } else {
-        launch_pos_on(ss, -1);
-      }
+      // mj_step1 for the current state, in index order: d_order may date from a step with another slice
+      // count (a permutation of other ranges), and every slice must write the hand-over of exactly ITS envs
+      // before its solver stage reads it (the solver stage consumes the hand-over: it parks values in it)
+      RpState<T> lead = ss;
+      lead.order = nullptr;
+      if (lazy_position && mode == 0) lead.active = d_lead;   // skipped for envs whose hand-over is still the one of their state
+      launch_pos_on(lead, -1);
       if (mode != 0) continue;
       // ... then n_sub x (mj_step2; mj_step1): dm_control's legacy order.  Two kernels per substep instead
       // of one fused launch: each half fits in registers, the hand-over (RpStage) stays in L2 / Infinity Cache.
@@ -644,6 +654,8 @@ struct Engine : EngineBase {
         }
         if (probe) { HIP_OK(hipEventRecord(sv0[slot], st)); sv_envs[slot] = cnt; }
         // solver stage; the build specialised for "every tree has a 4-link trunk" when it applies
+        // (light envs first, on the lean build at two waves per SIMD; the full-capacity build skips them)
+        if (lean) hipLaunchKernelGGL((rp_lean_solver_kernel<T>), dim3(cnt), dim3(64), 0, st, M, ss, B);
         if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 0, RPK_MAXD_DEEP>), dim3(cnt), dim3(64), 0, st, M, ss, B, k, nsub);
         else if (trunk4) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 4>), dim3(cnt), dim3(64), 0, st, M, ss, B, k, nsub);
         else hipLaunchKernelGGL((rp_stage_kernel<T, 1>), dim3(cnt), dim3(64), 0, st, M, ss, B, k, nsub);
@@ -748,6 +760,7 @@ int rp_set_lazy_position_stage(rp_engine* e, int on) {
   return 0;
 }
 int rp_set_acc_sensors(rp_engine* e, int on) { return e ? E(e)->acc_sensors(on) : fail("null engine"); }
+int rp_set_lean_solver(rp_engine* e, int on) { return e ? E(e)->lean_solver(on) : fail("null engine"); }
 int rp_set_stream_slices(rp_engine* e, int n) {
   if (!e) return fail("null engine");
   if (n != 0 && n != 1 && n != 2 && n != 4) return fail("rp_set_stream_slices: 0 (automatic), 1, 2 or 4");

@@ -6,6 +6,7 @@
 #include "rp_wave.hpp"
 #include "rp_narrow.hpp"
 #include "rp_dense.hpp"
+#include "rp_solver2.hpp"
 
 #ifdef RPK_NO_BOXBOX   // perf experiment: what the box-box routine costs the position kernel
 #define RPK_BOXBOX(...) 0
@@ -352,6 +353,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
     // ======================================================================
     if constexpr (MODE == 1) {
       // ---- what the position/velocity kernel left behind
+      if (S.lean && B.hdr[env * 8 + 6] == 1) return;   // a light env: rp_lean_solver_kernel steps it
       {
         ncon = B.hdr[env * 8]; nkt = B.hdr[env * 8 + 1];
         dirty_mask = ((unsigned long long)(unsigned)B.hdr[env * 8 + 3] << 32) | (unsigned)B.hdr[env * 8 + 2];
@@ -1959,7 +1961,12 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
       const int nent = wave_max(lane < ncon ? base + cnt : 0), maxm = wave_max(cnt);
       if constexpr (MODE == 0) {
         LI(10) = base | (cnt << 8);
-        if (lane == 0) { B.hdr[env * 8 + 4] = nent; B.hdr[env * 8 + 5] = maxm; }
+        if (lane == 0) {
+          B.hdr[env * 8 + 4] = nent; B.hdr[env * 8 + 5] = maxm;
+          // capacity class of this env's solve (rp_solver2.hpp): light = fits the lean solver stage
+          B.hdr[env * 8 + 6] = (S.lean && MD == RPK_MAXD && ncon <= LeanCaps::NC && nent <= LeanCaps::NE &&
+                                __popcll(dirty_mask) <= LeanCaps::HMAX && nkt <= LeanCaps::NK && nl + nkt <= 64) ? 1 : 0;
+        }
       }
       WSYNC();
       const int mycol = isl ? depth : sdepth + 1;

@@ -151,6 +151,10 @@ struct RpState {
   // may be null: shader-clock cycles (>> 8) every env's wave spent in its last position stage /
   // solver stage -- the cost predictor of the ordered launch
   int *cost_pos, *cost_sol;
+  // capacity classes of the solver stage: when set, the position stage marks every env whose constraint system
+  // fits rpk::LeanCaps as "light" (hdr[6] = 1); rp_lean_solver_kernel (two waves per SIMD) steps those and the
+  // full-capacity solver stage skips them
+  int lean;
 };
 
 // One workgroup == one wavefront, and a wave's LDS instructions execute in issue
@@ -187,7 +191,7 @@ struct RpStage {
   T* RM;      // [E][RPK_NLX(MD)][MD+1] mass-matrix rows (MD = RPK_MAXD or RPK_MAXD_DEEP, the build in use)
   T* lanef;   // [E][RPK_NLF][64]
   int* lanei; // [E][RPK_NLI][64]
-  int* hdr;   // [E][8]: ncon, nkt, dirty mask lo/hi, nent, max entries per contact
+  int* hdr;   // [E][8]: ncon, nkt, dirty mask lo/hi, nent, max entries per contact, capacity class (1 = light)
   T* entJ;    // [E][RpCaps<T>::NE][3]  contact Jacobian entries: d(contact point velocity)/d(qvel of one dof)
   int* entM;  // [E][RpCaps<T>::NE][2]  lane | contact<<6 | column<<11 | cross<<15 ; base | count<<8 | rank<<16
   int* slots; // [E][64]: slotkey[16], slotlink[16], slotmask lo[16], hi[16]

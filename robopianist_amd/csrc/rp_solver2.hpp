@@ -1,0 +1,984 @@
+// rp_solver2.hpp — the LEAN solver stage (mj_step2: actuation, Newton solve, Euler) for envs whose
+// constraint system fits the "light" capacity class.  Same arithmetic as rp_stage_kernel<T, 1>
+// (rp_kernels.hpp: that build keeps the full capacities and takes the other envs), restructured so that
+// the per-lane state is half as large: <= 256 registers and <= 20 KB of LDS per env, i.e. two waves per
+// SIMD in fp64 (the full-capacity build needs all 512 registers and 40 KB).
+//
+// What the reference does here: `physics.step()` inside composer.Environment.step,
+// /root/reference/robopianist/suite/tasks/base.py:28,31,68-70 (mj_step2 half of every substep);
+// MuJoCo's mj_fwdActuation / mj_fwdAcceleration / mj_solNewton (PrimalSearch) / mj_Euler restated.
+//
+// How the state shrinks:
+//   * tree factor/solve with every row in ITS OWN lane (`Rr[10]`): the links of one chain position are
+//     eliminated for all chains at once, their rows cross to their in-chain ancestors through LDS
+//     (per-lane addresses), the trunk receives sum_v H[v][t] H[v][t'] / d_v through LDS adds; no lane
+//     gathers a chain block (Ac[5][9] + At + dT of the full build: ~140 registers in all 64 lanes);
+//   * contact Jacobian entries are rotated into their contact frame once per launch: J x gives
+//     (normal, tangent 1, tangent 2) directly, the per-contact Hessian weight is 5 numbers, and the
+//     contact frame (9 values per lane) never sits in registers;
+//   * the line search recomputes a row's quadratic coefficients from (jar, jv) where it evaluates them
+//     (same expressions, same bits) instead of holding 21 coefficients;
+//   * M rows stay in registers, M x scatters its column part with LDS adds (no LDS copy of M);
+//     key values cross through 16 slot-indexed cells instead of a 128-key table;
+//   * state that the Newton loop does not touch (qpos, qvel, applied forces) is re-read at the end.
+#pragma once
+#ifdef RP_LEAN_TRACE
+#include <cstdio>
+#endif
+#include "rp_model.hpp"
+#include "rp_wave.hpp"
+#include "rp_dense.hpp"
+
+namespace rpk {
+// capacities of the light class (what the position stage tests before it marks an env "light")
+struct LeanCaps {
+  static constexpr int NC = 24;     // contacts
+  static constexpr int NE = 160;    // contact Jacobian entries
+  static constexpr int HMAX = 36;   // rows of the dense (cross-chain) block
+  static constexpr int NK = 12;     // touched keys (solver slots)
+};
+template <typename T>
+struct SmemLean {
+  T R[RPK_WAVE][RPK_MAXD + 1];   // tree rows: assembly target, then the rows published by the elimination
+  T H[(LeanCaps::HMAX + 1) * (LeanCaps::HMAX + 2) / 2];   // packed dense block + rhs row
+  T entJ[LeanCaps::NE][3];       // contact-frame Jacobian entries (normal, tangent 1, tangent 2)
+  int entM[LeanCaps::NE][2];
+  T cC[LeanCaps::NC][5];         // per-contact Hessian weight in the contact frame: sn, a1, a2, b1, b2
+  T cv[LeanCaps::NC][3];         // per-contact staging (J x, or the contact force), contact frame
+  T vec[RPK_WAVE];               // per-dof staging
+  T xs[RPK_WAVE];                // solve staging: right-hand sides / solution
+  T jt[RPK_WAVE];                // J^T f staging; pivots' reciprocals during a tree solve
+  T slotv[2][16];                // values of the touched keys, by solver slot
+  T trunk[RPK_MAXTREE][16];      // what the eliminated chains leave on their tree's trunk (10 + 4 values)
+  unsigned prof[RPK_NPROF];
+};
+}  // namespace rpk
+
+template <typename T>
+__global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B) {
+  using namespace rpk;
+  using N = Num<T>;
+  constexpr int MD = RPK_MAXD, TC = 4;
+  const int env = S.order ? S.order[S.env_base + blockIdx.x] : S.env_base + (int)blockIdx.x;
+  const int lane = threadIdx.x;
+  if (S.active && S.active[env] == 0) return;
+  if (B.hdr[env * 8 + 6] != 1) return;   // not a light env: the full-capacity build takes it
+  __shared__ SmemLean<T> sm;
+#ifdef RP_LEAN_TRACE
+  if (lane == 0) printf("lean kernel: env %d ncon %d\n", env, B.hdr[env * 8]);
+#endif
+#ifdef RPK_POISON_LDS  // debug build: nothing may depend on what a previous workgroup left in LDS
+  {
+    unsigned* w_ = reinterpret_cast<unsigned*>(&sm);
+    for (int i = threadIdx.x; i < (int)(sizeof(sm) / 4); i += 64) w_[i] = 0xFFF4DEADu;
+    WSYNC();
+  }
+#endif
+  int warn = 0;
+  if (S.prof && env == 0 && lane < RPK_NPROF) sm.prof[lane] = 0;
+  long long prof_t = (long long)__builtin_readcyclecounter();
+  const long long kernel_t0 = prof_t;
+  const int nl = M.nlink, nk = M.nkey, nv = M.nv, nu = M.nu;
+  const T h = M.timestep;
+  const bool isl = lane < nl;
+  const int L = isl ? lane : 0;
+  // The per-lane integers of the solve live PACKED in three registers and are unpacked, from an opaque copy,
+  // where they are used (v_bfe is one instruction; two dozen integers held through the Newton loop, and the
+  // lane masks the compiler derives from them and hoists, are what pushed this stage into scratch):
+  //   tpk: depth + 1 (0: not a link) | trunk length << 4 | trunk base lane << 7 | tree << 13 | links on my chain << 15
+  //   kpk: solver slot + 1 of my key (5 bits) | of my key + 64 << 5 | touched keys hanging under me << 10
+  //   spk: slot lanes: anchor link | its trunk length << 8 | its trunk base << 12 | its depth + 1 << 18; limit row signs + 1 << 22
+  int tpk, kpk, spk;
+  int ldof, lact;
+  {
+    const int4* rec = (const int4*)(M.lane_topo() + 16 * L);
+    const int4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+    ldof = isl ? r1.y : 0; lact = isl ? r2.z : -1;
+    tpk = isl ? ((r0.y + 1) | (r1.w << 4) | (r1.z << 7) | (r1.x << 13) | ((r2.w - r1.w) << 15)) : 0;
+  }
+  struct Topo { int depth, TL, tbase, ltree, clen; };
+  auto topo = [&]() -> Topo {
+    int t = tpk;
+    asm volatile("" : "+v"(t));
+    Topo o;
+    o.depth = (t & 15) - 1; o.TL = (t >> 4) & 7; o.tbase = (t >> 7) & 63; o.ltree = (t >> 13) & 3; o.clen = (t >> 15) & 7;
+    return o;
+  };
+  // lane of my ancestor at depth e (lanes are in preorder: trunk chain, then the leaf chains)
+  auto anc_at = [&](const Topo& tp, int e) -> int { return e < tp.TL ? tp.tbase + e : lane - (tp.depth - e); };
+  auto anc_of = [](int lk, int dl, int tl, int tb, int e) -> int { return e < tl ? tb + e : lk - (dl - e); };
+  const bool isk[2] = {lane < nk, lane + 64 < nk};
+  const int kid[2] = {lane, lane + 64};
+  int kdof[2], kact[2];
+  kpk = 0;
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    kdof[s] = isk[s] ? M.key_dof()[kid[s]] : 0;
+    kact[s] = isk[s] ? M.key_act()[kid[s]] : -1;
+    // solver slot of my key (-1: not touched)
+    const int ks = isk[s] ? (int)((const signed char*)(B.keyslot + (size_t)env * (RPK_NKEYS / 4)))[kid[s]] : -1;
+    kpk |= (ks + 1) << (5 * s);
+  }
+  auto myks = [&](int s) -> int {
+    int t = kpk;
+    asm volatile("" : "+v"(t));
+    return ((t >> (5 * s)) & 31) - 1;
+  };
+  const size_t eo = (size_t)env * nv;
+  const size_t lf = (size_t)env * RPK_NLF * 64 + lane, li = (size_t)env * RPK_NLI * 64 + lane;
+#define LF(i) B.lanef[lf + (size_t)(i) * 64]
+#define LI(i) B.lanei[li + (size_t)(i) * 64]
+  // ---- what the position / velocity stage left behind
+  const int ncon = B.hdr[env * 8], nkt = B.hdr[env * 8 + 1];
+  const unsigned long long dirty_mask = ((unsigned long long)(unsigned)B.hdr[env * 8 + 3] << 32) | (unsigned)B.hdr[env * 8 + 2];
+  const int nent = B.hdr[env * 8 + 4], maxm = B.hdr[env * 8 + 5];
+  // my mass-matrix row over my ancestors (diag at [depth]); re-read from the (L2-resident) hand-over where it
+  // is used instead of holding 20 registers through the Newton loop
+  auto load_Mr = [&](T* Mr) {
+    const T* row = fresh(B.RM) + ((size_t)env * RPK_NLX(MD) + L) * (MD + 1);
+#pragma unroll
+    for (int e = 0; e <= MD; e++) Mr[e] = isl ? row[e] : (T)0;
+  };
+  spk = (LI(0) & 63) << 22;
+  auto lim_sign = [&](int s) -> int {
+    int t = spk;
+    asm volatile("" : "+v"(t));
+    return ((t >> (22 + 2 * s)) & 3) - 1;
+  };
+  T lim_D[3] = {0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 3; k++) if (lim_sign(k) != 0) lim_D[k] = LF(8 + k);
+  T con_D = 0, con_mu = 0;
+  if (lane < ncon) {
+    con_D = LF(14); con_mu = LF(15);
+    // contact frame -> LDS (rows of sm.R are free until the first assembly), only to rotate the entries
+#pragma unroll
+    for (int k = 0; k < 9; k++) sm.R[lane][k] = LF(16 + k);
+  }
+  {
+    const int sl_ = LI(11), sd_ = LI(9);
+    spk |= (sl_ & 255) | (((sl_ >> 8) & 15) << 8) | (((sl_ >> 16) & 63) << 12) | (((sd_ + 1) & 15) << 18);
+  }
+  struct SlotI { int salink, sTL, sTB, sdepth; };
+  auto slot_info = [&]() -> SlotI {
+    int t = spk;
+    asm volatile("" : "+v"(t));
+    SlotI o;
+    o.salink = t & 255; o.sTL = (t >> 8) & 15; o.sTB = (t >> 12) & 63; o.sdepth = ((t >> 18) & 15) - 1;
+    return o;
+  };
+  // which touched keys hang under me (bit s: the anchor chain of slot s passes through this link)
+  {
+    const int* sl = B.slots + (size_t)env * 64;
+    for (int s = 0; s < nkt; s++) {
+      const unsigned long long am = ((unsigned long long)(unsigned)sl[48 + s] << 32) | (unsigned)sl[32 + s];
+      if (isl && ((am >> lane) & 1)) kpk |= 1 << (10 + s);
+    }
+  }
+  WSYNC();
+  // contact Jacobian entries, rotated into the contact frame of their contact
+  for (int i = lane; i < nent; i += 64) {
+    const size_t e = (size_t)env * RpCaps<T>::NE + i;
+    const T j0 = B.entJ[e * 3], j1 = B.entJ[e * 3 + 1], j2 = B.entJ[e * 3 + 2];
+    const int m0 = B.entM[e * 2], m1 = B.entM[e * 2 + 1];
+    const T* fr = sm.R[(m0 >> 6) & 31];
+    sm.entJ[i][0] = fr[0] * j0 + fr[1] * j1 + fr[2] * j2;
+    sm.entJ[i][1] = fr[3] * j0 + fr[4] * j1 + fr[5] * j2;
+    sm.entJ[i][2] = fr[6] * j0 + fr[7] * j1 + fr[8] * j2;
+    sm.entM[i][0] = m0; sm.entM[i][1] = m1;
+  }
+  WSYNC();
+  PROF(0);
+  // ---- per-lane constants of the dynamics
+  const T lfloss = isl ? M.link_floss()[L] : (T)0;
+  const T lflR = isl ? M.link_fl_R()[L] : (T)1;
+  const T lflD = (T)1 / lflR;
+  T kM[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) kM[s] = isk[s] ? M.key_M()[isk[s] ? kid[s] : 0] : (T)1;
+  // ---- actuation, passive forces, bias [MJ: mj_fwdActuation, mj_passive] -> qfrc_smooth
+  T qfs[3], qs[3];
+  {
+    const bool isa = lane < nu && M.act_kind()[lane < nu ? lane : 0] == 0;
+    const int A = lane < nu ? lane : 0;
+    T ctrl = (lane < nu) ? S.ctrl[(size_t)env * nu + lane] : (T)0;
+    if (lane < nu && M.act_ctrllimited()[A])
+      ctrl = fmin(M.act_ctrlrange()[2 * A + 1], fmax(M.act_ctrlrange()[2 * A], ctrl));
+    if (isa) {
+      const T alen = LF(1), avel = LF(2);
+      T aforce = M.act_gain()[A] * ctrl + M.act_bias()[3 * A] + M.act_bias()[3 * A + 1] * alen +
+                 M.act_bias()[3 * A + 2] * avel;
+      if (M.act_forcelimited()[A])
+        aforce = fmin(M.act_forcerange()[2 * A + 1], fmax(M.act_forcerange()[2 * A], aforce));
+      sm.vec[lane] = aforce;
+      S.act_force[(size_t)env * nu + lane] = aforce;
+    }
+    WSYNC();
+    const T qbias = LF(0);
+    const T q0 = isl ? S.qpos[eo + ldof] : (T)0, qd0 = isl ? S.qvel[eo + ldof] : (T)0;
+    const T qapp0 = (isl && S.qfrc_applied) ? S.qfrc_applied[eo + ldof] : (T)0;
+    const T lstiff = isl ? M.link_stiffness()[L] : (T)0, lsref = isl ? M.link_springref()[L] : (T)0;
+    const T lactcoef = isl ? M.link_act_coef()[L] : (T)0;
+    const T qact = (isl && lact >= 0) ? lactcoef * sm.vec[lact >= 0 ? lact : 0] : (T)0;
+    const T qpas = -lstiff * (q0 - lsref) - (isl ? M.link_damping()[L] : (T)0) * qd0;
+    qfs[0] = isl ? (qpas - qbias + qapp0 + qact) : (T)0;
+    const T ksin[2] = {LF(3), isk[1] ? LF(4) : (T)0}, kcos[2] = {LF(5), isk[1] ? LF(6) : (T)1};
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const int K = isk[s] ? kid[s] : 0;
+      const T kstiff = isk[s] ? M.key_stiffness()[K] : (T)0, ksref = isk[s] ? M.key_springref()[K] : (T)0;
+      const T kmass = isk[s] ? M.key_mass()[K] : (T)0, khx = isk[s] ? M.key_half()[3 * K] : (T)0;
+      const T qk = isk[s] ? S.qpos[eo + kdof[s]] : (T)0, qdk = isk[s] ? S.qvel[eo + kdof[s]] : (T)0;
+      const T qappk = (isk[s] && S.qfrc_applied) ? S.qfrc_applied[eo + kdof[s]] : (T)0;
+      const T grav = -kmass * M.gz * khx * kcos[s] - kmass * M.gx * khx * ksin[s];
+      T f = -kstiff * (qk - ksref) - (isk[s] ? M.key_damping()[K] : (T)0) * qdk + grav + qappk;
+      if (isk[s] && kact[s] >= 0) {
+        T c = S.ctrl[(size_t)env * nu + kact[s]];
+        if (M.act_ctrllimited()[kact[s]])
+          c = fmin(M.act_ctrlrange()[2 * kact[s] + 1], fmax(M.act_ctrlrange()[2 * kact[s]], c));
+        T af = M.act_gain()[kact[s]] * c;
+        if (M.act_forcelimited()[kact[s]])
+          af = fmin(M.act_forcerange()[2 * kact[s] + 1], fmax(M.act_forcerange()[2 * kact[s]], af));
+        f += M.act_coef()[2 * kact[s]] * af;
+        S.act_force[(size_t)env * nu + kact[s]] = af;
+      }
+      qfs[1 + s] = f;
+      qs[1 + s] = f / kM[s];
+    }
+    WSYNC();
+  }
+  // kdof / kact are recomputed where the new state is stored
+
+  PROF(1);
+
+  // ---- hybrid tree-sparse / dense factor + solve [MJ: mj_factorM / mj_solveLD], rows in their lanes.
+  // Row r of the symmetric system is held by lane r as Rr[e] = A[r][anc_e(r)] (diag at e = depth; slot
+  // lanes: key leaf under its anchor link, diag at e = sdepth + 1).  Rows whose bit is clear in `dm`
+  // ("clean") couple only to their ancestors and are eliminated leaf-to-root without fill-in: first the
+  // key leaves, then chain position 4, 3, .. 0 for all chains of both trees at once (the row of an
+  // eliminated link crosses to the links above it on its chain through LDS; what it leaves on the trunk
+  // is added into a per-tree table), then trunk position 3 .. 0.  The rows in `dm` (supports of cross-chain
+  // contacts: an ancestor-closed set) receive the Schur complement and are solved by the dense block
+  // (sm.H already holds the cross-contact terms).  Back-substitution runs root to leaves, one level at a
+  // time.  Returns x for this lane's row.
+  auto tree_solve = [&](T* Rr, T rhs, int nslots, unsigned long long dm) -> T {
+    // (the lane predicates below -- depth == d, pos == j, e <= depth: some fifty 64-bit masks -- are formed
+    // here, from an opaque copy of the packed topology, so that the compiler does not hoist them out of the
+    // Newton loop and then spill them: v_cmp is cheaper than a spilled SGPR pair)
+    const Topo tp = topo();
+    const int depth = tp.depth, TL = tp.TL, tbase = tp.tbase, ltree = tp.ltree, clen = tp.clen;
+    const SlotI si = slot_info();
+    const int sdepth = si.sdepth, salink = si.salink, sTL = si.sTL, sTB = si.sTB;
+    const int foldmask = kpk >> 10;
+    const int pos = isl ? depth - TL : -2;          // chain position (trunk links: negative)
+#ifdef RPK_X_NOTS   // compile-only experiment: register floor without the tree solve
+    return rhs * Rr[0] + (T)(nslots + (int)dm);
+#endif
+    const bool isslot = !isl && lane < nl + nslots;
+    const bool dirty = (dm >> lane) & 1;
+    const int mydiag = isl ? depth : sdepth + 1;
+    T mydinv = 0;   // reciprocal pivot of my (clean) row
+    if (lane < RPK_MAXTREE * 16) (&sm.trunk[0][0])[lane] = 0;
+    // ---- key leaves (they hang under chain / trunk links): the slot lanes publish their scaled rows,
+    // the link lanes on the anchor's path fold them in
+    T Dslot = 1;
+    if (nslots > 0) {
+      if (isslot) {
+        T Dk = (T)1;
+#pragma unroll
+        for (int e = 0; e <= MD; e++) if (e == mydiag) Dk = Rr[e];
+        if (!dirty) {
+          if (!(Dk >= RPK_MINVAL)) { Dk = RPK_MINVAL; warn |= 4; }
+          Dslot = Dk;
+        }
+        const T inv = dirty ? (T)1 : rcp_nr(Dk);
+#pragma unroll
+        for (int e = 0; e <= MD; e++) if (e <= mydiag) sm.R[lane][e] = e < mydiag ? Rr[e] * inv : Rr[e];
+        sm.jt[lane] = Dk;
+        sm.xs[lane] = rhs;
+      }
+      WSYNC();
+      if (isl) {
+        for (int sidx = 0; sidx < nslots; sidx++) {
+          const T* Lk = sm.R[nl + sidx];
+          T lrow[MD + 1];
+#pragma unroll
+          for (int e = 0; e <= MD; e++) lrow[e] = Lk[e];
+          const T lk = Lk[depth], dk = sm.jt[nl + sidx], xk = sm.xs[nl + sidx];
+          if (((foldmask >> sidx) & 1) && !((dm >> (nl + sidx)) & 1)) {
+            const T t = lk * dk;
+#pragma unroll
+            for (int e = 0; e <= MD; e++) if (e <= depth) Rr[e] -= t * lrow[e];
+            rhs -= lk * xk;
+          }
+        }
+      }
+      WSYNC();
+    }
+    PROF(20);
+    // ---- chains: position j = 4 .. 0.  (a) the links at position j publish their final row, right-hand
+    // side and reciprocal pivot; (b) the links above them on the same chain (position jp < j) take the
+    // update  R[e] -= (H[v][me] / d_v) H[v][e]  from the row of v = lane + (j - jp).
+#pragma unroll
+    for (int j = 4; j >= 0; j--) {
+      if (isl && pos == j) {
+        T dv = (T)1;
+#pragma unroll
+        for (int e = 0; e <= MD; e++) if (e == depth) dv = Rr[e];
+        if (!dirty) {
+          if (!(dv >= RPK_MINVAL)) { dv = RPK_MINVAL; warn |= 4; }
+          mydinv = rcp_nr(dv);
+        }
+#pragma unroll
+        for (int e = 0; e < MD; e++) if (e <= depth) sm.R[lane][e] = Rr[e];
+        sm.xs[lane] = rhs;
+        sm.jt[lane] = mydinv;
+      }
+      if (j == 0) break;
+      WSYNC();
+      {
+        const int v = lane + (j - pos);
+        const bool recv = isl && pos >= 0 && pos < j && j < clen && !((dm >> (v & 63)) & 1);
+        const int vr = recv ? v : lane;          // (unconditional loads from in-bounds addresses)
+        const T* Rv = sm.R[vr];
+        T rowv[MD];
+#pragma unroll
+        for (int e = 0; e < MD; e++) rowv[e] = Rv[e];
+        const T mult = Rv[depth >= 0 ? depth : 0];
+        const T l = mult * sm.jt[vr];
+        const T bv = sm.xs[vr];
+        // (other lanes read their own, partly unwritten row: the update is selected, not multiplied by zero)
+#pragma unroll
+        for (int e = 0; e < MD; e++) if (recv && e <= depth) Rr[e] -= l * rowv[e];
+        if (recv) rhs -= l * bv;
+      }
+    }
+    // ---- what the eliminated chain links leave on their trunk: sum over v of H[v][t] H[v][t'] / d_v
+    if (isl && pos >= 0 && !dirty) {
+      T* tt = sm.trunk[ltree];
+#pragma unroll
+      for (int t = 0; t < TC; t++) {
+        if (t < TL) {
+          const T lt = Rr[t] * mydinv;
+#pragma unroll
+          for (int t2 = 0; t2 <= t; t2++) lds_add(&tt[t * (t + 1) / 2 + t2], -(lt * Rr[t2]));
+          lds_add(&tt[10 + t], -(lt * rhs));
+        }
+      }
+    }
+    WSYNC();
+    if (isl && pos < 0) {
+      const T* tt = sm.trunk[ltree];
+      const int tro = depth * (depth + 1) / 2;
+#pragma unroll
+      for (int e = 0; e < TC; e++) { const T dv = tt[tro + e < 10 ? tro + e : 9]; if (e <= depth) Rr[e] += dv; }
+      rhs += tt[10 + depth];
+    }
+    // ---- trunk: position j = 3 .. 0, the same way along the trunk chain
+#pragma unroll
+    for (int j = TC - 1; j >= 0; j--) {
+      if (isl && pos < 0 && depth == j) {
+        T dv = (T)1;
+#pragma unroll
+        for (int e = 0; e < TC; e++) if (e == depth) dv = Rr[e];
+        if (!dirty) {
+          if (!(dv >= RPK_MINVAL)) { dv = RPK_MINVAL; warn |= 4; }
+          mydinv = rcp_nr(dv);
+        }
+#pragma unroll
+        for (int e = 0; e < TC; e++) if (e <= depth) sm.R[lane][e] = Rr[e];
+        sm.xs[lane] = rhs;
+        sm.jt[lane] = mydinv;
+      }
+      if (j == 0) break;
+      WSYNC();
+      {
+        const int v = tbase + j;
+        const bool recv = isl && pos < 0 && depth < j && j < TL && !((dm >> (v & 63)) & 1);
+        const int vr = recv ? v : lane;
+        const T* Rv = sm.R[vr];
+        T rowv[TC];
+#pragma unroll
+        for (int e = 0; e < TC; e++) rowv[e] = Rv[e];
+        const T mult = Rv[(depth >= 0 && depth < TC) ? depth : 0];
+        const T l = mult * sm.jt[vr];
+        const T bv = sm.xs[vr];
+#pragma unroll
+        for (int e = 0; e < TC; e++) if (recv && e <= depth) Rr[e] -= l * rowv[e];
+        if (recv) rhs -= l * bv;
+      }
+    }
+    WSYNC();
+    PROF(21);
+    // ---- dense block on the dirty rows (Schur complement + cross-contact terms)
+    if (dm) {
+      const int nD = __popcll(dm);
+      auto cidx = [&](int l) -> int { return __popcll(dm & lanemask_lt(l)); };
+      const int ci = cidx(lane);
+      // every (row, ancestor) element has exactly one owner lane: plain read-modify-write
+      if (dirty) {
+        if (isl) {
+#pragma unroll
+          for (int e = 0; e < MD; e++) if (e <= depth) sm.H[tri(ci, cidx(anc_at(tp, e)))] += Rr[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e <= MD; e++) {
+            if (e == mydiag) sm.H[tri(ci, ci)] += Rr[e];
+            else if (e <= sdepth) {
+              const int a_ = anc_of(salink, sdepth, sTL, sTB, e);
+              if ((dm >> a_) & 1) sm.H[tri(ci, cidx(a_))] += Rr[e];
+            }
+          }
+        }
+        // the rhs of compact row r is row nD of the packed block
+        sm.H[tri(nD, 0) + ci] = rhs;
+      }
+      WSYNC();
+      PROF(22);
+      const T xr = dense_factor_solve(sm.H, nD, lane, &warn);
+      WSYNC();
+      if (lane < nD) sm.vec[lane] = xr;
+      WSYNC();
+      if (dirty) sm.xs[lane] = sm.vec[ci];
+      WSYNC();
+    }
+    PROF(25);
+    // ---- back-substitution, root to leaves: x_v = (b_v - sum_{e < depth} H[v][anc_e] x[anc_e]) / d_v.
+    // After level d is published every deeper link subtracts its term with x[anc_d].
+    T s_ = rhs;
+#pragma unroll
+    for (int d = 0; d < MD; d++) {
+      if (isl && depth == d && !dirty) sm.xs[lane] = s_ * mydinv;
+      WSYNC();
+      const T xa = sm.xs[(isl && depth > d) ? anc_at(tp, d) : lane];
+      if (isl && depth > d) s_ -= Rr[d] * xa;
+    }
+    T x = isl ? sm.xs[lane] : (T)0;
+    if (isslot) {
+      x = sm.xs[lane];
+      if (!dirty) {
+        x = rhs / Dslot;
+#pragma unroll
+        for (int e = 0; e < MD; e++)
+          if (e <= sdepth) x -= sm.R[lane][e] * sm.xs[anc_of(salink, sdepth, sTL, sTB, e)];
+      }
+    }
+    WSYNC();
+    return x;
+  };
+
+  // ---- qacc_smooth = M^-1 qfrc_smooth (M is always tree-sparse)
+  {
+    T Rr[MD + 1];
+    load_Mr(Rr);
+    qs[0] = tree_solve(Rr, qfs[0], 0, 0ull);
+  }
+  PROF(2);
+
+
+  // ---- constraint solve [MJ: mj_solNewton]
+  // State of the iteration, per lane (dof slots: my hand dof, my key, my key + 64):
+  //   dq = qacc - qacc_smooth,  r0 = (M qacc - qfrc_smooth) of my hand dof (keys: r = kM dq),  qfc = J^T f,
+  //   jar = J qacc - aref for the rows I own.  qacc_smooth is parked in S.warm and qfrc_smooth in the
+  //   hand-over slots it came from until the Euler step needs them again.
+  const int nsys = nl + nkt;
+  const bool hascon = lane < ncon && con_D > 0;
+  const T scale = (T)1 / (M.meaninertia * (T)(nv > 1 ? nv : 1));
+  // rows owned by this lane: friction loss of my hand dof, one limit row per dof slot, four pyramidal
+  // rows of my contact
+  struct RowsL { T fr, lim[3], con[4]; };
+  T dq[3] = {0, 0, 0}, r0 = 0, qfc[3] = {0, 0, 0};
+  RowsL jar;
+  int act = 0;   // active-set bits: 0 friction row in its quadratic zone, 1..3 limit rows, 4..7 contact rows
+
+  // y = J x for the rows owned by this lane (x in per-lane slot registers)
+  auto mulJ = [&](const T* x, RowsL& out) {
+    sm.vec[lane] = x[0];
+#pragma unroll
+    for (int s = 0; s < 2; s++) { const int ks = myks(s); if (ks >= 0) sm.slotv[0][ks] = x[1 + s]; }
+    if (lane < ncon) { sm.cv[lane][0] = 0; sm.cv[lane][1] = 0; sm.cv[lane][2] = 0; }
+    WSYNC();
+    out.fr = x[0];
+#pragma unroll
+    for (int s = 0; s < 3; s++) out.lim[s] = (T)lim_sign(s) * x[s];
+    for (int e0 = 0; e0 < nent; e0 += 64) {
+      const int e = e0 + lane < nent ? e0 + lane : nent - 1;
+      const int m0 = sm.entM[e][0];
+      const int ln = m0 & 63, c = (m0 >> 6) & 31;
+      const T j0 = sm.entJ[e][0], j1 = sm.entJ[e][1], j2 = sm.entJ[e][2];
+      const T xl = sm.vec[ln];
+      const T xk = sm.slotv[0][ln >= nl ? ln - nl : 0];
+      const T xv = ln < nl ? xl : xk;
+      if (e0 + lane < nent) {
+        lds_add(&sm.cv[c][0], j0 * xv); lds_add(&sm.cv[c][1], j1 * xv); lds_add(&sm.cv[c][2], j2 * xv);
+      }
+    }
+    WSYNC();
+    T vc[3] = {0, 0, 0};
+    if (lane < ncon) { vc[0] = sm.cv[lane][0]; vc[1] = sm.cv[lane][1]; vc[2] = sm.cv[lane][2]; }
+    const T vn = vc[0], v1 = con_mu * vc[1], v2 = con_mu * vc[2];
+    out.con[0] = vn + v1; out.con[1] = vn - v1; out.con[2] = vn + v2; out.con[3] = vn - v2;
+    WSYNC();
+  };
+  // active set from jar; returns this lane's share of the constraint cost [MJ: mj_constraintUpdate]
+  auto update = [&](const RowsL& ja) -> T {
+    T cost = 0;
+    act = 0;
+    if (isl && lfloss > 0) {
+      const T x = ja.fr, rf = lflR * lfloss;
+      if (x <= -rf) cost += -(T)0.5 * rf * lfloss - lfloss * x;
+      else if (x >= rf) cost += -(T)0.5 * rf * lfloss + lfloss * x;
+      else { act |= 1; cost += (T)0.5 * lflD * x * x; }
+    }
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      if (lim_sign(s) != 0 && ja.lim[s] < 0) { act |= 2 << s; cost += (T)0.5 * lim_D[s] * ja.lim[s] * ja.lim[s]; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if (hascon && ja.con[r] < 0) { act |= 16 << r; cost += (T)0.5 * con_D * ja.con[r] * ja.con[r]; }
+    }
+    return cost;
+  };
+  // out = J^T f with the forces of the current active set: f = -D jar on active rows (friction rows in a
+  // linear zone: -+ floss)
+  auto mulJT = [&](const RowsL& ja, T* out) {
+    T ffr = 0;
+    if (isl && lfloss > 0) {
+      const T rf = lflR * lfloss;
+      ffr = ja.fr <= -rf ? lfloss : (ja.fr >= rf ? -lfloss : -lflD * ja.fr);
+    }
+    T fl[3], fc[4];
+#pragma unroll
+    for (int s = 0; s < 3; s++) fl[s] = ((act >> (1 + s)) & 1) ? -lim_D[s] * ja.lim[s] : (T)0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) fc[r] = ((act >> (4 + r)) & 1) ? -con_D * ja.con[r] : (T)0;
+    out[0] = ffr + (T)lim_sign(0) * fl[0];
+    out[1] = (T)lim_sign(1) * fl[1];
+    out[2] = (T)lim_sign(2) * fl[2];
+    if (lane < ncon) {
+      sm.cv[lane][0] = fc[0] + fc[1] + fc[2] + fc[3];
+      sm.cv[lane][1] = con_mu * (fc[0] - fc[1]);
+      sm.cv[lane][2] = con_mu * (fc[2] - fc[3]);
+    }
+    sm.jt[lane] = 0;
+    WSYNC();
+    for (int e0 = 0; e0 < nent; e0 += 64) {
+      const int e = e0 + lane < nent ? e0 + lane : nent - 1;
+      const int m0 = sm.entM[e][0];
+      const int ln = m0 & 63, c = (m0 >> 6) & 31;
+      const T v = sm.entJ[e][0] * sm.cv[c][0] + sm.entJ[e][1] * sm.cv[c][1] + sm.entJ[e][2] * sm.cv[c][2];
+      if (e0 + lane < nent) lds_add(&sm.jt[ln], v);
+    }
+    WSYNC();
+    if (isl) out[0] += sm.jt[lane];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const int ks = myks(s);
+      const T v = sm.jt[ks >= 0 ? nl + ks : 0];
+      if (ks >= 0) out[1 + s] += v;
+    }
+    WSYNC();
+  };
+  // Gauss term of the cost: (1/2) (M qacc - qfrc_smooth) . (qacc - qacc_smooth)
+  auto gauss = [&]() -> T { return (T)0.5 * (r0 * dq[0] + kM[0] * dq[1] * dq[1] + kM[1] * dq[2] * dq[2]); };
+  // (M x) of my hand dof with the tree-sparse rows: the row part from this lane's own row, the column part
+  // (descendants) scattered by the descendants with LDS adds.  Keys: M is diagonal (kM).
+  auto mulM0 = [&](T x0) -> T {
+    T Mr[MD + 1];
+    load_Mr(Mr);
+    sm.vec[lane] = x0;
+    sm.xs[lane] = 0;
+    WSYNC();
+    T y = 0;
+    if (isl) {
+      const Topo tp = topo();
+#pragma unroll
+      for (int e = 0; e < MD; e++) {
+        if (e <= tp.depth) y += Mr[e] * sm.vec[anc_at(tp, e)];
+        if (e < tp.depth) lds_add(&sm.xs[anc_at(tp, e)], Mr[e] * x0);
+      }
+    }
+    WSYNC();
+    y += sm.xs[lane];
+    WSYNC();
+    return y;
+  };
+
+  int anyrow = (isl && lfloss > 0) || lim_sign(0) || lim_sign(1) || lim_sign(2) || hascon;
+  anyrow = __ballot(anyrow) != 0ull;
+  int niter_last = 0;
+  // park qfrc_smooth (the hand-over slots it was built from are dead) and qacc_smooth
+  LF(0) = qfs[0]; LF(3) = qfs[1]; LF(4) = qfs[2];
+  T qw[3];
+  qw[0] = isl ? S.warm[eo + ldof] : (T)0;
+#pragma unroll
+  for (int s = 0; s < 2; s++) qw[1 + s] = isk[s] ? S.warm[eo + kdof[s]] : (T)0;
+  if (isl) S.warm[eo + ldof] = qs[0];
+  if (!anyrow) {
+    jar.fr = 0;
+#pragma unroll
+    for (int s = 0; s < 3; s++) jar.lim[s] = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) jar.con[r] = 0;
+  } else {
+    // warmstart [MJ: warmstart()]: the cheaper of qacc_warmstart and qacc_smooth
+    T cost;
+    {
+      // reference accelerations of my rows
+      const T fr_aref = LF(7);
+      T lim_aref[3] = {0, 0, 0}, con_aref[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 3; k++) if (lim_sign(k) != 0) lim_aref[k] = LF(11 + k);
+      if (lane < ncon) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) con_aref[k] = LF(25 + k);
+      }
+      auto sub_aref = [&](RowsL& r) {
+        r.fr -= fr_aref;
+#pragma unroll
+        for (int s = 0; s < 3; s++) r.lim[s] -= lim_aref[s];
+#pragma unroll
+        for (int k = 0; k < 4; k++) r.con[k] -= con_aref[k];
+      };
+      RowsL jtmp;
+      mulJ(qs, jtmp); sub_aref(jtmp);
+      const T cost_smooth = uni(wave_sum(update(jtmp)));
+      const T Mw = mulM0(qw[0]);
+      mulJ(qw, jar); sub_aref(jar);
+      r0 = Mw - qfs[0];
+#pragma unroll
+      for (int s = 0; s < 3; s++) dq[s] = qw[s] - qs[s];
+      // (keys: kM qw - qfs = kM (qw - qs))
+      cost = uni(wave_sum(update(jar) + (T)0.5 * (r0 * dq[0] + (kM[0] * qw[1] - qfs[1]) * dq[1] + (kM[1] * qw[2] - qfs[2]) * dq[2])));
+      if (cost > cost_smooth) {
+#pragma unroll
+        for (int s = 0; s < 3; s++) dq[s] = 0;
+        r0 = 0;
+        jar = jtmp;
+        cost = uni(wave_sum(update(jar)));
+      }
+    }
+    mulJT(jar, qfc);
+    PROF(3);
+    const int maxit = S.max_newton;
+    for (int iter = 0; iter < maxit; iter++) {
+      // gradient of the cost: M qacc - qfrc_smooth - J^T f
+      const T grad[3] = {r0 - qfc[0], kM[0] * dq[1] - qfc[1], kM[1] * dq[2] - qfc[2]};
+      // ---- H = M + J^T D J on the coupled system (hand dofs + touched keys)
+      // key diagonals and gradients to the solver slots
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const int ks = myks(s);
+        if (ks >= 0) {
+          sm.slotv[0][ks] = kM[s] + (((act >> (2 + s)) & 1) ? lim_D[1 + s] : (T)0);
+          sm.slotv[1][ks] = grad[1 + s];
+        }
+      }
+      // per-contact weight in the contact frame: C = sum_r D_r w_r w_r^T with w = (1, +-mu, 0), (1, 0, +-mu)
+      if (lane < ncon) {
+        T Dr[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) Dr[r] = ((act >> (4 + r)) & 1) ? con_D : (T)0;
+        sm.cC[lane][0] = Dr[0] + Dr[1] + Dr[2] + Dr[3];
+        sm.cC[lane][1] = con_mu * (Dr[0] - Dr[1]);
+        sm.cC[lane][2] = con_mu * (Dr[2] - Dr[3]);
+        sm.cC[lane][3] = con_mu * con_mu * (Dr[0] + Dr[1]);
+        sm.cC[lane][4] = con_mu * con_mu * (Dr[2] + Dr[3]);
+      }
+      const bool isslot = !isl && lane < nsys;
+      {
+        T Mr[MD + 1];
+        load_Mr(Mr);
+        const T mydiag_add = ((act & 1) ? lflD : (T)0) + (((act >> 1) & 1) ? lim_D[0] : (T)0);
+        if (isl) {
+          const int depth = topo().depth;
+#pragma unroll
+          for (int e = 0; e <= MD; e++) if (e <= depth) sm.R[lane][e] = Mr[e] + (e == depth ? mydiag_add : (T)0);
+        }
+      }
+      WSYNC();
+      T rhs = isl ? grad[0] : (T)0;
+      if (isslot) {
+        const T slotdiag = sm.slotv[0][lane - nl];
+        rhs = sm.slotv[1][lane - nl];
+        const int sdepth = slot_info().sdepth;
+#pragma unroll
+        for (int e = 0; e <= MD; e++) if (e <= sdepth + 1) sm.R[lane][e] = e == sdepth + 1 ? slotdiag : (T)0;
+      }
+      // ... + J^T C J of every contact.  Entry lane a of contact c holds u = C_c J_a and walks the entries
+      // b <= a of its contact (dofs in lane order: b is an ancestor of a, or the same dof): single-chain
+      // contacts add u.J_b to row(a)[col(b)] of the tree rows, cross-chain contacts to the packed dense
+      // block of the dirty rows (zeroed here; tree_solve adds the Schur complement of the clean rows).
+      const unsigned long long dmx = dirty_mask;
+      if (dmx) {
+        const int nD = __popcll(dmx);
+        for (int i = lane; i < tri(nD + 1, 0); i += 64) sm.H[i] = 0;
+      }
+      auto cidx = [&](int l) -> int { return __popcll(dmx & lanemask_lt(l)); };
+      WSYNC();
+      for (int e0 = 0; e0 < nent; e0 += 64) {
+        const bool valid = e0 + lane < nent;
+        const int e = valid ? e0 + lane : nent - 1;
+        const int m0 = sm.entM[e][0], m1 = sm.entM[e][1];
+        const int ln = m0 & 63, c = (m0 >> 6) & 31;
+        const int base = m1 & 255, rank = (m1 >> 16) & 255;
+        const T ja0 = sm.entJ[e][0], ja1 = sm.entJ[e][1], ja2 = sm.entJ[e][2];
+        const T* C = sm.cC[c];
+        const T sn = C[0], a1 = C[1], a2 = C[2], b1 = C[3], b2 = C[4];
+        const T u0 = sn * ja0 + a1 * ja1 + a2 * ja2;
+        const T u1 = a1 * ja0 + b1 * ja1;
+        const T u2 = a2 * ja0 + b2 * ja2;
+        const bool cross = ((m0 >> 15) & 1) != 0;
+        const int cia = cross ? cidx(ln) : 0;
+        for (int k0 = 0; k0 < maxm; k0 += 4) {
+          int mb[4];
+          T val[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int b = base + k0 + u < nent ? base + k0 + u : nent - 1;
+            mb[u] = sm.entM[b][0];
+            val[u] = u0 * sm.entJ[b][0] + u1 * sm.entJ[b][1] + u2 * sm.entJ[b][2];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            if (valid && k0 + u <= rank) {
+              T* dst = cross ? &sm.H[tri(cia, cidx(mb[u] & 63))] : &sm.R[ln][(mb[u] >> 11) & 15];
+              lds_add(dst, val[u]);
+            }
+          }
+        }
+      }
+      WSYNC();
+      T x;
+      {
+        T Rr[MD + 1];
+#pragma unroll
+        for (int e = 0; e <= MD; e++) Rr[e] = sm.R[lane][e];
+        WSYNC();
+        PROF(4);
+        x = tree_solve(Rr, rhs, nkt, dmx);
+      }
+      T search[3];
+      search[0] = isl ? -x : (T)0;
+      if (isslot) sm.slotv[0][lane - nl] = -x;
+      WSYNC();
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const int ks = myks(s);
+        const T via_slot = sm.slotv[0][ks >= 0 ? ks : 0];
+        const T own = -grad[1 + s] / (kM[s] + (((act >> (2 + s)) & 1) ? lim_D[1 + s] : (T)0));
+        search[1 + s] = isk[s] ? (ks >= 0 ? via_slot : own) : (T)0;
+      }
+      WSYNC();
+      PROF(5);
+      const T snorm = uni(N::sqrt(wave_sum(search[0] * search[0] + search[1] * search[1] + search[2] * search[2])));
+      if (!(snorm >= RPK_MINVAL)) break;
+      // phi'(0) = grad . search (before grad goes out of use)
+      const T f0g = uni(wave_sum(grad[0] * search[0] + grad[1] * search[1] + grad[2] * search[2]));
+      const T Mv0 = mulM0(search[0]);
+      RowsL jv;
+      mulJ(search, jv);
+      T g0, g1, g2;
+      {
+        const T rk1 = kM[0] * dq[1], rk2 = kM[1] * dq[2];
+        g0 = uni((T)0.5 * wave_sum(r0 * dq[0] + rk1 * dq[1] + rk2 * dq[2]));
+        g1 = uni(wave_sum(search[0] * r0 + search[1] * rk1 + search[2] * rk2));
+        g2 = uni((T)0.5 * wave_sum(search[0] * Mv0 + search[1] * (kM[0] * search[1]) + search[2] * (kM[1] * search[2])));
+      }
+      PROF(6);
+      // ---- exact line search [MJ: PrimalSearch].  Along the search direction every row's cost is a
+      // quadratic in alpha while the row stays in one zone, q0 + alpha q1 + alpha^2 q2 with
+      // q = D (jar^2 / 2, jar jv, jv^2 / 2) [MJ: PrimalPrepare]; an evaluation tests each row's zone at
+      // alpha and sums the coefficients of the active rows [MJ: PrimalEval] -- formed where they are used.
+      const T frf = (isl && lfloss > 0) ? lflR * lfloss : (T)-1;
+      const bool any_con = ncon > 0;
+      auto ls_eval = [&](T alpha, T& d1, T& d2, const bool with_cost) -> T {
+        T s0 = 0, s1 = 0, s2 = 0;
+        {
+          const T xx = jar.fr + alpha * jv.fr;
+          const bool lo_ = xx <= -frf, hi_ = xx >= frf;
+          const T ql0 = -(T)0.5 * frf * lfloss, ql1 = lfloss * jar.fr, frs = lfloss * jv.fr;
+          s0 = lo_ ? ql0 - ql1 : (hi_ ? ql0 + ql1 : (T)0.5 * lflD * jar.fr * jar.fr);
+          s1 = lo_ ? -frs : (hi_ ? frs : lflD * jar.fr * jv.fr);
+          s2 = (lo_ || hi_) ? (T)0 : (T)0.5 * lflD * jv.fr * jv.fr;
+          if (frf < 0) { s0 = 0; s1 = 0; s2 = 0; }
+        }
+#pragma unroll
+        for (int s = 0; s < 3; s++) {
+          const T xx = jar.lim[s] + alpha * jv.lim[s];
+          const T Dp = lim_D[s];   // (0 without a limit row)
+          if (xx < 0) {
+            s0 += (T)0.5 * Dp * jar.lim[s] * jar.lim[s]; s1 += Dp * jar.lim[s] * jv.lim[s];
+            s2 += (T)0.5 * Dp * jv.lim[s] * jv.lim[s];
+          }
+        }
+        if (any_con) {
+          const T Dp = hascon ? con_D : (T)0;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const T xx = jar.con[r] + alpha * jv.con[r];
+            if (xx < 0) {
+              s0 += (T)0.5 * Dp * jar.con[r] * jar.con[r]; s1 += Dp * jar.con[r] * jv.con[r];
+              s2 += (T)0.5 * Dp * jv.con[r] * jv.con[r];
+            }
+          }
+        }
+        s1 = wave_sum(s1) + g1; s2 = wave_sum(s2) + g2;
+        d1 = uni(s1 + (T)2 * alpha * s2);
+        d2 = uni((T)2 * s2);
+        if (!with_cost) return (T)0;
+        s0 = wave_sum(s0) + g0;
+        return uni(s0 + alpha * (s1 + alpha * s2));
+      };
+      const T gtol = uni(M.tolerance * M.ls_tolerance * snorm / scale);
+      // phi(0) is the current cost, phi'(0) = grad . search, phi''(0) = -phi'(0) (H search = -grad)
+      T f0, h0, c0;
+      if constexpr (sizeof(T) == 8) {
+        f0 = f0g; h0 = -f0; c0 = cost;
+      } else {
+        c0 = ls_eval((T)0, f0, h0, true);
+      }
+      struct LsPnt { T a, c, d0, d1; };
+      auto ls_point = [&](T al, const bool with_cost) -> LsPnt {
+        LsPnt p; p.a = uni(al); p.c = ls_eval(p.a, p.d0, p.d1, with_cost); return p;
+      };
+      T alpha = 0;
+      if (h0 > 0) {
+        const int max_ls = S.max_ls;
+        int evals = 2;
+        const LsPnt p0 = {(T)0, c0, f0, h0};
+        LsPnt p1 = ls_point(-f0 / h0, true);
+        if (p0.c < p1.c) p1 = p0;
+        alpha = p1.a;
+#ifndef RPK_X_LS1   // compile-only experiment: the line search cut down to its first Newton point
+        if (!(N::abs(p1.d0) < gtol)) {
+          const T dir = p1.d0 < 0 ? (T)1 : (T)-1;
+          LsPnt p2 = p1;
+          bool p2update = false, converged = false;
+          while (p1.d0 * dir <= -gtol && evals < max_ls) {
+            p2 = p1; p2update = true;
+            p1 = ls_point(p1.a - p1.d0 / p1.d1, false); evals++;
+            if (N::abs(p1.d0) < gtol) { converged = true; break; }
+          }
+          alpha = p1.a;
+          if (!converged && evals < max_ls && p2update) {
+            // bracketed search: per round the midpoint and the Newton successors of both bracket ends are the
+            // candidates; the cheapest one with |phi'| < gtol wins, otherwise each end moves to the candidate on
+            // its side of the root whose slope is closest to zero [MJ: updateBracket].  (Both ends choose among
+            // the round's candidates first and their successors are evaluated afterwards, in the same order as
+            // the sequential procedure: no copies of the candidates are held.)
+            LsPnt p2next = p1;
+            LsPnt p1next = ls_point(p1.a - p1.d0 / p1.d1, true); evals++;
+            auto choose = [&](LsPnt& p, const LsPnt& ca, const LsPnt& cb, const LsPnt& cc) -> bool {
+              bool moved = false;
+              T a_ = p.a, d0_ = p.d0, d1_ = p.d1;
+              auto consider = [&](const LsPnt& c) {
+                if ((d0_ < 0 && c.d0 < 0 && d0_ < c.d0) || (d0_ > 0 && c.d0 > 0 && d0_ > c.d0)) { a_ = c.a; d0_ = c.d0; d1_ = c.d1; moved = true; }
+              };
+              consider(ca); consider(cb); consider(cc);
+              p.a = a_; p.d0 = d0_; p.d1 = d1_;
+              return moved;
+            };
+            bool settled = false;
+            while (evals < max_ls) {
+              const LsPnt pmid = ls_point((T)0.5 * (p1.a + p2.a), true); evals++;
+              T bestc = 0; bool found = false;
+              if (N::abs(p1next.d0) < gtol) { found = true; bestc = p1next.c; alpha = p1next.a; }
+              if (N::abs(p2next.d0) < gtol && (!found || p2next.c < bestc)) { found = true; bestc = p2next.c; alpha = p2next.a; }
+              if (N::abs(pmid.d0) < gtol && (!found || pmid.c < bestc)) { found = true; alpha = pmid.a; }
+              if (found) { settled = true; break; }
+              const bool b1 = choose(p1, p1next, p2next, pmid);
+              const bool b2 = choose(p2, p1next, p2next, pmid);
+              if (b1) { p1next = ls_point(p1.a - p1.d0 / p1.d1, true); evals++; }
+              if (b2) { p2next = ls_point(p2.a - p2.d0 / p2.d1, true); evals++; }
+              if (!b1 && !b2) { alpha = pmid.a; settled = true; break; }
+            }
+            if (!settled) {
+              T t1, t2;
+              const T c1 = ls_eval(p1.a, t1, t2, true), c2 = ls_eval(p2.a, t1, t2, true);
+              alpha = (c1 <= c2 && c1 < p0.c) ? p1.a : ((c2 <= c1 && c2 < p0.c) ? p2.a : (T)0);
+            }
+          }
+        }
+#endif
+      }
+      PROF(7);
+      if (!(alpha > 0)) break;
+#pragma unroll
+      for (int s = 0; s < 3; s++) dq[s] += alpha * search[s];
+      r0 += alpha * Mv0;
+      jar.fr += alpha * jv.fr;
+#pragma unroll
+      for (int s = 0; s < 3; s++) jar.lim[s] += alpha * jv.lim[s];
+#pragma unroll
+      for (int r = 0; r < 4; r++) jar.con[r] += alpha * jv.con[r];
+      const T oldcost = cost;
+      cost = uni(wave_sum(update(jar) + gauss()));
+      mulJT(jar, qfc);
+      niter_last = iter + 1;
+      T gn;
+      {
+        const T ga = r0 - qfc[0], gb = kM[0] * dq[1] - qfc[1], gc = kM[1] * dq[2] - qfc[2];
+        gn = uni(N::sqrt(wave_sum(ga * ga + gb * gb + gc * gc)));
+      }
+      PROF(8);
+      if (scale * (oldcost - cost) < M.tolerance || scale * gn < M.tolerance) break;
+    }
+  }
+  // forces of the pyramidal contact rows, for the acceleration-stage sensors (MODE 2)
+  if (S.con_force && lane < RPK_NC) {
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      S.con_force[((size_t)env * RPK_NC + lane) * 4 + r] =
+          (anyrow && lane < ncon && ((act >> (4 + r)) & 1)) ? -con_D * jar.con[r] : (T)0;
+  }
+  PROF(8);
+  // ---- Euler with implicit joint damping [MJ: mj_Euler, eulerdamp]; qfrc_smooth comes back from its parking slots
+  T qe[3];
+  {
+    const T f0_ = LF(0);
+    const T ldamp = isl ? M.link_damping()[L] : (T)0;
+    T Rr[MD + 1];
+    load_Mr(Rr);
+#pragma unroll
+    for (int e = 0; e <= MD; e++) Rr[e] += ((isl && e == topo().depth) ? h * ldamp : (T)0);
+    qe[0] = tree_solve(Rr, f0_ + qfc[0], 0, 0ull);
+  }
+  PROF(9);
+  // ---- new state (qpos / qvel are re-read here: nothing above needed them after the passive forces;
+  // S.warm holds qacc_smooth of my hand dof, the keys' is qfrc_smooth / kM)
+  if (isl) {
+    const int ld = fresh(M.lane_topo())[16 * L + 5];   // my dof
+    const T qd0 = S.qvel[eo + ld] + h * qe[0];
+    S.qvel[eo + ld] = qd0;
+    S.qpos[eo + ld] += h * qd0;
+    S.warm[eo + ld] += dq[0];
+  }
+#pragma unroll
+  for (int s = 0; s < 2; s++) if (isk[s]) {
+    const int K = kid[s];
+    const int kd = M.key_dof()[K];
+    const T fk = s == 0 ? LF(3) : LF(4);
+    const T qek = (fk + qfc[1 + s]) / (kM[s] + h * M.key_damping()[K]);
+    const T qdk = S.qvel[eo + kd] + h * qek;
+    S.qvel[eo + kd] = qdk;
+    S.qpos[eo + kd] += h * qdk;
+    S.warm[eo + kd] = fk / kM[s] + dq[1 + s];
+  }
+  {
+    int w = wave_or(warn);
+    if (lane == 0) {
+      if (w) S.warn[env] |= w;
+      S.solver_iter[env] = (niter_last & 255) | ((__popcll(dirty_mask) & 255) << 8) | ((nkt & 255) << 16);
+      S.time[env] += h;
+    }
+  }
+  if (S.prof && env == 0 && lane < RPK_NPROF) {
+    WSYNC();
+    atomicAdd((unsigned long long*)&S.prof[lane], (unsigned long long)sm.prof[lane]);
+  }
+  if (S.cost_sol && lane == 0) S.cost_sol[env] = (int)(((long long)__builtin_readcyclecounter() - kernel_t0) >> 8);
+#undef LF
+#undef LI
+}

@@ -91,6 +91,16 @@ template <typename T> __device__ __forceinline__ void lds_add(T* p, T v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// A wave-uniform floating-point value, moved to scalar registers: the compiler then keeps it (and, under
+// pressure, spills it to a LANE of a vector register) instead of occupying a full vector register pair.
+__device__ __forceinline__ float uni(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ double uni(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) {
   return (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 }

@@ -37,7 +37,7 @@ WARN_DENSE_FULL = 32
 
 EXPORTED_SYMBOLS = (
     "rp_create", "rp_destroy", "rp_reset", "rp_set", "rp_get", "rp_step", "rp_forward",
-    "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_set_lazy_position_stage", "rp_set_cost_ordered_launch", "rp_set_stream_slices", "rp_set_acc_sensors", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
+    "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_set_lazy_position_stage", "rp_set_cost_ordered_launch", "rp_set_stream_slices", "rp_set_lean_solver", "rp_set_acc_sensors", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
     "rp_n_envs", "rp_dim",
     "rp_kernel_time", "rp_solver_kernel_time", "rp_solver_kernel_envs", "rp_profile", "rp_last_error",
 )
@@ -85,6 +85,7 @@ def load_library(path: str = LIB_PATH):
     L.rp_set_cost_ordered_launch.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.rp_set_acc_sensors.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.rp_set_stream_slices.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.rp_set_lean_solver.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.rp_get_stream.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
     L.rp_n_envs.argtypes = [ctypes.c_void_p]
     L.rp_dim.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
@@ -189,7 +190,9 @@ class BatchedPhysics:
         self._check(self._L.rp_set_stream(self._h, ctypes.c_void_p(hip_stream)))
 
     def view(self, f):
-        """Zero-copy torch tensor aliasing the engine's array for field `f`."""
+        """Zero-copy torch tensor aliasing the engine's array for field `f`.  Reads / writes through the view run
+        on torch's current stream: either make the engine step on that stream (`set_stream`, what
+        `suite.physics.TorchPhysics` does) or order them yourself (`sync()` / `torch.cuda.synchronize()`)."""
         import torch
         p = ctypes.c_void_p(); nb = ctypes.c_size_t()
         self._check(self._L.rp_field_ptr(self._h, f, ctypes.byref(p), ctypes.byref(nb)))
@@ -256,6 +259,10 @@ class BatchedPhysics:
     def set_stream_slices(self, n: int = 0):
         """rp_step steps the batch as `n` (1 or 2; 0 = the engine picks) kernel chains (include/rp_engine.h)."""
         self._check(self._L.rp_set_stream_slices(self._h, int(n)))
+
+    def set_lean_solver(self, on: bool = True):
+        """Capacity classes of the solver stage (include/rp_engine.h: rp_set_lean_solver)."""
+        self._check(self._L.rp_set_lean_solver(self._h, int(bool(on))))
 
     def set_cost_ordered_launch(self, on: bool = True):
         """Stage kernels process the envs heaviest-first (include/rp_engine.h); bit-identical results."""

@@ -402,11 +402,13 @@ def test_stream_slices_and_cost_order_are_bit_identical(two_hand_scene):
             p.set(engine.CTRL, c)
             if mask is not None:
                 p.reset(mask)
+            # (writes through a view run on torch's stream, the engine steps on its own: order them -- an env
+            # whose mask flips while a step is in flight would be stepped by some of the step's kernels only)
             if t == 12:
                 act = np.ones(E, np.int32); act[5::11] = 0
-                p.view(engine.ACTIVE).copy_(torch_i32(act))
+                p.sync(); p.view(engine.ACTIVE).copy_(torch_i32(act)); torch_sync()
             if t == 13:
-                p.view(engine.ACTIVE).fill_(1)
+                p.sync(); p.view(engine.ACTIVE).fill_(1); torch_sync()
             p.step(10)
         for p in modes:
             assert np.array_equal(ref.qpos, p.qpos) and np.array_equal(ref.qvel, p.qvel), t
@@ -414,6 +416,11 @@ def test_stream_slices_and_cost_order_are_bit_identical(two_hand_scene):
             assert np.array_equal(ref.get(engine.SENSOR_TORQUE), p.get(engine.SENSOR_TORQUE))
             assert np.array_equal(ref.get(engine.SENSOR_TOUCH), p.get(engine.SENSOR_TOUCH))
     assert ref.get(engine.NCON).max() > 0
+
+
+def torch_sync():
+    import torch
+    torch.cuda.synchronize()
 
 
 def torch_i32(x):
