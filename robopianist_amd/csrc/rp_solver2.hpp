@@ -134,6 +134,7 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
   const int nent = B.hdr[env * 8 + 4], maxm = B.hdr[env * 8 + 5];
   // my mass-matrix row over my ancestors (diag at [depth]); re-read from the (L2-resident) hand-over where it
   // is used instead of holding 20 registers through the Newton loop
+  auto Mrow = [&]() -> const T* { return fresh(B.RM) + ((size_t)env * RPK_NLX(MD) + L) * (MD + 1); };
   auto load_Mr = [&](T* Mr) {
     const T* row = fresh(B.RM) + ((size_t)env * RPK_NLX(MD) + L) * (MD + 1);
 #pragma unroll
@@ -261,9 +262,9 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
   // contacts: an ancestor-closed set) receive the Schur complement and are solved by the dense block
   // (sm.H already holds the cross-contact terms).  Back-substitution runs root to leaves, one level at a
   // time.  Returns x for this lane's row.
-  auto tree_solve = [&](T* Rr, T rhs, int nslots, unsigned long long dm) -> T {
-    // (the lane predicates below -- depth == d, pos == j, e <= depth: some fifty 64-bit masks -- are formed
-    // here, from an opaque copy of the packed topology, so that the compiler does not hoist them out of the
+  auto tree_solve = [&](const T* rowsrc, const bool add_diag, const T diag_add, T rhs, int nslots, unsigned long long dm) -> T {
+    // (the lane predicates below -- pos == j, depth == j, ...: some fifty 64-bit masks -- are formed here,
+    // from an opaque copy of the packed topology, so that the compiler does not hoist them out of the
     // Newton loop and then spill them: v_cmp is cheaper than a spilled SGPR pair)
     const Topo tp = topo();
     const int depth = tp.depth, TL = tp.TL, tbase = tp.tbase, ltree = tp.ltree, clen = tp.clen;
@@ -271,12 +272,24 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
     const int sdepth = si.sdepth, salink = si.salink, sTL = si.sTL, sTB = si.sTB;
     const int foldmask = kpk >> 10;
     const int pos = isl ? depth - TL : -2;          // chain position (trunk links: negative)
+    // Link lanes hold their row in a LOCAL column layout: columns 0 .. TC-1 = the trunk (the first TL of
+    // them exist), TC + p = the link at position p of my chain -- so the diagonal of "position j" is a
+    // compile-time register index for every trunk length.  Slot lanes keep the depth layout.
+    const int shift = (isl && pos >= 0) ? TL - TC : 0;
+    const int kd = pos >= 0 ? TC + pos : depth;     // my diagonal (link lanes)
+    T Rr[MD + 1];
+#pragma unroll
+    for (int k = 0; k <= MD; k++) Rr[k] = rowsrc[k < TC ? k : k + shift];
+    if (add_diag) {
+#pragma unroll
+      for (int k = 0; k < MD; k++) if (isl && k == kd) Rr[k] += diag_add;
+    }
 #ifdef RPK_X_NOTS   // compile-only experiment: register floor without the tree solve
     return rhs * Rr[0] + (T)(nslots + (int)dm);
 #endif
     const bool isslot = !isl && lane < nl + nslots;
     const bool dirty = (dm >> lane) & 1;
-    const int mydiag = isl ? depth : sdepth + 1;
+    const int mydiag = sdepth + 1;   // slot lanes
     T mydinv = 0;   // reciprocal pivot of my (clean) row
     if (lane < RPK_MAXTREE * 16) (&sm.trunk[0][0])[lane] = 0;
     // ---- key leaves (they hang under chain / trunk links): the slot lanes publish their scaled rows,
@@ -301,14 +314,14 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
       if (isl) {
         for (int sidx = 0; sidx < nslots; sidx++) {
           const T* Lk = sm.R[nl + sidx];
-          T lrow[MD + 1];
+          T lrow[MD];
 #pragma unroll
-          for (int e = 0; e <= MD; e++) lrow[e] = Lk[e];
+          for (int k = 0; k < MD; k++) lrow[k] = Lk[k < TC ? k : k + shift];
           const T lk = Lk[depth], dk = sm.jt[nl + sidx], xk = sm.xs[nl + sidx];
           if (((foldmask >> sidx) & 1) && !((dm >> (nl + sidx)) & 1)) {
             const T t = lk * dk;
 #pragma unroll
-            for (int e = 0; e <= MD; e++) if (e <= depth) Rr[e] -= t * lrow[e];
+            for (int k = 0; k < MD; k++) Rr[k] -= t * lrow[k];
             rhs -= lk * xk;
           }
         }
@@ -317,21 +330,21 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
     }
     PROF(20);
     // ---- chains: position j = 4 .. 0.  (a) the links at position j publish their final row, right-hand
-    // side and reciprocal pivot; (b) the links above them on the same chain (position jp < j) take the
-    // update  R[e] -= (H[v][me] / d_v) H[v][e]  from the row of v = lane + (j - jp).
+    // side (column MD of the record) and reciprocal pivot; (b) the links above them on the same chain
+    // (position jp < j) take the update  R[k] -= (H[v][me] / d_v) H[v][k]  from the row of v = lane + (j - jp).
+    // Whole records cross (one lane mask per step, wide LDS accesses): the columns a link does not own
+    // carry garbage in both directions and are never used.
 #pragma unroll
     for (int j = 4; j >= 0; j--) {
       if (isl && pos == j) {
-        T dv = (T)1;
-#pragma unroll
-        for (int e = 0; e <= MD; e++) if (e == depth) dv = Rr[e];
+        T dv = Rr[TC + j];
         if (!dirty) {
           if (!(dv >= RPK_MINVAL)) { dv = RPK_MINVAL; warn |= 4; }
           mydinv = rcp_nr(dv);
         }
 #pragma unroll
-        for (int e = 0; e < MD; e++) if (e <= depth) sm.R[lane][e] = Rr[e];
-        sm.xs[lane] = rhs;
+        for (int k = 0; k < MD; k++) sm.R[lane][k] = Rr[k];
+        sm.R[lane][MD] = rhs;
         sm.jt[lane] = mydinv;
       }
       if (j == 0) break;
@@ -339,18 +352,16 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
       {
         const int v = lane + (j - pos);
         const bool recv = isl && pos >= 0 && pos < j && j < clen && !((dm >> (v & 63)) & 1);
-        const int vr = recv ? v : lane;          // (unconditional loads from in-bounds addresses)
-        const T* Rv = sm.R[vr];
-        T rowv[MD];
+        if (recv) {
+          const T* Rv = sm.R[v];
+          T rowv[MD + 1];
 #pragma unroll
-        for (int e = 0; e < MD; e++) rowv[e] = Rv[e];
-        const T mult = Rv[depth >= 0 ? depth : 0];
-        const T l = mult * sm.jt[vr];
-        const T bv = sm.xs[vr];
-        // (other lanes read their own, partly unwritten row: the update is selected, not multiplied by zero)
+          for (int k = 0; k <= MD; k++) rowv[k] = Rv[k];
+          const T l = Rv[kd] * sm.jt[v];
 #pragma unroll
-        for (int e = 0; e < MD; e++) if (recv && e <= depth) Rr[e] -= l * rowv[e];
-        if (recv) rhs -= l * bv;
+          for (int k = 0; k < MD; k++) Rr[k] -= l * rowv[k];
+          rhs -= l * rowv[MD];
+        }
       }
     }
     // ---- what the eliminated chain links leave on their trunk: sum over v of H[v][t] H[v][t'] / d_v
@@ -378,16 +389,14 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
 #pragma unroll
     for (int j = TC - 1; j >= 0; j--) {
       if (isl && pos < 0 && depth == j) {
-        T dv = (T)1;
-#pragma unroll
-        for (int e = 0; e < TC; e++) if (e == depth) dv = Rr[e];
+        T dv = Rr[j];
         if (!dirty) {
           if (!(dv >= RPK_MINVAL)) { dv = RPK_MINVAL; warn |= 4; }
           mydinv = rcp_nr(dv);
         }
 #pragma unroll
-        for (int e = 0; e < TC; e++) if (e <= depth) sm.R[lane][e] = Rr[e];
-        sm.xs[lane] = rhs;
+        for (int k = 0; k < TC; k++) sm.R[lane][k] = Rr[k];
+        sm.R[lane][MD] = rhs;
         sm.jt[lane] = mydinv;
       }
       if (j == 0) break;
@@ -395,21 +404,23 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
       {
         const int v = tbase + j;
         const bool recv = isl && pos < 0 && depth < j && j < TL && !((dm >> (v & 63)) & 1);
-        const int vr = recv ? v : lane;
-        const T* Rv = sm.R[vr];
-        T rowv[TC];
+        if (recv) {
+          const T* Rv = sm.R[v];
+          T rowv[TC];
 #pragma unroll
-        for (int e = 0; e < TC; e++) rowv[e] = Rv[e];
-        const T mult = Rv[(depth >= 0 && depth < TC) ? depth : 0];
-        const T l = mult * sm.jt[vr];
-        const T bv = sm.xs[vr];
+          for (int k = 0; k < TC; k++) rowv[k] = Rv[k];
+          const T l = Rv[depth] * sm.jt[v];
 #pragma unroll
-        for (int e = 0; e < TC; e++) if (recv && e <= depth) Rr[e] -= l * rowv[e];
-        if (recv) rhs -= l * bv;
+          for (int k = 0; k < TC; k++) Rr[k] -= l * rowv[k];
+          rhs -= l * Rv[MD];
+        }
       }
     }
     WSYNC();
     PROF(21);
+    // local column k of a link lane: does it exist, and which lane is that ancestor
+    auto col_valid = [&](int k) -> bool { return k < TC ? (k < TL && k <= depth) : (pos >= 0 && k - TC <= pos); };
+    auto col_lane = [&](int k) -> int { return k < TC ? tbase + k : lane - (pos - (k - TC)); };
     // ---- dense block on the dirty rows (Schur complement + cross-contact terms)
     if (dm) {
       const int nD = __popcll(dm);
@@ -419,7 +430,7 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
       if (dirty) {
         if (isl) {
 #pragma unroll
-          for (int e = 0; e < MD; e++) if (e <= depth) sm.H[tri(ci, cidx(anc_at(tp, e)))] += Rr[e];
+          for (int k = 0; k < MD; k++) if (col_valid(k)) sm.H[tri(ci, cidx(col_lane(k)))] += Rr[k];
         } else {
 #pragma unroll
           for (int e = 0; e <= MD; e++) {
@@ -443,15 +454,17 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
       WSYNC();
     }
     PROF(25);
-    // ---- back-substitution, root to leaves: x_v = (b_v - sum_{e < depth} H[v][anc_e] x[anc_e]) / d_v.
-    // After level d is published every deeper link subtracts its term with x[anc_d].
+    // ---- back-substitution, root to leaves: x_v = (b_v - sum_{a above v} H[v][a] x[a]) / d_v.  One level
+    // per local column (trunk 0 .. TC-1, then chain positions): the links whose diagonal it is publish x,
+    // every link below subtracts its term.
     T s_ = rhs;
 #pragma unroll
-    for (int d = 0; d < MD; d++) {
-      if (isl && depth == d && !dirty) sm.xs[lane] = s_ * mydinv;
+    for (int k = 0; k < MD; k++) {
+      if (isl && kd == k && !dirty) sm.xs[lane] = s_ * mydinv;
       WSYNC();
-      const T xa = sm.xs[(isl && depth > d) ? anc_at(tp, d) : lane];
-      if (isl && depth > d) s_ -= Rr[d] * xa;
+      const bool below = isl && col_valid(k) && kd != k;
+      const T xa = sm.xs[below ? col_lane(k) : lane];
+      if (below) s_ -= Rr[k] * xa;
     }
     T x = isl ? sm.xs[lane] : (T)0;
     if (isslot) {
@@ -469,9 +482,7 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
 
   // ---- qacc_smooth = M^-1 qfrc_smooth (M is always tree-sparse)
   {
-    T Rr[MD + 1];
-    load_Mr(Rr);
-    qs[0] = tree_solve(Rr, qfs[0], 0, 0ull);
+    qs[0] = tree_solve(Mrow(), false, (T)0, qfs[0], 0, 0ull);
   }
   PROF(2);
 
@@ -750,15 +761,8 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
         }
       }
       WSYNC();
-      T x;
-      {
-        T Rr[MD + 1];
-#pragma unroll
-        for (int e = 0; e <= MD; e++) Rr[e] = sm.R[lane][e];
-        WSYNC();
-        PROF(4);
-        x = tree_solve(Rr, rhs, nkt, dmx);
-      }
+      PROF(4);
+      const T x = tree_solve(sm.R[lane], false, (T)0, rhs, nkt, dmx);
       T search[3];
       search[0] = isl ? -x : (T)0;
       if (isslot) sm.slotv[0][lane - nl] = -x;
@@ -939,11 +943,7 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
   {
     const T f0_ = LF(0);
     const T ldamp = isl ? M.link_damping()[L] : (T)0;
-    T Rr[MD + 1];
-    load_Mr(Rr);
-#pragma unroll
-    for (int e = 0; e <= MD; e++) Rr[e] += ((isl && e == topo().depth) ? h * ldamp : (T)0);
-    qe[0] = tree_solve(Rr, f0_ + qfc[0], 0, 0ull);
+    qe[0] = tree_solve(Mrow(), true, h * ldamp, f0_ + qfc[0], 0, 0ull);
   }
   PROF(9);
   // ---- new state (qpos / qvel are re-read here: nothing above needed them after the passive forces;
