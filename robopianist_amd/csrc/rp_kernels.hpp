@@ -1964,7 +1964,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
         if (lane == 0) {
           B.hdr[env * 8 + 4] = nent; B.hdr[env * 8 + 5] = maxm;
           // capacity class of this env's solve (rp_solver2.hpp): light = fits the lean solver stage
-          B.hdr[env * 8 + 6] = (S.lean && MD == RPK_MAXD && ncon <= LeanCaps::NC && nent <= LeanCaps::NE &&
+          B.hdr[env * 8 + 6] = (S.lean && MD == RPK_MAXD && M.ntree <= 2 && ncon <= LeanCaps::NC && nent <= LeanCaps::NE &&
                                 __popcll(dirty_mask) <= LeanCaps::HMAX && nkt <= LeanCaps::NK && nl + nkt <= 64) ? 1 : 0;
         }
       }

@@ -43,13 +43,17 @@ struct SmemLean {
   T H[(LeanCaps::HMAX + 1) * (LeanCaps::HMAX + 2) / 2];   // packed dense block + rhs row
   T entJ[LeanCaps::NE][3];       // contact-frame Jacobian entries (normal, tangent 1, tangent 2)
   int entM[LeanCaps::NE][2];
-  T cC[LeanCaps::NC][5];         // per-contact Hessian weight in the contact frame: sn, a1, a2, b1, b2
-  T cv[LeanCaps::NC][3];         // per-contact staging (J x, or the contact force), contact frame
+  union {
+    struct {
+      T cC[LeanCaps::NC][5];     // per-contact Hessian weight in the contact frame: sn, a1, a2, b1, b2
+      T cv[LeanCaps::NC][3];     // per-contact staging (J x, or the contact force), contact frame
+    };
+    T stage[2 * 5][16];          // tree solve / M x: per chain (tree * 5 + chain), what it leaves on its trunk
+  };
   T vec[RPK_WAVE];               // per-dof staging
   T xs[RPK_WAVE];                // solve staging: right-hand sides / solution
   T jt[RPK_WAVE];                // J^T f staging; pivots' reciprocals during a tree solve
   T slotv[2][16];                // values of the touched keys, by solver slot
-  T trunk[RPK_MAXTREE][16];      // what the eliminated chains leave on their tree's trunk (10 + 4 values)
   unsigned prof[RPK_NPROF];
 };
 }  // namespace rpk
@@ -86,6 +90,7 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
   // where they are used (v_bfe is one instruction; two dozen integers held through the Newton loop, and the
   // lane masks the compiler derives from them and hoists, are what pushed this stage into scratch):
   //   tpk: depth + 1 (0: not a link) | trunk length << 4 | trunk base lane << 7 | tree << 13 | links on my chain << 15
+  //        | my chain << 18 | chains of my tree (bit mask) << 21
   //   kpk: solver slot + 1 of my key (5 bits) | of my key + 64 << 5 | touched keys hanging under me << 10
   //   spk: slot lanes: anchor link | its trunk length << 8 | its trunk base << 12 | its depth + 1 << 18; limit row signs + 1 << 22
   int tpk, kpk, spk;
@@ -94,14 +99,16 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
     const int4* rec = (const int4*)(M.lane_topo() + 16 * L);
     const int4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
     ldof = isl ? r1.y : 0; lact = isl ? r2.z : -1;
-    tpk = isl ? ((r0.y + 1) | (r1.w << 4) | (r1.z << 7) | (r1.x << 13) | ((r2.w - r1.w) << 15)) : 0;
+    const int4 r3 = rec[3];
+    tpk = isl ? ((r0.y + 1) | (r1.w << 4) | (r1.z << 7) | (r1.x << 13) | ((r2.w - r1.w) << 15) | ((r3.x & 7) << 18) | ((r3.y & 31) << 21)) : 0;
   }
-  struct Topo { int depth, TL, tbase, ltree, clen; };
+  struct Topo { int depth, TL, tbase, ltree, clen, mychain, chainmask; };
   auto topo = [&]() -> Topo {
     int t = tpk;
     asm volatile("" : "+v"(t));
     Topo o;
     o.depth = (t & 15) - 1; o.TL = (t >> 4) & 7; o.tbase = (t >> 7) & 63; o.ltree = (t >> 13) & 3; o.clen = (t >> 15) & 7;
+    o.mychain = (t >> 18) & 7; o.chainmask = (t >> 21) & 31;
     return o;
   };
   // lane of my ancestor at depth e (lanes are in preorder: trunk chain, then the leaf chains)
@@ -291,7 +298,6 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
     const bool dirty = (dm >> lane) & 1;
     const int mydiag = sdepth + 1;   // slot lanes
     T mydinv = 0;   // reciprocal pivot of my (clean) row
-    if (lane < RPK_MAXTREE * 16) (&sm.trunk[0][0])[lane] = 0;
     // ---- key leaves (they hang under chain / trunk links): the slot lanes publish their scaled rows,
     // the link lanes on the anchor's path fold them in
     T Dslot = 1;
@@ -364,26 +370,53 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
         }
       }
     }
-    // ---- what the eliminated chain links leave on their trunk: sum over v of H[v][t] H[v][t'] / d_v
-    if (isl && pos >= 0 && !dirty) {
-      T* tt = sm.trunk[ltree];
+    // ---- what the eliminated chain links leave on their trunk: sum over v of H[v][t] H[v][t'] / d_v.  No LDS
+    // adds (22 lanes of a tree adding into one cell cost ~600 cycles per instruction: scratch/ub/ldsadd_ub.hip):
+    // the first link of every chain sums its chain's (<= 5) published records, the trunk links sum the chains.
+    if (isl && pos == 0) {
+      T acc[14];
 #pragma unroll
-      for (int t = 0; t < TC; t++) {
-        if (t < TL) {
-          const T lt = Rr[t] * mydinv;
+      for (int q = 0; q < 14; q++) acc[q] = 0;
 #pragma unroll
-          for (int t2 = 0; t2 <= t; t2++) lds_add(&tt[t * (t + 1) / 2 + t2], -(lt * Rr[t2]));
-          lds_add(&tt[10 + t], -(lt * rhs));
+      for (int p = 0; p < 5; p++) {
+        const int v = lane + p;
+        if (p < clen && !((dm >> (v & 63)) & 1)) {
+          const T* Rv = sm.R[v];
+          const T dv_ = sm.jt[v], bv = Rv[MD];
+          T rv[TC];
+#pragma unroll
+          for (int t = 0; t < TC; t++) rv[t] = Rv[t];
+#pragma unroll
+          for (int t = 0; t < TC; t++) {
+            if (t < TL) {
+              const T lt = rv[t] * dv_;
+#pragma unroll
+              for (int t2 = 0; t2 <= t; t2++) acc[t * (t + 1) / 2 + t2] -= lt * rv[t2];
+              acc[10 + t] -= lt * bv;
+            }
+          }
         }
       }
+      T* st = sm.stage[(ltree & 1) * 5 + tp.mychain];
+#pragma unroll
+      for (int q = 0; q < 14; q++) st[q] = acc[q];
     }
     WSYNC();
     if (isl && pos < 0) {
-      const T* tt = sm.trunk[ltree];
       const int tro = depth * (depth + 1) / 2;
 #pragma unroll
-      for (int e = 0; e < TC; e++) { const T dv = tt[tro + e < 10 ? tro + e : 9]; if (e <= depth) Rr[e] += dv; }
-      rhs += tt[10 + depth];
+      for (int c = 0; c < 5; c++) {
+        const T* st = sm.stage[(ltree & 1) * 5 + c];
+        T dv[TC];
+#pragma unroll
+        for (int e = 0; e < TC; e++) dv[e] = st[tro + e < 10 ? tro + e : 9];
+        const T dr = st[10 + depth];
+        if ((tp.chainmask >> c) & 1) {
+#pragma unroll
+          for (int e = 0; e < TC; e++) if (e <= depth) Rr[e] += dv[e];
+          rhs += dr;
+        }
+      }
     }
     // ---- trunk: position j = 3 .. 0, the same way along the trunk chain
 #pragma unroll
@@ -598,20 +631,48 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
   auto mulM0 = [&](T x0) -> T {
     T Mr[MD + 1];
     load_Mr(Mr);
+    const Topo tp = topo();
+    const int pos = isl ? tp.depth - tp.TL : -2;
+    // every link publishes its products M[me][a] x_me (a = my ancestors; sm.R is free outside the factorisation)
     sm.vec[lane] = x0;
-    sm.xs[lane] = 0;
+#pragma unroll
+    for (int e = 0; e < MD; e++) sm.R[lane][e] = Mr[e] * x0;
     WSYNC();
     T y = 0;
     if (isl) {
-      const Topo tp = topo();
 #pragma unroll
-      for (int e = 0; e < MD; e++) {
-        if (e <= tp.depth) y += Mr[e] * sm.vec[anc_at(tp, e)];
-        if (e < tp.depth) lds_add(&sm.xs[anc_at(tp, e)], Mr[e] * x0);
+      for (int e = 0; e < MD; e++) if (e <= tp.depth) y += Mr[e] * sm.vec[anc_at(tp, e)];
+      // column part, in-chain: the links below me on my chain
+      if (pos >= 0) {
+#pragma unroll
+        for (int q = 1; q < 5; q++) if (pos + q < tp.clen) y += sm.R[lane + q][tp.depth];
+      }
+      // the first link of every chain sums what its chain sends to the trunk
+      if (pos == 0) {
+        T acc[TC] = {0, 0, 0, 0};
+#pragma unroll
+        for (int p = 0; p < 5; p++) {
+          if (p < tp.clen) {
+#pragma unroll
+            for (int t = 0; t < TC; t++) acc[t] += sm.R[lane + p][t];
+          }
+        }
+        T* st = sm.stage[(tp.ltree & 1) * 5 + tp.mychain];
+#pragma unroll
+        for (int t = 0; t < TC; t++) st[t] = acc[t];
       }
     }
     WSYNC();
-    y += sm.xs[lane];
+    if (isl && pos < 0) {
+      // trunk links: the chains' sums and the trunk links below me
+#pragma unroll
+      for (int c = 0; c < 5; c++) {
+        const T v = sm.stage[(tp.ltree & 1) * 5 + c][tp.depth];
+        if ((tp.chainmask >> c) & 1) y += v;
+      }
+#pragma unroll
+      for (int q = 1; q < TC; q++) if (tp.depth + q < tp.TL) y += sm.R[lane + q][tp.depth];
+    }
     WSYNC();
     return y;
   };
