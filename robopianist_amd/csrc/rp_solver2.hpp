@@ -54,6 +54,8 @@ struct SmemLean {
   T xs[RPK_WAVE];                // solve staging: right-hand sides / solution
   T jt[RPK_WAVE];                // J^T f staging; pivots' reciprocals during a tree solve
   T slotv[2][16];                // values of the touched keys, by solver slot
+  unsigned long long csup[LeanCaps::NC];   // per contact: the lanes (links, solver slot) of its Jacobian entries
+  int cinf[LeanCaps::NC];        // per contact: first entry | entries << 8 | cross-chain << 16
   unsigned prof[RPK_NPROF];
 };
 }  // namespace rpk
@@ -142,6 +144,17 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
   // my mass-matrix row over my ancestors (diag at [depth]); re-read from the (L2-resident) hand-over where it
   // is used instead of holding 20 registers through the Newton loop
   auto Mrow = [&]() -> const T* { return fresh(B.RM) + ((size_t)env * RPK_NLX(MD) + L) * (MD + 1); };
+  // ... in the local column layout of the tree solve (see there), plus `add` on my diagonal
+  auto load_Mlocal = [&](T* Rl, const T add) {
+    const Topo tp = topo();
+    const int pos = isl ? tp.depth - tp.TL : -2;
+    const int shift = (isl && pos >= 0) ? tp.TL - TC : 0, kd = pos >= 0 ? TC + pos : tp.depth;
+    const T* row = Mrow();
+#pragma unroll
+    for (int k = 0; k <= MD; k++) Rl[k] = isl ? row[k < TC ? k : k + shift] : (T)0;
+#pragma unroll
+    for (int k = 0; k < MD; k++) if (isl && k == kd) Rl[k] += add;
+  };
   auto load_Mr = [&](T* Mr) {
     const T* row = fresh(B.RM) + ((size_t)env * RPK_NLX(MD) + L) * (MD + 1);
 #pragma unroll
@@ -157,8 +170,20 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
 #pragma unroll
   for (int k = 0; k < 3; k++) if (lim_sign(k) != 0) lim_D[k] = LF(8 + k);
   T con_D = 0, con_mu = 0;
+  int cinfo = 0;   // my contact: first entry | entries << 8 | cross-chain << 16
   if (lane < ncon) {
     con_D = LF(14); con_mu = LF(15);
+    {
+      const int bc = LI(10);
+      cinfo = (bc & 0xffff) | ((LI(4) & 1) << 16);
+      unsigned long long sup = 0;
+      if ((bc >> 8) & 255) {   // (a contact dropped for capacity keeps no entries)
+        sup = (((unsigned long long)(unsigned)LI(6) << 32) | (unsigned)LI(5)) | (((unsigned long long)(unsigned)LI(8) << 32) | (unsigned)LI(7));
+        const int slot = LI(3);
+        if (slot >= 0) sup |= 1ull << (nl + slot);
+      }
+      sm.csup[lane] = sup; sm.cinf[lane] = cinfo;
+    }
     // contact frame -> LDS (rows of sm.R are free until the first assembly), only to rotate the entries
 #pragma unroll
     for (int k = 0; k < 9; k++) sm.R[lane][k] = LF(16 + k);
@@ -269,7 +294,7 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
   // contacts: an ancestor-closed set) receive the Schur complement and are solved by the dense block
   // (sm.H already holds the cross-contact terms).  Back-substitution runs root to leaves, one level at a
   // time.  Returns x for this lane's row.
-  auto tree_solve = [&](const T* rowsrc, const bool add_diag, const T diag_add, T rhs, int nslots, unsigned long long dm) -> T {
+  auto tree_solve = [&](T* Rr, const T sdiag, T rhs, int nslots, unsigned long long dm) -> T {
     // (the lane predicates below -- pos == j, depth == j, ...: some fifty 64-bit masks -- are formed here,
     // from an opaque copy of the packed topology, so that the compiler does not hoist them out of the
     // Newton loop and then spill them: v_cmp is cheaper than a spilled SGPR pair)
@@ -282,37 +307,28 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
     // Link lanes hold their row in a LOCAL column layout: columns 0 .. TC-1 = the trunk (the first TL of
     // them exist), TC + p = the link at position p of my chain -- so the diagonal of "position j" is a
     // compile-time register index for every trunk length.  Slot lanes keep the depth layout.
+    // (slot lanes: Rr[e], e <= sdepth = my row over the anchor link's path, `sdiag` my diagonal)
     const int shift = (isl && pos >= 0) ? TL - TC : 0;
     const int kd = pos >= 0 ? TC + pos : depth;     // my diagonal (link lanes)
-    T Rr[MD + 1];
-#pragma unroll
-    for (int k = 0; k <= MD; k++) Rr[k] = rowsrc[k < TC ? k : k + shift];
-    if (add_diag) {
-#pragma unroll
-      for (int k = 0; k < MD; k++) if (isl && k == kd) Rr[k] += diag_add;
-    }
 #ifdef RPK_X_NOTS   // compile-only experiment: register floor without the tree solve
     return rhs * Rr[0] + (T)(nslots + (int)dm);
 #endif
     const bool isslot = !isl && lane < nl + nslots;
     const bool dirty = (dm >> lane) & 1;
-    const int mydiag = sdepth + 1;   // slot lanes
     T mydinv = 0;   // reciprocal pivot of my (clean) row
     // ---- key leaves (they hang under chain / trunk links): the slot lanes publish their scaled rows,
     // the link lanes on the anchor's path fold them in
     T Dslot = 1;
     if (nslots > 0) {
       if (isslot) {
-        T Dk = (T)1;
-#pragma unroll
-        for (int e = 0; e <= MD; e++) if (e == mydiag) Dk = Rr[e];
+        T Dk = sdiag;
         if (!dirty) {
           if (!(Dk >= RPK_MINVAL)) { Dk = RPK_MINVAL; warn |= 4; }
           Dslot = Dk;
         }
         const T inv = dirty ? (T)1 : rcp_nr(Dk);
 #pragma unroll
-        for (int e = 0; e <= MD; e++) if (e <= mydiag) sm.R[lane][e] = e < mydiag ? Rr[e] * inv : Rr[e];
+        for (int e = 0; e < MD; e++) sm.R[lane][e] = Rr[e] * inv;
         sm.jt[lane] = Dk;
         sm.xs[lane] = rhs;
       }
@@ -465,10 +481,10 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
 #pragma unroll
           for (int k = 0; k < MD; k++) if (col_valid(k)) sm.H[tri(ci, cidx(col_lane(k)))] += Rr[k];
         } else {
+          sm.H[tri(ci, ci)] += sdiag;
 #pragma unroll
-          for (int e = 0; e <= MD; e++) {
-            if (e == mydiag) sm.H[tri(ci, ci)] += Rr[e];
-            else if (e <= sdepth) {
+          for (int e = 0; e < MD; e++) {
+            if (e <= sdepth) {
               const int a_ = anc_of(salink, sdepth, sTL, sTB, e);
               if ((dm >> a_) & 1) sm.H[tri(ci, cidx(a_))] += Rr[e];
             }
@@ -515,7 +531,9 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
 
   // ---- qacc_smooth = M^-1 qfrc_smooth (M is always tree-sparse)
   {
-    qs[0] = tree_solve(Mrow(), false, (T)0, qfs[0], 0, 0ull);
+    T Rr[MD + 1];
+    load_Mlocal(Rr, (T)0);
+    qs[0] = tree_solve(Rr, (T)0, qfs[0], 0, 0ull);
   }
   PROF(2);
 
@@ -535,31 +553,34 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
   RowsL jar;
   int act = 0;   // active-set bits: 0 friction row in its quadratic zone, 1..3 limit rows, 4..7 contact rows
 
-  // y = J x for the rows owned by this lane (x in per-lane slot registers)
+  // y = J x for the rows owned by this lane (x in per-lane slot registers).  Every contact lane walks ITS
+  // entries (no LDS adds: ten lanes adding into one contact's cell cost ~400 cycles per instruction).
   auto mulJ = [&](const T* x, RowsL& out) {
     sm.vec[lane] = x[0];
 #pragma unroll
     for (int s = 0; s < 2; s++) { const int ks = myks(s); if (ks >= 0) sm.slotv[0][ks] = x[1 + s]; }
-    if (lane < ncon) { sm.cv[lane][0] = 0; sm.cv[lane][1] = 0; sm.cv[lane][2] = 0; }
     WSYNC();
     out.fr = x[0];
 #pragma unroll
     for (int s = 0; s < 3; s++) out.lim[s] = (T)lim_sign(s) * x[s];
-    for (int e0 = 0; e0 < nent; e0 += 64) {
-      const int e = e0 + lane < nent ? e0 + lane : nent - 1;
-      const int m0 = sm.entM[e][0];
-      const int ln = m0 & 63, c = (m0 >> 6) & 31;
-      const T j0 = sm.entJ[e][0], j1 = sm.entJ[e][1], j2 = sm.entJ[e][2];
-      const T xl = sm.vec[ln];
-      const T xk = sm.slotv[0][ln >= nl ? ln - nl : 0];
-      const T xv = ln < nl ? xl : xk;
-      if (e0 + lane < nent) {
-        lds_add(&sm.cv[c][0], j0 * xv); lds_add(&sm.cv[c][1], j1 * xv); lds_add(&sm.cv[c][2], j2 * xv);
+    T vc[3] = {0, 0, 0};
+    {
+      int ci_ = cinfo;
+      asm volatile("" : "+v"(ci_));
+      const int base = ci_ & 255, cnt = (ci_ >> 8) & 255;
+      for (int k0 = 0; k0 < maxm; k0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int e = base + k0 + u < nent ? base + k0 + u : nent - 1;
+          const int ln = sm.entM[e][0] & 63;
+          const T j0 = sm.entJ[e][0], j1 = sm.entJ[e][1], j2 = sm.entJ[e][2];
+          const T xl = sm.vec[ln];
+          const T xk = sm.slotv[0][ln >= nl ? ln - nl : 0];
+          const T xv = ln < nl ? xl : xk;
+          if (k0 + u < cnt) { vc[0] += j0 * xv; vc[1] += j1 * xv; vc[2] += j2 * xv; }
+        }
       }
     }
-    WSYNC();
-    T vc[3] = {0, 0, 0};
-    if (lane < ncon) { vc[0] = sm.cv[lane][0]; vc[1] = sm.cv[lane][1]; vc[2] = sm.cv[lane][2]; }
     const T vn = vc[0], v1 = con_mu * vc[1], v2 = con_mu * vc[2];
     out.con[0] = vn + v1; out.con[1] = vn - v1; out.con[2] = vn + v2; out.con[3] = vn - v2;
     WSYNC();
@@ -605,17 +626,19 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
       sm.cv[lane][1] = con_mu * (fc[0] - fc[1]);
       sm.cv[lane][2] = con_mu * (fc[2] - fc[3]);
     }
-    sm.jt[lane] = 0;
     WSYNC();
-    for (int e0 = 0; e0 < nent; e0 += 64) {
-      const int e = e0 + lane < nent ? e0 + lane : nent - 1;
-      const int m0 = sm.entM[e][0];
-      const int ln = m0 & 63, c = (m0 >> 6) & 31;
+    // every dof lane (link, solver slot) walks the contacts and takes its own entry of those that touch it
+    T acc = 0;
+    for (int c = 0; c < ncon; c++) {
+      const unsigned long long sup = sm.csup[c];
+      const int e_ = (sm.cinf[c] & 255) + __popcll(sup & lanemask_lt(lane));
+      const int e = e_ < nent ? e_ : (nent > 0 ? nent - 1 : 0);
       const T v = sm.entJ[e][0] * sm.cv[c][0] + sm.entJ[e][1] * sm.cv[c][1] + sm.entJ[e][2] * sm.cv[c][2];
-      if (e0 + lane < nent) lds_add(&sm.jt[ln], v);
+      if ((sup >> lane) & 1) acc += v;
     }
+    if (isl) out[0] += acc;
+    sm.jt[lane] = acc;
     WSYNC();
-    if (isl) out[0] += sm.jt[lane];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
       const int ks = myks(s);
@@ -759,71 +782,91 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
         sm.cC[lane][4] = con_mu * con_mu * (Dr[2] + Dr[3]);
       }
       const bool isslot = !isl && lane < nsys;
-      {
-        T Mr[MD + 1];
-        load_Mr(Mr);
-        const T mydiag_add = ((act & 1) ? lflD : (T)0) + (((act >> 1) & 1) ? lim_D[0] : (T)0);
-        if (isl) {
-          const int depth = topo().depth;
-#pragma unroll
-          for (int e = 0; e <= MD; e++) if (e <= depth) sm.R[lane][e] = Mr[e] + (e == depth ? mydiag_add : (T)0);
-        }
-      }
       WSYNC();
-      T rhs = isl ? grad[0] : (T)0;
-      if (isslot) {
-        const T slotdiag = sm.slotv[0][lane - nl];
-        rhs = sm.slotv[1][lane - nl];
-        const int sdepth = slot_info().sdepth;
-#pragma unroll
-        for (int e = 0; e <= MD; e++) if (e <= sdepth + 1) sm.R[lane][e] = e == sdepth + 1 ? slotdiag : (T)0;
-      }
-      // ... + J^T C J of every contact.  Entry lane a of contact c holds u = C_c J_a and walks the entries
-      // b <= a of its contact (dofs in lane order: b is an ancestor of a, or the same dof): single-chain
-      // contacts add u.J_b to row(a)[col(b)] of the tree rows, cross-chain contacts to the packed dense
-      // block of the dirty rows (zeroed here; tree_solve adds the Schur complement of the clean rows).
+      // rows of H in registers: links in the local column layout of the tree solve, solver slots over the
+      // path of their anchor link (+ `sdiag`)
+      T Rr[MD + 1];
+      T sdiag = 0, rhs = isl ? grad[0] : (T)0;
+      load_Mlocal(Rr, ((act & 1) ? lflD : (T)0) + (((act >> 1) & 1) ? lim_D[0] : (T)0));
+      if (isslot) { sdiag = sm.slotv[0][lane - nl]; rhs = sm.slotv[1][lane - nl]; }
       const unsigned long long dmx = dirty_mask;
       if (dmx) {
         const int nD = __popcll(dmx);
         for (int i = lane; i < tri(nD + 1, 0); i += 64) sm.H[i] = 0;
       }
-      auto cidx = [&](int l) -> int { return __popcll(dmx & lanemask_lt(l)); };
-      WSYNC();
-      for (int e0 = 0; e0 < nent; e0 += 64) {
-        const bool valid = e0 + lane < nent;
-        const int e = valid ? e0 + lane : nent - 1;
-        const int m0 = sm.entM[e][0], m1 = sm.entM[e][1];
-        const int ln = m0 & 63, c = (m0 >> 6) & 31;
-        const int base = m1 & 255, rank = (m1 >> 16) & 255;
-        const T ja0 = sm.entJ[e][0], ja1 = sm.entJ[e][1], ja2 = sm.entJ[e][2];
-        const T* C = sm.cC[c];
-        const T sn = C[0], a1 = C[1], a2 = C[2], b1 = C[3], b2 = C[4];
-        const T u0 = sn * ja0 + a1 * ja1 + a2 * ja2;
-        const T u1 = a1 * ja0 + b1 * ja1;
-        const T u2 = a2 * ja0 + b2 * ja2;
-        const bool cross = ((m0 >> 15) & 1) != 0;
-        const int cia = cross ? cidx(ln) : 0;
-        for (int k0 = 0; k0 < maxm; k0 += 4) {
-          int mb[4];
-          T val[4];
+      // ... + J^T C J of every single-chain contact, gathered by the ROW lanes: the entries of such a
+      // contact are the root path of its deepest link (entry e = the ancestor at depth e), then the key's
+      // slot.  Row lane r of the contact forms u = C_c J_r and adds u . J_a for every ancestor a (and
+      // itself): registers only, no LDS adds, fixed order.
+      {
+        const Topo tp = topo();
+        const int pos = isl ? tp.depth - tp.TL : -2;
+        const int shift = (isl && pos >= 0) ? tp.TL - TC : 0;
+        for (int c = 0; c < ncon; c++) {
+          const int inf = sm.cinf[c];
+          if ((inf >> 16) & 1) continue;   // cross-chain: below
+          const unsigned long long sup = sm.csup[c];
+          const int base = inf & 255, cnt = (inf >> 8) & 255;
+          const bool mem = (sup >> lane) & 1;
+          const int eo_ = base + (isl ? tp.depth : cnt - 1);
+          const int eo = (mem && eo_ < nent) ? eo_ : 0;
+          const T ja0 = sm.entJ[eo][0], ja1 = sm.entJ[eo][1], ja2 = sm.entJ[eo][2];
+          const T* C = sm.cC[c];
+          const T sn = C[0], a1 = C[1], a2 = C[2], b1 = C[3], b2 = C[4];
+          const T u0 = sn * ja0 + a1 * ja1 + a2 * ja2;
+          const T u1 = a1 * ja0 + b1 * ja1;
+          const T u2 = a2 * ja0 + b2 * ja2;
+          const int npath = cnt - 1;   // slot lanes: the links of this contact
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int b = base + k0 + u < nent ? base + k0 + u : nent - 1;
-            mb[u] = sm.entM[b][0];
-            val[u] = u0 * sm.entJ[b][0] + u1 * sm.entJ[b][1] + u2 * sm.entJ[b][2];
+          for (int k = 0; k < MD; k++) {
+            const int dk = k < TC ? k : k + shift;   // depth of local column k
+            const bool valid = mem && (isl ? (k < TC ? (k < tp.TL && k <= tp.depth) : (pos >= 0 && k - TC <= pos)) : k < npath);
+            const int eb = valid ? base + dk : 0;
+            const T v = u0 * sm.entJ[eb][0] + u1 * sm.entJ[eb][1] + u2 * sm.entJ[eb][2];
+            if (valid) Rr[k] += v;
           }
+          if (mem && !isl) sdiag += u0 * ja0 + u1 * ja1 + u2 * ja2;
+        }
+      }
+      // cross-chain contacts go to the packed dense block of the dirty rows (zeroed above; tree_solve adds the
+      // Schur complement of the clean rows): entry lane a holds u = C_c J_a and walks the entries b <= a
+      if (dmx) {
+        auto cidx = [&](int l) -> int { return __popcll(dmx & lanemask_lt(l)); };
+        WSYNC();
+        for (int e0 = 0; e0 < nent; e0 += 64) {
+          const bool valid = e0 + lane < nent;
+          const int e = valid ? e0 + lane : nent - 1;
+          const int m0 = sm.entM[e][0], m1 = sm.entM[e][1];
+          const int ln = m0 & 63, c = (m0 >> 6) & 31;
+          const int base = m1 & 255, rank = (m1 >> 16) & 255;
+          const bool cross = ((m0 >> 15) & 1) != 0;
+          if (__ballot(valid && cross) == 0ull) continue;
+          const T ja0 = sm.entJ[e][0], ja1 = sm.entJ[e][1], ja2 = sm.entJ[e][2];
+          const T* C = sm.cC[c];
+          const T sn = C[0], a1 = C[1], a2 = C[2], b1 = C[3], b2 = C[4];
+          const T u0 = sn * ja0 + a1 * ja1 + a2 * ja2;
+          const T u1 = a1 * ja0 + b1 * ja1;
+          const T u2 = a2 * ja0 + b2 * ja2;
+          const int cia = cross ? cidx(ln) : 0;
+          for (int k0 = 0; k0 < maxm; k0 += 4) {
+            int mb[4];
+            T val[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            if (valid && k0 + u <= rank) {
-              T* dst = cross ? &sm.H[tri(cia, cidx(mb[u] & 63))] : &sm.R[ln][(mb[u] >> 11) & 15];
-              lds_add(dst, val[u]);
+            for (int u = 0; u < 4; u++) {
+              const int b = base + k0 + u < nent ? base + k0 + u : nent - 1;
+              mb[u] = sm.entM[b][0];
+              val[u] = u0 * sm.entJ[b][0] + u1 * sm.entJ[b][1] + u2 * sm.entJ[b][2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              if (valid && cross && k0 + u <= rank) lds_add(&sm.H[tri(cia, cidx(mb[u] & 63))], val[u]);
             }
           }
         }
       }
       WSYNC();
       PROF(4);
-      const T x = tree_solve(sm.R[lane], false, (T)0, rhs, nkt, dmx);
+      const T x = tree_solve(Rr, sdiag, rhs, nkt, dmx);
       T search[3];
       search[0] = isl ? -x : (T)0;
       if (isslot) sm.slotv[0][lane - nl] = -x;
@@ -1004,7 +1047,9 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
   {
     const T f0_ = LF(0);
     const T ldamp = isl ? M.link_damping()[L] : (T)0;
-    qe[0] = tree_solve(Mrow(), true, h * ldamp, f0_ + qfc[0], 0, 0ull);
+    T Rr[MD + 1];
+    load_Mlocal(Rr, h * ldamp);
+    qe[0] = tree_solve(Rr, (T)0, f0_ + qfc[0], 0, 0ull);
   }
   PROF(9);
   // ---- new state (qpos / qvel are re-read here: nothing above needed them after the passive forces;
