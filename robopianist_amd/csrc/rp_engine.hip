@@ -29,7 +29,7 @@ __global__ void rp_mark_valid_kernel(unsigned char* valid, const int* active, in
 }
 
 // Launch order of the envs for the solver stage that follows a position stage: descending predicted
-// cost (counting sort on a small integer key), one workgroup of 1024 threads.  With one wave per env
+// cost (counting sort on a small integer key), one workgroup per residue class.  With one wave per env
 // and every SIMD running its envs one after the other, a heavy env that starts late is the tail of
 // the whole launch; the hardware dispatches workgroups in index order to whichever slot frees up, so
 // sorting the heaviest first is longest-processing-time-first list scheduling.
@@ -44,11 +44,13 @@ __global__ void rp_mark_valid_kernel(unsigned char* valid, const int* active, in
 //     heaviest env among those with index = x (mod 8).  Inactive envs go last in their class.
 #define RP_ORDER_BUCKETS 256
 #define RP_ORDER_CLASSES 8
-__global__ __launch_bounds__(1024) void rp_order_kernel(int* order_all, const int* hdr, const int* active, int base, int n) {
-  // (sorts the envs base .. base + n - 1 into order_all[base .. base + n - 1]; base is a multiple of 8)
+__global__ __launch_bounds__(512) void rp_order_kernel(int* order_all, const int* hdr, const int* active, int base, int n) {
+  // (sorts the envs base .. base + n - 1 into order_all[base .. base + n - 1]; base is a multiple of 8.
+  // One workgroup per residue class: eight short kernels side by side instead of one 1024-thread block.)
+  const int x = blockIdx.x;
   int* order = order_all + base;
-  __shared__ int hist[RP_ORDER_CLASSES][RP_ORDER_BUCKETS];
-  for (int i = threadIdx.x; i < RP_ORDER_CLASSES * RP_ORDER_BUCKETS; i += blockDim.x) (&hist[0][0])[i] = 0;
+  __shared__ int hist[RP_ORDER_BUCKETS];
+  for (int i = threadIdx.x; i < RP_ORDER_BUCKETS; i += blockDim.x) hist[i] = 0;
   __syncthreads();
   auto key_of = [&](int e) -> int {
     if (active && active[e] == 0) return 0;
@@ -59,27 +61,29 @@ __global__ __launch_bounds__(1024) void rp_order_kernel(int* order_all, const in
     const int k = 1 + (26 + 5 * (30 + nd + (nd >> 2) + nd * nd / 200 + 2 * nk) + 3 * nc) / 4;
     return k < RP_ORDER_BUCKETS ? k : RP_ORDER_BUCKETS - 1;
   };
-  for (int e = threadIdx.x; e < n; e += blockDim.x) atomicAdd(&hist[e & 7][key_of(base + e)], 1);
+  // (a thread's first env keeps its key in a register between the two passes)
+  const int e_first = x + RP_ORDER_CLASSES * (int)threadIdx.x;
+  const int k_first = e_first < n ? key_of(base + e_first) : 0;
+  for (int e = e_first; e < n; e += RP_ORDER_CLASSES * blockDim.x) atomicAdd(&hist[e == e_first ? k_first : key_of(base + e)], 1);
   __syncthreads();
-  // descending exclusive prefix per class: wave c scans class c, lane l owns the four buckets
-  // 255 - 4 l ... 252 - 4 l (the serial scan by eight threads was 2 of this kernel's 10.5 us)
-  static_assert(RP_ORDER_BUCKETS == 256 && RP_ORDER_CLASSES * 64 <= 1024, "scan layout");
-  if (threadIdx.x < 64 * RP_ORDER_CLASSES) {
-    const int c = threadIdx.x >> 6, l = threadIdx.x & 63;
+  // descending exclusive prefix: lane l of the first wave owns the four buckets 255 - 4 l ... 252 - 4 l
+  static_assert(RP_ORDER_BUCKETS == 256, "scan layout");
+  if (threadIdx.x < 64) {
+    const int l = threadIdx.x;
     int v[4], tot = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { v[k] = hist[c][RP_ORDER_BUCKETS - 1 - 4 * l - k]; tot += v[k]; }
+    for (int k = 0; k < 4; k++) { v[k] = hist[RP_ORDER_BUCKETS - 1 - 4 * l - k]; tot += v[k]; }
     int incl = tot;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (l >= d) incl += t; }
     int acc = incl - tot;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { hist[c][RP_ORDER_BUCKETS - 1 - 4 * l - k] = acc; acc += v[k]; }
+    for (int k = 0; k < 4; k++) { hist[RP_ORDER_BUCKETS - 1 - 4 * l - k] = acc; acc += v[k]; }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < n; e += blockDim.x) {
-    const int r = atomicAdd(&hist[e & 7][key_of(base + e)], 1);
-    order[8 * r + (e & 7)] = base + e;
+  for (int e = e_first; e < n; e += RP_ORDER_CLASSES * blockDim.x) {
+    const int r = atomicAdd(&hist[e == e_first ? k_first : key_of(base + e)], 1);
+    order[RP_ORDER_CLASSES * r + x] = base + e;
   }
 }
 
@@ -647,7 +651,7 @@ struct Engine : EngineBase {
         const bool probe = timeit && sl == 0 && k == (int)(step_calls % (unsigned)nsub);
         const bool sense = sensors_on && k == nsub - 1;
         // cost-ordered launch: heaviest envs first, from the hand-over the position stage just wrote
-        if (cost_order) hipLaunchKernelGGL(rp_order_kernel, dim3(1), dim3(1024), 0, st, d_order, B.hdr, s.active, base, cnt);
+        if (cost_order) hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(512), 0, st, d_order, B.hdr, s.active, base, cnt);
         if (sense) {  // the state this substep's forces belong to (the solver stage integrates in place)
           HIP_OK(hipMemcpyAsync(d_qpos_prev + (size_t)base * nv, S.qpos + (size_t)base * nv, sizeof(T) * (size_t)cnt * nv, hipMemcpyDeviceToDevice, st));
           HIP_OK(hipMemcpyAsync(d_qvel_prev + (size_t)base * nv, S.qvel + (size_t)base * nv, sizeof(T) * (size_t)cnt * nv, hipMemcpyDeviceToDevice, st));

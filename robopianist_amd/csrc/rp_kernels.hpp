@@ -148,6 +148,9 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
   using N = Num<T>;
   const int env = S.order ? S.order[S.env_base + blockIdx.x] : S.env_base + (int)blockIdx.x;
   const int lane = threadIdx.x;
+  if constexpr (MODE == 1) {
+    if (S.lean && B.hdr[env * 8 + 6] == 1) return;   // a light env: rp_lean_solver_kernel steps it
+  }
   const int env_active = S.active ? S.active[env] : 1;  // tested after the prologue loads are in flight
   __shared__ Smem<T, MODE, MD> sm;
   constexpr int TC = MD > 9 ? 8 : 4;            // trunk links the chain-blocked solver holds
@@ -353,7 +356,6 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
     // ======================================================================
     if constexpr (MODE == 1) {
       // ---- what the position/velocity kernel left behind
-      if (S.lean && B.hdr[env * 8 + 6] == 1) return;   // a light env: rp_lean_solver_kernel steps it
       {
         ncon = B.hdr[env * 8]; nkt = B.hdr[env * 8 + 1];
         dirty_mask = ((unsigned long long)(unsigned)B.hdr[env * 8 + 3] << 32) | (unsigned)B.hdr[env * 8 + 2];
