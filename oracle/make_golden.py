@@ -17,14 +17,15 @@ and writes, per config, `<out>/config<N>.npz`:
                uses MuJoCo's field names), so tests can run OUR engine and OUR oracle on the REAL
                model instead of the stand-in hand (mesh geoms excluded: primitive fingertips)
     ctrl       [T, nu]     actuator controls actually applied (after the canonical map)
-    qpos,qvel  [T*10+1, nv] state after every mj_step (row 0 = reset state)
+    qpos,qvel,qacc_warmstart  [T*10+1, nv] state after every mj_step (row 0 = reset state)
     ncon,nefc  [T*10]       contact / constraint-row counts per mj_step
     solver_niter [T*10]
 
-Nothing in tests/ consumes these files yet: running OUR engine / oracle on the dumped model needs an
-mjModel -> engine-table converter (bodies with several joints, the forearm / wrist collision meshes as
-<= 26-vertex hulls) that cannot be validated without a real dump -- round-3 work.  Until
-then the files pin the reference side only.  Here, without `mujoco`, the script prints what is missing
+`tests/test_mujoco_golden.py` consumes these files: `robopianist_amd/tools/mjmodel_to_blob.py` turns the dumped
+mjModel into the blob the oracle and the engine load (the real menagerie hand instead of the stand-in), and the
+tests replay the recorded action stream teacher-forced (every mj_step restarted from MuJoCo's state: 1e-9) and
+free-running (1e-4 over 1000 mj_steps) against MuJoCo's qpos / qvel / ncon.  The importer itself is exercised
+without MuJoCo by a round trip on the stand-in scene.  Here, without `mujoco`, the script prints what is missing
 and exits 0 (a no-op by design).
 """
 from __future__ import annotations
@@ -46,7 +47,8 @@ MODEL_FIELDS = (
     "geom_rbound site_bodyid site_pos site_quat tendon_adr tendon_num wrap_type wrap_objid wrap_prm "
     "actuator_trntype actuator_trnid actuator_gainprm actuator_biasprm actuator_gear "
     "actuator_ctrllimited actuator_ctrlrange actuator_forcelimited actuator_forcerange "
-    "exclude_signature").split()
+    "exclude_signature geom_dataid mesh_vert mesh_vertadr mesh_vertnum mesh_graph mesh_graphadr "
+    "site_size sensor_type sensor_objtype sensor_objid").split()
 
 
 def dump_model(m) -> dict:
@@ -60,6 +62,7 @@ def dump_model(m) -> dict:
     out["model_opt_gravity"] = np.asarray(o.gravity)
     out["model_stat_meaninertia"] = np.array([m.stat.meaninertia])
     import mujoco
+    out["model_opt_refsafe"] = np.asarray(0 if (int(o.disableflags) & int(mujoco.mjtDisableBit.mjDSBL_REFSAFE)) else 1)
     for kind, n, enum in (("body", m.nbody, mujoco.mjtObj.mjOBJ_BODY), ("joint", m.njnt, mujoco.mjtObj.mjOBJ_JOINT),
                           ("geom", m.ngeom, mujoco.mjtObj.mjOBJ_GEOM), ("site", m.nsite, mujoco.mjtObj.mjOBJ_SITE),
                           ("actuator", m.nu, mujoco.mjtObj.mjOBJ_ACTUATOR)):
@@ -93,6 +96,7 @@ def run_config(config: int, out_dir: str, reference_root: str, n_steps: int):
     n_sub = env.task.physics_steps_per_control_step
     env.reset()
     qpos, qvel, ncon, nefc, nit, ctrl = [d.qpos.copy()], [d.qvel.copy()], [], [], [], []
+    warm = [d.qacc_warmstart.copy()]
     import mujoco
     for t in range(min(n_steps, len(acts))):
         # composer.Environment.step, unrolled so that every mj_step is recorded: before_step writes
@@ -102,11 +106,12 @@ def run_config(config: int, out_dir: str, reference_root: str, n_steps: int):
         for _ in range(n_sub):
             mujoco.mj_step2(m, d)
             mujoco.mj_step1(m, d)
-            qpos.append(d.qpos.copy()); qvel.append(d.qvel.copy())
+            qpos.append(d.qpos.copy()); qvel.append(d.qvel.copy()); warm.append(d.qacc_warmstart.copy())
             ncon.append(d.ncon); nefc.append(d.nefc); nit.append(int(d.solver_niter[0]) if hasattr(d.solver_niter, "__len__") else int(d.solver_niter))
     os.makedirs(out_dir, exist_ok=True)
     path = os.path.join(out_dir, f"config{config}.npz")
     np.savez_compressed(path, ctrl=np.asarray(ctrl), qpos=np.asarray(qpos), qvel=np.asarray(qvel),
+                        qacc_warmstart=np.asarray(warm), n_substeps=np.asarray(n_sub),
                         ncon=np.asarray(ncon), nefc=np.asarray(nefc), solver_niter=np.asarray(nit),
                         mujoco_version=np.array([mujoco.__version__]), **dump_model(m))
     print("wrote", path)

@@ -414,10 +414,20 @@ def compile_scene(scene: spec.Scene) -> Model:
     for a, b in scene.excludes:
         ia, ib = names["body"].index(a), names["body"].index(b)
         excl.add((min(ia, ib), max(ia, ib)))
+    m["exclude_pairs"] = np.asarray(sorted(excl), np.int32).reshape(-1, 2)
+    static_pairs(m)
+    return m
+
+
+def static_pairs(m: Model) -> None:
+    """The candidate geom pairs MuJoCo's broad phase can ever return for this model [mj_collision filters:
+    contype / conaffinity, same body, both static or welded together, parent-child, <exclude>], as
+    m.pair_geom (geom with the lower type first).  Needs body_weldid, body_parentid, exclude_pairs."""
+    weld, parents = m.body_weldid, m.body_parentid
+    excl = set((int(a), int(b)) for a, b in np.asarray(m.exclude_pairs).reshape(-1, 2))
     pairs = []
-    dropped_boxbox = 0
-    for g1 in range(ngeom):
-        for g2 in range(g1 + 1, ngeom):
+    for g1 in range(m.ngeom):
+        for g2 in range(g1 + 1, m.ngeom):
             b1, b2 = m.geom_bodyid[g1], m.geom_bodyid[g2]
             if b1 == b2:
                 continue
@@ -438,8 +448,7 @@ def compile_scene(scene: spec.Scene) -> Model:
     pairs.sort()
     m["pair_geom"] = np.asarray([(p[2], p[3]) for p in pairs], np.int32).reshape(-1, 2)
     m["npair"] = len(pairs)
-    m["npair_dropped_boxbox"] = dropped_boxbox
-    return m
+    m["npair_dropped_boxbox"] = 0
 
 
 # ---------------------------------------------------------------------------
