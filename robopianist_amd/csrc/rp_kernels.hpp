@@ -21,19 +21,18 @@
     (rc_)[0] = o_[0]; (rc_)[1] = o_[1]; (rc_)[2] = o_[2];                                       \
     return n_; }()
 #endif
-// convex pair with a hull: arguments copied into memory-resident geom records (a real call)
-#define RPK_CONVEX(rc_, tA_, pA_, mA_, sA_, gA_, tB_, pB_, mB_, sB_, gB_) [&]() -> int {      \
+// convex pairs with a hull: arguments copied into memory-resident geom records (a real call, made by the whole
+// wave: lanes with `act_` hold a pair)
+#define RPK_CONVEX(rc_, act_, tA_, pA_, mA_, sA_, gA_, tB_, pB_, mB_, sB_, gB_) [&]() -> int {      \
     CGeom<T> a_, b_; RawCon<T> o_;                                                              \
     a_.type = (tA_); b_.type = (tB_);                                                           \
     _Pragma("unroll") for (int i_ = 0; i_ < 3; i_++) { a_.pos[i_] = (pA_)[i_]; b_.pos[i_] = (pB_)[i_]; a_.size[i_] = (sA_)[i_]; b_.size[i_] = (sB_)[i_]; } \
     _Pragma("unroll") for (int i_ = 0; i_ < 9; i_++) { a_.mat[i_] = (mA_)[i_]; b_.mat[i_] = (mB_)[i_]; }                     \
-    a_.nvert = (gA_) >= 0 ? M.geom_vertnum()[(gA_) >= 0 ? (gA_) : 0] : 0;                       \
-    b_.nvert = (gB_) >= 0 ? M.geom_vertnum()[(gB_) >= 0 ? (gB_) : 0] : 0;                       \
-    a_.vert = M.mesh_vert() + 3 * ((gA_) >= 0 ? M.geom_vertadr()[(gA_) >= 0 ? (gA_) : 0] : 0); \
-    b_.vert = M.mesh_vert() + 3 * ((gB_) >= 0 ? M.geom_vertadr()[(gB_) >= 0 ? (gB_) : 0] : 0); \
-    if (a_.type != GEOM_MESH_) { a_.nvert = 0; a_.vert = M.mesh_vert(); }                       \
-    if (b_.type != GEOM_MESH_) { b_.nvert = 0; b_.vert = M.mesh_vert(); }                       \
-    const int n_ = convex_mpr(&o_, &a_, &b_);                                                   \
+    a_.nvert = ((act_) && (gA_) >= 0 && a_.type == GEOM_MESH_) ? M.geom_vertnum()[(gA_) >= 0 ? (gA_) : 0] : 0; \
+    b_.nvert = ((act_) && (gB_) >= 0 && b_.type == GEOM_MESH_) ? M.geom_vertnum()[(gB_) >= 0 ? (gB_) : 0] : 0; \
+    a_.vadr = a_.nvert ? M.geom_vertadr()[(gA_) >= 0 ? (gA_) : 0] : 0;                           \
+    b_.vadr = b_.nvert ? M.geom_vertadr()[(gB_) >= 0 ? (gB_) : 0] : 0;                           \
+    const int n_ = convex_mpr_wave(&o_, &a_, &b_, M.mesh_vert(), (act_));                       \
     (rc_)[0] = o_;                                                                              \
     return n_; }()
 namespace rpk {
@@ -1713,9 +1712,13 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
         }
       }
       if constexpr (MESH != 0) {
-        if (mpr) {
-          n = RPK_CONVEX(rc, mpr_tA, mpr_pA, mpr_mA, mpr_sA, mpr_gA, GEOM_MESH_, mpr_pB, mpr_mB, mpr_sB, mpr_gB);
-          if (mpr_flip) { rc[0].n[0] = -rc[0].n[0]; rc[0].n[1] = -rc[0].n[1]; rc[0].n[2] = -rc[0].n[2]; }
+        if (__ballot(mpr) != 0ull) {   // (the whole wave walks the portal refinement together)
+          RawCon<T> rcm[1];
+          const int nm = RPK_CONVEX(rcm, mpr, mpr_tA, mpr_pA, mpr_mA, mpr_sA, mpr_gA, GEOM_MESH_, mpr_pB, mpr_mB, mpr_sB, mpr_gB);
+          if (mpr) {
+            n = nm; rc[0] = rcm[0];
+            if (mpr_flip) { rc[0].n[0] = -rc[0].n[0]; rc[0].n[1] = -rc[0].n[1]; rc[0].n[2] = -rc[0].n[2]; }
+          }
         }
       }
       PROF(13);

@@ -423,18 +423,26 @@ __device__ RPK_BOXBOX_INLINE int box_box(RawCon<T>* out, const T* p1, const T* m
 // Convex pairs with a hull (GEOM_MESH_) [MJ: mjc_Convex -> libccd MPR; restated, see the oracle]:
 // Minkowski Portal Refinement on B - A, one contact: depth along the final portal's normal,
 // normal from A to B, position = witness midpoints blended with the origin ray's barycentric
-// weights.  Tolerance 1e-6, at most 50 refinement steps.  Not inlined (register-bound caller).
-template <typename T> struct CGeom { int type, nvert; T pos[3], mat[9], size[3]; const T* vert; };
+// weights.  Tolerance 1e-6, at most 50 refinement steps.
+//
+// The whole wave walks the procedure together (wave-uniform control flow, one support evaluation per
+// trip for every lane that still has a pair in flight; a lane's own sequence of supports and decisions
+// is the sequential procedure's).  That is what makes the hull support cheap: the lanes that use the
+// same vertex set scan it together through the SCALAR cache (uniform addresses), instead of every lane
+// pulling 26 vertices through its own vector loads (7 dependent round trips per support: the narrow
+// phase was 38 % of all cycles of an mj_step in hull-fingertip mode).
+template <typename T> struct CGeom { int type, nvert, vadr; T pos[3], mat[9], size[3]; };
 template <typename T> struct MPoint { T v[3], p1[3], p2[3]; };
 
+// support point of a capsule / box (hulls: hull_support_wave)
 template <typename T>
-__device__ __forceinline__ void geom_support(const CGeom<T>& g, const T* d, T* out) {
+__device__ __forceinline__ void prim_support(const CGeom<T>& g, const T* d, T* out) {
   if (g.type == GEOM_CAPSULE_) {
     const T ax[3] = {g.mat[2], g.mat[5], g.mat[8]};
     const T sl = dot3(ax, d) >= 0 ? g.size[1] : -g.size[1];
 #pragma unroll
     for (int k = 0; k < 3; k++) out[k] = g.pos[k] + sl * ax[k] + g.size[0] * d[k];
-  } else if (g.type == GEOM_BOX_) {
+  } else {
     T o[3] = {g.pos[0], g.pos[1], g.pos[2]};
 #pragma unroll
     for (int a = 0; a < 3; a++) {
@@ -444,40 +452,41 @@ __device__ __forceinline__ void geom_support(const CGeom<T>& g, const T* d, T* o
       for (int k = 0; k < 3; k++) o[k] += sh * ax[k];
     }
     out[0] = o[0]; out[1] = o[1]; out[2] = o[2];
-  } else {
-    T dl[3];
-    matT_vec(dl, g.mat, d);
-    T bv = (T)-1e30, b0 = 0, b1 = 0, b2 = 0;
-    // first maximum wins.  Four vertices per trip: the twelve loads go out together (one lane walks
-    // this loop while the rest of the wave waits, so the load latency is all there is to hide); the
-    // tail repeats the last vertex, which cannot win a strict comparison against itself.
-    const int last = g.nvert - 1;
-    for (int i = 0; i < g.nvert; i += 4) {
-      T x[4], y[4], z[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int iu = i + u < last ? i + u : last;
-        x[u] = g.vert[3 * iu]; y[u] = g.vert[3 * iu + 1]; z[u] = g.vert[3 * iu + 2];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const T v = dl[0] * x[u] + dl[1] * y[u] + dl[2] * z[u];
-        if (v > bv) { bv = v; b0 = x[u]; b1 = y[u]; b2 = z[u]; }
-      }
-    }
-    const T bl[3] = {b0, b1, b2};
-    T w[3];
-    mat_vec(w, g.mat, bl);
-    out[0] = g.pos[0] + w[0]; out[1] = g.pos[1] + w[1]; out[2] = g.pos[2] + w[2];
   }
 }
+// Support point of hull g in direction d for every lane with `need` (called by the whole wave).  First
+// maximum wins, as in the sequential scan.  mv = the model's hull vertex table (uniform pointer).
 template <typename T>
-__device__ __forceinline__ void mpr_support(const CGeom<T>& A, const CGeom<T>& B, const T* d, MPoint<T>& o) {
-  const T nd[3] = {-d[0], -d[1], -d[2]};
-  geom_support(A, nd, o.p1);
-  geom_support(B, d, o.p2);
+__device__ __forceinline__ void hull_support_wave(const T* mv, const CGeom<T>& g, const T* d, const bool need, T* out) {
+  T dl[3];
+  matT_vec(dl, g.mat, d);
+  T bv = (T)-1e30;
+  int bi = 0;
+  unsigned long long todo = __ballot(need);
+  while (todo) {   // one trip per distinct vertex set among the lanes that need a support
+    const int L0 = __ffsll((long long)todo) - 1;
+    const int base = bcast(g.vadr, L0), nv = bcast(g.nvert, L0);
+    const bool mine = need && g.vadr == base;
+    todo &= ~__ballot(mine);
+    const T RPK_CONST_AS* vb = uniform_const(mv + 3 * base);
+    // (eight vertices per trip, so that their scalar loads are in flight together; the table pads every set to a
+    // multiple of eight with copies of its last vertex, which cannot win a strict comparison against itself)
+    for (int i = 0; i < nv; i += 8) {
+      T x[8], y[8], z[8];
 #pragma unroll
-  for (int k = 0; k < 3; k++) o.v[k] = o.p2[k] - o.p1[k];
+      for (int u = 0; u < 8; u++) { x[u] = vb[3 * (i + u)]; y[u] = vb[3 * (i + u) + 1]; z[u] = vb[3 * (i + u) + 2]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const T v = dl[0] * x[u] + dl[1] * y[u] + dl[2] * z[u];
+        if (mine && v > bv) { bv = v; bi = i + u; }
+      }
+    }
+  }
+  const int a = need ? 3 * (g.vadr + bi) : 0;
+  const T bl[3] = {mv[a], mv[a + 1], mv[a + 2]};
+  T w[3];
+  mat_vec(w, g.mat, bl);
+  out[0] = g.pos[0] + w[0]; out[1] = g.pos[1] + w[1]; out[2] = g.pos[2] + w[2];
 }
 template <typename T> __device__ __forceinline__ bool normalize3(T* v) {
   const T n = Num<T>::sqrt(dot3(v, v));
@@ -492,86 +501,122 @@ template <typename T> __device__ __forceinline__ void portal_dir(T* dir, const M
   cross3(dir, t1, t2);
 }
 
+// Called by the whole wave; lanes with `active` hold a pair (A, B).  Returns the number of contacts (0 / 1).
 template <typename T>
-__device__ __noinline__ int convex_mpr(RawCon<T>* out, const CGeom<T>* Ap, const CGeom<T>* Bp) {
+__device__ __noinline__ int convex_mpr_wave(RawCon<T>* out, const CGeom<T>* Ap, const CGeom<T>* Bp, const T* mv, const bool active) {
   const CGeom<T>& A = *Ap; const CGeom<T>& B = *Bp;
-  MPoint<T> v0, v1, v2, v3, v4;
+  MPoint<T> v0, v1, v2, v3, S;
   T dir[3], t1[3];
+  int phase = active ? 0 : 4;   // 0: first support, 1: second, 2: portal discovery, 3: refinement, 4: done
+  int it = 0, result = 0;
+  bool hit = false;
 #pragma unroll
   for (int k = 0; k < 3; k++) { v0.p1[k] = A.pos[k]; v0.p2[k] = B.pos[k]; v0.v[k] = B.pos[k] - A.pos[k]; }
   if (Num<T>::sqrt(dot3(v0.v, v0.v)) < (T)1e-10) v0.v[0] = (T)1e-5;
-  // ---- portal discovery
   dir[0] = -v0.v[0]; dir[1] = -v0.v[1]; dir[2] = -v0.v[2];
   normalize3(dir);
-  mpr_support(A, B, dir, v1);
-  if (dot3(v1.v, dir) <= 0) return 0;
-  cross3(dir, v0.v, v1.v);
-  if (!normalize3(dir)) {   // the origin lies on the ray v0 -> v1
-    T n[3] = {v1.v[0] - v0.v[0], v1.v[1] - v0.v[1], v1.v[2] - v0.v[2]};
-    normalize3(n);
-    out->dist = -dot3(v1.v, n);
+  v1 = v0; v2 = v0; v3 = v0;
+  while (__ballot(phase != 4) != 0ull) {
+    const bool run = phase != 4;
+    // ---- S = support of B - A along dir
+    {
+      const T nd[3] = {-dir[0], -dir[1], -dir[2]};
+      const bool hA = run && A.type == GEOM_MESH_, hB = run && B.type == GEOM_MESH_;
+      if (__ballot(hA) != 0ull) hull_support_wave(mv, A, nd, hA, S.p1);
+      if (__ballot(hB) != 0ull) hull_support_wave(mv, B, dir, hB, S.p2);
+      if (run && A.type != GEOM_MESH_) prim_support(A, nd, S.p1);
+      if (run && B.type != GEOM_MESH_) prim_support(B, dir, S.p2);
 #pragma unroll
-    for (int k = 0; k < 3; k++) { out->n[k] = -n[k]; out->pos[k] = (T)0.5 * (v1.p1[k] + v1.p2[k]); }
-    return out->dist <= 0 ? 1 : 0;
-  }
-  mpr_support(A, B, dir, v2);
-  if (dot3(v2.v, dir) <= 0) return 0;
-  portal_dir(dir, v1, v2, v0);
-  normalize3(dir);
-  if (dot3(dir, v0.v) > 0) {
-    const MPoint<T> tmp = v1; v1 = v2; v2 = tmp;
-    dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2];
-  }
-  for (int it = 0;; it++) {
-    if (it > 50) return 0;
-    mpr_support(A, B, dir, v3);
-    if (dot3(v3.v, dir) <= 0) return 0;
-    cross3(t1, v1.v, v3.v);
-    if (dot3(t1, v0.v) < 0) { v2 = v3; portal_dir(dir, v1, v3, v0); normalize3(dir); continue; }
-    cross3(t1, v3.v, v2.v);
-    if (dot3(t1, v0.v) < 0) { v1 = v3; portal_dir(dir, v3, v2, v0); normalize3(dir); continue; }
-    break;
-  }
-  // ---- refinement
-  bool hit = false;
-  for (int it = 0; it <= 50; it++) {
-    portal_dir(dir, v2, v3, v1);
-    if (!normalize3(dir)) return 0;
-    if (dot3(dir, v1.v) >= 0) hit = true;   // the origin is inside the portal
-    mpr_support(A, B, dir, v4);
-    const T reach = dot3(v4.v, dir) - dot3(v1.v, dir);
-    if (!hit && dot3(v4.v, dir) < 0) return 0;
-    if (reach <= (T)1e-6 || it == 50) {
-      if (!hit) return 0;
-      const T depth = dot3(v1.v, dir);
-      T b[4], c[3];
-      cross3(c, v1.v, v2.v); b[0] = dot3(c, v3.v);
-      cross3(c, v3.v, v2.v); b[1] = dot3(c, v0.v);
-      cross3(c, v0.v, v1.v); b[2] = dot3(c, v3.v);
-      cross3(c, v2.v, v1.v); b[3] = dot3(c, v0.v);
-      T sum = b[0] + b[1] + b[2] + b[3];
-      if (sum <= 0) {
-        b[0] = 0;
-        cross3(c, v2.v, v3.v); b[1] = dot3(c, dir);
-        cross3(c, v3.v, v1.v); b[2] = dot3(c, dir);
-        cross3(c, v1.v, v2.v); b[3] = dot3(c, dir);
-        sum = b[1] + b[2] + b[3];
-      }
-      const T inv = (T)1 / sum;
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const T acc = b[0] * (T)0.5 * (v0.p1[k] + v0.p2[k]) + b[1] * (T)0.5 * (v1.p1[k] + v1.p2[k]) +
-                      b[2] * (T)0.5 * (v2.p1[k] + v2.p2[k]) + b[3] * (T)0.5 * (v3.p1[k] + v3.p2[k]);
-        out->pos[k] = acc * inv;
-        out->n[k] = -dir[k];   // (the portal faces away from the centre of B - A: A -> B is -dir)
-      }
-      out->dist = -depth;
-      return 1;
+      for (int k = 0; k < 3; k++) S.v[k] = S.p2[k] - S.p1[k];
     }
-    cross3(t1, v4.v, v0.v);
-    if (dot3(v1.v, t1) > 0) { if (dot3(v2.v, t1) > 0) v1 = v4; else v3 = v4; }
-    else { if (dot3(v3.v, t1) > 0) v2 = v4; else v1 = v4; }
+    if (phase == 0) {
+      v1 = S;
+      if (dot3(v1.v, dir) <= 0) phase = 4;
+      else {
+        cross3(dir, v0.v, v1.v);
+        if (!normalize3(dir)) {   // the origin lies on the ray v0 -> v1
+          T n[3] = {v1.v[0] - v0.v[0], v1.v[1] - v0.v[1], v1.v[2] - v0.v[2]};
+          normalize3(n);
+          out->dist = -dot3(v1.v, n);
+#pragma unroll
+          for (int k = 0; k < 3; k++) { out->n[k] = -n[k]; out->pos[k] = (T)0.5 * (v1.p1[k] + v1.p2[k]); }
+          result = out->dist <= 0 ? 1 : 0;
+          phase = 4;
+        } else phase = 1;
+      }
+    } else if (phase == 1) {
+      v2 = S;
+      if (dot3(v2.v, dir) <= 0) phase = 4;
+      else {
+        portal_dir(dir, v1, v2, v0);
+        normalize3(dir);
+        if (dot3(dir, v0.v) > 0) {
+          const MPoint<T> tmp = v1; v1 = v2; v2 = tmp;
+          dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2];
+        }
+        phase = 2; it = 0;
+      }
+    } else if (phase == 2) {
+      // ---- portal discovery
+      v3 = S;
+      if (dot3(v3.v, dir) <= 0) phase = 4;
+      else {
+        cross3(t1, v1.v, v3.v);
+        if (dot3(t1, v0.v) < 0) { v2 = v3; portal_dir(dir, v1, v3, v0); normalize3(dir); if (++it > 50) phase = 4; }
+        else {
+          cross3(t1, v3.v, v2.v);
+          if (dot3(t1, v0.v) < 0) { v1 = v3; portal_dir(dir, v3, v2, v0); normalize3(dir); if (++it > 50) phase = 4; }
+          else {
+            // ---- refinement starts: direction of the first portal
+            it = 0; hit = false;
+            portal_dir(dir, v2, v3, v1);
+            if (!normalize3(dir)) phase = 4;
+            else { if (dot3(dir, v1.v) >= 0) hit = true; phase = 3; }
+          }
+        }
+      }
+    } else if (phase == 3) {
+      const T reach = dot3(S.v, dir) - dot3(v1.v, dir);
+      if (!hit && dot3(S.v, dir) < 0) phase = 4;
+      else if (reach <= (T)1e-6 || it == 50) {
+        if (hit) {
+          const T depth = dot3(v1.v, dir);
+          T b[4], c[3];
+          cross3(c, v1.v, v2.v); b[0] = dot3(c, v3.v);
+          cross3(c, v3.v, v2.v); b[1] = dot3(c, v0.v);
+          cross3(c, v0.v, v1.v); b[2] = dot3(c, v3.v);
+          cross3(c, v2.v, v1.v); b[3] = dot3(c, v0.v);
+          T sum = b[0] + b[1] + b[2] + b[3];
+          if (sum <= 0) {
+            b[0] = 0;
+            cross3(c, v2.v, v3.v); b[1] = dot3(c, dir);
+            cross3(c, v3.v, v1.v); b[2] = dot3(c, dir);
+            cross3(c, v1.v, v2.v); b[3] = dot3(c, dir);
+            sum = b[1] + b[2] + b[3];
+          }
+          const T inv = (T)1 / sum;
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const T acc = b[0] * (T)0.5 * (v0.p1[k] + v0.p2[k]) + b[1] * (T)0.5 * (v1.p1[k] + v1.p2[k]) +
+                          b[2] * (T)0.5 * (v2.p1[k] + v2.p2[k]) + b[3] * (T)0.5 * (v3.p1[k] + v3.p2[k]);
+            out->pos[k] = acc * inv;
+            out->n[k] = -dir[k];   // (the portal faces away from the centre of B - A: A -> B is -dir)
+          }
+          out->dist = -depth;
+          result = 1;
+        }
+        phase = 4;
+      } else {
+        cross3(t1, S.v, v0.v);
+        if (dot3(v1.v, t1) > 0) { if (dot3(v2.v, t1) > 0) v1 = S; else v3 = S; }
+        else { if (dot3(v3.v, t1) > 0) v2 = S; else v1 = S; }
+        it++;
+        portal_dir(dir, v2, v3, v1);
+        if (!normalize3(dir)) phase = 4;
+        else if (dot3(dir, v1.v) >= 0) hit = true;
+      }
+    }
   }
-  return 0;
+  return result;
 }
 }  // namespace rpk

@@ -101,6 +101,19 @@ __device__ __forceinline__ double uni(double v) {
   const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+// A wave-uniform pointer to memory no kernel writes (model tables), in the constant address space: loads through
+// it are scalar loads (one fetch for the wave, scalar cache) instead of 64-lane vector loads.  (RPK_CONST_AS: the
+// CPU wave emulator of tests/wavesim compiles this file for the host and defines it away.)
+#ifndef RPK_CONST_AS
+#define RPK_CONST_AS __attribute__((address_space(4)))
+#endif
+template <typename P>
+__device__ __forceinline__ const P RPK_CONST_AS* uniform_const(const P* p) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(a & 0xffffffffull));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32));
+  return (const P RPK_CONST_AS*)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) {
   return (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 }

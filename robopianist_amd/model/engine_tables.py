@@ -382,13 +382,23 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
     t["eng_geom_modelid"] = np.array(egeoms, np.int32)
     # convex hulls: vertices (geom frame; welded bodies are handled through geom_pos / geom_mat)
     if ng and "geom_vertnum" in m and int(np.sum(m.geom_vertnum[egeoms])) > 0:
-        vadr, vnum, verts = np.full(ng, -1, np.int32), np.zeros(ng, np.int32), []
+        # (geoms with identical vertex sets -- the four finger tips of a hand -- share one copy: the lanes of a wave
+        # that use the same set scan it together, rp_narrow.hpp: hull_support_wave)
+        vadr, vnum, verts, seen = np.full(ng, -1, np.int32), np.zeros(ng, np.int32), [], {}
         for i, g in enumerate(egeoms):
             if m.geom_type[g] == spec.GEOM_MESH:
-                vadr[i] = len(verts); vnum[i] = int(m.geom_vertnum[g])
+                vnum[i] = int(m.geom_vertnum[g])
                 a = int(m.geom_vertadr[g])
-                verts.extend(m.mesh_vert[a:a + vnum[i]].tolist())
-        assert len(verts) <= 320, "too many hull vertices for the engine (RPK_MAXMESHV)"
+                v = np.asarray(m.mesh_vert[a:a + vnum[i]], float)
+                key = v.tobytes()
+                if key not in seen:
+                    seen[key] = len(verts)
+                    verts.extend(v.tolist())
+                    # padded to a multiple of eight with copies of the last vertex (the scan reads eight per trip;
+                    # a copy cannot win its strict comparison)
+                    verts.extend([v[-1].tolist()] * ((-len(v)) % 8))
+                vadr[i] = seen[key]
+        assert len(verts) <= 320, "too many hull vertices for the engine (RPK_MAXMESHV; sets are padded to multiples of 8)"
         t["eng_geom_vertadr"] = vadr; t["eng_geom_vertnum"] = vnum
         t["eng_mesh_vert"] = np.asarray(verts, float).reshape(-1, 3)
 

@@ -17,6 +17,7 @@
 
 #define RP_WAVESIM 1
 #define RPK_SREG_CONSTRAINT "+r"
+#define RPK_CONST_AS
 
 // ---- language
 #define __global__
