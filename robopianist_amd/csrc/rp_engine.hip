@@ -364,7 +364,6 @@ struct Engine : EngineBase {
       PF(mesh_vert, "eng_mesh_vert"); PI(geom_vertadr, "eng_geom_vertadr"); PI(geom_vertnum, "eng_geom_vertnum");
       for (int t : b.i("eng_geom_type")) if (t == GEOM_MESH_) mesh = true;
     }
-    if (mesh && deep) throw std::string("hull geoms together with more than two forearm dofs are not built (no such kernel variant)");
 #undef PF
 #undef PI
     M.ft = upF(ft);
@@ -633,7 +632,8 @@ struct Engine : EngineBase {
       RpState<T> ss = s;
       ss.env_base = base;
       auto launch_pos_on = [&](const RpState<T>& q, int k) {
-        if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
+        if (deep && mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP, 1>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
+        else if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
         else if (mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD, 1>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
         else hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
       };
@@ -671,7 +671,8 @@ struct Engine : EngineBase {
           sq.qpos = d_qpos_prev; sq.qvel = d_qvel_prev;
           sq.sens_torque = d_sens_torque; sq.sens_touch = d_sens_touch;
           sq.key_trace = nullptr; sq.prof = nullptr;
-          if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 2, 0, RPK_MAXD_DEEP>), dim3(cnt), dim3(64), 0, st, M, sq, B, -1, nsub);
+          if (deep && mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 2, 0, RPK_MAXD_DEEP, 1>), dim3(cnt), dim3(64), 0, st, M, sq, B, -1, nsub);
+          else if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 2, 0, RPK_MAXD_DEEP>), dim3(cnt), dim3(64), 0, st, M, sq, B, -1, nsub);
           else if (mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 2, 0, RPK_MAXD, 1>), dim3(cnt), dim3(64), 0, st, M, sq, B, -1, nsub);
           else hipLaunchKernelGGL((rp_stage_kernel<T, 2>), dim3(cnt), dim3(64), 0, st, M, sq, B, -1, nsub);
         }

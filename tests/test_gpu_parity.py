@@ -418,6 +418,39 @@ def test_stream_slices_and_cost_order_are_bit_identical(two_hand_scene):
     assert ref.get(engine.NCON).max() > 0
 
 
+def test_teacher_forced_fp64_hull_fingertips_with_four_forearm_dofs():
+    """The reference's default fingertips (meshes -> hulls through MPR) on a hand with more than two forearm dofs
+    (shadow_hand.py:41-69 allows any subset): the deep builds of the position / sensor stages with the hull narrow
+    phase.  Same 1e-9 teacher-forced bar, hull contacts present."""
+    import warnings
+    from robopianist_amd import engine
+    from robopianist_amd.model import scene, spec
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=False,
+                               forearm_dofs=("forearm_tx", "forearm_ty", "forearm_roll", "forearm_yaw"))
+    m = si.model
+    assert int((m.geom_type == spec.GEOM_MESH).sum()) == 10
+    ctrl = np.concatenate([wrist_press_sequence(si, 200), ctrl_sequence(m, 100, 5)])
+    phys, orc = make_pair(si, 64)
+    worst, hull_contacts, borderline = 0.0, 0, 0
+    for c in ctrl:
+        phys.set(engine.QPOS, orc.qpos[None, :]); phys.set(engine.QVEL, orc.qvel[None, :])
+        phys.set(engine.QACC_WARMSTART, orc.qacc_warmstart[None, :])
+        phys.set(engine.CTRL, c[None, :]); orc.ctrl[:] = c
+        v0 = orc.qvel.copy()
+        phys.step(1); orc.step(1)
+        hull_contacts += sum(1 for cc in orc.contact.reshape(-1, 16) if m.geom_type[int(cc[14])] == spec.GEOM_MESH)
+        if int(phys.get(engine.NCON)[0]) != orc.ncon:
+            borderline += 1
+            continue
+        dv = np.abs(phys.qvel[0].astype(np.float64) - orc.qvel).max()
+        worst = max(worst, dv / max(np.abs(orc.qvel - v0).max(), 1e-9))
+    print(f"hull fingertips, four forearm dofs: {hull_contacts} hull contacts, worst rel dv {worst:.2e}, {borderline} borderline")
+    assert hull_contacts >= 50 and borderline <= 3
+    assert phys.warn_flags.max() == 0 and worst < 1e-9
+
+
 def torch_sync():
     import torch
     torch.cuda.synchronize()
