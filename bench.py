@@ -35,8 +35,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
-NOTEBOOK_KW = dict(control_timestep=0.05, gravity_compensation=True, primitive_fingertip_collisions=True,
-                   reduced_action_space=False, n_steps_lookahead=10)
+# task kwargs of the scripted-replay example / notebook cell 15, WITHOUT the fingertip collider:
+# that is `--fingertips` (default "hull" = primitive_fingertip_collisions=False, the reference's own default:
+# /root/reference/examples/piano_with_shadow_hands_env.py:40, suite/tasks/base.py:101)
+TASK_KW = dict(control_timestep=0.05, gravity_compensation=True, reduced_action_space=False, n_steps_lookahead=10)
 CONFIGS = {
     2: dict(envs=4096, policy="replay", name="PianoWithShadowHands-TwinkleTwinkle scripted replay (BASELINE configs[1])"),
     3: dict(envs=4096, policy="random", name="PianoWithShadowHands-TwinkleTwinkle random policy (BASELINE configs[2])"),
@@ -77,11 +79,26 @@ def _profile_json(name):
         return None
 
 
+def _valu_profile(precision):
+    """What actually bounds the solver stage (instruction issue + latency), from the committed
+    rocprofv3 --pmc passes and the compiler's resource report of the shipped build: waves per SIMD, the share of
+    VALU instructions that are fp64 arithmetic, the share of wave cycles that issue an instruction."""
+    for name in ("r03_sq_instruction_mix.json", "r02_sq_instruction_mix.json"):
+        d = _profile_json(name)
+        k = d and d.get("solver_stage_fp%d" % precision) or (d and d.get("solver_stage"))
+        if k:
+            return {"waves_per_simd": k.get("waves_per_simd"), "fp64_math_share": k.get("fp64_math_share_of_valu"),
+                    "issue_share": k.get("issue_share_of_wave_cycles"), "vgprs": k.get("vgprs"), "agprs": k.get("agprs"),
+                    "lds_bytes": k.get("lds_bytes"), "scratch_bytes_per_lane": k.get("scratch_bytes_per_lane"),
+                    "source": "profiles/" + name}
+    return None
+
+
 def _pmc_traffic(E, precision, envs_per_launch=None):
     """HBM-side bytes per solver-kernel launch from the committed rocprofv3 --pmc passes
     (newest profiles/traffic_rNN.json, see DESIGN.md 6), scaled to the envs one launch covers;
     null if not collected for this env count / precision."""
-    for name in ("traffic_r02.json", "traffic_r01.json"):
+    for name in ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
         d = _profile_json(name)
         if d and int(d.get("envs", -1)) == int(E) and int(d.get("precision", -1)) == int(precision):
             b = d.get("solver_kernel_bytes_per_launch")
@@ -117,18 +134,18 @@ def mixed_song_bank(n=150):
     return bank
 
 
-def build_env(config, E, rank, dev, precision, fingertips="primitive"):
+def build_env(config, E, rank, dev, precision, fingertips="hull"):
     from robopianist_amd import suite
     from robopianist_amd import distributed as rpd
     from robopianist_amd.suite import environment
     from robopianist_amd.suite.tasks import PianoWithShadowHands
     seed = rpd.rank_seed(12345, rank)
-    kw = dict(NOTEBOOK_KW, primitive_fingertip_collisions=(fingertips == "primitive"))
+    kw = dict(TASK_KW, primitive_fingertip_collisions=(fingertips == "primitive"))
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         if config in (2, 3):
-            # notebook cell 15 kwargs; fingertips: capsules (`primitive_fingertip_collisions=True`)
-            # or the stand-in convex hulls collided through MPR (the notebook's own setting, meshes)
+            # fingertips: the stand-in convex hulls collided through MPR (the reference's default: meshes) or capsules
+            # (`primitive_fingertip_collisions=True`)
             return suite.load("RoboPianist-debug-TwinkleTwinkleRousseau-v0", seed=seed, n_envs=E, device_id=dev,
                               precision=precision, task_kwargs=dict(trim_silence=True, **kw))
         if config == 4:
@@ -180,11 +197,11 @@ def main():
     ap.add_argument("--host-io", type=int, default=1,
                     help="N=1, config 2: also time the loop with host-resident actions/TimeSteps (aux.host_io)")
     ap.add_argument("--graph", type=int, default=0, help="replay env.step from a captured hipGraph")
-    ap.add_argument("--fingertips", default="primitive", choices=("primitive", "hull"),
-                    help="fingertip colliders of `value`: capsules (primitive_fingertip_collisions=True) or the "
-                         "stand-in convex hulls through MPR (the notebook's mesh setting); config 2 reports the other "
-                         "one under aux")
-    ap.add_argument("--aux-fingertips", type=int, default=1, help="config 2: also time the other fingertip mode (aux)")
+    ap.add_argument("--fingertips", default="hull", choices=("primitive", "hull"),
+                    help="fingertip colliders of `value`: the stand-in convex hulls through MPR (default: the "
+                         "reference's primitive_fingertip_collisions=False) or capsules (=True); config 2 reports the "
+                         "other one next to it (`value_primitive_fingertips` / `value_hull_fingertips`)")
+    ap.add_argument("--aux-fingertips", type=int, default=1, help="config 2: also time the other fingertip collider")
     ap.add_argument("--stagger", type=int, default=1,
                     help="config 2: every env at its own episode time (env e starts at replay row e mod 158), so any "
                          "timed window samples the whole episode; 0 = all envs in lockstep")
@@ -282,11 +299,14 @@ def main():
                 first = ts.step_type == 0
             state["sim"] += (~first).sum()
             if world > 1 and args.gather:
-                rec = rpd.pack_trajectory_record(
+                rec = rpd.pack_trajectory_record(   # (record dtype = the engine's precision: fp64 state survives the gather)
                     base_env.physics.qpos, ts.reward, ts.discount, ts.step_type, base_env.task.piano.activation)
-                # enqueue only: the all-gather of step t overlaps the physics of step t+1
+                # enqueue only: the all-gather of step t overlaps the physics of step t+1; what the compute stream
+                # still has to wait for (the part that did not overlap) is timed with an event pair
                 if state.get("gather") is not None:
-                    state["gather"][1].wait()
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record(); state["gather"][1].wait(); ev[1].record()
+                    state.setdefault("gwait", []).append(ev)
                 state["gather"] = rpd.gather_trajectories(rec, async_op=True, out=state.get("gather_buf"))
                 state["gather_buf"] = state["gather"][0]
             state["t"] = t + 1
@@ -316,6 +336,7 @@ def main():
         barrier()
         phys.solver_kernel_time(); phys.kernel_time()  # reset the event-timer statistics
         state["sim"].zero_()
+        state["gwait"] = []
         if base_env.physics.warn is not None:
             base_env.physics.warn.zero_()
         t0 = time.perf_counter()
@@ -324,6 +345,14 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         sim = int(state["sim"].item())
+        gather_wait_ms = sum(a.elapsed_time(b) for a, b in state.get("gwait", []))
+        per_rank = None
+        if dist is not None:
+            # every rank's own rate and its share of time stalled on the trajectory all-gather
+            mine = torch.tensor([sim / dt, gather_wait_ms / (1e3 * dt)], dtype=torch.float64, device=device)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = {"env_steps_per_s": [float(a[0]) for a in allr], "allgather_wait_share": [float(a[1]) for a in allr]}
         if dist is not None:
             tt = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -375,7 +404,7 @@ def main():
                        "note": "same env loop with the actions in host numpy arrays and every TimeStep field "
                                "copied back to numpy (pageable memory, synchronous copies) each step"}
 
-        return dict(host_io=host_io, dt=dt, kms=kms, nl=nl, sms=sms, snl=snl, senvs=senvs, warn=warn_or, finite=finite, phys=phys,
+        return dict(per_rank=per_rank, host_io=host_io, dt=dt, kms=kms, nl=nl, sms=sms, snl=snl, senvs=senvs, warn=warn_or, finite=finite, phys=phys,
                     m=m, E=E, key_ids=base_env.task.scene.key_joint_ids, sim=sim_all, n_spread=n_spread, events=events,
                     graphed=bool(use_graph and env.graph_captured), stagger=stagger)
 
@@ -412,16 +441,20 @@ def main():
                 "envs_per_gpu": E, "substeps_per_step": args.substeps, "nv": int(m.nv), "nu": int(m.nu),
                 "fingertips": ("capsule (primitive_fingertip_collisions=True) stand-in" if args.fingertips == "primitive"
                                else "26-vertex convex-hull stand-in for the f_distal_pst mesh, MPR narrow phase "
-                                    "(primitive_fingertip_collisions=False, the notebook's setting)"), "mj_steps_per_s": value * args.substeps,
+                                    "(primitive_fingertip_collisions=False, the reference's default)"), "mj_steps_per_s": value * args.substeps,
                 "simulated_env_steps": r["sim"], "reset_steps_not_counted": world * E * args.steps - r["sim"],
                 "episode_phase": ("staggered: env e is (e mod 158) steps into its episode, auto-reset per env "
                                   "(untimed %d-step prologue)" % r["n_spread"]) if r["stagger"] else "lockstep",
                 "trajectory_gather": bool(world > 1 and args.gather), "hipgraph_step": r["graphed"],
             },
+            "per_rank": r["per_rank"],
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(E, args.precision, r["senvs"]),
-                "kernel": "rp_stage_kernel<%s, 1> (mj_step2: constraint solver + Euler, one substep of all envs)" % tname,
+                "kernel": "rp_lean_solver_kernel<%s> (mj_step2: constraint solver + Euler, one substep of all envs; the "
+                          "probe brackets it together with the full-capacity rp_stage_kernel<%s, 1> that takes the envs "
+                          "outside the light capacity class)" % (tname, tname),
+                "valu": _valu_profile(args.precision),
                 "kernel_avg_ms": sms, "kernel_launches_sampled": snl,
                 "envs_per_launch": r["senvs"],
                 "algorithmic_bytes_per_launch": algo,
@@ -436,8 +469,8 @@ def main():
                         "envs_per_launch is the mean over the sampled launches; a slice's launch shares the GPU with the other slice's "
                         "kernels, so its duration is not exclusive and achieved/frac drop when slices are on although the step "
                         "gets faster -- compare step_sequence_avg_ms); one rp_step = 1 + 2*substeps launches "
-                        "per slice (rp_stage_kernel<T,0> position/velocity stage, <T,1> solver stage).  The path is instruction-issue / latency bound "
-                        "(one wave per env), not HBM bound: see DESIGN.md 6",
+                        "per slice (rp_stage_kernel<T,0> position/velocity stage, solver stage).  The path is instruction-issue / latency bound "
+                        "(one wave per env, two waves per SIMD), not HBM bound: `valu` carries the figures that bound it, see DESIGN.md 6",
             },
             "sanity": {"warn_flags_or": r["warn"], "finite": r["finite"], **(r["events"] or {})},
             "parity": "fp64 engine vs the CPU oracle: see cpu_baseline_parity (measured live when the CPU leg runs) and "
@@ -459,12 +492,14 @@ def main():
             # config 2 is run with both fingertip colliders
             other = "hull" if args.fingertips == "primitive" else "primitive"
             rh = measure(args.precision, 158, 10, fingertips=other)
+            out["value_" + other + "_fingertips"] = rh["sim"] / rh["dt"]
+            out["value_" + args.fingertips + "_fingertips"] = value
             out.setdefault("aux", {})[other + "_fingertips"] = {
                 "value": rh["sim"] / rh["dt"], "unit": "env-steps/s", "steps": 158, "kernel_avg_ms": rh["sms"],
                 "envs_per_launch": rh["senvs"], "step_sequence_avg_ms": rh["kms"],
                 "sanity": {"warn_flags_or": rh["warn"], "finite": rh["finite"], **(rh["events"] or {})},
                 "note": "same staggered workload with the other fingertip collider ("
-                        + ("the stand-in convex hulls through MPR: the notebook's mesh setting" if other == "hull"
+                        + ("the stand-in convex hulls through MPR: the reference's default, meshes" if other == "hull"
                            else "capsules: primitive_fingertip_collisions=True") + ")"}
             del rh
         if args.aux_fp32 and args.precision == 64 and world == 1 and args.config == 2:
@@ -472,7 +507,8 @@ def main():
             s32, w32 = min(args.steps, 80), min(args.warmup, 10)
             r32 = measure(32, s32, w32)
             out.setdefault("aux", {})["fp32_engine"] = {
-                "value": r32["sim"] / r32["dt"], "unit": "env-steps/s", "kernel_avg_ms": r32["kms"],
+                "value": r32["sim"] / r32["dt"], "unit": "env-steps/s", "kernel_avg_ms": r32["sms"],
+                "step_sequence_avg_ms": r32["kms"],
                 "warn_flags_or": r32["warn"],
                 "note": "same workload on the fp32 build; meets 1e-4 on smooth key-press scenarios only"}
             phys = r32["phys"]
@@ -499,22 +535,52 @@ def cpu_leg(args, m, phys, key_ids, cfg):
     else:
         rng = np.random.default_rng(12345)
         ctrl_seq = lo + rng.uniform(0, 1, size=(1000, m.nu)) * (hi - lo)
-    # bounded sample sized for ~15 s of host work: many short rollouts from reset (the transient,
-    # contact-changing part of an episode), each env holding a different row of the action stream
-    nenv_cpu = cores * 160
-    nstep = 400
-    rows = (40 + 7 * np.arange(nenv_cpu)) % ctrl_seq.shape[0]
-    cc = np.ascontiguousarray(ctrl_seq[rows])
-    secs, _ = orc.bench(nenv_cpu, nstep, cc, cores)
+    # bounded sample of the SAME workload: every CPU env replays the config's action stream -- a new row
+    # every control step (10 mj_steps), every env at its own phase of the stream, as the staggered GPU batch does.
+    # Sized for ~12 s of host work from a short calibration run (the hull narrow phase makes the oracle slower).
+    nstep, hold = 400, args.substeps
+    T = ctrl_seq.shape[0]
+    cal_env = cores * 4
+    secs_cal, _ = orc.bench_seq(cal_env, 100, ctrl_seq, (7 * np.arange(cal_env)) % T, hold, cores)
+    rate = cal_env * 100 / max(secs_cal, 1e-3)
+    nenv_cpu = int(min(cores * 160, max(cores * 8, 12.0 * rate / nstep)))
+    secs, _ = orc.bench_seq(nenv_cpu, nstep, ctrl_seq, (7 * np.arange(nenv_cpu)) % T, hold, cores)
     out["cpu_baseline"] = {
         "value": nenv_cpu * nstep / args.substeps / secs, "unit": "env-steps/s", "cores": cores, "kind": "port",
-        "sample": f"{nenv_cpu} envs x {nstep} mj_steps from reset ({secs:.1f} s of host time), fp64 C oracle (CPU "
-                  f"restatement, not MuJoCo), OpenMP {cores} threads, each env holds one row of the config's action "
-                  "stream as ctrl",
+        "sample": f"{nenv_cpu} envs x {nstep} mj_steps ({secs:.1f} s of host time), fp64 C oracle (CPU restatement, not "
+                  f"MuJoCo), OpenMP {cores} threads; every env replays the config's action stream from its own row, "
+                  "one row per control step (10 mj_steps), from the reset state",
         "mj_steps_per_s": nenv_cpu * nstep / secs,
     }
-    # ---- parity on this config's own action stream (2 envs, precision of `value`)
+    # ---- parity on this config's own action stream (2 envs, precision of `value`), for the collider of `value` and,
+    # on config 2, for the other one
+    note = ("engine (2 envs, same precision as value) vs the CPU oracle on this config's action stream; free running: "
+            "rel = |dq| / max(|q_cpu|, 1e-2); teacher forced (the contract): every mj_step restarts from the oracle "
+            "state, error relative to the step's largest velocity change.  The free-running figure measures how "
+            "chaotic the trajectory is, not the engine: with capsule fingertips the scripted replay stays under the "
+            "1e-4 bar; with hull fingertips the portal refinement stops on a 1e-6 tolerance, so a rounding-level "
+            "difference can add or drop one refinement step and move a contact distance by up to 1e-6 -- ten orders of "
+            "magnitude above rounding -- and the free-running curves separate (random policies likewise)")
+    out["cpu_baseline_parity"] = dict(parity_block(args, m, key_ids, ctrl_seq), fingertips=args.fingertips, note=note)
+    if args.config == 2:
+        from robopianist_amd.model import scene as _scene
+        other = "primitive" if args.fingertips == "hull" else "hull"
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            so = _scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=(other == "primitive"))
+        out["cpu_baseline_parity_" + other + "_fingertips"] = dict(
+            parity_block(args, so.model, so.key_joint_ids, load_actions(so.model)[0]), fingertips=other)
+    return out
+
+
+
+def parity_block(args, m, key_ids, ctrl_seq):
+    """Engine (2 envs, precision of `value`) vs the CPU oracle on one action stream: free running over 1000 mj_steps
+    and teacher forced over 300."""
+    from oracle.rp_oracle import Oracle
+    from robopianist_amd import engine as _eng
     chk = _eng.BatchedPhysics(m, key_ids, n_envs=2, precision=args.precision)
+    orc = Oracle(m, chk.blob)
     is_key = np.zeros(int(m.nv), bool); is_key[np.asarray(key_ids)] = True
     is_arm = np.array(["forearm" in n for n in m.names["joint"]])
     groups = {"keys": is_key, "forearms": is_arm & ~is_key, "fingers_and_wrists": ~is_key & ~is_arm}
@@ -548,17 +614,11 @@ def cpu_leg(args, m, phys, key_ids, cfg):
         tf_worst = max(tf_worst, float(dv / max(np.abs(orc.qvel - v0).max(), 1e-9)))
         ncon_mismatch += int(chk.get(_eng.NCON)[0] != orc.ncon)
         ncon_max = max(ncon_max, int(orc.ncon))
-    out["cpu_baseline_parity"] = {
+    return {
         "max_rel_qpos_error_1000_mj_steps": worst, "max_abs_qpos_error_1000_mj_steps": worst_abs,
         "bar": 1e-4, "rel_error_at_mj_step": curve, "max_rel_error_by_dof_group": gmax,
         "teacher_forced_worst_rel_dv_300_mj_steps": tf_worst, "teacher_forced_bar": 1e-9 if args.precision == 64 else 5e-3,
-        "teacher_forced_contact_count_mismatches": ncon_mismatch, "teacher_forced_max_contacts": ncon_max,
-        "note": "engine (2 envs, same precision as value) vs the CPU oracle on this config's action stream; free "
-                "running: rel = |dq| / max(|q_cpu|, 1e-2) (random policies are chaotic: the free-running figure is "
-                "reported, the bar applies to the scripted replay); teacher forced: every mj_step restarts from the "
-                "oracle state, error relative to the step's largest velocity change"}
-    return out
-
+        "teacher_forced_contact_count_mismatches": ncon_mismatch, "teacher_forced_max_contacts": ncon_max}
 
 if __name__ == "__main__":
     main()

@@ -1727,6 +1727,35 @@ double rpo_bench(const rpo_model* m, int nenv, int nstep, const double* ctrl, in
   return t1 - t0;
 }
 
+/* Like rpo_bench, but every env REPLAYS an action stream: env e applies row (start[e] + s / hold) mod T of
+ * ctrl_seq [T][nu] at mj_step s (hold = mj_steps per control step), i.e. the benchmark's own workload -- rows
+ * advancing every control step, every env at its own episode phase -- instead of one constant row. */
+double rpo_bench_seq(const rpo_model* m, int nenv, int nstep, const double* ctrl_seq, int T, int hold,
+                     const int* start, int nthreads, double* qpos_out) {
+  rpo_data** ds = (rpo_data**)calloc(nenv, sizeof(rpo_data*));
+  for (int e = 0; e < nenv; e++) { ds[e] = rpo_data_new(m); rpo_reset(m, ds[e]); }
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+  (void)nthreads;
+#endif
+  double t0 = now_s();
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int e = 0; e < nenv; e++)
+    for (int s = 0; s < nstep; s++) {
+      if (s % hold == 0)
+        memcpy(ds[e]->ctrl, ctrl_seq + (size_t)((start[e] + s / hold) % T) * m->nu, sizeof(double) * m->nu);
+      rpo_step(m, ds[e]);
+    }
+  double t1 = now_s();
+  for (int e = 0; e < nenv; e++) {
+    if (qpos_out) memcpy(qpos_out + (size_t)e*m->nv, ds[e]->qpos, sizeof(double)*m->nv);
+    rpo_data_free(ds[e]);
+  }
+  free(ds);
+  return t1 - t0;
+}
+
 /* ---- test hook (rp_oracle.h): PrimalSearch on a hand-made one-dimensional problem */
 double rpo_debug_line_search(int n, const int* type, const double* jar, const double* jv, const double* D,
                              const double* floss, const double* R, const double quad[3], double gtol,

@@ -71,6 +71,9 @@ int rpo_warnings(const rpo_data* d);
  * seconds of wall time. */
 double rpo_bench(const rpo_model* m, int nenv, int nstep, const double* ctrl,
                  int nthreads, double* qpos_out /* [nenv][nq] or NULL */);
+/* every env replays ctrl_seq [T][nu]: row (start[e] + s / hold) mod T at mj_step s */
+double rpo_bench_seq(const rpo_model* m, int nenv, int nstep, const double* ctrl_seq, int T, int hold,
+                     const int* start, int nthreads, double* qpos_out);
 
 /* Test hook: the line search of the Newton solver (PrimalSearch as restated in rp_oracle.c) on a
  * hand-made one-dimensional problem  phi(alpha) = q0 + q1 alpha + q2 alpha^2 + sum_i row_i(jar_i + alpha jv_i)

@@ -58,6 +58,9 @@ def lib():
         L.rpo_bench.restype = ctypes.c_double
         L.rpo_bench.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                 ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.rpo_bench_seq.restype = ctypes.c_double
+        L.rpo_bench_seq.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         _lib = L
     return _lib
 
@@ -135,6 +138,17 @@ class Oracle:
     def step(self, n: int = 1):
         for _ in range(n):
             self._L.rpo_step(self._model, self._data)
+
+    def bench_seq(self, nenv, nstep, ctrl_seq, start, hold=10, nthreads=0):
+        """Every env replays `ctrl_seq` [T, nu] from its own row start[e], one row per `hold` mj_steps.
+        Returns (seconds, qpos[nenv, nv])."""
+        out = np.zeros((nenv, self.m.nv))
+        c = np.ascontiguousarray(ctrl_seq, np.float64)
+        st = np.ascontiguousarray(start, np.int32)
+        assert c.shape[1] == self.m.nu and st.shape == (nenv,)
+        t = self._L.rpo_bench_seq(self._model, nenv, nstep, c.ctypes.data, c.shape[0], hold, st.ctypes.data,
+                                  nthreads, out.ctypes.data)
+        return t, out
 
     def bench(self, nenv, nstep, ctrl=None, nthreads=0):
         """Returns (seconds, qpos[nenv, nv])."""

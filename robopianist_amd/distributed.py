@@ -48,24 +48,28 @@ def rank_seed(seed: int, rank: int) -> int:
     return int(seed) + 1000 * int(rank)
 
 
-def pack_trajectory_record(qpos, reward, discount, step_type, key_activation):
-    """Compact per-env record (§8e): qpos | reward | discount | step_type | activation
-    bits packed in three 32-bit words, as one float32 row per env."""
+def pack_trajectory_record(qpos, reward, discount, step_type, key_activation, dtype=None):
+    """Compact per-env record (§8e): qpos | reward | discount | step_type | activation bits, one row per env.
+    `dtype`: torch.float32 (half the xGMI bytes; qpos rounded to single) or torch.float64 (the engine's
+    precision survives the gather); default = the dtype of `qpos`.  The activation bits travel as raw bytes
+    in the last 3 (float32) / 2 (float64) columns."""
+    dtype = dtype or (qpos.dtype if qpos.dtype in (torch.float32, torch.float64) else torch.float32)
     E, nk = qpos.shape[0], key_activation.shape[1]
-    # bits -> 12 bytes per env (little-endian inside each 32-bit word), a handful of launches
+    nbytes = 12 if dtype == torch.float32 else 16
+    # bits -> bytes (little-endian inside each word), a handful of launches
     byte_w = (1 << torch.arange(8, device=key_activation.device, dtype=torch.int32))
-    padded = torch.zeros((E, 96), dtype=torch.int32, device=key_activation.device)
+    padded = torch.zeros((E, 8 * nbytes), dtype=torch.int32, device=key_activation.device)
     padded[:, :nk] = key_activation
-    by = (padded.view(E, 12, 8) * byte_w).sum(2).to(torch.uint8)          # [E, 12]
-    bits = by.contiguous().view(torch.float32)                              # [E, 3]
-    return torch.cat([qpos.float(), reward.float().reshape(E, 1), discount.float().reshape(E, 1),
-                      step_type.float().reshape(E, 1), bits], dim=1).contiguous()
+    by = (padded.view(E, nbytes, 8) * byte_w).sum(2).to(torch.uint8)        # [E, nbytes]
+    bits = by.contiguous().view(dtype)                                        # [E, 3] or [E, 2]
+    return torch.cat([qpos.to(dtype), reward.to(dtype).reshape(E, 1), discount.to(dtype).reshape(E, 1),
+                      step_type.to(dtype).reshape(E, 1), bits], dim=1).contiguous()
 
 
 def unpack_key_activation(record: torch.Tensor, nv: int, n_keys: int = 88) -> torch.Tensor:
-    words = record[:, nv + 3: nv + 6].contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
-    shifts = torch.arange(32, device=record.device, dtype=torch.int64)
-    bits = ((words[:, :, None] >> shifts) & 1).reshape(record.shape[0], 96)
+    raw = record[:, nv + 3:].contiguous().view(torch.uint8).to(torch.int64)    # [E, 12 or 16] bytes
+    shifts = torch.arange(8, device=record.device, dtype=torch.int64)
+    bits = ((raw[:, :, None] >> shifts) & 1).reshape(record.shape[0], -1)
     return bits[:, :n_keys].bool()
 
 

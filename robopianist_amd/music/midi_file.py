@@ -266,30 +266,25 @@ class NoteTrajectory:
         piano_roll = sequence_to_pianoroll(
             seq, frames_per_second=1 / dt, min_pitch=consts.MIN_MIDI_PITCH,
             max_pitch=consts.MAX_MIDI_PITCH, onset_window=0)
-        notes: List[List[PianoNote]] = []
-        for t, timestep in enumerate(piano_roll.active_velocities):
-            notes_in_timestep: List[PianoNote] = []
-            for index in np.nonzero(timestep)[0]:
-                if (t > 0 and piano_roll.active_velocities[t - 1][index]
-                        and piano_roll.onset_velocities[t][index]):
-                    # repeated note: force a release between consecutive presses
-                    continue
-                velocity = int(round(timestep[index] * consts.MAX_VELOCITY))
-                fingering = int(piano_roll.fingerings[t, index])
-                notes_in_timestep.append(PianoNote.create(int(index), velocity, fingering))
-            notes.append(notes_in_timestep)
-        sustains: List[int] = []
-        prev_sustain = 0
-        for timestep in piano_roll.control_changes:
-            event = timestep[consts.SUSTAIN_PEDAL_CC_NUMBER]
-            if 1 <= event <= consts.SUSTAIN_PEDAL_CC_NUMBER:
-                sustain = 0
-            elif consts.SUSTAIN_PEDAL_CC_NUMBER + 1 <= event <= consts.MAX_CC_VALUE + 1:
-                sustain = 1
-            else:
-                sustain = prev_sustain
-            sustains.append(sustain)
-            prev_sustain = sustain
+        act = np.asarray(piano_roll.active_velocities)
+        ons = np.asarray(piano_roll.onset_velocities)
+        # a key that was already down in the previous frame and is struck again in this one is left out of this frame:
+        # consecutive presses of one key need a release in between (reference: music/midi_file.py:335-345)
+        held = np.zeros_like(act, dtype=bool)
+        held[1:] = (act[:-1] != 0) & (ons[1:] != 0)
+        keep = (act != 0) & ~held
+        vel = np.rint(act * consts.MAX_VELOCITY).astype(np.int64)
+        fing = np.asarray(piano_roll.fingerings).astype(np.int64)
+        notes: List[List[PianoNote]] = [
+            [PianoNote.create(int(k), int(vel[t, k]), int(fing[t, k])) for k in np.flatnonzero(keep[t])]
+            for t in range(act.shape[0])]
+        # sustain pedal per frame: control value + 1 in 1..64 releases it, 65..128 presses it, 0 (no event in the
+        # frame) keeps the last state -- a forward fill of the frames that carry an event
+        ev = np.asarray(piano_roll.control_changes)[:, consts.SUSTAIN_PEDAL_CC_NUMBER].astype(np.int64)
+        has = (ev >= 1) & (ev <= consts.MAX_CC_VALUE + 1)
+        state = (ev > consts.SUSTAIN_PEDAL_CC_NUMBER).astype(np.int64)
+        last = np.maximum.accumulate(np.where(has, np.arange(len(ev)), -1))
+        sustains: List[int] = [int(v) for v in np.where(last >= 0, state[np.maximum(last, 0)], 0)]
         return notes, sustains
 
     def __len__(self) -> int:

@@ -34,6 +34,14 @@ def test_trajectory_record_round_trip():
     assert rec.shape == (E, nv + 6) and rec.dtype == torch.float32
     assert torch.equal(rec[:, :nv], qpos)
     assert torch.equal(rpd.unpack_key_activation(rec, nv), act)
+    # fp64 state keeps its precision through the record (the default follows qpos)
+    q64 = torch.randn(E, nv, dtype=torch.float64)
+    rec64 = rpd.pack_trajectory_record(q64, torch.arange(E), torch.ones(E), torch.full((E,), 2), act)
+    assert rec64.shape == (E, nv + 5) and rec64.dtype == torch.float64
+    assert torch.equal(rec64[:, :nv], q64) and torch.equal(rec64[:, nv + 2], torch.full((E,), 2.0, dtype=torch.float64))
+    assert torch.equal(rpd.unpack_key_activation(rec64, nv), act)
+    rec32 = rpd.pack_trajectory_record(q64, torch.arange(E), torch.ones(E), torch.full((E,), 2), act, dtype=torch.float32)
+    assert rec32.dtype == torch.float32 and torch.equal(rpd.unpack_key_activation(rec32, nv), act)
 
 
 def _free_port():
