@@ -157,7 +157,7 @@ int rp_set_stream(rp_engine* e, void* hip_stream);
  * Accesses must be ordered on the engine's stream. */
 int rp_field_ptr(rp_engine* e, rp_field f, void** ptr, size_t* bytes);
 int rp_n_envs(const rp_engine* e);
-int rp_dim(const rp_engine* e, const char* name); /* "nv","nu","nsite","ntree","nkey","nlink" */
+int rp_dim(const rp_engine* e, const char* name); /* "nv","nu","nsite","ntree","nkey","nlink","maxdepth","precision"; "rm_rows","rm_cols" = per-env shape of RP_DEBUG_MASS_ROWS */
 /* Average device time (ms) of one rp_step launch sequence (1 + 2*n_substeps kernels)
  * since the last call, measured with HIP events on the engine stream; also returns
  * the number of sequences timed. */

@@ -139,6 +139,7 @@ struct Blob {
 struct EngineBase {
   virtual ~EngineBase() {}
   int nenv = 0, device = 0, precision = 32;
+  int rm_rows = 0, rm_cols = 0;   // shape of RP_DEBUG_MASS_ROWS per env (the kernel build in use)
   int nv = 0, nu = 0, nsite = 0, ntree = 0, nkey = 0, nlink = 0, maxdepth = 0;
   hipStream_t stream = nullptr;
   // ring of HIP event pairs bracketing every step-kernel launch on `stream`
@@ -384,6 +385,7 @@ struct Engine : EngineBase {
     S.ncon = dalloc<int>(E); S.contact_geoms = dalloc<int>(E * RPK_NCOUT * 2);
     S.warn = dalloc<int>(E); S.solver_iter = dalloc<int>(E);
     B.RM = dalloc<T>(E * RPK_NLX(md()) * (md() + 1));
+    rm_rows = RPK_NLX(md()); rm_cols = md() + 1;
     B.lanef = dalloc<T>(E * RPK_NLF * 64);
     B.lanei = dalloc<int>(E * RPK_NLI * 64);
     B.hdr = dalloc<int>(E * 8);
@@ -489,7 +491,9 @@ struct Engine : EngineBase {
         dmask = d_mask;
       }
     }
-    hipLaunchKernelGGL(rp_reset_kernel<T>, dim3(nenv), dim3(64), 0, stream, S, d_qpos0, dmask, nv, nu, d_valid);
+    RpState<T> sr = S;
+    sr.sens_torque = sensors_on ? d_sens_torque : nullptr; sr.sens_touch = sensors_on ? d_sens_touch : nullptr;
+    hipLaunchKernelGGL(rp_reset_kernel<T>, dim3(nenv), dim3(64), 0, stream, sr, d_qpos0, dmask, nv, nu, nsite, d_valid);
     HIP_OK(hipGetLastError());
     return 0;
   }
@@ -815,6 +819,8 @@ int rp_dim(const rp_engine* e, const char* name) {
   if (!strcmp(name, "nlink")) return b->nlink;
   if (!strcmp(name, "maxdepth")) return b->maxdepth;
   if (!strcmp(name, "precision")) return b->precision;
+  if (!strcmp(name, "rm_rows")) return b->rm_rows;
+  if (!strcmp(name, "rm_cols")) return b->rm_cols;
   return -1;
 }
 int rp_kernel_time(rp_engine* e, double* avg_ms, int* n_launches) {

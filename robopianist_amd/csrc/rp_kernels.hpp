@@ -116,7 +116,7 @@ template <typename T> struct Rows { T fr, lim[3], con[4]; };
 
 // physics.reset() for the envs selected by a device-side mask (null = all).
 template <typename T>
-__global__ void rp_reset_kernel(RpState<T> S, const T* qpos0, const unsigned char* mask, int nv, int nu,
+__global__ void rp_reset_kernel(RpState<T> S, const T* qpos0, const unsigned char* mask, int nv, int nu, int nsite,
                                 unsigned char* stage_valid) {
   const int env = blockIdx.x;
   if (mask && !mask[env]) return;
@@ -129,6 +129,10 @@ __global__ void rp_reset_kernel(RpState<T> S, const T* qpos0, const unsigned cha
   }
   for (int i = threadIdx.x; i < nu; i += blockDim.x) S.ctrl[(size_t)env * nu + i] = 0;
   if (threadIdx.x == 0) { S.time[env] = 0; S.warn[env] = 0; }
+  // acceleration-stage sensors: no reading of the previous episode survives a reset (the first observation of the
+  // new episode reports zero until the first step has run the sensor stage)
+  if (S.sens_torque) for (int i = threadIdx.x; i < nv; i += blockDim.x) S.sens_torque[(size_t)env * nv + i] = 0;
+  if (S.sens_touch) for (int i = threadIdx.x; i < nsite; i += blockDim.x) S.sens_touch[(size_t)env * nsite + i] = 0;
 }
 
 // ============================================================================

@@ -149,8 +149,7 @@ class BatchedPhysics:
             TREE_OFFSET: (self.ntree, 3), ACTIVE: (), SENSOR_TORQUE: (self.nv,), SENSOR_TOUCH: (self.nsite,),
             ENV_COST: (), DEBUG_HANDOVER_HDR: (8,),
         }
-        deep = self.dim("nlink") > 52 or self.dim("maxdepth") > 9
-        self._shapes[DEBUG_MASS_ROWS] = ((60, 14) if deep else (52, 10))
+        self._shapes[DEBUG_MASS_ROWS] = (self.dim("rm_rows"), self.dim("rm_cols"))   # (the kernel build in use decides)
         self._int_fields = {NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER, ACTIVE, ENV_COST, DEBUG_HANDOVER_HDR}
         if self_check is None:
             self_check = os.environ.get("RP_SKIP_SELF_CHECK", "0") != "1"

@@ -110,7 +110,7 @@ class Environment:
         # the action of an env that is being reset is discarded (dm_env): it must not leak into ctrl /
         # the sustain latch, which the FIRST observation reports as 0 after reset()
         action = torch.as_tensor(action, device=phys.device, dtype=phys.dtype).reshape(self._n_envs, -1)
-        action = action * active[:, None].to(action.dtype)
+        action = torch.where(active[:, None], action, torch.zeros_like(action))   # (a NaN times zero would survive a product)
         fused = task.fused_advance_for(phys) if hasattr(task, "fused_advance_for") else None
         if fused is not None:
             # HIP task layer (include/rp_task.h): the episode reset of the flagged envs, the

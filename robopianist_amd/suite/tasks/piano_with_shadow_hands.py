@@ -83,7 +83,7 @@ class PianoWithShadowHands(base.PianoTask):
         # state does -- reward 0, discount 0 -- instead of stepping on with silently altered dynamics
         from robopianist_amd import engine as _eng
         self.fatal_warn_mask = _eng.WARN_BADSTATE | (
-            (_eng.WARN_CONTACT_FULL | _eng.WARN_KEYSLOT_FULL | _eng.WARN_DENSE_FULL) if overflow_termination else 0)
+            (_eng.WARN_CONTACT_FULL | _eng.WARN_KEYSLOT_FULL | _eng.WARN_DENSE_FULL | _eng.WARN_WORK_FULL) if overflow_termination else 0)
         self._fatal_count = None
         self._use_fused_rewards = True   # set False to force the torch reward functions
         self._fused_rewards = None
@@ -307,6 +307,9 @@ class PianoWithShadowHands(base.PianoTask):
         self._bind_hands()
         self._bind_task_state()
         self._fatal_count = torch.zeros(n_envs, device=physics.device, dtype=torch.long)
+        self._physics = physics
+        if any(n.split("/")[1] in ("joints_torque", "fingertip_force") for n in getattr(self, "_extra_observables", ())):
+            physics.enable_acc_sensors()
         if self._prefetch:
             # both slots of every env are filled before the first step, whether or not the caller
             # starts with an explicit reset()
@@ -681,6 +684,10 @@ class PianoWithShadowHands(base.PianoTask):
         if not enabled:
             extra = [n for n in extra if n != name]
         self._extra_observables = extra
+        # the acceleration-stage sensors are switched on here, not at the first read (which would allocate and
+        # synchronise in the middle of a step, and return readings the sensor stage never filled)
+        if enabled and name.split("/")[1] in ("joints_torque", "fingertip_force") and getattr(self, "_physics", None) is not None:
+            self._physics.enable_acc_sensors()
 
     def _optional_observable(self, physics, name):
         owner, what = name.split("/")

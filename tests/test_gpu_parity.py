@@ -451,6 +451,32 @@ def test_teacher_forced_fp64_hull_fingertips_with_four_forearm_dofs():
     assert phys.warn_flags.max() == 0 and worst < 1e-9
 
 
+def test_state_writes_across_slice_count_changes_are_bit_identical(two_hand_scene):
+    """The automatic slice mode steps the batch with 1 2 2 1 1 2 2 1 slices over its first eight steps, and the
+    cost-ordered launch keeps a permutation from the previous step: a state write (which makes every hand-over
+    stale) on exactly those steps must give the plain engine's bits -- every slice rebuilds the hand-over of ITS
+    envs, in index order, before its solver stage consumes it."""
+    from robopianist_amd import engine
+    si = two_hand_scene
+    m = si.model
+    E = 1100
+    ctrl = _replay_ctrl(si)
+    rng = np.random.default_rng(2)
+    gain = 1 + 0.1 * rng.standard_normal((E, 1))
+    ref = engine.BatchedPhysics(m, si.key_joint_ids, n_envs=E, precision=64)
+    p = engine.BatchedPhysics(m, si.key_joint_ids, n_envs=E, precision=64)
+    p.set_stream_slices(0); p.set_cost_ordered_launch(True)
+    for t in range(12):
+        c = ctrl[10 * (t + 20)][None, :] * gain
+        kick = 0.05 * rng.standard_normal((E, m.nv)) * (rng.uniform(size=(E, 1)) < 0.3)
+        for q in (ref, p):
+            q.set(engine.CTRL, c)
+            q.set(engine.QVEL, q.qvel + kick)      # every env's hand-over is stale now
+            q.step(10)
+        assert np.array_equal(ref.qpos, p.qpos) and np.array_equal(ref.qvel, p.qvel), t
+    assert ref.get(engine.NCON).max() > 0
+
+
 def torch_sync():
     import torch
     torch.cuda.synchronize()
