@@ -363,6 +363,7 @@ struct Engine : EngineBase {
     if (b.has("eng_link_bodylink")) PI(link_bodylink, "eng_link_bodylink");
     if (b.has("eng_mesh_vert")) {
       PF(mesh_vert, "eng_mesh_vert"); PI(geom_vertadr, "eng_geom_vertadr"); PI(geom_vertnum, "eng_geom_vertnum");
+      if (b.has("eng_geom_vertflip")) PI(geom_vertflip, "eng_geom_vertflip");
       for (int t : b.i("eng_geom_type")) if (t == GEOM_MESH_) mesh = true;
     }
 #undef PF

@@ -21,20 +21,6 @@
     (rc_)[0] = o_[0]; (rc_)[1] = o_[1]; (rc_)[2] = o_[2];                                       \
     return n_; }()
 #endif
-// convex pairs with a hull: arguments copied into memory-resident geom records (a real call, made by the whole
-// wave: lanes with `act_` hold a pair)
-#define RPK_CONVEX(rc_, act_, tA_, pA_, mA_, sA_, gA_, tB_, pB_, mB_, sB_, gB_) [&]() -> int {      \
-    CGeom<T> a_, b_; RawCon<T> o_;                                                              \
-    a_.type = (tA_); b_.type = (tB_);                                                           \
-    _Pragma("unroll") for (int i_ = 0; i_ < 3; i_++) { a_.pos[i_] = (pA_)[i_]; b_.pos[i_] = (pB_)[i_]; a_.size[i_] = (sA_)[i_]; b_.size[i_] = (sB_)[i_]; } \
-    _Pragma("unroll") for (int i_ = 0; i_ < 9; i_++) { a_.mat[i_] = (mA_)[i_]; b_.mat[i_] = (mB_)[i_]; }                     \
-    a_.nvert = ((act_) && (gA_) >= 0 && a_.type == GEOM_MESH_) ? M.geom_vertnum()[(gA_) >= 0 ? (gA_) : 0] : 0; \
-    b_.nvert = ((act_) && (gB_) >= 0 && b_.type == GEOM_MESH_) ? M.geom_vertnum()[(gB_) >= 0 ? (gB_) : 0] : 0; \
-    a_.vadr = a_.nvert ? M.geom_vertadr()[(gA_) >= 0 ? (gA_) : 0] : 0;                           \
-    b_.vadr = b_.nvert ? M.geom_vertadr()[(gB_) >= 0 ? (gB_) : 0] : 0;                           \
-    const int n_ = convex_mpr_wave(&o_, &a_, &b_, M.mesh_vert(), (act_));                       \
-    (rc_)[0] = o_;                                                                              \
-    return n_; }()
 namespace rpk {
 // ----------------------------------------------------------------- shared memory
 // LDS budget drives occupancy (fp64: 40.5 KB -> 4 workgroups per CU).  Scratch of the
@@ -1306,31 +1292,48 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
     }
     PROF(10);
     // ---- spatial inertia and motion axis about the tree reference point [MJ: mj_comPos]
-    T cin[10];
-    {
-      T t[3], A9[9], dd[3];
-      mat_vec(t, xm, lipos);
+    // (the link's own spatial inertia is formed twice from the link frame in LDS -- here for the composite
+    // inertias, and again after the collision phase for the bias forces -- with the same arithmetic, hence the
+    // same bits: ten doubles carried across the collision phase instead were spilled inside its loops)
+    auto link_inertia = [&](T* cin) {
+      const T *p_ipos = fresh(M.link_ipos()), *p_inert = fresh(M.link_inertia()), *p_tref = fresh(M.tree_ref());
+      const T lm_ = isl ? fresh(M.link_mass())[L] : (T)0;
+      T xm_[9], xp_[3], ip_[3], in_[6], tr_[3];
 #pragma unroll
-      for (int k = 0; k < 3; k++) dd[k] = xp[k] + t[k] - tref[k];
+      for (int k = 0; k < 9; k++) xm_[k] = isl ? sm.xmat[L][k] : (k % 4 == 0 ? (T)1 : (T)0);
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        xp_[k] = isl ? sm.xpos[L][k] : (T)0; ip_[k] = isl ? p_ipos[3 * L + k] : (T)0;
+        tr_[k] = isl ? p_tref[3 * ltree + k] : (T)0;
+      }
+#pragma unroll
+      for (int k = 0; k < 6; k++) in_[k] = isl ? p_inert[6 * L + k] : (T)0;
+      T t[3], A9[9], dd[3];
+      mat_vec(t, xm_, ip_);
+#pragma unroll
+      for (int k = 0; k < 3; k++) dd[k] = xp_[k] + t[k] - tr_[k];
       // A = xm * Iloc (Iloc symmetric)
-      const T I9[9] = {linert[0], linert[3], linert[4], linert[3], linert[1], linert[5],
-                       linert[4], linert[5], linert[2]};
-      mat_mul(A9, xm, I9);
+      const T I9[9] = {in_[0], in_[3], in_[4], in_[3], in_[1], in_[5], in_[4], in_[5], in_[2]};
+      mat_mul(A9, xm_, I9);
       T Iw[6];  // xx yy zz xy xz yz of A * xm^T
-      Iw[0] = A9[0] * xm[0] + A9[1] * xm[1] + A9[2] * xm[2];
-      Iw[1] = A9[3] * xm[3] + A9[4] * xm[4] + A9[5] * xm[5];
-      Iw[2] = A9[6] * xm[6] + A9[7] * xm[7] + A9[8] * xm[8];
-      Iw[3] = A9[0] * xm[3] + A9[1] * xm[4] + A9[2] * xm[5];
-      Iw[4] = A9[0] * xm[6] + A9[1] * xm[7] + A9[2] * xm[8];
-      Iw[5] = A9[3] * xm[6] + A9[4] * xm[7] + A9[5] * xm[8];
-      T d2 = dot3(dd, dd);
-      cin[0] = Iw[0] + lmass * (d2 - dd[0] * dd[0]);
-      cin[1] = Iw[1] + lmass * (d2 - dd[1] * dd[1]);
-      cin[2] = Iw[2] + lmass * (d2 - dd[2] * dd[2]);
-      cin[3] = Iw[3] - lmass * dd[0] * dd[1];
-      cin[4] = Iw[4] - lmass * dd[0] * dd[2];
-      cin[5] = Iw[5] - lmass * dd[1] * dd[2];
-      cin[6] = lmass * dd[0]; cin[7] = lmass * dd[1]; cin[8] = lmass * dd[2]; cin[9] = lmass;
+      Iw[0] = A9[0] * xm_[0] + A9[1] * xm_[1] + A9[2] * xm_[2];
+      Iw[1] = A9[3] * xm_[3] + A9[4] * xm_[4] + A9[5] * xm_[5];
+      Iw[2] = A9[6] * xm_[6] + A9[7] * xm_[7] + A9[8] * xm_[8];
+      Iw[3] = A9[0] * xm_[3] + A9[1] * xm_[4] + A9[2] * xm_[5];
+      Iw[4] = A9[0] * xm_[6] + A9[1] * xm_[7] + A9[2] * xm_[8];
+      Iw[5] = A9[3] * xm_[6] + A9[4] * xm_[7] + A9[5] * xm_[8];
+      const T d2 = dot3(dd, dd);
+      cin[0] = Iw[0] + lm_ * (d2 - dd[0] * dd[0]);
+      cin[1] = Iw[1] + lm_ * (d2 - dd[1] * dd[1]);
+      cin[2] = Iw[2] + lm_ * (d2 - dd[2] * dd[2]);
+      cin[3] = Iw[3] - lm_ * dd[0] * dd[1];
+      cin[4] = Iw[4] - lm_ * dd[0] * dd[2];
+      cin[5] = Iw[5] - lm_ * dd[1] * dd[2];
+      cin[6] = lm_ * dd[0]; cin[7] = lm_ * dd[1]; cin[8] = lm_ * dd[2]; cin[9] = lm_;
+    };
+    {
+      T cin[10];
+      link_inertia(cin);
       if (jtype == JNT_SLIDE_) {
         cdofr[0] = cdofr[1] = cdofr[2] = 0;
         cdofr[3] = axw[0]; cdofr[4] = axw[1]; cdofr[5] = axw[2];
@@ -1408,7 +1411,8 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
       sm.gax[lane][3] = cap ? (float)M.geom_size()[3 * lane + 1] : 0.f;
       sm.grr[lane] = cap ? (float)M.geom_size()[3 * lane] : (float)M.geom_rbound()[lane];
     }
-    // geoms are sorted capsules first: box b is geom ncap + b
+    // geoms are sorted capsules first: box b is geom ncap + b; `boxmask`: the geoms that are boxes (not hulls)
+    const unsigned long long boxmask = __ballot(lane < M.ngeom && M.geom_type()[lane < M.ngeom ? lane : 0] == GEOM_BOX_);
     const int ncap = __popcll(__ballot(lane < M.ngeom && M.geom_type()[lane < M.ngeom ? lane : 0] == GEOM_CAPSULE_));
     if (lane >= ncap && lane < M.ngeom && lane - ncap < RPK_NBOXF) {
       const int gl = M.geom_link()[lane];
@@ -1516,8 +1520,13 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
 #endif
     int gen_phase = 0;
     while (true) {
+      // ---- drain rounds, in a loop of their own (until 64 candidates are pending or the masks are empty): the
+      // narrow phase below is the register-hungriest part of this kernel, and in one loop with it the
+      // allocator spilled the drain loop's own variables -- every round then paid scratch round trips
+      // (measured: 34 k cycles per mj_step in the capsule builds, 163 k in the hull builds)
+      while (gen_phase < 3 && nwork < 64) {
       // ---- one drain round: every lane contributes at most one candidate
-      if (gen_phase < 3) {
+      {
         const unsigned long long rem = gen_phase == 0 ? remA : (gen_phase == 1 ? remK0 : remK1);
         bool has = rem != 0ull;
         if (__ballot(has) == 0ull) gen_phase++;
@@ -1564,8 +1573,11 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
               // box against box: the full 15-axis separating-axis test in fp32 (0.1 mm allowance), so
               // that the fp64 box-box routine only ever runs for boxes that really touch.  (The vote is
               // taken by the whole wave, in uniform control flow; the test itself runs on the box-box lanes.)
+              // (true boxes only: a pair with a hull goes on with the three-axis test above -- the portal
+              // refinement drops a separated pair within its first two supports, and the fifteen-axis test is
+              // paid by the whole wave in every round that holds such a pair)
               const int ai = lane - ncap;
-              const bool abox = bbox && ai >= 0 && ai < RPK_NBOXF;
+              const bool abox = bbox && ai >= 0 && ai < RPK_NBOXF && ((boxmask >> lane) & 1) && ((boxmask >> bit) & 1);
               if (__builtin_amdgcn_ballot_w64(abox && has) != 0ull && abox) {
                 const float* ga_ = sm.gbox[ai];
                 float Rf[3][3], Qf[3][3], tf[3];
@@ -1617,11 +1629,9 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
           nwork += __popcll(mk);
         }
       }
-      const bool gen_done = gen_phase == 3;
-      if (!(nwork >= 64 || (gen_done && nwork > 0))) {
-        if (gen_done) break;
-        continue;
       }
+      PROF(23);   // (drain rounds: candidate prefilters)
+      if (nwork == 0) break;   // (the masks are empty and nothing is pending)
       WSYNC();
       // ---- narrow phase on the first min(64, nwork) candidates
       // [MJ: mjc_*, mj_contactParam, mj_makeImpedance]
@@ -1638,10 +1648,21 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
       // MESH builds: both kinds of hull pair (key box vs hull, hand geom vs hull) collect their arguments
       // here and meet at ONE call of the MPR routine below -- with a call in each branch a pass that holds
       // both kinds walks the (serial, one-lane-at-a-time) routine twice
+      // (the two geom records are memory-resident -- the routine is a real call -- and are filled where the pair
+      // is recognised: thirty doubles held in registers across the capsule / box code instead cost the MESH builds
+      // 150 k cycles of spills per mj_step)
       bool mpr = false, mpr_flip = false;
-      int mpr_tA = 0, mpr_gA = -1, mpr_gB = -1;
-      T mpr_pA[3] = {0, 0, 0}, mpr_mA[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, mpr_sA[3] = {0, 0, 0};
-      T mpr_pB[3] = {0, 0, 0}, mpr_mB[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, mpr_sB[3] = {0, 0, 0};
+      CGeom<T> mpr_a, mpr_b;
+      mpr_a.type = GEOM_BOX_; mpr_b.type = GEOM_BOX_; mpr_a.nvert = 0; mpr_b.nvert = 0; mpr_a.vadr = 0; mpr_b.vadr = 0;
+      mpr_a.flip = 0; mpr_b.flip = 0;
+      auto hull_of = [&](CGeom<T>& g, int type, int geom) {
+        const bool hull = type == GEOM_MESH_ && geom >= 0;
+        const int gi = geom >= 0 ? geom : 0;
+        g.type = type;
+        g.nvert = hull ? M.geom_vertnum()[gi] : 0;
+        g.vadr = hull ? M.geom_vertadr()[gi] : 0;
+        g.flip = hull ? M.geom_vertflip()[gi] : 0;
+      };
       if (w < nproc) {
         ga = sm.work[w][0]; gb = sm.work[w][1];
         int la = M.geom_link()[ga];
@@ -1668,11 +1689,12 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
           if (MESH && M.geom_type()[ga] == GEOM_MESH_) {
             // (box, hull) in geom-type order: the key is geom 1 of the pair; the engine keeps the hand
             // geom as side A of the contact, so the normal is turned around
-            mpr = true; mpr_flip = true; mpr_tA = GEOM_BOX_; mpr_gA = -1; mpr_gB = ga;
+            mpr = true; mpr_flip = true;
+            hull_of(mpr_a, GEOM_BOX_, -1); hull_of(mpr_b, GEOM_MESH_, ga);
 #pragma unroll
-            for (int i = 0; i < 3; i++) { mpr_pA[i] = bp[i]; mpr_sA[i] = M.key_half()[3 * k + i]; mpr_pB[i] = posA[i]; mpr_sB[i] = M.geom_size()[3 * ga + i]; }
+            for (int i = 0; i < 3; i++) { mpr_a.pos[i] = bp[i]; mpr_a.size[i] = M.key_half()[3 * k + i]; mpr_b.pos[i] = posA[i]; mpr_b.size[i] = M.geom_size()[3 * ga + i]; }
 #pragma unroll
-            for (int i = 0; i < 9; i++) { mpr_mA[i] = bm[i]; mpr_mB[i] = mA[i]; }
+            for (int i = 0; i < 9; i++) { mpr_a.mat[i] = bm[i]; mpr_b.mat[i] = mA[i]; }
           } else {
             boxside = true; bxs = M.key_half() + 3 * k;
 #pragma unroll
@@ -1694,11 +1716,12 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
           if (M.geom_type()[gb] == GEOM_CAPSULE_)
             n = capsule_capsule(rc, posA, mA, M.geom_size() + 3 * ga, posB, mB, M.geom_size() + 3 * gb);
           else if (MESH && M.geom_type()[gb] == GEOM_MESH_) {
-            mpr = true; mpr_tA = M.geom_type()[ga]; mpr_gA = ga; mpr_gB = gb;
+            mpr = true;
+            hull_of(mpr_a, M.geom_type()[ga], ga); hull_of(mpr_b, GEOM_MESH_, gb);
 #pragma unroll
-            for (int i = 0; i < 3; i++) { mpr_pA[i] = posA[i]; mpr_sA[i] = M.geom_size()[3 * ga + i]; mpr_pB[i] = posB[i]; mpr_sB[i] = M.geom_size()[3 * gb + i]; }
+            for (int i = 0; i < 3; i++) { mpr_a.pos[i] = posA[i]; mpr_a.size[i] = M.geom_size()[3 * ga + i]; mpr_b.pos[i] = posB[i]; mpr_b.size[i] = M.geom_size()[3 * gb + i]; }
 #pragma unroll
-            for (int i = 0; i < 9; i++) { mpr_mA[i] = mA[i]; mpr_mB[i] = mB[i]; }
+            for (int i = 0; i < 9; i++) { mpr_a.mat[i] = mA[i]; mpr_b.mat[i] = mB[i]; }
           } else {
             boxside = true; bxs = M.geom_size() + 3 * gb;
 #pragma unroll
@@ -1716,14 +1739,16 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
         }
       }
       if constexpr (MESH != 0) {
+        PROF(13);
         if (__ballot(mpr) != 0ull) {   // (the whole wave walks the portal refinement together)
           RawCon<T> rcm[1];
-          const int nm = RPK_CONVEX(rcm, mpr, mpr_tA, mpr_pA, mpr_mA, mpr_sA, mpr_gA, GEOM_MESH_, mpr_pB, mpr_mB, mpr_sB, mpr_gB);
+          const int nm = convex_mpr_wave(rcm, &mpr_a, &mpr_b, M.mesh_vert(), mpr);
           if (mpr) {
             n = nm; rc[0] = rcm[0];
             if (mpr_flip) { rc[0].n[0] = -rc[0].n[0]; rc[0].n[1] = -rc[0].n[1]; rc[0].n[2] = -rc[0].n[2]; }
           }
         }
+        PROF(19);
       }
       PROF(13);
 #pragma unroll
@@ -2098,6 +2123,8 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
     }
     {
       T f1[6], iv[6], f2[6], t1[3], t2[3];
+      T cin[10];
+      link_inertia(cin);
       mul_inert(f1, cin, ca);
       mul_inert(iv, cin, cv);
       cross3(t1, cv, iv); cross3(t2, cv + 3, iv + 3);
@@ -2280,6 +2307,8 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
       }
       {
         T f1[6], iv[6], f2[6], t1[3], t2[3];
+        T cin[10];
+        link_inertia(cin);
         mul_inert(f1, cin, ca2);
         mul_inert(iv, cin, cv);
         cross3(t1, cv, iv); cross3(t2, cv + 3, iv + 3);

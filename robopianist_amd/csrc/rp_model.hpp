@@ -86,7 +86,7 @@
   X(geom_pairmask, RPK_WAVE, 2) X(geom_iskeycap, RPK_WAVE, 1) \
   X(act_kind,     RPK_MAXACT, 1) X(act_lane, RPK_MAXACT, 2) X(act_ctrllimited, RPK_MAXACT, 1) \
   X(act_forcelimited, RPK_MAXACT, 1) X(site_link, RPK_WAVE, 1) X(link_bodylink, RPK_NL_DEEP, 1) \
-  X(geom_vertadr, RPK_WAVE, 1) X(geom_vertnum, RPK_WAVE, 1)
+  X(geom_vertadr, RPK_WAVE, 1) X(geom_vertnum, RPK_WAVE, 1) X(geom_vertflip, RPK_WAVE, 1)
 
 struct RpLayout {
   enum : int {

@@ -1,6 +1,9 @@
 // rp_narrow.hpp — narrow-phase collision primitives (sphere/capsule/box), one candidate
 // pair per lane [MJ: engine_collision_primitive.c / engine_collision_box.c, restated].
 #pragma once
+#ifdef RP_MPR_COUNT
+#include <cstdio>
+#endif
 #include "rp_wave.hpp"
 
 namespace rpk {
@@ -431,8 +434,8 @@ __device__ RPK_BOXBOX_INLINE int box_box(RawCon<T>* out, const T* p1, const T* m
 // same vertex set scan it together through the SCALAR cache (uniform addresses), instead of every lane
 // pulling 26 vertices through its own vector loads (7 dependent round trips per support: the narrow
 // phase was 38 % of all cycles of an mj_step in hull-fingertip mode).
-template <typename T> struct CGeom { int type, nvert, vadr; T pos[3], mat[9], size[3]; };
-template <typename T> struct MPoint { T v[3], p1[3], p2[3]; };
+template <typename T> struct CGeom { int type, nvert, vadr, flip; T pos[3], mat[9], size[3]; };   // flip: bit k = the stored vertex set is this hull's mirror image in coordinate k
+template <typename T> struct MPoint { T v[3], m[3]; };   // a point of B - A and the midpoint of its two witness points
 
 // support point of a capsule / box (hulls: hull_support_wave)
 template <typename T>
@@ -460,6 +463,8 @@ template <typename T>
 __device__ __forceinline__ void hull_support_wave(const T* mv, const CGeom<T>& g, const T* d, const bool need, T* out) {
   T dl[3];
   matT_vec(dl, g.mat, d);
+#pragma unroll
+  for (int k = 0; k < 3; k++) if ((g.flip >> k) & 1) dl[k] = -dl[k];
   T bv = (T)-1e30;
   int bi = 0;
   unsigned long long todo = __ballot(need);
@@ -471,7 +476,11 @@ __device__ __forceinline__ void hull_support_wave(const T* mv, const CGeom<T>& g
     const T RPK_CONST_AS* vb = uniform_const(mv + 3 * base);
     // (eight vertices per trip, so that their scalar loads are in flight together; the table pads every set to a
     // multiple of eight with copies of its last vertex, which cannot win a strict comparison against itself)
+#ifdef RPK_X_MPR_SHORTSCAN   // timing experiment only (wrong results): what the vertex scan costs
+    for (int i = 0; i < 8; i += 8) {
+#else
     for (int i = 0; i < nv; i += 8) {
+#endif
       T x[8], y[8], z[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) { x[u] = vb[3 * (i + u)]; y[u] = vb[3 * (i + u) + 1]; z[u] = vb[3 * (i + u) + 2]; }
@@ -483,7 +492,9 @@ __device__ __forceinline__ void hull_support_wave(const T* mv, const CGeom<T>& g
     }
   }
   const int a = need ? 3 * (g.vadr + bi) : 0;
-  const T bl[3] = {mv[a], mv[a + 1], mv[a + 2]};
+  T bl[3] = {mv[a], mv[a + 1], mv[a + 2]};
+#pragma unroll
+  for (int k = 0; k < 3; k++) if ((g.flip >> k) & 1) bl[k] = -bl[k];
   T w[3];
   mat_vec(w, g.mat, bl);
   out[0] = g.pos[0] + w[0]; out[1] = g.pos[1] + w[1]; out[2] = g.pos[2] + w[2];
@@ -502,32 +513,49 @@ template <typename T> __device__ __forceinline__ void portal_dir(T* dir, const M
 }
 
 // Called by the whole wave; lanes with `active` hold a pair (A, B).  Returns the number of contacts (0 / 1).
+#ifndef RPK_MPR_INLINE
+#define RPK_MPR_INLINE __forceinline__   // (inlined: as a real call it cost the position stage 290 more scratch operations, 19 of them in the drain loop)
+#endif
 template <typename T>
-__device__ __noinline__ int convex_mpr_wave(RawCon<T>* out, const CGeom<T>* Ap, const CGeom<T>* Bp, const T* mv, const bool active) {
-  const CGeom<T>& A = *Ap; const CGeom<T>& B = *Bp;
+__device__ RPK_MPR_INLINE int convex_mpr_wave(RawCon<T>* __restrict__ out, const CGeom<T>* __restrict__ Ap,
+                                            const CGeom<T>* __restrict__ Bp, const T* __restrict__ mv, const bool active) {
+  // (the two geoms by value: re-reading them through the pointers on every trip -- scratch memory, a
+  // dependent round trip each -- was most of this routine's time)
+  const CGeom<T> A = *Ap, B = *Bp;
   MPoint<T> v0, v1, v2, v3, S;
+  RawCon<T> res;
+  res.dist = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { res.pos[k] = 0; res.n[k] = 0; }
   T dir[3], t1[3];
   int phase = active ? 0 : 4;   // 0: first support, 1: second, 2: portal discovery, 3: refinement, 4: done
   int it = 0, result = 0;
   bool hit = false;
 #pragma unroll
-  for (int k = 0; k < 3; k++) { v0.p1[k] = A.pos[k]; v0.p2[k] = B.pos[k]; v0.v[k] = B.pos[k] - A.pos[k]; }
+  for (int k = 0; k < 3; k++) { v0.m[k] = (T)0.5 * (A.pos[k] + B.pos[k]); v0.v[k] = B.pos[k] - A.pos[k]; }
   if (Num<T>::sqrt(dot3(v0.v, v0.v)) < (T)1e-10) v0.v[0] = (T)1e-5;
   dir[0] = -v0.v[0]; dir[1] = -v0.v[1]; dir[2] = -v0.v[2];
   normalize3(dir);
   v1 = v0; v2 = v0; v3 = v0;
+#ifdef RP_MPR_COUNT   // emulator-only diagnostics: trips per call, lanes in flight
+  int trips_ = 0; const int lanes_ = __popcll(__ballot(active));
+#endif
   while (__ballot(phase != 4) != 0ull) {
+#ifdef RP_MPR_COUNT
+    trips_++;
+#endif
     const bool run = phase != 4;
     // ---- S = support of B - A along dir
     {
       const T nd[3] = {-dir[0], -dir[1], -dir[2]};
+      T p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
       const bool hA = run && A.type == GEOM_MESH_, hB = run && B.type == GEOM_MESH_;
-      if (__ballot(hA) != 0ull) hull_support_wave(mv, A, nd, hA, S.p1);
-      if (__ballot(hB) != 0ull) hull_support_wave(mv, B, dir, hB, S.p2);
-      if (run && A.type != GEOM_MESH_) prim_support(A, nd, S.p1);
-      if (run && B.type != GEOM_MESH_) prim_support(B, dir, S.p2);
+      if (__ballot(hA) != 0ull) hull_support_wave(mv, A, nd, hA, p1);
+      if (__ballot(hB) != 0ull) hull_support_wave(mv, B, dir, hB, p2);
+      if (run && A.type != GEOM_MESH_) prim_support(A, nd, p1);
+      if (run && B.type != GEOM_MESH_) prim_support(B, dir, p2);
 #pragma unroll
-      for (int k = 0; k < 3; k++) S.v[k] = S.p2[k] - S.p1[k];
+      for (int k = 0; k < 3; k++) { S.v[k] = p2[k] - p1[k]; S.m[k] = (T)0.5 * (p1[k] + p2[k]); }
     }
     if (phase == 0) {
       v1 = S;
@@ -537,10 +565,10 @@ __device__ __noinline__ int convex_mpr_wave(RawCon<T>* out, const CGeom<T>* Ap, 
         if (!normalize3(dir)) {   // the origin lies on the ray v0 -> v1
           T n[3] = {v1.v[0] - v0.v[0], v1.v[1] - v0.v[1], v1.v[2] - v0.v[2]};
           normalize3(n);
-          out->dist = -dot3(v1.v, n);
+          res.dist = -dot3(v1.v, n);
 #pragma unroll
-          for (int k = 0; k < 3; k++) { out->n[k] = -n[k]; out->pos[k] = (T)0.5 * (v1.p1[k] + v1.p2[k]); }
-          result = out->dist <= 0 ? 1 : 0;
+          for (int k = 0; k < 3; k++) { res.n[k] = -n[k]; res.pos[k] = v1.m[k]; }
+          result = res.dist <= 0 ? 1 : 0;
           phase = 4;
         } else phase = 1;
       }
@@ -597,12 +625,11 @@ __device__ __noinline__ int convex_mpr_wave(RawCon<T>* out, const CGeom<T>* Ap, 
           const T inv = (T)1 / sum;
 #pragma unroll
           for (int k = 0; k < 3; k++) {
-            const T acc = b[0] * (T)0.5 * (v0.p1[k] + v0.p2[k]) + b[1] * (T)0.5 * (v1.p1[k] + v1.p2[k]) +
-                          b[2] * (T)0.5 * (v2.p1[k] + v2.p2[k]) + b[3] * (T)0.5 * (v3.p1[k] + v3.p2[k]);
-            out->pos[k] = acc * inv;
-            out->n[k] = -dir[k];   // (the portal faces away from the centre of B - A: A -> B is -dir)
+            const T acc = b[0] * v0.m[k] + b[1] * v1.m[k] + b[2] * v2.m[k] + b[3] * v3.m[k];
+            res.pos[k] = acc * inv;
+            res.n[k] = -dir[k];   // (the portal faces away from the centre of B - A: A -> B is -dir)
           }
-          out->dist = -depth;
+          res.dist = -depth;
           result = 1;
         }
         phase = 4;
@@ -617,6 +644,10 @@ __device__ __noinline__ int convex_mpr_wave(RawCon<T>* out, const CGeom<T>* Ap, 
       }
     }
   }
+  *out = res;
+#ifdef RP_MPR_COUNT
+  { const int hits_ = __popcll(__ballot(result != 0)); if ((threadIdx.x & 63) == 0) printf("MPR call: %d pairs, %d trips, %d contacts\n", lanes_, trips_, hits_); }
+#endif
   return result;
 }
 }  // namespace rpk

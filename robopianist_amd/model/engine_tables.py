@@ -382,24 +382,35 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
     t["eng_geom_modelid"] = np.array(egeoms, np.int32)
     # convex hulls: vertices (geom frame; welded bodies are handled through geom_pos / geom_mat)
     if ng and "geom_vertnum" in m and int(np.sum(m.geom_vertnum[egeoms])) > 0:
-        # (geoms with identical vertex sets -- the four finger tips of a hand -- share one copy: the lanes of a wave
-        # that use the same set scan it together, rp_narrow.hpp: hull_support_wave)
-        vadr, vnum, verts, seen = np.full(ng, -1, np.int32), np.zeros(ng, np.int32), [], {}
+        # (geoms with identical vertex sets -- the four finger tips of a hand -- share one copy, and so do sets that
+        # are mirror images of a stored one in one coordinate -- the other hand: the lanes of a wave that use the
+        # same stored set scan it together, rp_narrow.hpp: hull_support_wave; support(mirrored set, d) = mirror of
+        # support(set, mirrored d), vertex order and with it "first maximum wins" unchanged)
+        vadr, vnum, vflip, verts, seen = np.full(ng, -1, np.int32), np.zeros(ng, np.int32), np.zeros(ng, np.int32), [], []
         for i, g in enumerate(egeoms):
             if m.geom_type[g] == spec.GEOM_MESH:
                 vnum[i] = int(m.geom_vertnum[g])
                 a = int(m.geom_vertadr[g])
                 v = np.asarray(m.mesh_vert[a:a + vnum[i]], float)
-                key = v.tobytes()
-                if key not in seen:
-                    seen[key] = len(verts)
+                hit = None
+                for adr, v0 in seen:
+                    for flip in (0, 1, 2, 4):
+                        sgn = np.array([-1.0 if flip & 1 else 1.0, -1.0 if flip & 2 else 1.0, -1.0 if flip & 4 else 1.0])
+                        if v0.shape == v.shape and np.array_equal(v0 * sgn, v):
+                            hit = (adr, flip)
+                            break
+                    if hit:
+                        break
+                if hit is None:
+                    hit = (len(verts), 0)
+                    seen.append((len(verts), v))
                     verts.extend(v.tolist())
                     # padded to a multiple of eight with copies of the last vertex (the scan reads eight per trip;
                     # a copy cannot win its strict comparison)
                     verts.extend([v[-1].tolist()] * ((-len(v)) % 8))
-                vadr[i] = seen[key]
+                vadr[i], vflip[i] = hit
         assert len(verts) <= 320, "too many hull vertices for the engine (RPK_MAXMESHV; sets are padded to multiples of 8)"
-        t["eng_geom_vertadr"] = vadr; t["eng_geom_vertnum"] = vnum
+        t["eng_geom_vertadr"] = vadr; t["eng_geom_vertnum"] = vnum; t["eng_geom_vertflip"] = vflip
         t["eng_mesh_vert"] = np.asarray(verts, float).reshape(-1, 3)
 
     # static pairs (neither geom is a key) and the capsule-x-all-keys family
