@@ -186,6 +186,11 @@ struct EngineBase {
   static const int kMaxSlices = 4;
   hipStream_t xstream[kMaxSlices] = {};   // [0] unused: slice 0 runs on the caller's stream
   hipEvent_t ev_fork = nullptr, ev_join[kMaxSlices] = {};
+  // capacity classes: the full-capacity solver stage (few envs, one wave per SIMD, long waves) runs beside the
+  // lean one on a companion stream of its slice, forked / joined with events every substep -- in one stream the
+  // two launches serialise and every substep pays the slowest heavy env on an otherwise idle GPU
+  hipStream_t hstream[kMaxSlices] = {};
+  hipEvent_t ev_hfork[kMaxSlices] = {}, ev_hjoin[kMaxSlices] = {};
   virtual int acc_sensors(int on) = 0;
   virtual int lean_solver(int on) = 0;
   virtual int field_ptr(rp_field f, void** p, size_t* bytes) = 0;
@@ -229,6 +234,11 @@ struct Engine : EngineBase {
     for (int i = 1; i < kMaxSlices; i++) {
       if (xstream[i]) hipStreamDestroy(xstream[i]);
       if (ev_join[i]) hipEventDestroy(ev_join[i]);
+    }
+    for (int i = 0; i < kMaxSlices; i++) {
+      if (hstream[i]) hipStreamDestroy(hstream[i]);
+      if (ev_hfork[i]) hipEventDestroy(ev_hfork[i]);
+      if (ev_hjoin[i]) hipEventDestroy(ev_hjoin[i]);
     }
     if (ev_fork) hipEventDestroy(ev_fork);
   }
@@ -663,11 +673,27 @@ struct Engine : EngineBase {
         }
         if (probe) { HIP_OK(hipEventRecord(sv0[slot], st)); sv_envs[slot] = cnt; }
         // solver stage; the build specialised for "every tree has a 4-link trunk" when it applies
-        // (light envs first, on the lean build at two waves per SIMD; the full-capacity build skips them)
+        // light envs on the lean build (two waves per SIMD), the others on the full-capacity build (it skips
+        // the light ones) -- side by side: the full-capacity launch goes to the slice's companion stream
+        hipStream_t hs = st;
+        if (lean && !capturing) {
+          if (!hstream[sl] && (hipStreamCreateWithFlags(&hstream[sl], hipStreamNonBlocking) != hipSuccess ||
+                               hipEventCreateWithFlags(&ev_hfork[sl], hipEventDisableTiming) != hipSuccess ||
+                               hipEventCreateWithFlags(&ev_hjoin[sl], hipEventDisableTiming) != hipSuccess)) {
+            (void)hipGetLastError(); hstream[sl] = nullptr;
+          }
+          if (hstream[sl]) {
+            hs = hstream[sl];
+            HIP_OK(hipEventRecord(ev_hfork[sl], st));
+            HIP_OK(hipStreamWaitEvent(hs, ev_hfork[sl], 0));
+          }
+        }
+        if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 0, RPK_MAXD_DEEP>), dim3(cnt), dim3(64), 0, hs, M, ss, B, k, nsub);
+        else if (trunk4) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 4>), dim3(cnt), dim3(64), 0, hs, M, ss, B, k, nsub);
+        else hipLaunchKernelGGL((rp_stage_kernel<T, 1>), dim3(cnt), dim3(64), 0, hs, M, ss, B, k, nsub);
+        if (hs != st) HIP_OK(hipEventRecord(ev_hjoin[sl], hs));
         if (lean) hipLaunchKernelGGL((rp_lean_solver_kernel<T>), dim3(cnt), dim3(64), 0, st, M, ss, B);
-        if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 0, RPK_MAXD_DEEP>), dim3(cnt), dim3(64), 0, st, M, ss, B, k, nsub);
-        else if (trunk4) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 4>), dim3(cnt), dim3(64), 0, st, M, ss, B, k, nsub);
-        else hipLaunchKernelGGL((rp_stage_kernel<T, 1>), dim3(cnt), dim3(64), 0, st, M, ss, B, k, nsub);
+        if (hs != st) HIP_OK(hipStreamWaitEvent(st, ev_hjoin[sl], 0));
         if (probe) HIP_OK(hipEventRecord(sv1[slot], st));
         if (sense) {
           // sensor stage: position / velocity stage of the saved state + mj_rnePostConstraint with the
