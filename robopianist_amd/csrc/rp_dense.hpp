@@ -49,14 +49,14 @@ template <> __device__ __forceinline__ float rcp_nr<float>(float x) {
 //     the forward substitution for free; only the backward pass is a serial chain.
 // Measured on gfx950, one wave per SIMD, n = 20, fp64: 12 k cycles (the first version,
 // one column per step with sqrt/divide/readlane, took 34 k).
-template <typename T>
+template <typename T, bool WIDE = (sizeof(T) == 4)>
 __device__ T dense_factor_solve(T* H, int n, int lane, int* warn) {
   T invd_me = 0;
   int j = 0;
   // four columns per step while they last (one LDS hand-over per four pivots) ...
   // (fp32 only: the fp64 solver kernel is at its register limit and the four-column step
   // pushes it into scratch spills, measured -7 %)
-  for (; sizeof(T) == 4 && j + 4 <= n; j += 4) {
+  for (; WIDE && j + 4 <= n; j += 4) {
     const bool act = lane >= j && lane <= n;
     const T* ri = H + tri(act ? lane : 0, 0);
     const T* r0 = H + tri(j, 0);

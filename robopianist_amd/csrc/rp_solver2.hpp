@@ -495,7 +495,8 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
       }
       WSYNC();
       PROF(22);
-      const T xr = dense_factor_solve(sm.H, nD, lane, &warn);
+      // (four columns per step also in fp64: this build has the registers for it; +0.8 ... 1.7 %)
+      const T xr = dense_factor_solve<T, true>(sm.H, nD, lane, &warn);
       WSYNC();
       if (lane < nD) sm.vec[lane] = xr;
       WSYNC();
