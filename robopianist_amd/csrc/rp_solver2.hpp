@@ -340,12 +340,11 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
 #pragma unroll
           for (int k = 0; k < MD; k++) lrow[k] = Lk[k < TC ? k : k + shift];
           const T lk = Lk[depth], dk = sm.jt[nl + sidx], xk = sm.xs[nl + sidx];
-          if (((foldmask >> sidx) & 1) && !((dm >> (nl + sidx)) & 1)) {
-            const T t = lk * dk;
+          const bool fold = ((foldmask >> sidx) & 1) && !((dm >> (nl + sidx)) & 1);
+          const T t = lk * dk;
 #pragma unroll
-            for (int k = 0; k < MD; k++) Rr[k] -= t * lrow[k];
-            rhs -= lk * xk;
-          }
+          for (int k = 0; k < MD; k++) Rr[k] -= fold ? t * lrow[k] : (T)0;   // (selected: unwritten columns may hold NaN)
+          rhs -= fold ? lk * xk : (T)0;
         }
       }
       WSYNC();
@@ -479,14 +478,14 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
       if (dirty) {
         if (isl) {
 #pragma unroll
-          for (int k = 0; k < MD; k++) if (col_valid(k)) sm.H[tri(ci, cidx(col_lane(k)))] += Rr[k];
+          for (int k = 0; k < MD; k++) if (col_valid(k)) lds_add(&sm.H[tri(ci, cidx(col_lane(k)))], Rr[k]);   // (one owner per element: conflict-free, no round trip)
         } else {
-          sm.H[tri(ci, ci)] += sdiag;
+          lds_add(&sm.H[tri(ci, ci)], sdiag);
 #pragma unroll
           for (int e = 0; e < MD; e++) {
             if (e <= sdepth) {
               const int a_ = anc_of(salink, sdepth, sTL, sTB, e);
-              if ((dm >> a_) & 1) sm.H[tri(ci, cidx(a_))] += Rr[e];
+              if ((dm >> a_) & 1) lds_add(&sm.H[tri(ci, cidx(a_))], Rr[e]);
             }
           }
         }
@@ -578,7 +577,8 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
           const T xl = sm.vec[ln];
           const T xk = sm.slotv[0][ln >= nl ? ln - nl : 0];
           const T xv = ln < nl ? xl : xk;
-          if (k0 + u < cnt) { vc[0] += j0 * xv; vc[1] += j1 * xv; vc[2] += j2 * xv; }
+          const T xm = k0 + u < cnt ? xv : (T)0;   // (selected, not branched: the loads of the four entries batch)
+          vc[0] += j0 * xm; vc[1] += j1 * xm; vc[2] += j2 * xm;
         }
       }
     }
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
       const int e_ = (sm.cinf[c] & 255) + __popcll(sup & lanemask_lt(lane));
       const int e = e_ < nent ? e_ : (nent > 0 ? nent - 1 : 0);
       const T v = sm.entJ[e][0] * sm.cv[c][0] + sm.entJ[e][1] * sm.cv[c][1] + sm.entJ[e][2] * sm.cv[c][2];
-      if ((sup >> lane) & 1) acc += v;
+      acc += ((sup >> lane) & 1) ? v : (T)0;
     }
     if (isl) out[0] += acc;
     sm.jt[lane] = acc;
@@ -667,19 +667,23 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
 #pragma unroll
       for (int e = 0; e < MD; e++) if (e <= tp.depth) y += Mr[e] * sm.vec[anc_at(tp, e)];
       // column part, in-chain: the links below me on my chain
-      if (pos >= 0) {
+      {
 #pragma unroll
-        for (int q = 1; q < 5; q++) if (pos + q < tp.clen) y += sm.R[lane + q][tp.depth];
+        for (int q = 1; q < 5; q++) {
+          const bool on = pos >= 0 && pos + q < tp.clen;
+          const T v = sm.R[on ? lane + q : lane][tp.depth];
+          y += on ? v : (T)0;
+        }
       }
       // the first link of every chain sums what its chain sends to the trunk
       if (pos == 0) {
         T acc[TC] = {0, 0, 0, 0};
 #pragma unroll
         for (int p = 0; p < 5; p++) {
-          if (p < tp.clen) {
+          const bool on = p < tp.clen;
+          const T* row = sm.R[on ? lane + p : lane];
 #pragma unroll
-            for (int t = 0; t < TC; t++) acc[t] += sm.R[lane + p][t];
-          }
+          for (int t = 0; t < TC; t++) { const T v = row[t]; acc[t] += on ? v : (T)0; }
         }
         T* st = sm.stage[(tp.ltree & 1) * 5 + tp.mychain];
 #pragma unroll
@@ -695,7 +699,11 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
         if ((tp.chainmask >> c) & 1) y += v;
       }
 #pragma unroll
-      for (int q = 1; q < TC; q++) if (tp.depth + q < tp.TL) y += sm.R[lane + q][tp.depth];
+      for (int q = 1; q < TC; q++) {
+        const bool on = tp.depth + q < tp.TL;
+        const T v = sm.R[on ? lane + q : lane][tp.depth];
+        y += on ? v : (T)0;
+      }
     }
     WSYNC();
     return y;
@@ -818,13 +826,28 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
           const T u1 = a1 * ja0 + b1 * ja1;
           const T u2 = a2 * ja0 + b2 * ja2;
           const int npath = cnt - 1;   // slot lanes: the links of this contact
+          // (branch-free: the reads of a group of columns go out together and the products are selected -- a
+          // predicated block per column made every column wait for its own two LDS round trips: 2.2 k cycles per
+          // contact, the largest single phase of the stage)
 #pragma unroll
-          for (int k = 0; k < MD; k++) {
-            const int dk = k < TC ? k : k + shift;   // depth of local column k
-            const bool valid = mem && (isl ? (k < TC ? (k < tp.TL && k <= tp.depth) : (pos >= 0 && k - TC <= pos)) : k < npath);
-            const int eb = valid ? base + dk : 0;
-            const T v = u0 * sm.entJ[eb][0] + u1 * sm.entJ[eb][1] + u2 * sm.entJ[eb][2];
-            if (valid) Rr[k] += v;
+          for (int k0 = 0; k0 < MD; k0 += 5) {
+            T jb[5][3];
+            bool valid[5];
+#pragma unroll
+            for (int u = 0; u < 5; u++) {
+              const int k = k0 + u < MD ? k0 + u : MD - 1;
+              const int dk = k < TC ? k : k + shift;   // depth of local column k
+              valid[u] = k0 + u < MD && mem && (isl ? (k < TC ? (k < tp.TL && k <= tp.depth) : (pos >= 0 && k - TC <= pos)) : k < npath);
+              const int eb = valid[u] ? base + dk : 0;
+              jb[u][0] = sm.entJ[eb][0]; jb[u][1] = sm.entJ[eb][1]; jb[u][2] = sm.entJ[eb][2];
+            }
+#pragma unroll
+            for (int u = 0; u < 5; u++) {
+              if (k0 + u < MD) {
+                const T v = u0 * jb[u][0] + u1 * jb[u][1] + u2 * jb[u][2];
+                Rr[k0 + u] += valid[u] ? v : (T)0;
+              }
+            }
           }
           if (mem && !isl) sdiag += u0 * ja0 + u1 * ja1 + u2 * ja2;
         }
@@ -913,26 +936,35 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
           s2 = (lo_ || hi_) ? (T)0 : (T)0.5 * lflD * jv.fr * jv.fr;
           if (frf < 0) { s0 = 0; s1 = 0; s2 = 0; }
         }
+        // limit rows (a weight each) and the four pyramid rows of my contact (one weight: applied once to the
+        // sums of the active rows' products) -- the stage is VALU-issue bound and the line search is its largest
+        // consumer, so an evaluation forms as few products per row as the algebra allows
+        T h0_ = 0, h2_ = 0;   // twice the alpha^0 / alpha^2 coefficients
 #pragma unroll
         for (int s = 0; s < 3; s++) {
           const T xx = jar.lim[s] + alpha * jv.lim[s];
-          const T Dp = lim_D[s];   // (0 without a limit row)
           if (xx < 0) {
-            s0 += (T)0.5 * Dp * jar.lim[s] * jar.lim[s]; s1 += Dp * jar.lim[s] * jv.lim[s];
-            s2 += (T)0.5 * Dp * jv.lim[s] * jv.lim[s];
+            const T t = lim_D[s] * jar.lim[s], u = lim_D[s] * jv.lim[s];   // (weight 0 without a limit row)
+            s1 += t * jv.lim[s]; h2_ += u * jv.lim[s];
+            if (with_cost) h0_ += t * jar.lim[s];
           }
         }
         if (any_con) {
-          const T Dp = hascon ? con_D : (T)0;
+          T c0_ = 0, c1_ = 0, c2_ = 0;
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const T xx = jar.con[r] + alpha * jv.con[r];
             if (xx < 0) {
-              s0 += (T)0.5 * Dp * jar.con[r] * jar.con[r]; s1 += Dp * jar.con[r] * jv.con[r];
-              s2 += (T)0.5 * Dp * jv.con[r] * jv.con[r];
+              c1_ += jar.con[r] * jv.con[r]; c2_ += jv.con[r] * jv.con[r];
+              if (with_cost) c0_ += jar.con[r] * jar.con[r];
             }
           }
+          const T Dp = hascon ? con_D : (T)0;
+          s1 += Dp * c1_; h2_ += Dp * c2_;
+          if (with_cost) h0_ += Dp * c0_;
         }
+        s2 += (T)0.5 * h2_;
+        if (with_cost) s0 += (T)0.5 * h0_;
         s1 = wave_sum(s1) + g1; s2 = wave_sum(s2) + g2;
         d1 = uni(s1 + (T)2 * alpha * s2);
         d2 = uni((T)2 * s2);
