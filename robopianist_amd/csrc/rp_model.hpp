@@ -165,7 +165,7 @@ struct RpState {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
     __builtin_amdgcn_wave_barrier();                         \
   } while (0)
-#define RPK_NPROF 32
+#define RPK_NPROF 48
 // Per-phase shader-clock counters of env 0 (debug aid), accumulated in LDS so a probe
 // costs about one LDS round trip; flushed to global memory once at kernel exit.
 #ifdef RPK_MARK  // static analysis aid: phase boundaries as comments in the ISA listing

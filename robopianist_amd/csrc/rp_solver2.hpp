@@ -355,6 +355,22 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
     // (position jp < j) take the update  R[k] -= (H[v][me] / d_v) H[v][k]  from the row of v = lane + (j - jp).
     // Whole records cross (one lane mask per step, wide LDS accesses): the columns a link does not own
     // carry garbage in both directions and are never used.
+    // What the eliminated chain links leave on their trunk -- sum over v of H[v][t] H[v][t'] / d_v (lower triangle,
+    // then the right-hand sides) -- is accumulated by the first link of every chain, which receives every row of
+    // its chain anyway.  (No LDS adds: 22 lanes of a tree adding into one cell cost ~600 cycles per instruction,
+    // scratch/ub/ldsadd_ub.hip; a separate gather of the published records cost a thousand VALU instructions.)
+    T acc[14];
+#pragma unroll
+    for (int q = 0; q < 14; q++) acc[q] = 0;
+    auto trunk_part = [&](const T* rowv, const T dinv, const T bv) {
+#pragma unroll
+      for (int t = 0; t < TC; t++) {
+        const T lt = rowv[t] * dinv;
+#pragma unroll
+        for (int t2 = 0; t2 <= t; t2++) acc[t * (t + 1) / 2 + t2] -= lt * rowv[t2];
+        acc[10 + t] -= lt * bv;
+      }
+    };
 #pragma unroll
     for (int j = 4; j >= 0; j--) {
       if (isl && pos == j) {
@@ -378,44 +394,23 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
           T rowv[MD + 1];
 #pragma unroll
           for (int k = 0; k <= MD; k++) rowv[k] = Rv[k];
-          const T l = Rv[kd] * sm.jt[v];
+          const T dinv = sm.jt[v];
+          const T l = Rv[kd] * dinv;
 #pragma unroll
           for (int k = 0; k < MD; k++) Rr[k] -= l * rowv[k];
           rhs -= l * rowv[MD];
+          trunk_part(rowv, dinv, rowv[MD]);   // (used by the lanes at position 0)
         }
       }
     }
-    // ---- what the eliminated chain links leave on their trunk: sum over v of H[v][t] H[v][t'] / d_v.  No LDS
-    // adds (22 lanes of a tree adding into one cell cost ~600 cycles per instruction: scratch/ub/ldsadd_ub.hip):
-    // the first link of every chain sums its chain's (<= 5) published records, the trunk links sum the chains.
+    PROF(32);
     if (isl && pos == 0) {
-      T acc[14];
-#pragma unroll
-      for (int q = 0; q < 14; q++) acc[q] = 0;
-#pragma unroll
-      for (int p = 0; p < 5; p++) {
-        const int v = lane + p;
-        if (p < clen && !((dm >> (v & 63)) & 1)) {
-          const T* Rv = sm.R[v];
-          const T dv_ = sm.jt[v], bv = Rv[MD];
-          T rv[TC];
-#pragma unroll
-          for (int t = 0; t < TC; t++) rv[t] = Rv[t];
-#pragma unroll
-          for (int t = 0; t < TC; t++) {
-            if (t < TL) {
-              const T lt = rv[t] * dv_;
-#pragma unroll
-              for (int t2 = 0; t2 <= t; t2++) acc[t * (t + 1) / 2 + t2] -= lt * rv[t2];
-              acc[10 + t] -= lt * bv;
-            }
-          }
-        }
-      }
+      if (!dirty) trunk_part(Rr, mydinv, rhs);
       T* st = sm.stage[(ltree & 1) * 5 + tp.mychain];
 #pragma unroll
       for (int q = 0; q < 14; q++) st[q] = acc[q];
     }
+    PROF(33);
     WSYNC();
     if (isl && pos < 0) {
       const int tro = depth * (depth + 1) / 2;
@@ -433,6 +428,7 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
         }
       }
     }
+    PROF(34);
     // ---- trunk: position j = 3 .. 0, the same way along the trunk chain
 #pragma unroll
     for (int j = TC - 1; j >= 0; j--) {
@@ -630,12 +626,23 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
     WSYNC();
     // every dof lane (link, solver slot) walks the contacts and takes its own entry of those that touch it
     T acc = 0;
-    for (int c = 0; c < ncon; c++) {
-      const unsigned long long sup = sm.csup[c];
-      const int e_ = (sm.cinf[c] & 255) + __popcll(sup & lanemask_lt(lane));
-      const int e = e_ < nent ? e_ : (nent > 0 ? nent - 1 : 0);
-      const T v = sm.entJ[e][0] * sm.cv[c][0] + sm.entJ[e][1] * sm.cv[c][1] + sm.entJ[e][2] * sm.cv[c][2];
-      acc += ((sup >> lane) & 1) ? v : (T)0;
+    // (four contacts per trip: their headers, then their entries, travel together)
+    for (int c0 = 0; c0 < ncon; c0 += 4) {
+      unsigned long long sup[4];
+      int e[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int c = c0 + u < ncon ? c0 + u : c0;
+        sup[u] = c0 + u < ncon ? sm.csup[c] : 0ull;
+        const int e_ = (sm.cinf[c] & 255) + __popcll(sup[u] & lanemask_lt(lane));
+        e[u] = e_ < nent ? e_ : (nent > 0 ? nent - 1 : 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int c = c0 + u < ncon ? c0 + u : c0;
+        const T v = sm.entJ[e[u]][0] * sm.cv[c][0] + sm.entJ[e[u]][1] * sm.cv[c][1] + sm.entJ[e[u]][2] * sm.cv[c][2];
+        acc += ((sup[u] >> lane) & 1) ? v : (T)0;
+      }
     }
     if (isl) out[0] += acc;
     sm.jt[lane] = acc;
@@ -811,10 +818,18 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
         const Topo tp = topo();
         const int pos = isl ? tp.depth - tp.TL : -2;
         const int shift = (isl && pos >= 0) ? tp.TL - TC : 0;
+        // (the header of the next contact is fetched while this one is worked on: one LDS round trip less on
+        // the dependent chain of every contact)
+        int inf_n = ncon > 0 ? sm.cinf[0] : 0;
+        unsigned long long sup_n = ncon > 0 ? sm.csup[0] : 0ull;
         for (int c = 0; c < ncon; c++) {
-          const int inf = sm.cinf[c];
+          const int inf = inf_n;
+          const unsigned long long sup = sup_n;
+          {
+            const int cn = c + 1 < ncon ? c + 1 : c;
+            inf_n = sm.cinf[cn]; sup_n = sm.csup[cn];
+          }
           if ((inf >> 16) & 1) continue;   // cross-chain: below
-          const unsigned long long sup = sm.csup[c];
           const int base = inf & 255, cnt = (inf >> 8) & 255;
           const bool mem = (sup >> lane) & 1;
           const int eo_ = base + (isl ? tp.depth : cnt - 1);
@@ -909,8 +924,10 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
       // phi'(0) = grad . search (before grad goes out of use)
       const T f0g = uni(wave_sum(grad[0] * search[0] + grad[1] * search[1] + grad[2] * search[2]));
       const T Mv0 = mulM0(search[0]);
+      PROF(35);
       RowsL jv;
       mulJ(search, jv);
+      PROF(36);
       T g0, g1, g2;
       {
         const T rk1 = kM[0] * dq[1], rk2 = kM[1] * dq[2];

@@ -290,8 +290,8 @@ class BatchedPhysics:
 
     def profile(self, enable=True):
         """Reads+clears the per-phase cycle counters of env 0, then (dis)enables them."""
-        out = np.zeros(32, np.int64)
-        self._check(self._L.rp_profile(self._h, out.ctypes.data, 32, int(bool(enable))))
+        out = np.zeros(48, np.int64)
+        self._check(self._L.rp_profile(self._h, out.ctypes.data, 48, int(bool(enable))))
         return out
 
     @property
