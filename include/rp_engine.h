@@ -130,7 +130,8 @@ int rp_set_cost_ordered_launch(rp_engine* e, int on);
  * fits the light class (<= 24 contacts, <= 160 contact Jacobian entries, <= 36 cross-coupled rows, <= 12 touched
  * keys) are stepped by the lean build of the solver stage (two waves per SIMD), the others by the full-capacity
  * build; results do not depend on the class to more than rounding.  No counterpart in the reference (MuJoCo
- * allocates its constraint arrays per step). */
+ * allocates its constraint arrays per step).  on > 1 (tests): as 1, with the light class further restricted to
+ * envs with at most `on` contact Jacobian entries, so that small scenes exercise both classes. */
 int rp_set_lean_solver(rp_engine* e, int on);
 
 /* Stream slices (0, 1, 2 or 4; default 1): with n > 1, rp_step runs n slices of the batch as n

@@ -44,10 +44,19 @@ __global__ void rp_mark_valid_kernel(unsigned char* valid, const int* active, in
 //     heaviest env among those with index = x (mod 8).  Inactive envs go last in their class.
 #define RP_ORDER_BUCKETS 256
 #define RP_ORDER_CLASSES 8
-__global__ __launch_bounds__(512) void rp_order_kernel(int* order_all, const int* hdr, const int* active, int base, int n) {
+__global__ __launch_bounds__(512) void rp_order_kernel(int* order_all, const int* hdr, const int* active, int base, int n,
+                                                       int* heavy_list, int* heavy_cnt) {
   // (sorts the envs base .. base + n - 1 into order_all[base .. base + n - 1]; base is a multiple of 8.
   // One workgroup per residue class: eight short kernels side by side instead of one 1024-thread block.)
   const int x = blockIdx.x;
+  // the envs outside the light capacity class, compacted for the full-capacity solver stage (any order: envs
+  // are independent); the counter is cleared by that stage's last workgroup
+  if (heavy_list) {
+    for (int e = x + RP_ORDER_CLASSES * (int)threadIdx.x; e < n; e += RP_ORDER_CLASSES * blockDim.x) {
+      if (hdr[(base + e) * 8 + 6] != 1 && !(active && active[base + e] == 0)) heavy_list[base + atomicAdd(heavy_cnt, 1)] = base + e;
+    }
+  }
+  if (!order_all) return;
   int* order = order_all + base;
   __shared__ int hist[RP_ORDER_BUCKETS];
   for (int i = threadIdx.x; i < RP_ORDER_BUCKETS; i += blockDim.x) hist[i] = 0;
@@ -214,7 +223,7 @@ struct Engine : EngineBase {
   bool lean = false;    // light envs are stepped by rp_lean_solver_kernel (rp_solver2.hpp), the others by the full build
   int lean_solver(int on) override {
     if (on && (deep || sizeof(T) != 8)) return fail("rp_set_lean_solver: the lean solver stage exists for the fp64 default builds only");
-    lean = on != 0; S.lean = lean ? 1 : 0;
+    lean = on != 0; S.lean = on > 0 ? on : 0;   // (on > 1: the light class capped at that many Jacobian entries)
     return 0;
   }
   int md() const { return deep ? RPK_MAXD_DEEP : RPK_MAXD; }
@@ -426,6 +435,8 @@ struct Engine : EngineBase {
       hipMemcpy(d_order, id.data(), E * sizeof(int), hipMemcpyHostToDevice);
     }
     S.cost_pos = dalloc<int>(E); S.cost_sol = dalloc<int>(E);
+    d_heavy = dalloc<int>(E); d_heavy_cnt = dalloc<int>(2 * kMaxSlices);   // (zero-filled)
+    S.heavy_list = nullptr; S.heavy_cnt = nullptr; S.heavy_done = nullptr;
     d_valid = dalloc<unsigned char>(E);  // (zero-filled: nothing is valid yet)
     S.max_newton = M.iterations; S.max_ls = M.ls_iterations;
     {
@@ -441,6 +452,10 @@ struct Engine : EngineBase {
   long long* d_prof = nullptr;
   int* d_active = nullptr;
   int* d_order = nullptr;           // cost-ordered launch: workgroup -> env
+  // the envs outside the light capacity class, compacted per slice (entries base .. of slice sl; d_heavy_cnt[2 sl]
+  // = entries, [2 sl + 1] = finished workgroups of the stage that walks them)
+  int *d_heavy = nullptr, *d_heavy_cnt = nullptr;
+  static const int kHeavyGrid = 512;   // (one wave of that stage owns a SIMD: half the chip at most)
   // acceleration-stage sensors (rp_set_acc_sensors): state before the last Euler step, outputs
   bool sensors_on = false;
   T *d_qpos_prev = nullptr, *d_qvel_prev = nullptr, *d_con_force = nullptr, *d_sens_torque = nullptr,
@@ -666,7 +681,11 @@ struct Engine : EngineBase {
         const bool probe = timeit && sl == 0 && k == (int)(step_calls % (unsigned)nsub);
         const bool sense = sensors_on && k == nsub - 1;
         // cost-ordered launch: heaviest envs first, from the hand-over the position stage just wrote
-        if (cost_order) hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(512), 0, st, d_order, B.hdr, s.active, base, cnt);
+        // (the same pass compacts the envs outside the light class for the full-capacity solver stage)
+        const bool listed = lean && d_heavy != nullptr;
+        if (cost_order || listed)
+          hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(512), 0, st, cost_order ? d_order : nullptr, B.hdr, s.active, base, cnt,
+                             listed ? d_heavy : nullptr, listed ? d_heavy_cnt + 2 * sl : nullptr);
         if (sense) {  // the state this substep's forces belong to (the solver stage integrates in place)
           HIP_OK(hipMemcpyAsync(d_qpos_prev + (size_t)base * nv, S.qpos + (size_t)base * nv, sizeof(T) * (size_t)cnt * nv, hipMemcpyDeviceToDevice, st));
           HIP_OK(hipMemcpyAsync(d_qvel_prev + (size_t)base * nv, S.qvel + (size_t)base * nv, sizeof(T) * (size_t)cnt * nv, hipMemcpyDeviceToDevice, st));
@@ -688,9 +707,15 @@ struct Engine : EngineBase {
             HIP_OK(hipStreamWaitEvent(hs, ev_hfork[sl], 0));
           }
         }
-        if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 0, RPK_MAXD_DEEP>), dim3(cnt), dim3(64), 0, hs, M, ss, B, k, nsub);
-        else if (trunk4) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 4>), dim3(cnt), dim3(64), 0, hs, M, ss, B, k, nsub);
-        else hipLaunchKernelGGL((rp_stage_kernel<T, 1>), dim3(cnt), dim3(64), 0, hs, M, ss, B, k, nsub);
+        RpState<T> sh = ss;
+        int hgrid = cnt;
+        if (listed) {
+          sh.heavy_list = d_heavy + base; sh.heavy_cnt = d_heavy_cnt + 2 * sl; sh.heavy_done = d_heavy_cnt + 2 * sl + 1;
+          hgrid = cnt < kHeavyGrid ? cnt : kHeavyGrid;
+        }
+        if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 0, RPK_MAXD_DEEP>), dim3(hgrid), dim3(64), 0, hs, M, sh, B, k, nsub);
+        else if (trunk4) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 4>), dim3(hgrid), dim3(64), 0, hs, M, sh, B, k, nsub);
+        else hipLaunchKernelGGL((rp_stage_kernel<T, 1>), dim3(hgrid), dim3(64), 0, hs, M, sh, B, k, nsub);
         if (hs != st) HIP_OK(hipEventRecord(ev_hjoin[sl], hs));
         if (lean) hipLaunchKernelGGL((rp_lean_solver_kernel<T>), dim3(cnt), dim3(64), 0, st, M, ss, B);
         if (hs != st) HIP_OK(hipStreamWaitEvent(st, ev_hjoin[sl], 0));

@@ -131,11 +131,10 @@ template <typename T, int MODE, int FIXED_TL = 0, int MD = RPK_MAXD, int MESH = 
 #ifndef RPK_SOL64_WAVES
 #define RPK_SOL64_WAVES 1
 #endif
-__global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_WAVES) void rp_stage_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep,
-                                                     int nsub) {
+__device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState<T>& S, const RpStage<T>& B, const int substep,
+                                              const int nsub, const int env) {
   using namespace rpk;
   using N = Num<T>;
-  const int env = S.order ? S.order[S.env_base + blockIdx.x] : S.env_base + (int)blockIdx.x;
   const int lane = threadIdx.x;
   if constexpr (MODE == 1) {
     if (S.lean && B.hdr[env * 8 + 6] == 1) return;   // a light env: rp_lean_solver_kernel steps it
@@ -1998,7 +1997,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
         if (lane == 0) {
           B.hdr[env * 8 + 4] = nent; B.hdr[env * 8 + 5] = maxm;
           // capacity class of this env's solve (rp_solver2.hpp): light = fits the lean solver stage
-          B.hdr[env * 8 + 6] = (S.lean && MD == RPK_MAXD && M.ntree <= 2 && ncon <= LeanCaps::NC && nent <= LeanCaps::NE &&
+          B.hdr[env * 8 + 6] = (S.lean && MD == RPK_MAXD && M.ntree <= 2 && ncon <= LeanCaps::NC && nent <= (S.lean > 1 && S.lean < LeanCaps::NE ? S.lean : LeanCaps::NE) &&
                                 __popcll(dirty_mask) <= LeanCaps::HMAX && nkt <= LeanCaps::NK && nl + nkt <= 64) ? 1 : 0;
         }
       }
@@ -2383,4 +2382,25 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
   }
 #undef LF
 #undef LI
+}
+
+template <typename T, int MODE, int FIXED_TL = 0, int MD = RPK_MAXD, int MESH = 0>
+__global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_WAVES) void rp_stage_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep,
+                                                     int nsub) {
+  // One env per workgroup -- or, for the full-capacity solver stage next to the lean one, a small grid walking
+  // the compacted list of the envs outside the light class (RpState::heavy_list).
+  const bool listed = MODE == 1 && S.heavy_list != nullptr;
+  const int n = listed ? *(volatile const int*)S.heavy_cnt : (int)gridDim.x;
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int env = listed ? S.heavy_list[i] : (S.order ? S.order[S.env_base + i] : S.env_base + i);
+    rp_stage_body<T, MODE, FIXED_TL, MD, MESH>(M, S, B, substep, nsub, env);
+    if (!listed) break;
+    __syncthreads();
+  }
+  if constexpr (MODE == 1) {
+    if (listed && threadIdx.x == 0) {
+      __threadfence();
+      if (atomicAdd(S.heavy_done, 1) == (int)gridDim.x - 1) { *S.heavy_cnt = 0; *S.heavy_done = 0; __threadfence(); }
+    }
+  }
 }

@@ -155,6 +155,12 @@ struct RpState {
   // fits rpk::LeanCaps as "light" (hdr[6] = 1); rp_lean_solver_kernel (two waves per SIMD) steps those and the
   // full-capacity solver stage skips them
   int lean;
+  // may be null: the envs of this launch outside the light class, compacted (rp_order_kernel builds the list from
+  // the hand-over headers).  The full-capacity solver stage then runs as a small grid that walks the list -- its
+  // workgroups need a whole SIMD's registers each, and a full grid of them, although all but a few leave at
+  // once, waited for the lean launch next to it to drain (measured: the join cost up to 200 us per substep)
+  const int* heavy_list;
+  int *heavy_cnt, *heavy_done;   // entries in the list; finished workgroups (the last one clears both)
 };
 
 // One workgroup == one wavefront, and a wave's LDS instructions execute in issue

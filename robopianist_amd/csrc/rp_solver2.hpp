@@ -31,9 +31,12 @@
 
 namespace rpk {
 // capacities of the light class (what the position stage tests before it marks an env "light")
+#ifndef RPK_LEAN_NE   // (tests shrink it to send envs through the full-capacity stage's compacted list)
+#define RPK_LEAN_NE 184
+#endif
 struct LeanCaps {
   static constexpr int NC = 24;     // contacts
-  static constexpr int NE = 160;    // contact Jacobian entries
+  static constexpr int NE = RPK_LEAN_NE;    // contact Jacobian entries (what the 20 KB of LDS per wave leave room for; the config-2 replay peaks at 166)
   static constexpr int HMAX = 36;   // rows of the dense (cross-chain) block
   static constexpr int NK = 12;     // touched keys (solver slots)
 };

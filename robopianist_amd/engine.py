@@ -259,9 +259,10 @@ class BatchedPhysics:
         """rp_step steps the batch as `n` (1 or 2; 0 = the engine picks) kernel chains (include/rp_engine.h)."""
         self._check(self._L.rp_set_stream_slices(self._h, int(n)))
 
-    def set_lean_solver(self, on: bool = True):
-        """Capacity classes of the solver stage (include/rp_engine.h: rp_set_lean_solver)."""
-        self._check(self._L.rp_set_lean_solver(self._h, int(bool(on))))
+    def set_lean_solver(self, on=True):
+        """Capacity classes of the solver stage (include/rp_engine.h: rp_set_lean_solver); an int > 1 caps the
+        light class at that many contact Jacobian entries (tests: both classes in one small scene)."""
+        self._check(self._L.rp_set_lean_solver(self._h, int(on)))
 
     def set_cost_ordered_launch(self, on: bool = True):
         """Stage kernels process the envs heaviest-first (include/rp_engine.h); bit-identical results."""

@@ -477,6 +477,45 @@ def test_state_writes_across_slice_count_changes_are_bit_identical(two_hand_scen
     assert ref.get(engine.NCON).max() > 0
 
 
+def test_both_capacity_classes_in_one_batch_match_the_full_capacity_stage(two_hand_scene):
+    """The light class capped at 40 Jacobian entries (rp_set_lean_solver(e, 40)) sends a good share of a small
+    scene's envs through the full-capacity solver stage's compacted list, next to the lean stage, in every slice
+    mode: same control steps as the engine with the lean stage off (both stages solve the same system: 1e-9 per
+    control step of ten mj_steps, restarted from the lean-off engine's state; bit-identical between the slice modes)."""
+    from robopianist_amd import engine
+    si = two_hand_scene
+    m = si.model
+    E = 1100
+    ctrl = _replay_ctrl(si)
+    rng = np.random.default_rng(3)
+    gain = 1 + 0.1 * rng.standard_normal((E, 1))
+    ref = engine.BatchedPhysics(m, si.key_joint_ids, n_envs=E, precision=64)
+    ref.set_lean_solver(False)
+    modes = []
+    for slices, order in ((1, False), (2, True), (4, True)):
+        p = engine.BatchedPhysics(m, si.key_joint_ids, n_envs=E, precision=64)
+        p.set_lean_solver(40); p.set_stream_slices(slices); p.set_cost_ordered_launch(order)
+        modes.append(p)
+    heavy = light = 0
+    for t in range(24):
+        c = ctrl[10 * (t + 20)][None, :] * gain
+        for p in [ref] + modes:
+            p.set(engine.CTRL, c)
+            if p is not ref:   # teacher forced from the lean-off engine at every control step
+                p.set(engine.QPOS, ref.qpos); p.set(engine.QVEL, ref.qvel)
+                p.set(engine.QACC_WARMSTART, ref.get(engine.QACC_WARMSTART))
+        for p in [ref] + modes:
+            p.step(10)
+        h = modes[0].get(engine.DEBUG_HANDOVER_HDR)[:, 6]
+        heavy += int((h == 0).sum()); light += int((h == 1).sum())
+        for p in modes[1:]:
+            assert np.array_equal(modes[0].qpos, p.qpos) and np.array_equal(modes[0].qvel, p.qvel), t
+        assert np.abs(ref.qpos - modes[0].qpos).max() < 1e-9, t
+    print(f"env-steps in the light class {light}, outside {heavy}")
+    assert heavy > 0.05 * (heavy + light) and light > 0.05 * (heavy + light)
+    assert max(int(p.warn_flags.max()) for p in [ref] + modes) == 0
+
+
 def torch_sync():
     import torch
     torch.cuda.synchronize()
