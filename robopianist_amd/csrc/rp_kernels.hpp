@@ -1465,12 +1465,32 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         }
       }
     }
+    PROF(37);
     // allowed pairs this lane owns (engine_tables.py deals every static pair to one of its two lanes)
     unsigned long long remA = (((unsigned long long)hithi << 32) | hitlo) & gpm;
     // keys: capsules that reach down to the keyboard, against this lane's two keys
     unsigned long long remK0 = 0, remK1 = 0;
     {
-      unsigned long long near_mask = __ballot(gkc && (fcz - frb <= (float)M.key_zmax));
+      // extents along world x, y, z of MY geom: a capsule's own axis-aligned extents |axis| * half length +
+      // radius, the oriented box's for boxes (a palm box hovering over the keyboard is no candidate), the
+      // bounding radius otherwise -- once per lane, outside the loop over the near geoms (the loop used to
+      // fetch the box of every geom it visited: one LDS round trip on the dependent chain of each trip)
+      float gex = frb, gey = frb, gez = frb;
+      {
+        const int bi_ = lane - ncap;
+        if (isg && bi_ >= 0 && bi_ < RPK_NBOXF) {
+          const float* gb_ = sm.gbox[bi_];
+          gex = fabsf(gb_[0]) * gb_[9] + fabsf(gb_[1]) * gb_[10] + fabsf(gb_[2]) * gb_[11] + 1e-4f;
+          gey = fabsf(gb_[3]) * gb_[9] + fabsf(gb_[4]) * gb_[10] + fabsf(gb_[5]) * gb_[11] + 1e-4f;
+          gez = fabsf(gb_[6]) * gb_[9] + fabsf(gb_[7]) * gb_[10] + fabsf(gb_[8]) * gb_[11] + 1e-4f;
+        } else if (isg && lane < ncap && M.geom_type()[lane] == GEOM_CAPSULE_) {
+          // (fp32 with an allowance of 0.1 mm + 1e-4 of the size: the cull only has to be a superset)
+          gex = fminf(frb, (fabsf(fax) * fhl + frr) * 1.0001f + 1e-4f);
+          gey = fminf(frb, (fabsf(fay) * fhl + frr) * 1.0001f + 1e-4f);
+          gez = fminf(frb, (fabsf(faz) * fhl + frr) * 1.0001f + 1e-4f);
+        }
+      }
+      unsigned long long near_mask = __ballot(gkc && (fcz - gez <= (float)M.key_zmax));
       if (nk == 0) near_mask = 0;
       float kx[2], kz[2], kpx[2], kpy[2], ktop[2], khx_[2], khy_[2], krb_[2];
 #pragma unroll
@@ -1483,30 +1503,28 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         khx_[s] = (float)khalf[s][0] + 0.01f; khy_[s] = (float)khalf[s][1];
         krb_[s] = (float)krb[s] * 1.0001f + 1e-6f;
       }
+      PROF(38);
+      // two near geoms per trip (their broadcasts and tests interleave)
       while (near_mask) {
-        const int g = __ffsll((long long)near_mask) - 1;
+        const int g0 = __ffsll((long long)near_mask) - 1;
         near_mask &= near_mask - 1;
-        const float cx = bcast(fcx, g), cy = bcast(fcy, g), cz = bcast(fcz, g), rb = bcast(frb, g);
-        // extents along world x, y, z: the bounding radius for capsules, the oriented box's own
-        // axis-aligned extents for boxes (a palm box hovering over the keyboard is no candidate)
-        float ex_ = rb, ey_ = rb, ez_ = rb;
-        {
-          const int bi_ = g - ncap;
-          if (bi_ >= 0 && bi_ < RPK_NBOXF) {
-            const float* gb_ = sm.gbox[bi_];
-            ex_ = fabsf(gb_[0]) * gb_[9] + fabsf(gb_[1]) * gb_[10] + fabsf(gb_[2]) * gb_[11] + 1e-4f;
-            ey_ = fabsf(gb_[3]) * gb_[9] + fabsf(gb_[4]) * gb_[10] + fabsf(gb_[5]) * gb_[11] + 1e-4f;
-            ez_ = fabsf(gb_[6]) * gb_[9] + fabsf(gb_[7]) * gb_[10] + fabsf(gb_[8]) * gb_[11] + 1e-4f;
-          }
-        }
+        const bool two = near_mask != 0ull;
+        const int g1 = two ? __ffsll((long long)near_mask) - 1 : g0;
+        near_mask &= near_mask - 1;   // (0 & -1 = 0)
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-          const float dx = kx[s] - cx, dy = kpy[s] - cy, dz = kz[s] - cz, rr = rb + krb_[s];
-          // bounding spheres, then a conservative box test (the key only rotates about
-          // y, so its y-extent is exact; x/z get a 1 cm allowance)
-          const bool hit = isk[s] && dx * dx + dy * dy + dz * dz <= rr * rr && fabsf(dy) <= khy_[s] + ey_ &&
-                           fabsf(cx - kpx[s]) <= khx_[s] + ex_ && cz - ez_ <= ktop[s];
-          if (s == 0) remK0 |= hit ? (1ull << g) : 0ull; else remK1 |= hit ? (1ull << g) : 0ull;
+        for (int u = 0; u < 2; u++) {
+          const int g = u == 0 ? g0 : g1;
+          const float cx = bcast(fcx, g), cy = bcast(fcy, g), cz = bcast(fcz, g), rb = bcast(frb, g);
+          const float ex_ = bcast(gex, g), ey_ = bcast(gey, g), ez_ = bcast(gez, g);
+#pragma unroll
+          for (int s = 0; s < 2; s++) {
+            const float dx = kx[s] - cx, dy = kpy[s] - cy, dz = kz[s] - cz, rr = rb + krb_[s];
+            // bounding spheres, then a conservative box test (the key only rotates about
+            // y, so its y-extent is exact; x/z get a 1 cm allowance)
+            const bool hit = (u == 0 || two) && isk[s] && dx * dx + dy * dy + dz * dz <= rr * rr && fabsf(dy) <= khy_[s] + ey_ &&
+                             fabsf(cx - kpx[s]) <= khx_[s] + ex_ && cz - ez_ <= ktop[s];
+            if (s == 0) remK0 |= hit ? (1ull << g) : 0ull; else remK1 |= hit ? (1ull << g) : 0ull;
+          }
         }
       }
     }
