@@ -371,7 +371,8 @@ def main():
                 eager_env.step(a)
             barrier()
         sms, snl = phys.solver_kernel_time()
-        senvs = phys.solver_kernel_envs() or float(E)   # a launch covers the batch or one slice of it
+        senvs = phys.solver_kernel_envs() or float(E)   # a launch covers the batch or one slice of it (fused schedule: x substeps)
+        fused = senvs > 1.5 * E   # (the probes of the fused schedule cover all substeps of the batch)
         kms, nl = phys.kernel_time()
         wf = base_env.physics.warn
         warn_or = int(torch.bitwise_or(wf, torch.zeros_like(wf)).max().item()) if wf is not None else 0
@@ -404,7 +405,7 @@ def main():
                        "note": "same env loop with the actions in host numpy arrays and every TimeStep field "
                                "copied back to numpy (pageable memory, synchronous copies) each step"}
 
-        return dict(per_rank=per_rank, host_io=host_io, dt=dt, kms=kms, nl=nl, sms=sms, snl=snl, senvs=senvs, warn=warn_or, finite=finite, phys=phys,
+        return dict(per_rank=per_rank, host_io=host_io, dt=dt, kms=kms, nl=nl, sms=sms, snl=snl, senvs=senvs, fused=fused, warn=warn_or, finite=finite, phys=phys,
                     m=m, E=E, key_ids=base_env.task.scene.key_joint_ids, sim=sim_all, n_spread=n_spread, events=events,
                     graphed=bool(use_graph and env.graph_captured), stagger=stagger)
 
@@ -451,9 +452,14 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(E, args.precision, r["senvs"]),
-                "kernel": "rp_lean_solver_kernel<%s> (mj_step2: constraint solver + Euler, one substep of all envs; the "
-                          "probe brackets it together with the full-capacity rp_stage_kernel<%s, 1> that takes the envs "
-                          "outside the light capacity class)" % (tname, tname),
+                "kernel": ("rp_fused_steps_kernel<%s> (all substeps of the step in one launch: n_sub x (mj_step2 solver stage; mj_step1 "
+                           "position stage), a wave keeps its env; the probe brackets it together with rp_cleanup_steps_kernel<%s> "
+                           "that finishes the envs outside the light capacity class; envs_per_launch counts env-substeps)" % (tname, tname))
+                          if r["fused"] else
+                          ("rp_lean_solver_kernel<%s> (mj_step2: constraint solver + Euler, one substep of all envs; the "
+                           "probe brackets it together with the full-capacity rp_stage_kernel<%s, 1> that takes the envs "
+                           "outside the light capacity class)" % (tname, tname)),
+                "schedule": "fused substeps" if r["fused"] else "one launch per stage",
                 "valu": _valu_profile(args.precision),
                 "kernel_avg_ms": sms, "kernel_launches_sampled": snl,
                 "envs_per_launch": r["senvs"],
@@ -469,7 +475,9 @@ def main():
                         "envs_per_launch is the mean over the sampled launches; a slice's launch shares the GPU with the other slice's "
                         "kernels, so its duration is not exclusive and achieved/frac drop when slices are on although the step "
                         "gets faster -- compare step_sequence_avg_ms); one rp_step = 1 + 2*substeps launches "
-                        "per slice (rp_stage_kernel<T,0> position/velocity stage, solver stage).  The path is instruction-issue / latency bound "
+                        "per slice (rp_stage_kernel<T,0> position/velocity stage, solver stage), or 4 launches with the fused schedule "
+                        "(the engine times both on a few steps of every 128 and runs the faster: `schedule`; probes are taken on "
+                        "the steps of the schedule in use only).  The path is instruction-issue / latency bound "
                         "(one wave per env, two waves per SIMD), not HBM bound: `valu` carries the figures that bound it, see DESIGN.md 6",
             },
             "sanity": {"warn_flags_or": r["warn"], "finite": r["finite"], **(r["events"] or {})},

@@ -134,6 +134,18 @@ int rp_set_cost_ordered_launch(rp_engine* e, int on);
  * envs with at most `on` contact Jacobian entries, so that small scenes exercise both classes. */
 int rp_set_lean_solver(rp_engine* e, int on);
 
+/* Fused substeps (fp64 default builds, i.e. wherever the lean solver stage applies): rp_step runs all its
+ * substeps in ONE launch -- a wave keeps its env through n_sub x (solver stage; position stage) -- followed by one
+ * small clean-up launch for the envs that left the light capacity class on the way.  on: 0 = never (one launch
+ * per stage and substep), 1 = always, 2 = automatic (the default): with rp_set_stream_slices(e, 0) the engine
+ * times this schedule against the per-stage ones on a few steps of every 128 and runs the fastest -- fused wins
+ * when the batch is at most one round of resident waves (<= 2048 envs) or the envs are alike, two slices win on
+ * 4096 envs at different episode times.  Same results to rounding (the same stage code in the same order per
+ * env).  rp_get_fused_substeps: 0 = not in use, 1 = the schedule rp_step currently runs, 2 = a candidate the
+ * automatic choice currently rejects.  No counterpart in the reference (mj_step is one CPU call per substep). */
+int rp_set_fused_substeps(rp_engine* e, int on);
+int rp_get_fused_substeps(rp_engine* e);
+
 /* Stream slices (0, 1, 2 or 4; default 1): with n > 1, rp_step runs n slices of the batch as n
  * independent kernel chains (the caller's stream and internal ones, forked / joined with events
  * inside the call), so that the tail of one slice's launch overlaps another slice's next kernel:
@@ -163,13 +175,15 @@ int rp_dim(const rp_engine* e, const char* name); /* "nv","nu","nsite","ntree","
  * since the last call, measured with HIP events on the engine stream; also returns
  * the number of sequences timed. */
 int rp_kernel_time(rp_engine* e, double* avg_ms, int* n_launches);
-/* Average device time (ms) of ONE launch of the dominant kernel (the mj_step2 /
- * constraint-solver stage, rp_stage_kernel<T,1>), sampled on the middle substep of
- * every rp_step call, HIP events on the engine stream.  Call before rp_kernel_time
- * if both are wanted for the same interval. */
+/* Average device time (ms) of ONE launch of the dominant kernel, HIP events on the engine stream: the solver
+ * stage of one substep (rp_lean_solver_kernel + the full-capacity rp_stage_kernel<T,1> next to it; the probed
+ * substep rotates with the call count), or -- fused schedule -- rp_fused_steps_kernel + its clean-up launch (all
+ * substeps of the step).  Steps the automatic schedule choice runs as trials carry no probe; when both
+ * schedules were sampled the one with more samples is reported.  Call before rp_kernel_time if both are wanted
+ * for the same interval. */
 int rp_solver_kernel_time(rp_engine* e, double* avg_ms, int* n_launches);
-/* Average number of envs one timed solver-stage launch covered, over the launches the last
- * rp_solver_kernel_time call reported (the whole batch, or one slice of it: rp_set_stream_slices). */
+/* Average number of env-substeps one timed launch covered, over the launches the last rp_solver_kernel_time
+ * call reported: the whole batch or one slice of it (rp_set_stream_slices); fused schedule: batch x substeps. */
 int rp_solver_kernel_envs(rp_engine* e, double* avg_envs);
 /* Debug aid: per-phase shader-clock counters of env 0 (see rp_kernels.hpp PROF).
  * Reads and clears the counters (out may be NULL), then enables/disables them. */

@@ -161,15 +161,20 @@ struct EngineBase {
   // with the call count, so the running average is the mean over all substeps by construction
   hipEvent_t sv0[kRing] = {}, sv1[kRing] = {};
   unsigned step_calls = 0;
-  double solver_ms = 0; int solver_launches = 0;
+  // (kept per schedule kind -- [0] one launch per stage, [1] fused substeps -- and reported for the kind with more samples)
+  double solver_ms_k[2] = {0, 0}, solver_envs_k[2] = {0, 0}; int solver_launches_k[2] = {0, 0};
+  int sv_kind[kRing] = {};
   int sv_envs[kRing] = {};            // envs the probed solver launch of that slot covered (a slice or the batch)
-  double solver_envs = 0, last_solver_envs = 0;
-  // stream slices, automatic choice (n_slices == 0): the first 8 steps of every 64 run with one and two
-  // slices in the order 1 2 2 1 1 2 2 1 (a linear drift of the workload cancels); the mode with the lower
-  // mean step time (event ring; sums decay by 1/2 per 64 steps; 1 % hysteresis) runs the other 56
-  int ev_trial[kRing] = {};           // 0 = not a trial step, else the slice count it ran with
-  double trial_ms[3] = {0, 0, 0}, trial_n[3] = {0, 0, 0};
-  int auto_slices = 1; unsigned auto_pos = 0;
+  double last_solver_envs = 0;
+  // schedule of an rp_step, automatic choice (n_slices == 0) among: 1 = one launch per stage, 2 = the same as
+  // two slices on two streams (>= 1024 envs), 3 = fused substeps (where they apply and are left on "auto").
+  // Steps 16 .. of every 128 run the candidates in the order a b c c b a a b c c b a (a linear drift of
+  // the workload cancels); the one with the lowest mean step time in that block (event ring; 1 %
+  // hysteresis) runs the rest.  Measured, config 2 with 4096 envs at staggered episode times: two
+  // slices; the same in lockstep, or with <= 2048 envs: fused.
+  int ev_trial[kRing] = {};           // 0 = not a trial step, else the schedule it ran with
+  double trial_ms[4] = {0, 0, 0, 0}, trial_n[4] = {0, 0, 0, 0};
+  int auto_mode = 1; unsigned auto_pos = 0;
   void harvest(int i, bool wait) {
     if (!ev_pending[i]) return;
     if (wait) hipEventSynchronize(ev1[i]);
@@ -180,7 +185,11 @@ struct EngineBase {
       if (ev_trial[i]) { trial_ms[ev_trial[i]] += ms; trial_n[ev_trial[i]]++; }
     }
     ev_trial[i] = 0;
-    if (hipEventElapsedTime(&ms, sv0[i], sv1[i]) == hipSuccess) { solver_ms += ms; solver_launches++; solver_envs += sv_envs[i]; }
+    if (sv_envs[i] > 0 && hipEventElapsedTime(&ms, sv0[i], sv1[i]) == hipSuccess) {
+      const int kd = sv_kind[i] & 1;
+      solver_ms_k[kd] += ms; solver_launches_k[kd]++; solver_envs_k[kd] += sv_envs[i];
+    }
+    sv_envs[i] = 0;   // (a step without a probe leaves 0)
     ev_pending[i] = false;
   }
   virtual int reset(const uint8_t* mask) = 0;
@@ -202,6 +211,8 @@ struct EngineBase {
   hipEvent_t ev_hfork[kMaxSlices] = {}, ev_hjoin[kMaxSlices] = {};
   virtual int acc_sensors(int on) = 0;
   virtual int lean_solver(int on) = 0;
+  virtual int fused_substeps(int on) = 0;
+  virtual int fused_substeps_on() const = 0;
   virtual int field_ptr(rp_field f, void** p, size_t* bytes) = 0;
   bool own_stream = true;
   virtual int profile(long long* out, int n, int enable) = 0;
@@ -437,6 +448,7 @@ struct Engine : EngineBase {
     S.cost_pos = dalloc<int>(E); S.cost_sol = dalloc<int>(E);
     d_heavy = dalloc<int>(E); d_heavy_cnt = dalloc<int>(2 * kMaxSlices);   // (zero-filled)
     S.heavy_list = nullptr; S.heavy_cnt = nullptr; S.heavy_done = nullptr;
+    S.qpos_prev = nullptr; S.qvel_prev = nullptr;
     d_valid = dalloc<unsigned char>(E);  // (zero-filled: nothing is valid yet)
     S.max_newton = M.iterations; S.max_ls = M.ls_iterations;
     {
@@ -455,6 +467,15 @@ struct Engine : EngineBase {
   // the envs outside the light capacity class, compacted per slice (entries base .. of slice sl; d_heavy_cnt[2 sl]
   // = entries, [2 sl + 1] = finished workgroups of the stage that walks them)
   int *d_heavy = nullptr, *d_heavy_cnt = nullptr;
+  // fused substeps (rp_fused_steps_kernel): one launch takes every light env through all substeps of an rp_step
+  // 0 = off, 1 = on, 2 = automatic (a candidate of the schedule choice when the slice count is automatic too)
+  int fused = getenv("RP_FUSED") ? atoi(getenv("RP_FUSED")) : 2;
+  int fused_substeps(int on) override { fused = on < 0 ? 2 : (on > 2 ? 2 : on); return 0; }
+  int fused_substeps_on() const override {
+    const bool capable = lean && !deep && sizeof(T) == 8;
+    return !capable ? 0 : (fused == 1 ? 1 : (fused == 2 && n_slices == 0 ? (auto_mode == 3 ? 1 : 2) : 0));
+  }
+  bool companion = !(getenv("RP_COMPANION") && getenv("RP_COMPANION")[0] == '0');   // (experiment: the full-capacity launch on the slice's own stream)
   static const int kHeavyGrid = 512;   // (one wave of that stage owns a SIMD: half the chip at most)
   // acceleration-stage sensors (rp_set_acc_sensors): state before the last Euler step, outputs
   bool sensors_on = false;
@@ -625,22 +646,48 @@ struct Engine : EngineBase {
     // half's launch (a few heavy envs still running, most SIMDs idle) is filled by the other half's
     // next kernel instead of waiting for a launch boundary.
     int want = n_slices;
-    if (n_slices == 0 && mode == 0 && !capturing && nenv >= 1024) {
-      const unsigned pos = auto_pos++ % 64u;
-      if (pos < 8) { want = 1 + (int)(((pos + 1u) >> 1) & 1u); ev_trial[slot] = want; }
-      else {
-        if (pos == 40) {  // the trial steps finished long ago: read them without waiting
+    const bool fused_capable = lean && !deep && sizeof(T) == 8;
+    bool fused_now = fused == 1 && fused_capable && mode == 0;
+    if (n_slices == 0 && mode == 0 && !fused_now) {
+      int cand[3], nc = 0;
+      cand[nc++] = 1;
+      if (nenv >= 1024 && !capturing) cand[nc++] = 2;
+      if (fused == 2 && fused_capable) cand[nc++] = 3;
+      bool have = false;
+      for (int j = 0; j < nc; j++) have = have || cand[j] == auto_mode;
+      if (!have) auto_mode = cand[0];
+      int sched = auto_mode;
+      if (nc > 1 && !capturing) {
+        const unsigned pos = auto_pos++ % 128u;
+        if (pos >= 16u && pos < 16u + 4u * nc) {   // (short runs -- tests, smoke -- never reach the trials)
+          const int idx = (int)((pos - 16u) % (2u * nc));
+          sched = cand[idx < nc ? idx : 2 * nc - 1 - idx];
+          ev_trial[slot] = sched;
+        } else if (pos == 64) {  // the trial steps finished long ago: read them without waiting
           for (int i = 0; i < kRing; i++) if (ev_trial[i]) harvest(i, false);
-          if (trial_n[1] >= 3 && trial_n[2] >= 3) {
-            const double m1 = trial_ms[1] / trial_n[1], m2 = trial_ms[2] / trial_n[2];
-            if (auto_slices == 1 ? m2 < 0.99 * m1 : m1 < 0.99 * m2) auto_slices = 3 - auto_slices;
+          bool all = true;
+          for (int j = 0; j < nc; j++) all = all && trial_n[cand[j]] >= 3;
+          if (all) {
+            int best = auto_mode;
+            double mb = trial_ms[auto_mode] / trial_n[auto_mode];
+            for (int j = 0; j < nc; j++) {
+              const double m = trial_ms[cand[j]] / trial_n[cand[j]];
+              if (m < 0.99 * trial_ms[auto_mode] / trial_n[auto_mode] && m < mb) { best = cand[j]; mb = m; }
+            }
+            auto_mode = best;
+            if (getenv("RP_SCHED_DEBUG")) {
+              fprintf(stderr, "rp schedule choice:");
+              for (int j = 0; j < nc; j++) fprintf(stderr, " mode %d %.3f ms (n %.1f)", cand[j], trial_ms[cand[j]] / trial_n[cand[j]], trial_n[cand[j]]);
+              fprintf(stderr, " -> %d\n", auto_mode);
+            }
           }
-          for (int k = 1; k <= 2; k++) { trial_ms[k] *= 0.5; trial_n[k] *= 0.5; }
+          for (int k = 1; k <= 3; k++) { trial_ms[k] = 0; trial_n[k] = 0; }   // (the latest block decides: the workload drifts)
         }
-        want = auto_slices;
       }
+      fused_now = sched == 3;
+      want = sched == 2 ? 2 : 1;
     }
-    int nsl = (mode == 0 && want > 1 && nenv >= 1024 && !capturing) ? (want >= 4 ? 4 : 2) : 1;
+    int nsl = (mode == 0 && want > 1 && nenv >= 1024 && !capturing && !fused_now) ? (want >= 4 ? 4 : 2) : 1;
     if (nsl > 1 && !ev_fork && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev_fork = nullptr; nsl = 1; }
     for (int i = 1; i < nsl; i++) {
       if (xstream[i]) continue;
@@ -675,10 +722,42 @@ struct Engine : EngineBase {
       if (lazy_position && mode == 0) lead.active = d_lead;   // skipped for envs whose hand-over is still the one of their state
       launch_pos_on(lead, -1);
       if (mode != 0) continue;
+      if constexpr (sizeof(T) == 8) {
+        if (fused_now) {
+          // heaviest envs first (4096 envs are two rounds of resident waves), from the hand-over just written
+          if (cost_order)
+            hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(512), 0, st, d_order, B.hdr, s.active, base, cnt, (int*)nullptr, (int*)nullptr);
+          RpState<T> sf = ss;
+          sf.heavy_list = d_heavy + base; sf.heavy_cnt = d_heavy_cnt + 2 * sl; sf.heavy_done = d_heavy_cnt + 2 * sl + 1;
+          if (sensors_on) { sf.qpos_prev = d_qpos_prev; sf.qvel_prev = d_qvel_prev; }
+          const bool probe = timeit && sl == 0 && !ev_trial[slot];   // (probes: the schedule in use only)
+          if (probe) { HIP_OK(hipEventRecord(sv0[slot], st)); sv_envs[slot] = cnt * nsub; sv_kind[slot] = 1; }
+          const int cgrid = cnt < kHeavyGrid ? cnt : kHeavyGrid;
+          if (mesh) {
+            hipLaunchKernelGGL((rp_fused_steps_kernel<T, 1>), dim3(cnt), dim3(64), 0, st, M, sf, B, nsub);
+            hipLaunchKernelGGL((rp_cleanup_steps_kernel<T, 1>), dim3(cgrid), dim3(64), 0, st, M, sf, B, nsub);
+          } else {
+            hipLaunchKernelGGL((rp_fused_steps_kernel<T, 0>), dim3(cnt), dim3(64), 0, st, M, sf, B, nsub);
+            hipLaunchKernelGGL((rp_cleanup_steps_kernel<T, 0>), dim3(cgrid), dim3(64), 0, st, M, sf, B, nsub);
+          }
+          if (probe) HIP_OK(hipEventRecord(sv1[slot], st));
+          if (sensors_on) {
+            // sensor stage: position / velocity stage of the state before the last substep + mj_rnePostConstraint
+            // with the constrained qacc (S.warm) and the contact row forces of that substep's solver stage
+            RpState<T> sq = ss;
+            sq.qpos = d_qpos_prev; sq.qvel = d_qvel_prev;
+            sq.sens_torque = d_sens_torque; sq.sens_touch = d_sens_touch;
+            sq.key_trace = nullptr; sq.prof = nullptr;
+            if (mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 2, 0, RPK_MAXD, 1>), dim3(cnt), dim3(64), 0, st, M, sq, B, -1, nsub);
+            else hipLaunchKernelGGL((rp_stage_kernel<T, 2>), dim3(cnt), dim3(64), 0, st, M, sq, B, -1, nsub);
+          }
+          continue;
+        }
+      }
       // ... then n_sub x (mj_step2; mj_step1): dm_control's legacy order.  Two kernels per substep instead
       // of one fused launch: each half fits in registers, the hand-over (RpStage) stays in L2 / Infinity Cache.
       for (int k = 0; k < nsub; k++) {
-        const bool probe = timeit && sl == 0 && k == (int)(step_calls % (unsigned)nsub);
+        const bool probe = timeit && sl == 0 && k == (int)(step_calls % (unsigned)nsub) && !ev_trial[slot];
         const bool sense = sensors_on && k == nsub - 1;
         // cost-ordered launch: heaviest envs first, from the hand-over the position stage just wrote
         // (the same pass compacts the envs outside the light class for the full-capacity solver stage)
@@ -690,12 +769,12 @@ struct Engine : EngineBase {
           HIP_OK(hipMemcpyAsync(d_qpos_prev + (size_t)base * nv, S.qpos + (size_t)base * nv, sizeof(T) * (size_t)cnt * nv, hipMemcpyDeviceToDevice, st));
           HIP_OK(hipMemcpyAsync(d_qvel_prev + (size_t)base * nv, S.qvel + (size_t)base * nv, sizeof(T) * (size_t)cnt * nv, hipMemcpyDeviceToDevice, st));
         }
-        if (probe) { HIP_OK(hipEventRecord(sv0[slot], st)); sv_envs[slot] = cnt; }
+        if (probe) { HIP_OK(hipEventRecord(sv0[slot], st)); sv_envs[slot] = cnt; sv_kind[slot] = 0; }
         // solver stage; the build specialised for "every tree has a 4-link trunk" when it applies
         // light envs on the lean build (two waves per SIMD), the others on the full-capacity build (it skips
         // the light ones) -- side by side: the full-capacity launch goes to the slice's companion stream
         hipStream_t hs = st;
-        if (lean && !capturing) {
+        if (lean && !capturing && companion) {
           if (!hstream[sl] && (hipStreamCreateWithFlags(&hstream[sl], hipStreamNonBlocking) != hipSuccess ||
                                hipEventCreateWithFlags(&ev_hfork[sl], hipEventDisableTiming) != hipSuccess ||
                                hipEventCreateWithFlags(&ev_hjoin[sl], hipEventDisableTiming) != hipSuccess)) {
@@ -822,6 +901,8 @@ int rp_set_lazy_position_stage(rp_engine* e, int on) {
 }
 int rp_set_acc_sensors(rp_engine* e, int on) { return e ? E(e)->acc_sensors(on) : fail("null engine"); }
 int rp_set_lean_solver(rp_engine* e, int on) { return e ? E(e)->lean_solver(on) : fail("null engine"); }
+int rp_set_fused_substeps(rp_engine* e, int on) { return e ? E(e)->fused_substeps(on) : fail("null engine"); }
+int rp_get_fused_substeps(rp_engine* e) { return e ? E(e)->fused_substeps_on() : fail("null engine"); }
 int rp_set_stream_slices(rp_engine* e, int n) {
   if (!e) return fail("null engine");
   if (n != 0 && n != 1 && n != 2 && n != 4) return fail("rp_set_stream_slices: 0 (automatic), 1, 2 or 4");
@@ -892,10 +973,11 @@ int rp_solver_kernel_time(rp_engine* e, double* avg_ms, int* n_launches) {
   // harvest without clearing the step-sequence statistics
   double km = b->kernel_ms; int kl = b->kernel_launches;
   for (int i = 0; i < EngineBase::kRing; i++) b->harvest(i, true);
-  if (avg_ms) *avg_ms = b->solver_launches ? b->solver_ms / b->solver_launches : 0.0;
-  if (n_launches) *n_launches = b->solver_launches;
-  b->last_solver_envs = b->solver_launches ? b->solver_envs / b->solver_launches : 0.0;
-  b->solver_ms = 0; b->solver_launches = 0; b->solver_envs = 0;
+  const int kd = b->solver_launches_k[1] > b->solver_launches_k[0] ? 1 : 0;
+  if (avg_ms) *avg_ms = b->solver_launches_k[kd] ? b->solver_ms_k[kd] / b->solver_launches_k[kd] : 0.0;
+  if (n_launches) *n_launches = b->solver_launches_k[kd];
+  b->last_solver_envs = b->solver_launches_k[kd] ? b->solver_envs_k[kd] / b->solver_launches_k[kd] : 0.0;
+  for (int k = 0; k < 2; k++) { b->solver_ms_k[k] = 0; b->solver_launches_k[k] = 0; b->solver_envs_k[k] = 0; }
   (void)km; (void)kl;
   return 0;
 }

@@ -127,20 +127,19 @@ __global__ void rp_reset_kernel(RpState<T> S, const T* qpos0, const unsigned cha
 // solver + Euler).  FIXED_TL > 0 specialises the solver for trunks of exactly that many links.
 // The host launches  pos, then n_substeps x (sol, pos);  RpStage carries the hand-over.
 // ============================================================================
-template <typename T, int MODE, int FIXED_TL = 0, int MD = RPK_MAXD, int MESH = 0>
 #ifndef RPK_SOL64_WAVES
 #define RPK_SOL64_WAVES 1
 #endif
+template <typename T, int MODE, int FIXED_TL = 0, int MD = RPK_MAXD, int MESH = 0, bool EXT = false>
 __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState<T>& S, const RpStage<T>& B, const int substep,
-                                              const int nsub, const int env) {
+                                              const int nsub, const int env, void* ext, const int lane) {
   using namespace rpk;
   using N = Num<T>;
-  const int lane = threadIdx.x;
   if constexpr (MODE == 1) {
     if (S.lean && B.hdr[env * 8 + 6] == 1) return;   // a light env: rp_lean_solver_kernel steps it
   }
   const int env_active = S.active ? S.active[env] : 1;  // tested after the prologue loads are in flight
-  __shared__ Smem<T, MODE, MD> sm;
+  Smem<T, MODE, MD>& sm = rp_smem<Smem<T, MODE, MD>, EXT>(ext);
   constexpr int TC = MD > 9 ? 8 : 4;            // trunk links the chain-blocked solver holds
   constexpr int NT = TC * (TC + 1) / 2, NREC = NT + TC;  // packed trunk block / per-chain record
   // the chain records of the tree elimination live at the end of the dense block's LDS (sm.H); the
@@ -2411,7 +2410,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
   const int n = listed ? *(volatile const int*)S.heavy_cnt : (int)gridDim.x;
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     const int env = listed ? S.heavy_list[i] : (S.order ? S.order[S.env_base + i] : S.env_base + i);
-    rp_stage_body<T, MODE, FIXED_TL, MD, MESH>(M, S, B, substep, nsub, env);
+    rp_stage_body<T, MODE, FIXED_TL, MD, MESH, false>(M, S, B, substep, nsub, env, nullptr, (int)threadIdx.x);
     if (!listed) break;
     __syncthreads();
   }
@@ -2420,5 +2419,88 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
       __threadfence();
       if (atomicAdd(S.heavy_done, 1) == (int)gridDim.x - 1) { *S.heavy_cnt = 0; *S.heavy_done = 0; __threadfence(); }
     }
+  }
+}
+
+// ============================================================================
+// Fused substeps.  One wave keeps its env through ALL substeps of an rp_step:
+//   n_sub x (lean solver stage; position stage)
+// in one launch -- the stages are the bodies above, run in turn over one LDS allocation (both need ~20 KB and
+// 256 registers: the fused kernel has the occupancy of either).  With one launch per stage, every launch ended
+// with most SIMDs waiting for the few heaviest envs (measured: 38 % of the wave slots idle over an rp_step);
+// over ten substeps an env's cost averages out, and nothing waits at a launch boundary any more.
+// An env that leaves the light capacity class at substep k stops there (hdr[7] = k, appended to the list);
+// rp_cleanup_steps_kernel, launched right after, takes such envs through their remaining substeps with the
+// full-capacity solver stage.  The hand-over between the two stages is global memory written and read by the
+// same wave: a fence + L1 invalidate separates them.
+// ============================================================================
+template <typename T>
+__device__ __forceinline__ void rp_save_prev_state(const RpModel<T>& M, const RpState<T>& S, const int env) {
+  // the state the last substep's forces belong to (acceleration-stage sensors)
+  for (int i = threadIdx.x; i < M.nv; i += 64) {
+    S.qpos_prev[(size_t)env * M.nv + i] = S.qpos[(size_t)env * M.nv + i];
+    S.qvel_prev[(size_t)env * M.nv + i] = S.qvel[(size_t)env * M.nv + i];
+  }
+}
+// (workgroup scope: writer and reader are the same wave, behind the same vector L1, which a CU's own stores keep
+// coherent; an agent-scope fence writes the L2 back and invalidates it -- 20 times per wave and step it cost
+// more than the launch tails the fusion removes)
+#define RPK_STAGE_FENCE()                                     \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");    \
+    __builtin_amdgcn_wave_barrier();                          \
+  } while (0)
+
+template <typename T, int MESH>
+__global__ __launch_bounds__(64, 2) void rp_fused_steps_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int nsub) {
+  using namespace rpk;
+  constexpr size_t NB = sizeof(SmemLean<T>) > sizeof(Smem<T, 0, RPK_MAXD>) ? sizeof(SmemLean<T>) : sizeof(Smem<T, 0, RPK_MAXD>);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NB];
+  const int env = S.order ? S.order[S.env_base + blockIdx.x] : S.env_base + (int)blockIdx.x;
+  if (S.active && S.active[env] == 0) return;
+  for (int k = 0; k < nsub; k++) {
+    // (the lane index goes through an opaque copy every trip: otherwise the per-lane addresses and constants of
+    // BOTH stages are loop invariants, hoisted out of the substep loop and held in registers across it -- 244
+    // spilled registers)
+    int lane = (int)threadIdx.x;
+    asm volatile("" : "+v"(lane));
+    if (*(volatile const int*)&B.hdr[env * 8 + 6] != 1) {
+      // outside the light class from here on: the clean-up launch continues with substep k
+      if (threadIdx.x == 0) { B.hdr[env * 8 + 7] = k; S.heavy_list[atomicAdd(S.heavy_cnt, 1)] = env; }
+      return;
+    }
+    if (S.qpos_prev && k == nsub - 1) rp_save_prev_state(M, S, env);
+    rp_lean_solver_body<T, true>(M, S, B, env, smem, lane);
+    RPK_STAGE_FENCE();
+    asm volatile("" : "+v"(lane));
+    rp_stage_body<T, 0, 0, RPK_MAXD, MESH, true>(M, S, B, k, nsub, env, smem, lane);
+    RPK_STAGE_FENCE();
+  }
+}
+
+template <typename T, int MESH>
+__global__ __launch_bounds__(64, 1) void rp_cleanup_steps_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int nsub) {
+  using namespace rpk;
+  constexpr size_t NB = sizeof(Smem<T, 1, RPK_MAXD>) > sizeof(Smem<T, 0, RPK_MAXD>) ? sizeof(Smem<T, 1, RPK_MAXD>) : sizeof(Smem<T, 0, RPK_MAXD>);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NB];
+  const int n = *(volatile const int*)S.heavy_cnt;
+  RpState<T> Sh = S;   // the full-capacity solver stage takes the env whatever its class
+  Sh.lean = 0; Sh.heavy_list = nullptr;
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int env = S.heavy_list[i];
+    for (int k = *(volatile const int*)&B.hdr[env * 8 + 7]; k < nsub; k++) {
+      int lane = (int)threadIdx.x;
+      asm volatile("" : "+v"(lane));
+      if (S.qpos_prev && k == nsub - 1) rp_save_prev_state(M, S, env);
+      rp_stage_body<T, 1, 0, RPK_MAXD, 0, true>(M, Sh, B, k, nsub, env, smem, lane);
+      RPK_STAGE_FENCE();
+      asm volatile("" : "+v"(lane));
+      rp_stage_body<T, 0, 0, RPK_MAXD, MESH, true>(M, S, B, k, nsub, env, smem, lane);
+      RPK_STAGE_FENCE();
+    }
+  }
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(S.heavy_done, 1) == (int)gridDim.x - 1) { *S.heavy_cnt = 0; *S.heavy_done = 0; __threadfence(); }
   }
 }

@@ -159,8 +159,11 @@ struct RpState {
   // the hand-over headers).  The full-capacity solver stage then runs as a small grid that walks the list -- its
   // workgroups need a whole SIMD's registers each, and a full grid of them, although all but a few leave at
   // once, waited for the lean launch next to it to drain (measured: the join cost up to 200 us per substep)
-  const int* heavy_list;
+  int* heavy_list;
   int *heavy_cnt, *heavy_done;   // entries in the list; finished workgroups (the last one clears both)
+  // fused substeps (rp_fused_steps_kernel): may be null -- where the state before the last substep's solver
+  // stage goes (the acceleration-stage sensors belong to that state)
+  T *qpos_prev, *qvel_prev;
 };
 
 // One workgroup == one wavefront, and a wave's LDS instructions execute in issue
@@ -171,6 +174,12 @@ struct RpState {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
     __builtin_amdgcn_wave_barrier();                         \
   } while (0)
+// The LDS block of a stage: its own static allocation, or (EXT) a buffer the calling kernel owns -- the
+// fused-substeps kernels run two stages in turn over one allocation.
+template <typename S_, bool EXT> __device__ __forceinline__ S_& rp_smem(void* ext) {
+  if constexpr (EXT) return *reinterpret_cast<S_*>(ext);
+  else { __shared__ S_ own; return own; }
+}
 #define RPK_NPROF 48
 // Per-phase shader-clock counters of env 0 (debug aid), accumulated in LDS so a probe
 // costs about one LDS round trip; flushed to global memory once at kernel exit.

@@ -63,16 +63,14 @@ struct SmemLean {
 };
 }  // namespace rpk
 
-template <typename T>
-__global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B) {
+template <typename T, bool EXT = false>
+__device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const RpState<T>& S, const RpStage<T>& B, const int env, void* ext, const int lane) {
   using namespace rpk;
   using N = Num<T>;
   constexpr int MD = RPK_MAXD, TC = 4;
-  const int env = S.order ? S.order[S.env_base + blockIdx.x] : S.env_base + (int)blockIdx.x;
-  const int lane = threadIdx.x;
   if (S.active && S.active[env] == 0) return;
   if (B.hdr[env * 8 + 6] != 1) return;   // not a light env: the full-capacity build takes it
-  __shared__ SmemLean<T> sm;
+  SmemLean<T>& sm = rp_smem<SmemLean<T>, EXT>(ext);
 #ifdef RP_LEAN_TRACE
   if (lane == 0) printf("lean kernel: env %d ncon %d\n", env, B.hdr[env * 8]);
 #endif
@@ -1140,4 +1138,10 @@ __global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpS
   if (S.cost_sol && lane == 0) S.cost_sol[env] = (int)(((long long)__builtin_readcyclecounter() - kernel_t0) >> 8);
 #undef LF
 #undef LI
+}
+
+template <typename T>
+__global__ __launch_bounds__(64, 2) void rp_lean_solver_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B) {
+  const int env = S.order ? S.order[S.env_base + blockIdx.x] : S.env_base + (int)blockIdx.x;
+  rp_lean_solver_body<T, false>(M, S, B, env, nullptr, (int)threadIdx.x);
 }

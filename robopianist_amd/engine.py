@@ -37,7 +37,7 @@ WARN_DENSE_FULL = 32
 
 EXPORTED_SYMBOLS = (
     "rp_create", "rp_destroy", "rp_reset", "rp_set", "rp_get", "rp_step", "rp_forward",
-    "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_set_lazy_position_stage", "rp_set_cost_ordered_launch", "rp_set_stream_slices", "rp_set_lean_solver", "rp_set_acc_sensors", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
+    "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_set_lazy_position_stage", "rp_set_cost_ordered_launch", "rp_set_stream_slices", "rp_set_lean_solver", "rp_set_fused_substeps", "rp_get_fused_substeps", "rp_set_acc_sensors", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
     "rp_n_envs", "rp_dim",
     "rp_kernel_time", "rp_solver_kernel_time", "rp_solver_kernel_envs", "rp_profile", "rp_last_error",
 )
@@ -86,6 +86,8 @@ def load_library(path: str = LIB_PATH):
     L.rp_set_acc_sensors.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.rp_set_stream_slices.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.rp_set_lean_solver.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.rp_set_fused_substeps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.rp_get_fused_substeps.argtypes = [ctypes.c_void_p]
     L.rp_get_stream.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
     L.rp_n_envs.argtypes = [ctypes.c_void_p]
     L.rp_dim.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
@@ -263,6 +265,16 @@ class BatchedPhysics:
         """Capacity classes of the solver stage (include/rp_engine.h: rp_set_lean_solver); an int > 1 caps the
         light class at that many contact Jacobian entries (tests: both classes in one small scene)."""
         self._check(self._L.rp_set_lean_solver(self._h, int(on)))
+
+    def set_fused_substeps(self, on=True):
+        """All substeps of a step in one launch (include/rp_engine.h: rp_set_fused_substeps): False / True, or
+        "auto" (2): a candidate of the engine's own schedule choice."""
+        self._check(self._L.rp_set_fused_substeps(self._h, 2 if on == "auto" else int(on)))
+
+    @property
+    def fused_substeps(self) -> bool:
+        """True if rp_step currently runs the fused schedule."""
+        return self._L.rp_get_fused_substeps(self._h) == 1
 
     def set_cost_ordered_launch(self, on: bool = True):
         """Stage kernels process the envs heaviest-first (include/rp_engine.h); bit-identical results."""

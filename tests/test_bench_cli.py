@@ -80,7 +80,8 @@ def test_bench_configs_emit_the_contract_line(config):
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["kernel_launches_sampled"] >= 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
-    assert rf["algorithmic_bytes_per_launch"] == 7072 * 128
+    # (a launch is one stage of one substep of the batch, or -- fused schedule -- all ten substeps of it)
+    assert rf["algorithmic_bytes_per_launch"] == 7072 * 128 * (10 if rf["schedule"] == "fused substeps" else 1)
 
 
 @pytest.mark.gpu

@@ -516,6 +516,54 @@ def test_both_capacity_classes_in_one_batch_match_the_full_capacity_stage(two_ha
     assert max(int(p.warn_flags.max()) for p in [ref] + modes) == 0
 
 
+def test_fused_substeps_match_the_per_stage_schedule(two_hand_scene):
+    """rp_set_fused_substeps: all substeps of a step in one launch (a wave keeps its env; envs that leave the light
+    class finish in the clean-up launch) against one launch per stage -- the same stage code in the same order per
+    env.  1100 envs on different controls, sensors on, a masked reset and envs sitting out on the way; restarted
+    from the per-stage engine's state at every control step (1e-9 per ten mj_steps; bit-identical while every env
+    stays in the light class).  Second pass with the light class capped at 40 Jacobian entries: a good share of the
+    envs changes class mid-step."""
+    from robopianist_amd import engine
+    si = two_hand_scene
+    m = si.model
+    E = 1100
+    ctrl = _replay_ctrl(si)
+    rng = np.random.default_rng(4)
+    gain = 1 + 0.1 * rng.standard_normal((E, 1))
+    for cap in (1, 40):
+        ref = engine.BatchedPhysics(m, si.key_joint_ids, n_envs=E, precision=64)
+        p = engine.BatchedPhysics(m, si.key_joint_ids, n_envs=E, precision=64)
+        for q, fu in ((ref, False), (p, True)):
+            q.set_lean_solver(cap); q.set_fused_substeps(fu); q.set_acc_sensors(True); q.set_stream_slices(1)
+        assert p.fused_substeps and not ref.fused_substeps
+        left = 0
+        for t in range(16):
+            c = ctrl[10 * (t + 20)][None, :] * gain
+            p.set(engine.QPOS, ref.qpos); p.set(engine.QVEL, ref.qvel); p.set(engine.QACC_WARMSTART, ref.get(engine.QACC_WARMSTART))
+            for q in (ref, p):
+                q.set(engine.CTRL, c)
+                if t == 5:
+                    mask = np.zeros(E, np.uint8); mask[::7] = 1
+                    q.reset(mask)
+                if t == 8:
+                    act = np.ones(E, np.int32); act[5::11] = 0
+                    q.sync(); q.view(engine.ACTIVE).copy_(torch_i32(act)); torch_sync()
+                if t == 9:
+                    q.sync(); q.view(engine.ACTIVE).fill_(1); torch_sync()
+                q.step(10)
+            if cap == 1:
+                assert np.array_equal(ref.qpos, p.qpos) and np.array_equal(ref.qvel, p.qvel), t
+                assert np.array_equal(ref.get(engine.SENSOR_TORQUE), p.get(engine.SENSOR_TORQUE))
+                assert np.array_equal(ref.get(engine.SENSOR_TOUCH), p.get(engine.SENSOR_TOUCH))
+            else:
+                left += int((p.get(engine.DEBUG_HANDOVER_HDR)[:, 6] == 0).sum())
+                assert np.abs(ref.qpos - p.qpos).max() < 1e-9 and np.abs(ref.qvel - p.qvel).max() < 1e-7, t
+                assert np.abs(ref.get(engine.SENSOR_TORQUE) - p.get(engine.SENSOR_TORQUE)).max() < 1e-6
+            assert np.array_equal(ref.get(engine.NCON), p.get(engine.NCON))
+        assert cap == 1 or left > 0.05 * 16 * E
+        assert ref.get(engine.NCON).max() > 0 and max(int(ref.warn_flags.max()), int(p.warn_flags.max())) == 0
+
+
 def torch_sync():
     import torch
     torch.cuda.synchronize()

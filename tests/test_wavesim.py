@@ -35,3 +35,16 @@ def test_kernels_on_the_wave_emulator_match_the_oracle(wavesim_lib, scenario, ns
     worst, maxcon = _run(wavesim_lib, str(nsteps), scenario)
     assert maxcon >= mincon, maxcon
     assert worst < 1e-9, worst
+
+
+def test_fused_substeps_on_the_wave_emulator_match_the_per_stage_schedule(wavesim_lib):
+    """rp_fused_steps_kernel / rp_cleanup_steps_kernel (all substeps of a step in one launch) against one launch
+    per stage, both on the emulator: control steps of ten mj_steps with the sensor stage on, the light class capped
+    so that envs change class mid-step (tests/wavesim/compare_fused.py)."""
+    env = dict(os.environ, RP_ENGINE_LIB=wavesim_lib, WAVESIM_SITE="0")
+    out = subprocess.run([sys.executable, os.path.join(WS, "compare_fused.py"), "4", "wild", "40", "sensors"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    m = re.search(r"fused vs per-stage ([0-9.e+-]+), fused vs oracle ([0-9.e+-]+)", out.stdout)
+    assert m, out.stdout
+    assert float(m.group(1)) < 1e-9 and float(m.group(2)) < 1e-9, out.stdout
