@@ -25,6 +25,8 @@ timeout 500 rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_INSTS_SMEM SQ_INSTS
 timeout 500 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_BRANCH --output-format csv -d $R/sq3 -- $SHORT > $R/sq3.log 2>&1
 unset RP_STREAM_SLICES
 cd $GRAFT_REPO_ROOT
+python scratch/r3/timeline.py $R/stats > $R/timeline.txt 2>&1
 python scratch/r3/summarize_profiles_r03.py $R 2>&1 | tail -40
+mkdir -p $R/summary; cp $R/timeline.txt $R/summary/r03_timeline.txt
 for d in stats fetch write sq1 sq2 sq3; do rm -rf $R/$d; done
 du -sh $R

@@ -15,7 +15,8 @@ try:
     gcol = "Grid_Size_X" if "Grid_Size_X" in kt.columns else ("Grid_Size" if "Grid_Size" in kt.columns else None)
     def sel(pat): return kt[kt.Kernel_Name.str.contains(pat, regex=False)]
     lean, full, pos, task, order = sel(LEAN), sel(FULL), sel(POS), sel("rp_task_"), sel("rp_order_kernel")
-    other = kt[~kt.Kernel_Name.str.contains("rp_stage_kernel|rp_lean_solver|rp_task_|rp_reset|rp_order|rp_lead|rp_mark", regex=True)]
+    fusedk, cleank = sel("rp_fused_steps_kernel"), sel("rp_cleanup_steps_kernel")
+    other = kt[~kt.Kernel_Name.str.contains("rp_stage_kernel|rp_lean_solver|rp_fused_steps|rp_cleanup_steps|rp_task_|rp_reset|rp_order|rp_lead|rp_mark", regex=True)]
     nstep = max(1, len(task))
     cfg = lambda df: {k: str(df.iloc[0][k]) for k in ["LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count"] if k in df.columns} if len(df) else None
     def by_grid(df):
@@ -31,12 +32,14 @@ try:
                 "max_us": float(d.dur.max() / 1e3) if len(d) else None, "share_of_gpu_time": float(df.dur.sum() / kt.dur.sum()),
                 "by_launch_size": by_grid(d), "launch_config": cfg(d)}
     out.update({
-        "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --aux-fp32 0 --host-io 0 --aux-fingertips 0 --steps 158 --warmup 20  (fp64, config 2, hull fingertips = the reference's default, 4096 envs, staggered episode phases, full env.step, stream slices chosen by the engine; the trace also holds the untimed prologue and the lockstep aux leg)",
+        "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --aux-fp32 0 --host-io 0 --aux-fingertips 0 --steps 158 --warmup 20  (fp64, config 2, hull fingertips = the reference's default, 4096 envs, staggered episode phases, full env.step, schedule (stream slices / fused substeps) chosen by the engine; the trace also holds the untimed prologue and the lockstep aux leg)",
         "kernels": {
             "rp_lean_solver_kernel<double> (solver stage of the light envs, dominant)": block(lean),
             "rp_stage_kernel<double, 1, 4, 9> (full-capacity solver stage: the envs outside the light class; empty launches exit at once)": block(full),
             "rp_stage_kernel<double, 0, 0, 9, 1> (position/velocity stage, hull build)": dict(block(pos, 30000), masked_forward_launches=int((pos.dur <= 30000).sum())),
-            "rp_order_kernel (cost-ordered launch)": {"launches": int(len(order)), "avg_us": float(order.dur.mean() / 1e3) if len(order) else None, "share_of_gpu_time": float(order.dur.sum() / kt.dur.sum())},
+            "rp_fused_steps_kernel<double, 1> (fused schedule: all substeps of a step in one launch; trial steps of the schedule choice, the spread prologue and the lockstep aux leg)": block(fusedk),
+            "rp_cleanup_steps_kernel<double, 1> (envs that left the light class under the fused schedule)": block(cleank),
+            "rp_order_kernel (cost-ordered launch + compaction of the envs outside the light class)": {"launches": int(len(order)), "avg_us": float(order.dur.mean() / 1e3) if len(order) else None, "share_of_gpu_time": float(order.dur.sum() / kt.dur.sum())},
             "rp_task_advance_kernel<double> (fused task layer)": {"launches": int(len(task)), "avg_us": float(task.dur.mean() / 1e3) if len(task) else None, "share_of_gpu_time": float(task.dur.sum() / kt.dur.sum())},
             "torch kernels (action gather / scaling, ctrl scatter, masks, output copies)": {"launches_per_step": float(len(other) / nstep), "share_of_gpu_time": float(other.dur.sum() / kt.dur.sum())}},
         "note": "kernel durations overlap when the engine steps two slices on two streams: shares are of the summed kernel time, not of wall time"})
