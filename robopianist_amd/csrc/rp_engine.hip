@@ -476,6 +476,9 @@ struct Engine : EngineBase {
     return !capable ? 0 : (fused == 1 ? 1 : (fused == 2 && n_slices == 0 ? (auto_mode == 3 ? 1 : 2) : 0));
   }
   bool companion = !(getenv("RP_COMPANION") && getenv("RP_COMPANION")[0] == '0');   // (experiment: the full-capacity launch on the slice's own stream)
+  // (one wave per class: a 512-thread workgroup needs a whole idle CU, and with both stage kernels at two waves
+  // per SIMD it waited ~60 us for one on every substep of its slice)
+  int order_threads = getenv("RP_ORDER_THREADS") ? atoi(getenv("RP_ORDER_THREADS")) : 64;
   static const int kHeavyGrid = 512;   // (one wave of that stage owns a SIMD: half the chip at most)
   // acceleration-stage sensors (rp_set_acc_sensors): state before the last Euler step, outputs
   bool sensors_on = false;
@@ -726,7 +729,7 @@ struct Engine : EngineBase {
         if (fused_now) {
           // heaviest envs first (4096 envs are two rounds of resident waves), from the hand-over just written
           if (cost_order)
-            hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(512), 0, st, d_order, B.hdr, s.active, base, cnt, (int*)nullptr, (int*)nullptr);
+            hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(order_threads), 0, st, d_order, B.hdr, s.active, base, cnt, (int*)nullptr, (int*)nullptr);
           RpState<T> sf = ss;
           sf.heavy_list = d_heavy + base; sf.heavy_cnt = d_heavy_cnt + 2 * sl; sf.heavy_done = d_heavy_cnt + 2 * sl + 1;
           if (sensors_on) { sf.qpos_prev = d_qpos_prev; sf.qvel_prev = d_qvel_prev; }
@@ -763,7 +766,7 @@ struct Engine : EngineBase {
         // (the same pass compacts the envs outside the light class for the full-capacity solver stage)
         const bool listed = lean && d_heavy != nullptr;
         if (cost_order || listed)
-          hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(512), 0, st, cost_order ? d_order : nullptr, B.hdr, s.active, base, cnt,
+          hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(order_threads), 0, st, cost_order ? d_order : nullptr, B.hdr, s.active, base, cnt,
                              listed ? d_heavy : nullptr, listed ? d_heavy_cnt + 2 * sl : nullptr);
         if (sense) {  // the state this substep's forces belong to (the solver stage integrates in place)
           HIP_OK(hipMemcpyAsync(d_qpos_prev + (size_t)base * nv, S.qpos + (size_t)base * nv, sizeof(T) * (size_t)cnt * nv, hipMemcpyDeviceToDevice, st));
