@@ -479,7 +479,9 @@ struct Engine : EngineBase {
   // (one wave per class: a 512-thread workgroup needs a whole idle CU, and with both stage kernels at two waves
   // per SIMD it waited ~60 us for one on every substep of its slice)
   int order_threads = getenv("RP_ORDER_THREADS") ? atoi(getenv("RP_ORDER_THREADS")) : 64;
-  static const int kHeavyGrid = 512;   // (one wave of that stage owns a SIMD: half the chip at most)
+  // (each of these workgroups needs a whole idle SIMD, also just to find the list empty: 512 of them delayed the slice's join;
+  // measured 64 ... 128 best on configs 2-4, 16 starves config 3)
+  const int kHeavyGrid = getenv("RP_HEAVY_GRID") ? atoi(getenv("RP_HEAVY_GRID")) : 128;   // (one wave of that stage owns a SIMD: half the chip at most)
   // acceleration-stage sensors (rp_set_acc_sensors): state before the last Euler step, outputs
   bool sensors_on = false;
   T *d_qpos_prev = nullptr, *d_qvel_prev = nullptr, *d_con_force = nullptr, *d_sens_torque = nullptr,
