@@ -476,9 +476,16 @@ struct Engine : EngineBase {
     return !capable ? 0 : (fused == 1 ? 1 : (fused == 2 && n_slices == 0 ? (auto_mode == 3 ? 1 : 2) : 0));
   }
   bool companion = !(getenv("RP_COMPANION") && getenv("RP_COMPANION")[0] == '0');   // (experiment: the full-capacity launch on the slice's own stream)
-  // (one wave per class: a 512-thread workgroup needs a whole idle CU, and with both stage kernels at two waves
-  // per SIMD it waited ~60 us for one on every substep of its slice)
-  int order_threads = getenv("RP_ORDER_THREADS") ? atoi(getenv("RP_ORDER_THREADS")) : 64;
+  // Threads per residue class of rp_order_kernel: two envs per thread.  (A 512-thread workgroup needs a whole
+  // idle CU -- with both stage kernels at two waves per SIMD it waited ~60 us for one on every substep of a
+  // 2048-env slice -- while a single wave takes too long over 512 envs.  Measured: 2048-env slices 64 / 128 /
+  // 256 threads: 681 / 678 / 647 k env-steps/s; 4096-env slices 64 / 128 / 256 / 512: 540 / 547 / 561 / 562 k.)
+  int order_threads_env = getenv("RP_ORDER_THREADS") ? atoi(getenv("RP_ORDER_THREADS")) : 0;
+  int order_threads_for(int cnt) const {
+    if (order_threads_env > 0) return order_threads_env;
+    const int t = ((cnt / 16 + 63) / 64) * 64;
+    return t < 64 ? 64 : (t > 512 ? 512 : t);
+  }
   // (each of these workgroups needs a whole idle SIMD, also just to find the list empty: 512 of them delayed the slice's join;
   // measured 64 ... 128 best on configs 2-4, 16 starves config 3)
   const int kHeavyGrid = getenv("RP_HEAVY_GRID") ? atoi(getenv("RP_HEAVY_GRID")) : 128;   // (one wave of that stage owns a SIMD: half the chip at most)
@@ -731,7 +738,7 @@ struct Engine : EngineBase {
         if (fused_now) {
           // heaviest envs first (4096 envs are two rounds of resident waves), from the hand-over just written
           if (cost_order)
-            hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(order_threads), 0, st, d_order, B.hdr, s.active, base, cnt, (int*)nullptr, (int*)nullptr);
+            hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(order_threads_for(cnt)), 0, st, d_order, B.hdr, s.active, base, cnt, (int*)nullptr, (int*)nullptr);
           RpState<T> sf = ss;
           sf.heavy_list = d_heavy + base; sf.heavy_cnt = d_heavy_cnt + 2 * sl; sf.heavy_done = d_heavy_cnt + 2 * sl + 1;
           if (sensors_on) { sf.qpos_prev = d_qpos_prev; sf.qvel_prev = d_qvel_prev; }
@@ -768,7 +775,7 @@ struct Engine : EngineBase {
         // (the same pass compacts the envs outside the light class for the full-capacity solver stage)
         const bool listed = lean && d_heavy != nullptr;
         if (cost_order || listed)
-          hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(order_threads), 0, st, cost_order ? d_order : nullptr, B.hdr, s.active, base, cnt,
+          hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(order_threads_for(cnt)), 0, st, cost_order ? d_order : nullptr, B.hdr, s.active, base, cnt,
                              listed ? d_heavy : nullptr, listed ? d_heavy_cnt + 2 * sl : nullptr);
         if (sense) {  // the state this substep's forces belong to (the solver stage integrates in place)
           HIP_OK(hipMemcpyAsync(d_qpos_prev + (size_t)base * nv, S.qpos + (size_t)base * nv, sizeof(T) * (size_t)cnt * nv, hipMemcpyDeviceToDevice, st));
