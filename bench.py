@@ -293,7 +293,7 @@ def main():
                 ts = env.step(act_dev.index_select(0, idx))
                 first = ts.step_type == 0
                 # dm_env: the step after LAST resets the env and returns FIRST without simulating
-                idx.copy_(torch.where(first, torch.zeros_like(idx), torch.clamp(idx + 1, max=T - 1)))
+                idx.add_(1).clamp_(max=T - 1).masked_fill_(first, 0)
             else:
                 ts = env.step(act_dev[t % act_dev.shape[0]])
                 first = ts.step_type == 0

@@ -110,7 +110,7 @@ class Environment:
         # the action of an env that is being reset is discarded (dm_env): it must not leak into ctrl /
         # the sustain latch, which the FIRST observation reports as 0 after reset()
         action = torch.as_tensor(action, device=phys.device, dtype=phys.dtype).reshape(self._n_envs, -1)
-        action = torch.where(active[:, None], action, torch.zeros_like(action))   # (a NaN times zero would survive a product)
+        action = action.masked_fill(resetting[:, None], 0.0)   # (a NaN times zero would survive a product)
         fused = task.fused_advance_for(phys) if hasattr(task, "fused_advance_for") else None
         if fused is not None:
             # HIP task layer (include/rp_task.h): the episode reset of the flagged envs, the
@@ -179,6 +179,19 @@ class Environment:
         out the live buffers instead)."""
         if not self._copy_outputs:
             return ts
-        obs = {k: v.clone() for k, v in ts.observation.items()}
-        return TimeStep(ts.step_type.clone(), None if ts.reward is None else ts.reward.clone(),
-                        None if ts.discount is None else ts.discount.clone(), obs)
+        # (one multi-tensor copy instead of a device memcpy per field: ~9 launches per step between two steps'
+        # kernels, when nothing else runs on the GPU)
+        keys = list(ts.observation)
+        src = [ts.step_type] + [v for v in (ts.reward, ts.discount) if v is not None] + [ts.observation[k] for k in keys]
+        dst = [torch.empty_like(v, memory_format=torch.contiguous_format) for v in src]
+        groups = {}
+        for d, v in zip(dst, src):   # (the multi-tensor kernel takes one dtype per call)
+            groups.setdefault(v.dtype, ([], []))[0].append(d); groups[v.dtype][1].append(v)
+        for ds, vs in groups.values():
+            if len(ds) > 1: torch._foreach_copy_(ds, vs)
+            else: ds[0].copy_(vs[0])
+        it = iter(dst)
+        st = next(it)
+        rw = None if ts.reward is None else next(it)
+        dc = None if ts.discount is None else next(it)
+        return TimeStep(st, rw, dc, {k: next(it) for k in keys})

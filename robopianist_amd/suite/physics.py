@@ -104,7 +104,7 @@ class TorchPhysics:
         self._tree_offset.copy_(torch.as_tensor(off, dtype=self.dtype, device=self.device))
 
     def set_active(self, mask: torch.Tensor):
-        self._active.copy_(mask.to(torch.int32))
+        self._active.copy_(mask)   # (bool -> int32 in the copy kernel)
 
     # -- checkpoint / resume -----------------------------------------------------
     _STATE_FIELDS = ("qpos", "qvel", "qacc_warmstart", "ctrl", "qfrc_applied", "time", "tree_offset")

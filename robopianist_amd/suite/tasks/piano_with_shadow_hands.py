@@ -458,8 +458,11 @@ class PianoWithShadowHands(base.PianoTask):
         hands = action[:, :-1]
         n_r = len(self.right_hand.actuators)
         ctrl = physics.ctrl  # zero-copy view of the engine's ctrl array
-        ctrl[:, self._rh_act] = hands[:, :n_r]
-        ctrl[:, self._lh_act] = hands[:, n_r:]
+        if getattr(self, "_hand_act", None) is None or self._hand_act.device != ctrl.device:
+            self._hand_act = torch.cat([torch.as_tensor(self._rh_act, device=ctrl.device).reshape(-1).long(),
+                                        torch.as_tensor(self._lh_act, device=ctrl.device).reshape(-1).long()])
+            assert self._hand_act.numel() == hands.shape[1] and n_r == torch.as_tensor(self._rh_act).numel()
+        ctrl.index_copy_(1, self._hand_act, hands)   # (right hand's actuators, then the left's: one launch)
         self.piano.apply_sustain(action[:, -1])
 
     def after_substeps(self, physics) -> None:
