@@ -210,6 +210,19 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
     }
   }
   WSYNC();
+  // the single-chain contacts that touch my row (bit c), for the Hessian gather: a lane then walks ITS contacts,
+  // and the wave takes as many trips as the busiest lane has contacts (a trunk link: the contacts of its hand)
+  // instead of one trip per contact of the env
+  unsigned cmine = 0;
+  for (int c0 = 0; c0 < ncon; c0 += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int c = c0 + u < ncon ? c0 + u : c0;
+      const int inf = sm.cinf[c];
+      const unsigned long long sup = sm.csup[c];
+      if (c0 + u < ncon && !((inf >> 16) & 1) && ((sup >> lane) & 1)) cmine |= 1u << c;
+    }
+  }
   // contact Jacobian entries, rotated into the contact frame of their contact
   for (int i = lane; i < nent; i += 64) {
     const size_t e = (size_t)env * RpCaps<T>::NE + i;
@@ -819,20 +832,19 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
         const Topo tp = topo();
         const int pos = isl ? tp.depth - tp.TL : -2;
         const int shift = (isl && pos >= 0) ? tp.TL - TC : 0;
-        // (the header of the next contact is fetched while this one is worked on: one LDS round trip less on
-        // the dependent chain of every contact)
-        int inf_n = ncon > 0 ? sm.cinf[0] : 0;
-        unsigned long long sup_n = ncon > 0 ? sm.csup[0] : 0ull;
-        for (int c = 0; c < ncon; c++) {
+        // (every lane walks its own contacts, in ascending order: the same sums as a loop over all contacts,
+        // in as many trips as the busiest lane needs; the header of a lane's next contact is fetched while
+        // this one is worked on)
+        unsigned cm = cmine;
+        asm volatile("" : "+v"(cm));
+        int inf_n = sm.cinf[cm ? __ffs(cm) - 1 : 0];
+        while (__ballot(cm != 0u) != 0ull) {
+          const bool mem = cm != 0u;
+          const int c = mem ? __ffs(cm) - 1 : 0;
+          cm &= cm - 1u;   // (0 & 0xffffffff = 0)
           const int inf = inf_n;
-          const unsigned long long sup = sup_n;
-          {
-            const int cn = c + 1 < ncon ? c + 1 : c;
-            inf_n = sm.cinf[cn]; sup_n = sm.csup[cn];
-          }
-          if ((inf >> 16) & 1) continue;   // cross-chain: below
+          inf_n = sm.cinf[cm ? __ffs(cm) - 1 : 0];
           const int base = inf & 255, cnt = (inf >> 8) & 255;
-          const bool mem = (sup >> lane) & 1;
           const int eo_ = base + (isl ? tp.depth : cnt - 1);
           const int eo = (mem && eo_ < nent) ? eo_ : 0;
           const T ja0 = sm.entJ[eo][0], ja1 = sm.entJ[eo][1], ja2 = sm.entJ[eo][2];
