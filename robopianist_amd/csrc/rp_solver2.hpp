@@ -210,19 +210,21 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
     }
   }
   WSYNC();
-  // the single-chain contacts that touch my row (bit c), for the Hessian gather: a lane then walks ITS contacts,
-  // and the wave takes as many trips as the busiest lane has contacts (a trunk link: the contacts of its hand)
-  // instead of one trip per contact of the env
-  unsigned cmine = 0;
+  // the contacts that touch my row (bit c; `crossm`, uniform: the cross-chain ones), for the Hessian gather and
+  // J^T f: a lane then walks ITS contacts, and the wave takes as many trips as the busiest lane has contacts (a
+  // trunk link: the contacts of its hand) instead of one trip per contact of the env
+  unsigned call = 0, crossm = 0;
   for (int c0 = 0; c0 < ncon; c0 += 4) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int c = c0 + u < ncon ? c0 + u : c0;
       const int inf = sm.cinf[c];
       const unsigned long long sup = sm.csup[c];
-      if (c0 + u < ncon && !((inf >> 16) & 1) && ((sup >> lane) & 1)) cmine |= 1u << c;
+      if (c0 + u < ncon && ((sup >> lane) & 1)) call |= 1u << c;
+      if (c0 + u < ncon && ((inf >> 16) & 1)) crossm |= 1u << c;
     }
   }
+  crossm = (unsigned)uni((int)crossm);
   // contact Jacobian entries, rotated into the contact frame of their contact
   for (int i = lane; i < nent; i += 64) {
     const size_t e = (size_t)env * RpCaps<T>::NE + i;
@@ -640,22 +642,26 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
     WSYNC();
     // every dof lane (link, solver slot) walks the contacts and takes its own entry of those that touch it
     T acc = 0;
-    // (four contacts per trip: their headers, then their entries, travel together)
-    for (int c0 = 0; c0 < ncon; c0 += 4) {
-      unsigned long long sup[4];
-      int e[4];
+    // (its OWN contacts, ascending, four per trip -- their headers, then their entries, travel together: one trip
+    // for most envs instead of one per four contacts of the env)
+    unsigned cm = call;
+    asm volatile("" : "+v"(cm));
+    while (__ballot(cm != 0u) != 0ull) {
+      int c[4], e[4];
+      bool on[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int c = c0 + u < ncon ? c0 + u : c0;
-        sup[u] = c0 + u < ncon ? sm.csup[c] : 0ull;
-        const int e_ = (sm.cinf[c] & 255) + __popcll(sup[u] & lanemask_lt(lane));
+        on[u] = cm != 0u;
+        c[u] = on[u] ? __ffs((int)cm) - 1 : 0;
+        cm &= cm - 1u;
+        const unsigned long long sup = sm.csup[c[u]];
+        const int e_ = (sm.cinf[c[u]] & 255) + __popcll(sup & lanemask_lt(lane));
         e[u] = e_ < nent ? e_ : (nent > 0 ? nent - 1 : 0);
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int c = c0 + u < ncon ? c0 + u : c0;
-        const T v = sm.entJ[e[u]][0] * sm.cv[c][0] + sm.entJ[e[u]][1] * sm.cv[c][1] + sm.entJ[e[u]][2] * sm.cv[c][2];
-        acc += ((sup[u] >> lane) & 1) ? v : (T)0;
+        const T v = sm.entJ[e[u]][0] * sm.cv[c[u]][0] + sm.entJ[e[u]][1] * sm.cv[c[u]][1] + sm.entJ[e[u]][2] * sm.cv[c[u]][2];
+        acc += on[u] ? v : (T)0;
       }
     }
     if (isl) out[0] += acc;
@@ -835,8 +841,9 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
         // (every lane walks its own contacts, in ascending order: the same sums as a loop over all contacts,
         // in as many trips as the busiest lane needs; the header of a lane's next contact is fetched while
         // this one is worked on)
-        unsigned cm = cmine;
+        unsigned cm = call;
         asm volatile("" : "+v"(cm));
+        cm &= ~crossm;   // (cross-chain contacts: below)
         int inf_n = sm.cinf[cm ? __ffs(cm) - 1 : 0];
         while (__ballot(cm != 0u) != 0ull) {
           const bool mem = cm != 0u;
