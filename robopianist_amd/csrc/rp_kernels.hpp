@@ -1982,7 +1982,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     {
       if (isk[0]) sm.keyvec[0][kid[0]] = qd[1];
       if (isk[1]) sm.keyvec[0][kid[1]] = qd[2];
-      if (lane < ncon) { sm.cv[lane][0] = 0; sm.cv[lane][1] = 0; sm.cv[lane][2] = 0; }
+      T cvr[3] = {0, 0, 0};   // J qvel of MY contact (contact lanes)
       unsigned long long sup = 0;
       if (lane < ncon) {
         sup = con_maskA | con_maskB;
@@ -2040,6 +2040,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
                                       (unsigned)bcast((int)(omB & 0xffffffffu), c);
         const int cA = bcast(con_A, c), cb = bcast(base, c), cc = bcast(cnt, c), cx = bcast(con_cross, c);
         const T px = sm.cpos[c][0], py = sm.cpos[c][1], pz = sm.cpos[c][2];
+        T jv3[3] = {0, 0, 0};   // my column times my velocity
         if ((sc >> lane) & 1) {
           T j3[3];
           if (isl) {
@@ -2056,7 +2057,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
             const T rx = px - khx_, rz = pz - khz_;
             j3[0] = sg * rz; j3[1] = 0; j3[2] = sg * -rx;    // (0,1,0) x r
           }
-          lds_add(&sm.cv[c][0], j3[0] * xv); lds_add(&sm.cv[c][1], j3[1] * xv); lds_add(&sm.cv[c][2], j3[2] * xv);
+          jv3[0] = j3[0] * xv; jv3[1] = j3[1] * xv; jv3[2] = j3[2] * xv;
           const int rank = __popcll(sc & lanemask_lt(lane));
           if constexpr (MODE == 0) {
             const size_t e = (size_t)env * RpCaps<T>::NE + cb + rank;
@@ -2065,10 +2066,15 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
             B.entM[e * 2 + 1] = cb | (cc << 8) | (rank << 16);
           }
         }
+        // J qvel of contact c: a wave sum (DPP) of the ~10 member lanes' products, kept by the contact's lane.
+        // (It used to be three LDS adds into the contact's cell: ten lanes on one address cost ~450 cycles of
+        // the CU's LDS pipe per instruction, scratch/ub/ldsadd_ub.hip.)
+        const T s0 = wave_sum(jv3[0]), s1 = wave_sum(jv3[1]), s2 = wave_sum(jv3[2]);
+        if (lane == c) { cvr[0] = s0; cvr[1] = s1; cvr[2] = s2; }
       }
       WSYNC();
       if (lane < ncon) {
-        const T vc[3] = {sm.cv[lane][0], sm.cv[lane][1], sm.cv[lane][2]};
+        const T vc[3] = {cvr[0], cvr[1], cvr[2]};
         const T vn = dot3(con_n, vc), v1 = con_mu * dot3(con_t1, vc), v2 = con_mu * dot3(con_t2, vc);
         const T Bc = sm.cpar[lane][2], kt = sm.cpar[lane][1];
         con_aref[0] = -Bc * (vn + v1) - kt; con_aref[1] = -Bc * (vn - v1) - kt;
