@@ -36,7 +36,7 @@ struct SmemShared {  // used by both stages
   short slotkey[16];
   short slotlink[16];
   signed char keyslot[RPK_NKEYS];
-  unsigned prof[RPK_NPROF];   // per-launch phase cycle counts of env 0 (debug aid)
+  unsigned prof[RPK_NPROF_STAGE];   // per-launch phase cycle counts of env 0 (debug aid)
 #ifdef RPK_OCC_TEST  // occupancy experiment: pad the LDS footprint to force one workgroup per SIMD
   char occ_pad[RPK_OCC_TEST];
 #endif
@@ -52,7 +52,10 @@ struct Smem<T, 0, MD> : SmemShared<T> {
   union {
     T cdof[RPK_NLX(MD)][6];  // until the mass-matrix rows are built
     T vel[RPK_NLX(MD)][6];   // velocity stage: spatial velocities / accelerations
-    float gbox[RPK_NBOXF][12];  // in between (collision): world frame + half sizes of the boxes
+    struct {
+      float gbox[RPK_NBOXF][12];  // in between (collision): world frame + half sizes of the boxes
+      unsigned short glist[RPK_GLIST];   // ... and the compacted geom-geom candidates of the drain rounds (owner << 6 | partner)
+    };
   };
   union {
     T acc[RPK_NLX(MD)][10];  // composite inertias, then subtree forces
@@ -153,7 +156,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
   }
 #endif
   int warn = 0;
-  if (S.prof && env == 0 && lane < RPK_NPROF) sm.prof[lane] = 0;
+  if (S.prof && env == 0 && lane < RPK_NPROF_STAGE) sm.prof[lane] = 0;
   long long prof_t = (long long)__builtin_readcyclecounter();
   const long long kernel_t0 = prof_t;
   const int nl = M.nlink, nk = M.nkey, nv = M.nv, nu = M.nu;
@@ -1464,7 +1467,6 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         }
       }
     }
-    PROF(37);
     // allowed pairs this lane owns (engine_tables.py deals every static pair to one of its two lanes)
     unsigned long long remA = (((unsigned long long)hithi << 32) | hitlo) & gpm;
     // keys: capsules that reach down to the keyboard, against this lane's two keys
@@ -1502,7 +1504,6 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         khx_[s] = (float)khalf[s][0] + 0.01f; khy_[s] = (float)khalf[s][1];
         krb_[s] = (float)krb[s] * 1.0001f + 1e-6f;
       }
-      PROF(38);
       // two near geoms per trip (their broadcasts and tests interleave)
       while (near_mask) {
         const int g0 = __ffsll((long long)near_mask) - 1;
@@ -1535,6 +1536,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     }
 #endif
     int gen_phase = 0;
+    int lpos = 0, lcount = 0;   // compacted geom-geom candidates: next / number of list entries
     while (true) {
       // ---- drain rounds, in a loop of their own (until 64 candidates are pending or the masks are empty): the
       // narrow phase below is the register-hungriest part of this kernel, and in one loop with it the
@@ -1543,14 +1545,55 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       while (gen_phase < 3 && nwork < 64) {
       // ---- one drain round: every lane contributes at most one candidate
       {
-        const unsigned long long rem = gen_phase == 0 ? remA : (gen_phase == 1 ? remK0 : remK1);
-        bool has = rem != 0ull;
+        // Geom-geom candidates are COMPACTED first: the sphere-overlap hits sit unevenly in the lanes (a palm box
+        // touches a dozen spheres, most capsules two or three), and one candidate per lane and round took as many
+        // rounds as the busiest lane has hits (measured 12.5 per mj_step for 185 candidates).  Every lane writes
+        // its hits (owner << 6 | partner) at its prefix offset into a flat list, and a round takes the next 64
+        // entries whoever owns them: three rounds.  (A list that does not hold all hits is refilled.)
+        if (gen_phase == 0 && lpos >= lcount) {
+          if (__ballot(remA != 0ull) == 0ull) { gen_phase = 1; continue; }
+          const int myc = __popcll(remA);
+          int incl = myc;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+          int k = incl - myc;
+          const int total = bcast(incl, 63);
+          unsigned long long m_ = remA;
+          while (__ballot(m_ != 0ull && k < RPK_GLIST) != 0ull) {
+            if (m_ != 0ull && k < RPK_GLIST) {
+              const int b_ = __ffsll((long long)m_) - 1;
+              m_ &= m_ - 1;
+              sm.glist[k] = (unsigned short)((lane << 6) | b_);
+              k++;
+            }
+          }
+          remA = m_;   // (what did not fit stays for the next refill)
+          lcount = total < RPK_GLIST ? total : RPK_GLIST;
+          lpos = 0;
+          WSYNC();
+        }
+        const unsigned long long rem = gen_phase == 1 ? remK0 : remK1;
+        bool has = gen_phase == 0 ? lpos + lane < lcount : rem != 0ull;
+#ifndef RPK_MARK
+        if (S.prof && env == 0 && lane == 0) sm.prof[26] += 1;   // (diagnostic: drain rounds)
+#endif
         if (__ballot(has) == 0ull) gen_phase++;
         else {
-          const int bit = has ? __ffsll((long long)rem) - 1 : 0;
-          const unsigned long long rest = rem & (rem - 1);
-          if (gen_phase == 0) remA = rest; else if (gen_phase == 1) remK0 = rest; else remK1 = rest;
+          // the pair of this lane: geom-geom from the list (a = the lane that found it), keys from my own masks
+          int a = lane, bit = 0;
           if (gen_phase == 0) {
+            const int item = has ? (int)sm.glist[lpos + lane] : 0;
+            a = item >> 6; bit = item & 63;
+            lpos += 64;
+          } else {
+            bit = has ? __ffsll((long long)rem) - 1 : 0;
+            const unsigned long long rest = rem & (rem - 1);
+            if (gen_phase == 1) remK0 = rest; else remK1 = rest;
+          }
+          if (gen_phase == 0) {
+            // (geom a's data from LDS: the same fp32 values its lane held in registers)
+            const float fcx = (float)sm.gpos[a][0], fcy = (float)sm.gpos[a][1], fcz = (float)sm.gpos[a][2];
+            const float fax = sm.gax[a][0], fay = sm.gax[a][1], faz = sm.gax[a][2], fhl = sm.gax[a][3], frr = sm.grr[a];
             // segment-segment distance (boxes: centre point with their bounding radius)
             // against the sum of radii, fp32 with a 0.1 mm allowance: most sphere-overlap
             // candidates between neighbouring phalanges end here
@@ -1592,8 +1635,8 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
               // (true boxes only: a pair with a hull goes on with the three-axis test above -- the portal
               // refinement drops a separated pair within its first two supports, and the fifteen-axis test is
               // paid by the whole wave in every round that holds such a pair)
-              const int ai = lane - ncap;
-              const bool abox = bbox && ai >= 0 && ai < RPK_NBOXF && ((boxmask >> lane) & 1) && ((boxmask >> bit) & 1);
+              const int ai = a - ncap;
+              const bool abox = bbox && ai >= 0 && ai < RPK_NBOXF && ((boxmask >> a) & 1) && ((boxmask >> bit) & 1);
               if (__builtin_amdgcn_ballot_w64(abox && has) != 0ull && abox) {
                 const float* ga_ = sm.gbox[ai];
                 float Rf[3][3], Qf[3][3], tf[3];
@@ -1639,7 +1682,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
           const int idx = nwork + __popcll(mk & lanemask_lt(lane));
           if (has) {
             // (a static pair is owned by either of its lanes: geom 1 of the pair is the lower one)
-            if (gen_phase == 0) { sm.work[idx][0] = (short)(lane < bit ? lane : bit); sm.work[idx][1] = (short)(lane < bit ? bit : lane); }
+            if (gen_phase == 0) { sm.work[idx][0] = (short)(a < bit ? a : bit); sm.work[idx][1] = (short)(a < bit ? bit : a); }
             else { sm.work[idx][0] = (short)bit; sm.work[idx][1] = (short)(RPK_KEYBASE + (gen_phase == 1 ? kid[0] : kid[1])); }
           }
           nwork += __popcll(mk);
@@ -2395,7 +2438,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       }
     }
   }
-  if (S.prof && env == 0 && lane < RPK_NPROF) {
+  if (S.prof && env == 0 && lane < RPK_NPROF_STAGE) {
     WSYNC();
     atomicAdd((unsigned long long*)&S.prof[lane], (unsigned long long)sm.prof[lane]);
   }

@@ -30,6 +30,7 @@
 #define RPK_HMAX 60      // max rows of the dense cross-coupling block (+1 row for its rhs = one lane each; fp64)
 #endif
 #define RPK_WORK 128     // narrow-phase work list
+#define RPK_GLIST 512    // compacted sphere-overlap candidates per refill of the drain rounds (typical: 185 per mj_step)
 #define RPK_MAXD 9       // tree depth levels held by the default kernel builds (trunk <= 4 links + chain <= 5)
 #define RPK_MAXD_DEEP 13 // ... by the deep builds (trunk <= 8 links: every subset of the six forearm dofs)
 #define RPK_NL 52        // max links held by the default kernel builds (two hands x (24 + 2 forearm dofs))
@@ -180,7 +181,8 @@ template <typename S_, bool EXT> __device__ __forceinline__ S_& rp_smem(void* ex
   if constexpr (EXT) return *reinterpret_cast<S_*>(ext);
   else { __shared__ S_ own; return own; }
 }
-#define RPK_NPROF 48
+#define RPK_NPROF 48        // counters the host reads (slots 32.. belong to the lean solver stage)
+#define RPK_NPROF_STAGE 32  // ... of which the stage kernels use the first 32 (their LDS is full: 20480 B at two waves per SIMD)
 // Per-phase shader-clock counters of env 0 (debug aid), accumulated in LDS so a probe
 // costs about one LDS round trip; flushed to global memory once at kernel exit.
 #ifdef RPK_MARK  // static analysis aid: phase boundaries as comments in the ISA listing

@@ -10,7 +10,7 @@ si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions
 m = si.model
 phys = engine.BatchedPhysics(m, si.key_joint_ids, n_envs=E, precision=prec)
 ctrl,_ = load_actions(m)
-names = {0:'load',1:'actuation',2:'M chol+solve',3:'warmstart',4:'H assembly',5:'H chol+solve',6:'mulM/mulJ/quad',7:'linesearch',8:'update+JT',9:'euler',10:'FK',11:'inertia+CRB',18:'geom centres',12:'col: gen: key loop',13:'col: narrow geometry',19:'col: hull pairs (MPR)',24:'col: contact emission',14:'slots+jac',15:'cvel+rne',16:'transm+rows',17:'trace',20:'ts: leaves+rows->LDS',21:'ts: trunk levels',22:'ts: dense gather',23:'col: drain rounds / prefilters',25:'ts: dense chol+solve',5:'ts: back-subst + rest of H solve',32:'ts: chain levels',33:'ts: leader part',34:'ts: trunk gather',35:'mulM0',36:'mulJ',37:'col: gen: sphere pairs',38:'col: gen: key setup'}
+names = {0:'load',1:'actuation',2:'M chol+solve',3:'warmstart',4:'H assembly',5:'H chol+solve',6:'mulM/mulJ/quad',7:'linesearch',8:'update+JT',9:'euler',10:'FK',11:'inertia+CRB',18:'geom centres',12:'col: candidate gen',13:'col: narrow geometry',19:'col: hull pairs (MPR)',24:'col: contact emission',14:'slots+jac',15:'cvel+rne',16:'transm+rows',17:'trace',20:'ts: leaves+rows->LDS',21:'ts: trunk levels',22:'ts: dense gather',23:'col: drain rounds / prefilters',25:'ts: dense chol+solve',5:'ts: back-subst + rest of H solve',32:'ts: chain levels',33:'ts: leader part',34:'ts: trunk gather',35:'mulM0',36:'mulJ'}
 for t in range(30):
     phys.set(engine.CTRL, ctrl[t][None,:]); phys.step(10)
 phys.profile(True)
@@ -21,6 +21,7 @@ for t in range(30,30+n):
     its.append(phys.get(engine.SOLVER_ITER).mean())
 p = phys.profile(False)
 cand, passes = p[30], p[31]; p[30]=0; p[31]=0
+print('drain rounds/mj_step %.2f' % (p[26]/n/10)); p[26]=0
 print('capsule-box cands after prefilter/mj_step %.1f' % (p[27]/n/10)); p[27]=0
 print('geom-geom cands/mj_step %.1f key cands %.1f' % (p[28]/n/10, p[29]/n/10)); p[28]=0; p[29]=0
 tot = p.sum()
