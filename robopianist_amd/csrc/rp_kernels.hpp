@@ -55,6 +55,7 @@ struct Smem<T, 0, MD> : SmemShared<T> {
     struct {
       float gbox[RPK_NBOXF][12];  // in between (collision): world frame + half sizes of the boxes
       unsigned short glist[RPK_GLIST];   // ... and the compacted geom-geom candidates of the drain rounds (owner << 6 | partner)
+      unsigned short klist[RPK_KLIST];   // ... and the geom-key candidates (geom << 7 | key)
     };
   };
   union {
@@ -1469,13 +1470,20 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     }
     // allowed pairs this lane owns (engine_tables.py deals every static pair to one of its two lanes)
     unsigned long long remA = (((unsigned long long)hithi << 32) | hitlo) & gpm;
-    // keys: capsules that reach down to the keyboard, against this lane's two keys
-    unsigned long long remK0 = 0, remK1 = 0;
+    // keys: every geom that reaches down to the keyboard (a lane) walks the keys whose y-interval can reach it.
+    // (The loop used to run the other way round -- the key lanes over the ~40 near geoms, one or two per trip,
+    // 32 k cycles per mj_step for 8.5 candidates.  Keys lie along y in index order, so the keys a geom can touch
+    // are an index window around (y - y_first) / pitch; its half-width covers the keys' half-widths and their
+    // worst deviation from the even grid, both taken from the model at run time: a superset for any layout.)
+    // (Capsule builds.  The hull builds keep the key lanes' loop over the near geoms: with the window walk their
+    // register allocation spilled inside the CRB / RNE level loops -- 207 spilled VGPRs against 144 -- and the
+    // step got 2.8 % slower although candidate generation itself went from 40 k to 26 k cycles.)
+    int kcount = 0;
+    unsigned long long remK0 = 0, remK1 = 0;   // hull builds: the capsules near this lane's two keys
     {
       // extents along world x, y, z of MY geom: a capsule's own axis-aligned extents |axis| * half length +
       // radius, the oriented box's for boxes (a palm box hovering over the keyboard is no candidate), the
-      // bounding radius otherwise -- once per lane, outside the loop over the near geoms (the loop used to
-      // fetch the box of every geom it visited: one LDS round trip on the dependent chain of each trip)
+      // bounding radius otherwise
       float gex = frb, gey = frb, gez = frb;
       {
         const int bi_ = lane - ncap;
@@ -1491,58 +1499,111 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
           gez = fminf(frb, (fabsf(faz) * fhl + frr) * 1.0001f + 1e-4f);
         }
       }
-      unsigned long long near_mask = __ballot(gkc && (fcz - gez <= (float)M.key_zmax));
-      if (nk == 0) near_mask = 0;
-      float kx[2], kz[2], kpx[2], kpy[2], ktop[2], khx_[2], khy_[2], krb_[2];
+      const bool near_me = nk > 0 && gkc && (fcz - gez <= (float)M.key_zmax);
+      if constexpr (MESH != 0) {
+        unsigned long long near_mask = __ballot(near_me);
+        float kx[2], kz[2], kpx[2], kpy[2], ktop[2], khx_[2], khy_[2], krb_[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+          // key box centre = anchor + R_y(q) (hx,0,0)
+          kx[s] = (float)(kpos[s][0] - khalf[s][0] + khalf[s][0] * kcos[s]);
+          kz[s] = (float)(kpos[s][2] - khalf[s][0] * ksin[s]);
+          kpx[s] = (float)kpos[s][0]; kpy[s] = (float)kpos[s][1];
+          ktop[s] = (float)(kpos[s][2] + khalf[s][2]) + 0.01f;
+          khx_[s] = (float)khalf[s][0] + 0.01f; khy_[s] = (float)khalf[s][1];
+          krb_[s] = (float)krb[s] * 1.0001f + 1e-6f;
+        }
+        // two near geoms per trip (their broadcasts and tests interleave)
+        while (near_mask) {
+          const int g0 = __ffsll((long long)near_mask) - 1;
+          near_mask &= near_mask - 1;
+          const bool two = near_mask != 0ull;
+          const int g1 = two ? __ffsll((long long)near_mask) - 1 : g0;
+          near_mask &= near_mask - 1;   // (0 & -1 = 0)
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            const int g = u == 0 ? g0 : g1;
+            const float cx = bcast(fcx, g), cy = bcast(fcy, g), cz = bcast(fcz, g), rb = bcast(frb, g);
+            const float ex_ = bcast(gex, g), ey_ = bcast(gey, g), ez_ = bcast(gez, g);
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+              const float dx = kx[s] - cx, dy = kpy[s] - cy, dz = kz[s] - cz, rr = rb + krb_[s];
+              // bounding spheres, then a conservative box test (the key only rotates about
+              // y, so its y-extent is exact; x/z get a 1 cm allowance)
+              const bool hit = (u == 0 || two) && isk[s] && dx * dx + dy * dy + dz * dz <= rr * rr && fabsf(dy) <= khy_[s] + ey_ &&
+                               fabsf(cx - kpx[s]) <= khx_[s] + ex_ && cz - ez_ <= ktop[s];
+              if (s == 0) remK0 |= hit ? (1ull << g) : 0ull; else remK1 |= hit ? (1ull << g) : 0ull;
+            }
+          }
+        }
+      } else {
+      float kx[2], kz[2], kpy[2], khy_[2];
 #pragma unroll
       for (int s = 0; s < 2; s++) {
         // key box centre = anchor + R_y(q) (hx,0,0)
         kx[s] = (float)(kpos[s][0] - khalf[s][0] + khalf[s][0] * kcos[s]);
         kz[s] = (float)(kpos[s][2] - khalf[s][0] * ksin[s]);
-        kpx[s] = (float)kpos[s][0]; kpy[s] = (float)kpos[s][1];
-        ktop[s] = (float)(kpos[s][2] + khalf[s][2]) + 0.01f;
-        khx_[s] = (float)khalf[s][0] + 0.01f; khy_[s] = (float)khalf[s][1];
-        krb_[s] = (float)krb[s] * 1.0001f + 1e-6f;
+        kpy[s] = (float)kpos[s][1]; khy_[s] = (float)khalf[s][1];
       }
-      // two near geoms per trip (their broadcasts and tests interleave)
-      while (near_mask) {
-        const int g0 = __ffsll((long long)near_mask) - 1;
-        near_mask &= near_mask - 1;
-        const bool two = near_mask != 0ull;
-        const int g1 = two ? __ffsll((long long)near_mask) - 1 : g0;
-        near_mask &= near_mask - 1;   // (0 & -1 = 0)
+      // the even grid through the first and the last key, and how far a key's y-interval can reach from its node
+      const float ky0 = bcast(kpy[0], 0);
+      const float kyl = nk > 64 ? bcast(kpy[1], (nk - 1) & 63) : bcast(kpy[0], nk > 0 ? nk - 1 : 0);
+      const float kpitch = nk > 1 ? (kyl - ky0) / (float)(nk - 1) : 1.f;
+      float dev = 0.f;
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-          const int g = u == 0 ? g0 : g1;
-          const float cx = bcast(fcx, g), cy = bcast(fcy, g), cz = bcast(fcz, g), rb = bcast(frb, g);
-          const float ex_ = bcast(gex, g), ey_ = bcast(gey, g), ez_ = bcast(gez, g);
-#pragma unroll
-          for (int s = 0; s < 2; s++) {
-            const float dx = kx[s] - cx, dy = kpy[s] - cy, dz = kz[s] - cz, rr = rb + krb_[s];
-            // bounding spheres, then a conservative box test (the key only rotates about
-            // y, so its y-extent is exact; x/z get a 1 cm allowance)
-            const bool hit = (u == 0 || two) && isk[s] && dx * dx + dy * dy + dz * dz <= rr * rr && fabsf(dy) <= khy_[s] + ey_ &&
-                             fabsf(cx - kpx[s]) <= khx_[s] + ex_ && cz - ez_ <= ktop[s];
-            if (s == 0) remK0 |= hit ? (1ull << g) : 0ull; else remK1 |= hit ? (1ull << g) : 0ull;
-          }
-        }
+      for (int s = 0; s < 2; s++) if (isk[s]) dev = fmaxf(dev, fabsf(kpy[s] - (ky0 + (float)kid[s] * kpitch)) + khy_[s]);
+      const float kslack = __int_as_float(wave_max(__float_as_int(dev))) * 1.0001f + 1e-5f;   // (non-negative floats order like ints)
+      const float apitch = fabsf(kpitch) > 1e-9f ? fabsf(kpitch) : 1e-9f;
+      int klo = 0, kn = 0;
+      if (near_me) {
+        const float c = (fcy - ky0) / kpitch, w = (gey + kslack) / apitch + 1e-3f;
+        const float lo_ = floorf(c - w), hi_ = ceilf(c + w);
+        const int lo = lo_ < 0.f ? 0 : (lo_ > (float)(nk - 1) ? nk : (int)lo_), hi = hi_ < 0.f ? -1 : (hi_ > (float)(nk - 1) ? nk - 1 : (int)hi_);
+        klo = lo; kn = hi - lo + 1 > 0 ? hi - lo + 1 : 0;
+      }
+      const int kmax = wave_max(kn);
+      for (int r = 0; r < kmax; r++) {
+        const bool on = r < kn;
+        const int k = on ? klo + r : 0;
+        const int src = k & 63;
+        const bool s1 = k >= 64;
+        // the key's moving box centre from the lane that holds the key (ds_bpermute); what does not move, from the
+        // model tables (the same fp32 values the key lanes used to hold)
+        const float tx0 = __shfl(kx[0], src, 64), tx1 = __shfl(kx[1], src, 64), tz0 = __shfl(kz[0], src, 64), tz1 = __shfl(kz[1], src, 64);
+        const float kx_ = s1 ? tx1 : tx0, kz_ = s1 ? tz1 : tz0;
+        const int kk = k < nk ? k : 0;
+        const T *kp_ = M.key_pos() + 3 * kk, *kh_ = M.key_half() + 3 * kk;
+        const float kpx_ = (float)kp_[0], kpy_ = (float)kp_[1], ktop_ = (float)(kp_[2] + kh_[2]) + 0.01f;
+        const float khx2 = (float)kh_[0] + 0.01f, khy2 = (float)kh_[1], krb2 = (float)M.key_rbound()[kk] * 1.0001f + 1e-6f;
+        const float dx = kx_ - fcx, dy = kpy_ - fcy, dz = kz_ - fcz, rr = frb + krb2;
+        // bounding spheres, then a conservative box test (the key only rotates about
+        // y, so its y-extent is exact; x/z get a 1 cm allowance)
+        const bool hit = on && k < nk && dx * dx + dy * dy + dz * dz <= rr * rr && fabsf(dy) <= khy2 + gey &&
+                         fabsf(fcx - kpx_) <= khx2 + gex && fcz - gez <= ktop_;
+        const unsigned long long hm = __ballot(hit);
+        const int at = kcount + __popcll(hm & lanemask_lt(lane));
+        if (hit && at < RPK_KLIST) sm.klist[at] = (unsigned short)((lane << 7) | k);
+        kcount += __popcll(hm);
+      }
+      if (kcount > RPK_KLIST) { warn |= 16; kcount = RPK_KLIST; }   // (RP_WARN_WORK_FULL: more geom-key candidates than the list holds)
       }
     }
     PROF(12);
 #ifndef RPK_MARK
     if (S.prof && env == 0) {
-      int ca = (int)wave_sum((float)__popcll(remA)), ck = (int)wave_sum((float)(__popcll(remK0) + __popcll(remK1)));
+      int ca = (int)wave_sum((float)__popcll(remA)), ck = MESH ? (int)wave_sum((float)(__popcll(remK0) + __popcll(remK1))) : kcount;
       if (lane == 0) { sm.prof[28] += ca; sm.prof[29] += ck; }
     }
 #endif
     int gen_phase = 0;
     int lpos = 0, lcount = 0;   // compacted geom-geom candidates: next / number of list entries
+    int kpos_ = 0;              // geom-key candidates: next list entry
     while (true) {
       // ---- drain rounds, in a loop of their own (until 64 candidates are pending or the masks are empty): the
       // narrow phase below is the register-hungriest part of this kernel, and in one loop with it the
       // allocator spilled the drain loop's own variables -- every round then paid scratch round trips
       // (measured: 34 k cycles per mj_step in the capsule builds, 163 k in the hull builds)
-      while (gen_phase < 3 && nwork < 64) {
+      while (gen_phase < (MESH ? 3 : 2) && nwork < 64) {
       // ---- one drain round: every lane contributes at most one candidate
       {
         // Geom-geom candidates are COMPACTED first: the sphere-overlap hits sit unevenly in the lanes (a palm box
@@ -1572,23 +1633,28 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
           lpos = 0;
           WSYNC();
         }
-        const unsigned long long rem = gen_phase == 1 ? remK0 : remK1;
-        bool has = gen_phase == 0 ? lpos + lane < lcount : rem != 0ull;
+        const unsigned long long rem = gen_phase == 1 ? remK0 : remK1;   // (hull builds)
+        bool has = gen_phase == 0 ? lpos + lane < lcount : (MESH ? rem != 0ull : kpos_ + lane < kcount);
 #ifndef RPK_MARK
         if (S.prof && env == 0 && lane == 0) sm.prof[26] += 1;   // (diagnostic: drain rounds)
 #endif
         if (__ballot(has) == 0ull) gen_phase++;
         else {
-          // the pair of this lane: geom-geom from the list (a = the lane that found it), keys from my own masks
+          // the pair of this lane, from the lists: geom-geom (a = the lane that found it), then geom-key
           int a = lane, bit = 0;
           if (gen_phase == 0) {
             const int item = has ? (int)sm.glist[lpos + lane] : 0;
             a = item >> 6; bit = item & 63;
             lpos += 64;
-          } else {
+          } else if constexpr (MESH != 0) {
             bit = has ? __ffsll((long long)rem) - 1 : 0;
             const unsigned long long rest = rem & (rem - 1);
             if (gen_phase == 1) remK0 = rest; else remK1 = rest;
+            a = gen_phase == 1 ? kid[0] : kid[1];   // (key, geom)
+          } else {
+            const int item = has ? (int)sm.klist[kpos_ + lane] : 0;
+            a = item & 127; bit = item >> 7;   // (key, geom)
+            kpos_ += 64;
           }
           if (gen_phase == 0) {
             // (geom a's data from LDS: the same fp32 values its lane held in registers)
@@ -1683,7 +1749,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
           if (has) {
             // (a static pair is owned by either of its lanes: geom 1 of the pair is the lower one)
             if (gen_phase == 0) { sm.work[idx][0] = (short)(a < bit ? a : bit); sm.work[idx][1] = (short)(a < bit ? bit : a); }
-            else { sm.work[idx][0] = (short)bit; sm.work[idx][1] = (short)(RPK_KEYBASE + (gen_phase == 1 ? kid[0] : kid[1])); }
+            else { sm.work[idx][0] = (short)bit; sm.work[idx][1] = (short)(RPK_KEYBASE + a); }
           }
           nwork += __popcll(mk);
         }

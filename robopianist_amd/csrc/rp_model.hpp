@@ -30,7 +30,10 @@
 #define RPK_HMAX 60      // max rows of the dense cross-coupling block (+1 row for its rhs = one lane each; fp64)
 #endif
 #define RPK_WORK 128     // narrow-phase work list
-#define RPK_GLIST 512    // compacted sphere-overlap candidates per refill of the drain rounds (typical: 185 per mj_step)
+#define RPK_KLIST 192    // geom-key candidates per mj_step (typical: 8.5; with RPK_GLIST and the box table inside the 2496 B the link table leaves)
+#ifndef RPK_GLIST        // (tests shrink it to exercise the refill)
+#define RPK_GLIST 256    // compacted sphere-overlap candidates per refill of the drain rounds (typical: 185 per mj_step)
+#endif
 #define RPK_MAXD 9       // tree depth levels held by the default kernel builds (trunk <= 4 links + chain <= 5)
 #define RPK_MAXD_DEEP 13 // ... by the deep builds (trunk <= 8 links: every subset of the six forearm dofs)
 #define RPK_NL 52        // max links held by the default kernel builds (two hands x (24 + 2 forearm dofs))

@@ -115,6 +115,8 @@ static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 // real atomics
 #define __hip_atomic_fetch_add(p, v, order, scope) ws_fetch_add((p), (v))
 template <typename V> static inline V ws_fetch_add(V* p, V v) { const V o = *p; *p = o + v; return o; }
+static inline float __int_as_float(int v) { float f; __builtin_memcpy(&f, &v, 4); return f; }
+static inline int __float_as_int(float f) { int v; __builtin_memcpy(&v, &f, 4); return v; }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
