@@ -1353,15 +1353,14 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     }
     WSYNC();
     // ---- composite inertias, children -> parent by level and sibling rank [MJ: mj_crb]
+    // (siblings add into their parent's cell together: fire-and-forget LDS adds, at most five lanes on a cell at
+    // the finger roots, instead of one read-modify-write round per sibling rank)
     for (int d = M.maxdepth - 1; d >= 1; d--) {
-      int mr = M.level_maxrank()[d];
-      for (int r = 0; r < mr; r++) {
-        if (isl && depth == d && sibrank == r) {
+      if (isl && depth == d) {
 #pragma unroll
-          for (int k = 0; k < 10; k++) sm.acc[parent][k] += sm.acc[lane][k];
-        }
-        WSYNC();
+        for (int k = 0; k < 10; k++) lds_add(&sm.acc[parent][k], sm.acc[lane][k]);
       }
+      WSYNC();
     }
     if (isl) {
       T crb[10], buf[6];
@@ -2268,14 +2267,11 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     }
     WSYNC();
     for (int d = M.maxdepth - 1; d >= 1; d--) {
-      int mr = M.level_maxrank()[d];
-      for (int r = 0; r < mr; r++) {
-        if (isl && depth == d && sibrank == r) {
+      if (isl && depth == d) {
 #pragma unroll
-          for (int k = 0; k < 6; k++) sm.acc[parent][k] += sm.acc[lane][k];
-        }
-        WSYNC();
+        for (int k = 0; k < 6; k++) lds_add(&sm.acc[parent][k], sm.acc[lane][k]);
       }
+      WSYNC();
     }
     qbias = isl ? dot6(cdofr, sm.acc[lane]) : (T)0;
     PROF(15);
