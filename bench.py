@@ -372,7 +372,7 @@ def main():
             barrier()
         sms, snl = phys.solver_kernel_time()
         senvs = phys.solver_kernel_envs() or float(E)   # a launch covers the batch or one slice of it (fused schedule: x substeps)
-        fused = senvs > 1.5 * E   # (the probes of the fused schedule cover all substeps of the batch)
+        fused = phys.solver_kernel_fused()   # (which schedule's launches the probe figures belong to)
         kms, nl = phys.kernel_time()
         wf = base_env.physics.warn
         warn_or = int(torch.bitwise_or(wf, torch.zeros_like(wf)).max().item()) if wf is not None else 0
@@ -565,10 +565,12 @@ def cpu_leg(args, m, phys, key_ids, cfg):
     note = ("engine (2 envs, same precision as value) vs the CPU oracle on this config's action stream; free running: "
             "rel = |dq| / max(|q_cpu|, 1e-2); teacher forced (the contract): every mj_step restarts from the oracle "
             "state, error relative to the step's largest velocity change.  The free-running figure measures how "
-            "chaotic the trajectory is, not the engine: with capsule fingertips the scripted replay stays under the "
-            "1e-4 bar; with hull fingertips the portal refinement stops on a 1e-6 tolerance, so a rounding-level "
-            "difference can add or drop one refinement step and move a contact distance by up to 1e-6 -- ten orders of "
-            "magnitude above rounding -- and the free-running curves separate (random policies likewise)")
+            "chaotic the trajectory is, not the engine -- see chaos_control: the oracle started 1e-15 away from itself "
+            "separates as far as the engine does (hull fingertips: 1e-4 ... 3e-3; capsule fingertips: 1e-6 ... 5e-6). "
+            "The hull replay amplifies more because the stand-in hand's fingers bounce on each other there (nearly "
+            "parallel capsule-capsule contacts between the ring / little finger's middle links, steps 420-440); the "
+            "portal refinement's tolerance is not the cause: for polytope pairs a tolerance-free termination rule "
+            "gives the bit-identical trajectory (tests/test_oracle.py)")
     out["cpu_baseline_parity"] = dict(parity_block(args, m, key_ids, ctrl_seq), fingertips=args.fingertips, note=note)
     if args.config == 2:
         from robopianist_amd.model import scene as _scene
@@ -622,7 +624,23 @@ def parity_block(args, m, key_ids, ctrl_seq):
         tf_worst = max(tf_worst, float(dv / max(np.abs(orc.qvel - v0).max(), 1e-9)))
         ncon_mismatch += int(chk.get(_eng.NCON)[0] != orc.ncon)
         ncon_max = max(ncon_max, int(orc.ncon))
+    # (3) the CONTROL of figure (1): the oracle against itself with a rounding-sized one-time perturbation of qpos0 on
+    # the same stream.  If the control separates as far as the engine does, (1) measures the trajectory's sensitivity
+    # (a contact-rich replay on the stand-in hand), not the engine.
+    from oracle.rp_oracle import chaos_control
+    control = {}
+    if args.precision == 64:
+        for eps0 in (1e-15, 1e-14):
+            runs = chaos_control(m, chk.blob, ctrl_seq, nstep=1000, hold=args.substeps, seeds=(0, 1, 2), eps0=eps0)
+            control[f"qpos0_perturbed_by_{eps0:g}"] = {
+                "max_rel_qpos_error_1000_mj_steps_by_seed": [r["max_rel_qpos_error"] for r in runs],
+                "running_max_at_mj_step_seed0": runs[0]["running_max_at_mj_step"]}
+        cmax = max(max(v["max_rel_qpos_error_1000_mj_steps_by_seed"]) for v in control.values())
+        control["engine_over_worst_control"] = worst / max(cmax, 1e-300)
+        control["note"] = ("oracle vs the SAME oracle started from qpos0 + eps * N(0, 1) (three seeds each), identical "
+                           "actions: what a rounding-sized difference does to this trajectory in 1000 mj_steps")
     return {
+        "chaos_control": control,
         "max_rel_qpos_error_1000_mj_steps": worst, "max_abs_qpos_error_1000_mj_steps": worst_abs,
         "bar": 1e-4, "rel_error_at_mj_step": curve, "max_rel_error_by_dof_group": gmax,
         "teacher_forced_worst_rel_dv_300_mj_steps": tf_worst, "teacher_forced_bar": 1e-9 if args.precision == 64 else 5e-3,

@@ -185,6 +185,9 @@ int rp_solver_kernel_time(rp_engine* e, double* avg_ms, int* n_launches);
 /* Average number of env-substeps one timed launch covered, over the launches the last rp_solver_kernel_time
  * call reported: the whole batch or one slice of it (rp_set_stream_slices); fused schedule: batch x substeps. */
 int rp_solver_kernel_envs(rp_engine* e, double* avg_envs);
+/* 1 if the launches the last rp_solver_kernel_time call reported were fused-substeps launches, 0 if they were
+ * per-stage solver launches (bench.py names the timed kernel from this, not from a heuristic). */
+int rp_solver_kernel_fused(rp_engine* e);
 /* Debug aid: per-phase shader-clock counters of env 0 (see rp_kernels.hpp PROF).
  * Reads and clears the counters (out may be NULL), then enables/disables them. */
 int rp_profile(rp_engine* e, long long* out, int n, int enable);

@@ -48,7 +48,9 @@ MODEL_FIELDS = (
     "actuator_trntype actuator_trnid actuator_gainprm actuator_biasprm actuator_gear "
     "actuator_ctrllimited actuator_ctrlrange actuator_forcelimited actuator_forcerange "
     "exclude_signature geom_dataid mesh_vert mesh_vertadr mesh_vertnum mesh_graph mesh_graphadr "
-    "site_size sensor_type sensor_objtype sensor_objid").split()
+    "site_size sensor_type sensor_objtype sensor_objid "
+    # what the importer (tools/mjmodel_to_blob.py) must be able to REJECT: dynamics the engine does not model
+    "neq npair actuator_gaintype actuator_biastype actuator_dyntype jnt_group").split()
 
 
 def dump_model(m) -> dict:
@@ -60,6 +62,10 @@ def dump_model(m) -> dict:
     out["model_opt"] = np.array([o.timestep, o.tolerance, o.ls_tolerance, o.impratio, o.iterations,
                                  o.ls_iterations, o.cone, o.jacobian, o.solver, o.integrator], float)
     out["model_opt_gravity"] = np.asarray(o.gravity)
+    if hasattr(o, "mpr_tolerance"):      # (MuJoCo < 3.2; later versions call them ccd_*)
+        out["model_opt_mpr"] = np.array([o.mpr_tolerance, o.mpr_iterations], float)
+    elif hasattr(o, "ccd_tolerance"):
+        out["model_opt_mpr"] = np.array([o.ccd_tolerance, o.ccd_iterations], float)
     out["model_stat_meaninertia"] = np.array([m.stat.meaninertia])
     import mujoco
     out["model_opt_refsafe"] = np.asarray(0 if (int(o.disableflags) & int(mujoco.mjtDisableBit.mjDSBL_REFSAFE)) else 1)

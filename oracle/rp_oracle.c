@@ -684,7 +684,9 @@ static int capsule_box(rawcon* out, const double* cp, const double* cm, const do
  * one contact at the closest points of the two edges.  Contact position = midway between the
  * surfaces, dist = -penetration, normal from geom1 to geom2.  Capacity: the RPO_BOXBOX_MAX deepest
  * points are kept (the engine has three contact slots per geom pair). */
-#define RPO_BOXBOX_MAX 3
+static int g_boxbox_max = 3;   /* experiment knob */
+void rpo_debug_set_boxbox_max(int n) { g_boxbox_max = n; }
+#define RPO_BOXBOX_MAX g_boxbox_max
 static void bb_keep(rawcon* out, int* n, const double* pos, const double* nrm, double dist) {
   /* keep the deepest RPO_BOXBOX_MAX candidates, sorted by dist ascending; the corners of a face
    * resting flat tie exactly, so depths within 1e-10 count as equal and the first comer wins */
@@ -862,30 +864,39 @@ static int box_box(rawcon* out, const double* p1, const double* m1, const double
  * (1e-6, 50). */
 #define CCD_TOL 1e-6
 #define CCD_ITER 50
+static double g_mpr_tol = CCD_TOL;   /* experiment knobs (rpo_debug_set_mpr) */
+static int g_mpr_discrete = 0;
+void rpo_debug_set_mpr(double tol, int discrete) { g_mpr_tol = tol; g_mpr_discrete = discrete; }
 typedef struct { int type; const double *pos, *mat, *size; const double* vert; int nvert; } cgeom;
-typedef struct { double v[3], p1[3], p2[3]; } mpoint;   /* point of B - A, its witnesses on A and B */
+typedef struct { double v[3], p1[3], p2[3]; int id; } mpoint;   /* point of B - A, its witnesses on A and B; id = (vertex of A, vertex of B) for polytopes */
 
-static void geom_support(const cgeom* g, const double* d, double* out) {   /* d: unit, world */
+static int geom_support(const cgeom* g, const double* d, double* out) {   /* d: unit, world; returns the vertex id (polytopes) */
   if (g->type == GEOM_CAPSULE) {
     double ax[3] = {g->mat[2], g->mat[5], g->mat[8]}, sg = dot3(ax, d) >= 0 ? 1.0 : -1.0;
     for (int k = 0; k < 3; k++) out[k] = g->pos[k] + sg*g->size[1]*ax[k] + g->size[0]*d[k];
+    return 0;
   } else if (g->type == GEOM_BOX) {
+    int id = 0;
     for (int k = 0; k < 3; k++) out[k] = g->pos[k];
     for (int a = 0; a < 3; a++) {
       double ax[3] = {g->mat[a], g->mat[3+a], g->mat[6+a]}, sg = dot3(ax, d) >= 0 ? 1.0 : -1.0;
+      if (sg > 0) id |= 1 << a;
       for (int k = 0; k < 3; k++) out[k] += sg*g->size[a]*ax[k];
     }
+    return id;
   } else {
     double dl[3]; matT_vec(dl, g->mat, d);
     int best = 0; double bv = -1e300;
     for (int i = 0; i < g->nvert; i++) { double v = dot3(dl, g->vert + 3*i); if (v > bv) { bv = v; best = i; } }
     double w[3]; mat_vec(w, g->mat, g->vert + 3*best);
     for (int k = 0; k < 3; k++) out[k] = g->pos[k] + w[k];
+    return best;
   }
 }
 static void mpr_support(const cgeom* A, const cgeom* B, const double* d, mpoint* o) {
   double nd[3] = {-d[0], -d[1], -d[2]};
-  geom_support(A, nd, o->p1); geom_support(B, d, o->p2);
+  int ia = geom_support(A, nd, o->p1), ib = geom_support(B, d, o->p2);
+  o->id = ia | (ib << 16);
   for (int k = 0; k < 3; k++) o->v[k] = o->p2[k] - o->p1[k];
 }
 static int normalize3(double* v) { double n = norm3(v); if (n < 1e-14) return 0; v[0] /= n; v[1] /= n; v[2] /= n; return 1; }
@@ -945,7 +956,10 @@ static int mpr_penetration(const cgeom* A, const cgeom* B, rawcon* out) {
     mpr_support(A, B, dir, &v4);
     double reach = dot3(v4.v, dir) - dot3(v1.v, dir);
     if (!hit && dot3(v4.v, dir) < 0) return 0;             /* the origin lies beyond the support plane */
-    if (reach <= CCD_TOL || it == CCD_ITER) {
+    int stop = reach <= g_mpr_tol;
+    if (g_mpr_discrete && A->type != GEOM_CAPSULE && B->type != GEOM_CAPSULE)
+      stop = v4.id == v1.id || v4.id == v2.id || v4.id == v3.id || reach <= 1e-10;
+    if (stop || it == CCD_ITER) {
       if (!hit) return 0;
       /* penetration: depth along the portal normal, witnesses weighted by the origin's ray */
       double depth = dot3(v1.v, dir);
@@ -990,7 +1004,7 @@ static void collision(const rpo_model* m, rpo_data* d) {
     double dv[3] = {p1[0]-p2[0], p1[1]-p2[1], p1[2]-p2[2]};
     double bound = m->geom_rbound[g1] + m->geom_rbound[g2] + margin;
     if (dot3(dv, dv) > bound*bound) continue;
-    rawcon rc[4]; int n = 0;
+    rawcon rc[8]; int n = 0;
     int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
     if (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE)
       n = capsule_capsule(rc, p1, d->geom_xmat + 9*g1, m->geom_size + 3*g1, p2,

@@ -61,8 +61,51 @@ def lib():
         L.rpo_bench_seq.restype = ctypes.c_double
         L.rpo_bench_seq.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                     ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.rpo_debug_set_mpr.argtypes = [ctypes.c_double, ctypes.c_int]
         _lib = L
     return _lib
+
+
+def set_mpr_experiment(tolerance: float = 1e-6, discrete: bool = False) -> None:
+    """Experiment knob of the hull narrow phase (process-wide): the refinement's stopping tolerance, and `discrete`
+    = polytope pairs stop when the support vertex already is a portal vertex (a tolerance-free rule)."""
+    lib().rpo_debug_set_mpr(float(tolerance), int(bool(discrete)))
+
+
+def chaos_control(model, blob, ctrl_seq, nstep=1000, hold=10, seeds=(0, 1, 2), eps0=1e-15, eps_step=0.0,
+                  marks=(1, 10, 100, 300, 1000)):
+    """The CONTROL of the free-running parity figure: the oracle against ITSELF with a rounding-sized perturbation,
+    on the action stream `ctrl_seq` [T, nu] (one row per `hold` mj_steps) from the reset state.
+      eps0     one-time perturbation of qpos after the reset: qpos += eps0 * N(0, 1)
+      eps_step per-step multiplicative noise on qvel: qvel *= 1 + eps_step * N(0, 1) (the size of a second
+               implementation's per-step rounding difference; the engine's measured teacher-forced discrepancy is
+               ~3e-12 of the step's velocity change)
+    Returns, per seed, the same figures bench.py's parity block prints for engine-vs-oracle:
+    rel = |dq| / max(|q_ref|, 1e-2), its maximum over the run and the running maximum at `marks`."""
+    base = Oracle(model, blob)
+    base.reset()
+    ref = np.zeros((nstep, model.nv))
+    for i in range(nstep):
+        base.ctrl[:] = ctrl_seq[(i // hold) % ctrl_seq.shape[0]]
+        base.step(1)
+        ref[i] = base.qpos
+    out = []
+    for seed in seeds:
+        rng = np.random.default_rng(seed)
+        o = Oracle(model, blob)
+        o.reset()
+        o.qpos[:] += eps0 * rng.standard_normal(model.nv)
+        worst, curve = 0.0, {}
+        for i in range(nstep):
+            o.ctrl[:] = ctrl_seq[(i // hold) % ctrl_seq.shape[0]]
+            o.step(1)
+            if eps_step:
+                o.qvel[:] *= 1.0 + eps_step * rng.standard_normal(model.nv)
+            worst = max(worst, float((np.abs(o.qpos - ref[i]) / np.maximum(np.abs(ref[i]), 1e-2)).max()))
+            if i + 1 in marks:
+                curve[str(i + 1)] = worst
+        out.append({"seed": int(seed), "max_rel_qpos_error": worst, "running_max_at_mj_step": curve})
+    return out
 
 
 class Oracle:

@@ -166,6 +166,7 @@ struct EngineBase {
   int sv_kind[kRing] = {};
   int sv_envs[kRing] = {};            // envs the probed solver launch of that slot covered (a slice or the batch)
   double last_solver_envs = 0;
+  int last_solver_kind = 0;
   // schedule of an rp_step, automatic choice (n_slices == 0) among: 1 = one launch per stage, 2 = the same as
   // two slices on two streams (>= 1024 envs), 3 = fused substeps (where they apply and are left on "auto").
   // Steps 16 .. of every 128 run the candidates in the order a b c c b a a b c c b a (a linear drift of
@@ -482,7 +483,8 @@ struct Engine : EngineBase {
   // 256 threads: 681 / 678 / 647 k env-steps/s; 4096-env slices 64 / 128 / 256 / 512: 540 / 547 / 561 / 562 k.)
   int order_threads_env = getenv("RP_ORDER_THREADS") ? atoi(getenv("RP_ORDER_THREADS")) : 0;
   int order_threads_for(int cnt) const {
-    if (order_threads_env > 0) return order_threads_env;
+    // (the kernel's scan needs a full first wave and its launch bound is 512: multiples of 64 in 64 .. 512)
+    if (order_threads_env > 0) { const int t = (order_threads_env + 63) / 64 * 64; return t > 512 ? 512 : t; }
     const int t = ((cnt / 16 + 63) / 64) * 64;
     return t < 64 ? 64 : (t > 512 ? 512 : t);
   }
@@ -665,10 +667,12 @@ struct Engine : EngineBase {
       cand[nc++] = 1;
       if (nenv >= 1024 && !capturing) cand[nc++] = 2;
       if (fused == 2 && fused_capable) cand[nc++] = 3;
+      // (a schedule that is no candidate right now -- two slices inside a stream capture -- is replaced for THIS
+      // step only: the measured choice survives the capture)
       bool have = false;
       for (int j = 0; j < nc; j++) have = have || cand[j] == auto_mode;
-      if (!have) auto_mode = cand[0];
-      int sched = auto_mode;
+      int sched = have ? auto_mode : cand[0];
+      if (!have && !capturing) auto_mode = cand[0];
       if (nc > 1 && !capturing) {
         const unsigned pos = auto_pos++ % 128u;
         if (pos >= 16u && pos < 16u + 4u * nc) {   // (short runs -- tests, smoke -- never reach the trials)
@@ -989,10 +993,12 @@ int rp_solver_kernel_time(rp_engine* e, double* avg_ms, int* n_launches) {
   if (avg_ms) *avg_ms = b->solver_launches_k[kd] ? b->solver_ms_k[kd] / b->solver_launches_k[kd] : 0.0;
   if (n_launches) *n_launches = b->solver_launches_k[kd];
   b->last_solver_envs = b->solver_launches_k[kd] ? b->solver_envs_k[kd] / b->solver_launches_k[kd] : 0.0;
+  b->last_solver_kind = kd;
   for (int k = 0; k < 2; k++) { b->solver_ms_k[k] = 0; b->solver_launches_k[k] = 0; b->solver_envs_k[k] = 0; }
   (void)km; (void)kl;
   return 0;
 }
+int rp_solver_kernel_fused(rp_engine* e) { return e ? E(e)->last_solver_kind : fail("null engine"); }
 int rp_solver_kernel_envs(rp_engine* e, double* avg_envs) {
   if (!e) return fail("null engine");
   if (avg_envs) *avg_envs = E(e)->last_solver_envs;

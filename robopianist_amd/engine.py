@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = (
     "rp_create", "rp_destroy", "rp_reset", "rp_set", "rp_get", "rp_step", "rp_forward",
     "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_set_lazy_position_stage", "rp_set_cost_ordered_launch", "rp_set_stream_slices", "rp_set_lean_solver", "rp_set_fused_substeps", "rp_get_fused_substeps", "rp_set_acc_sensors", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
     "rp_n_envs", "rp_dim",
-    "rp_kernel_time", "rp_solver_kernel_time", "rp_solver_kernel_envs", "rp_profile", "rp_last_error",
+    "rp_kernel_time", "rp_solver_kernel_time", "rp_solver_kernel_envs", "rp_solver_kernel_fused", "rp_profile", "rp_last_error",
 )
 
 _lib = None
@@ -96,6 +96,7 @@ def load_library(path: str = LIB_PATH):
     L.rp_solver_kernel_time.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_int)]
     L.rp_solver_kernel_envs.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+    L.rp_solver_kernel_fused.argtypes = [ctypes.c_void_p]
     L.rp_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     L.rp_set_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.rp_field_ptr.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
@@ -300,6 +301,10 @@ class BatchedPhysics:
         v = ctypes.c_double()
         self._check(self._L.rp_solver_kernel_envs(self._h, ctypes.byref(v)))
         return v.value
+
+    def solver_kernel_fused(self) -> bool:
+        """True when the launches the last solver_kernel_time() reported were fused-substeps launches."""
+        return self._L.rp_solver_kernel_fused(self._h) == 1
 
     def profile(self, enable=True):
         """Reads+clears the per-phase cycle counters of env 0, then (dis)enables them."""

@@ -14,8 +14,10 @@ recorded with:
 engine-table builder consume; `npz_from_model` writes the same file format from a compiled `Model`, so the
 mapping is exercised here -- where MuJoCo cannot be installed -- by a round trip on the stand-in scene
 (tests/test_mujoco_golden.py).  What the mapping requires of the model is asserted, not assumed: 1-dof joints
-only (hinge / slide), fixed tendons, joint / tendon transmissions with position-servo bias, sphere / capsule /
-box / mesh geoms (meshes enter through the vertices of their convex hull).
+only (hinge / slide), fixed tendons (`wrap_type`), joint / tendon transmissions, fixed gain / affine bias / no
+activation dynamics, no equality constraints, no explicit contact pairs, pyramidal cone + Newton + Euler, default
+convex-collision tolerance; sphere / capsule / box / mesh geoms (meshes enter through the vertices of their convex
+hull).  A dump that violates one of these raises ValueError in `model_from_npz`.
 """
 from __future__ import annotations
 
@@ -54,6 +56,24 @@ def model_from_npz(src) -> Tuple[mcompile.Model, np.ndarray]:
     nv, nq, nu = int(g("nv")), int(g("nq")), int(g("nu"))
     if not (nv == nq == njnt):
         raise ValueError(f"the engine handles 1-dof joints only (nq {nq}, nv {nv}, njnt {njnt}): free / ball joints present")
+    # Dynamics the engine does not model are REJECTED, never imported silently (a recording of such a model would
+    # make the golden tests blame the engine).  Dumps written before these fields were recorded pass unchecked.
+    def _reject(key, ok, what):
+        if "model_" + key in d and not ok(np.asarray(d["model_" + key])):
+            raise ValueError(f"unsupported model: {what} (model_{key} = {np.asarray(d['model_' + key]).ravel()[:8]})")
+    _reject("neq", lambda v: int(v) == 0, "equality constraints")
+    _reject("npair", lambda v: int(v) == 0, "explicit contact pairs")
+    _reject("wrap_type", lambda v: (v == 1).all(), "tendon wrapping other than fixed (joint) tendons")             # mjWRAP_JOINT
+    _reject("actuator_gaintype", lambda v: (v == 0).all(), "actuator gain types other than fixed")                 # mjGAIN_FIXED
+    _reject("actuator_biastype", lambda v: np.isin(v, (0, 1)).all(), "actuator bias types other than none / affine")  # mjBIAS_NONE / AFFINE
+    _reject("actuator_dyntype", lambda v: (v == 0).all(), "actuators with activation dynamics")                    # mjDYN_NONE
+    _reject("opt_mpr", lambda v: abs(float(v[0]) - 1e-6) < 1e-12 and int(v[1]) == 50,
+            "convex-collision tolerance / iteration cap other than MuJoCo's defaults (1e-6, 50)")
+    if "model_opt" in d:
+        o_ = np.asarray(d["model_opt"], float)
+        if len(o_) >= 10 and (int(o_[6]) != 0 or int(o_[8]) != 2 or int(o_[9]) != 0):
+            raise ValueError(f"unsupported options: cone {int(o_[6])} (pyramidal = 0), solver {int(o_[8])} (Newton = 2), "
+                             f"integrator {int(o_[9])} (Euler = 0)")
     names = {}
     for kind in ("body", "joint", "geom", "site", "actuator", "tendon"):
         key = "names_" + kind
@@ -175,6 +195,12 @@ def npz_from_model(m: mcompile.Model) -> Dict[str, np.ndarray]:
                                  m.opt_ls_iterations, 0, 0, 2, 0], float)
     out["model_opt_refsafe"] = np.asarray(int(m.opt_refsafe))
     out["model_opt_gravity"] = np.asarray(m.opt_gravity, float)
+    # what the importer checks and rejects (values of a model the engine supports)
+    out["model_opt_mpr"] = np.array([1e-6, 50.0])
+    out["model_neq"] = np.asarray(0); out["model_npair"] = np.asarray(0)
+    out["model_wrap_type"] = np.ones(len(np.asarray(m.wrap_objid).reshape(-1)), np.int32)
+    out["model_actuator_gaintype"] = np.zeros(nu, np.int32); out["model_actuator_biastype"] = np.ones(nu, np.int32)
+    out["model_actuator_dyntype"] = np.zeros(nu, np.int32)
     out["model_stat_meaninertia"] = np.array([m.stat_meaninertia])
     ex = np.asarray(m.exclude_pairs, np.int64).reshape(-1, 2)
     out["model_exclude_signature"] = (ex[:, 0] << 16) + ex[:, 1]

@@ -534,7 +534,13 @@ def test_evaluation_wrapper_fused_reduction_matches_torch():
     dev = a.physics.device
     kj = torch.as_tensor(a.task.piano.joints, device=dev, dtype=torch.long)
     n_last = 0
+    # the reference's own call (evaluation.py:139-141,167-169), per step and env, accumulated like the wrapper does:
+    # pins the fused kernel (and the torch definition) to sklearn, corners included (no positives at all on most
+    # steps, a wrong key without a goal in env 3, all-correct presses in envs 0-2)
+    from sklearn.metrics import precision_recall_fscore_support
+    sk_sums, sk_corners = np.zeros((E, 6)), set()
     for step in range(260):
+        goal_rows = _np(b.task._goal_state[:, 0]) > 0
         act = torch.as_tensor(0.3 * rng.uniform(-1, 1, size=(E, 45)), device=dev)
         act[:, -1] = float(rng.uniform(-1, 1))   # sustain pedal toggles
         if step % 9 == 0:   # press the goal keys of env 0..2 (and a wrong key in env 3) with torques
@@ -548,6 +554,21 @@ def test_evaluation_wrapper_fused_reduction_matches_torch():
         ta, tb = a.step(act), b.step(act)
         assert torch.equal(ta.step_type, tb.step_type)
         assert torch.equal(a._count, b._count), step
+        keys_pred, sus_pred = _np(b.task.piano.activation), _np(b.task.piano.sustain_activation)
+        first, last = _np(tb.first()), _np(tb.last())
+        for e in range(E):
+            if first[e]:
+                continue
+            vals = []
+            for yt, yp in ((goal_rows[e, :-1], keys_pred[e]), (goal_rows[e, -1:], sus_pred[e].reshape(-1))):
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    p, r, f, _ = precision_recall_fscore_support(y_true=yt, y_pred=yp > 0, average="binary", zero_division=1)
+                vals += [p, r, f]
+                sk_corners.add((bool((yt & (yp > 0)).any()), bool((~yt & (yp > 0)).any()), bool((yt & ~(yp > 0)).any())))
+            sk_sums[e] += vals
+        np.testing.assert_allclose(np.where(last[:, None], 0.0, sk_sums), _np(a._sums), rtol=0, atol=1e-12, err_msg=f"sklearn @ {step}")
+        sk_sums[last] = 0.0
         np.testing.assert_allclose(_np(a._sums), _np(b._sums), rtol=0, atol=1e-12, err_msg=str(step))
         np.testing.assert_allclose(_np(a._hist), _np(b._hist), rtol=0, atol=1e-12, err_msg=str(step))
         assert torch.equal(a._n_finished, b._n_finished)
@@ -557,6 +578,7 @@ def test_evaluation_wrapper_fused_reduction_matches_torch():
     for k in ma:
         assert abs(ma[k] - mb[k]) < 1e-12, k
     assert 0.0 < ma["f1"] < 1.0 and ma["recall"] > 0.0, ma
+    assert {(False, False, False), (False, True, False), (True, False, False)} <= sk_corners, sk_corners
 
 
 def test_augmentation_prefetch_switches_bank_slots_without_host_reads():

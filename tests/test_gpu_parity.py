@@ -204,6 +204,32 @@ def test_replay_fp64_1000_steps(two_hand_scene):
     assert rel.max() < 1e-4
 
 
+def test_replay_fp64_1000_steps_hull():
+    """The same replay with the reference's DEFAULT fingertip collider (`primitive_fingertip_collisions=False`: hulls
+    through MPR; /root/reference/robopianist/models/hands/shadow_hand.py:105-107), the configuration bench.py's
+    `value` is quoted on.  This trajectory is more sensitive than the capsule one (the stand-in hand's ring / little
+    finger bounce on each other around step 430), so the free-running engine-vs-oracle figure is judged against its
+    CONTROL: the oracle against itself started qpos0 + 1e-14 N(0, 1) away (oracle.rp_oracle.chaos_control, eight
+    seeds).  Asserted: (a) while the trajectory is still smooth (300 mj_steps) engine and oracle agree to 1e-8;
+    (b) over 1000 mj_steps the engine separates from the oracle no further than 2x the worst control does."""
+    from robopianist_amd.model import scene
+    from oracle.rp_oracle import chaos_control
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=False)
+    ctrl = _replay_ctrl(si)[:1000]
+    rel, maxcon = free_running(si, 64, ctrl)
+    from robopianist_amd import engine
+    blob = engine.make_blob(si.model, si.key_joint_ids)
+    control = chaos_control(si.model, blob, ctrl[::10], nstep=1000, hold=10, seeds=range(8), eps0=1e-14)
+    cworst = max(r["max_rel_qpos_error"] for r in control)
+    print("fp64 hull replay rel err @[1,10,100,300,1000]:", rel[[0, 9, 99, 299, 999]], "max", rel.max(), "max contacts", maxcon)
+    print("control (oracle vs oracle + 1e-14):", sorted(r["max_rel_qpos_error"] for r in control))
+    assert maxcon >= 8
+    assert rel[:300].max() < 1e-8
+    assert rel.max() <= 2.0 * cworst, (rel.max(), cworst)
+
+
 def test_replay_fp32_curve_is_reported(two_hand_scene):
     """fp32 engine on the same replay: parity holds while the motion is smooth and is
     lost once the chaotic self-collisions start.  Bounded (no blow-up), not asserted at

@@ -62,6 +62,31 @@ def test_importer_round_trip_on_the_standin(tmp_path, primitive):
         assert a[k] == b[k], k
 
 
+@pytest.mark.parametrize("field,value,what", [
+    ("model_neq", 1, "equality"), ("model_npair", 2, "contact pairs"), ("model_wrap_type", 3, "tendon wrapping"),
+    ("model_actuator_gaintype", 1, "gain"), ("model_actuator_biastype", 2, "bias"), ("model_actuator_dyntype", 1, "activation"),
+    ("model_opt_mpr", [1e-8, 50.0], "tolerance"), ("model_opt", None, "cone")])
+def test_importer_rejects_dynamics_the_engine_does_not_model(field, value, what):
+    """A real-MuJoCo dump with equality constraints, explicit contact pairs, spatial tendons, non-position actuators,
+    activation dynamics, an elliptic cone or a non-default convex-collision tolerance must raise, not import."""
+    from robopianist_amd.model import scene
+    from robopianist_amd.tools import mjmodel_to_blob as imp
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=True)
+    d = imp.npz_from_model(si.model)
+    imp.model_from_npz(dict(d))   # the supported dump passes
+    bad = dict(d)
+    if field == "model_opt":
+        o = np.array(d["model_opt"], float); o[6] = 1; bad[field] = o   # elliptic cone
+    elif np.ndim(d[field]) == 0 or isinstance(value, list):
+        bad[field] = np.asarray(value)
+    else:
+        v = np.array(d[field]); v[0] = value; bad[field] = v
+    with pytest.raises(ValueError, match=what):
+        imp.model_from_npz(bad)
+
+
 def test_oracle_steps_the_imported_model_like_the_compiled_one(tmp_path):
     from robopianist_amd import engine
     from robopianist_amd.tools import mjmodel_to_blob as imp

@@ -545,3 +545,42 @@ def test_line_search_respects_the_evaluation_limit():
     a_cut, ev_cut = _line_search(rows, quad, 1e-13, ls_iterations=3)
     assert ev_cut <= 4 and ev_full >= ev_cut     # (the limit is checked between evaluations, as in MuJoCo)
     assert _phi(rows, quad, a_cut)[0] <= _phi(rows, quad, 0.0)[0]
+
+
+def test_hull_replay_chaos_control_and_tolerance_free_mpr_termination():
+    """(1) The chaos control of the free-running parity figure: on the Twinkle replay with hull fingertips the
+    oracle started 1e-15 away from itself separates by more than north_star's 1e-4 within 1000 mj_steps (so no
+    second implementation can be held to 1e-4 free-running on this trajectory), while the capsule-fingertip replay
+    stays under it.  (2) A tolerance-free termination of the portal refinement for polytope pairs (stop when the
+    support vertex already is a portal vertex) gives the BIT-IDENTICAL trajectory: with 26-vertex hulls against
+    boxes the 1e-6 tolerance never decides, i.e. it is not what makes the hull replay sensitive."""
+    import os
+    from robopianist_amd import engine
+    from oracle import rp_oracle
+    def build(prim):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=prim)
+        m = si.model
+        a = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "twinkle_twinkle_actions.npy")).astype(np.float64)[:, :-1]
+        lo, hi = m.actuator_ctrlrange[:, 0], m.actuator_ctrlrange[:, 1]
+        return m, engine.make_blob(m, si.key_joint_ids), lo + (np.clip(a, -1, 1) + 1.0) * 0.5 * (hi - lo)
+    m, blob, ctrl = build(False)
+    hull = [r["max_rel_qpos_error"] for r in rp_oracle.chaos_control(m, blob, ctrl, seeds=(0, 1, 2), eps0=1e-15)]
+    assert max(hull) > 1e-4, hull
+    def traj(discrete):
+        rp_oracle.set_mpr_experiment(1e-6, discrete)
+        try:
+            o = rp_oracle.Oracle(m, blob)
+            out = np.zeros((600, m.nv))
+            for i in range(600):
+                o.ctrl[:] = ctrl[i // 10]
+                o.step(1)
+                out[i] = o.qpos
+            return out
+        finally:
+            rp_oracle.set_mpr_experiment(1e-6, False)
+    assert np.array_equal(traj(False), traj(True))
+    mc, blobc, ctrlc = build(True)
+    cap = [r["max_rel_qpos_error"] for r in rp_oracle.chaos_control(mc, blobc, ctrlc, seeds=(0, 1), eps0=1e-15)]
+    assert max(cap) < 1e-4, cap

@@ -416,3 +416,43 @@ def test_optional_observables_can_be_enabled():
     assert obs["piano/activation"].shape == (2, 88)
     task.enable_observable("piano/activation", False)
     assert "piano/activation" not in task.get_observation(env.physics)
+
+
+def test_prf_matches_sklearn_known_answers():
+    """wrappers/evaluation.py::_prf is the definition of the per-step metric of MidiEvaluationWrapper; the reference
+    calls sklearn's precision_recall_fscore_support(average="binary", zero_division=1)
+    (/root/reference/robopianist/wrappers/evaluation.py:139-141,167-169).  Known answers recorded from sklearn
+    (tests/golden/make_prf_golden.py -> prf_sklearn.json) incl. the corners: no positives at all, predictions without
+    a true positive, misses only, all correct; and, where scikit-learn is importable, the live call."""
+    import json
+    import os
+    from robopianist_amd.wrappers.evaluation import _prf
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prf_sklearn.json")) as fh:
+        gold = json.load(fh)
+    assert len(gold["cases"]) >= 70
+    corners = set()
+    for c in gold["cases"]:
+        yt, yp = torch.tensor(c["y_true"]) > 0, torch.tensor(c["y_pred"]) > 0
+        p, r, f = (float(v) for v in _prf(yt, yp))
+        assert abs(p - c["precision"]) < 1e-15 and abs(r - c["recall"]) < 1e-15 and abs(f - c["f1"]) < 1e-15, c
+        tp, fp, fn = int((yt & yp).sum()), int((~yt & yp).sum()), int((yt & ~yp).sum())
+        corners.add((tp > 0, fp > 0, fn > 0))
+    # documented zero_division=1 behaviour at the corners
+    z = torch.zeros(88, dtype=torch.bool); one = z.clone(); one[3] = True
+    assert [float(v) for v in _prf(z, z)] == [1.0, 1.0, 1.0]        # nothing to press, nothing pressed
+    assert [float(v) for v in _prf(z, one)] == [0.0, 1.0, 0.0]      # tp = 0 with fp > 0
+    assert [float(v) for v in _prf(one, z)] == [1.0, 0.0, 0.0]      # a miss, no prediction
+    assert [float(v) for v in _prf(one, one)] == [1.0, 1.0, 1.0]
+    assert len(corners) >= 7, corners     # every tp / fp / fn combination occurs
+    try:
+        from sklearn.metrics import precision_recall_fscore_support
+    except ImportError:
+        return
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        yt, yp = rng.random(88) < 0.1 * rng.random(), rng.random(88) < 0.1 * rng.random()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            p, r, f, _ = precision_recall_fscore_support(y_true=yt, y_pred=yp, average="binary", zero_division=1)
+        got = [float(v) for v in _prf(torch.tensor(yt), torch.tensor(yp))]
+        assert np.allclose(got, [p, r, f], rtol=0, atol=1e-15)
