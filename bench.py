@@ -376,7 +376,11 @@ def main():
         kms, nl = phys.kernel_time()
         wf = base_env.physics.warn
         warn_or = int(torch.bitwise_or(wf, torch.zeros_like(wf)).max().item()) if wf is not None else 0
-        events = {"capacity_overflow_episodes": int(base_env.task.overflow_terminations())
+        # episodes a capacity overflow of the engine touched (they go on, as the reference's would: overflow_termination
+        # is off), and episodes an engine warn flag ENDED (a diverged state)
+        events = {"capacity_overflow_episodes": int(base_env.task.overflow_episodes())
+                  if hasattr(base_env.task, "overflow_episodes") else None,
+                  "episodes_ended_by_warn_flag": int(base_env.task.overflow_terminations())
                   if hasattr(base_env.task, "overflow_terminations") else None}
         q = phys.qpos
         finite = bool(np.isfinite(q).all())

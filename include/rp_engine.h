@@ -65,7 +65,7 @@ typedef enum {
                            observable  shadow_hand.py:248-270,425-432.  Needs rp_set_acc_sensors(e, 1). */
 } rp_field;
 
-#define RP_MAX_CONTACTS 32
+#define RP_MAX_CONTACTS 64
 
 #define RP_WARN_BADSTATE 1     /* NaN / |q|>1e10 in qpos or qvel */
 #define RP_WARN_CONTACT_FULL 2 /* more than 32 simultaneous contacts (or 256 contact Jacobian

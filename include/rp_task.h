@@ -123,6 +123,12 @@ typedef struct rp_task_advance_args {
    * fatal_count (optional) counts those episodes per env */
   int warn_fatal_mask;
   long long* fatal_count;            /* [E] or NULL */
+  /* warn_count (optional) counts per env the episodes that END -- for whatever reason -- with one of
+   * warn_count_mask's bits raised: the episodes a capacity overflow touched when overflows do not end them
+   * (the reference ends an episode only at the end of the MIDI or on a wrong press,
+   * suite/tasks/piano_with_shadow_hands.py:212-220) */
+  int warn_count_mask;
+  long long* warn_count;             /* [E] or NULL */
 } rp_task_advance_args;
 
 int rp_task_advance(const rp_task_advance_args* args, void* hip_stream);

@@ -682,22 +682,17 @@ static int capsule_box(rawcon* out, const double* cp, const double* cm, const do
  * the part of the other box's incident face inside the reference face's prism (vertices, reference
  * corners, edge crossings: up to 8 points), all with that face normal; if it is an edge-edge axis,
  * one contact at the closest points of the two edges.  Contact position = midway between the
- * surfaces, dist = -penetration, normal from geom1 to geom2.  Capacity: the RPO_BOXBOX_MAX deepest
- * points are kept (the engine has three contact slots per geom pair). */
-static int g_boxbox_max = 3;   /* experiment knob */
+ * surfaces, dist = -penetration, normal from geom1 to geom2.  A quadrilateral clipped by a rectangle
+ * has at most eight corners: all candidates are kept in emission order, up to RPO_BOXBOX_MAX = 8
+ * (MuJoCo's maximum for the pair; rounds 1-3 kept the three deepest). */
+static int g_boxbox_max = 8;   /* experiment knob (scratch/r4/contact_stats.py) */
 void rpo_debug_set_boxbox_max(int n) { g_boxbox_max = n; }
 #define RPO_BOXBOX_MAX g_boxbox_max
 static void bb_keep(rawcon* out, int* n, const double* pos, const double* nrm, double dist) {
-  /* keep the deepest RPO_BOXBOX_MAX candidates, sorted by dist ascending; the corners of a face
-   * resting flat tie exactly, so depths within 1e-10 count as equal and the first comer wins */
-  int at = *n;
-  for (int i = 0; i < *n; i++) if (dist < out[i].dist - 1e-10) { at = i; break; }
-  if (at >= RPO_BOXBOX_MAX) return;
-  int last = *n < RPO_BOXBOX_MAX ? *n : RPO_BOXBOX_MAX - 1;
-  for (int i = last; i > at; i--) out[i] = out[i-1];
-  out[at].dist = dist;
-  memcpy(out[at].pos, pos, 3*sizeof(double)); memcpy(out[at].normal, nrm, 3*sizeof(double));
-  if (*n < RPO_BOXBOX_MAX) (*n)++;
+  if (*n >= RPO_BOXBOX_MAX) return;
+  out[*n].dist = dist;
+  memcpy(out[*n].pos, pos, 3*sizeof(double)); memcpy(out[*n].normal, nrm, 3*sizeof(double));
+  (*n)++;
 }
 
 static int box_box(rawcon* out, const double* p1, const double* m1, const double* s1,

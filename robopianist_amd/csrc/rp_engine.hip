@@ -245,6 +245,7 @@ struct Engine : EngineBase {
     for (void* p : allocs) hipFree(p);
     if (d_trace) hipFree(d_trace);
     if (d_mask) hipFree(d_mask);
+    if (h_heavy_peak) hipHostFree(h_heavy_peak);
     for (int i = 0; i < kRing; i++) {
       if (ev0[i]) hipEventDestroy(ev0[i]);
       if (ev1[i]) hipEventDestroy(ev1[i]);
@@ -425,6 +426,8 @@ struct Engine : EngineBase {
     B.entM = dalloc<int>(E * RpCaps<T>::NE * 2);
     B.slots = dalloc<int>(E * 64);
     B.keyslot = dalloc<int>(E * (RPK_NKEYS / 4));
+    B.covf = dalloc<T>(E * (RPK_NC - RPK_NCL) * 12);
+    B.covi = dalloc<int>(E * (RPK_NC - RPK_NCL) * 4);
     // hand-over buffers start as NaN / -1 patterns: a read of anything the position kernel
     // did not write this substep shows up as a bad state instead of silently reusing old data
     hipMemset(B.RM, 0xFF, sizeof(T) * E * RPK_NLX(md()) * (md() + 1));
@@ -448,6 +451,9 @@ struct Engine : EngineBase {
     }
     S.cost_pos = dalloc<int>(E); S.cost_sol = dalloc<int>(E);
     d_heavy = dalloc<int>(E); d_heavy_cnt = dalloc<int>(2 * kMaxSlices);   // (zero-filled)
+    d_heavy_peak = dalloc<int>(kMaxSlices);
+    if (hipHostMalloc((void**)&h_heavy_peak, sizeof(int) * kMaxSlices) != hipSuccess) { (void)hipGetLastError(); h_heavy_peak = nullptr; }
+    else for (int i = 0; i < kMaxSlices; i++) h_heavy_peak[i] = -1;
     S.heavy_list = nullptr; S.heavy_cnt = nullptr; S.heavy_done = nullptr;
     S.qpos_prev = nullptr; S.qvel_prev = nullptr;
     d_valid = dalloc<unsigned char>(E);  // (zero-filled: nothing is valid yet)
@@ -468,6 +474,22 @@ struct Engine : EngineBase {
   // the envs outside the light capacity class, compacted per slice (entries base .. of slice sl; d_heavy_cnt[2 sl]
   // = entries, [2 sl + 1] = finished workgroups of the stage that walks them)
   int *d_heavy = nullptr, *d_heavy_cnt = nullptr;
+  // Grid of the full-capacity solver stage.  Each of its workgroups needs a whole idle SIMD (512 registers) and 55 KB of
+  // LDS even to find the list empty, and the slice's join waits for the last of them: the grid follows the longest
+  // list the stage saw recently -- read back one step late, never waited for (a list longer than the grid is walked
+  // in rounds: slower for a step, never wrong).  Measured, config 2 / 3 hull: fixed 128: 618 / 435 k env-steps/s.
+  int *d_heavy_peak = nullptr, *h_heavy_peak = nullptr;
+  double heavy_est[kMaxSlices] = {64, 64, 64, 64};
+  int heavy_grid_for(int sl, int cnt) {
+    int g = kHeavyGrid;
+    if (!heavy_grid_fixed && h_heavy_peak) {
+      const int seen = *(volatile int*)&h_heavy_peak[sl];
+      if (seen >= 0) { heavy_est[sl] = seen > heavy_est[sl] ? seen : 0.9 * heavy_est[sl] + 0.1 * seen; *(volatile int*)&h_heavy_peak[sl] = -1; }
+      g = (int)(1.25 * heavy_est[sl]) + 4;
+      g = g < 8 ? 8 : (g > kHeavyGrid ? kHeavyGrid : g);
+    }
+    return cnt < g ? cnt : g;
+  }
   // fused substeps (rp_fused_steps_kernel): one launch takes every light env through all substeps of an rp_step
   // 0 = off, 1 = on, 2 = automatic (a candidate of the schedule choice when the slice count is automatic too)
   int fused = getenv("RP_FUSED") ? atoi(getenv("RP_FUSED")) : 2;
@@ -491,6 +513,7 @@ struct Engine : EngineBase {
   // (each of these workgroups needs a whole idle SIMD, also just to find the list empty: 512 of them delayed the slice's join;
   // measured 64 ... 128 best on configs 2-4, 16 starves config 3)
   const int kHeavyGrid = getenv("RP_HEAVY_GRID") ? atoi(getenv("RP_HEAVY_GRID")) : 128;   // (one wave of that stage owns a SIMD: half the chip at most)
+  const bool heavy_grid_fixed = getenv("RP_HEAVY_GRID") != nullptr;   // (experiment: RP_HEAVY_GRID pins the grid)
   // acceleration-stage sensors (rp_set_acc_sensors): state before the last Euler step, outputs
   bool sensors_on = false;
   T *d_qpos_prev = nullptr, *d_qvel_prev = nullptr, *d_con_force = nullptr, *d_sens_torque = nullptr,
@@ -745,16 +768,19 @@ struct Engine : EngineBase {
             hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(order_threads_for(cnt)), 0, st, d_order, B.hdr, s.active, base, cnt, (int*)nullptr, (int*)nullptr);
           RpState<T> sf = ss;
           sf.heavy_list = d_heavy + base; sf.heavy_cnt = d_heavy_cnt + 2 * sl; sf.heavy_done = d_heavy_cnt + 2 * sl + 1;
+          sf.heavy_peak = capturing ? nullptr : d_heavy_peak + sl;
           if (sensors_on) { sf.qpos_prev = d_qpos_prev; sf.qvel_prev = d_qvel_prev; }
           const bool probe = timeit && sl == 0 && !ev_trial[slot];   // (probes: the schedule in use only)
           if (probe) { HIP_OK(hipEventRecord(sv0[slot], st)); sv_envs[slot] = cnt * nsub; sv_kind[slot] = 1; }
-          const int cgrid = cnt < kHeavyGrid ? cnt : kHeavyGrid;
+          const int cgrid = capturing ? (cnt < kHeavyGrid ? cnt : kHeavyGrid) : heavy_grid_for(sl, cnt);
           if (mesh) {
             hipLaunchKernelGGL((rp_fused_steps_kernel<T, 1>), dim3(cnt), dim3(64), 0, st, M, sf, B, nsub);
-            hipLaunchKernelGGL((rp_cleanup_steps_kernel<T, 1>), dim3(cgrid), dim3(64), 0, st, M, sf, B, nsub);
+            if (trunk4) hipLaunchKernelGGL((rp_cleanup_steps_kernel<T, 1, 4>), dim3(cgrid), dim3(64), 0, st, M, sf, B, nsub);
+            else hipLaunchKernelGGL((rp_cleanup_steps_kernel<T, 1, 0>), dim3(cgrid), dim3(64), 0, st, M, sf, B, nsub);
           } else {
             hipLaunchKernelGGL((rp_fused_steps_kernel<T, 0>), dim3(cnt), dim3(64), 0, st, M, sf, B, nsub);
-            hipLaunchKernelGGL((rp_cleanup_steps_kernel<T, 0>), dim3(cgrid), dim3(64), 0, st, M, sf, B, nsub);
+            if (trunk4) hipLaunchKernelGGL((rp_cleanup_steps_kernel<T, 0, 4>), dim3(cgrid), dim3(64), 0, st, M, sf, B, nsub);
+            else hipLaunchKernelGGL((rp_cleanup_steps_kernel<T, 0, 0>), dim3(cgrid), dim3(64), 0, st, M, sf, B, nsub);
           }
           if (probe) HIP_OK(hipEventRecord(sv1[slot], st));
           if (sensors_on) {
@@ -772,6 +798,7 @@ struct Engine : EngineBase {
       }
       // ... then n_sub x (mj_step2; mj_step1): dm_control's legacy order.  Two kernels per substep instead
       // of one fused launch: each half fits in registers, the hand-over (RpStage) stays in L2 / Infinity Cache.
+      int hgrid_step = 0;   // (the full-capacity stage's grid: one choice per step and slice)
       for (int k = 0; k < nsub; k++) {
         const bool probe = timeit && sl == 0 && k == (int)(step_calls % (unsigned)nsub) && !ev_trial[slot];
         const bool sense = sensors_on && k == nsub - 1;
@@ -806,7 +833,8 @@ struct Engine : EngineBase {
         int hgrid = cnt;
         if (listed) {
           sh.heavy_list = d_heavy + base; sh.heavy_cnt = d_heavy_cnt + 2 * sl; sh.heavy_done = d_heavy_cnt + 2 * sl + 1;
-          hgrid = cnt < kHeavyGrid ? cnt : kHeavyGrid;
+          sh.heavy_peak = capturing ? nullptr : d_heavy_peak + sl;
+          hgrid = capturing ? (cnt < kHeavyGrid ? cnt : kHeavyGrid) : (k == 0 ? (hgrid_step = heavy_grid_for(sl, cnt)) : hgrid_step);
         }
         if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 0, RPK_MAXD_DEEP>), dim3(hgrid), dim3(64), 0, hs, M, sh, B, k, nsub);
         else if (trunk4) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 4>), dim3(hgrid), dim3(64), 0, hs, M, sh, B, k, nsub);
@@ -832,6 +860,11 @@ struct Engine : EngineBase {
     }
     for (int i = 1; i < nsl; i++) { HIP_OK(hipEventRecord(ev_join[i], xstream[i])); HIP_OK(hipStreamWaitEvent(stream, ev_join[i], 0)); }
     hipLaunchKernelGGL(rp_mark_valid_kernel, dim3(hb), dim3(256), 0, stream, d_valid, s.active, nenv);
+    if (mode == 0 && lean && !capturing && h_heavy_peak && !heavy_grid_fixed) {
+      // the longest lists of this step, for the grids of a later one (the host never waits for the copy)
+      HIP_OK(hipMemcpyAsync(h_heavy_peak, d_heavy_peak, sizeof(int) * kMaxSlices, hipMemcpyDeviceToHost, stream));
+      HIP_OK(hipMemsetAsync(d_heavy_peak, 0, sizeof(int) * kMaxSlices, stream));
+    }
     HIP_OK(hipGetLastError());
     if (mode == 0) step_calls++;
     if (timeit) { HIP_OK(hipEventRecord(ev1[slot], stream)); ev_pending[slot] = true; }

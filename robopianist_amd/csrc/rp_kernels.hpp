@@ -13,11 +13,13 @@
 #else
 // (the box-box routine is a real call: its arguments and result live in memory, so they are copies --
 // the capsule paths' own arrays stay in registers)
-#define RPK_BOXBOX(rc_, pA_, mA_, sA_, pB_, mB_, sB_) [&]() -> int {                            \
+// (up to eight points: the first three go on in registers like every other pair's, points four to eight stay in
+// the memory-resident array `bx_` and are emitted from there)
+#define RPK_BOXBOX(rc_, bx_, pA_, mA_, sA_, pB_, mB_, sB_) [&]() -> int {                       \
     T a_[15], b_[15]; RawCon<T> o_[3];                                                          \
     _Pragma("unroll") for (int i_ = 0; i_ < 3; i_++) { a_[i_] = (pA_)[i_]; b_[i_] = (pB_)[i_]; a_[12 + i_] = (sA_)[i_]; b_[12 + i_] = (sB_)[i_]; } \
     _Pragma("unroll") for (int i_ = 0; i_ < 9; i_++) { a_[3 + i_] = (mA_)[i_]; b_[3 + i_] = (mB_)[i_]; }                     \
-    const int n_ = box_box(o_, a_, a_ + 3, a_ + 12, b_, b_ + 3, b_ + 12);                       \
+    const int n_ = box_box(o_, bx_, a_, a_ + 3, a_ + 12, b_, b_ + 3, b_ + 12);                  \
     (rc_)[0] = o_[0]; (rc_)[1] = o_[1]; (rc_)[2] = o_[2];                                       \
     return n_; }()
 #endif
@@ -63,17 +65,16 @@ struct Smem<T, 0, MD> : SmemShared<T> {
     struct {            // in between (collision .. contact Jacobians):
       float gax[RPK_WAVE][4];  // fp32 capsule axes for the candidate prefilter: world axis, half-length
       float grr[RPK_WAVE];     // radius (bounding radius for boxes)
-      T cpos[RPK_NC][3];       // contact points, normals, distances
-      T cn[RPK_NC][3];
-      T cdist[RPK_NC];
-      T cpar[RPK_NC][4];       // mu, kterm (K*imp*dist), B, D
-      T cv[RPK_NC][3];         // J qvel per contact (accumulated with LDS adds)
+      T cpos[RPK_NCL][3];      // contact points, normals, distances of the first RPK_NCL contacts (the rest: RpStage::covf)
+      T cn[RPK_NCL][3];
+      T cdist[RPK_NCL];
+      T cpar[RPK_NCL][4];      // mu, kterm (K*imp*dist), B, D
     };
   };
   T gpos[RPK_WAVE][3];
   T kq[RPK_NKEYS];
   T keyvec[1][RPK_NKEYS];
-  int cA[RPK_NC], cB[RPK_NC], cgA[RPK_NC], cgB[RPK_NC];
+  int cA[RPK_NCL], cB[RPK_NCL], cgA[RPK_NCL], cgB[RPK_NCL];
 };
 // ---- sensor stage (MODE 2): the position / velocity stage of the state BEFORE the last Euler
 // step, plus what the acceleration-stage sensors need (mj_rnePostConstraint, mj_sensorAcc)
@@ -93,8 +94,8 @@ struct Smem<T, 1, MD> : SmemShared<T> {
   T keyvec[2][RPK_NKEYS];
   T entJ[RpCaps<T>::NE][3];            // contact Jacobian entries (see RpStage)
   int entM[RpCaps<T>::NE][2];
-  T cC[RPK_NC][6];              // per-contact 3x3 weight of the current Newton iteration
-  T cv[RPK_NC][3];              // per-contact 3-vector staging (J x, or the contact force)
+  T cC[RpCaps<T>::NC][6];       // per-contact 3x3 weight of the current Newton iteration
+  T cv[RpCaps<T>::NC][3];       // per-contact 3-vector staging (J x, or the contact force)
   T jt[RPK_WAVE];               // J^T f staging, one value per solver row
   T actf[RPK_WAVE];
 };
@@ -770,7 +771,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         for (int e0 = 0; e0 < nent; e0 += 64) {
           const int e = e0 + lane < nent ? e0 + lane : nent - 1;
           const int m0 = sm.entM[e][0];
-          const int ln = m0 & 63, c = (m0 >> 6) & 31;
+          const int ln = RPK_EM_LANE(m0), c = RPK_EM_CON(m0);
           const T j0 = sm.entJ[e][0], j1 = sm.entJ[e][1], j2 = sm.entJ[e][2];
           const T xl = sm.vec[0][ln];
           const T xk = sm.keyvec[0][sm.slotkey[ln >= nl ? ln - nl : 0]];
@@ -830,7 +831,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         for (int e0 = 0; e0 < nent; e0 += 64) {
           const int e = e0 + lane < nent ? e0 + lane : nent - 1;
           const int m0 = sm.entM[e][0];
-          const int ln = m0 & 63, c = (m0 >> 6) & 31;
+          const int ln = RPK_EM_LANE(m0), c = RPK_EM_CON(m0);
           const T v = sm.entJ[e][0] * sm.cv[c][0] + sm.entJ[e][1] * sm.cv[c][1] + sm.entJ[e][2] * sm.cv[c][2];
           if (e0 + lane < nent) lds_add(&sm.jt[ln], v);
         }
@@ -891,6 +892,11 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         mulM(qa, Ma);
         mulJ(qa, jar); sub_aref(jar);
         T cost = wave_sum(update(jar, frc) + gauss(qa, Ma));
+#ifdef RP_SOLVER_TRACE   // (emulator-only diagnostics)
+        if (env == 0 && lane < ncon) printf("  contact %d: D %.6e aref %.6e %.6e jar(smooth) %.6e %.6e %.6e %.6e cross %d A %d B %d\n", lane, (double)con_D, (double)con_aref[0], (double)con_aref[2],
+                                (double)jtmp.con[0], (double)jtmp.con[1], (double)jtmp.con[2], (double)jtmp.con[3], con_cross, con_A, con_B);
+        if (lane == 0) printf("solver trace: env %d ncon %d nent %d cost_smooth %.10e cost_warm %.10e\n", env, ncon, nent, (double)cost_smooth, (double)cost);
+#endif
         if (cost > cost_smooth) {
 #pragma unroll
           for (int s = 0; s < 3; s++) { qa[s] = qs[s]; Ma[s] = qfs[s]; }
@@ -973,15 +979,15 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
                 const bool valid = e0 + lane < nent;
                 const int e = valid ? e0 + lane : nent - 1;
                 const int m0 = sm.entM[e][0], m1 = sm.entM[e][1];
-                const int ln = m0 & 63, c = (m0 >> 6) & 31;
-                const int base = m1 & 255, rank = (m1 >> 16) & 255;
+                const int ln = RPK_EM_LANE(m0), c = RPK_EM_CON(m0);
+                const int base = RPK_EM_BASE(m1), rank = RPK_EM_RANK(m1);
                 const T ja0 = sm.entJ[e][0], ja1 = sm.entJ[e][1], ja2 = sm.entJ[e][2];
                 const T* C = sm.cC[c];
                 const T C0 = C[0], C1 = C[1], C2 = C[2], C3 = C[3], C4 = C[4], C5 = C[5];
                 const T u0 = C0 * ja0 + C3 * ja1 + C4 * ja2;
                 const T u1 = C3 * ja0 + C1 * ja1 + C5 * ja2;
                 const T u2 = C4 * ja0 + C5 * ja1 + C2 * ja2;
-                const bool cross = ((m0 >> 15) & 1) != 0;
+                const bool cross = RPK_EM_CROSS(m0) != 0;
                 const bool mine = valid && (!cross || dmx != 0);
                 const int cia = cross ? cidx(ln) : 0;
                 for (int k0 = 0; k0 < maxm; k0 += 4) {
@@ -997,7 +1003,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
 #pragma unroll
                   for (int u = 0; u < 4; u++) {
                     if (mine && k0 + u <= rank) {
-                      T* dst = cross ? &sm.H[tri(cia, cidx(mb[u] & 63))] : &sm.R[ln][(mb[u] >> 11) & 15];
+                      T* dst = cross ? &sm.H[tri(cia, cidx(RPK_EM_LANE(mb[u])))] : &sm.R[ln][RPK_EM_COL(mb[u])];
                       lds_add(dst, val[u]);
                     }
                   }
@@ -1203,10 +1209,10 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
 #pragma unroll
       for (int s = 0; s < 3; s++) qw[s] = qa[s];
       // forces of the pyramidal contact rows, for the acceleration-stage sensors (MODE 2)
-      if (S.con_force && lane < RPK_NC) {
+      if (S.con_force && lane < RPK_NCOUT) {
 #pragma unroll
         for (int r = 0; r < 4; r++)
-          S.con_force[((size_t)env * RPK_NC + lane) * 4 + r] = (anyrow && lane < ncon) ? frc.con[r] : (T)0;
+          S.con_force[((size_t)env * RPK_NCOUT + lane) * 4 + r] = (anyrow && lane < ncon) ? frc.con[r] : (T)0;
       }
 
       PROF(8);
@@ -1442,6 +1448,24 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     // pending they are narrow-phased, so the list never overflows whatever the pose.
     int nwork = 0;
     ncon = 0;
+    constexpr int NCX = RpCaps<T>::NC;   // contact capacity: RPK_NCL records in LDS, the rest in the env's overflow records
+    T* const ovf = B.covf + (size_t)env * (RPK_NC - RPK_NCL) * 12;
+    int* const ovi = B.covi + (size_t)env * (RPK_NC - RPK_NCL) * 4;
+    // field f of MY contact's record (contact lanes): 0-2 position, 3-5 normal, 6 dist, 7 mu, 8 kterm, 9 B, 10 D
+    auto conf = [&](const int f) -> T {
+      T v;
+      if (NCX <= RPK_NCL || lane < RPK_NCL)
+        v = f < 3 ? sm.cpos[lane][f] : (f < 6 ? sm.cn[lane][f - 3] : (f == 6 ? sm.cdist[lane] : sm.cpar[lane][f - 7]));
+      else v = ovf[(size_t)(lane - RPK_NCL) * 12 + f];
+      return v;
+    };
+    // ... and its integer fields: 0 link A, 1 link B (or RPK_KEYBASE + key), 2 / 3 model geom ids
+    auto coni = [&](const int f) -> int {
+      int v;
+      if (NCX <= RPK_NCL || lane < RPK_NCL) v = f == 0 ? sm.cA[lane] : (f == 1 ? sm.cB[lane] : (f == 2 ? sm.cgA[lane] : sm.cgB[lane]));
+      else v = ovi[(size_t)(lane - RPK_NCL) * 4 + f];
+      return v;
+    };
     {
     const bool isg = lane < M.ngeom;
     const float fcx = isg ? (float)sm.gpos[lane][0] : 0.f, fcy = isg ? (float)sm.gpos[lane][1] : 0.f,
@@ -1767,6 +1791,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       const int base = 0;
       int w = base + lane;
       RawCon<T> rc[3];
+      RawCon<T> bbx[5];   // (box-box points four to eight: memory-resident, indexed dynamically)
       int n = 0, ga = 0, gb = 0;
       T pB[8], invw = 0;
       // MESH builds: both kinds of hull pair (key box vs hull, hand geom vs hull) collect their arguments
@@ -1859,7 +1884,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         }
         if (boxside) {
           if (M.geom_type()[ga] == GEOM_CAPSULE_) n = capsule_box(rc, posA, mA, M.geom_size() + 3 * ga, bxp, bxm, bxs);
-          else n = RPK_BOXBOX(rc, posA, mA, M.geom_size() + 3 * ga, bxp, bxm, bxs);
+          else n = RPK_BOXBOX(rc, bbx, posA, mA, M.geom_size() + 3 * ga, bxp, bxm, bxs);
         }
       }
       if constexpr (MESH != 0) {
@@ -1875,61 +1900,90 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         PROF(19);
       }
       PROF(13);
+      // One contact slot of every lane: records in lane order.  The first RPK_NCL records live in LDS; the rest (rare:
+      // hand-on-hand pile-ups) go to the env's global overflow records through `emit_ovf`, a separate cold block, so that
+      // the hot path keeps the code and the register allocation it had with one store target.
+      auto contact_params = [&](const T dist, T* par) {   // par: mu, kterm (K*imp*dist), B, D
+        const T* pA = M.geom_cparam() + 8 * ga;
+        T solref0 = (T)0.5 * (pA[0] + pB[0]), solref1 = (T)0.5 * (pA[1] + pB[1]);
+        T solimp[5];
 #pragma unroll
-      for (int slot = 0; slot < 3; slot++) {
-        bool has = n > slot;
+        for (int e = 0; e < 5; e++) solimp[e] = (T)0.5 * (pA[2 + e] + pB[2 + e]);
+        T mu = fmax(pA[7], pB[7]);
+        if (solref0 > 0) solref0 = fmax(solref0, (T)2 * h);
+        T dmax = fmin((T)0.9999, fmax((T)0.0001, solimp[1]));
+        T Kc = (T)1 / fmax(RPK_MINVAL, dmax * dmax * solref0 * solref0 * solref1 * solref1);
+        T Bc = (T)2 / fmax(RPK_MINVAL, dmax * solref0);
+        T imp = impedance(solimp, dist);
+        T Rn = fmax(RPK_MINVAL, ((T)1 - imp) * invw * ((T)1 + mu * mu) / imp);
+        T Rpy = fmax(RPK_MINVAL, (T)2 * mu * mu * Rn);
+        par[0] = mu; par[1] = Kc * imp * dist; par[2] = Bc; par[3] = (T)1 / Rpy;
+      };
+      auto emit = [&](const int idx, const RawCon<T>& r) {   // idx < RPK_NCL
+        T par[4];
+        contact_params(r.dist, par);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { sm.cpos[idx][k] = r.pos[k]; sm.cn[idx][k] = r.n[k]; }
+        sm.cdist[idx] = r.dist;
+#pragma unroll
+        for (int k = 0; k < 4; k++) sm.cpar[idx][k] = par[k];
+        sm.cA[idx] = M.geom_link()[ga];
+        sm.cB[idx] = gb >= RPK_KEYBASE ? gb : M.geom_link()[gb];
+        sm.cgA[idx] = M.geom_modelid()[ga];
+        sm.cgB[idx] = gb >= RPK_KEYBASE ? M.key_geomid()[gb - RPK_KEYBASE] : M.geom_modelid()[gb];
+      };
+      auto emit_ovf = [&](const int at, const RawCon<T>& r) {   // RPK_NCL <= at < NCX
+        T par[4];
+        contact_params(r.dist, par);
+        T* o = ovf + (size_t)(at - RPK_NCL) * 12;
+        int* oi = ovi + (size_t)(at - RPK_NCL) * 4;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { o[k] = r.pos[k]; o[3 + k] = r.n[k]; }
+        o[6] = r.dist;
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[7 + k] = par[k];
+        oi[0] = M.geom_link()[ga];
+        oi[1] = gb >= RPK_KEYBASE ? gb : M.geom_link()[gb];
+        oi[2] = M.geom_modelid()[ga];
+        oi[3] = gb >= RPK_KEYBASE ? M.key_geomid()[gb - RPK_KEYBASE] : M.geom_modelid()[gb];
+      };
+      auto emit_slot = [&](const bool has, const RawCon<T>& r) {
         unsigned long long mk = __ballot(has);
         int idx = ncon + __popcll(mk & lanemask_lt(lane));
-        // writes this lane's contact `slot` into contact record `at`
-        auto emit = [&](int at) {
-          const int idx = at;
-          const T* pA = M.geom_cparam() + 8 * ga;
-          T solref0 = (T)0.5 * (pA[0] + pB[0]), solref1 = (T)0.5 * (pA[1] + pB[1]);
-          T solimp[5];
-#pragma unroll
-          for (int e = 0; e < 5; e++) solimp[e] = (T)0.5 * (pA[2 + e] + pB[2 + e]);
-          T mu = fmax(pA[7], pB[7]);
-          if (solref0 > 0) solref0 = fmax(solref0, (T)2 * h);
-          T dmax = fmin((T)0.9999, fmax((T)0.0001, solimp[1]));
-          T Kc = (T)1 / fmax(RPK_MINVAL, dmax * dmax * solref0 * solref0 * solref1 * solref1);
-          T Bc = (T)2 / fmax(RPK_MINVAL, dmax * solref0);
-          T dist = rc[slot].dist;
-          T imp = impedance(solimp, dist);
-          T Rn = fmax(RPK_MINVAL, ((T)1 - imp) * invw * ((T)1 + mu * mu) / imp);
-          T Rpy = fmax(RPK_MINVAL, (T)2 * mu * mu * Rn);
-#pragma unroll
-          for (int k = 0; k < 3; k++) { sm.cpos[idx][k] = rc[slot].pos[k]; sm.cn[idx][k] = rc[slot].n[k]; }
-          sm.cdist[idx] = dist;
-          sm.cpar[idx][0] = mu; sm.cpar[idx][1] = Kc * imp * dist; sm.cpar[idx][2] = Bc;
-          sm.cpar[idx][3] = (T)1 / Rpy;
-          int la = M.geom_link()[ga];
-          sm.cA[idx] = la;
-          sm.cB[idx] = gb >= RPK_KEYBASE ? gb : M.geom_link()[gb];
-          sm.cgA[idx] = M.geom_modelid()[ga];
-          sm.cgB[idx] = gb >= RPK_KEYBASE ? M.key_geomid()[gb - RPK_KEYBASE] : M.geom_modelid()[gb];
-        };
-        if (has && idx < RPK_NC) emit(idx);
-        if (ncon + __popcll(mk) > RPK_NC) {
-          // capacity overflow (rare; RP_WARN_CONTACT_FULL is raised below): keep the deepest
-          // contacts -- one that does not fit replaces the shallowest stored contact if it
-          // penetrates more.  Uniform loop, one overflowing lane at a time.
-          WSYNC();
-          unsigned long long ovm = __ballot(has && idx >= RPK_NC);
-          while (ovm) {
-            const int L = __ffsll((long long)ovm) - 1;
-            ovm &= ovm - 1;
-            const T dL = bcast(rc[slot].dist, L);
-            T worst = sm.cdist[0];
-            int wi = 0;
-            for (int c = 1; c < RPK_NC; c++) {
-              const T d = sm.cdist[c];
-              if (d > worst) { worst = d; wi = c; }
+        if (has && idx < RPK_NCL) emit(idx, r);
+        if (ncon + __popcll(mk) > RPK_NCL) {   // (uniform, rare)
+          if (NCX > RPK_NCL && has && idx >= RPK_NCL && idx < NCX) emit_ovf(idx, r);
+          if (ncon + __popcll(mk) > NCX) {
+            // capacity overflow (RP_WARN_CONTACT_FULL is raised below): keep the deepest
+            // contacts -- one that does not fit replaces the shallowest stored contact if it
+            // penetrates more.  Uniform loop, one overflowing lane at a time.
+            RPK_STAGE_FENCE();
+            unsigned long long ovm = __ballot(has && idx >= NCX);
+            while (ovm) {
+              const int L = __ffsll((long long)ovm) - 1;
+              ovm &= ovm - 1;
+              const T dL = bcast(r.dist, L);
+              T worst = sm.cdist[0];
+              int wi = 0;
+              for (int c = 1; c < NCX; c++) {
+                const T d = (NCX <= RPK_NCL || c < RPK_NCL) ? sm.cdist[c < RPK_NCL ? c : 0] : ovf[(size_t)(c - RPK_NCL) * 12 + 6];
+                if (d > worst) { worst = d; wi = c; }
+              }
+              if (dL < worst && lane == L) { if (NCX <= RPK_NCL || wi < RPK_NCL) emit(wi < RPK_NCL ? wi : 0, r); else emit_ovf(wi, r); }
+              RPK_STAGE_FENCE();
             }
-            if (dL < worst && lane == L) emit(wi);
-            WSYNC();
           }
         }
         ncon += __popcll(mk);
+      };
+#pragma unroll
+      for (int slot = 0; slot < 3; slot++) emit_slot(n > slot, rc[slot]);
+      // box-box pairs resting face to face: points four to eight, from the routine's result array
+      if (RPK_BOXBOX_MAX > 3 && __ballot(n > 3) != 0ull) {
+        for (int slot = 3; slot < 8; slot++) {
+          RawCon<T> r = bbx[n > slot ? slot - 3 : 0];
+          emit_slot(n > slot, r);
+        }
       }
       }
       PROF(24);
@@ -1944,8 +1998,9 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       WSYNC();
     }
     }
-    if (ncon > RPK_NC) { warn |= 2; ncon = RPK_NC; }
+    if (ncon > NCX) { warn |= 2; ncon = NCX; }
     WSYNC();
+    if (NCX > RPK_NCL && ncon > RPK_NCL) RPK_STAGE_FENCE();   // (the overflow records: written by the emitting lanes, read below by the contact lanes)
 
     // The position / velocity stages are register-bound around the narrow phase: the state is re-read here
     // (L2 hits) instead of being carried -- that is: spilled to scratch and reloaded -- across the collision.
@@ -1975,8 +2030,9 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     {
       int kb = -1;
       if (lane < ncon) {
-        if (sm.cB[lane] >= RPK_KEYBASE) kb = sm.cB[lane] - RPK_KEYBASE;
-        else if (sm.cA[lane] >= RPK_KEYBASE) kb = sm.cA[lane] - RPK_KEYBASE;
+        const int a_ = coni(0), b_ = coni(1);
+        if (b_ >= RPK_KEYBASE) kb = b_ - RPK_KEYBASE;
+        else if (a_ >= RPK_KEYBASE) kb = a_ - RPK_KEYBASE;
       }
       bool first = kb >= 0;
       for (int c2 = 0; c2 < ncon; c2++) {
@@ -1994,13 +2050,13 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       // per-contact registers
       con_A = -1; con_B = -1; con_D = 0; con_mu = 0; con_maskA = 0; con_maskB = 0;
       if (lane < ncon) {
-        con_A = sm.cA[lane]; con_B = sm.cB[lane];
-        con_mu = sm.cpar[lane][0];
-        con_D = sm.cpar[lane][3];
-        con_dist = sm.cdist[lane];  // (the LDS copy is recycled by the velocity stage)
+        con_A = coni(0); con_B = coni(1);
+        con_mu = conf(7);
+        con_D = conf(10);
+        con_dist = conf(6);  // (the LDS copy is recycled by the velocity stage)
         if (kb >= 0 && con_slot < 0) con_D = 0;  // dropped (slot overflow)
 #pragma unroll
-        for (int k = 0; k < 3; k++) con_n[k] = sm.cn[lane][k];
+        for (int k = 0; k < 3; k++) con_n[k] = conf(3 + k);
         make_frame(con_n, con_t1, con_t2);
         if (con_A >= 0 && con_A < RPK_KEYBASE)
           con_maskA = ((unsigned long long)M.link_ancmask_u()[2 * con_A + 1] << 32) | M.link_ancmask_u()[2 * con_A];
@@ -2017,7 +2073,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     const int bodyA = con_A, bodyB = con_B;   // (the nested-contact collapse below edits con_A / con_B)
     T con_pos[3] = {0, 0, 0};
     if constexpr (MODE == 2) {
-      if (lane < ncon) { con_pos[0] = sm.cpos[lane][0]; con_pos[1] = sm.cpos[lane][1]; con_pos[2] = sm.cpos[lane][2]; }
+      if (lane < ncon) { con_pos[0] = conf(0); con_pos[1] = conf(1); con_pos[2] = conf(2); }
     }
     {
       int cross = 0;
@@ -2030,8 +2086,8 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
           if (deep < 0) cross = 1;
           else {  // the support of the contact is the deeper chain
             const int sh = 1 - deep;
-            if (sh == 0) { con_A = -1; con_maskA = 0; sm.cA[lane] = -1; }
-            else { con_B = -1; con_maskB = 0; sm.cB[lane] = -1; }
+            if (sh == 0) { con_A = -1; con_maskA = 0; }
+            else { con_B = -1; con_maskB = 0; }
           }
         }
       }
@@ -2118,7 +2174,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       }
       const int nent = wave_max(lane < ncon ? base + cnt : 0), maxm = wave_max(cnt);
       if constexpr (MODE == 0) {
-        LI(10) = base | (cnt << 8);
+        LI(10) = base | (cnt << 12);
         if (lane == 0) {
           B.hdr[env * 8 + 4] = nent; B.hdr[env * 8 + 5] = maxm;
           // capacity class of this env's solve (rp_solver2.hpp): light = fits the lean solver stage
@@ -2147,7 +2203,9 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         const unsigned long long mB = ((unsigned long long)(unsigned)bcast((int)(omB >> 32), c) << 32) |
                                       (unsigned)bcast((int)(omB & 0xffffffffu), c);
         const int cA = bcast(con_A, c), cb = bcast(base, c), cc = bcast(cnt, c), cx = bcast(con_cross, c);
-        const T px = sm.cpos[c][0], py = sm.cpos[c][1], pz = sm.cpos[c][2];
+        T px, py, pz;
+        if (NCX <= RPK_NCL || c < RPK_NCL) { px = sm.cpos[c][0]; py = sm.cpos[c][1]; pz = sm.cpos[c][2]; }
+        else { const T* o_ = ovf + (size_t)(c - RPK_NCL) * 12; px = o_[0]; py = o_[1]; pz = o_[2]; }
         T jv3[3] = {0, 0, 0};   // my column times my velocity
         if ((sc >> lane) & 1) {
           T j3[3];
@@ -2170,8 +2228,8 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
           if constexpr (MODE == 0) {
             const size_t e = (size_t)env * RpCaps<T>::NE + cb + rank;
             B.entJ[e * 3] = j3[0]; B.entJ[e * 3 + 1] = j3[1]; B.entJ[e * 3 + 2] = j3[2];
-            B.entM[e * 2] = lane | (c << 6) | (mycol << 11) | (cx << 15);
-            B.entM[e * 2 + 1] = cb | (cc << 8) | (rank << 16);
+            B.entM[e * 2] = RPK_EM0(lane, c, mycol, cx);
+            B.entM[e * 2 + 1] = RPK_EM1(cb, cc, rank);
           }
         }
         // J qvel of contact c: a wave sum (DPP) of the ~10 member lanes' products, kept by the contact's lane.
@@ -2184,7 +2242,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       if (lane < ncon) {
         const T vc[3] = {cvr[0], cvr[1], cvr[2]};
         const T vn = dot3(con_n, vc), v1 = con_mu * dot3(con_t1, vc), v2 = con_mu * dot3(con_t2, vc);
-        const T Bc = sm.cpar[lane][2], kt = sm.cpar[lane][1];
+        const T Bc = conf(9), kt = conf(8);
         con_aref[0] = -Bc * (vn + v1) - kt; con_aref[1] = -Bc * (vn - v1) - kt;
         con_aref[2] = -Bc * (vn + v2) - kt; con_aref[3] = -Bc * (vn - v2) - kt;
       } else {
@@ -2370,7 +2428,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       if (lane < ncon) {
         T f[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) f[r] = S.con_force[((size_t)env * RPK_NC + lane) * 4 + r];
+        for (int r = 0; r < 4; r++) f[r] = S.con_force[((size_t)env * RPK_NCOUT + lane) * 4 + r];
         // [MJ: mju_decodePyramid] normal force and the two friction components
         const T fn = f[0] + f[1] + f[2] + f[3];
         const T f1 = con_mu * (f[0] - f[1]), f2 = con_mu * (f[2] - f[3]);
@@ -2483,8 +2541,16 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
   if (isa) S.act_vel[(size_t)env * nu + lane] = avel;
   if (lane < RPK_NCOUT) {
     bool v = lane < ncon;
-    S.contact_geoms[((size_t)env * RPK_NCOUT + lane) * 2] = v ? sm.cgA[lane] : -1;
-    S.contact_geoms[((size_t)env * RPK_NCOUT + lane) * 2 + 1] = v ? sm.cgB[lane] : -1;
+    int ga_ = -1, gb_ = -1;
+    if (v) {
+      if (RpCaps<T>::NC <= RPK_NCL || lane < RPK_NCL) { ga_ = sm.cgA[lane]; gb_ = sm.cgB[lane]; }
+      else {
+        const int* oi_ = B.covi + ((size_t)env * (RPK_NC - RPK_NCL) + (lane - RPK_NCL)) * 4;
+        ga_ = oi_[2]; gb_ = oi_[3];
+      }
+    }
+    S.contact_geoms[((size_t)env * RPK_NCOUT + lane) * 2] = ga_;
+    S.contact_geoms[((size_t)env * RPK_NCOUT + lane) * 2 + 1] = gb_;
     S.contact_dist[(size_t)env * RPK_NCOUT + lane] = v ? con_dist : (T)0;
   }
   }
@@ -2528,7 +2594,10 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
   if constexpr (MODE == 1) {
     if (listed && threadIdx.x == 0) {
       __threadfence();
-      if (atomicAdd(S.heavy_done, 1) == (int)gridDim.x - 1) { *S.heavy_cnt = 0; *S.heavy_done = 0; __threadfence(); }
+      if (atomicAdd(S.heavy_done, 1) == (int)gridDim.x - 1) {
+        if (S.heavy_peak && n > *S.heavy_peak) *S.heavy_peak = n;
+        *S.heavy_cnt = 0; *S.heavy_done = 0; __threadfence();
+      }
     }
   }
 }
@@ -2556,11 +2625,6 @@ __device__ __forceinline__ void rp_save_prev_state(const RpModel<T>& M, const Rp
 // (workgroup scope: writer and reader are the same wave, behind the same vector L1, which a CU's own stores keep
 // coherent; an agent-scope fence writes the L2 back and invalidates it -- 20 times per wave and step it cost
 // more than the launch tails the fusion removes)
-#define RPK_STAGE_FENCE()                                     \
-  do {                                                        \
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");    \
-    __builtin_amdgcn_wave_barrier();                          \
-  } while (0)
 
 template <typename T, int MESH>
 __global__ __launch_bounds__(64, 2) void rp_fused_steps_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int nsub) {
@@ -2589,10 +2653,11 @@ __global__ __launch_bounds__(64, 2) void rp_fused_steps_kernel(RpModel<T> M, RpS
   }
 }
 
-template <typename T, int MESH>
+template <typename T, int MESH, int FIXED_TL>
 __global__ __launch_bounds__(64, 1) void rp_cleanup_steps_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int nsub) {
   using namespace rpk;
-  constexpr size_t NB = sizeof(Smem<T, 1, RPK_MAXD>) > sizeof(Smem<T, 0, RPK_MAXD>) ? sizeof(Smem<T, 1, RPK_MAXD>) : sizeof(Smem<T, 0, RPK_MAXD>);
+  constexpr size_t NA = sizeof(Smem<T, 1, RPK_MAXD>) > sizeof(Smem<T, 0, RPK_MAXD>) ? sizeof(Smem<T, 1, RPK_MAXD>) : sizeof(Smem<T, 0, RPK_MAXD>);
+  constexpr size_t NB = NA > sizeof(SmemLean<T>) ? NA : sizeof(SmemLean<T>);
   __shared__ __attribute__((aligned(16))) unsigned char smem[NB];
   const int n = *(volatile const int*)S.heavy_cnt;
   RpState<T> Sh = S;   // the full-capacity solver stage takes the env whatever its class
@@ -2603,7 +2668,10 @@ __global__ __launch_bounds__(64, 1) void rp_cleanup_steps_kernel(RpModel<T> M, R
       int lane = (int)threadIdx.x;
       asm volatile("" : "+v"(lane));
       if (S.qpos_prev && k == nsub - 1) rp_save_prev_state(M, S, env);
-      rp_stage_body<T, 1, 0, RPK_MAXD, 0, true>(M, Sh, B, k, nsub, env, smem, lane);
+      // the same solver build per substep as the per-stage schedule picks (light again: the lean stage; FIXED_TL as
+      // the host picks it there), so that both schedules produce the same bits
+      if (*(volatile const int*)&B.hdr[env * 8 + 6] == 1) rp_lean_solver_body<T, true>(M, S, B, env, smem, lane);
+      else rp_stage_body<T, 1, FIXED_TL, RPK_MAXD, 0, true>(M, Sh, B, k, nsub, env, smem, lane);
       RPK_STAGE_FENCE();
       asm volatile("" : "+v"(lane));
       rp_stage_body<T, 0, 0, RPK_MAXD, MESH, true>(M, S, B, k, nsub, env, smem, lane);
@@ -2612,6 +2680,9 @@ __global__ __launch_bounds__(64, 1) void rp_cleanup_steps_kernel(RpModel<T> M, R
   }
   if (threadIdx.x == 0) {
     __threadfence();
-    if (atomicAdd(S.heavy_done, 1) == (int)gridDim.x - 1) { *S.heavy_cnt = 0; *S.heavy_done = 0; __threadfence(); }
+    if (atomicAdd(S.heavy_done, 1) == (int)gridDim.x - 1) {
+      if (S.heavy_peak && n > *S.heavy_peak) *S.heavy_peak = n;
+      *S.heavy_cnt = 0; *S.heavy_done = 0; __threadfence();
+    }
   }
 }

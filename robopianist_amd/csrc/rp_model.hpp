@@ -20,11 +20,27 @@
 #include <stdint.h>
 
 #define RPK_WAVE 64
-#define RPK_NC 32        // max contacts kept per env (= RP_MAX_CONTACTS; contact c lives in lane c)
-#define RPK_NCOUT 32     // == RP_MAX_CONTACTS
-#ifndef RPK_NE
-#define RPK_NE 256      // max contact Jacobian entries (contact, dof) handed to the solver (fp64; see RpCaps)
+#define RPK_NC 64        // max contacts kept per env (= RP_MAX_CONTACTS; contact c lives in lane c; fp64 -- see RpCaps)
+#define RPK_NCOUT 64     // == RP_MAX_CONTACTS
+#ifndef RPK_NCL          // (tests shrink it to exercise the overflow records with small scenes)
+#define RPK_NCL 32       // contacts staged in the position stage's LDS; contacts RPK_NCL.. go through RpStage::covf / covi
 #endif
+#ifndef RPK_NE
+#define RPK_NE 640      // max contact Jacobian entries (contact, dof) handed to the solver (fp64; see RpCaps)
+#endif
+// Contact Jacobian entry records (RpStage::entM) and the per-contact entry range (lane field LI(10)):
+//   entM[.][0] = dof lane | contact << 6 | column of the dof in its row layout << 12 | cross-chain << 16
+//   entM[.][1] = first entry of the contact | entries of the contact << 12 | rank of this entry << 18
+//   LI(10)     = first entry | entries << 12
+#define RPK_EM0(lane_, con_, col_, cross_) ((lane_) | ((con_) << 6) | ((col_) << 12) | ((cross_) << 16))
+#define RPK_EM1(base_, cnt_, rank_) ((base_) | ((cnt_) << 12) | ((rank_) << 18))
+#define RPK_EM_LANE(m0_) ((m0_) & 63)
+#define RPK_EM_CON(m0_) (((m0_) >> 6) & 63)
+#define RPK_EM_COL(m0_) (((m0_) >> 12) & 15)
+#define RPK_EM_CROSS(m0_) (((m0_) >> 16) & 1)
+#define RPK_EM_BASE(m1_) ((m1_) & 4095)
+#define RPK_EM_CNT(m1_) (((m1_) >> 12) & 63)
+#define RPK_EM_RANK(m1_) (((m1_) >> 18) & 63)
 #define RPK_NBOXF 32     // boxes / hull boxes covered by the oriented-box prefilter
 #ifndef RPK_HMAX
 #define RPK_HMAX 60      // max rows of the dense cross-coupling block (+1 row for its rhs = one lane each; fp64)
@@ -112,6 +128,10 @@ template <typename T>
 struct RpCaps {
   static constexpr int NE = sizeof(T) == 4 ? 240 : RPK_NE;
   static constexpr int HMAX = sizeof(T) == 4 ? 56 : RPK_HMAX;
+  // contacts per env.  fp64: one per lane -- the envs beyond the light class run the full-capacity solver stage on a
+  // small grid (rp_order_kernel's compacted list), so its LDS (57 KB) costs no occupancy that matters; the position
+  // stage stages the first RPK_NCL contacts in LDS and the rest in global overflow records.
+  static constexpr int NC = sizeof(T) == 4 ? 32 : RPK_NC;
 };
 
 template <typename T>
@@ -165,6 +185,7 @@ struct RpState {
   // once, waited for the lean launch next to it to drain (measured: the join cost up to 200 us per substep)
   int* heavy_list;
   int *heavy_cnt, *heavy_done;   // entries in the list; finished workgroups (the last one clears both)
+  int* heavy_peak;               // may be null: the longest list seen (the host sizes that stage's grid from it, one step late)
   // fused substeps (rp_fused_steps_kernel): may be null -- where the state before the last substep's solver
   // stage goes (the acceleration-stage sensors belong to that state)
   T *qpos_prev, *qvel_prev;
@@ -177,6 +198,14 @@ struct RpState {
   do {                                                       \
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
     __builtin_amdgcn_wave_barrier();                         \
+  } while (0)
+// ... and a hand-off through GLOBAL memory between lanes of one wave (the stages of the fused-substeps kernels; the
+// position stage's contact overflow records).  Workgroup scope: writer and reader sit behind the same vector L1,
+// which a CU's own stores keep coherent; an agent-scope fence writes the L2 back and invalidates it.
+#define RPK_STAGE_FENCE()                                     \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");    \
+    __builtin_amdgcn_wave_barrier();                          \
   } while (0)
 // The LDS block of a stage: its own static allocation, or (EXT) a buffer the calling kernel owns -- the
 // fused-substeps kernels run two stages in turn over one allocation.
@@ -216,4 +245,8 @@ struct RpStage {
   int* entM;  // [E][RpCaps<T>::NE][2]  lane | contact<<6 | column<<11 | cross<<15 ; base | count<<8 | rank<<16
   int* slots; // [E][64]: slotkey[16], slotlink[16], slotmask lo[16], hi[16]
   int* keyslot; // [E][RPK_NKEYS/4] (packed signed char)
+  // contacts RPK_NCL.. of the position stage (rare: hand-on-hand pile-ups), staged here instead of in LDS between the
+  // narrow phase that emits them and the contact lanes that take them into registers
+  T* covf;      // [E][RPK_NC - RPK_NCL][12]: pos[3], normal[3], dist, mu, kterm, B, D
+  int* covi;    // [E][RPK_NC - RPK_NCL][4]: link A, link B (or RPK_KEYBASE + key), model geom ids
 };

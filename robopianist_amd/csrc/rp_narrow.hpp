@@ -200,30 +200,22 @@ __device__ int capsule_box(RawCon<T>* out, const T* cp, const T* cm, const T* cs
 // face axis of least penetration -> the part of the other box's facing face inside the reference
 // face's prism (its vertices, the reference corners under it, the edge crossings), all with the face
 // normal; an edge-edge axis -> one contact at the closest points of the two edges.  Position midway
-// between the surfaces, dist = -penetration, normal from geom1 to geom2.  The three deepest points
-// are kept (contact slots per geom pair).  Not inlined: the position kernel is register-bound and
-// box-box pairs are rare; nothing here indexes a register array dynamically.
+// between the surfaces, dist = -penetration, normal from geom1 to geom2.  A quadrilateral clipped by a
+// rectangle has at most eight corners: all of them are kept, in emission order (up to RPK_BOXBOX_MAX = 8,
+// [MJ: mjc_BoxBox's maximum]).  The first three go to out[0..2] through registers (static indices: selects), points
+// four to eight -- two faces resting on each other -- to `extra[0..4]`, memory-resident and indexed dynamically
+// (measured: all eight through memory cost the hull position stage 10 %: 16 candidate sites x 7 scratch stores on
+// every mj_step of the stand-in hand, whose forearm box always touches its palm boxes).
+#ifndef RPK_BOXBOX_MAX   // (experiments: 3 = the contract of rounds 1-3 without the depth ordering)
+#define RPK_BOXBOX_MAX 8
+#endif
 template <typename T> __device__ __forceinline__ T pick3(T a0, T a1, T a2, int i) { return i == 0 ? a0 : (i == 1 ? a1 : a2); }
-
-template <typename T>
-__device__ __forceinline__ void bb_keep(RawCon<T>* out, int& n, const T* pos, const T* nrm, T dist) {
-  RawCon<T> c;
-  c.dist = dist;
-#pragma unroll
-  for (int k = 0; k < 3; k++) { c.pos[k] = pos[k]; c.n[k] = nrm[k]; }
-  // sorted insertion into (out[0] <= out[1] <= out[2]) by dist, first come first on ties
-  const bool v0 = n > 0, v1 = n > 1, v2 = n > 2;
-  if (!v0 || c.dist < out[0].dist) { out[2] = out[1]; out[1] = out[0]; out[0] = c; }
-  else if (!v1 || c.dist < out[1].dist) { out[2] = out[1]; out[1] = c; }
-  else if (!v2 || c.dist < out[2].dist) { out[2] = c; }
-  if (n < 3) n++;
-}
 
 #ifndef RPK_BOXBOX_INLINE
 #define RPK_BOXBOX_INLINE __forceinline__   // (measured: +1.6 % hull mode, +0.5 % capsule mode over a real call)
 #endif
 template <typename T>
-__device__ RPK_BOXBOX_INLINE int box_box(RawCon<T>* out, const T* p1, const T* m1, const T* s1, const T* p2,
+__device__ RPK_BOXBOX_INLINE int box_box(RawCon<T>* out, RawCon<T>* extra, const T* p1, const T* m1, const T* s1, const T* p2,
                                     const T* m2, const T* s2) {
   using N = Num<T>;
   T R[3][3], Q[3][3], t[3], tb[3];
@@ -303,8 +295,10 @@ __device__ RPK_BOXBOX_INLINE int box_box(RawCon<T>* out, const T* p1, const T* m
     T pos[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) pos[c] = (T)0.5 * ((pa[c] + alpha * ua[c]) + (pb[c] + beta * ub[c]));
-    bb_keep(out, n, pos, nrm, ebest);
-    return n;
+    out[0].dist = ebest;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { out[0].pos[c] = pos[c]; out[0].n[c] = nrm[c]; }
+    return 1;
   }
   // ---- face contact.  Reference frame (zr = fs * face axis towards the other box, ur, vr) and the
   // incident box (centre ci, scaled axes) are built with selects, never with dynamic indices.
@@ -348,16 +342,22 @@ __device__ RPK_BOXBOX_INLINE int box_box(RawCon<T>* out, const T* p1, const T* m
   T nrm[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) nrm[k] = refA ? zr[k] : -zr[k];
-  // candidates are reduced on the fly to the three deepest (depth, u, v); ties: first come
-  T bd[3] = {(T)-1, (T)-1, (T)-1}, bu[3] = {0, 0, 0}, bv[3] = {0, 0, 0};
+  // every candidate that penetrates is a contact: position midway between the surfaces
   auto emit = [&](T cu, T cv, T zz) {
     const T depth = h - zz;
-    if (depth >= (T)0) {
-      // (the corners of a face resting flat tie exactly: depths within 1e-10 count as equal)
-      const bool g0 = depth > bd[0] + (T)1e-10, g1 = depth > bd[1] + (T)1e-10, g2 = depth > bd[2] + (T)1e-10;
-      bd[2] = g1 ? bd[1] : (g2 ? depth : bd[2]); bu[2] = g1 ? bu[1] : (g2 ? cu : bu[2]); bv[2] = g1 ? bv[1] : (g2 ? cv : bv[2]);
-      bd[1] = g0 ? bd[0] : (g1 ? depth : bd[1]); bu[1] = g0 ? bu[0] : (g1 ? cu : bu[1]); bv[1] = g0 ? bv[0] : (g1 ? cv : bv[1]);
-      bd[0] = g0 ? depth : bd[0]; bu[0] = g0 ? cu : bu[0]; bv[0] = g0 ? cv : bv[0];
+    if (depth >= (T)0 && n < RPK_BOXBOX_MAX) {
+      const T zc = h - (T)0.5 * depth;
+      RawCon<T> c;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { c.pos[k] = pr[k] + ur[k] * cu + vr[k] * cv + zr[k] * zc; c.n[k] = nrm[k]; }
+      c.dist = -depth;
+      if (n < 3) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) if (n == i) out[i] = c;
+      } else if (RPK_BOXBOX_MAX > 3) {
+        extra[n - 3] = c;
+      }
+      n++;
     }
   };
   T q[4][3];
@@ -408,16 +408,6 @@ __device__ RPK_BOXBOX_INLINE int box_box(RawCon<T>* out, const T* p1, const T* m
           }
         }
       }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    if (bd[i] >= (T)0) {
-      const T zc = h - (T)0.5 * bd[i];     // midway between the surfaces
-#pragma unroll
-      for (int k = 0; k < 3; k++) { out[i].pos[k] = pr[k] + ur[k] * bu[i] + vr[k] * bv[i] + zr[k] * zc; out[i].n[k] = nrm[k]; }
-      out[i].dist = -bd[i];
-      n = i + 1;
     }
   }
   return n;

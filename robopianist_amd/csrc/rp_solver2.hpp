@@ -175,10 +175,10 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
   if (lane < ncon) {
     con_D = LF(14); con_mu = LF(15);
     {
-      const int bc = LI(10);
-      cinfo = (bc & 0xffff) | ((LI(4) & 1) << 16);
+      const int bc = LI(10);   // (hand-over layout: first entry | entries << 12; a light env's fit in 8 bits each)
+      cinfo = (bc & 255) | (((bc >> 12) & 63) << 8) | ((LI(4) & 1) << 16);
       unsigned long long sup = 0;
-      if ((bc >> 8) & 255) {   // (a contact dropped for capacity keeps no entries)
+      if ((bc >> 12) & 63) {   // (a contact dropped for capacity keeps no entries)
         sup = (((unsigned long long)(unsigned)LI(6) << 32) | (unsigned)LI(5)) | (((unsigned long long)(unsigned)LI(8) << 32) | (unsigned)LI(7));
         const int slot = LI(3);
         if (slot >= 0) sup |= 1ull << (nl + slot);
@@ -229,7 +229,12 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
   for (int i = lane; i < nent; i += 64) {
     const size_t e = (size_t)env * RpCaps<T>::NE + i;
     const T j0 = B.entJ[e * 3], j1 = B.entJ[e * 3 + 1], j2 = B.entJ[e * 3 + 2];
-    const int m0 = B.entM[e * 2], m1 = B.entM[e * 2 + 1];
+    // (the hand-over's records, rp_model.hpp, repacked into this stage's narrower fields: lane | contact << 6 |
+    // column << 11 | cross << 15 and first entry | entries << 8 | rank << 16 -- a light env has < 32 contacts and
+    // < 256 entries)
+    const int h0 = B.entM[e * 2], h1 = B.entM[e * 2 + 1];
+    const int m0 = RPK_EM_LANE(h0) | (RPK_EM_CON(h0) << 6) | (RPK_EM_COL(h0) << 11) | (RPK_EM_CROSS(h0) << 15);
+    const int m1 = RPK_EM_BASE(h1) | (RPK_EM_CNT(h1) << 8) | (RPK_EM_RANK(h1) << 16);
     const T* fr = sm.R[(m0 >> 6) & 31];
     sm.entJ[i][0] = fr[0] * j0 + fr[1] * j1 + fr[2] * j2;
     sm.entJ[i][1] = fr[3] * j0 + fr[4] * j1 + fr[5] * j2;

@@ -353,6 +353,7 @@ __global__ __launch_bounds__(64) void rp_task_advance_kernel(rp_task_advance_arg
     const bool bad = (p.warn[env] & fatal) != 0 && active;
     if (bad && p.fatal_count) p.fatal_count[env] += 1;
     terminate = terminate || bad;
+    if (terminate && p.warn_count && (p.warn[env] & p.warn_count_mask) != 0) p.warn_count[env] += 1;
     if (bad) { reward = (T)0; disc = (T)0; }
     int st = terminate ? 2 : 1;
     if (resetting) { st = 0; reward = (T)0; disc = (T)1; }

@@ -26,7 +26,7 @@ LIB_PATH = os.environ.get("RP_ENGINE_LIB") or os.path.join(_HERE, "csrc", "librp
 QPOS, QVEL, QACC_WARMSTART, CTRL, QFRC_APPLIED, ACT_FORCE, ACT_VELOCITY, SITE_XPOS, \
     TIME, NCON, CONTACT_GEOMS, WARN_FLAGS, SOLVER_ITER, CONTACT_DIST, TREE_OFFSET, ACTIVE, \
     SENSOR_TORQUE, SENSOR_TOUCH, ENV_COST, DEBUG_MASS_ROWS, DEBUG_HANDOVER_HDR = range(21)
-MAX_CONTACTS = 32
+MAX_CONTACTS = 64
 
 WARN_BADSTATE = 1
 WARN_CONTACT_FULL = 2

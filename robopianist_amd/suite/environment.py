@@ -150,6 +150,8 @@ class Environment:
         if hasattr(task, "count_fatal"):
             task.count_fatal(phys.warn, active)
         terminate = terminate | bad
+        if hasattr(task, "count_overflow"):
+            task.count_overflow(phys.warn, terminate)
         reward = torch.where(bad, torch.zeros_like(reward), reward)
         discount = torch.where(bad, torch.zeros_like(discount), discount)
         st = torch.where(terminate, int(StepType.LAST), int(StepType.MID)).to(torch.int32)

@@ -52,7 +52,7 @@ class PianoWithShadowHands(base.PianoTask):
         energy_penalty_coef: float = _ENERGY_PENALTY_COEF,
         randomize_hand_positions: bool = False,
         augmentation_prefetch: bool = False,
-        overflow_termination: bool = True,
+        overflow_termination: bool = False,
         **kwargs,
     ) -> None:
         super().__init__(disable_hand_collisions=disable_hand_collisions, **kwargs)
@@ -78,13 +78,18 @@ class PianoWithShadowHands(base.PianoTask):
         self._disable_hand_collisions = disable_hand_collisions
         self._energy_penalty_coef = energy_penalty_coef
         self._randomize_hand_positions = randomize_hand_positions
-        # extension: an engine capacity overflow (contacts / Jacobian entries / key slots / dense rows
-        # dropped: the physics of that env is wrong from there on) ends the episode like a diverged
-        # state does -- reward 0, discount 0 -- instead of stepping on with silently altered dynamics
+        # The reference ends an episode only at the end of the MIDI or on a wrong press (:212-220), and so does this
+        # task by default: an engine capacity overflow (more than 64 contacts / 640 contact Jacobian entries / 12
+        # touched keys / 57 cross-coupled rows in one env: the shallowest contacts / the excess are dropped) raises
+        # the env's warn flag and is COUNTED (`overflow_episodes`; < 1e-5 of the env-steps of a uniformly random
+        # policy since round 4), the episode goes on.  Extension, `overflow_termination=True` (the default of rounds
+        # 2-3, when a third of a percent of such env-steps overflowed): the overflow ends the episode like a diverged
+        # state does -- reward 0, discount 0.
         from robopianist_amd import engine as _eng
-        self.fatal_warn_mask = _eng.WARN_BADSTATE | (
-            (_eng.WARN_CONTACT_FULL | _eng.WARN_KEYSLOT_FULL | _eng.WARN_DENSE_FULL | _eng.WARN_WORK_FULL) if overflow_termination else 0)
+        self.overflow_warn_mask = _eng.WARN_CONTACT_FULL | _eng.WARN_KEYSLOT_FULL | _eng.WARN_DENSE_FULL | _eng.WARN_WORK_FULL
+        self.fatal_warn_mask = _eng.WARN_BADSTATE | (self.overflow_warn_mask if overflow_termination else 0)
         self._fatal_count = None
+        self._overflow_count = None
         self._use_fused_rewards = True   # set False to force the torch reward functions
         self._fused_rewards = None
         self._use_fused_advance = True   # set False to force the torch task hooks
@@ -307,6 +312,7 @@ class PianoWithShadowHands(base.PianoTask):
         self._bind_hands()
         self._bind_task_state()
         self._fatal_count = torch.zeros(n_envs, device=physics.device, dtype=torch.long)
+        self._overflow_count = torch.zeros(n_envs, device=physics.device, dtype=torch.long)
         self._physics = physics
         if any(n.split("/")[1] in ("joints_torque", "fingertip_force") for n in getattr(self, "_extra_observables", ())):
             physics.enable_acc_sensors()
@@ -318,6 +324,17 @@ class PianoWithShadowHands(base.PianoTask):
     def count_fatal(self, warn, active) -> None:
         """Torch path: counts the episodes ended by an engine warn flag (see fatal_warn_mask)."""
         self._fatal_count.add_(((warn & self.fatal_warn_mask) != 0) & active)
+
+    def count_overflow(self, warn, terminate) -> None:
+        """Torch path: counts the episodes that end with a capacity-overflow flag raised."""
+        self._overflow_count.add_(((warn & self.overflow_warn_mask) != 0) & terminate)
+
+    def overflow_episodes(self) -> int:
+        """Episodes that ended (for any reason) after an engine capacity overflow, all envs."""
+        n = int(self._overflow_count.sum().item()) if self._overflow_count is not None else 0
+        if self._fused_advance is not None:
+            n += int(self._fused_advance.warn_count.sum().item())
+        return n
 
     def overflow_terminations(self) -> int:
         """Episodes ended by a warn flag so far (bad state or capacity overflow), all envs."""
@@ -551,7 +568,8 @@ class PianoWithShadowHands(base.PianoTask):
                 finger_bank=self._finger_bank, song_len=self._song_len, song_id=self._song_id,
                 wrong_press_termination=self._wrong_press_termination,
                 key_threshold=_base._KEY_THRESHOLD, sustain_threshold=_base._SUSTAIN_THRESHOLD,
-                key_qrange=self.piano._qpos_range, warn_fatal_mask=self.fatal_warn_mask)
+                key_qrange=self.piano._qpos_range, warn_fatal_mask=self.fatal_warn_mask,
+                warn_count_mask=self.overflow_warn_mask)
             if getattr(self, "_eval_buffers", None) is not None:
                 self._fused_advance.set_evaluation_buffers(*self._eval_buffers)
             if self._prefetch:

@@ -56,6 +56,7 @@ class AdvanceArgs(ctypes.Structure):
         ("eval_nfinished", ctypes.c_void_p), ("eval_deque", ctypes.c_int),
         ("next_ready", ctypes.c_void_p), ("consumed", ctypes.c_void_p),
         ("warn_fatal_mask", ctypes.c_int), ("fatal_count", ctypes.c_void_p),
+        ("warn_count_mask", ctypes.c_int), ("warn_count", ctypes.c_void_p),
     ]
 
 
@@ -158,7 +159,8 @@ class FusedAdvance:
     are the task's persistent buffers and are updated in place."""
 
     def __init__(self, rewards: FusedRewards, *, n_lookahead, goal_bank, finger_bank, song_len, song_id,
-                 wrong_press_termination, key_threshold, sustain_threshold, key_qrange, warn_fatal_mask=1):
+                 wrong_press_termination, key_threshold, sustain_threshold, key_qrange, warn_fatal_mask=1,
+                 warn_count_mask=0):
         self._L = _lib()
         self._rw = rewards
         E, dt, dev = rewards._E, rewards._dt, rewards._phys.device
@@ -183,6 +185,9 @@ class FusedAdvance:
         p.warn_fatal_mask = int(warn_fatal_mask)
         self.fatal_count = torch.zeros((E,), device=dev, dtype=torch.int64)
         p.fatal_count = self.fatal_count.data_ptr()
+        p.warn_count_mask = int(warn_count_mask)
+        self.warn_count = torch.zeros((E,), device=dev, dtype=torch.int64)
+        p.warn_count = self.warn_count.data_ptr()
         self._p = p
         self._L_lookahead = int(n_lookahead)
 

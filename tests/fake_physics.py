@@ -18,7 +18,7 @@ class FakePhysics:
         self.qvel = torch.zeros((E, m.nv), dtype=self.dtype)
         self.act_force = torch.zeros((E, m.nu), dtype=self.dtype)
         self.act_vel = torch.zeros((E, m.nu), dtype=self.dtype)
-        self.contact_geoms = torch.full((E, 32, 2), -1, dtype=torch.int32)
+        self.contact_geoms = torch.full((E, 64, 2), -1, dtype=torch.int32)
         self.warn = torch.zeros(E, dtype=torch.int32)
         self.time = torch.zeros(E, dtype=self.dtype)
         self._ctrl = torch.zeros((E, m.nu), dtype=self.dtype)

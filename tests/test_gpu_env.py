@@ -690,8 +690,7 @@ def test_device_rasterizer_matches_the_host_tables(precision):
 def test_uniformly_random_actions_do_not_diverge():
     """BASELINE config 3's policy (i.i.d. uniform actions every step) at 8192 envs: hands
     swing into each other at ~18 rad/s and pile up more contacts / Jacobian entries than the
-    kernels hold.  Capacity overflow keeps the deepest contacts, so no env may diverge (with
-    drop-in-emission-order this very run lost 20 envs), and the overflow path is exercised."""
+    kernels held in rounds 1-3 (32 / 256).  No env may diverge, and hardly any may overflow."""
     from robopianist_amd import suite
     from robopianist_amd.wrappers import CanonicalSpecWrapper
     E = 8192
@@ -711,7 +710,10 @@ def test_uniformly_random_actions_do_not_diverge():
         assert torch.isfinite(ts.reward).all()
     assert int((ever & 1).sum()) == 0, "diverged envs"
     assert int((ever & 4).sum()) == 0, "clamped Hessian pivots"
-    assert int((ever & 2).sum()) > 0, "the capacity-overflow path was meant to be exercised"
+    # capacity (round 4: 64 contacts / 640 contact Jacobian entries per env): overflows are rare now -- at most 1e-5 of
+    # the env-steps (rounds 2-3: ~3e-4, and those episodes were ended); the overflow path itself is exercised by
+    # tests/test_gpu_parity.py::test_contact_capacity_overflow_keeps_the_deepest_contacts
+    assert int((ever & 2).sum()) <= 1e-5 * E * 120, int((ever & 2).sum())
     assert torch.isfinite(env.physics.qpos).all()
 
 
@@ -808,12 +810,13 @@ def test_ot_fingering_reward_on_device_matches_scipy():
 
 
 def test_capacity_overflow_ends_the_episode():
-    """An engine capacity overflow (RP_WARN_CONTACT_FULL etc.) ends the episode with reward 0 /
-    discount 0 like a diverged state, on the fused path and on the torch hooks alike; with
-    overflow_termination=False the env steps on (round-1 behaviour)."""
+    """With `overflow_termination=True` (extension) an engine capacity overflow (RP_WARN_CONTACT_FULL etc.) ends
+    the episode with reward 0 / discount 0 like a diverged state, on the fused path and on the torch hooks alike;
+    by default the env steps on, as the reference's would (piano_with_shadow_hands.py:212-220 names the only
+    termination causes), and the episode is counted in `overflow_episodes` when it ends."""
     from robopianist_amd import engine
-    fused, ref = _load_pair(4, 64)
-    loose, _ = _load_pair(4, 64, overflow_termination=False)
+    fused, ref = _load_pair(4, 64, overflow_termination=True)
+    loose, _ = _load_pair(4, 64)
     dev = fused.physics.device
     A = fused.action_spec().shape[0]
     a = torch.zeros((4, A), device=dev, dtype=torch.float64)
@@ -828,6 +831,8 @@ def test_capacity_overflow_ends_the_episode():
         assert float(ts.reward[2]) == 0.0 and float(ts.discount[2]) == 0.0
     assert ts_l.step_type.tolist() == [1, 1, 1, 1]
     assert fused.task.overflow_terminations() == 1 and ref.task.overflow_terminations() == 1
+    assert fused.task.overflow_episodes() == 1 and ref.task.overflow_episodes() == 1
+    assert loose.task.overflow_terminations() == 0 and loose.task.overflow_episodes() == 0   # (its episode is still running)
     ts_f = fused.step(a)
     assert ts_f.step_type.tolist() == [1, 1, 0, 1]          # auto-reset clears the flag
     assert int(fused.physics.warn[2]) == 0

@@ -14,6 +14,9 @@ Two kinds of comparison:
     Asserted for the fp64 engine on the scripted key-press scenario; the fp32
     engine's curve is reported and held to the same 1e-4.
 """
+import os
+import warnings
+
 import numpy as np
 import pytest
 
@@ -546,9 +549,8 @@ def test_fused_substeps_match_the_per_stage_schedule(two_hand_scene):
     """rp_set_fused_substeps: all substeps of a step in one launch (a wave keeps its env; envs that leave the light
     class finish in the clean-up launch) against one launch per stage -- the same stage code in the same order per
     env.  1100 envs on different controls, sensors on, a masked reset and envs sitting out on the way; restarted
-    from the per-stage engine's state at every control step (1e-9 per ten mj_steps; bit-identical while every env
-    stays in the light class).  Second pass with the light class capped at 40 Jacobian entries: a good share of the
-    envs changes class mid-step."""
+    from the per-stage engine's state at every control step, bit-identical.  Second pass with the light class capped
+    at 40 Jacobian entries: a good share of the envs changes class mid-step."""
     from robopianist_amd import engine
     si = two_hand_scene
     m = si.model
@@ -577,14 +579,14 @@ def test_fused_substeps_match_the_per_stage_schedule(two_hand_scene):
                 if t == 9:
                     q.sync(); q.view(engine.ACTIVE).fill_(1); torch_sync()
                 q.step(10)
-            if cap == 1:
-                assert np.array_equal(ref.qpos, p.qpos) and np.array_equal(ref.qvel, p.qvel), t
-                assert np.array_equal(ref.get(engine.SENSOR_TORQUE), p.get(engine.SENSOR_TORQUE))
-                assert np.array_equal(ref.get(engine.SENSOR_TOUCH), p.get(engine.SENSOR_TOUCH))
-            else:
+            # bit-identical in both passes: the clean-up launch picks, substep by substep, the solver build the
+            # per-stage schedule picks (round 3 kept an env on the full-capacity build once it had left the light
+            # class: 1e-13 apart, and with the automatic schedule choice a seeded run was not reproducible)
+            if cap != 1:
                 left += int((p.get(engine.DEBUG_HANDOVER_HDR)[:, 6] == 0).sum())
-                assert np.abs(ref.qpos - p.qpos).max() < 1e-9 and np.abs(ref.qvel - p.qvel).max() < 1e-7, t
-                assert np.abs(ref.get(engine.SENSOR_TORQUE) - p.get(engine.SENSOR_TORQUE)).max() < 1e-6
+            assert np.array_equal(ref.qpos, p.qpos) and np.array_equal(ref.qvel, p.qvel), (cap, t, np.abs(ref.qpos - p.qpos).max())
+            assert np.array_equal(ref.get(engine.SENSOR_TORQUE), p.get(engine.SENSOR_TORQUE))
+            assert np.array_equal(ref.get(engine.SENSOR_TOUCH), p.get(engine.SENSOR_TOUCH))
             assert np.array_equal(ref.get(engine.NCON), p.get(engine.NCON))
         assert cap == 1 or left > 0.05 * 16 * E
         assert ref.get(engine.NCON).max() > 0 and max(int(ref.warn_flags.max()), int(p.warn_flags.max())) == 0
@@ -745,6 +747,195 @@ def test_teacher_forced_fp64_with_box_box_contacts(two_hand_scene):
         maxcon = max(maxcon, orc.ncon)
     print(f"box-box: {boxbox} box-box contacts over {len(phases)} steps, max contacts {maxcon}, worst rel dv {worst:.2e}")
     assert boxbox >= 50 and (phys.warn_flags.max() & ~engine.WARN_CONTACT_FULL) == 0
+    assert worst < 1e-9
+
+
+def pile_up(si, nsteps=120, seed=3, lo_dx=0.083, hi_dx=0.098):
+    """Teacher-forced steps from hand-IN-hand poses: both forearms shifted towards each other until the hands
+    interpenetrate (30 ... 64 contacts, most of them hand-hand, i.e. ~14 Jacobian entries each and one large dense
+    block), fingers at random postures.  Returns (worst rel dv, max contacts, max entries, steps beyond 32 contacts)."""
+    from robopianist_amd import engine
+    from robopianist_amd.model import spec
+    m = si.model
+    jn = m.names["joint"]
+    rng = np.random.default_rng(seed)
+    phys, orc = make_pair(si, 64)
+    lo, hi = m.actuator_ctrlrange[:, 0], m.actuator_ctrlrange[:, 1]
+    nanc = np.zeros(m.nbody, int)
+    for b in range(1, m.nbody):
+        nanc[b] = nanc[m.body_parentid[b]] + m.body_jntnum[b]
+    worst, maxcon, maxent, beyond = 0.0, 0, 0, 0
+    for it in range(nsteps):
+        orc.reset()
+        q = orc.qpos.copy()
+        dx = rng.uniform(lo_dx, hi_dx)
+        for i, n in enumerate(jn):
+            s = n.split("/")[-1]
+            if s == "forearm_tx":
+                q[i] += -dx if n.startswith("rh") else dx
+            elif "shadow_hand" in n and s != "forearm_ty":
+                r0, r1 = m.jnt_range[i]
+                q[i] = np.clip(q[i] + rng.normal(0, 0.06), r0, r1)
+        v = rng.normal(0, 0.2, m.nv)
+        c = lo + rng.uniform(0.2, 0.8, m.nu) * (hi - lo)
+        orc.qpos[:] = q; orc.qvel[:] = v; orc.qacc_warmstart[:] = 0; orc.ctrl[:] = c
+        orc.forward()   # (the step is mj_step2; mj_step1: the position-dependent stage of the imposed state)
+        w = orc.qacc_warmstart.copy()   # (forward leaves its solution as the next solve's warm start)
+
+        def entries():
+            return int(sum(nanc[m.geom_bodyid[int(x[13])]] + nanc[m.geom_bodyid[int(x[14])]] for x in orc.contact.reshape(-1, 16)))
+        ncon0, ne0 = orc.ncon, entries()
+
+        def axis_in_box():
+            # a capsule whose AXIS passes through a box: a whole interval of the axis is at distance zero, the
+            # closest-point rule of capsule-box lands on the box surface (dist = -radius exactly) and rounding decides
+            # which face's normal the contact gets -- in the oracle as in the engine.  Not a pose of this task.
+            for x in orc.contact.reshape(-1, 16):
+                g1, g2 = int(x[13]), int(x[14])
+                if m.geom_type[g1] == spec.GEOM_CAPSULE and m.geom_type[g2] == spec.GEOM_BOX and abs(x[0] + m.geom_size[g1][0]) < 1e-9:
+                    return True
+            return False
+        degenerate = axis_in_box()
+        phys.reset()   # (clears the sticky warn flags of an iteration that was beyond the capacity)
+        phys.set(engine.QPOS, q[None, :]); phys.set(engine.QVEL, v[None, :])
+        phys.set(engine.QACC_WARMSTART, w[None, :]); phys.set(engine.CTRL, c[None, :])
+        v0 = orc.qvel.copy()
+        phys.step(1); orc.step(1)
+        con = orc.contact.reshape(-1, 16)
+        ne = entries()
+        if max(ncon0, orc.ncon) > engine.MAX_CONTACTS or max(ne0, ne) > 600:
+            continue   # (beyond the engine's capacity: covered by the overflow tests)
+        if degenerate or axis_in_box():
+            continue
+        ne_ = int(phys.get(engine.NCON)[0])
+        if ne_ != orc.ncon:
+            gm = m.names["geom"]
+            ce = phys.get(engine.CONTACT_GEOMS)[0][:ne_]
+            pe = sorted((gm[a].split("/")[-1], gm[b].split("/")[-1], round(float(d), 6)) for (a, b), d in
+                        zip(ce, phys.get(engine.CONTACT_DIST)[0][:ne_]))
+            po = sorted((gm[int(c[13])].split("/")[-1], gm[int(c[14])].split("/")[-1], round(float(c[0]), 6)) for c in con)
+            raise AssertionError(f"contact sets differ ({ne_} vs {orc.ncon}): engine-only {sorted(set(pe) - set(po))}, "
+                                 f"oracle-only {sorted(set(po) - set(pe))}")
+        assert phys.warn_flags.max() == 0, int(phys.warn_flags.max())
+        dv = np.abs(phys.qvel[0].astype(np.float64) - orc.qvel).max()
+        worst = max(worst, dv / max(np.abs(orc.qvel - v0).max(), 1e-9))
+        if os.environ.get("RP_PILEUP_VERBOSE"):
+            print(f"  pile-up step {it}: contacts {ncon0} -> {orc.ncon}, entries <= {ne0}, solver_iter {orc.solver_iter} / "
+                  f"{int(phys.get(engine.SOLVER_ITER)[0]) & 255}, rel dv {dv / max(np.abs(orc.qvel - v0).max(), 1e-9):.2e}")
+        maxcon = max(maxcon, ncon0, orc.ncon); maxent = max(maxent, ne0, ne); beyond += max(ncon0, orc.ncon) > 32
+    return worst, maxcon, maxent, beyond
+
+
+def test_teacher_forced_fp64_pile_up_beyond_32_contacts(two_hand_scene):
+    """More than 32 contacts / 256 contact Jacobian entries per env (rounds 1-3 ended such episodes: the reference
+    ends an episode only at the end of the MIDI or on a wrong press, piano_with_shadow_hands.py:212-220): the
+    position stage's overflow records and the full-capacity solver stage's 64 contact lanes against the oracle."""
+    worst, maxcon, maxent, beyond = pile_up(two_hand_scene)
+    print(f"pile-up: worst rel dv {worst:.2e}, max contacts {maxcon}, max entries {maxent}, {beyond} steps beyond 32 contacts")
+    assert maxcon > 40 and beyond >= 10 and maxent > 300
+    assert worst < 1e-9
+
+
+def palm_flat(si, nsteps=30, seed=5):
+    """Teacher-forced steps with the right hand lowered until its palm boxes lie on the keys (rp_set(RP_TREE_OFFSET)
+    / the oracle's body_pos): box-box pairs resting face to face -- four to eight points per pair -- with the wrist
+    yawed and tilted a little so that the incident face is clipped by the reference rectangle.  Returns (worst rel
+    dv, max contacts, box-box pairs with more than three points, their largest point count)."""
+    from collections import Counter
+    from robopianist_amd import engine
+    from robopianist_amd.model import spec
+    m = si.model
+    jn, bn = m.names["joint"], m.names["body"]
+    rng = np.random.default_rng(seed)
+    phys, orc = make_pair(si, 64)
+    root = [i for i, n in enumerate(bn) if m.body_parentid[i] == 0 and n.startswith("rh_shadow_hand")][0]
+    bp0 = orc.body_pos.copy()
+    lo, hi = m.actuator_ctrlrange[:, 0], m.actuator_ctrlrange[:, 1]
+    ntree = phys.dim("ntree")
+    worst, maxcon, pairs, most = 0.0, 0, 0, 0
+    try:
+        for it in range(nsteps):
+            dz = rng.uniform(0.0965, 0.1005)
+            orc.body_pos[:] = bp0; orc.body_pos[3 * root + 2] -= dz
+            orc.reset()
+            q = orc.qpos.copy()
+            for i, n in enumerate(jn):
+                s = n.split("/")[-1]
+                if n.startswith("rh_shadow_hand"):
+                    r0, r1 = m.jnt_range[i]
+                    if s[3:] in ("FFJ3", "MFJ3", "RFJ3", "LFJ3"):
+                        q[i] = r0                                    # fingers lifted off the keys
+                    elif s in ("rh_WRJ1", "rh_WRJ2"):
+                        q[i] = np.clip(rng.normal(0, 0.03), r0, r1)   # a little yaw / tilt
+            v = rng.normal(0, 0.05, m.nv)
+            c = lo + rng.uniform(0.3, 0.7, m.nu) * (hi - lo)
+            orc.qpos[:] = q; orc.qvel[:] = v; orc.qacc_warmstart[:] = 0; orc.ctrl[:] = c
+            orc.forward()
+            w = orc.qacc_warmstart.copy()
+            con0 = orc.contact.reshape(-1, 16).copy()
+            off = np.zeros((1, ntree, 3))
+            off[0, 0, 2] = -dz   # (tree 0 = the right hand: the first hand of the scene)
+            phys.reset()
+            phys.set(engine.TREE_OFFSET, off)
+            phys.set(engine.QPOS, q[None, :]); phys.set(engine.QVEL, v[None, :])
+            phys.set(engine.QACC_WARMSTART, w[None, :]); phys.set(engine.CTRL, c[None, :])
+            v0 = orc.qvel.copy()
+            phys.step(1); orc.step(1)
+            if max(len(con0), orc.ncon) > engine.MAX_CONTACTS:
+                continue
+            assert int(phys.get(engine.NCON)[0]) == orc.ncon, (int(phys.get(engine.NCON)[0]), orc.ncon)
+            assert phys.warn_flags.max() == 0, int(phys.warn_flags.max())
+            dv = np.abs(phys.qvel[0].astype(np.float64) - orc.qvel).max()
+            worst = max(worst, dv / max(np.abs(orc.qvel - v0).max(), 1e-9))
+            bb = Counter((int(x[13]), int(x[14])) for x in con0
+                         if m.geom_type[int(x[13])] == spec.GEOM_BOX and m.geom_type[int(x[14])] == spec.GEOM_BOX)
+            pairs += sum(1 for n_ in bb.values() if n_ > 3); most = max([most] + list(bb.values()))
+            maxcon = max(maxcon, len(con0), orc.ncon)
+    finally:
+        orc.body_pos[:] = bp0
+    return worst, maxcon, pairs, most
+
+
+def test_contact_capacity_overflow_keeps_the_deepest_contacts(two_hand_scene):
+    """Beyond the capacity (64 contacts / 640 entries per env; here: the two hands pushed 10-14 cm into each other,
+    70-200 contacts) the position stage keeps the deepest contacts and raises RP_WARN_CONTACT_FULL; the env stays
+    finite and steps on."""
+    from robopianist_amd import engine
+    si = two_hand_scene
+    m = si.model
+    jn = m.names["joint"]
+    phys, orc = make_pair(si, 64)
+    flagged = 0
+    for dx in (0.10, 0.12, 0.14):
+        orc.reset()
+        q = orc.qpos.copy()
+        for i, n in enumerate(jn):
+            if n.split("/")[-1] == "forearm_tx":
+                q[i] += -dx if n.startswith("rh") else dx
+        orc.qpos[:] = q
+        orc.forward()
+        assert orc.ncon > engine.MAX_CONTACTS, orc.ncon
+        deepest = np.sort(orc.contact.reshape(-1, 16)[:, 0])[:engine.MAX_CONTACTS]
+        phys.reset()
+        phys.set(engine.QPOS, q[None, :])
+        phys.forward()
+        assert int(phys.get(engine.NCON)[0]) == engine.MAX_CONTACTS
+        assert int(phys.warn_flags.max()) & engine.WARN_CONTACT_FULL
+        kept = np.sort(phys.get(engine.CONTACT_DIST)[0].astype(np.float64))
+        # (the Jacobian-entry capacity may drop further, shallowest first: the kept set is a prefix of the deepest)
+        np.testing.assert_allclose(kept, deepest, rtol=0, atol=1e-9)
+        phys.step(10)
+        assert np.isfinite(phys.qpos).all() and np.isfinite(phys.qvel).all()
+        flagged += 1
+    assert flagged == 3
+
+
+def test_teacher_forced_fp64_palm_flat_on_the_keys(two_hand_scene):
+    """mjc_BoxBox emits up to eight points for two boxes resting face to face (rounds 1-3 kept the three deepest):
+    the palm boxes flat on the keys, engine against oracle at 1e-9 per step."""
+    worst, maxcon, pairs, most = palm_flat(two_hand_scene)
+    print(f"palm flat on the keys: worst rel dv {worst:.2e}, max contacts {maxcon}, {pairs} box-box pairs with > 3 points (most: {most})")
+    assert pairs >= 50 and most >= 5
     assert worst < 1e-9
 
 

@@ -308,13 +308,14 @@ def test_box_on_box_face_contact_settles():
     assert m.npair == 1
     o.step(600)
     con = o.contact.reshape(-1, 16)
-    assert o.ncon == 3                                    # deepest three of the four face corners
-    np.testing.assert_allclose(con[:, 4:7], np.tile([0, 0, 1.0], (3, 1)), atol=1e-12)   # floor (geom1) -> top
+    assert o.ncon == 4                                    # the four corners of the small face (rounds 1-3: the deepest three)
+    np.testing.assert_allclose(con[:, 4:7], np.tile([0, 0, 1.0], (4, 1)), atol=1e-12)   # floor (geom1) -> top
     # rest: top box centre at 0.02 + 0.01 - penetration, a soft-contact penetration of well under 1 mm
     z = 0.05 + o.qpos[0]
     assert 0.0290 < z < 0.0300 and abs(o.qvel[0]) < 1e-6
     np.testing.assert_allclose(con[:, 0], z - 0.03, atol=1e-12)      # dist = -penetration
     assert set(map(tuple, np.round(np.abs(con[:, 1:3]), 12))) == {(0.02, 0.02)}      # corners of the small face
+    assert len(set(map(tuple, np.round(con[:, 1:3], 12)))) == 4                       # ... all four of them
     np.testing.assert_allclose(con[:, 3], 0.02 + 0.5 * (z - 0.03), atol=1e-12)       # midway between the surfaces
     # static balance: the contact normal forces carry the weight
     f = o.efc_force[o.nefc - 4 * o.ncon:].sum()
@@ -327,14 +328,34 @@ def test_box_box_rotated_face_and_edge_edge_cases():
     m, o = _two_box_scene(top_quat=(c, 0, 0, s_))
     o.qpos[0] = -0.0205; o.forward()
     con = o.contact.reshape(-1, 16)
-    assert o.ncon == 3 and np.allclose(con[:, 0], -0.0005)
+    assert o.ncon == 4 and np.allclose(con[:, 0], -0.0005)
     r = np.hypot(con[:, 1], con[:, 2])
     np.testing.assert_allclose(r, 0.02 * np.sqrt(2), atol=1e-12)
+    # (1b) a 6 x 6 cm face turned 45 degrees over the 10 x 10 cm floor face... the other way round: the small face is
+    # the floor's.  A 4 x 4 cm square turned 45 degrees inside a 10 x 10 cm one stays a square; clipped by a 5 x 5 cm
+    # one it becomes an octagon: eight contacts [mjc_BoxBox's maximum], all on the rim of the clipping rectangle or of
+    # the turned square
+    from robopianist_amd.model import spec
+    world = spec.Body(name="world")
+    world.geoms.append(spec.Geom("floor_box", spec.GEOM_BOX, (0.025, 0.025, 0.01), pos=(0, 0, 0.01)))
+    top = spec.Body(name="top", pos=(0, 0, 0.05), quat=(c, 0, 0, s_),
+                    joints=[spec.Joint("z", type=spec.JNT_SLIDE, axis=(0, 0, 1), damping=0.5)],
+                    geoms=[spec.Geom("top_box", spec.GEOM_BOX, (0.02, 0.02, 0.01), mass=0.1)])
+    world.add(top)
+    m8 = mc.compile_scene(spec.Scene(world=world))
+    o8 = Oracle(m8, mc.to_blob(m8))
+    o8.qpos[0] = -0.0205; o8.forward()
+    con = o8.contact.reshape(-1, 16)
+    assert o8.ncon == 8 and np.allclose(con[:, 0], -0.0005)
+    np.testing.assert_allclose(con[:, 4:7], np.tile([0, 0, 1.0], (8, 1)), atol=1e-12)
+    on_rect = np.isclose(np.abs(con[:, 1:3]).max(axis=1), 0.025, atol=1e-12)
+    on_diamond = np.isclose(np.abs(con[:, 1]) + np.abs(con[:, 2]), 0.02 * np.sqrt(2), atol=1e-12)
+    assert np.all(on_rect & on_diamond) and len(set(map(tuple, np.round(con[:, 1:3], 9)))) == 8
     # (2) a big top face over a small floor: the reference corners / crossings come from the other box
     m, o = _two_box_scene(hinges=((1, 0, 0),))
     o.qpos[0] = -0.0202; o.qpos[1] = 0.3; o.forward()       # tilted about x: one edge of the top box digs in
     con = o.contact.reshape(-1, 16)
-    assert 1 <= o.ncon <= 3 and np.all(con[:, 0] <= 0)
+    assert 1 <= o.ncon <= 8 and np.all(con[:, 0] <= 0)
     np.testing.assert_allclose(con[:, 4:7], np.tile([0, 0, 1.0], (o.ncon, 1)), atol=1e-12)
     assert np.all(con[:, 2] < 0)                              # the lowered edge is on the -y side
     # (3) edge against edge: top box rolled 45 deg about x and yawed 90 deg - its lowest edge (along x

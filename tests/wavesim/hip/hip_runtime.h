@@ -146,6 +146,8 @@ static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = ::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }
 static inline hipError_t hipFree(void* p) { ::free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = ::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }
+static inline hipError_t hipHostFree(void* p) { ::free(p); return hipSuccess; }
 static inline hipError_t hipMemset(void* p, int v, size_t n) { ::memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { ::memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { ::memmove(d, s, n); return hipSuccess; }
