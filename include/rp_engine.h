@@ -104,6 +104,15 @@ int rp_step(rp_engine* e, int n_substeps, uint32_t* key_trace);
  * for the current state without stepping: physics.forward(). */
 int rp_forward(rp_engine* e);
 
+/* One call for what composer.Environment.step does around its substep loop when episodes of a batch end at
+ * different times (dm_control composer/environment.py: a step after LAST resets instead of stepping):
+ * rp_reset(reset_mask) of the flagged envs, physics.forward() of those (their position / velocity stage: the
+ * FIRST observation reads site positions / contacts of the reset state), and rp_step of the envs the RP_ACTIVE mask
+ * selects -- the caller clears the flagged envs there (rp_task_prestep writes both masks).  reset_mask: [E] bytes,
+ * device memory; NULL = rp_step.  Same results as rp_reset + rp_set(RP_ACTIVE) + rp_forward + rp_set(RP_ACTIVE) +
+ * rp_step, with one leading position / velocity stage instead of two. */
+int rp_step_masked(rp_engine* e, int n_substeps, uint32_t* key_trace, const uint8_t* reset_mask);
+
 /* Solver iteration caps (defaults: model opt.iterations / opt.ls_iterations). */
 int rp_set_solver_limits(rp_engine* e, int max_newton_iter, int max_ls_iter);
 

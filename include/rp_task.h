@@ -133,6 +133,33 @@ typedef struct rp_task_advance_args {
 
 int rp_task_advance(const rp_task_advance_args* args, void* hip_stream);
 
+/* rp_task_prestep: everything between env.step(action) and physics.step(), one launch (thread = env):
+ *   - CanonicalSpecWrapper.step (robopianist/wrappers/canonical.py; dm_env_wrappers): an action in [-1, 1] is mapped
+ *     onto the spec's bounds, lo + (a + 1) / 2 * (hi - lo), optionally clipped to [-1, 1] first (act_lo == NULL: the
+ *     action already is in the spec's units);
+ *   - composer.Environment.step's bookkeeping: an env whose episode ended at the previous step (needs_reset) is
+ *     reset and NOT simulated in this step, its action is discarded (dm_env): active = !needs_reset goes to the
+ *     engine's RP_ACTIVE mask, reset_mask = needs_reset is what rp_step_masked takes;
+ *   - PianoWithShadowHands.before_step (suite/tasks/piano_with_shadow_hands.py:176-186): the hand actions go to
+ *     their actuators' ctrl (right hand's, then the left's: hand_act), the last action entry to
+ *     piano.apply_sustain (models/piano/piano.py:140-143; 0 for an env that is being reset). */
+typedef struct rp_task_prestep_args {
+  int n_envs, precision;             /* 32 / 64: element type of action, bounds, ctrl, sustain_state */
+  int n_action, nu;                  /* action row length (hand actions + sustain), ctrl row length */
+  const void* action;                /* [E][n_action] */
+  const void* act_lo;                /* [n_action] or NULL */
+  const void* act_range;             /* [n_action] hi - lo (with act_lo) */
+  int clip;
+  const unsigned char* needs_reset;  /* [E] */
+  const int* hand_act;               /* [n_action - 1] */
+  void* ctrl;                        /* [E][nu], rows of the envs that are stepped */
+  void* sustain_state;               /* [E] */
+  int* active;                       /* [E] out */
+  unsigned char* reset_mask;         /* [E] out */
+} rp_task_prestep_args;
+
+int rp_task_prestep(const rp_task_prestep_args* args, void* hip_stream);
+
 /* rp_task_rasterize: goal / fingering tables of augmented songs, built on the device.
  * What the reference does on the host at every episode start when `augmentations` are given
  * (suite/tasks/piano_with_shadow_hands.py:151-165): MidiFile.stretch / transpose

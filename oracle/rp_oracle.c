@@ -79,6 +79,7 @@ struct rpo_model {
       *geom_solref, *geom_solimp, *geom_solmix, *geom_margin, *geom_gap;
   const int32_t *geom_vertadr, *geom_vertnum;   /* GEOM_MESH: hull vertices (geom frame) */
   const double* mesh_vert;
+  const int32_t *geom_vertgraph, *mesh_graph;   /* large hulls: 1 = walk the vertex graph; rows [degree, neighbours...] (model/hull.py) */
   const int32_t* site_bodyid;
   const double* site_pos;
   const double* site_touch_radius; /* > 0: the site is the zone of a touch sensor (sphere); may be NULL */
@@ -159,6 +160,8 @@ rpo_model* rpo_model_load(const void* blob, size_t nbytes) {
     if (blob_find(m, "geom_vertadr")) {
       m->geom_vertadr = BI("geom_vertadr"); m->geom_vertnum = BI("geom_vertnum");
       m->mesh_vert = blob_find(m, "mesh_vert") ? BF("mesh_vert") : NULL;
+      m->geom_vertgraph = blob_find(m, "geom_vertgraph") ? BI("geom_vertgraph") : NULL;
+      m->mesh_graph = blob_find(m, "mesh_graph") ? BI("mesh_graph") : NULL;
     }
   }
   if (m->nsite) {
@@ -862,7 +865,8 @@ static int box_box(rawcon* out, const double* p1, const double* m1, const double
 static double g_mpr_tol = CCD_TOL;   /* experiment knobs (rpo_debug_set_mpr) */
 static int g_mpr_discrete = 0;
 void rpo_debug_set_mpr(double tol, int discrete) { g_mpr_tol = tol; g_mpr_discrete = discrete; }
-typedef struct { int type; const double *pos, *mat, *size; const double* vert; int nvert; } cgeom;
+#define HULL_GRAPH_ROW 24   /* ints per vertex of mesh_graph: degree + neighbours (model/hull.py: GRAPH_ROW) */
+typedef struct { int type; const double *pos, *mat, *size; const double* vert; int nvert; const int32_t* graph; } cgeom;
 typedef struct { double v[3], p1[3], p2[3]; int id; } mpoint;   /* point of B - A, its witnesses on A and B; id = (vertex of A, vertex of B) for polytopes */
 
 static int geom_support(const cgeom* g, const double* d, double* out) {   /* d: unit, world; returns the vertex id (polytopes) */
@@ -882,6 +886,18 @@ static int geom_support(const cgeom* g, const double* d, double* out) {   /* d: 
   } else {
     double dl[3]; matT_vec(dl, g->mat, d);
     int best = 0; double bv = -1e300;
+    if (g->graph) {
+      /* large hull: walk its vertex graph from vertex 0 -- to the neighbour with the largest dot product (first
+       * one on ties) while that is strictly larger than the current value [MJ: hill climbing over mesh_graph] */
+      bv = dot3(dl, g->vert);
+      for (;;) {
+        const int32_t* row = g->graph + (size_t)HULL_GRAPH_ROW * best;
+        int next = -1; double nv_ = bv;
+        for (int j = 0; j < row[0]; j++) { double v = dot3(dl, g->vert + 3*row[1+j]); if (v > nv_) { nv_ = v; next = row[1+j]; } }
+        if (next < 0) break;
+        best = next; bv = nv_;
+      }
+    } else
     for (int i = 0; i < g->nvert; i++) { double v = dot3(dl, g->vert + 3*i); if (v > bv) { bv = v; best = i; } }
     double w[3]; mat_vec(w, g->mat, g->vert + 3*best);
     for (int k = 0; k < 3; k++) out[k] = g->pos[k] + w[k];
@@ -1011,9 +1027,13 @@ static void collision(const rpo_model* m, rpo_data* d) {
       n = box_box(rc, p1, d->geom_xmat + 9*g1, m->geom_size + 3*g1, p2,
                   d->geom_xmat + 9*g2, m->geom_size + 3*g2, margin);
     else if (t2 == GEOM_MESH && m->mesh_vert) {
+#define HULL_GRAPH_OF(g_) ((m->geom_vertgraph && m->mesh_graph && m->geom_vertgraph[g_]) ? m->mesh_graph + (size_t)HULL_GRAPH_ROW * m->geom_vertadr[g_] : NULL)
       cgeom A = {t1, p1, d->geom_xmat + 9*g1, m->geom_size + 3*g1,
-                 t1 == GEOM_MESH ? m->mesh_vert + 3*m->geom_vertadr[g1] : NULL, t1 == GEOM_MESH ? m->geom_vertnum[g1] : 0};
-      cgeom B = {t2, p2, d->geom_xmat + 9*g2, m->geom_size + 3*g2, m->mesh_vert + 3*m->geom_vertadr[g2], m->geom_vertnum[g2]};
+                 t1 == GEOM_MESH ? m->mesh_vert + 3*m->geom_vertadr[g1] : NULL, t1 == GEOM_MESH ? m->geom_vertnum[g1] : 0,
+                 t1 == GEOM_MESH ? HULL_GRAPH_OF(g1) : NULL};
+      cgeom B = {t2, p2, d->geom_xmat + 9*g2, m->geom_size + 3*g2, m->mesh_vert + 3*m->geom_vertadr[g2], m->geom_vertnum[g2],
+                 HULL_GRAPH_OF(g2)};
+#undef HULL_GRAPH_OF
       n = mpr_penetration(&A, &B, rc);
     }
     else continue;

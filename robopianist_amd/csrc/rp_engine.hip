@@ -19,13 +19,15 @@ namespace {
 
 // Bookkeeping of the lazy position stage (rp_set_lazy_position_stage): which envs' hand-over
 // (RpStage) still matches their state.
-__global__ void rp_lead_mask_kernel(int* lead, const int* active, const unsigned char* valid, int n) {
+// (lazy: skip the envs whose hand-over is still the one of their state; also: the envs rp_step_masked has just
+// reset, stepped or not -- their position / velocity stage is the physics.forward() of the new episode)
+__global__ void rp_lead_mask_kernel(int* lead, const int* active, const unsigned char* valid, int lazy, const unsigned char* also, int n) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n) lead[e] = ((active ? active[e] != 0 : true) && !valid[e]) ? 1 : 0;
+  if (e < n) lead[e] = (((active ? active[e] != 0 : true) && !(lazy && valid[e])) || (also && also[e])) ? 1 : 0;
 }
-__global__ void rp_mark_valid_kernel(unsigned char* valid, const int* active, int n) {
+__global__ void rp_mark_valid_kernel(unsigned char* valid, const int* active, const unsigned char* also, int n) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n && (!active || active[e] != 0)) valid[e] = 1;
+  if (e < n && (!active || active[e] != 0 || (also && also[e]))) valid[e] = 1;
 }
 
 // Launch order of the envs for the solver stage that follows a position stage: descending predicted
@@ -196,7 +198,7 @@ struct EngineBase {
   virtual int reset(const uint8_t* mask) = 0;
   virtual int set(rp_field f, const void* src) = 0;
   virtual int get(rp_field f, void* dst) = 0;
-  virtual int step(int nsub, uint32_t* trace, int mode) = 0;
+  virtual int step(int nsub, uint32_t* trace, int mode, const uint8_t* reset_mask = nullptr) = 0;
   virtual void limits(int newton, int ls) = 0;
   virtual void tolerances(double tol, double ls_tol) = 0;
   bool lazy_position = false;
@@ -477,7 +479,8 @@ struct Engine : EngineBase {
   // Grid of the full-capacity solver stage.  Each of its workgroups needs a whole idle SIMD (512 registers) and 55 KB of
   // LDS even to find the list empty, and the slice's join waits for the last of them: the grid follows the longest
   // list the stage saw recently -- read back one step late, never waited for (a list longer than the grid is walked
-  // in rounds: slower for a step, never wrong).  Measured, config 2 / 3 hull: fixed 128: 618 / 435 k env-steps/s.
+  // in rounds: slower for a step, never wrong).  Measured with the 55 KB stage, config 2 hull: fixed 128: 618 k
+  // env-steps/s, following the list: 651 k (the 40 KB stage of round 3 at 128: 650 k).
   int *d_heavy_peak = nullptr, *h_heavy_peak = nullptr;
   double heavy_est[kMaxSlices] = {64, 64, 64, 64};
   int heavy_grid_for(int sl, int cnt) {
@@ -485,7 +488,7 @@ struct Engine : EngineBase {
     if (!heavy_grid_fixed && h_heavy_peak) {
       const int seen = *(volatile int*)&h_heavy_peak[sl];
       if (seen >= 0) { heavy_est[sl] = seen > heavy_est[sl] ? seen : 0.9 * heavy_est[sl] + 0.1 * seen; *(volatile int*)&h_heavy_peak[sl] = -1; }
-      g = (int)(1.25 * heavy_est[sl]) + 4;
+      g = (int)(2.0 * heavy_est[sl]) + 8;   // (config 3, 4096 envs: fixed grids of 24 / 48 / 128: 409 / 436 / 445 k env-steps/s)
       g = g < 8 ? 8 : (g > kHeavyGrid ? kHeavyGrid : g);
     }
     return cnt < g ? cnt : g;
@@ -649,9 +652,20 @@ struct Engine : EngineBase {
     if (!on_device) HIP_OK(hipStreamSynchronize(stream));  // device destinations stay stream-ordered
     return 0;
   }
-  int step(int nsub, uint32_t* trace, int mode) override {
+  int step(int nsub, uint32_t* trace, int mode, const uint8_t* reset_mask = nullptr) override {
     HIP_OK(hipSetDevice(device));
     if (mode == 0 && nsub <= 0) return fail("rp_step: n_substeps must be positive");
+    if (reset_mask) {
+      // rp_step_masked: physics.reset() of the flagged envs first (same launch as rp_reset with a device mask); their
+      // physics.forward() is the leading position / velocity stage below
+      hipPointerAttribute_t attr;
+      const bool on_device = hipPointerGetAttributes(&attr, reset_mask) == hipSuccess && attr.type == hipMemoryTypeDevice;
+      (void)hipGetLastError();
+      if (!on_device) return fail("rp_step_masked: the reset mask must be device memory");
+      RpState<T> sr = S;
+      sr.sens_torque = sensors_on ? d_sens_torque : nullptr; sr.sens_touch = sensors_on ? d_sens_touch : nullptr;
+      hipLaunchKernelGGL(rp_reset_kernel<T>, dim3(nenv), dim3(64), 0, stream, sr, d_qpos0, reset_mask, nv, nu, nsite, d_valid);
+    }
     RpState<T> s = S;
     size_t need = (size_t)nenv * (nsub > 0 ? nsub : 1) * 4;
     if (trace && mode == 0) {
@@ -736,8 +750,9 @@ struct Engine : EngineBase {
     // slice sl covers the envs [bound(sl), bound(sl + 1)); bounds are multiples of 8 (XCD classes of the order)
     auto bound = [&](int sl) { return sl >= nsl ? nenv : (int)(((long long)nenv * sl / nsl + 7) / 8 * 8); };
     if (cost_order && mode == 0) s.order = d_order;   // (initialised to the identity; refreshed below)
-    if (lazy_position && mode == 0)
-      hipLaunchKernelGGL(rp_lead_mask_kernel, dim3(hb), dim3(256), 0, stream, d_lead, s.active, d_valid, nenv);
+    const bool lead_masked = (lazy_position || reset_mask) && mode == 0;
+    if (lead_masked)
+      hipLaunchKernelGGL(rp_lead_mask_kernel, dim3(hb), dim3(256), 0, stream, d_lead, s.active, d_valid, lazy_position ? 1 : 0, reset_mask, nenv);
     if (nsl > 1) {
       HIP_OK(hipEventRecord(ev_fork, stream));
       for (int i = 1; i < nsl; i++) HIP_OK(hipStreamWaitEvent(xstream[i], ev_fork, 0));
@@ -758,7 +773,7 @@ struct Engine : EngineBase {
       // before its solver stage reads it (the solver stage consumes the hand-over: it parks values in it)
       RpState<T> lead = ss;
       lead.order = nullptr;
-      if (lazy_position && mode == 0) lead.active = d_lead;   // skipped for envs whose hand-over is still the one of their state
+      if (lead_masked) lead.active = d_lead;   // skipped for envs whose hand-over is still the one of their state
       launch_pos_on(lead, -1);
       if (mode != 0) continue;
       if constexpr (sizeof(T) == 8) {
@@ -859,7 +874,7 @@ struct Engine : EngineBase {
       }
     }
     for (int i = 1; i < nsl; i++) { HIP_OK(hipEventRecord(ev_join[i], xstream[i])); HIP_OK(hipStreamWaitEvent(stream, ev_join[i], 0)); }
-    hipLaunchKernelGGL(rp_mark_valid_kernel, dim3(hb), dim3(256), 0, stream, d_valid, s.active, nenv);
+    hipLaunchKernelGGL(rp_mark_valid_kernel, dim3(hb), dim3(256), 0, stream, d_valid, s.active, reset_mask, nenv);
     if (mode == 0 && lean && !capturing && h_heavy_peak && !heavy_grid_fixed) {
       // the longest lists of this step, for the grids of a later one (the host never waits for the copy)
       HIP_OK(hipMemcpyAsync(h_heavy_peak, d_heavy_peak, sizeof(int) * kMaxSlices, hipMemcpyDeviceToHost, stream));
@@ -930,6 +945,9 @@ int rp_step(rp_engine* e, int n_substeps, uint32_t* key_trace) {
   return e ? E(e)->step(n_substeps, key_trace, 0) : fail("null engine");
 }
 int rp_forward(rp_engine* e) { return e ? E(e)->step(0, nullptr, 1) : fail("null engine"); }
+int rp_step_masked(rp_engine* e, int n_substeps, uint32_t* key_trace, const uint8_t* reset_mask) {
+  return e ? E(e)->step(n_substeps, key_trace, 0, reset_mask) : fail("null engine");
+}
 int rp_set_solver_limits(rp_engine* e, int max_newton_iter, int max_ls_iter) {
   if (!e) return fail("null engine");
   E(e)->limits(max_newton_iter, max_ls_iter);

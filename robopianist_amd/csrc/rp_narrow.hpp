@@ -342,20 +342,18 @@ __device__ RPK_BOXBOX_INLINE int box_box(RawCon<T>* out, RawCon<T>* extra, const
   T nrm[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) nrm[k] = refA ? zr[k] : -zr[k];
-  // every candidate that penetrates is a contact: position midway between the surfaces
+  // every candidate that penetrates is a contact.  Candidates are collected as (depth, u, v): the first three in
+  // registers (static indices), the rest in the memory-resident `extra` (its first three words per record); the
+  // world-frame points are formed after the last candidate
+  T bd[3] = {(T)-1, (T)-1, (T)-1}, bu[3] = {0, 0, 0}, bv[3] = {0, 0, 0};
   auto emit = [&](T cu, T cv, T zz) {
     const T depth = h - zz;
     if (depth >= (T)0 && n < RPK_BOXBOX_MAX) {
-      const T zc = h - (T)0.5 * depth;
-      RawCon<T> c;
-#pragma unroll
-      for (int k = 0; k < 3; k++) { c.pos[k] = pr[k] + ur[k] * cu + vr[k] * cv + zr[k] * zc; c.n[k] = nrm[k]; }
-      c.dist = -depth;
       if (n < 3) {
 #pragma unroll
-        for (int i = 0; i < 3; i++) if (n == i) out[i] = c;
+        for (int i = 0; i < 3; i++) { const bool me = n == i; bd[i] = me ? depth : bd[i]; bu[i] = me ? cu : bu[i]; bv[i] = me ? cv : bv[i]; }
       } else if (RPK_BOXBOX_MAX > 3) {
-        extra[n - 3] = c;
+        extra[n - 3].dist = depth; extra[n - 3].pos[0] = cu; extra[n - 3].pos[1] = cv;
       }
       n++;
     }
@@ -407,6 +405,27 @@ __device__ RPK_BOXBOX_INLINE int box_box(RawCon<T>* out, RawCon<T>* extra, const
             if (cax == 0) emit(lim, oc, zz); else emit(oc, lim, zz);
           }
         }
+      }
+    }
+  }
+  // position midway between the surfaces
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const T zc = h - (T)0.5 * bd[i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { out[i].pos[k] = pr[k] + ur[k] * bu[i] + vr[k] * bv[i] + zr[k] * zc; out[i].n[k] = nrm[k]; }
+    out[i].dist = -bd[i];
+  }
+  if (RPK_BOXBOX_MAX > 3 && n > 3) {   // (two faces resting on each other: rare)
+    for (int i = 3; i < RPK_BOXBOX_MAX; i++) {
+      if (i < n) {
+        const T depth = extra[i - 3].dist, cu = extra[i - 3].pos[0], cv = extra[i - 3].pos[1];
+        const T zc = h - (T)0.5 * depth;
+        RawCon<T> c;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { c.pos[k] = pr[k] + ur[k] * cu + vr[k] * cv + zr[k] * zc; c.n[k] = nrm[k]; }
+        c.dist = -depth;
+        extra[i - 3] = c;
       }
     }
   }

@@ -464,11 +464,50 @@ __global__ __launch_bounds__(128) void rp_task_raster_kernel(rp_task_raster_args
   }
   if (tid == 0) { a.song_len[slot] = Tn + nb; a.status[job] = 0; }
 }
+// rp_task_prestep (include/rp_task.h): 16 lanes per env walk its action row.
+template <typename T>
+__global__ __launch_bounds__(64) void rp_task_prestep_kernel(rp_task_prestep_args a) {
+  const int env = blockIdx.x * 4 + (int)(threadIdx.x >> 4), l = (int)(threadIdx.x & 15);
+  if (env >= a.n_envs) return;
+  const bool resetting = a.needs_reset[env] != 0;
+  if (l == 0) { a.active[env] = resetting ? 0 : 1; a.reset_mask[env] = resetting ? 1 : 0; }
+  const T* act = (const T*)a.action + (size_t)env * a.n_action;
+  const T *lo = (const T*)a.act_lo, *rng = (const T*)a.act_range;
+  for (int i = l; i < a.n_action; i += 16) {
+#pragma clang fp contract(off)   // (the wrapper's torch expression rounds after every operation)
+    T v = act[i];
+    if (lo) {
+      if (a.clip) v = fmin((T)1, fmax((T)-1, v));
+      v = lo[i] + (v + (T)1) * (T)0.5 * rng[i];   // (the wrapper's expression, term by term)
+    }
+    if (i == a.n_action - 1) ((T*)a.sustain_state)[env] = resetting ? (T)0 : v;
+    else if (!resetting) ((T*)a.ctrl)[(size_t)env * a.nu + a.hand_act[i]] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
 const char* rp_task_last_error(void) { return g_task_err.c_str(); }
+
+int rp_task_prestep(const rp_task_prestep_args* a, void* hip_stream) {
+  if (!a) { g_task_err = "rp_task_prestep: null args"; return -1; }
+  if (a->precision != 32 && a->precision != 64) { g_task_err = "rp_task_prestep: precision must be 32 or 64"; return -1; }
+  if (a->n_envs <= 0 || a->n_action < 1 || a->nu < a->n_action - 1) { g_task_err = "rp_task_prestep: bad sizes"; return -1; }
+  if (!a->action || !a->needs_reset || !a->hand_act || !a->ctrl || !a->sustain_state || !a->active || !a->reset_mask ||
+      (a->act_lo && !a->act_range)) {
+    g_task_err = "rp_task_prestep: null array pointer";
+    return -1;
+  }
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int nb = (a->n_envs + 3) / 4;   // (64 threads = 16 lanes per env x 4 envs)
+  if (a->precision == 32) hipLaunchKernelGGL(rp_task_prestep_kernel<float>, dim3(nb), dim3(64), 0, s, *a);
+  else hipLaunchKernelGGL(rp_task_prestep_kernel<double>, dim3(nb), dim3(64), 0, s, *a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { g_task_err = std::string("rp_task_prestep: ") + hipGetErrorString(e); return -2; }
+  return 0;
+}
 
 int rp_task_rewards(const rp_task_reward_args* a, void* hip_stream) {
   if (!a) { g_task_err = "rp_task_rewards: null args"; return -1; }

@@ -36,7 +36,7 @@ WARN_WORK_FULL = 16
 WARN_DENSE_FULL = 32
 
 EXPORTED_SYMBOLS = (
-    "rp_create", "rp_destroy", "rp_reset", "rp_set", "rp_get", "rp_step", "rp_forward",
+    "rp_create", "rp_destroy", "rp_reset", "rp_set", "rp_get", "rp_step", "rp_forward", "rp_step_masked",
     "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_set_lazy_position_stage", "rp_set_cost_ordered_launch", "rp_set_stream_slices", "rp_set_lean_solver", "rp_set_fused_substeps", "rp_get_fused_substeps", "rp_set_acc_sensors", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
     "rp_n_envs", "rp_dim",
     "rp_kernel_time", "rp_solver_kernel_time", "rp_solver_kernel_envs", "rp_solver_kernel_fused", "rp_profile", "rp_last_error",
@@ -78,6 +78,7 @@ def load_library(path: str = LIB_PATH):
     L.rp_get.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     L.rp_step.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     L.rp_forward.argtypes = [ctypes.c_void_p]
+    L.rp_step_masked.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     L.rp_set_solver_limits.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     L.rp_sync.argtypes = [ctypes.c_void_p]
     L.rp_set_solver_tolerance.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]
@@ -241,6 +242,11 @@ class BatchedPhysics:
 
     def forward(self):
         self._check(self._L.rp_forward(self._h))
+
+    def step_masked(self, n_substeps: int, key_trace, reset_mask):
+        """rp_step_masked: reset + forward of the envs `reset_mask` (uint8 device tensor [n_envs]) flags, then the
+        step of the envs the RP_ACTIVE mask selects (include/rp_engine.h)."""
+        self._check(self._L.rp_step_masked(self._h, int(n_substeps), _ptr(key_trace), _ptr(reset_mask)))
 
     def sync(self):
         self._check(self._L.rp_sync(self._h))

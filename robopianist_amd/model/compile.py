@@ -298,6 +298,8 @@ def compile_scene(scene: spec.Scene) -> Model:
     m["geom_vertnum"] = arr(geom["vertnum"], np.int32)
     m["mesh_vert"] = arr(mesh_vert, shape=(len(mesh_vert), 3))
     m["nmeshvert"] = len(mesh_vert)
+    from robopianist_amd.model import hull as _hull
+    _hull.attach_graphs(m)   # (hulls with many vertices: vertices on the hull + the vertex graph of the support walk)
     m["geom_contype"] = arr(geom["contype"], np.int32)
     m["geom_conaffinity"] = arr(geom["conaffinity"], np.int32)
     m["geom_condim"] = arr(geom["condim"], np.int32)

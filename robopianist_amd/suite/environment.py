@@ -99,19 +99,40 @@ class Environment:
         had just ended.  Device-side, no synchronisation."""
         self._needs_reset.logical_or_(mask.to(device=self._needs_reset.device, dtype=torch.bool))
 
-    def step(self, action) -> TimeStep:
+    def step_canonical(self, action, bounds, clip=False) -> TimeStep:
+        """step() for an action in [-1, 1] with the mapping onto the spec's bounds (`bounds` = (lo, hi - lo) device
+        tensors) folded into the pre-step launch: what CanonicalSpecWrapper.step does in front of step()."""
+        return self.step(action, _canonical=(bounds, clip))
+
+    def step(self, action, _canonical=None) -> TimeStep:
         """Fully asynchronous for n_envs > 1: resets are applied through device-side
-        masks, nothing is read back to the host."""
+        masks, nothing is read back to the host.  On the HIP engine with the standard task set an env step is
+        three C calls: rp_task_prestep, rp_step_masked, rp_task_advance."""
         phys, task = self._physics, self._task
         resetting = self._needs_reset
         if self._n_envs == 1 and bool(resetting.all()):
             return self.reset()  # dm_env: step after LAST == reset (reward None)
+        fused = task.fused_advance_for(phys) if hasattr(task, "fused_advance_for") else None
+        pre = task.fused_prestep_for(phys) if (fused is not None and hasattr(task, "fused_prestep_for")) else None
+        if pre is not None and not getattr(task, "needs_host_episode_setup", False):
+            action = torch.as_tensor(action, device=phys.device, dtype=phys.dtype).reshape(self._n_envs, -1)
+            if not action.is_contiguous():
+                action = action.contiguous()
+            mask = pre.run(action, resetting, *(_canonical if _canonical is not None else (None, False)))
+            phys.step_masked(self._n_sub_steps, self._key_trace, mask)
+            st, reward, discount, obs = task.fused_advance(phys, self._needs_reset)
+            return self._fresh(TimeStep(st, reward, discount, obs))
+        if _canonical is not None:
+            (lo, rng), clip = _canonical
+            action = torch.as_tensor(action, device=phys.device, dtype=phys.dtype)
+            if clip:
+                action = torch.clamp(action, -1.0, 1.0)
+            action = lo + (action + 1.0) * 0.5 * rng
         active = ~resetting
         # the action of an env that is being reset is discarded (dm_env): it must not leak into ctrl /
         # the sustain latch, which the FIRST observation reports as 0 after reset()
         action = torch.as_tensor(action, device=phys.device, dtype=phys.dtype).reshape(self._n_envs, -1)
         action = action.masked_fill(resetting[:, None], 0.0)   # (a NaN times zero would survive a product)
-        fused = task.fused_advance_for(phys) if hasattr(task, "fused_advance_for") else None
         if fused is not None:
             # HIP task layer (include/rp_task.h): the episode reset of the flagged envs, the
             # key state, after_step, observables, rewards, termination and the step types

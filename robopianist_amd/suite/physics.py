@@ -103,6 +103,11 @@ class TorchPhysics:
     def set_tree_offset(self, off):
         self._tree_offset.copy_(torch.as_tensor(off, dtype=self.dtype, device=self.device))
 
+    @property
+    def active_mask(self):
+        """The engine's RP_ACTIVE array (int32 [n_envs], zero-copy)."""
+        return self._active
+
     def set_active(self, mask: torch.Tensor):
         self._active.copy_(mask)   # (bool -> int32 in the copy kernel)
 
@@ -143,3 +148,8 @@ class TorchPhysics:
 
     def step(self, n_substeps: int, key_trace=None):
         self.engine.step(n_substeps, key_trace)
+
+    def step_masked(self, n_substeps: int, key_trace, reset_mask):
+        """One C call: reset + forward of the flagged envs, step of the active ones (rp_step_masked)."""
+        self._reset_mask = reset_mask  # keep alive until the kernels have run
+        self.engine.step_masked(n_substeps, key_trace, reset_mask)

@@ -119,6 +119,18 @@ class PianoWithOneShadowHand(two_hands.PianoWithShadowHands):
     def hand_side(self) -> str:
         return self._hand_side
 
+    def fused_prestep_for(self, physics):
+        """rp_task_prestep with this hand's actuators (include/rp_task.h)."""
+        if self.fused_advance_for(physics) is None:
+            return None
+        if getattr(self, "_fused_prestep", None) is None:
+            from robopianist_amd import task_kernels
+            hand_act = [int(x) for x in torch.as_tensor(self._act).reshape(-1).tolist()]
+            self._fused_prestep = task_kernels.FusedPrestep(
+                physics, n_envs=self._E, n_action=len(hand_act) + 1, hand_act=hand_act,
+                sustain_state=self.piano._sustain_state)
+        return self._fused_prestep
+
     # -- hooks ---------------------------------------------------------------------------
     def before_step(self, physics, action) -> None:
         """:194-197."""

@@ -576,6 +576,20 @@ class PianoWithShadowHands(base.PianoTask):
                 self._fused_advance.set_prefetch_buffers(self._next_ready, self._consumed)
         return self._fused_advance
 
+    def fused_prestep_for(self, physics):
+        """The one-launch replacement of everything between env.step(action) and physics.step() (include/rp_task.h:
+        rp_task_prestep), wherever the fused advance applies."""
+        if self.fused_advance_for(physics) is None:
+            return None
+        if getattr(self, "_fused_prestep", None) is None:
+            from robopianist_amd import task_kernels
+            hand_act = [int(x) for x in torch.as_tensor(self._rh_act).reshape(-1).tolist()] + \
+                       [int(x) for x in torch.as_tensor(self._lh_act).reshape(-1).tolist()]
+            self._fused_prestep = task_kernels.FusedPrestep(
+                physics, n_envs=self._E, n_action=len(hand_act) + 1, hand_act=hand_act,
+                sustain_state=self.piano._sustain_state)
+        return self._fused_prestep
+
     def set_evaluation_buffers(self, buffers) -> None:
         """(sums, count, hist, n_finished) of a MidiEvaluationWrapper, or None: the fused launch
         then performs the wrapper's reduction (include/rp_task.h `eval_*`)."""

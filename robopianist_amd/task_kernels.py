@@ -13,7 +13,7 @@ import torch
 
 from robopianist_amd import engine
 
-EXPORTED_SYMBOLS = ("rp_task_rewards", "rp_task_advance", "rp_task_rasterize", "rp_task_last_error")
+EXPORTED_SYMBOLS = ("rp_task_rewards", "rp_task_advance", "rp_task_prestep", "rp_task_rasterize", "rp_task_last_error")
 TERM_NAMES = ("key_press_reward", "sustain_reward", "energy_reward", "fingering_reward", "forearm_reward")
 
 
@@ -60,6 +60,17 @@ class AdvanceArgs(ctypes.Structure):
     ]
 
 
+class PrestepArgs(ctypes.Structure):
+    _fields_ = [
+        ("n_envs", ctypes.c_int), ("precision", ctypes.c_int), ("n_action", ctypes.c_int), ("nu", ctypes.c_int),
+        ("action", ctypes.c_void_p), ("act_lo", ctypes.c_void_p), ("act_range", ctypes.c_void_p),
+        ("clip", ctypes.c_int),
+        ("needs_reset", ctypes.c_void_p), ("hand_act", ctypes.c_void_p),
+        ("ctrl", ctypes.c_void_p), ("sustain_state", ctypes.c_void_p),
+        ("active", ctypes.c_void_p), ("reset_mask", ctypes.c_void_p),
+    ]
+
+
 class RasterArgs(ctypes.Structure):
     _fields_ = [
         ("n_jobs", ctypes.c_int), ("precision", ctypes.c_int),
@@ -83,6 +94,8 @@ def _lib():
         L.rp_task_rewards.restype = ctypes.c_int
         L.rp_task_advance.argtypes = [ctypes.POINTER(AdvanceArgs), ctypes.c_void_p]
         L.rp_task_advance.restype = ctypes.c_int
+        L.rp_task_prestep.argtypes = [ctypes.POINTER(PrestepArgs), ctypes.c_void_p]
+        L.rp_task_prestep.restype = ctypes.c_int
         L.rp_task_rasterize.argtypes = [ctypes.POINTER(RasterArgs), ctypes.c_void_p]
         L.rp_task_rasterize.restype = ctypes.c_int
         L.rp_task_last_error.restype = ctypes.c_char_p
@@ -247,6 +260,50 @@ class FusedAdvance:
         if rc != 0:
             raise engine.EngineError(self._L.rp_task_last_error().decode())
         return self.step_type, self._rw.total, self.discount, self._rw.terms
+
+
+class FusedPrestep:
+    """rp_task_prestep: canonical action -> spec bounds, reset bookkeeping (active / reset masks), hand actions ->
+    actuator ctrl, sustain -> the piano's latch: one launch before the physics (include/rp_task.h)."""
+
+    def __init__(self, physics, *, n_envs, n_action, hand_act, sustain_state):
+        self._L = _lib()
+        dev, dt = physics.device, physics.dtype
+        self._phys, self._E, self._dt = physics, int(n_envs), dt
+        self._hand_act = torch.as_tensor([int(x) for x in hand_act], dtype=torch.int32, device=dev).contiguous()
+        if int(self._hand_act.numel()) != int(n_action) - 1:
+            raise engine.EngineError("fused pre-step kernel: one actuator per hand action expected")
+        self.reset_mask = torch.zeros((self._E,), device=dev, dtype=torch.uint8)
+        a = PrestepArgs()
+        a.n_envs, a.precision = self._E, 64 if dt == torch.float64 else 32
+        a.n_action, a.nu = int(n_action), int(physics.ctrl.shape[1])
+        a.hand_act = self._hand_act.data_ptr()
+        a.ctrl = _chk(physics.ctrl, dt, (self._E, a.nu))
+        a.sustain_state = _chk(sustain_state, dt, (self._E, 1))
+        a.active = _chk(physics.active_mask, torch.int32, (self._E,))
+        a.reset_mask = self.reset_mask.data_ptr()
+        self._keep = (sustain_state,)
+        self._args = a
+        self._bounds = None
+
+    def run(self, action, needs_reset, bounds=None, clip=False):
+        """action [E, n_action] (device, the engine's dtype); bounds = (lo, hi - lo) device tensors for a canonical
+        action in [-1, 1], None for an action in the spec's units.  Returns the reset mask for step_masked."""
+        a, E = self._args, self._E
+        a.action = _chk(action, self._dt, (E, a.n_action))
+        a.needs_reset = _chk(needs_reset, torch.bool, (E,))
+        if bounds is None:
+            a.act_lo = a.act_range = None
+        else:
+            a.act_lo = _chk(bounds[0], self._dt, (a.n_action,)); a.act_range = _chk(bounds[1], self._dt, (a.n_action,))
+        a.clip = int(bool(clip))
+        self._bounds = bounds
+        with torch.cuda.device(self._phys.device):
+            stream = torch.cuda.current_stream(self._phys.device).cuda_stream
+            rc = self._L.rp_task_prestep(ctypes.byref(a), ctypes.c_void_p(stream))
+        if rc != 0:
+            raise engine.EngineError(self._L.rp_task_last_error().decode())
+        return self.reset_mask
 
 
 class Rasterizer:

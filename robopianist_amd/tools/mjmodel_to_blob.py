@@ -134,6 +134,8 @@ def model_from_npz(src) -> Tuple[mcompile.Model, np.ndarray]:
             m.geom_size[gi] = np.abs(v).max(axis=0)
     m["geom_vertadr"] = vertadr; m["geom_vertnum"] = vertnum
     m["mesh_vert"] = mesh_vert; m["nmeshvert"] = len(mesh_vert)
+    from robopianist_amd.model import hull as _hull
+    _hull.attach_graphs(m)   # (large hulls -- the real hand's forearm / wrist / palm / thumb meshes: the support walk's graph)
     # touch sensors: the radius of the site's sphere where a touch sensor is attached, else 0 [mjSENS_TOUCH = 0]
     touch = np.zeros(m.nsite)
     if "model_site_touch_radius" in d:

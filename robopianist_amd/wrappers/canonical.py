@@ -40,7 +40,15 @@ class CanonicalSpecWrapper:
         return lo + (a + 1.0) * 0.5 * rng
 
     def step(self, action):
-        return self._environment.step(self._convert(action))
+        env = self._environment
+        if type(env).__name__ == "Environment" and hasattr(env, "step_canonical"):
+            # directly around the batched environment: the mapping runs inside its pre-step launch
+            dev, dt = env.physics.device, env.physics.dtype
+            if getattr(dev, "type", None) == "cuda":
+                a = torch.as_tensor(action, device=dev, dtype=dt)
+                self._convert(a[:0])   # (fills the bounds cache)
+                return env.step_canonical(a, (self._bounds[2], self._bounds[3]), self._clip)
+        return env.step(self._convert(action))
 
     def reset(self):
         return self._environment.reset()

@@ -273,7 +273,7 @@ def test_fused_task_advance_matches_torch_hooks(wrong_press):
     T, E = actions.shape[0], 6
     fused, ref = _load_pair(E, 64, n_steps_lookahead=4, wrong_press_termination=wrong_press)
     fused.reset(); ref.reset()
-    assert fused.task.fused_advance_for(fused.physics) is not None
+    assert fused.task.fused_advance_for(fused.physics) is not None and fused.task.fused_prestep_for(fused.physics) is not None
     assert ref.task.fused_advance_for(ref.physics) is None
     rng = np.random.RandomState(5)
     dev = fused.physics.device
@@ -303,6 +303,10 @@ def test_fused_task_advance_matches_torch_hooks(wrong_press):
         for name in ("_activation", "_sustain_activation", "_state", "_normalized_state", "_sustain_state"):
             assert torch.equal(getattr(tf.piano, name), getattr(tr.piano, name)), f"piano.{name} @ {step}"
         assert torch.equal(fused._needs_reset, ref._needs_reset)
+        # the pre-step launch (rp_task_prestep: canonical action -> bounds, masks, ctrl scatter, sustain latch) and
+        # rp_step_masked against the wrapper's torch expression, the torch hooks and reset / forward / step
+        assert torch.equal(fused.physics.ctrl, ref.physics.ctrl), step
+        assert torch.equal(fused.physics.qpos, ref.physics.qpos) and torch.equal(fused.physics.qvel, ref.physics.qvel), step
         seen["first"] += int((ts_f.step_type == 0).sum())
         seen["last"] += int((ts_f.step_type == 2).sum())
         seen["zero_discount"] += int(((tf._discount == 0) & (ts_f.step_type == 2)).sum())
