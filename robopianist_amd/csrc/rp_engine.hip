@@ -233,6 +233,7 @@ struct Engine : EngineBase {
   uint8_t* d_mask = nullptr;
   bool trunk4 = false;  // every tree has a 4-link trunk: launch the specialised solver build
   bool mesh = false;    // the model has convex-hull geoms: position / sensor stages with MPR
+  bool graph = false;   // ... some of them with a vertex graph (more than 32 vertices): the MESH = 2 builds
   bool deep = false;    // a trunk of 5..8 links (more than two forearm dofs): the RPK_MAXD_DEEP builds
   bool lean = false;    // light envs are stepped by rp_lean_solver_kernel (rp_solver2.hpp), the others by the full build
   int lean_solver(int on) override {
@@ -398,12 +399,19 @@ struct Engine : EngineBase {
     if (b.has("eng_mesh_vert")) {
       PF(mesh_vert, "eng_mesh_vert"); PI(geom_vertadr, "eng_geom_vertadr"); PI(geom_vertnum, "eng_geom_vertnum");
       if (b.has("eng_geom_vertflip")) PI(geom_vertflip, "eng_geom_vertflip");
+      if (b.has("eng_geom_vertgraph")) PI(geom_vertgraph, "eng_geom_vertgraph");
       for (int t : b.i("eng_geom_type")) if (t == GEOM_MESH_) mesh = true;
     }
 #undef PF
 #undef PI
     M.ft = upF(ft);
     M.it = upI(it);
+    if (b.has("eng_hull_vert") && !b.f("eng_hull_vert").empty()) {
+      if (b.i("eng_hull_graph").size() != b.f("eng_hull_vert").size() / 3 * RPK_HULL_GRAPH_ROW) throw std::string("eng_hull_graph does not match eng_hull_vert");
+      M.hull_vert = upF(b.f("eng_hull_vert"));
+      M.hull_graph = upI(b.i("eng_hull_graph"));
+      graph = true;
+    }
     {
       auto q0 = b.f("qpos0");
       qpos0.assign(q0.begin(), q0.end());
@@ -498,7 +506,7 @@ struct Engine : EngineBase {
   int fused = getenv("RP_FUSED") ? atoi(getenv("RP_FUSED")) : 2;
   int fused_substeps(int on) override { fused = on < 0 ? 2 : (on > 2 ? 2 : on); return 0; }
   int fused_substeps_on() const override {
-    const bool capable = lean && !deep && sizeof(T) == 8;
+    const bool capable = lean && !deep && !graph && sizeof(T) == 8;
     return !capable ? 0 : (fused == 1 ? 1 : (fused == 2 && n_slices == 0 ? (auto_mode == 3 ? 1 : 2) : 0));
   }
   bool companion = !(getenv("RP_COMPANION") && getenv("RP_COMPANION")[0] == '0');   // (experiment: the full-capacity launch on the slice's own stream)
@@ -697,7 +705,7 @@ struct Engine : EngineBase {
     // half's launch (a few heavy envs still running, most SIMDs idle) is filled by the other half's
     // next kernel instead of waiting for a launch boundary.
     int want = n_slices;
-    const bool fused_capable = lean && !deep && sizeof(T) == 8;
+    const bool fused_capable = lean && !deep && !graph && sizeof(T) == 8;   // (no fused builds for scenes with graph hulls)
     bool fused_now = fused == 1 && fused_capable && mode == 0;
     if (n_slices == 0 && mode == 0 && !fused_now) {
       int cand[3], nc = 0;
@@ -763,7 +771,9 @@ struct Engine : EngineBase {
       RpState<T> ss = s;
       ss.env_base = base;
       auto launch_pos_on = [&](const RpState<T>& q, int k) {
-        if (deep && mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP, 1>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
+        if (deep && mesh && graph) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP, 2>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
+        else if (mesh && graph) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD, 2>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
+        else if (deep && mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP, 1>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
         else if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
         else if (mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD, 1>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
         else hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
@@ -865,7 +875,9 @@ struct Engine : EngineBase {
           sq.qpos = d_qpos_prev; sq.qvel = d_qvel_prev;
           sq.sens_torque = d_sens_torque; sq.sens_touch = d_sens_touch;
           sq.key_trace = nullptr; sq.prof = nullptr;
-          if (deep && mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 2, 0, RPK_MAXD_DEEP, 1>), dim3(cnt), dim3(64), 0, st, M, sq, B, -1, nsub);
+          if (deep && mesh && graph) hipLaunchKernelGGL((rp_stage_kernel<T, 2, 0, RPK_MAXD_DEEP, 2>), dim3(cnt), dim3(64), 0, st, M, sq, B, -1, nsub);
+          else if (mesh && graph) hipLaunchKernelGGL((rp_stage_kernel<T, 2, 0, RPK_MAXD, 2>), dim3(cnt), dim3(64), 0, st, M, sq, B, -1, nsub);
+          else if (deep && mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 2, 0, RPK_MAXD_DEEP, 1>), dim3(cnt), dim3(64), 0, st, M, sq, B, -1, nsub);
           else if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 2, 0, RPK_MAXD_DEEP>), dim3(cnt), dim3(64), 0, st, M, sq, B, -1, nsub);
           else if (mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 2, 0, RPK_MAXD, 1>), dim3(cnt), dim3(64), 0, st, M, sq, B, -1, nsub);
           else hipLaunchKernelGGL((rp_stage_kernel<T, 2>), dim3(cnt), dim3(64), 0, st, M, sq, B, -1, nsub);

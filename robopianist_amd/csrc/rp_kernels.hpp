@@ -1803,7 +1803,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       bool mpr = false, mpr_flip = false;
       CGeom<T> mpr_a, mpr_b;
       mpr_a.type = GEOM_BOX_; mpr_b.type = GEOM_BOX_; mpr_a.nvert = 0; mpr_b.nvert = 0; mpr_a.vadr = 0; mpr_b.vadr = 0;
-      mpr_a.flip = 0; mpr_b.flip = 0;
+      mpr_a.flip = 0; mpr_b.flip = 0; mpr_a.graph = 0; mpr_b.graph = 0;
       auto hull_of = [&](CGeom<T>& g, int type, int geom) {
         const bool hull = type == GEOM_MESH_ && geom >= 0;
         const int gi = geom >= 0 ? geom : 0;
@@ -1811,6 +1811,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         g.nvert = hull ? M.geom_vertnum()[gi] : 0;
         g.vadr = hull ? M.geom_vertadr()[gi] : 0;
         g.flip = hull ? M.geom_vertflip()[gi] : 0;
+        g.graph = (MESH > 1 && hull) ? M.geom_vertgraph()[gi] : 0;   // (MESH = 2: builds for scenes with graph hulls)
       };
       if (w < nproc) {
         ga = sm.work[w][0]; gb = sm.work[w][1];
@@ -1891,7 +1892,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         PROF(13);
         if (__ballot(mpr) != 0ull) {   // (the whole wave walks the portal refinement together)
           RawCon<T> rcm[1];
-          const int nm = convex_mpr_wave(rcm, &mpr_a, &mpr_b, M.mesh_vert(), mpr);
+          const int nm = convex_mpr_wave<T, (MESH > 1)>(rcm, &mpr_a, &mpr_b, M.mesh_vert(), M.hull_vert, M.hull_graph, mpr);
           if (mpr) {
             n = nm; rc[0] = rcm[0];
             if (mpr_flip) { rc[0].n[0] = -rc[0].n[0]; rc[0].n[1] = -rc[0].n[1]; rc[0].n[2] = -rc[0].n[2]; }

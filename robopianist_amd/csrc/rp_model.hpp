@@ -63,7 +63,8 @@
 #define GEOM_CAPSULE_ 3
 #define GEOM_BOX_ 6
 #define GEOM_MESH_ 7   // convex hull (vertices in the geom frame)
-#define RPK_MAXMESHV 320 // hull vertices of all hull geoms together
+#define RPK_MAXMESHV 320 // vertices of all SCANNED hulls together (hulls with a vertex graph: RpModel::hull_vert, any size)
+#define RPK_HULL_GRAPH_ROW 24
 
 // All model tables live in TWO device arrays (one of T, one of int) at compile-time
 // offsets (tables are padded to their maximum item counts).  A table access is then
@@ -106,7 +107,7 @@
   X(geom_pairmask, RPK_WAVE, 2) X(geom_iskeycap, RPK_WAVE, 1) \
   X(act_kind,     RPK_MAXACT, 1) X(act_lane, RPK_MAXACT, 2) X(act_ctrllimited, RPK_MAXACT, 1) \
   X(act_forcelimited, RPK_MAXACT, 1) X(site_link, RPK_WAVE, 1) X(link_bodylink, RPK_NL_DEEP, 1) \
-  X(geom_vertadr, RPK_WAVE, 1) X(geom_vertnum, RPK_WAVE, 1) X(geom_vertflip, RPK_WAVE, 1)
+  X(geom_vertadr, RPK_WAVE, 1) X(geom_vertnum, RPK_WAVE, 1) X(geom_vertflip, RPK_WAVE, 1) X(geom_vertgraph, RPK_WAVE, 1)
 
 struct RpLayout {
   enum : int {
@@ -141,6 +142,10 @@ struct RpModel {
   T timestep, gx, gy, gz, tolerance, ls_tolerance, meaninertia, key_zmax;
   const T* ft;    // RpLayout::F_* offsets
   const int* it;  // RpLayout::I_* offsets
+  // hulls with a vertex graph (model/hull.py: more than 32 vertices -- the real hand's forearm / wrist / palm / thumb
+  // meshes): vertices [n][3] and graph rows [n][RPK_HULL_GRAPH_ROW] = degree, neighbours; any size, may be null
+  const T* hull_vert;
+  const int* hull_graph;
 #define X(name, items, stride) \
   __device__ __forceinline__ const T* name() const { return ft + RpLayout::F_##name; }
   RPK_FTABLES(X)

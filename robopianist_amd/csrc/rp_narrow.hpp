@@ -443,7 +443,7 @@ __device__ RPK_BOXBOX_INLINE int box_box(RawCon<T>* out, RawCon<T>* extra, const
 // same vertex set scan it together through the SCALAR cache (uniform addresses), instead of every lane
 // pulling 26 vertices through its own vector loads (7 dependent round trips per support: the narrow
 // phase was 38 % of all cycles of an mj_step in hull-fingertip mode).
-template <typename T> struct CGeom { int type, nvert, vadr, flip; T pos[3], mat[9], size[3]; };   // flip: bit k = the stored vertex set is this hull's mirror image in coordinate k
+template <typename T> struct CGeom { int type, nvert, vadr, flip, graph; T pos[3], mat[9], size[3]; };   // flip: bit k = the stored vertex set is this hull's mirror image in coordinate k; graph: the set has a vertex graph (walked, not scanned)
 template <typename T> struct MPoint { T v[3], m[3]; };   // a point of B - A and the midpoint of its two witness points
 
 // support point of a capsule / box (hulls: hull_support_wave)
@@ -468,14 +468,41 @@ __device__ __forceinline__ void prim_support(const CGeom<T>& g, const T* d, T* o
 }
 // Support point of hull g in direction d for every lane with `need` (called by the whole wave).  First
 // maximum wins, as in the sequential scan.  mv = the model's hull vertex table (uniform pointer).
-template <typename T>
-__device__ __forceinline__ void hull_support_wave(const T* mv, const CGeom<T>& g, const T* d, const bool need, T* out) {
+// Hulls with a vertex graph (more than 32 vertices; hv / hg = RpModel::hull_vert / hull_graph): every such lane walks
+// ITS hull from vertex 0 to the neighbour with the largest dot product while that is strictly larger -- the oracle's
+// walk (geom_support), vertex for vertex.  Per-lane loads; the wave loops until its last walker has arrived.
+// (GRAPH = false: the builds for scenes without such hulls -- the benchmark's -- carry none of this: with the walk
+// compiled in, the position stage of the stand-in scene lost 4 %)
+template <typename T, bool GRAPH>
+__device__ __forceinline__ void hull_support_wave(const T* mv, const T* hv, const int* hg, const CGeom<T>& g, const T* d, const bool need_any, T* out) {
   T dl[3];
   matT_vec(dl, g.mat, d);
 #pragma unroll
   for (int k = 0; k < 3; k++) if ((g.flip >> k) & 1) dl[k] = -dl[k];
   T bv = (T)-1e30;
   int bi = 0;
+  const bool walk = GRAPH && need_any && g.graph != 0;
+  const bool need = need_any && !walk;
+  if (GRAPH && __ballot(walk) != 0ull) {
+    bool going = walk;
+    if (walk) { const T* v0 = hv + 3 * (size_t)g.vadr; bv = dl[0] * v0[0] + dl[1] * v0[1] + dl[2] * v0[2]; }
+    while (__ballot(going) != 0ull) {
+      if (going) {
+        const int* row = hg + (size_t)RPK_HULL_GRAPH_ROW * (g.vadr + bi);
+        const int deg = row[0];
+        int next = -1;
+        T nv_ = bv;
+        for (int j = 0; j < deg; j++) {
+          const int nb = row[1 + j];
+          const T* vn = hv + 3 * (size_t)(g.vadr + nb);
+          const T v = dl[0] * vn[0] + dl[1] * vn[1] + dl[2] * vn[2];
+          if (v > nv_) { nv_ = v; next = nb; }
+        }
+        if (next < 0) going = false;
+        else { bi = next; bv = nv_; }
+      }
+    }
+  }
   unsigned long long todo = __ballot(need);
   while (todo) {   // one trip per distinct vertex set among the lanes that need a support
     const int L0 = __ffsll((long long)todo) - 1;
@@ -500,8 +527,9 @@ __device__ __forceinline__ void hull_support_wave(const T* mv, const CGeom<T>& g
       }
     }
   }
-  const int a = need ? 3 * (g.vadr + bi) : 0;
-  T bl[3] = {mv[a], mv[a + 1], mv[a + 2]};
+  const int a = need_any ? 3 * (g.vadr + bi) : 0;
+  const T* src = (GRAPH && walk) ? hv : mv;
+  T bl[3] = {src[a], src[a + 1], src[a + 2]};
 #pragma unroll
   for (int k = 0; k < 3; k++) if ((g.flip >> k) & 1) bl[k] = -bl[k];
   T w[3];
@@ -525,9 +553,10 @@ template <typename T> __device__ __forceinline__ void portal_dir(T* dir, const M
 #ifndef RPK_MPR_INLINE
 #define RPK_MPR_INLINE __forceinline__   // (inlined: as a real call it cost the position stage 290 more scratch operations, 19 of them in the drain loop)
 #endif
-template <typename T>
+template <typename T, bool GRAPH>
 __device__ RPK_MPR_INLINE int convex_mpr_wave(RawCon<T>* __restrict__ out, const CGeom<T>* __restrict__ Ap,
-                                            const CGeom<T>* __restrict__ Bp, const T* __restrict__ mv, const bool active) {
+                                            const CGeom<T>* __restrict__ Bp, const T* __restrict__ mv, const T* __restrict__ hv,
+                                            const int* __restrict__ hg, const bool active) {
   // (the two geoms by value: re-reading them through the pointers on every trip -- scratch memory, a
   // dependent round trip each -- was most of this routine's time)
   const CGeom<T> A = *Ap, B = *Bp;
@@ -559,8 +588,8 @@ __device__ RPK_MPR_INLINE int convex_mpr_wave(RawCon<T>* __restrict__ out, const
       const T nd[3] = {-dir[0], -dir[1], -dir[2]};
       T p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
       const bool hA = run && A.type == GEOM_MESH_, hB = run && B.type == GEOM_MESH_;
-      if (__ballot(hA) != 0ull) hull_support_wave(mv, A, nd, hA, p1);
-      if (__ballot(hB) != 0ull) hull_support_wave(mv, B, dir, hB, p2);
+      if (__ballot(hA) != 0ull) hull_support_wave<T, GRAPH>(mv, hv, hg, A, nd, hA, p1);
+      if (__ballot(hB) != 0ull) hull_support_wave<T, GRAPH>(mv, hv, hg, B, dir, hB, p2);
       if (run && A.type != GEOM_MESH_) prim_support(A, nd, p1);
       if (run && B.type != GEOM_MESH_) prim_support(B, dir, p2);
 #pragma unroll

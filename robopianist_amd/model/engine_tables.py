@@ -387,7 +387,32 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
         # same stored set scan it together, rp_narrow.hpp: hull_support_wave; support(mirrored set, d) = mirror of
         # support(set, mirrored d), vertex order and with it "first maximum wins" unchanged)
         vadr, vnum, vflip, verts, seen = np.full(ng, -1, np.int32), np.zeros(ng, np.int32), np.zeros(ng, np.int32), [], []
+        # hulls with a vertex graph (more than 32 vertices, model/hull.py) live in tables of their own, of any size:
+        # their support function walks the graph with per-lane loads instead of scanning the set
+        vgraph, bverts, bgraph, bseen = np.zeros(ng, np.int32), [], [], []
+        has_graph = "geom_vertgraph" in m and "mesh_graph" in m
         for i, g in enumerate(egeoms):
+            if m.geom_type[g] == spec.GEOM_MESH and has_graph and int(m.geom_vertgraph[g]):
+                vnum[i] = int(m.geom_vertnum[g])
+                a = int(m.geom_vertadr[g])
+                v = np.asarray(m.mesh_vert[a:a + vnum[i]], float)
+                rows = np.asarray(m.mesh_graph[a:a + vnum[i]], np.int32)
+                hit = None
+                for adr, v0, r0 in bseen:   # identical / mirrored sets share one copy (same vertex order: same graph)
+                    for flip in (0, 1, 2, 4):
+                        sgn = np.array([-1.0 if flip & 1 else 1.0, -1.0 if flip & 2 else 1.0, -1.0 if flip & 4 else 1.0])
+                        if v0.shape == v.shape and np.array_equal(v0 * sgn, v) and np.array_equal(r0, rows):
+                            hit = (adr, flip)
+                            break
+                    if hit:
+                        break
+                if hit is None:
+                    hit = (len(bverts), 0)
+                    bseen.append((len(bverts), v, rows))
+                    bverts.extend(v.tolist()); bgraph.extend(rows.tolist())
+                vadr[i], vflip[i] = hit
+                vgraph[i] = 1
+                continue
             if m.geom_type[g] == spec.GEOM_MESH:
                 vnum[i] = int(m.geom_vertnum[g])
                 a = int(m.geom_vertadr[g])
@@ -409,9 +434,13 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
                     # a copy cannot win its strict comparison)
                     verts.extend([v[-1].tolist()] * ((-len(v)) % 8))
                 vadr[i], vflip[i] = hit
-        assert len(verts) <= 320, "too many hull vertices for the engine (RPK_MAXMESHV; sets are padded to multiples of 8)"
+        assert len(verts) <= 320, ("too many vertices of SCANNED hulls for the engine (RPK_MAXMESHV; sets are padded to "
+                                   "multiples of 8; hulls with a vertex graph are not counted)")
         t["eng_geom_vertadr"] = vadr; t["eng_geom_vertnum"] = vnum; t["eng_geom_vertflip"] = vflip
         t["eng_mesh_vert"] = np.asarray(verts, float).reshape(-1, 3)
+        t["eng_geom_vertgraph"] = vgraph
+        t["eng_hull_vert"] = np.asarray(bverts, float).reshape(-1, 3)
+        t["eng_hull_graph"] = np.asarray(bgraph, np.int32).reshape(-1, 24)
 
     # static pairs (neither geom is a key) and the capsule-x-all-keys family
     spairs = []

@@ -54,6 +54,33 @@ class SceneInfo:
     piano_size: tuple
 
 
+def _inscribed_hull(g: "spec.Geom", n: int):
+    """n points on the surface of the capsule / box-inscribed ellipsoid of geom g (its own frame): Fibonacci
+    directions, each mapped to the primitive's support point (capsule) or scaled by the half sizes (box)."""
+    i = np.arange(n) + 0.5
+    z = 1.0 - 2.0 * i / n
+    phi = np.pi * (1.0 + 5.0 ** 0.5) * i
+    r = np.sqrt(1.0 - z * z)
+    u = np.stack([r * np.cos(phi), r * np.sin(phi), z], 1)
+    if g.type == spec.GEOM_CAPSULE:
+        rad, half = float(g.size[0]), float(g.size[1])
+        p = rad * u
+        p[:, 2] += np.where(u[:, 2] >= 0, half, -half)
+    else:
+        p = u * np.asarray(list(g.size)[:3], float)[None, :]
+    return [tuple(float(x) for x in row) for row in p]
+
+
+def _meshify(root: "spec.Body", n: int) -> None:
+    def walk(b):
+        for k, g in enumerate(b.geoms):
+            if g.type in (spec.GEOM_CAPSULE, spec.GEOM_BOX):
+                b.geoms[k] = dataclasses.replace(g, type=spec.GEOM_MESH, vertices=_inscribed_hull(g, n))
+        for c in b.children:
+            walk(c)
+    walk(root)
+
+
 def build_scene(
     hands: Sequence[str] = ("right", "left"),
     add_piano_actuators: bool = False,
@@ -65,7 +92,13 @@ def build_scene(
     physics_timestep: float = PHYSICS_TIMESTEP,
     disable_hand_collisions: bool = False,
     root_sites: bool = False,
+    mesh_colliders: int = 0,
 ) -> SceneInfo:
+    """`mesh_colliders` = n > 0 (extension, for tests and the large-hull bench figure): every collider of the hands
+    becomes a convex hull of ~n vertices inscribed in its stand-in primitive -- what the reference's default hand looks
+    like to the collision pipeline, where forearm, wrist, palm, thumb links and fingertips all are `plastic_collision`
+    meshes collided through their hulls (/root/reference/robopianist/models/hands/shadow_hand.py:144-152,
+    shadow_hand_constants.py:52-53)."""
     if hands and not primitive_fingertip_collisions:
         warnings.warn(
             "The menagerie fingertip meshes are not available (mujoco_menagerie is not vendored in the "
@@ -109,6 +142,8 @@ def build_scene(
         if root_sites:
             # origin of the hand's root body, for HandObservables.position (hands/base.py:111-114)
             hb.root.sites.append(spec.Site(hb._n("forearm_origin_site"), (0.0, 0.0, 0.0)))
+        if mesh_colliders:
+            _meshify(hb.root, int(mesh_colliders))
         world.add(hb.root)
         scene.tendons.extend(hb.tendons)
         scene.actuators.extend(hb.actuators)

@@ -20,5 +20,5 @@ PY
 }
 for rep in 1 2; do
   (cd $ROOT/scratch/r4/ab_old && timeout 400 python bench.py $FLAGS > $R/old_$rep.json 2> $R/old_$rep.err); summ "old#$rep" $R/old_$rep.json
-  (cd $ROOT && timeout 400 python bench.py $FLAGS > $R/new_$rep.json 2> $R/new_$rep.err); summ "new#$rep" $R/new_$rep.json
+  (cd $ROOT && timeout 400 python bench.py $FLAGS --aux-large-hulls 0 > $R/new_$rep.json 2> $R/new_$rep.err); summ "new#$rep" $R/new_$rep.json
 done

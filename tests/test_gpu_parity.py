@@ -750,6 +750,24 @@ def test_teacher_forced_fp64_with_box_box_contacts(two_hand_scene):
     assert worst < 1e-9
 
 
+def test_teacher_forced_fp64_large_hull_colliders():
+    """The reference's default hand collides EVERY `plastic_collision` mesh (forearm, wrist, palm, thumb links,
+    fingertips) through its convex hull (/root/reference/robopianist/models/hands/shadow_hand.py:144-152,
+    shadow_hand_constants.py:52-53).  Stand-in: every hand collider a ~200-vertex hull (52 hulls, 10 400 vertices:
+    far beyond the 320 vertices the engine's scanned-hull table holds), supported by the walk over the hull's vertex
+    graph (model/hull.py) in the oracle and in the engine alike: same contact counts, 1e-9 per step."""
+    from robopianist_amd.model import scene
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=False, mesh_colliders=200)
+    m = si.model
+    assert int(m.geom_vertgraph.sum()) >= 40 and int(m.nmeshvert) > 5000
+    worst, maxcon = teacher_forced(si, 64, _replay_ctrl(si)[300:900])
+    print(f"large hulls: worst rel dv {worst:.2e}, max contacts {maxcon}")
+    assert maxcon >= 8
+    assert worst < 1e-9
+
+
 def pile_up(si, nsteps=120, seed=3, lo_dx=0.083, hi_dx=0.098):
     """Teacher-forced steps from hand-IN-hand poses: both forearms shifted towards each other until the hands
     interpenetrate (30 ... 64 contacts, most of them hand-hand, i.e. ~14 Jacobian entries each and one large dense

@@ -39,11 +39,14 @@ def _blob_entries(blob: bytes):
     return out
 
 
-@pytest.mark.parametrize("primitive", [True, False])
+@pytest.mark.parametrize("primitive", [True, False, "large hulls"])
 def test_importer_round_trip_on_the_standin(tmp_path, primitive):
+    """(third case: every hand collider a 200-vertex convex hull -- what a dump of the real hand carries, where forearm,
+    wrist, palm, thumb links and fingertips all are meshes; the importer rebuilds the vertex graphs of the support walk)"""
     from robopianist_amd import engine
     from robopianist_amd.tools import mjmodel_to_blob as imp
-    si = _standin(primitive_fingertip_collisions=primitive)
+    si = _standin(primitive_fingertip_collisions=False, mesh_colliders=200) if primitive == "large hulls" else \
+        _standin(primitive_fingertip_collisions=primitive)
     path = os.path.join(tmp_path, "standin.npz")
     np.savez_compressed(path, **imp.npz_from_model(si.model))
     m2, keys = imp.model_from_npz(path)

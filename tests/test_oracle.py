@@ -605,3 +605,42 @@ def test_hull_replay_chaos_control_and_tolerance_free_mpr_termination():
     mc, blobc, ctrlc = build(True)
     cap = [r["max_rel_qpos_error"] for r in rp_oracle.chaos_control(mc, blobc, ctrlc, seeds=(0, 1), eps0=1e-15)]
     assert max(cap) < 1e-4, cap
+
+
+def test_hull_support_walk_finds_the_scans_vertex():
+    """Large hulls (more than 32 vertices) are supported by a walk over their vertex graph (model/hull.py,
+    rp_oracle.c: geom_support): on a convex polytope the walk ends at the vertex a full scan finds, so the contact of
+    a 300-vertex hull resting on a box equals the one computed with the graph switched off."""
+    from robopianist_amd.model import spec
+    i = np.arange(300) + 0.5
+    z = 1.0 - 2.0 * i / 300
+    phi = np.pi * (1.0 + 5.0 ** 0.5) * i
+    r = np.sqrt(1.0 - z * z)
+    verts = np.stack([0.03 * r * np.cos(phi), 0.02 * r * np.sin(phi), 0.015 * z], 1)
+    def build():
+        world = spec.Body(name="world")
+        world.geoms.append(spec.Geom("floor", spec.GEOM_BOX, (0.05, 0.05, 0.01), pos=(0, 0, 0.01)))
+        top = spec.Body(name="top", pos=(0, 0, 0.05), mass=0.1, inertia=(1e-4, 1e-4, 1e-4),
+                        joints=[spec.Joint("z", type=spec.JNT_SLIDE, axis=(0, 0, 1), damping=0.5),
+                                spec.Joint("rx", type=spec.JNT_HINGE, axis=(1, 0, 0), damping=0.01),
+                                spec.Joint("ry", type=spec.JNT_HINGE, axis=(0, 1, 0), damping=0.01)],
+                        geoms=[spec.Geom("hull", spec.GEOM_MESH, (0, 0, 0), vertices=verts.tolist())])
+        world.add(top)
+        return mc.compile_scene(spec.Scene(world=world))
+    m = build()
+    o = Oracle(m, mc.to_blob(m))
+    assert int(m.geom_vertgraph.sum()) == 1 and int(m.mesh_graph[:, 0].max()) <= 23 and int(m.nmeshvert) == 300
+    m2 = build()
+    m2["geom_vertgraph"] = np.zeros_like(m2["geom_vertgraph"])      # same hull, scanned
+    o2 = Oracle(m2, mc.to_blob(m2))
+    rng = np.random.default_rng(0)
+    hits = 0
+    for _ in range(60):
+        q = np.array([rng.uniform(-0.03, -0.005), rng.uniform(-3, 3), rng.uniform(-3, 3)])
+        for oo in (o, o2):
+            oo.qpos[:] = q; oo.forward()
+        assert o.ncon == o2.ncon
+        if o.ncon:
+            np.testing.assert_allclose(o.contact.reshape(-1, 16)[:, :7], o2.contact.reshape(-1, 16)[:, :7], rtol=0, atol=1e-12)
+            hits += 1
+    assert hits >= 20
