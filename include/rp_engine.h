@@ -57,7 +57,7 @@ typedef enum {
                            (key dofs: 0).  Needs rp_set_acc_sensors(e, 1). */
   RP_ENV_COST = 18,     /* [E] int32  shader-clock cycles >> 8 of the env's last solver-stage wave (diagnostic; the
                            predictor of rp_set_cost_ordered_launch) */
-  RP_DEBUG_MASS_ROWS = 19, /* [E][52 or 60][10 or 14] hand-over: row i = M[link i][its ancestors by depth] (tests) */
+  RP_DEBUG_MASS_ROWS = 19, /* [E][rm_rows][rm_cols] (rp_dim; 52 x 10, deep builds 60 x 14) hand-over: row i = M[link i][its ancestors by depth] (tests) */
   RP_DEBUG_HANDOVER_HDR = 20, /* [E][8] int32 hand-over header of the last position stage: contacts, touched keys,
                            dirty-row mask lo / hi, contact Jacobian entries, max entries per contact (diagnostics) */
   RP_SENSOR_TOUCH = 17  /* [E][nsite] `touch` sensors (sum of the normal forces of the contacts whose force ray
@@ -68,8 +68,8 @@ typedef enum {
 #define RP_MAX_CONTACTS 64
 
 #define RP_WARN_BADSTATE 1     /* NaN / |q|>1e10 in qpos or qvel */
-#define RP_WARN_CONTACT_FULL 2 /* more than 32 simultaneous contacts (or 256 contact Jacobian
-                                  entries; 240 in the fp32 build) in one env; the deepest contacts are kept */
+#define RP_WARN_CONTACT_FULL 2 /* more than 64 simultaneous contacts or 640 contact Jacobian entries (rpk: RpCaps; the
+                                  fp32 build: 32 / 240) in one env; the deepest contacts are kept */
 #define RP_WARN_HESSIAN 4      /* non-positive pivot in the Newton Hessian */
 #define RP_WARN_KEYSLOT_FULL 8 /* more simultaneously touched keys than solver slots */
 #define RP_WARN_WORK_FULL 16   /* narrow-phase work list overflow */
@@ -136,8 +136,8 @@ int rp_set_lazy_position_stage(rp_engine* e, int on);
 int rp_set_cost_ordered_launch(rp_engine* e, int on);
 /* Capacity classes of the solver stage (on by default for the fp64 engine on scenes with <= 2 forearm dofs per
  * hand; RP_LEAN=0 in the environment turns the default off).  on: envs whose constraint system of the substep
- * fits the light class (<= 24 contacts, <= 160 contact Jacobian entries, <= 36 cross-coupled rows, <= 12 touched
- * keys) are stepped by the lean build of the solver stage (two waves per SIMD), the others by the full-capacity
+ * fits the light class (rpk::LeanCaps: <= 24 contacts, <= 184 contact Jacobian entries, <= 36 cross-coupled rows,
+ * <= 12 touched keys) are stepped by the lean build of the solver stage (two waves per SIMD), the others by the full-capacity
  * build; results do not depend on the class to more than rounding.  No counterpart in the reference (MuJoCo
  * allocates its constraint arrays per step).  on > 1 (tests): as 1, with the light class further restricted to
  * envs with at most `on` contact Jacobian entries, so that small scenes exercise both classes. */

@@ -509,7 +509,21 @@ struct Engine : EngineBase {
     const bool capable = lean && !deep && !graph && sizeof(T) == 8;
     return !capable ? 0 : (fused == 1 ? 1 : (fused == 2 && n_slices == 0 ? (auto_mode == 3 ? 1 : 2) : 0));
   }
+  bool split_heavy_pos = !(getenv("RP_SPLIT_HEAVY_POS") && getenv("RP_SPLIT_HEAVY_POS")[0] == '0');   // (experiment switch)
   bool companion = !(getenv("RP_COMPANION") && getenv("RP_COMPANION")[0] == '0');   // (experiment: the full-capacity launch on the slice's own stream)
+  // (Experiment, RP_HEAVY_PRIORITY=1: the companion stream at the highest priority the device offers.  The idea: the
+  // full-capacity launch and the lean one become ready together, and whichever is dispatched first takes the machine
+  // -- 2048 lean workgroups fill every SIMD, and a full-capacity workgroup, a whole SIMD's registers, then waits for
+  // both waves of some SIMD to retire, so the heavy envs START when the lean launch ends.  Measured: no effect on the
+  // dispatch order -- configs 3 / 4 447 / 580 k env-steps/s either way, config 2 -0.6 %.  Off.)
+  hipError_t create_companion_stream(hipStream_t* s) {
+    int least = 0, greatest = 0;
+    const bool prio = getenv("RP_HEAVY_PRIORITY") && getenv("RP_HEAVY_PRIORITY")[0] == '1';
+    if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+      return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+    (void)hipGetLastError();
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  }
   // Threads per residue class of rp_order_kernel: two envs per thread.  (A 512-thread workgroup needs a whole
   // idle CU -- with both stage kernels at two waves per SIMD it waited ~60 us for one on every substep of a
   // 2048-env slice -- while a single wave takes too long over 512 envs.  Measured: 2048-env slices 64 / 128 /
@@ -770,6 +784,14 @@ struct Engine : EngineBase {
       const int base = bound(sl), cnt = bound(sl + 1) - base;
       RpState<T> ss = s;
       ss.env_base = base;
+      auto launch_pos_listed = [&](const RpState<T>& q, int k, int grid, hipStream_t str) {
+        if (deep && mesh && graph) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP, 2>), dim3(grid), dim3(64), 0, str, M, q, B, k, nsub);
+        else if (mesh && graph) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD, 2>), dim3(grid), dim3(64), 0, str, M, q, B, k, nsub);
+        else if (deep && mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP, 1>), dim3(grid), dim3(64), 0, str, M, q, B, k, nsub);
+        else if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP>), dim3(grid), dim3(64), 0, str, M, q, B, k, nsub);
+        else if (mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD, 1>), dim3(grid), dim3(64), 0, str, M, q, B, k, nsub);
+        else hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(grid), dim3(64), 0, str, M, q, B, k, nsub);
+      };
       auto launch_pos_on = [&](const RpState<T>& q, int k) {
         if (deep && mesh && graph) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP, 2>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
         else if (mesh && graph) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD, 2>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
@@ -843,7 +865,7 @@ struct Engine : EngineBase {
         // the light ones) -- side by side: the full-capacity launch goes to the slice's companion stream
         hipStream_t hs = st;
         if (lean && !capturing && companion) {
-          if (!hstream[sl] && (hipStreamCreateWithFlags(&hstream[sl], hipStreamNonBlocking) != hipSuccess ||
+          if (!hstream[sl] && (create_companion_stream(&hstream[sl]) != hipSuccess ||
                                hipEventCreateWithFlags(&ev_hfork[sl], hipEventDisableTiming) != hipSuccess ||
                                hipEventCreateWithFlags(&ev_hjoin[sl], hipEventDisableTiming) != hipSuccess)) {
             (void)hipGetLastError(); hstream[sl] = nullptr;
@@ -859,14 +881,19 @@ struct Engine : EngineBase {
         if (listed) {
           sh.heavy_list = d_heavy + base; sh.heavy_cnt = d_heavy_cnt + 2 * sl; sh.heavy_done = d_heavy_cnt + 2 * sl + 1;
           sh.heavy_peak = capturing ? nullptr : d_heavy_peak + sl;
+          sh.heavy_keep = (split_heavy_pos && hs != st && !sense) ? 1 : 0;
           hgrid = capturing ? (cnt < kHeavyGrid ? cnt : kHeavyGrid) : (k == 0 ? (hgrid_step = heavy_grid_for(sl, cnt)) : hgrid_step);
         }
         if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 0, RPK_MAXD_DEEP>), dim3(hgrid), dim3(64), 0, hs, M, sh, B, k, nsub);
         else if (trunk4) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 4>), dim3(hgrid), dim3(64), 0, hs, M, sh, B, k, nsub);
         else hipLaunchKernelGGL((rp_stage_kernel<T, 1>), dim3(hgrid), dim3(64), 0, hs, M, sh, B, k, nsub);
-        if (hs != st) HIP_OK(hipEventRecord(ev_hjoin[sl], hs));
+        // ... and, except at a substep the sensor stage follows, the heavy envs' position / velocity stage goes with
+        // them: the slice's own position launch then skips them and no longer waits for the slowest heavy solve
+        // (config 3: 0.27 ms of every 0.81 ms substep); the streams join after it, in front of the next order pass
+        const bool split_pos = split_heavy_pos && listed && hs != st && !sense;
+        if (hs != st && !split_pos) HIP_OK(hipEventRecord(ev_hjoin[sl], hs));
         if (lean) hipLaunchKernelGGL((rp_lean_solver_kernel<T>), dim3(cnt), dim3(64), 0, st, M, ss, B);
-        if (hs != st) HIP_OK(hipStreamWaitEvent(st, ev_hjoin[sl], 0));
+        if (hs != st && !split_pos) HIP_OK(hipStreamWaitEvent(st, ev_hjoin[sl], 0));
         if (probe) HIP_OK(hipEventRecord(sv1[slot], st));
         if (sense) {
           // sensor stage: position / velocity stage of the saved state + mj_rnePostConstraint with the
@@ -882,7 +909,18 @@ struct Engine : EngineBase {
           else if (mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 2, 0, RPK_MAXD, 1>), dim3(cnt), dim3(64), 0, st, M, sq, B, -1, nsub);
           else hipLaunchKernelGGL((rp_stage_kernel<T, 2>), dim3(cnt), dim3(64), 0, st, M, sq, B, -1, nsub);
         }
-        launch_pos_on(ss, k);
+        if (split_pos) {
+          RpState<T> sp = sh;              // (the list; walked in list order)
+          sp.order = nullptr; sp.heavy_keep = 0;
+          launch_pos_listed(sp, k, hgrid, hs);
+          HIP_OK(hipEventRecord(ev_hjoin[sl], hs));
+          RpState<T> sm_ = ss;
+          sm_.skip_heavy = 1;
+          launch_pos_on(sm_, k);
+          HIP_OK(hipStreamWaitEvent(st, ev_hjoin[sl], 0));
+        } else {
+          launch_pos_on(ss, k);
+        }
       }
     }
     for (int i = 1; i < nsl; i++) { HIP_OK(hipEventRecord(ev_join[i], xstream[i])); HIP_OK(hipStreamWaitEvent(stream, ev_join[i], 0)); }

@@ -143,6 +143,9 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
   if constexpr (MODE == 1) {
     if (S.lean && B.hdr[env * 8 + 6] == 1) return;   // a light env: rp_lean_solver_kernel steps it
   }
+  if constexpr (MODE == 0) {
+    if (S.skip_heavy && B.hdr[env * 8 + 6] != 1) return;   // (its position stage follows its solve on the companion stream)
+  }
   const int env_active = S.active ? S.active[env] : 1;  // tested after the prologue loads are in flight
   Smem<T, MODE, MD>& sm = rp_smem<Smem<T, MODE, MD>, EXT>(ext);
   constexpr int TC = MD > 9 ? 8 : 4;            // trunk links the chain-blocked solver holds
@@ -1502,6 +1505,12 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     // register allocation spilled inside the CRB / RNE level loops -- 207 spilled VGPRs against 144 -- and the
     // step got 2.8 % slower although candidate generation itself went from 40 k to 26 k cycles.)
     int kcount = 0;
+    // (hull builds walk the key lanes over the near geoms: see above; RPK_MESH_KEYWALK = experiment: the window walk there too)
+#ifdef RPK_MESH_KEYWALK
+    constexpr bool KEYLANES = false;
+#else
+    constexpr bool KEYLANES = MESH != 0;
+#endif
     unsigned long long remK0 = 0, remK1 = 0;   // hull builds: the capsules near this lane's two keys
     {
       // extents along world x, y, z of MY geom: a capsule's own axis-aligned extents |axis| * half length +
@@ -1523,7 +1532,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         }
       }
       const bool near_me = nk > 0 && gkc && (fcz - gez <= (float)M.key_zmax);
-      if constexpr (MESH != 0) {
+      if constexpr (KEYLANES) {
         unsigned long long near_mask = __ballot(near_me);
         float kx[2], kz[2], kpx[2], kpy[2], ktop[2], khx_[2], khy_[2], krb_[2];
 #pragma unroll
@@ -1614,7 +1623,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     PROF(12);
 #ifndef RPK_MARK
     if (S.prof && env == 0) {
-      int ca = (int)wave_sum((float)__popcll(remA)), ck = MESH ? (int)wave_sum((float)(__popcll(remK0) + __popcll(remK1))) : kcount;
+      int ca = (int)wave_sum((float)__popcll(remA)), ck = KEYLANES ? (int)wave_sum((float)(__popcll(remK0) + __popcll(remK1))) : kcount;
       if (lane == 0) { sm.prof[28] += ca; sm.prof[29] += ck; }
     }
 #endif
@@ -1626,7 +1635,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       // narrow phase below is the register-hungriest part of this kernel, and in one loop with it the
       // allocator spilled the drain loop's own variables -- every round then paid scratch round trips
       // (measured: 34 k cycles per mj_step in the capsule builds, 163 k in the hull builds)
-      while (gen_phase < (MESH ? 3 : 2) && nwork < 64) {
+      while (gen_phase < (KEYLANES ? 3 : 2) && nwork < 64) {
       // ---- one drain round: every lane contributes at most one candidate
       {
         // Geom-geom candidates are COMPACTED first: the sphere-overlap hits sit unevenly in the lanes (a palm box
@@ -1657,7 +1666,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
           WSYNC();
         }
         const unsigned long long rem = gen_phase == 1 ? remK0 : remK1;   // (hull builds)
-        bool has = gen_phase == 0 ? lpos + lane < lcount : (MESH ? rem != 0ull : kpos_ + lane < kcount);
+        bool has = gen_phase == 0 ? lpos + lane < lcount : (KEYLANES ? rem != 0ull : kpos_ + lane < kcount);
 #ifndef RPK_MARK
         if (S.prof && env == 0 && lane == 0) sm.prof[26] += 1;   // (diagnostic: drain rounds)
 #endif
@@ -1669,7 +1678,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
             const int item = has ? (int)sm.glist[lpos + lane] : 0;
             a = item >> 6; bit = item & 63;
             lpos += 64;
-          } else if constexpr (MESH != 0) {
+          } else if constexpr (KEYLANES) {
             bit = has ? __ffsll((long long)rem) - 1 : 0;
             const unsigned long long rest = rem & (rem - 1);
             if (gen_phase == 1) remK0 = rest; else remK1 = rest;
@@ -2584,7 +2593,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
                                                      int nsub) {
   // One env per workgroup -- or, for the full-capacity solver stage next to the lean one, a small grid walking
   // the compacted list of the envs outside the light class (RpState::heavy_list).
-  const bool listed = MODE == 1 && S.heavy_list != nullptr;
+  const bool listed = (MODE == 1 || MODE == 0) && S.heavy_list != nullptr;
   const int n = listed ? *(volatile const int*)S.heavy_cnt : (int)gridDim.x;
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     const int env = listed ? S.heavy_list[i] : (S.order ? S.order[S.env_base + i] : S.env_base + i);
@@ -2592,8 +2601,9 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
     if (!listed) break;
     __syncthreads();
   }
-  if constexpr (MODE == 1) {
-    if (listed && threadIdx.x == 0) {
+  if constexpr (MODE == 1 || MODE == 0) {
+    // (the list's last reader clears it: this stage, or the position stage that follows it on the same stream)
+    if (listed && !S.heavy_keep && threadIdx.x == 0) {
       __threadfence();
       if (atomicAdd(S.heavy_done, 1) == (int)gridDim.x - 1) {
         if (S.heavy_peak && n > *S.heavy_peak) *S.heavy_peak = n;

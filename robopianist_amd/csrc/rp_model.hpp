@@ -191,6 +191,11 @@ struct RpState {
   int* heavy_list;
   int *heavy_cnt, *heavy_done;   // entries in the list; finished workgroups (the last one clears both)
   int* heavy_peak;               // may be null: the longest list seen (the host sizes that stage's grid from it, one step late)
+  // The position / velocity stage of a substep may run as two launches: the slice's launch skips the envs outside the
+  // light class (skip_heavy: hdr[6] of the substep just solved), a small grid on the companion stream walks the list
+  // right behind the full-capacity solver stage (which then leaves the list alone: heavy_keep) -- the light envs'
+  // position stage no longer waits for the slowest heavy solve.
+  int skip_heavy, heavy_keep;
   // fused substeps (rp_fused_steps_kernel): may be null -- where the state before the last substep's solver
   // stage goes (the acceleration-stage sensors belong to that state)
   T *qpos_prev, *qvel_prev;
