@@ -510,6 +510,7 @@ struct Engine : EngineBase {
     return !capable ? 0 : (fused == 1 ? 1 : (fused == 2 && n_slices == 0 ? (auto_mode == 3 ? 1 : 2) : 0));
   }
   bool split_heavy_pos = !(getenv("RP_SPLIT_HEAVY_POS") && getenv("RP_SPLIT_HEAVY_POS")[0] == '0');   // (experiment switch)
+  const bool x_no_heavy = getenv("RP_X_NO_HEAVY") && getenv("RP_X_NO_HEAVY")[0] == '1';
   bool companion = !(getenv("RP_COMPANION") && getenv("RP_COMPANION")[0] == '0');   // (experiment: the full-capacity launch on the slice's own stream)
   // (Experiment, RP_HEAVY_PRIORITY=1: the companion stream at the highest priority the device offers.  The idea: the
   // full-capacity launch and the lean one become ready together, and whichever is dispatched first takes the machine
@@ -785,12 +786,10 @@ struct Engine : EngineBase {
       RpState<T> ss = s;
       ss.env_base = base;
       auto launch_pos_listed = [&](const RpState<T>& q, int k, int grid, hipStream_t str) {
-        if (deep && mesh && graph) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP, 2>), dim3(grid), dim3(64), 0, str, M, q, B, k, nsub);
-        else if (mesh && graph) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD, 2>), dim3(grid), dim3(64), 0, str, M, q, B, k, nsub);
-        else if (deep && mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP, 1>), dim3(grid), dim3(64), 0, str, M, q, B, k, nsub);
-        else if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP>), dim3(grid), dim3(64), 0, str, M, q, B, k, nsub);
-        else if (mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD, 1>), dim3(grid), dim3(64), 0, str, M, q, B, k, nsub);
-        else hipLaunchKernelGGL((rp_stage_kernel<T, 0>), dim3(grid), dim3(64), 0, str, M, q, B, k, nsub);
+        if constexpr (sizeof(T) == 8) {   // (the light class exists in the fp64 default builds only)
+          if (mesh) hipLaunchKernelGGL((rp_pos_list_kernel<T, 1>), dim3(grid), dim3(64), 0, str, M, q, B, k, nsub);
+          else hipLaunchKernelGGL((rp_pos_list_kernel<T, 0>), dim3(grid), dim3(64), 0, str, M, q, B, k, nsub);
+        }
       };
       auto launch_pos_on = [&](const RpState<T>& q, int k) {
         if (deep && mesh && graph) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP, 2>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
@@ -846,6 +845,7 @@ struct Engine : EngineBase {
       // ... then n_sub x (mj_step2; mj_step1): dm_control's legacy order.  Two kernels per substep instead
       // of one fused launch: each half fits in registers, the hand-over (RpStage) stays in L2 / Infinity Cache.
       int hgrid_step = 0;   // (the full-capacity stage's grid: one choice per step and slice)
+      bool split_step = false;
       for (int k = 0; k < nsub; k++) {
         const bool probe = timeit && sl == 0 && k == (int)(step_calls % (unsigned)nsub) && !ev_trial[slot];
         const bool sense = sensors_on && k == nsub - 1;
@@ -881,16 +881,22 @@ struct Engine : EngineBase {
         if (listed) {
           sh.heavy_list = d_heavy + base; sh.heavy_cnt = d_heavy_cnt + 2 * sl; sh.heavy_done = d_heavy_cnt + 2 * sl + 1;
           sh.heavy_peak = capturing ? nullptr : d_heavy_peak + sl;
-          sh.heavy_keep = (split_heavy_pos && hs != st && !sense) ? 1 : 0;
+          // (the split pays when the list is long: config 3 446 -> 455 k; on a batch whose lists are empty the extra
+          // launch and the later join cost 1-4 %: config 2 657 -> 632 ... 651 k -- so it follows the same lagged estimate)
           hgrid = capturing ? (cnt < kHeavyGrid ? cnt : kHeavyGrid) : (k == 0 ? (hgrid_step = heavy_grid_for(sl, cnt)) : hgrid_step);
+          split_step = split_heavy_pos && hs != st && !deep && !graph && sizeof(T) == 8 && heavy_est[sl] >= 4.0;
+          sh.heavy_keep = (split_step && !sense) ? 1 : 0;
         }
-        if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 0, RPK_MAXD_DEEP>), dim3(hgrid), dim3(64), 0, hs, M, sh, B, k, nsub);
+        // (RP_X_NO_HEAVY=1: MEASUREMENT ONLY -- the full-capacity launch is suppressed, envs outside the light class are
+        // not stepped at all: what the launch costs a batch whose lists are empty)
+        if (x_no_heavy && listed) { /* nothing */ }
+        else if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 0, RPK_MAXD_DEEP>), dim3(hgrid), dim3(64), 0, hs, M, sh, B, k, nsub);
         else if (trunk4) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 4>), dim3(hgrid), dim3(64), 0, hs, M, sh, B, k, nsub);
         else hipLaunchKernelGGL((rp_stage_kernel<T, 1>), dim3(hgrid), dim3(64), 0, hs, M, sh, B, k, nsub);
         // ... and, except at a substep the sensor stage follows, the heavy envs' position / velocity stage goes with
         // them: the slice's own position launch then skips them and no longer waits for the slowest heavy solve
         // (config 3: 0.27 ms of every 0.81 ms substep); the streams join after it, in front of the next order pass
-        const bool split_pos = split_heavy_pos && listed && hs != st && !sense;
+        const bool split_pos = split_step && listed && !sense;
         if (hs != st && !split_pos) HIP_OK(hipEventRecord(ev_hjoin[sl], hs));
         if (lean) hipLaunchKernelGGL((rp_lean_solver_kernel<T>), dim3(cnt), dim3(64), 0, st, M, ss, B);
         if (hs != st && !split_pos) HIP_OK(hipStreamWaitEvent(st, ev_hjoin[sl], 0));

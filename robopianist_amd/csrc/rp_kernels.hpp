@@ -2593,7 +2593,7 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
                                                      int nsub) {
   // One env per workgroup -- or, for the full-capacity solver stage next to the lean one, a small grid walking
   // the compacted list of the envs outside the light class (RpState::heavy_list).
-  const bool listed = (MODE == 1 || MODE == 0) && S.heavy_list != nullptr;
+  const bool listed = MODE == 1 && S.heavy_list != nullptr;
   const int n = listed ? *(volatile const int*)S.heavy_cnt : (int)gridDim.x;
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     const int env = listed ? S.heavy_list[i] : (S.order ? S.order[S.env_base + i] : S.env_base + i);
@@ -2601,14 +2601,37 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
     if (!listed) break;
     __syncthreads();
   }
-  if constexpr (MODE == 1 || MODE == 0) {
-    // (the list's last reader clears it: this stage, or the position stage that follows it on the same stream)
+  if constexpr (MODE == 1) {
+    // (the list's last reader clears it: this stage, or the position stage that follows it on the same stream,
+    // rp_pos_list_kernel)
     if (listed && !S.heavy_keep && threadIdx.x == 0) {
       __threadfence();
       if (atomicAdd(S.heavy_done, 1) == (int)gridDim.x - 1) {
         if (S.heavy_peak && n > *S.heavy_peak) *S.heavy_peak = n;
         *S.heavy_cnt = 0; *S.heavy_done = 0; __threadfence();
       }
+    }
+  }
+}
+
+// The position / velocity stage of the envs on the compacted list (the envs outside the light class), on the companion
+// stream right behind their full-capacity solver stage; the slice's own position launch skips them (RpState::skip_heavy).
+// A kernel of its own: with this loop around the body, rp_stage_kernel<T, 0> itself -- the launch every env of the
+// benchmark goes through -- spilled 500 registers instead of 340 (loop-invariant per-lane state hoisted out of the loop).
+template <typename T, int MESH>
+__global__ __launch_bounds__(64, 2) void rp_pos_list_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep, int nsub) {
+  const int n = *(volatile const int*)S.heavy_cnt;
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    int lane = (int)threadIdx.x;
+    asm volatile("" : "+v"(lane));
+    rp_stage_body<T, 0, 0, RPK_MAXD, MESH, false>(M, S, B, substep, nsub, S.heavy_list[i], nullptr, lane);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(S.heavy_done, 1) == (int)gridDim.x - 1) {
+      if (S.heavy_peak && n > *S.heavy_peak) *S.heavy_peak = n;
+      *S.heavy_cnt = 0; *S.heavy_done = 0; __threadfence();
     }
   }
 }
