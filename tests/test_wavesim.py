@@ -48,3 +48,46 @@ def test_fused_substeps_on_the_wave_emulator_match_the_per_stage_schedule(wavesi
     m = re.search(r"fused vs per-stage ([0-9.e+-]+), fused vs oracle ([0-9.e+-]+)", out.stdout)
     assert m, out.stdout
     assert float(m.group(1)) < 1e-9 and float(m.group(2)) < 1e-9, out.stdout
+
+
+def _run_parity_fn(lib, fn, *args, timeout=900):
+    """Runs one scenario function of tests/test_gpu_parity.py (engine vs oracle) against the emulator build."""
+    env = dict(os.environ, RP_ENGINE_LIB=lib, WAVESIM_SITE="0", RP_SKIP_SELF_CHECK="1")
+    code = ("import sys, warnings; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_parity as t\nfrom robopianist_amd.model import scene\n"
+            "warnings.simplefilter('ignore')\n"
+            "si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=True)\n"
+            "print('RESULT', *t.%s(si, %s))\n") % (os.path.dirname(HERE), HERE, fn, ", ".join(repr(a) for a in args))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    return [float(x) for x in re.search(r"RESULT (.*)", out.stdout).group(1).split()]
+
+
+def test_pile_up_beyond_32_contacts_on_the_wave_emulator(wavesim_lib):
+    """Round 4's contact capacity (64 contacts / 640 contact Jacobian entries per env: overflow records behind the
+    position stage's LDS staging, 64 contact lanes in the full-capacity solver stage) without a GPU: hand-in-hand
+    poses, teacher-forced at 1e-9 (the GPU twin: test_teacher_forced_fp64_pile_up_beyond_32_contacts)."""
+    worst, maxcon, maxent, beyond = _run_parity_fn(wavesim_lib, "pile_up", 60)
+    assert maxcon > 36 and beyond >= 4 and maxent > 300, (maxcon, beyond, maxent)
+    assert worst < 1e-9, worst
+
+
+def test_box_box_face_contacts_on_the_wave_emulator(wavesim_lib):
+    """Box-box pairs with four to eight points (the palm flat on the keys) on the emulator."""
+    worst, maxcon, pairs, most = _run_parity_fn(wavesim_lib, "palm_flat", 12)
+    assert pairs >= 20 and most >= 4, (pairs, most)
+    assert worst < 1e-9, worst
+
+
+def test_large_hull_colliders_on_the_wave_emulator(wavesim_lib):
+    """Every hand collider a 200-vertex hull (the graph walk of model/hull.py, MESH = 2 kernel builds) on the emulator."""
+    env = dict(os.environ, RP_ENGINE_LIB=wavesim_lib, WAVESIM_SITE="0", RP_SKIP_SELF_CHECK="1")
+    code = ("import sys, warnings; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_parity as t\nfrom robopianist_amd.model import scene\n"
+            "warnings.simplefilter('ignore')\n"
+            "si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=False, mesh_colliders=200)\n"
+            "print('RESULT', *t.teacher_forced(si, 64, t._replay_ctrl(si)[400:480]))\n") % (os.path.dirname(HERE), HERE)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    worst, maxcon = [float(x) for x in re.search(r"RESULT (.*)", out.stdout).group(1).split()]
+    assert maxcon >= 4 and worst < 1e-9, (worst, maxcon)
