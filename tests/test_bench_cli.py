@@ -71,7 +71,8 @@ def test_eight_ranks_sharing_one_gpu_keep_up_with_one_rank():
     """BASELINE config 3's shape on the one GPU there is: eight ranks x 512 envs on cuda:0 against one rank x 4096
     envs.  Eight host launch paths (~20 k launches/s each on an 8-GPU node) must not serialise: without the gather
     the aggregate stays within reach of the single rank's rate although every rank's 512-env launches fill a quarter
-    of the chip and eight processes time-share one device (the gate is deliberately loose; the ratio is printed).
+    of the chip and eight processes time-share one device (measured: 246 k against 444 k env-steps/s = 0.56 x, every
+    rank at 30.8 k +- 3; the gate, 0.3 x, only catches serialisation -- on the node each rank has a device of its own).
     The trajectory gather is exercised in a second, short run -- over gloo, because RCCL refuses several ranks per
     device; gloo moves the records through host memory and TCP loopback (measured: 72 % of a step at 512 envs per
     rank), which says nothing about RCCL over xGMI: that run only checks that the line carries the per-rank rates
@@ -87,7 +88,9 @@ def test_eight_ranks_sharing_one_gpu_keep_up_with_one_rank():
     assert len(out["per_rank"]["env_steps_per_s"]) == 8
     print(f"8 ranks x 512 envs on one GPU: {out['value']:.0f} env-steps/s = {out['value'] / v1:.2f} x one rank x 4096 envs ({v1:.0f}); "
           f"per rank {[round(x) for x in out['per_rank']['env_steps_per_s']]}")
-    assert out["value"] >= 0.5 * v1, (out["value"], v1)
+    assert out["value"] >= 0.3 * v1, (out["value"], v1)
+    pr = out["per_rank"]["env_steps_per_s"]
+    assert max(pr) <= 1.5 * min(pr), pr     # (no rank starves)
     g = _run(["--gpus", "8", "--same-device", "--dist-backend", "gloo", "--envs", "64", "--config", "3", "--steps", "6",
               "--warmup", "1", "--no-cpu-baseline"], timeout=1200)
     assert g.returncode == 0, g.stderr[-2000:]
