@@ -7,7 +7,7 @@ from robopianist_amd.wrappers import CanonicalSpecWrapper, MidiEvaluationWrapper
 E, steps = 4096, int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 acts = np.load("tests/golden/twinkle_twinkle_actions.npy"); T = acts.shape[0]
 env = MidiEvaluationWrapper(CanonicalSpecWrapper(suite.load("RoboPianist-debug-TwinkleTwinkleRousseau-v0", seed=3, n_envs=E,
-    task_kwargs=dict(trim_silence=True, control_timestep=0.05, gravity_compensation=True, primitive_fingertip_collisions=True, n_steps_lookahead=10))))
+    task_kwargs=dict(trim_silence=True, control_timestep=0.05, gravity_compensation=True, primitive_fingertip_collisions=not (len(sys.argv) > 2 and sys.argv[2] == "hull"), n_steps_lookahead=10))))
 env.reset()
 a = torch.as_tensor(acts, device='cuda', dtype=torch.float64)
 g = torch.Generator(device='cuda'); g.manual_seed(0)
