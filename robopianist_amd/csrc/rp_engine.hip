@@ -511,6 +511,7 @@ struct Engine : EngineBase {
   }
   bool split_heavy_pos = !(getenv("RP_SPLIT_HEAVY_POS") && getenv("RP_SPLIT_HEAVY_POS")[0] == '0');   // (experiment switch)
   const bool x_no_heavy = getenv("RP_X_NO_HEAVY") && getenv("RP_X_NO_HEAVY")[0] == '1';
+  const bool x_order_twice = getenv("RP_X_ORDER_TWICE") && getenv("RP_X_ORDER_TWICE")[0] == '1';
   bool companion = !(getenv("RP_COMPANION") && getenv("RP_COMPANION")[0] == '0');   // (experiment: the full-capacity launch on the slice's own stream)
   // (Experiment, RP_HEAVY_PRIORITY=1: the companion stream at the highest priority the device offers.  The idea: the
   // full-capacity launch and the lean one become ready together, and whichever is dispatched first takes the machine
@@ -855,6 +856,9 @@ struct Engine : EngineBase {
         if (cost_order || listed)
           hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(order_threads_for(cnt)), 0, st, cost_order ? d_order : nullptr, B.hdr, s.active, base, cnt,
                              listed ? d_heavy : nullptr, listed ? d_heavy_cnt + 2 * sl : nullptr);
+        // (RP_X_ORDER_TWICE=1: MEASUREMENT ONLY -- the order pass a second time (no list): what the pass costs the step)
+        if (x_order_twice && cost_order)
+          hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(order_threads_for(cnt)), 0, st, d_order, B.hdr, s.active, base, cnt, (int*)nullptr, (int*)nullptr);
         if (sense) {  // the state this substep's forces belong to (the solver stage integrates in place)
           HIP_OK(hipMemcpyAsync(d_qpos_prev + (size_t)base * nv, S.qpos + (size_t)base * nv, sizeof(T) * (size_t)cnt * nv, hipMemcpyDeviceToDevice, st));
           HIP_OK(hipMemcpyAsync(d_qvel_prev + (size_t)base * nv, S.qvel + (size_t)base * nv, sizeof(T) * (size_t)cnt * nv, hipMemcpyDeviceToDevice, st));
