@@ -472,6 +472,7 @@ struct Engine : EngineBase {
       const char* le = getenv("RP_LEAN");
       lean = sizeof(T) == 8 && !deep && !(le && le[0] == '0');
       S.lean = lean ? 1 : 0;
+      if (lean && le && atoi(le) > 1) S.lean = atoi(le);   // (RP_LEAN=n > 1: the light class capped at n Jacobian entries, as rp_set_lean_solver(e, n))
     }
     // The fills and uploads above went through the null stream, which is NOT ordered with the
     // engine's non-blocking stream: everything must have landed before the first kernel.
