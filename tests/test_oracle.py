@@ -644,3 +644,20 @@ def test_hull_support_walk_finds_the_scans_vertex():
             np.testing.assert_allclose(o.contact.reshape(-1, 16)[:, :7], o2.contact.reshape(-1, 16)[:, :7], rtol=0, atol=1e-12)
             hits += 1
     assert hits >= 20
+
+
+def test_oracle_reproduces_its_regression_fixture():
+    """tests/golden/oracle_regression.npz (make_oracle_regression.py): the oracle's own trajectory on the benchmark
+    scene and action stream, both fingertip colliders, inside the smooth window.  Pins the oracle and the model
+    builders against accidental change -- NOT against MuJoCo (parity unpinned)."""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec_ = importlib.util.spec_from_file_location("make_oracle_regression", os.path.join(here, "golden", "make_oracle_regression.py"))
+    mod = importlib.util.module_from_spec(spec_); spec_.loader.exec_module(mod)
+    ref = np.load(os.path.join(here, "golden", "oracle_regression.npz"))
+    assert tuple(ref["marks"]) == mod.MARKS
+    for name, prim in (("hull", False), ("capsule", True)):
+        q, ncon = mod.rollout(prim)
+        assert np.array_equal(ncon, ref[f"ncon_{name}"]), name
+        np.testing.assert_allclose(q, ref[f"qpos_{name}"], rtol=0, atol=1e-10, err_msg=name)
