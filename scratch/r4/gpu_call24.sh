@@ -1,0 +1,10 @@
+#!/bin/bash
+# The env-level GPU tests under every schedule the engine may pick on its own (forced from the environment).
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT/gpurun_out/r04_call24
+rm -rf $R; mkdir -p $R
+cd $GRAFT_REPO_ROOT
+for v in "RP_FUSED=1" "RP_FUSED=0 RP_STREAM_SLICES=2" "RP_LEAN=0" "RP_SPLIT_HEAVY_POS=0 RP_HEAVY_GRID=128"; do
+  env $v timeout 900 python -m pytest tests/test_gpu_env.py tests/test_gpu_parity.py -m gpu -q -x -k "not eight_ranks" > $R/pytest_$(echo $v | tr ' =' '__').log 2>&1
+  echo "$v: $(tail -1 $R/pytest_$(echo $v | tr ' =' '__').log)"
+done
