@@ -155,6 +155,18 @@ int rp_set_lean_solver(rp_engine* e, int on);
 int rp_set_fused_substeps(rp_engine* e, int on);
 int rp_get_fused_substeps(rp_engine* e);
 
+/* Split position stage (fp64 default-depth builds; on by default there, RP_SPLIT_POS=0 in the environment turns the
+ * default off).  on: in the per-stage schedules the position / velocity stage of every substep (mj_step1: kinematics,
+ * CRB, collision, constraint rows) runs as three launches instead of one -- front part (kinematics, composite inertias,
+ * broad phase, fp32 prefilters; one wave per env), POOLED narrow phase (one wave per 64 candidate pairs of one geom-type
+ * pair, whatever envs they belong to: capsule-capsule, capsule-box, box-box, hull pairs through MPR), back part
+ * (constraint rows, contact Jacobians, velocity stage; one wave per env).  Bit-identical results (the same routines on
+ * the same inputs, contacts collected in the one-kernel stage's order); candidates beyond 256 per env and mj_step
+ * are dropped and flagged RP_WARN_WORK_FULL.  What it replaces: mj_collision's narrow phase inside
+ * physics.step() (robopianist/suite/tasks/base.py:28,31,68-70).  rp_get_split_position_stage: 1 when in use. */
+int rp_set_split_position_stage(rp_engine* e, int on);
+int rp_get_split_position_stage(rp_engine* e);
+
 /* Stream slices (0, 1, 2 or 4; default 1): with n > 1, rp_step runs n slices of the batch as n
  * independent kernel chains (the caller's stream and internal ones, forked / joined with events
  * inside the call), so that the tail of one slice's launch overlaps another slice's next kernel:

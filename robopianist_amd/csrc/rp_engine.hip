@@ -216,6 +216,8 @@ struct EngineBase {
   virtual int lean_solver(int on) = 0;
   virtual int fused_substeps(int on) = 0;
   virtual int fused_substeps_on() const = 0;
+  virtual int split_position(int on) = 0;
+  virtual int split_position_on() const = 0;
   virtual int field_ptr(rp_field f, void** p, size_t* bytes) = 0;
   bool own_stream = true;
   virtual int profile(long long* out, int n, int enable) = 0;
@@ -236,6 +238,15 @@ struct Engine : EngineBase {
   bool graph = false;   // ... some of them with a vertex graph (more than 32 vertices): the MESH = 2 builds
   bool deep = false;    // a trunk of 5..8 links (more than two forearm dofs): the RPK_MAXD_DEEP builds
   bool lean = false;    // light envs are stepped by rp_lean_solver_kernel (rp_solver2.hpp), the others by the full build
+  // the position stage of the substeps as three launches: front part, pooled narrow phase (rp_collide.hpp), back part
+  bool split_capable = false, split_pos = false;
+  const int narrow_grid_env = getenv("RP_NARROW_GRID") ? atoi(getenv("RP_NARROW_GRID")) : 0;
+  int split_position(int on) override {
+    if (on && !split_capable) return fail("rp_set_split_position_stage: the split stage exists for the fp64 default-depth builds only");
+    split_pos = on != 0;
+    return 0;
+  }
+  int split_position_on() const override { return split_pos ? 1 : 0; }
   int lean_solver(int on) override {
     if (on && (deep || sizeof(T) != 8)) return fail("rp_set_lean_solver: the lean solver stage exists for the fp64 default builds only");
     lean = on != 0; S.lean = on > 0 ? on : 0;   // (on > 1: the light class capped at that many Jacobian entries)
@@ -438,6 +449,27 @@ struct Engine : EngineBase {
     B.keyslot = dalloc<int>(E * (RPK_NKEYS / 4));
     B.covf = dalloc<T>(E * (RPK_NC - RPK_NCL) * 12);
     B.covi = dalloc<int>(E * (RPK_NC - RPK_NCL) * 4);
+    // split position stage (front part -> pooled narrow phase -> back part): the fp64 default-depth builds
+    {
+      const char* sp = getenv("RP_SPLIT_POS");
+      split_capable = sizeof(T) == 8 && !deep;
+      split_pos = split_capable && !(sp && sp[0] == '0');
+      if (split_capable) {
+        B.frames = dalloc<T>(E * RPK_NFRAME * 64);
+        B.gframe = dalloc<T>(E * 64 * 12);
+        B.cand = dalloc<int>(E * RPK_NCAND * 2);
+        B.ncand = dalloc<int>(E);
+        B.cres = dalloc<T>(E * RPK_NRES * 12);
+        B.cres_n = dalloc<int>(E * RPK_NCAND);
+        B.tstride = E * RPK_NCAND;
+        B.tlist = dalloc<int>((size_t)RPK_NTYPE * B.tstride * 4);
+        B.tcount = dalloc<int>(kMaxSlices * RPK_NTYPE);   // (zero-filled)
+        B.tcount_off = 0;
+        hipMemset(B.ncand, 0xFF, sizeof(int) * E);        // -1: no front part has run
+        hipMemset(B.frames, 0xFF, sizeof(T) * E * RPK_NFRAME * 64);
+        hipMemset(B.gframe, 0xFF, sizeof(T) * E * 64 * 12);
+      }
+    }
     // hand-over buffers start as NaN / -1 patterns: a read of anything the position kernel
     // did not write this substep shows up as a bad state instead of silently reusing old data
     hipMemset(B.RM, 0xFF, sizeof(T) * E * RPK_NLX(md()) * (md() + 1));
@@ -793,7 +825,30 @@ struct Engine : EngineBase {
           else hipLaunchKernelGGL((rp_pos_list_kernel<T, 0>), dim3(grid), dim3(64), 0, str, M, q, B, k, nsub);
         }
       };
+      // the position / velocity stage of substep k as front part, pooled narrow phase, back part (same results, bit for bit)
+      auto launch_pos_split = [&](const RpState<T>& q, int k) {
+        if constexpr (sizeof(T) == 8) {
+          RpStage<T> Bs = B;
+          Bs.tcount_off = sl * RPK_NTYPE;
+          int ng = narrow_grid_env > 0 ? narrow_grid_env : cnt / 2;
+          ng = ng < 64 ? 64 : (ng > 2048 ? 2048 : ng);
+          if (mesh && graph) {
+            hipLaunchKernelGGL((rp_pos_front_kernel<T, 2>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);
+            hipLaunchKernelGGL((rp_narrow_kernel<T, 2>), dim3(ng), dim3(64), 0, st, M, q, Bs);
+            hipLaunchKernelGGL((rp_pos_back_kernel<T, 2>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);
+          } else if (mesh) {
+            hipLaunchKernelGGL((rp_pos_front_kernel<T, 1>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);
+            hipLaunchKernelGGL((rp_narrow_kernel<T, 1>), dim3(ng), dim3(64), 0, st, M, q, Bs);
+            hipLaunchKernelGGL((rp_pos_back_kernel<T, 1>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);
+          } else {
+            hipLaunchKernelGGL((rp_pos_front_kernel<T, 0>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);
+            hipLaunchKernelGGL((rp_narrow_kernel<T, 0>), dim3(ng), dim3(64), 0, st, M, q, Bs);
+            hipLaunchKernelGGL((rp_pos_back_kernel<T, 0>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);
+          }
+        }
+      };
       auto launch_pos_on = [&](const RpState<T>& q, int k) {
+        if (split_pos && !deep && sizeof(T) == 8) { launch_pos_split(q, k); return; }
         if (deep && mesh && graph) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP, 2>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
         else if (mesh && graph) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD, 2>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
         else if (deep && mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP, 1>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
@@ -1031,6 +1086,8 @@ int rp_set_acc_sensors(rp_engine* e, int on) { return e ? E(e)->acc_sensors(on) 
 int rp_set_lean_solver(rp_engine* e, int on) { return e ? E(e)->lean_solver(on) : fail("null engine"); }
 int rp_set_fused_substeps(rp_engine* e, int on) { return e ? E(e)->fused_substeps(on) : fail("null engine"); }
 int rp_get_fused_substeps(rp_engine* e) { return e ? E(e)->fused_substeps_on() : fail("null engine"); }
+int rp_set_split_position_stage(rp_engine* e, int on) { return e ? E(e)->split_position(on) : fail("null engine"); }
+int rp_get_split_position_stage(rp_engine* e) { return e ? E(e)->split_position_on() : fail("null engine"); }
 int rp_set_stream_slices(rp_engine* e, int n) {
   if (!e) return fail("null engine");
   if (n != 0 && n != 1 && n != 2 && n != 4) return fail("rp_set_stream_slices: 0 (automatic), 1, 2 or 4");

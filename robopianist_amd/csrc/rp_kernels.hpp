@@ -5,6 +5,7 @@
 #include "rp_model.hpp"
 #include "rp_wave.hpp"
 #include "rp_narrow.hpp"
+#include "rp_collide.hpp"
 #include "rp_dense.hpp"
 #include "rp_solver2.hpp"
 
@@ -65,10 +66,15 @@ struct Smem<T, 0, MD> : SmemShared<T> {
     struct {            // in between (collision .. contact Jacobians):
       float gax[RPK_WAVE][4];  // fp32 capsule axes for the candidate prefilter: world axis, half-length
       float grr[RPK_WAVE];     // radius (bounding radius for boxes)
-      T cpos[RPK_NCL][3];      // contact points, normals, distances of the first RPK_NCL contacts (the rest: RpStage::covf)
-      T cn[RPK_NCL][3];
-      T cdist[RPK_NCL];
-      T cpar[RPK_NCL][4];      // mu, kterm (K*imp*dist), B, D
+      union {
+        struct {
+          T cpos[RPK_NCL][3];      // contact points, normals, distances of the first RPK_NCL contacts (the rest: RpStage::covf)
+          T cn[RPK_NCL][3];
+          T cdist[RPK_NCL];
+          T cpar[RPK_NCL][4];      // mu, kterm (K*imp*dist), B, D
+        };
+        int clist[RPK_NCAND];      // split stage, front part: the candidates that passed the prefilters (ga | gb << 16)
+      };
     };
   };
   T gpos[RPK_WAVE][3];
@@ -135,7 +141,10 @@ __global__ void rp_reset_kernel(RpState<T> S, const T* qpos0, const unsigned cha
 #ifndef RPK_SOL64_WAVES
 #define RPK_SOL64_WAVES 1
 #endif
-template <typename T, int MODE, int FIXED_TL = 0, int MD = RPK_MAXD, int MESH = 0, bool EXT = false>
+// PART (MODE 0 only): 0 = the whole position / velocity stage; 1 = its front part (kinematics, CRB, broad phase, fp32
+// prefilters: leaves link / geom frames and the candidate list, RpStage::frames .. tlist); 2 = its back part (collects the
+// pooled narrow phase's results in the whole stage's emission order, then constraint rows, Jacobians, velocity stage).
+template <typename T, int MODE, int FIXED_TL = 0, int MD = RPK_MAXD, int MESH = 0, bool EXT = false, int PART = 0>
 __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState<T>& S, const RpStage<T>& B, const int substep,
                                               const int nsub, const int env, void* ext, const int lane) {
   using namespace rpk;
@@ -144,7 +153,8 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     if (S.lean && B.hdr[env * 8 + 6] == 1) return;   // a light env: rp_lean_solver_kernel steps it
   }
   if constexpr (MODE == 0) {
-    if (S.skip_heavy && B.hdr[env * 8 + 6] != 1) return;   // (its position stage follows its solve on the companion stream)
+    if constexpr (PART == 2) { if (B.ncand[env] < 0) return; }   // (the front part did not run for this env: masked, or heavy)
+    else if (S.skip_heavy && B.hdr[env * 8 + 6] != 1) return;   // (its position stage follows its solve on the companion stream)
   }
   const int env_active = S.active ? S.active[env] : 1;  // tested after the prologue loads are in flight
   Smem<T, MODE, MD>& sm = rp_smem<Smem<T, MODE, MD>, EXT>(ext);
@@ -1245,6 +1255,64 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     // MODE 0: POSITION + VELOCITY STAGE  (mj_step1)
     // ======================================================================
     if constexpr (MODE != 1) {
+    // (the link's own spatial inertia is formed twice from the link frame in LDS -- here for the composite
+    // inertias, and again after the collision phase for the bias forces -- with the same arithmetic, hence the
+    // same bits: ten doubles carried across the collision phase instead were spilled inside its loops)
+    auto link_inertia = [&](T* cin) {
+      const T *p_ipos = fresh(M.link_ipos()), *p_inert = fresh(M.link_inertia()), *p_tref = fresh(M.tree_ref());
+      const T lm_ = isl ? fresh(M.link_mass())[L] : (T)0;
+      T xm_[9], xp_[3], ip_[3], in_[6], tr_[3];
+#pragma unroll
+      for (int k = 0; k < 9; k++) xm_[k] = isl ? sm.xmat[L][k] : (k % 4 == 0 ? (T)1 : (T)0);
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        xp_[k] = isl ? sm.xpos[L][k] : (T)0; ip_[k] = isl ? p_ipos[3 * L + k] : (T)0;
+        tr_[k] = isl ? p_tref[3 * ltree + k] : (T)0;
+      }
+#pragma unroll
+      for (int k = 0; k < 6; k++) in_[k] = isl ? p_inert[6 * L + k] : (T)0;
+      T t[3], A9[9], dd[3];
+      mat_vec(t, xm_, ip_);
+#pragma unroll
+      for (int k = 0; k < 3; k++) dd[k] = xp_[k] + t[k] - tr_[k];
+      // A = xm * Iloc (Iloc symmetric)
+      const T I9[9] = {in_[0], in_[3], in_[4], in_[3], in_[1], in_[5], in_[4], in_[5], in_[2]};
+      mat_mul(A9, xm_, I9);
+      T Iw[6];  // xx yy zz xy xz yz of A * xm^T
+      Iw[0] = A9[0] * xm_[0] + A9[1] * xm_[1] + A9[2] * xm_[2];
+      Iw[1] = A9[3] * xm_[3] + A9[4] * xm_[4] + A9[5] * xm_[5];
+      Iw[2] = A9[6] * xm_[6] + A9[7] * xm_[7] + A9[8] * xm_[8];
+      Iw[3] = A9[0] * xm_[3] + A9[1] * xm_[4] + A9[2] * xm_[5];
+      Iw[4] = A9[0] * xm_[6] + A9[1] * xm_[7] + A9[2] * xm_[8];
+      Iw[5] = A9[3] * xm_[6] + A9[4] * xm_[7] + A9[5] * xm_[8];
+      const T d2 = dot3(dd, dd);
+      cin[0] = Iw[0] + lm_ * (d2 - dd[0] * dd[0]);
+      cin[1] = Iw[1] + lm_ * (d2 - dd[1] * dd[1]);
+      cin[2] = Iw[2] + lm_ * (d2 - dd[2] * dd[2]);
+      cin[3] = Iw[3] - lm_ * dd[0] * dd[1];
+      cin[4] = Iw[4] - lm_ * dd[0] * dd[2];
+      cin[5] = Iw[5] - lm_ * dd[1] * dd[2];
+      cin[6] = lm_ * dd[0]; cin[7] = lm_ * dd[1]; cin[8] = lm_ * dd[2]; cin[9] = lm_;
+    };
+    constexpr int NCX = RpCaps<T>::NC;   // contact capacity: RPK_NCL records in LDS, the rest in the env's overflow records
+    T* const ovf = B.covf + (size_t)env * (RPK_NC - RPK_NCL) * 12;
+    int* const ovi = B.covi + (size_t)env * (RPK_NC - RPK_NCL) * 4;
+    // field f of MY contact's record (contact lanes): 0-2 position, 3-5 normal, 6 dist, 7 mu, 8 kterm, 9 B, 10 D
+    auto conf = [&](const int f) -> T {
+      T v;
+      if (NCX <= RPK_NCL || lane < RPK_NCL)
+        v = f < 3 ? sm.cpos[lane][f] : (f < 6 ? sm.cn[lane][f - 3] : (f == 6 ? sm.cdist[lane] : sm.cpar[lane][f - 7]));
+      else v = ovf[(size_t)(lane - RPK_NCL) * 12 + f];
+      return v;
+    };
+    // ... and its integer fields: 0 link A, 1 link B (or RPK_KEYBASE + key), 2 / 3 model geom ids
+    auto coni = [&](const int f) -> int {
+      int v;
+      if (NCX <= RPK_NCL || lane < RPK_NCL) v = f == 0 ? sm.cA[lane] : (f == 1 ? sm.cB[lane] : (f == 2 ? sm.cgA[lane] : sm.cgB[lane]));
+      else v = ovi[(size_t)(lane - RPK_NCL) * 4 + f];
+      return v;
+    };
+    if constexpr (PART != 2) {
     {
       bool bad = !(N::abs(q[0]) < (T)1e10) || !(N::abs(q[1]) < (T)1e10) || !(N::abs(q[2]) < (T)1e10) ||
                  !(N::abs(qd[0]) < (T)1e10) || !(N::abs(qd[1]) < (T)1e10) || !(N::abs(qd[2]) < (T)1e10);
@@ -1301,47 +1369,17 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
 #pragma unroll
       for (int k = 0; k < 3; k++) S.site_xpos[((size_t)env * M.nsite + lane) * 3 + k] = sm.xpos[sl][k] + t[k];
     }
+    if constexpr (PART == 1) {   // the link frames, for the back part (lane-major: coalesced both ways)
+      if (isl) {
+        T* fr_ = B.frames + (size_t)env * RPK_NFRAME * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { fr_[(size_t)k * 64] = xp[k]; fr_[(size_t)(12 + k) * 64] = axw[k]; fr_[(size_t)(15 + k) * 64] = anw[k]; }
+#pragma unroll
+        for (int k = 0; k < 9; k++) fr_[(size_t)(3 + k) * 64] = xm[k];
+      }
+    }
     PROF(10);
     // ---- spatial inertia and motion axis about the tree reference point [MJ: mj_comPos]
-    // (the link's own spatial inertia is formed twice from the link frame in LDS -- here for the composite
-    // inertias, and again after the collision phase for the bias forces -- with the same arithmetic, hence the
-    // same bits: ten doubles carried across the collision phase instead were spilled inside its loops)
-    auto link_inertia = [&](T* cin) {
-      const T *p_ipos = fresh(M.link_ipos()), *p_inert = fresh(M.link_inertia()), *p_tref = fresh(M.tree_ref());
-      const T lm_ = isl ? fresh(M.link_mass())[L] : (T)0;
-      T xm_[9], xp_[3], ip_[3], in_[6], tr_[3];
-#pragma unroll
-      for (int k = 0; k < 9; k++) xm_[k] = isl ? sm.xmat[L][k] : (k % 4 == 0 ? (T)1 : (T)0);
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        xp_[k] = isl ? sm.xpos[L][k] : (T)0; ip_[k] = isl ? p_ipos[3 * L + k] : (T)0;
-        tr_[k] = isl ? p_tref[3 * ltree + k] : (T)0;
-      }
-#pragma unroll
-      for (int k = 0; k < 6; k++) in_[k] = isl ? p_inert[6 * L + k] : (T)0;
-      T t[3], A9[9], dd[3];
-      mat_vec(t, xm_, ip_);
-#pragma unroll
-      for (int k = 0; k < 3; k++) dd[k] = xp_[k] + t[k] - tr_[k];
-      // A = xm * Iloc (Iloc symmetric)
-      const T I9[9] = {in_[0], in_[3], in_[4], in_[3], in_[1], in_[5], in_[4], in_[5], in_[2]};
-      mat_mul(A9, xm_, I9);
-      T Iw[6];  // xx yy zz xy xz yz of A * xm^T
-      Iw[0] = A9[0] * xm_[0] + A9[1] * xm_[1] + A9[2] * xm_[2];
-      Iw[1] = A9[3] * xm_[3] + A9[4] * xm_[4] + A9[5] * xm_[5];
-      Iw[2] = A9[6] * xm_[6] + A9[7] * xm_[7] + A9[8] * xm_[8];
-      Iw[3] = A9[0] * xm_[3] + A9[1] * xm_[4] + A9[2] * xm_[5];
-      Iw[4] = A9[0] * xm_[6] + A9[1] * xm_[7] + A9[2] * xm_[8];
-      Iw[5] = A9[3] * xm_[6] + A9[4] * xm_[7] + A9[5] * xm_[8];
-      const T d2 = dot3(dd, dd);
-      cin[0] = Iw[0] + lm_ * (d2 - dd[0] * dd[0]);
-      cin[1] = Iw[1] + lm_ * (d2 - dd[1] * dd[1]);
-      cin[2] = Iw[2] + lm_ * (d2 - dd[2] * dd[2]);
-      cin[3] = Iw[3] - lm_ * dd[0] * dd[1];
-      cin[4] = Iw[4] - lm_ * dd[0] * dd[2];
-      cin[5] = Iw[5] - lm_ * dd[1] * dd[2];
-      cin[6] = lm_ * dd[0]; cin[7] = lm_ * dd[1]; cin[8] = lm_ * dd[2]; cin[9] = lm_;
-    };
     {
       T cin[10];
       link_inertia(cin);
@@ -1412,6 +1450,18 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         gp[0] = sm.xpos[gl][0] + t[0]; gp[1] = sm.xpos[gl][1] + t[1]; gp[2] = sm.xpos[gl][2] + t[2];
       }
       sm.gpos[lane][0] = gp[0]; sm.gpos[lane][1] = gp[1]; sm.gpos[lane][2] = gp[2];
+      if constexpr (PART == 1) {   // the geom's world frame, for the pooled narrow phase (the whole stage forms it per candidate)
+        T mw_[9];
+        if (gl >= 0) mat_mul(mw_, sm.xmat[gl], M.geom_mat() + 9 * lane);
+        else {
+#pragma unroll
+          for (int k = 0; k < 9; k++) mw_[k] = M.geom_mat()[9 * lane + k];
+        }
+        T* gf_ = B.gframe + ((size_t)env * 64 + lane) * 12;
+        gf_[0] = gp[0]; gf_[1] = gp[1]; gf_[2] = gp[2];
+#pragma unroll
+        for (int k = 0; k < 9; k++) gf_[3 + k] = mw_[k];
+      }
       // capsule axis (third column of the world geom frame) for the segment prefilter
       const T* gm = M.geom_mat() + 9 * lane;
       T az[3] = {gm[2], gm[5], gm[8]};
@@ -1451,24 +1501,6 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     // pending they are narrow-phased, so the list never overflows whatever the pose.
     int nwork = 0;
     ncon = 0;
-    constexpr int NCX = RpCaps<T>::NC;   // contact capacity: RPK_NCL records in LDS, the rest in the env's overflow records
-    T* const ovf = B.covf + (size_t)env * (RPK_NC - RPK_NCL) * 12;
-    int* const ovi = B.covi + (size_t)env * (RPK_NC - RPK_NCL) * 4;
-    // field f of MY contact's record (contact lanes): 0-2 position, 3-5 normal, 6 dist, 7 mu, 8 kterm, 9 B, 10 D
-    auto conf = [&](const int f) -> T {
-      T v;
-      if (NCX <= RPK_NCL || lane < RPK_NCL)
-        v = f < 3 ? sm.cpos[lane][f] : (f < 6 ? sm.cn[lane][f - 3] : (f == 6 ? sm.cdist[lane] : sm.cpar[lane][f - 7]));
-      else v = ovf[(size_t)(lane - RPK_NCL) * 12 + f];
-      return v;
-    };
-    // ... and its integer fields: 0 link A, 1 link B (or RPK_KEYBASE + key), 2 / 3 model geom ids
-    auto coni = [&](const int f) -> int {
-      int v;
-      if (NCX <= RPK_NCL || lane < RPK_NCL) v = f == 0 ? sm.cA[lane] : (f == 1 ? sm.cB[lane] : (f == 2 ? sm.cgA[lane] : sm.cgB[lane]));
-      else v = ovi[(size_t)(lane - RPK_NCL) * 4 + f];
-      return v;
-    };
     {
     const bool isg = lane < M.ngeom;
     const float fcx = isg ? (float)sm.gpos[lane][0] : 0.f, fcy = isg ? (float)sm.gpos[lane][1] : 0.f,
@@ -1635,7 +1667,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       // narrow phase below is the register-hungriest part of this kernel, and in one loop with it the
       // allocator spilled the drain loop's own variables -- every round then paid scratch round trips
       // (measured: 34 k cycles per mj_step in the capsule builds, 163 k in the hull builds)
-      while (gen_phase < (KEYLANES ? 3 : 2) && nwork < 64) {
+      while (gen_phase < (KEYLANES ? 3 : 2) && (PART == 1 || nwork < 64)) {
       // ---- one drain round: every lane contributes at most one candidate
       {
         // Geom-geom candidates are COMPACTED first: the sphere-overlap hits sit unevenly in the lanes (a palm box
@@ -1778,7 +1810,12 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
           }
 #endif
           const int idx = nwork + __popcll(mk & lanemask_lt(lane));
-          if (has) {
+          if constexpr (PART == 1) {
+            if (has && idx < RPK_NCAND) {
+              if (gen_phase == 0) sm.clist[idx] = (a < bit ? a : bit) | ((a < bit ? bit : a) << 16);
+              else sm.clist[idx] = bit | ((RPK_KEYBASE + a) << 16);
+            }
+          } else if (has) {
             // (a static pair is owned by either of its lanes: geom 1 of the pair is the lower one)
             if (gen_phase == 0) { sm.work[idx][0] = (short)(a < bit ? a : bit); sm.work[idx][1] = (short)(a < bit ? bit : a); }
             else { sm.work[idx][0] = (short)bit; sm.work[idx][1] = (short)(RPK_KEYBASE + a); }
@@ -1788,6 +1825,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       }
       }
       PROF(23);   // (drain rounds: candidate prefilters)
+      if constexpr (PART == 1) break;   // (everything is on the candidate list)
       if (nwork == 0) break;   // (the masks are empty and nothing is pending)
       WSYNC();
       // ---- narrow phase on the first min(64, nwork) candidates
@@ -2007,7 +2045,139 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       nwork -= nproc;
       WSYNC();
     }
+    if constexpr (PART == 1) {
+      // ---- split stage, front part: the candidate list leaves the wave.  Every candidate gets its result records
+      // (by pair type: 2 / 2 / 8 / 1) and an entry on its type's POOLED list, which the narrow-phase kernel walks
+      // with lane = candidate whatever env it came from.  (Where an entry lands on that list depends on the order
+      // in which the waves of the launch arrive; the results do not: they return to the candidate's own records.)
+      int nc_ = nwork;
+      if (nc_ > RPK_NCAND) { warn |= 16; nc_ = RPK_NCAND; }   // (RP_WARN_WORK_FULL)
+      WSYNC();
+      int rbase = 0;
+      int* const cl_ = B.cand + (size_t)env * RPK_NCAND * 2;
+      int* const tc_ = B.tcount + B.tcount_off;
+      for (int c0 = 0; c0 < nc_; c0 += 64) {
+        const int i = c0 + lane;
+        const bool in = i < nc_;
+        const int pair = in ? sm.clist[in ? i : 0] : 0;
+        const int ga = pair & 0xffff, gb = (pair >> 16) & 0xffff;
+        const int ta = M.geom_type()[ga];
+        int ty;
+        if (gb >= RPK_KEYBASE) ty = ta == GEOM_CAPSULE_ ? 1 : (ta == GEOM_BOX_ ? 2 : 3);
+        else {
+          const int tb = M.geom_type()[gb];
+          ty = tb == GEOM_CAPSULE_ ? 0 : ((tb == GEOM_MESH_ || ta == GEOM_MESH_) ? 3 : (ta == GEOM_CAPSULE_ ? 1 : 2));
+        }
+        const int wdt = ty == 2 ? 8 : (ty == 3 ? 1 : 2);
+        int incl = in ? wdt : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        const int myb = rbase + incl - (in ? wdt : 0);
+        const bool ok = in && myb + wdt <= RPK_NRES;
+        if (__ballot(in && !ok) != 0ull) warn |= 16;   // (its records do not fit: the candidate is dropped, flagged)
+        rbase += bcast(incl, 63);
+        const unsigned long long m0 = __ballot(ok && ty == 0), m1 = __ballot(ok && ty == 1), m2 = __ballot(ok && ty == 2),
+                                 m3 = __ballot(ok && ty == 3);
+        const unsigned long long mine = ty == 0 ? m0 : (ty == 1 ? m1 : (ty == 2 ? m2 : m3));
+        int tb_ = 0;
+        {
+          const int cntT = lane == 0 ? __popcll(m0) : (lane == 1 ? __popcll(m1) : (lane == 2 ? __popcll(m2) : __popcll(m3)));
+          if (lane < RPK_NTYPE && cntT > 0) tb_ = atomicAdd(&tc_[lane], cntT);
+        }
+        const int tbase = __shfl(tb_, ty, 64);
+        if (in) {
+          cl_[2 * i] = pair; cl_[2 * i + 1] = (ok ? myb : 0) | (ty << 16);
+          B.cres_n[(size_t)env * RPK_NCAND + i] = 0;
+        }
+        if (ok) {
+          int4* e_ = (int4*)(B.tlist + ((size_t)ty * B.tstride + (size_t)S.env_base * RPK_NCAND + tbase + __popcll(mine & lanemask_lt(lane))) * 4);
+          int4 v_; v_.x = env; v_.y = pair; v_.z = myb; v_.w = i;
+          *e_ = v_;
+        }
+      }
+      if (lane == 0) B.ncand[env] = nc_;
     }
+    }
+    }  // PART != 2
+    if constexpr (PART == 2) {
+      // ---- split stage, back part: the link frames the front part left, then the narrow phase's contacts in the
+      // emission order of the whole stage -- candidates in chunks of 64 (the passes of its work list), within a chunk
+      // point 1 of every candidate, then point 2, ... -- so that both ways of running the stage produce the same bits.
+      if (isl) {
+        const T* fr_ = B.frames + (size_t)env * RPK_NFRAME * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          sm.xpos[lane][k] = fr_[(size_t)k * 64]; sm.xaxis[lane][k] = fr_[(size_t)(12 + k) * 64]; sm.xanchor[lane][k] = fr_[(size_t)(15 + k) * 64];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) sm.xmat[lane][k] = fr_[(size_t)(3 + k) * 64];
+      }
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        if (isk[s]) { N::sincos(q[1 + s], &ksin[s], &kcos[s]); sm.keyslot[kid[s]] = -1; }
+      }
+      ncon = 0;
+      const int nc_ = B.ncand[env];
+      const int* const cl_ = B.cand + (size_t)env * RPK_NCAND * 2;
+      const T* const res_ = B.cres + (size_t)env * RPK_NRES * 12;
+      for (int c0 = 0; c0 < nc_; c0 += 64) {
+        const int i = c0 + lane;
+        const bool in = i < nc_;
+        const int pair = in ? cl_[2 * i] : 0, meta = in ? cl_[2 * i + 1] : 0;
+        const int n = in ? B.cres_n[(size_t)env * RPK_NCAND + i] : 0;
+        const int ga = pair & 0xffff, gb = (pair >> 16) & 0xffff, rb = meta & 0xffff;
+        const int iA = M.geom_link()[ga], iB = gb >= RPK_KEYBASE ? gb : M.geom_link()[gb >= RPK_KEYBASE ? 0 : gb];
+        const int igA = M.geom_modelid()[ga], igB = gb >= RPK_KEYBASE ? M.key_geomid()[gb - RPK_KEYBASE] : M.geom_modelid()[gb >= RPK_KEYBASE ? 0 : gb];
+        auto put = [&](const int at, const T* r) {   // record r -> contact slot `at` (LDS, or the env's overflow records)
+          if (NCX <= RPK_NCL || at < RPK_NCL) {
+            const int a_ = at < RPK_NCL ? at : 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { sm.cpos[a_][k] = r[k]; sm.cn[a_][k] = r[3 + k]; }
+            sm.cdist[a_] = r[6];
+#pragma unroll
+            for (int k = 0; k < 4; k++) sm.cpar[a_][k] = r[7 + k];
+            sm.cA[a_] = iA; sm.cB[a_] = iB; sm.cgA[a_] = igA; sm.cgB[a_] = igB;
+          } else {
+            T* o = ovf + (size_t)(at - RPK_NCL) * 12;
+            int* oi = ovi + (size_t)(at - RPK_NCL) * 4;
+#pragma unroll
+            for (int k = 0; k < 11; k++) o[k] = r[k];
+            oi[0] = iA; oi[1] = iB; oi[2] = igA; oi[3] = igB;
+          }
+        };
+        const int nslot = __ballot(n > 3) != 0ull ? 8 : 3;
+        for (int slot = 0; slot < nslot; slot++) {
+          const bool has = n > slot;
+          const unsigned long long mk = __ballot(has);
+          if (mk == 0ull) continue;
+          const T* r = res_ + (size_t)(rb + (has ? slot : 0)) * 12;
+          const int idx = ncon + __popcll(mk & lanemask_lt(lane));
+          if (has && idx < NCX) put(idx, r);
+          if (ncon + __popcll(mk) > NCX) {
+            // capacity overflow: keep the deepest contacts (the whole stage's procedure, one overflowing lane at a time)
+            RPK_STAGE_FENCE();
+            unsigned long long ovm = __ballot(has && idx >= NCX);
+            const T myd = has ? r[6] : (T)0;
+            while (ovm) {
+              const int L_ = __ffsll((long long)ovm) - 1;
+              ovm &= ovm - 1;
+              const T dL = bcast(myd, L_);
+              T worst = sm.cdist[0];
+              int wi = 0;
+              for (int c = 1; c < NCX; c++) {
+                const T d = (NCX <= RPK_NCL || c < RPK_NCL) ? sm.cdist[c < RPK_NCL ? c : 0] : ovf[(size_t)(c - RPK_NCL) * 12 + 6];
+                if (d > worst) { worst = d; wi = c; }
+              }
+              if (dL < worst && lane == L_) put(wi, r);
+              RPK_STAGE_FENCE();
+            }
+          }
+          ncon += __popcll(mk);
+        }
+      }
+      if (lane == 0) B.ncand[env] = -1;   // (consumed)
+    }
+    if constexpr (PART != 1) {
     if (ncon > NCX) { warn |= 2; ncon = NCX; }
     WSYNC();
     if (NCX > RPK_NCL && ncon > RPK_NCL) RPK_STAGE_FENCE();   // (the overflow records: written by the emitting lanes, read below by the contact lanes)
@@ -2530,7 +2700,8 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         // of a multi-joint body carry the same one); moment about the body origin, on the joint axis
         const int bl = M.link_bodylink()[L];
         T axb[3], t[3];
-        mat_vec(axb, sm.xmat[bl], laxis);
+        const T* tref = M.tree_ref() + 3 * ltree;
+        mat_vec(axb, sm.xmat[bl], M.link_axis() + 3 * L);
         const T r[3] = {tref[0] - sm.xpos[bl][0], tref[1] - sm.xpos[bl][1], tref[2] - sm.xpos[bl][2]};
         const T* fi = sm.acc[lane];
         cross3(t, r, fi + 3);
@@ -2538,12 +2709,13 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       }
       if (lane < M.nsite && S.sens_touch) S.sens_touch[(size_t)env * M.nsite + lane] = sm.touch[lane];
     }
+    }  // PART != 1
     }  // MODE 0
   }
 
   PROF(17);
   // ------------------------------------------------------------------ outputs
-  if constexpr (MODE == 0) {
+  if constexpr (MODE == 0 && PART != 1) {
 #pragma unroll
   for (int s = 0; s < 2; s++) if (isk[s]) {
     if (kact[s] >= 0) S.act_vel[(size_t)env * nu + kact[s]] = M.act_coef()[2 * kact[s]] * qd[1 + s];
@@ -2569,7 +2741,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     w = wave_or(w);
     if (lane == 0) {
       S.warn[env] |= w;
-      if constexpr (MODE == 0) S.ncon[env] = ncon;
+      if constexpr (MODE == 0 && PART != 1) S.ncon[env] = ncon;
       if constexpr (MODE == 1) {
         S.solver_iter[env] = (niter_last & 255) | ((__popcll(dirty_mask) & 255) << 8) | ((nkt & 255) << 16);
         S.time[env] = time;
@@ -2612,6 +2784,21 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
       }
     }
   }
+}
+
+// The split position / velocity stage (round 5): front part -> rp_narrow_kernel (rp_collide.hpp) -> back part.  One env
+// per workgroup, as rp_stage_kernel<T, 0>; the back part's first workgroup clears the pooled lists' counters for the
+// next front launch on this stream (the narrow-phase launch between them has finished reading them by then).
+template <typename T, int MESH>
+__global__ __launch_bounds__(64, 2) void rp_pos_front_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep, int nsub) {
+  const int env = S.order ? S.order[S.env_base + blockIdx.x] : S.env_base + (int)blockIdx.x;
+  rp_stage_body<T, 0, 0, RPK_MAXD, MESH, false, 1>(M, S, B, substep, nsub, env, nullptr, (int)threadIdx.x);
+}
+template <typename T, int MESH>
+__global__ __launch_bounds__(64, 2) void rp_pos_back_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep, int nsub) {
+  if (blockIdx.x == 0 && threadIdx.x < RPK_NTYPE) B.tcount[B.tcount_off + threadIdx.x] = 0;
+  const int env = S.order ? S.order[S.env_base + blockIdx.x] : S.env_base + (int)blockIdx.x;
+  rp_stage_body<T, 0, 0, RPK_MAXD, MESH, false, 2>(M, S, B, substep, nsub, env, nullptr, (int)threadIdx.x);
 }
 
 // The position / velocity stage of the envs on the compacted list (the envs outside the light class), on the companion

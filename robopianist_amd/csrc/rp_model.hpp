@@ -46,6 +46,12 @@
 #define RPK_HMAX 60      // max rows of the dense cross-coupling block (+1 row for its rhs = one lane each; fp64)
 #endif
 #define RPK_WORK 128     // narrow-phase work list
+// Split position stage (round 5: rp_pos_front_kernel -> rp_narrow_kernel -> rp_pos_back_kernel): per env, the
+// candidates that passed the fp32 prefilters and the narrow-phase results they map to
+#define RPK_NCAND 256    // candidates per env and mj_step (typical: 20-30); beyond: RP_WARN_WORK_FULL
+#define RPK_NRES 384     // result records per env: 1 per capsule-capsule / hull pair, 2 per capsule-box, 8 per box-box
+#define RPK_NTYPE 4      // pooled narrow-phase lists: 0 capsule-capsule, 1 capsule-box, 2 box-box, 3 hull pairs (MPR)
+#define RPK_NFRAME 18    // per-link frame fields handed from the front to the back part: xpos 3, xmat 9, xaxis 3, xanchor 3
 #define RPK_KLIST 192    // geom-key candidates per mj_step (typical: 8.5; with RPK_GLIST and the box table inside the 2496 B the link table leaves)
 #ifndef RPK_GLIST        // (tests shrink it to exercise the refill)
 #define RPK_GLIST 256    // compacted sphere-overlap candidates per refill of the drain rounds (typical: 185 per mj_step)
@@ -259,4 +265,18 @@ struct RpStage {
   // narrow phase that emits them and the contact lanes that take them into registers
   T* covf;      // [E][RPK_NC - RPK_NCL][12]: pos[3], normal[3], dist, mu, kterm, B, D
   int* covi;    // [E][RPK_NC - RPK_NCL][4]: link A, link B (or RPK_KEYBASE + key), model geom ids
+  // ---- split position stage (all null when the engine runs the position stage as one kernel).  The front part
+  // (kinematics, CRB, broad phase, fp32 prefilters) leaves link frames, geom frames and the candidate list; the pooled
+  // narrow phase (lane = candidate, whatever env it belongs to, one routine per wave) fills the result records; the
+  // back part (constraint rows, Jacobians, velocity stage) collects them in the one-kernel stage's emission order.
+  T* frames;      // [E][RPK_NFRAME][64]   lane = link
+  T* gframe;      // [E][64][12]           geom world frame: pos[3], mat[9]
+  int* cand;      // [E][RPK_NCAND][2]     ga | gb << 16 ; first result record | type << 16
+  int* ncand;     // [E]                   candidates of this mj_step; -1: the front part did not run for this env
+  T* cres;        // [E][RPK_NRES][12]     pos[3], normal[3], dist, mu, kterm, B, D (as covf)
+  int* cres_n;    // [E][RPK_NCAND]        contacts of candidate i (0 .. 8)
+  int* tlist;     // [RPK_NTYPE][E * RPK_NCAND][4]  env, ga | gb << 16, first result record, candidate index
+  int* tcount;    // [slices][RPK_NTYPE]   entries per type (the back part's first workgroup clears them)
+  int tcount_off; // this launch's slice: tcount + tcount_off
+  size_t tstride; // E * RPK_NCAND
 };

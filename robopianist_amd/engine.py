@@ -37,7 +37,7 @@ WARN_DENSE_FULL = 32
 
 EXPORTED_SYMBOLS = (
     "rp_create", "rp_destroy", "rp_reset", "rp_set", "rp_get", "rp_step", "rp_forward", "rp_step_masked",
-    "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_set_lazy_position_stage", "rp_set_cost_ordered_launch", "rp_set_stream_slices", "rp_set_lean_solver", "rp_set_fused_substeps", "rp_get_fused_substeps", "rp_set_acc_sensors", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
+    "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_set_lazy_position_stage", "rp_set_cost_ordered_launch", "rp_set_stream_slices", "rp_set_lean_solver", "rp_set_fused_substeps", "rp_get_fused_substeps", "rp_set_split_position_stage", "rp_get_split_position_stage", "rp_set_acc_sensors", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
     "rp_n_envs", "rp_dim",
     "rp_kernel_time", "rp_solver_kernel_time", "rp_solver_kernel_envs", "rp_solver_kernel_fused", "rp_profile", "rp_last_error",
 )
@@ -89,6 +89,8 @@ def load_library(path: str = LIB_PATH):
     L.rp_set_lean_solver.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.rp_set_fused_substeps.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.rp_get_fused_substeps.argtypes = [ctypes.c_void_p]
+    L.rp_set_split_position_stage.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.rp_get_split_position_stage.argtypes = [ctypes.c_void_p]
     L.rp_get_stream.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
     L.rp_n_envs.argtypes = [ctypes.c_void_p]
     L.rp_dim.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
@@ -282,6 +284,15 @@ class BatchedPhysics:
     def fused_substeps(self) -> bool:
         """True if rp_step currently runs the fused schedule."""
         return self._L.rp_get_fused_substeps(self._h) == 1
+
+    def set_split_position_stage(self, on: bool = True):
+        """Position stage of the substeps as front part / pooled narrow phase / back part (include/rp_engine.h:
+        rp_set_split_position_stage); bit-identical results."""
+        self._check(self._L.rp_set_split_position_stage(self._h, int(bool(on))))
+
+    @property
+    def split_position_stage(self) -> bool:
+        return self._L.rp_get_split_position_stage(self._h) == 1
 
     def set_cost_ordered_launch(self, on: bool = True):
         """Stage kernels process the envs heaviest-first (include/rp_engine.h); bit-identical results."""

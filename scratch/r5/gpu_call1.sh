@@ -1,0 +1,32 @@
+#!/bin/bash
+# Round 5, call 1: split position stage on the GPU -- bit equality with the one-kernel stage, then A/B on config 2.
+export TMPDIR=/tmp
+ROOT=$GRAFT_REPO_ROOT
+R=$ROOT/gpurun_out/r05_call1
+rm -rf $R; mkdir -p $R
+cd $ROOT
+FLAGS="--no-cpu-baseline --aux-fp32 0 --host-io 0 --aux-fingertips 0 --aux-large-hulls 0"
+summ() {
+python - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+    r = d["roofline"]; s = d.get("sanity", {})
+    print(sys.argv[1], "value", round(d["value"]), "ms/step", round(d["ms_per_step"], 3), "seq", round(r.get("step_sequence_avg_ms") or 0, 3),
+          "sol", round(r.get("kernel_avg_ms") or 0, 4), "sched", r.get("schedule"), "overflow_eps", s.get("capacity_overflow_episodes"), "warn_or", s.get("warn_flags_or"))
+except Exception as e:
+    print(sys.argv[1], "FAILED", e)
+PY
+}
+timeout 300 python scratch/r5/ws_split_vs_whole.py 150 hull replay 300 2>&1 | tail -2
+timeout 300 python scratch/r5/ws_split_vs_whole.py 150 cap replay 300 2>&1 | tail -2
+timeout 300 python scratch/r5/ws_split_vs_whole.py 120 hull wrist 2>&1 | tail -2
+for rep in 1 2; do
+  RP_SPLIT_POS=0 timeout 400 python bench.py $FLAGS > $R/whole_$rep.json 2> $R/whole_$rep.err; summ "whole#$rep" $R/whole_$rep.json
+  RP_SPLIT_POS=1 timeout 400 python bench.py $FLAGS > $R/split_$rep.json 2> $R/split_$rep.err; summ "split#$rep" $R/split_$rep.json
+done
+RP_SPLIT_POS=1 timeout 400 python bench.py $FLAGS --fingertips primitive > $R/split_cap.json 2> $R/split_cap.err; summ "split cap" $R/split_cap.json
+RP_SPLIT_POS=0 timeout 400 python bench.py $FLAGS --fingertips primitive > $R/whole_cap.json 2> $R/whole_cap.err; summ "whole cap" $R/whole_cap.json
+RP_SPLIT_POS=1 timeout 400 python bench.py $FLAGS --config 3 > $R/split_c3.json 2> $R/split_c3.err; summ "split c3" $R/split_c3.json
+RP_SPLIT_POS=0 timeout 400 python bench.py $FLAGS --config 3 > $R/whole_c3.json 2> $R/whole_c3.err; summ "whole c3" $R/whole_c3.json
+tail -3 $R/*.err | head -60
