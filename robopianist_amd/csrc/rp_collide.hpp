@@ -18,140 +18,154 @@
 #include "rp_wave.hpp"
 #include "rp_narrow.hpp"
 
-#ifndef RPK_NARROW_WAVES
-#define RPK_NARROW_WAVES 1   // (a launch has fewer chunks than the chip has SIMDs: registers, not occupancy)
-#endif
-template <typename T, int MESH>
-__global__ __launch_bounds__(64, RPK_NARROW_WAVES) void rp_narrow_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B) {
+// One pair type per routine, each a REAL call (noinline): the kernel then needs the registers of its hungriest routine,
+// not of all four inlined side by side (256 VGPRs + 96 AGPRs, one wave per SIMD -- a workgroup that has to wait for a
+// whole idle SIMD while the other slice's kernels hold the chip), and nothing of the caller lives across the call.
+// TYPE: 0 capsule-capsule, 1 capsule-box, 2 box-box, 3 .. 6 hull pairs (MPR; MESH builds; the buckets of rp_model.hpp).  `e` = this lane's entry on the
+// type's pooled list, `in` = it exists.
+template <typename T, int MESH, int TYPE>
+__device__ __noinline__ void rp_narrow_chunk(const RpModel<T>& M, const RpState<T>& S, const RpStage<T>& B, const int stripe, const int e, const bool in) {
   using namespace rpk;
   using N = Num<T>;
-  const int lane = (int)threadIdx.x;
-  const int* const tc = B.tcount + B.tcount_off;
-  // chunks of 64 candidates, the long routines first (hull pairs, box-box, capsule-box, capsule-capsule)
-  const int c0 = tc[0], c1 = tc[1], c2 = tc[2], c3 = tc[3];
-  const int n3 = (c3 + 63) >> 6, n2 = (c2 + 63) >> 6, n1 = (c1 + 63) >> 6, n0 = (c0 + 63) >> 6;
-  const int total = n0 + n1 + n2 + n3;
   const T h = M.timestep;
-  for (int ch = (int)blockIdx.x; ch < total; ch += (int)gridDim.x) {
-    int ty, off, cnt;
-    if (ch < n3) { ty = 3; off = ch; cnt = c3; }
-    else if (ch < n3 + n2) { ty = 2; off = ch - n3; cnt = c2; }
-    else if (ch < n3 + n2 + n1) { ty = 1; off = ch - n3 - n2; cnt = c1; }
-    else { ty = 0; off = ch - n3 - n2 - n1; cnt = c0; }
-    const int e = off * 64 + lane;
-    const bool in = e < cnt;
-    int env = 0, pair = 0, rb = 0, ci = 0;
-    if (in) {
-      const int4 rec = *(const int4*)(B.tlist + ((size_t)ty * B.tstride + (size_t)S.env_base * RPK_NCAND + e) * 4);
-      env = rec.x; pair = rec.y; rb = rec.z; ci = rec.w;
-    }
-    const int ga = pair & 0xffff, gb = (pair >> 16) & 0xffff;
-    const bool key = gb >= RPK_KEYBASE;
-    const int kk = key ? gb - RPK_KEYBASE : 0, gbi = key ? 0 : gb;
-    // side A: a hand geom; side B: a hand geom, or the key's box (moving with the key's hinge angle)
-    T posA[3], mA[9], posB[3], mB[9];
-    const T* sB;
-    {
-      const T* fa = B.gframe + ((size_t)env * 64 + ga) * 12;
+  int env = 0, pair = 0, rb = 0, ci = 0;
+  if (in) {
+    const int4 rec = *(const int4*)(B.tlist + (((size_t)TYPE * RPK_NSTRIPE + stripe) * B.tstride + (size_t)(S.env_base / RPK_NSTRIPE) * RPK_NCAND + e) * 4);
+    env = rec.x; pair = rec.y; rb = rec.z; ci = rec.w;
+  }
+  const int ga = pair & 0xffff, gb = (pair >> 16) & 0xffff;
+  const bool key = gb >= RPK_KEYBASE;
+  const int kk = key ? gb - RPK_KEYBASE : 0, gbi = key ? 0 : gb;
+  // side A: a hand geom; side B: a hand geom, or the key's box (moving with the key's hinge angle)
+  T posA[3], mA[9], posB[3], mB[9];
+  const T* sB;
+  {
+    const T* fa = B.gframe + ((size_t)env * 64 + ga) * 12;
 #pragma unroll
-      for (int k = 0; k < 3; k++) posA[k] = fa[k];
+    for (int k = 0; k < 3; k++) posA[k] = fa[k];
 #pragma unroll
-      for (int k = 0; k < 9; k++) mA[k] = fa[3 + k];
-    }
-    T invw = M.geom_invw()[ga];
-    const T* pB;
+    for (int k = 0; k < 9; k++) mA[k] = fa[3 + k];
+  }
+  T invw = M.geom_invw()[ga];
+  const T* pB;
+  if (key) {
+    T s, c;
+    N::sincos(S.qpos[(size_t)env * M.nv + M.key_dof()[kk]], &s, &c);
+    const T hx = M.key_half()[3 * kk];
+    posB[0] = M.key_pos()[3 * kk] - hx + hx * c; posB[1] = M.key_pos()[3 * kk + 1]; posB[2] = M.key_pos()[3 * kk + 2] - hx * s;
+    mB[0] = c; mB[1] = 0; mB[2] = s; mB[3] = 0; mB[4] = 1; mB[5] = 0; mB[6] = -s; mB[7] = 0; mB[8] = c;
+    sB = M.key_half() + 3 * kk;
+    pB = M.key_cparam();
+    invw += M.key_invw_body()[kk];
+  } else {
+    const T* fb = B.gframe + ((size_t)env * 64 + gbi) * 12;
+#pragma unroll
+    for (int k = 0; k < 3; k++) posB[k] = fb[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) mB[k] = fb[3 + k];
+    sB = M.geom_size() + 3 * gbi;
+    pB = M.geom_cparam() + 8 * gbi;
+    invw += M.geom_invw()[gbi];
+  }
+  RawCon<T> rc[3];
+  RawCon<T> bbx[TYPE == 2 ? 5 : 1];   // (box-box points four to eight)
+  int n = 0;
+  if constexpr (TYPE == 0) {
+    if (in) n = capsule_capsule(rc, posA, mA, M.geom_size() + 3 * ga, posB, mB, sB);
+  } else if constexpr (TYPE == 1) {
+    if (in) n = capsule_box(rc, posA, mA, M.geom_size() + 3 * ga, posB, mB, sB);
+  } else if constexpr (TYPE == 2) {
+    if (in) n = box_box(rc, bbx, posA, mA, M.geom_size() + 3 * ga, posB, mB, sB);
+  } else if constexpr (MESH != 0) {
+    // (box, hull) in geom-type order when the partner is a key: the key is geom 1 of the pair; the engine keeps the
+    // hand geom as side A of the contact, so the normal is turned around afterwards
+    CGeom<T> a_, b_;
+    auto hull_of = [&](CGeom<T>& g, const int type, const int geom) {
+      const bool hull = type == GEOM_MESH_ && geom >= 0;
+      const int gi = geom >= 0 ? geom : 0;
+      g.type = type;
+      g.nvert = hull ? M.geom_vertnum()[gi] : 0;
+      g.vadr = hull ? M.geom_vertadr()[gi] : 0;
+      g.flip = hull ? M.geom_vertflip()[gi] : 0;
+      g.graph = (MESH > 1 && hull) ? M.geom_vertgraph()[gi] : 0;
+    };
     if (key) {
-      T s, c;
-      N::sincos(S.qpos[(size_t)env * M.nv + M.key_dof()[kk]], &s, &c);
-      const T hx = M.key_half()[3 * kk];
-      posB[0] = M.key_pos()[3 * kk] - hx + hx * c; posB[1] = M.key_pos()[3 * kk + 1]; posB[2] = M.key_pos()[3 * kk + 2] - hx * s;
-      mB[0] = c; mB[1] = 0; mB[2] = s; mB[3] = 0; mB[4] = 1; mB[5] = 0; mB[6] = -s; mB[7] = 0; mB[8] = c;
-      sB = M.key_half() + 3 * kk;
-      pB = M.key_cparam();
-      invw += M.key_invw_body()[kk];
+      hull_of(a_, GEOM_BOX_, -1); hull_of(b_, GEOM_MESH_, ga);
+#pragma unroll
+      for (int i = 0; i < 3; i++) { a_.pos[i] = posB[i]; a_.size[i] = sB[i]; b_.pos[i] = posA[i]; b_.size[i] = M.geom_size()[3 * ga + i]; }
+#pragma unroll
+      for (int i = 0; i < 9; i++) { a_.mat[i] = mB[i]; b_.mat[i] = mA[i]; }
     } else {
-      const T* fb = B.gframe + ((size_t)env * 64 + gbi) * 12;
+      hull_of(a_, M.geom_type()[ga], ga); hull_of(b_, GEOM_MESH_, gbi);
 #pragma unroll
-      for (int k = 0; k < 3; k++) posB[k] = fb[k];
+      for (int i = 0; i < 3; i++) { a_.pos[i] = posA[i]; a_.size[i] = M.geom_size()[3 * ga + i]; b_.pos[i] = posB[i]; b_.size[i] = sB[i]; }
 #pragma unroll
-      for (int k = 0; k < 9; k++) mB[k] = fb[3 + k];
-      sB = M.geom_size() + 3 * gbi;
-      pB = M.geom_cparam() + 8 * gbi;
-      invw += M.geom_invw()[gbi];
+      for (int i = 0; i < 9; i++) { a_.mat[i] = mA[i]; b_.mat[i] = mB[i]; }
     }
-    RawCon<T> rc[3];
-    RawCon<T> bbx[5];   // (box-box points four to eight)
-    int n = 0;
-    if (ty == 0) {
-      if (in) n = capsule_capsule(rc, posA, mA, M.geom_size() + 3 * ga, posB, mB, sB);
-    } else if (ty == 1) {
-      if (in) n = capsule_box(rc, posA, mA, M.geom_size() + 3 * ga, posB, mB, sB);
-    } else if (ty == 2) {
-      if (in) n = box_box(rc, bbx, posA, mA, M.geom_size() + 3 * ga, posB, mB, sB);
-    } else {
-      if constexpr (MESH != 0) {
-        // (box, hull) in geom-type order when the partner is a key: the key is geom 1 of the pair; the engine keeps the
-        // hand geom as side A of the contact, so the normal is turned around afterwards
-        CGeom<T> a_, b_;
-        auto hull_of = [&](CGeom<T>& g, const int type, const int geom) {
-          const bool hull = type == GEOM_MESH_ && geom >= 0;
-          const int gi = geom >= 0 ? geom : 0;
-          g.type = type;
-          g.nvert = hull ? M.geom_vertnum()[gi] : 0;
-          g.vadr = hull ? M.geom_vertadr()[gi] : 0;
-          g.flip = hull ? M.geom_vertflip()[gi] : 0;
-          g.graph = (MESH > 1 && hull) ? M.geom_vertgraph()[gi] : 0;
-        };
-        if (key) {
-          hull_of(a_, GEOM_BOX_, -1); hull_of(b_, GEOM_MESH_, ga);
-#pragma unroll
-          for (int i = 0; i < 3; i++) { a_.pos[i] = posB[i]; a_.size[i] = sB[i]; b_.pos[i] = posA[i]; b_.size[i] = M.geom_size()[3 * ga + i]; }
-#pragma unroll
-          for (int i = 0; i < 9; i++) { a_.mat[i] = mB[i]; b_.mat[i] = mA[i]; }
-        } else {
-          hull_of(a_, M.geom_type()[ga], ga); hull_of(b_, GEOM_MESH_, gbi);
-#pragma unroll
-          for (int i = 0; i < 3; i++) { a_.pos[i] = posA[i]; a_.size[i] = M.geom_size()[3 * ga + i]; b_.pos[i] = posB[i]; b_.size[i] = sB[i]; }
-#pragma unroll
-          for (int i = 0; i < 9; i++) { a_.mat[i] = mA[i]; b_.mat[i] = mB[i]; }
-        }
-        RawCon<T> rcm[1];
-        const int nm = convex_mpr_wave<T, (MESH > 1)>(rcm, &a_, &b_, M.mesh_vert(), M.hull_vert, M.hull_graph, in);
-        if (in) {
-          n = nm; rc[0] = rcm[0];
-          if (key) { rc[0].n[0] = -rc[0].n[0]; rc[0].n[1] = -rc[0].n[1]; rc[0].n[2] = -rc[0].n[2]; }
-        }
-      }
-    }
-    // ---- the records: contact + its parameters [MJ: mj_contactParam, mj_makeImpedance] (as the one-kernel stage's `emit`)
+    RawCon<T> rcm[1];
+    const int nm = convex_mpr_wave<T, (MESH > 1)>(rcm, &a_, &b_, M.mesh_vert(), M.hull_vert, M.hull_graph, in);
     if (in) {
-      const T* pA = M.geom_cparam() + 8 * ga;
-      T solref0 = (T)0.5 * (pA[0] + pB[0]);
-      const T solref1 = (T)0.5 * (pA[1] + pB[1]);
-      T solimp[5];
+      n = nm; rc[0] = rcm[0];
+      if (key) { rc[0].n[0] = -rc[0].n[0]; rc[0].n[1] = -rc[0].n[1]; rc[0].n[2] = -rc[0].n[2]; }
+    }
+  }
+  // ---- the records: contact + its parameters [MJ: mj_contactParam, mj_makeImpedance] (as the one-kernel stage's `emit`)
+  if (in) {
+    const T* pA = M.geom_cparam() + 8 * ga;
+    T solref0 = (T)0.5 * (pA[0] + pB[0]);
+    const T solref1 = (T)0.5 * (pA[1] + pB[1]);
+    T solimp[5];
 #pragma unroll
-      for (int q = 0; q < 5; q++) solimp[q] = (T)0.5 * (pA[2 + q] + pB[2 + q]);
-      const T mu = fmax(pA[7], pB[7]);
-      if (solref0 > 0) solref0 = fmax(solref0, (T)2 * h);
-      const T dmax = fmin((T)0.9999, fmax((T)0.0001, solimp[1]));
-      const T Kc = (T)1 / fmax(RPK_MINVAL, dmax * dmax * solref0 * solref0 * solref1 * solref1);
-      const T Bc = (T)2 / fmax(RPK_MINVAL, dmax * solref0);
-      T* const res = B.cres + ((size_t)env * RPK_NRES + rb) * 12;
-      auto put = [&](const int slot, const RawCon<T>& r) {
-        const T imp = impedance(solimp, r.dist);
-        const T Rn = fmax(RPK_MINVAL, ((T)1 - imp) * invw * ((T)1 + mu * mu) / imp);
-        const T Rpy = fmax(RPK_MINVAL, (T)2 * mu * mu * Rn);
-        T* o = res + (size_t)slot * 12;
+    for (int q = 0; q < 5; q++) solimp[q] = (T)0.5 * (pA[2 + q] + pB[2 + q]);
+    const T mu = fmax(pA[7], pB[7]);
+    if (solref0 > 0) solref0 = fmax(solref0, (T)2 * h);
+    const T dmax = fmin((T)0.9999, fmax((T)0.0001, solimp[1]));
+    const T Kc = (T)1 / fmax(RPK_MINVAL, dmax * dmax * solref0 * solref0 * solref1 * solref1);
+    const T Bc = (T)2 / fmax(RPK_MINVAL, dmax * solref0);
+    T* const res = B.cres + ((size_t)env * RPK_NRES + rb) * 12;
+    auto put = [&](const int slot, const RawCon<T>& r) {
+      const T imp = impedance(solimp, r.dist);
+      const T Rn = fmax(RPK_MINVAL, ((T)1 - imp) * invw * ((T)1 + mu * mu) / imp);
+      const T Rpy = fmax(RPK_MINVAL, (T)2 * mu * mu * Rn);
+      T* o = res + (size_t)slot * 12;
 #pragma unroll
-        for (int k = 0; k < 3; k++) { o[k] = r.pos[k]; o[3 + k] = r.n[k]; }
-        o[6] = r.dist; o[7] = mu; o[8] = Kc * imp * r.dist; o[9] = Bc; o[10] = (T)1 / Rpy;
-      };
+      for (int k = 0; k < 3; k++) { o[k] = r.pos[k]; o[3 + k] = r.n[k]; }
+      o[6] = r.dist; o[7] = mu; o[8] = Kc * imp * r.dist; o[9] = Bc; o[10] = (T)1 / Rpy;
+    };
 #pragma unroll
-      for (int slot = 0; slot < 3; slot++) if (n > slot) put(slot, rc[slot]);
+    for (int slot = 0; slot < (TYPE >= 3 ? 1 : (TYPE == 2 ? 3 : 2)); slot++) if (n > slot) put(slot, rc[slot]);
+    if constexpr (TYPE == 2) {
       if (RPK_BOXBOX_MAX > 3 && n > 3) {
         for (int slot = 3; slot < n && slot < 8; slot++) put(slot, bbx[slot - 3]);
       }
-      B.cres_n[(size_t)env * RPK_NCAND + ci] = n;
     }
+    B.cres_n[(size_t)env * RPK_NCAND + ci] = n;
   }
+}
+
+#ifndef RPK_NARROW_WAVES
+#define RPK_NARROW_WAVES 2
+#endif
+template <typename T, int MESH>
+__global__ __launch_bounds__(64, RPK_NARROW_WAVES) void rp_narrow_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B) {
+  const int lane = (int)threadIdx.x;
+  const int* const tc = B.tcount + B.tcount_off;
+  // chunks of candidates of one list: the long routines first (hull buckets, box-box, capsule-box, capsule-capsule)
+  int first = 0;   // (first chunk of the list under test)
+#define RP_NARROW_LIST(TYPE_, LANES_)                                                                  \
+  for (int st_ = 0; st_ < RPK_NSTRIPE; st_++) {                                                        \
+    const int cnt_ = tc[st_ * RPK_NTYPE_PAD + TYPE_], nch_ = (cnt_ + (LANES_) - 1) / (LANES_);         \
+    int ch = (int)blockIdx.x;                                                                          \
+    if (ch < first) ch += (first - ch + (int)gridDim.x - 1) / (int)gridDim.x * (int)gridDim.x;         \
+    for (; ch < first + nch_; ch += (int)gridDim.x) {                                                  \
+      const int e = (ch - first) * (LANES_) + lane;                                                    \
+      rp_narrow_chunk<T, MESH, TYPE_>(M, S, B, st_, e, lane < (LANES_) && e < cnt_);                   \
+    }                                                                                                  \
+    first += nch_;                                                                                     \
+  }
+  if constexpr (MESH != 0) {
+    RP_NARROW_LIST(6, RPK_MPR_LANES) RP_NARROW_LIST(5, RPK_MPR_LANES) RP_NARROW_LIST(4, RPK_MPR_LANES) RP_NARROW_LIST(3, RPK_MPR_LANES)
+  }
+  RP_NARROW_LIST(2, 64) RP_NARROW_LIST(1, 64) RP_NARROW_LIST(0, 64)
+#undef RP_NARROW_LIST
 }

@@ -47,7 +47,7 @@ __global__ void rp_mark_valid_kernel(unsigned char* valid, const int* active, co
 #define RP_ORDER_BUCKETS 256
 #define RP_ORDER_CLASSES 8
 __global__ __launch_bounds__(512) void rp_order_kernel(int* order_all, const int* hdr, const int* active, int base, int n,
-                                                       int* heavy_list, int* heavy_cnt) {
+                                                       int* heavy_list, int* heavy_cnt, unsigned char* listed) {
   // (sorts the envs base .. base + n - 1 into order_all[base .. base + n - 1]; base is a multiple of 8.
   // One workgroup per residue class: eight short kernels side by side instead of one 1024-thread block.)
   const int x = blockIdx.x;
@@ -55,7 +55,9 @@ __global__ __launch_bounds__(512) void rp_order_kernel(int* order_all, const int
   // are independent); the counter is cleared by that stage's last workgroup
   if (heavy_list) {
     for (int e = x + RP_ORDER_CLASSES * (int)threadIdx.x; e < n; e += RP_ORDER_CLASSES * blockDim.x) {
-      if (hdr[(base + e) * 8 + 6] != 1 && !(active && active[base + e] == 0)) heavy_list[base + atomicAdd(heavy_cnt, 1)] = base + e;
+      const bool on = hdr[(base + e) * 8 + 6] != 1 && !(active && active[base + e] == 0);
+      if (on) heavy_list[base + atomicAdd(heavy_cnt, 1)] = base + e;
+      if (listed) listed[base + e] = on ? 1 : 0;   // (the snapshot the split position launches test: RpState::listed)
     }
   }
   if (!order_all) return;
@@ -239,14 +241,15 @@ struct Engine : EngineBase {
   bool deep = false;    // a trunk of 5..8 links (more than two forearm dofs): the RPK_MAXD_DEEP builds
   bool lean = false;    // light envs are stepped by rp_lean_solver_kernel (rp_solver2.hpp), the others by the full build
   // the position stage of the substeps as three launches: front part, pooled narrow phase (rp_collide.hpp), back part
-  bool split_capable = false, split_pos = false;
+  bool split_capable = false, split_stage = false;
+  bool fuse_lean_front = getenv("RP_FUSE_LF") && getenv("RP_FUSE_LF")[0] == '1';   // (lean solver stage + front part in one launch)
   const int narrow_grid_env = getenv("RP_NARROW_GRID") ? atoi(getenv("RP_NARROW_GRID")) : 0;
   int split_position(int on) override {
     if (on && !split_capable) return fail("rp_set_split_position_stage: the split stage exists for the fp64 default-depth builds only");
-    split_pos = on != 0;
+    split_stage = on != 0;
     return 0;
   }
-  int split_position_on() const override { return split_pos ? 1 : 0; }
+  int split_position_on() const override { return split_stage ? 1 : 0; }
   int lean_solver(int on) override {
     if (on && (deep || sizeof(T) != 8)) return fail("rp_set_lean_solver: the lean solver stage exists for the fp64 default builds only");
     lean = on != 0; S.lean = on > 0 ? on : 0;   // (on > 1: the light class capped at that many Jacobian entries)
@@ -453,7 +456,7 @@ struct Engine : EngineBase {
     {
       const char* sp = getenv("RP_SPLIT_POS");
       split_capable = sizeof(T) == 8 && !deep;
-      split_pos = split_capable && !(sp && sp[0] == '0');
+      split_stage = split_capable && !(sp && sp[0] == '0');
       if (split_capable) {
         B.frames = dalloc<T>(E * RPK_NFRAME * 64);
         B.gframe = dalloc<T>(E * 64 * 12);
@@ -461,9 +464,9 @@ struct Engine : EngineBase {
         B.ncand = dalloc<int>(E);
         B.cres = dalloc<T>(E * RPK_NRES * 12);
         B.cres_n = dalloc<int>(E * RPK_NCAND);
-        B.tstride = E * RPK_NCAND;
-        B.tlist = dalloc<int>((size_t)RPK_NTYPE * B.tstride * 4);
-        B.tcount = dalloc<int>(kMaxSlices * RPK_NTYPE);   // (zero-filled)
+        B.tstride = ((E + RPK_NSTRIPE - 1) / RPK_NSTRIPE + 1) * RPK_NCAND;   // (+1: a slice's stripe may hold one env more than cnt / 8)
+        B.tlist = dalloc<int>((size_t)RPK_NTYPE * RPK_NSTRIPE * B.tstride * 4);
+        B.tcount = dalloc<int>(kMaxSlices * RPK_NSTRIPE * RPK_NTYPE_PAD);   // (zero-filled)
         B.tcount_off = 0;
         hipMemset(B.ncand, 0xFF, sizeof(int) * E);        // -1: no front part has run
         hipMemset(B.frames, 0xFF, sizeof(T) * E * RPK_NFRAME * 64);
@@ -493,6 +496,7 @@ struct Engine : EngineBase {
     }
     S.cost_pos = dalloc<int>(E); S.cost_sol = dalloc<int>(E);
     d_heavy = dalloc<int>(E); d_heavy_cnt = dalloc<int>(2 * kMaxSlices);   // (zero-filled)
+    d_listed = dalloc<unsigned char>(E); S.listed = d_listed;
     d_heavy_peak = dalloc<int>(kMaxSlices);
     if (hipHostMalloc((void**)&h_heavy_peak, sizeof(int) * kMaxSlices) != hipSuccess) { (void)hipGetLastError(); h_heavy_peak = nullptr; }
     else for (int i = 0; i < kMaxSlices; i++) h_heavy_peak[i] = -1;
@@ -517,6 +521,7 @@ struct Engine : EngineBase {
   // the envs outside the light capacity class, compacted per slice (entries base .. of slice sl; d_heavy_cnt[2 sl]
   // = entries, [2 sl + 1] = finished workgroups of the stage that walks them)
   int *d_heavy = nullptr, *d_heavy_cnt = nullptr;
+  unsigned char* d_listed = nullptr;   // 1 = on the list of the substep just solved (rp_order_kernel's snapshot)
   // Grid of the full-capacity solver stage.  Each of its workgroups needs a whole idle SIMD (512 registers) and 55 KB of
   // LDS even to find the list empty, and the slice's join waits for the last of them: the grid follows the longest
   // list the stage saw recently -- read back one step late, never waited for (a list longer than the grid is walked
@@ -543,8 +548,20 @@ struct Engine : EngineBase {
     return !capable ? 0 : (fused == 1 ? 1 : (fused == 2 && n_slices == 0 ? (auto_mode == 3 ? 1 : 2) : 0));
   }
   bool split_heavy_pos = !(getenv("RP_SPLIT_HEAVY_POS") && getenv("RP_SPLIT_HEAVY_POS")[0] == '0');   // (experiment switch)
-  const bool x_no_heavy = getenv("RP_X_NO_HEAVY") && getenv("RP_X_NO_HEAVY")[0] == '1';
-  const bool x_order_twice = getenv("RP_X_ORDER_TWICE") && getenv("RP_X_ORDER_TWICE")[0] == '1';
+  // MEASUREMENT-ONLY switches (they skip or repeat work: wrong physics / wasted time).  Compiled in only with
+  // -DRP_EXPERIMENTS, and loud when set: a stray environment variable must not silently change a production step.
+#ifdef RP_EXPERIMENTS
+  static bool x_switch(const char* name) {
+    const char* v = getenv(name);
+    const bool on = v && v[0] == '1';
+    if (on) fprintf(stderr, "librp_engine: MEASUREMENT-ONLY switch %s=1 is active -- results are not valid physics\n", name);
+    return on;
+  }
+  const bool x_no_heavy = x_switch("RP_X_NO_HEAVY");
+  const bool x_order_twice = x_switch("RP_X_ORDER_TWICE");
+#else
+  static constexpr bool x_no_heavy = false, x_order_twice = false;
+#endif
   bool companion = !(getenv("RP_COMPANION") && getenv("RP_COMPANION")[0] == '0');   // (experiment: the full-capacity launch on the slice's own stream)
   // (Experiment, RP_HEAVY_PRIORITY=1: the companion stream at the highest priority the device offers.  The idea: the
   // full-capacity launch and the lean one become ready together, and whichever is dispatched first takes the machine
@@ -572,7 +589,7 @@ struct Engine : EngineBase {
   }
   // (each of these workgroups needs a whole idle SIMD, also just to find the list empty: 512 of them delayed the slice's join;
   // measured 64 ... 128 best on configs 2-4, 16 starves config 3)
-  const int kHeavyGrid = getenv("RP_HEAVY_GRID") ? atoi(getenv("RP_HEAVY_GRID")) : 128;   // (one wave of that stage owns a SIMD: half the chip at most)
+  const int kHeavyGrid = getenv("RP_HEAVY_GRID") ? (atoi(getenv("RP_HEAVY_GRID")) > 0 ? atoi(getenv("RP_HEAVY_GRID")) : 1) : 128;   // (one wave of that stage owns a SIMD: half the chip at most)
   const bool heavy_grid_fixed = getenv("RP_HEAVY_GRID") != nullptr;   // (experiment: RP_HEAVY_GRID pins the grid)
   // acceleration-stage sensors (rp_set_acc_sensors): state before the last Euler step, outputs
   bool sensors_on = false;
@@ -826,29 +843,29 @@ struct Engine : EngineBase {
         }
       };
       // the position / velocity stage of substep k as front part, pooled narrow phase, back part (same results, bit for bit)
-      auto launch_pos_split = [&](const RpState<T>& q, int k) {
+      // (front: 1 = the front part as a launch of its own, 2 = fused behind the lean solver stage (rp_lean_front_kernel:
+      // `q` then is that stage's state), 0 = already done; rest: the pooled narrow phase and the back part)
+      auto launch_pos_split = [&](const RpState<T>& q, int k, int front = 1, bool rest = true) {
         if constexpr (sizeof(T) == 8) {
           RpStage<T> Bs = B;
-          Bs.tcount_off = sl * RPK_NTYPE;
+          Bs.tcount_off = sl * RPK_NSTRIPE * RPK_NTYPE_PAD;
           int ng = narrow_grid_env > 0 ? narrow_grid_env : cnt / 2;
           ng = ng < 64 ? 64 : (ng > 2048 ? 2048 : ng);
-          if (mesh && graph) {
-            hipLaunchKernelGGL((rp_pos_front_kernel<T, 2>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);
-            hipLaunchKernelGGL((rp_narrow_kernel<T, 2>), dim3(ng), dim3(64), 0, st, M, q, Bs);
-            hipLaunchKernelGGL((rp_pos_back_kernel<T, 2>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);
-          } else if (mesh) {
-            hipLaunchKernelGGL((rp_pos_front_kernel<T, 1>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);
-            hipLaunchKernelGGL((rp_narrow_kernel<T, 1>), dim3(ng), dim3(64), 0, st, M, q, Bs);
-            hipLaunchKernelGGL((rp_pos_back_kernel<T, 1>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);
-          } else {
-            hipLaunchKernelGGL((rp_pos_front_kernel<T, 0>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);
-            hipLaunchKernelGGL((rp_narrow_kernel<T, 0>), dim3(ng), dim3(64), 0, st, M, q, Bs);
-            hipLaunchKernelGGL((rp_pos_back_kernel<T, 0>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);
+#define RP_SPLIT_LAUNCH(MESH_)                                                                                                     \
+          {                                                                                                                        \
+            if (front == 1) hipLaunchKernelGGL((rp_pos_front_kernel<T, MESH_>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);     \
+            if (front == 2) hipLaunchKernelGGL((rp_lean_front_kernel<T, MESH_>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);    \
+            if (rest) {                                                                                                            \
+              hipLaunchKernelGGL((rp_narrow_kernel<T, MESH_>), dim3(ng), dim3(64), 0, st, M, q, Bs);                                \
+              hipLaunchKernelGGL((rp_pos_back_kernel<T, MESH_>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);                    \
+            }                                                                                                                      \
           }
+          if (mesh && graph) RP_SPLIT_LAUNCH(2) else if (mesh) RP_SPLIT_LAUNCH(1) else RP_SPLIT_LAUNCH(0)
+#undef RP_SPLIT_LAUNCH
         }
       };
       auto launch_pos_on = [&](const RpState<T>& q, int k) {
-        if (split_pos && !deep && sizeof(T) == 8) { launch_pos_split(q, k); return; }
+        if (split_stage && !deep && sizeof(T) == 8) { launch_pos_split(q, k); return; }
         if (deep && mesh && graph) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP, 2>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
         else if (mesh && graph) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD, 2>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
         else if (deep && mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP, 1>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
@@ -868,7 +885,7 @@ struct Engine : EngineBase {
         if (fused_now) {
           // heaviest envs first (4096 envs are two rounds of resident waves), from the hand-over just written
           if (cost_order)
-            hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(order_threads_for(cnt)), 0, st, d_order, B.hdr, s.active, base, cnt, (int*)nullptr, (int*)nullptr);
+            hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(order_threads_for(cnt)), 0, st, d_order, B.hdr, s.active, base, cnt, (int*)nullptr, (int*)nullptr, (unsigned char*)nullptr);
           RpState<T> sf = ss;
           sf.heavy_list = d_heavy + base; sf.heavy_cnt = d_heavy_cnt + 2 * sl; sf.heavy_done = d_heavy_cnt + 2 * sl + 1;
           sf.heavy_peak = capturing ? nullptr : d_heavy_peak + sl;
@@ -902,7 +919,7 @@ struct Engine : EngineBase {
       // ... then n_sub x (mj_step2; mj_step1): dm_control's legacy order.  Two kernels per substep instead
       // of one fused launch: each half fits in registers, the hand-over (RpStage) stays in L2 / Infinity Cache.
       int hgrid_step = 0;   // (the full-capacity stage's grid: one choice per step and slice)
-      bool split_step = false;
+      bool split_step = false, fuse_lf = false;
       for (int k = 0; k < nsub; k++) {
         const bool probe = timeit && sl == 0 && k == (int)(step_calls % (unsigned)nsub) && !ev_trial[slot];
         const bool sense = sensors_on && k == nsub - 1;
@@ -911,10 +928,10 @@ struct Engine : EngineBase {
         const bool listed = lean && d_heavy != nullptr;
         if (cost_order || listed)
           hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(order_threads_for(cnt)), 0, st, cost_order ? d_order : nullptr, B.hdr, s.active, base, cnt,
-                             listed ? d_heavy : nullptr, listed ? d_heavy_cnt + 2 * sl : nullptr);
+                             listed ? d_heavy : nullptr, listed ? d_heavy_cnt + 2 * sl : nullptr, listed ? d_listed : nullptr);
         // (RP_X_ORDER_TWICE=1: MEASUREMENT ONLY -- the order pass a second time (no list): what the pass costs the step)
         if (x_order_twice && cost_order)
-          hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(order_threads_for(cnt)), 0, st, d_order, B.hdr, s.active, base, cnt, (int*)nullptr, (int*)nullptr);
+          hipLaunchKernelGGL(rp_order_kernel, dim3(RP_ORDER_CLASSES), dim3(order_threads_for(cnt)), 0, st, d_order, B.hdr, s.active, base, cnt, (int*)nullptr, (int*)nullptr, (unsigned char*)nullptr);
         if (sense) {  // the state this substep's forces belong to (the solver stage integrates in place)
           HIP_OK(hipMemcpyAsync(d_qpos_prev + (size_t)base * nv, S.qpos + (size_t)base * nv, sizeof(T) * (size_t)cnt * nv, hipMemcpyDeviceToDevice, st));
           HIP_OK(hipMemcpyAsync(d_qvel_prev + (size_t)base * nv, S.qvel + (size_t)base * nv, sizeof(T) * (size_t)cnt * nv, hipMemcpyDeviceToDevice, st));
@@ -944,7 +961,10 @@ struct Engine : EngineBase {
           // (the split pays when the list is long: config 3 446 -> 455 k; on a batch whose lists are empty the extra
           // launch and the later join cost 1-4 %: config 2 657 -> 632 ... 651 k -- so it follows the same lagged estimate)
           hgrid = capturing ? (cnt < kHeavyGrid ? cnt : kHeavyGrid) : (k == 0 ? (hgrid_step = heavy_grid_for(sl, cnt)) : hgrid_step);
-          split_step = split_heavy_pos && hs != st && !deep && !graph && sizeof(T) == 8 && heavy_est[sl] >= 4.0;
+          // (the lean solver stage fused with the front part of the split position stage: the listed envs then always
+          // take their position stage with them to the companion stream)
+          fuse_lf = fuse_lean_front && split_stage && lean && hs != st && !deep && !graph && sizeof(T) == 8;
+          split_step = (split_heavy_pos && hs != st && !deep && !graph && sizeof(T) == 8 && heavy_est[sl] >= 4.0) || fuse_lf;
           sh.heavy_keep = (split_step && !sense) ? 1 : 0;
         }
         // (RP_X_NO_HEAVY=1: MEASUREMENT ONLY -- the full-capacity launch is suppressed, envs outside the light class are
@@ -958,7 +978,9 @@ struct Engine : EngineBase {
         // (config 3: 0.27 ms of every 0.81 ms substep); the streams join after it, in front of the next order pass
         const bool split_pos = split_step && listed && !sense;
         if (hs != st && !split_pos) HIP_OK(hipEventRecord(ev_hjoin[sl], hs));
-        if (lean) hipLaunchKernelGGL((rp_lean_solver_kernel<T>), dim3(cnt), dim3(64), 0, st, M, ss, B);
+        const bool fuse_now = fuse_lf && split_pos && !sense;
+        if (fuse_now) { RpState<T> sf_ = ss; sf_.skip_heavy = 1; launch_pos_split(sf_, k, 2, false); }
+        else if (lean) hipLaunchKernelGGL((rp_lean_solver_kernel<T>), dim3(cnt), dim3(64), 0, st, M, ss, B);
         if (hs != st && !split_pos) HIP_OK(hipStreamWaitEvent(st, ev_hjoin[sl], 0));
         if (probe) HIP_OK(hipEventRecord(sv1[slot], st));
         if (sense) {
@@ -982,7 +1004,8 @@ struct Engine : EngineBase {
           HIP_OK(hipEventRecord(ev_hjoin[sl], hs));
           RpState<T> sm_ = ss;
           sm_.skip_heavy = 1;
-          launch_pos_on(sm_, k);
+          if (fuse_now) launch_pos_split(sm_, k, 0, true);
+          else launch_pos_on(sm_, k);
           HIP_OK(hipStreamWaitEvent(st, ev_hjoin[sl], 0));
         } else {
           launch_pos_on(ss, k);

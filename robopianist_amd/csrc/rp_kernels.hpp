@@ -2,6 +2,7 @@
 // constraint-solver stage), their LDS layouts, and the reset kernel.  Lane roles, tables and
 // hand-over buffers: rp_model.hpp.
 #pragma once
+#include <type_traits>
 #include "rp_model.hpp"
 #include "rp_wave.hpp"
 #include "rp_narrow.hpp"
@@ -82,6 +83,32 @@ struct Smem<T, 0, MD> : SmemShared<T> {
   T keyvec[1][RPK_NKEYS];
   int cA[RPK_NCL], cB[RPK_NCL], cgA[RPK_NCL], cgB[RPK_NCL];
 };
+// ---- front part of the split position stage (PART 1): kinematics, composite inertias, broad phase, prefilters.  Only
+// what those need: 13 312 B, so that TWELVE workgroups fit a CU (three waves per SIMD; the part needs 164 registers)
+// where the whole stage's 19.7 KB allow eight.
+template <typename T, int MD>
+struct SmemFront {
+  unsigned prof[RPK_NPROF_STAGE];
+  T xpos[RPK_NLX(MD)][3];
+  T xmat[RPK_NLX(MD)][9];
+  union {
+    T cdof[RPK_NLX(MD)][6];
+    struct {
+      float gbox[RPK_NBOXF][12];
+      unsigned short glist[RPK_GLIST];
+      unsigned short klist[RPK_KLIST];
+    };
+  };
+  union {
+    T acc[RPK_NLX(MD)][10];
+    struct {
+      float gax[RPK_WAVE][4];
+      float grr[RPK_WAVE];
+      int clist[RPK_NCAND];      // the candidates that passed the prefilters (ga | gb << 16)
+    };
+  };
+  T gpos[RPK_WAVE][3];
+};
 // ---- sensor stage (MODE 2): the position / velocity stage of the state BEFORE the last Euler
 // step, plus what the acceleration-stage sensors need (mj_rnePostConstraint, mj_sensorAcc)
 template <typename T, int MD>
@@ -154,10 +181,11 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
   }
   if constexpr (MODE == 0) {
     if constexpr (PART == 2) { if (B.ncand[env] < 0) return; }   // (the front part did not run for this env: masked, or heavy)
-    else if (S.skip_heavy && B.hdr[env * 8 + 6] != 1) return;   // (its position stage follows its solve on the companion stream)
+    else if (S.skip_heavy && S.listed[env]) return;   // (its position stage follows its solve on the companion stream)
   }
   const int env_active = S.active ? S.active[env] : 1;  // tested after the prologue loads are in flight
-  Smem<T, MODE, MD>& sm = rp_smem<Smem<T, MODE, MD>, EXT>(ext);
+  using SM_ = std::conditional_t<(MODE == 0 && PART == 1), SmemFront<T, MD>, Smem<T, MODE, MD>>;
+  SM_& sm = rp_smem<SM_, EXT>(ext);
   constexpr int TC = MD > 9 ? 8 : 4;            // trunk links the chain-blocked solver holds
   constexpr int NT = TC * (TC + 1) / 2, NREC = NT + TC;  // packed trunk block / per-chain record
   // the chain records of the tree elimination live at the end of the dense block's LDS (sm.H); the
@@ -1299,17 +1327,21 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     int* const ovi = B.covi + (size_t)env * (RPK_NC - RPK_NCL) * 4;
     // field f of MY contact's record (contact lanes): 0-2 position, 3-5 normal, 6 dist, 7 mu, 8 kterm, 9 B, 10 D
     auto conf = [&](const int f) -> T {
-      T v;
-      if (NCX <= RPK_NCL || lane < RPK_NCL)
-        v = f < 3 ? sm.cpos[lane][f] : (f < 6 ? sm.cn[lane][f - 3] : (f == 6 ? sm.cdist[lane] : sm.cpar[lane][f - 7]));
-      else v = ovf[(size_t)(lane - RPK_NCL) * 12 + f];
+      T v = 0;
+      if constexpr (PART != 1) {
+        if (NCX <= RPK_NCL || lane < RPK_NCL)
+          v = f < 3 ? sm.cpos[lane][f] : (f < 6 ? sm.cn[lane][f - 3] : (f == 6 ? sm.cdist[lane] : sm.cpar[lane][f - 7]));
+        else v = ovf[(size_t)(lane - RPK_NCL) * 12 + f];
+      }
       return v;
     };
     // ... and its integer fields: 0 link A, 1 link B (or RPK_KEYBASE + key), 2 / 3 model geom ids
     auto coni = [&](const int f) -> int {
-      int v;
-      if (NCX <= RPK_NCL || lane < RPK_NCL) v = f == 0 ? sm.cA[lane] : (f == 1 ? sm.cB[lane] : (f == 2 ? sm.cgA[lane] : sm.cgB[lane]));
-      else v = ovi[(size_t)(lane - RPK_NCL) * 4 + f];
+      int v = 0;
+      if constexpr (PART != 1) {
+        if (NCX <= RPK_NCL || lane < RPK_NCL) v = f == 0 ? sm.cA[lane] : (f == 1 ? sm.cB[lane] : (f == 2 ? sm.cgA[lane] : sm.cgB[lane]));
+        else v = ovi[(size_t)(lane - RPK_NCL) * 4 + f];
+      }
       return v;
     };
     if constexpr (PART != 2) {
@@ -1355,7 +1387,8 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-          sm.xpos[lane][k] = xp[k]; sm.xaxis[lane][k] = axw[k]; sm.xanchor[lane][k] = anw[k];
+          sm.xpos[lane][k] = xp[k];
+          if constexpr (PART != 1) { sm.xaxis[lane][k] = axw[k]; sm.xanchor[lane][k] = anw[k]; }   // (the front part hands them over in RpStage::frames)
         }
 #pragma unroll
         for (int k = 0; k < 9; k++) sm.xmat[lane][k] = xm[k];
@@ -1436,8 +1469,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     for (int s = 0; s < 2; s++) {
       if (isk[s]) {
         N::sincos(q[1 + s], &ksin[s], &kcos[s]);
-        sm.kq[kid[s]] = q[1 + s];
-        sm.keyslot[kid[s]] = -1;
+        if constexpr (PART != 1) { sm.kq[kid[s]] = q[1 + s]; sm.keyslot[kid[s]] = -1; }
       }
     }
     WSYNC();
@@ -1815,17 +1847,18 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
               if (gen_phase == 0) sm.clist[idx] = (a < bit ? a : bit) | ((a < bit ? bit : a) << 16);
               else sm.clist[idx] = bit | ((RPK_KEYBASE + a) << 16);
             }
-          } else if (has) {
+          } else if constexpr (PART != 1) { if (has) {
             // (a static pair is owned by either of its lanes: geom 1 of the pair is the lower one)
             if (gen_phase == 0) { sm.work[idx][0] = (short)(a < bit ? a : bit); sm.work[idx][1] = (short)(a < bit ? bit : a); }
             else { sm.work[idx][0] = (short)bit; sm.work[idx][1] = (short)(RPK_KEYBASE + a); }
-          }
+          } }
           nwork += __popcll(mk);
         }
       }
       }
       PROF(23);   // (drain rounds: candidate prefilters)
       if constexpr (PART == 1) break;   // (everything is on the candidate list)
+      else {
       if (nwork == 0) break;   // (the masks are empty and nothing is pending)
       WSYNC();
       // ---- narrow phase on the first min(64, nwork) candidates
@@ -2044,6 +2077,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       if (mv) { sm.work[lane][0] = w0; sm.work[lane][1] = w1; }
       nwork -= nproc;
       WSYNC();
+      }   // (PART != 1)
     }
     if constexpr (PART == 1) {
       // ---- split stage, front part: the candidate list leaves the wave.  Every candidate gets its result records
@@ -2055,7 +2089,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       WSYNC();
       int rbase = 0;
       int* const cl_ = B.cand + (size_t)env * RPK_NCAND * 2;
-      int* const tc_ = B.tcount + B.tcount_off;
+      int* const tc_ = B.tcount + B.tcount_off + (env & (RPK_NSTRIPE - 1)) * RPK_NTYPE_PAD;
       for (int c0 = 0; c0 < nc_; c0 += 64) {
         const int i = c0 + lane;
         const bool in = i < nc_;
@@ -2068,7 +2102,12 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
           const int tb = M.geom_type()[gb];
           ty = tb == GEOM_CAPSULE_ ? 0 : ((tb == GEOM_MESH_ || ta == GEOM_MESH_) ? 3 : (ta == GEOM_CAPSULE_ ? 1 : 2));
         }
-        const int wdt = ty == 2 ? 8 : (ty == 3 ? 1 : 2);
+        if (MESH != 0 && ty == 3) {   // hull pairs: the bucket of lanes that need the same vertex scans (rp_model.hpp)
+          const int hb_ = gb >= RPK_KEYBASE ? ga : gb;   // (side B of the refinement: the hull)
+          const int vlast = M.geom_vertadr()[M.ngeom > 0 ? M.ngeom - 1 : 0];   // (geoms are sorted by type: hulls last)
+          ty = 3 + ((gb < RPK_KEYBASE && ta == GEOM_MESH_) ? 1 : 0) + (M.geom_vertadr()[hb_] != vlast ? 2 : 0);
+        }
+        const int wdt = ty == 2 ? 8 : (ty >= 3 ? 1 : 2);
         int incl = in ? wdt : 0;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
@@ -2076,21 +2115,24 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         const bool ok = in && myb + wdt <= RPK_NRES;
         if (__ballot(in && !ok) != 0ull) warn |= 16;   // (its records do not fit: the candidate is dropped, flagged)
         rbase += bcast(incl, 63);
-        const unsigned long long m0 = __ballot(ok && ty == 0), m1 = __ballot(ok && ty == 1), m2 = __ballot(ok && ty == 2),
-                                 m3 = __ballot(ok && ty == 3);
-        const unsigned long long mine = ty == 0 ? m0 : (ty == 1 ? m1 : (ty == 2 ? m2 : m3));
-        int tb_ = 0;
-        {
-          const int cntT = lane == 0 ? __popcll(m0) : (lane == 1 ? __popcll(m1) : (lane == 2 ? __popcll(m2) : __popcll(m3)));
-          if (lane < RPK_NTYPE && cntT > 0) tb_ = atomicAdd(&tc_[lane], cntT);
+        unsigned long long mine = 0ull;
+        int cntT = 0;
+#pragma unroll
+        for (int t = 0; t < RPK_NTYPE; t++) {
+          const unsigned long long mt = __ballot(ok && ty == t);
+          if (ty == t) mine = mt;
+          if (lane == t) cntT = __popcll(mt);
         }
+        int tb_ = 0;
+        if (lane < RPK_NTYPE && cntT > 0) tb_ = atomicAdd(&tc_[lane], cntT);
         const int tbase = __shfl(tb_, ty, 64);
         if (in) {
           cl_[2 * i] = pair; cl_[2 * i + 1] = (ok ? myb : 0) | (ty << 16);
           B.cres_n[(size_t)env * RPK_NCAND + i] = 0;
         }
         if (ok) {
-          int4* e_ = (int4*)(B.tlist + ((size_t)ty * B.tstride + (size_t)S.env_base * RPK_NCAND + tbase + __popcll(mine & lanemask_lt(lane))) * 4);
+          int4* e_ = (int4*)(B.tlist + (((size_t)ty * RPK_NSTRIPE + (env & (RPK_NSTRIPE - 1))) * B.tstride + (size_t)(S.env_base / RPK_NSTRIPE) * RPK_NCAND + tbase +
+                                       __popcll(mine & lanemask_lt(lane))) * 4);
           int4 v_; v_.x = env; v_.y = pair; v_.z = myb; v_.w = i;
           *e_ = v_;
         }
@@ -2796,9 +2838,30 @@ __global__ __launch_bounds__(64, 2) void rp_pos_front_kernel(RpModel<T> M, RpSta
 }
 template <typename T, int MESH>
 __global__ __launch_bounds__(64, 2) void rp_pos_back_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep, int nsub) {
-  if (blockIdx.x == 0 && threadIdx.x < RPK_NTYPE) B.tcount[B.tcount_off + threadIdx.x] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < RPK_NSTRIPE * RPK_NTYPE_PAD) B.tcount[B.tcount_off + threadIdx.x] = 0;
   const int env = S.order ? S.order[S.env_base + blockIdx.x] : S.env_base + (int)blockIdx.x;
   rp_stage_body<T, 0, 0, RPK_MAXD, MESH, false, 2>(M, S, B, substep, nsub, env, nullptr, (int)threadIdx.x);
+}
+
+// Lean solver stage + front part of the position stage of the state it produces, one wave per env in ONE launch (the
+// per-stage schedules with the split position stage): one launch boundary -- one tail of waves waiting for the slowest
+// env -- less per substep, and the front part starts from an env's new state the moment its solve ends.  Envs outside
+// the light class are not touched: their full-capacity solve and their (one-kernel) position stage run on the
+// companion stream (RpState::listed is rp_order_kernel's snapshot of the list).
+template <typename T, int MESH>
+__global__ __launch_bounds__(64, 2) void rp_lean_front_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep, int nsub) {
+  using namespace rpk;
+  constexpr size_t NB = sizeof(SmemLean<T>) > sizeof(SmemFront<T, RPK_MAXD>) ? sizeof(SmemLean<T>) : sizeof(SmemFront<T, RPK_MAXD>);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NB];
+  const int env = S.order ? S.order[S.env_base + blockIdx.x] : S.env_base + (int)blockIdx.x;
+  if (S.active && S.active[env] == 0) return;
+  if (S.listed[env]) return;
+  int lane = (int)threadIdx.x;
+  asm volatile("" : "+v"(lane));
+  rp_lean_solver_body<T, true>(M, S, B, env, smem, lane);
+  RPK_STAGE_FENCE();
+  asm volatile("" : "+v"(lane));
+  rp_stage_body<T, 0, 0, RPK_MAXD, MESH, true, 1>(M, S, B, substep, nsub, env, smem, lane);
 }
 
 // The position / velocity stage of the envs on the compacted list (the envs outside the light class), on the companion

@@ -50,7 +50,19 @@
 // candidates that passed the fp32 prefilters and the narrow-phase results they map to
 #define RPK_NCAND 256    // candidates per env and mj_step (typical: 20-30); beyond: RP_WARN_WORK_FULL
 #define RPK_NRES 384     // result records per env: 1 per capsule-capsule / hull pair, 2 per capsule-box, 8 per box-box
-#define RPK_NTYPE 4      // pooled narrow-phase lists: 0 capsule-capsule, 1 capsule-box, 2 box-box, 3 hull pairs (MPR)
+// pooled narrow-phase lists: 0 capsule-capsule, 1 capsule-box, 2 box-box, 3 .. 6 hull pairs (MPR) in four buckets:
+// 3 + (side A is a hull too) + 2 * (the hull of side B uses another vertex set than the model's last hull) -- a wave
+// walking the portal refinement scans, on every trip, every vertex set ANY of its lanes needs on either side, so lanes
+// that need the same scans belong together (any bucketing is correct; this one fits "two fingertip shapes")
+#define RPK_NTYPE 7
+#define RPK_NTYPE_PAD 8  // counters per slice and stripe
+// every list is kept in RPK_NSTRIPE stripes (env & 7): the front part's waves -- thousands per launch -- reserve their
+// entries with one returning atomic per list, and on ONE counter per list those serialise (measured: 29 k cycles per
+// wave for the hand-over block, most of it waiting for the atomics)
+#define RPK_NSTRIPE 8
+#ifndef RPK_MPR_LANES    // candidates per wave on the hull lists (the wave walks as many trips as its slowest lane needs)
+#define RPK_MPR_LANES 64
+#endif
 #define RPK_NFRAME 18    // per-link frame fields handed from the front to the back part: xpos 3, xmat 9, xaxis 3, xanchor 3
 #define RPK_KLIST 192    // geom-key candidates per mj_step (typical: 8.5; with RPK_GLIST and the box table inside the 2496 B the link table leaves)
 #ifndef RPK_GLIST        // (tests shrink it to exercise the refill)
@@ -202,6 +214,9 @@ struct RpState {
   // right behind the full-capacity solver stage (which then leaves the list alone: heavy_keep) -- the light envs'
   // position stage no longer waits for the slowest heavy solve.
   int skip_heavy, heavy_keep;
+  // (skip_heavy tests this snapshot -- 1 = rp_order_kernel put the env on the list of the substep just solved -- not
+  // hdr[6], which the list's own position stage rewrites on the companion stream while the slice's launch reads it)
+  const unsigned char* listed;
   // fused substeps (rp_fused_steps_kernel): may be null -- where the state before the last substep's solver
   // stage goes (the acceleration-stage sensors belong to that state)
   T *qpos_prev, *qvel_prev;
@@ -275,8 +290,8 @@ struct RpStage {
   int* ncand;     // [E]                   candidates of this mj_step; -1: the front part did not run for this env
   T* cres;        // [E][RPK_NRES][12]     pos[3], normal[3], dist, mu, kterm, B, D (as covf)
   int* cres_n;    // [E][RPK_NCAND]        contacts of candidate i (0 .. 8)
-  int* tlist;     // [RPK_NTYPE][E * RPK_NCAND][4]  env, ga | gb << 16, first result record, candidate index
-  int* tcount;    // [slices][RPK_NTYPE]   entries per type (the back part's first workgroup clears them)
+  int* tlist;     // [RPK_NTYPE][RPK_NSTRIPE][ceil(E / 8) * RPK_NCAND][4]  env, ga | gb << 16, first result record, candidate index
+  int* tcount;    // [slices][RPK_NSTRIPE][RPK_NTYPE_PAD]   entries per list (the back part's first workgroup clears them)
   int tcount_off; // this launch's slice: tcount + tcount_off
-  size_t tstride; // E * RPK_NCAND
+  size_t tstride; // ceil(E / 8) * RPK_NCAND: one stripe of one type (a slice's entries start at (env_base / 8) * RPK_NCAND)
 };

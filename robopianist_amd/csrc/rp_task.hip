@@ -477,7 +477,7 @@ __global__ __launch_bounds__(64) void rp_task_prestep_kernel(rp_task_prestep_arg
 #pragma clang fp contract(off)   // (the wrapper's torch expression rounds after every operation)
     T v = act[i];
     if (lo) {
-      if (a.clip) v = fmin((T)1, fmax((T)-1, v));
+      if (a.clip) v = (v != v) ? v : fmin((T)1, fmax((T)-1, v));   // (torch.clamp propagates NaN: a diverged policy's action reaches ctrl and raises RP_WARN_BADSTATE, as on the torch path)
       v = lo[i] + (v + (T)1) * (T)0.5 * rng[i];   // (the wrapper's expression, term by term)
     }
     if (i == a.n_action - 1) ((T*)a.sustain_state)[env] = resetting ? (T)0 : v;

@@ -14,6 +14,8 @@ original order) and gets one row of `mesh_graph` per vertex: [degree, neighbour 
 within the hull's own set, ascending, padded with -1)."""
 from __future__ import annotations
 
+import warnings
+
 import numpy as np
 
 SCAN_MAX = 32      # hulls up to this many vertices are scanned
@@ -25,9 +27,18 @@ GEOM_MESH = 7
 def hull_graph(v: np.ndarray):
     """(hull vertices in their original order, graph rows [n][GRAPH_ROW]) of the point set v [n][3], or None when a
     vertex of the triangulated hull has more neighbours than a row holds (the caller then scans the set)."""
-    from scipy.spatial import ConvexHull
     v = np.asarray(v, float).reshape(-1, 3)
-    hull = ConvexHull(v)            # (triangulated facets)
+    try:
+        from scipy.spatial import ConvexHull, QhullError
+    except ImportError:   # (no scipy: the set is scanned; hulls beyond the scanned table's capacity then fail loudly there)
+        warnings.warn("scipy is not importable: convex hulls with more than %d vertices are scanned, not walked" % SCAN_MAX)
+        return None
+    try:
+        hull = ConvexHull(v)            # (triangulated facets)
+    except QhullError as e:             # (degenerate / coplanar mesh: no graph, the set is scanned)
+        warnings.warn("ConvexHull failed on a %d-vertex mesh (%s): the set is scanned, not walked"
+                      % (len(v), str(e).strip().splitlines()[0] if str(e).strip() else "QhullError"))
+        return None
     keep = np.sort(hull.vertices)
     remap = -np.ones(len(v), np.int64); remap[keep] = np.arange(len(keep))
     nbrs = [set() for _ in keep]

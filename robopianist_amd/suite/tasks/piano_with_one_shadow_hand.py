@@ -123,6 +123,8 @@ class PianoWithOneShadowHand(two_hands.PianoWithShadowHands):
         """rp_task_prestep with this hand's actuators (include/rp_task.h)."""
         if self.fused_advance_for(physics) is None:
             return None
+        if type(self).before_step is not PianoWithOneShadowHand.before_step:   # (a subclass's own hook is not bypassed)
+            return None
         if getattr(self, "_fused_prestep", None) is None:
             from robopianist_amd import task_kernels
             hand_act = [int(x) for x in torch.as_tensor(self._act).reshape(-1).tolist()]

@@ -93,7 +93,7 @@ class PianoWithShadowHands(base.PianoTask):
         self._use_fused_rewards = True   # set False to force the torch reward functions
         self._fused_rewards = None
         self._use_fused_advance = True   # set False to force the torch task hooks
-        self._fused_advance = None
+        self._fused_advance = None; self._fused_prestep = None
         self._reset_trajectory()
         self._set_rewards()
 
@@ -289,7 +289,7 @@ class PianoWithShadowHands(base.PianoTask):
         self._finger_bank = torch.full((n, cap, 88), -1, device=old_f.device, dtype=old_f.dtype)
         self._goal_bank[:, :t] = old_g
         self._finger_bank[:, :t] = old_f
-        self._fused_advance = None
+        self._fused_advance = None; self._fused_prestep = None
 
     def prepare_episodes(self, physics, mask) -> None:
         """Host-side part of initialize_episode that the fused device path cannot do:
@@ -308,6 +308,7 @@ class PianoWithShadowHands(base.PianoTask):
 
     def bind(self, physics, n_envs, random_state):
         super().bind(physics, n_envs, random_state)
+        self._fused_advance = None; self._fused_prestep = None   # (both hold raw pointers into the bound physics)
         self._bind_goal_bank()
         self._bind_hands()
         self._bind_task_state()
@@ -356,7 +357,7 @@ class PianoWithShadowHands(base.PianoTask):
             self._song_len = self._song_len[self._song_id].contiguous()
             self._song_id = torch.arange(E, device=dev)
             self._env_midi = [self._initial_midis[e % len(self._initial_midis)] for e in range(E)]
-            self._fused_advance = None
+            self._fused_advance = None; self._fused_prestep = None
             if self._prefetch:
                 if dev.type != "cuda":
                     raise ValueError("augmentation_prefetch needs the HIP task path (a GPU)")
@@ -451,7 +452,7 @@ class PianoWithShadowHands(base.PianoTask):
             self._goal_bank = sd["_goal_bank"].to(dev).clone()
             self._finger_bank = sd["_finger_bank"].to(dev).clone()
             self._song_len.copy_(sd["_song_len"].to(dev))
-            self._fused_advance = None
+            self._fused_advance = None; self._fused_prestep = None
         if self._prefetch:
             for k in ("_song_id", "_next_ready", "_consumed"):
                 getattr(self, k).copy_(sd[k].to(dev))
@@ -580,6 +581,10 @@ class PianoWithShadowHands(base.PianoTask):
         """The one-launch replacement of everything between env.step(action) and physics.step() (include/rp_task.h:
         rp_task_prestep), wherever the fused advance applies."""
         if self.fused_advance_for(physics) is None:
+            return None
+        # a subclass with its own before_step (action noise, extra ctrl writes, another sustain rule) must not be
+        # bypassed by the launch that restates the STOCK hook: it gets the before_step path of Environment.step
+        if type(self).before_step is not PianoWithShadowHands.before_step:
             return None
         if getattr(self, "_fused_prestep", None) is None:
             from robopianist_amd import task_kernels

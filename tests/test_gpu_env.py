@@ -316,6 +316,43 @@ def test_fused_task_advance_matches_torch_hooks(wrong_press):
         assert seen["zero_discount"] >= 1, seen
 
 
+def test_subclass_before_step_is_not_bypassed_and_nan_actions_propagate():
+    """(a) a task subclass that overrides before_step must not be bypassed by the pre-step launch
+    (which restates the STOCK hook); (b) with clip=True a NaN action stays NaN on the fused path, as torch.clamp
+    keeps it on the torch path (it then reaches ctrl and the engine flags the env)."""
+    from robopianist_amd import music
+    from robopianist_amd.suite import environment
+    from robopianist_amd.suite.tasks import piano_with_shadow_hands as pw
+    from robopianist_amd.wrappers import CanonicalSpecWrapper
+
+    class Halved(pw.PianoWithShadowHands):
+        def before_step(self, physics, action):
+            super().before_step(physics, torch.as_tensor(action) * 0.5)
+
+    midi = music.load("TwinkleTwinkleRousseau")
+    kw = dict(trim_silence=True, control_timestep=0.05, gravity_compensation=True, primitive_fingertip_collisions=True)
+    env = environment.Environment(Halved(midi=midi, **kw), n_envs=2, random_state=3, precision=64)
+    env.reset()
+    assert env.task.fused_advance_for(env.physics) is not None and env.task.fused_prestep_for(env.physics) is None
+    spec = env.action_spec()
+    a = torch.as_tensor(np.tile(0.5 * (spec.minimum + spec.maximum), (2, 1)), device=env.physics.device)
+    env.step(a)
+    ctrl = _np(env.physics.ctrl)
+    hand = np.concatenate([_np(env.task._rh_act).reshape(-1), _np(env.task._lh_act).reshape(-1)]).astype(int)
+    np.testing.assert_allclose(ctrl[0, hand], 0.5 * _np(a)[0, :-1], rtol=0, atol=0)
+    # (b) NaN through the canonical wrapper with clipping, fused vs torch path
+    fused, ref = _load_pair(2, 64)
+    fused.reset(); ref.reset()
+    assert fused.task.fused_prestep_for(fused.physics) is not None
+    an = np.zeros((2, fused.action_spec().shape[0])); an[1, 3] = np.nan
+    for env2 in (fused, ref):
+        env2._clip = True
+        env2.step(torch.as_tensor(an, device=env2.physics.device, dtype=torch.float64))
+    cf, cr = _np(fused.physics.ctrl), _np(ref.physics.ctrl)
+    assert np.isnan(cf[1]).sum() == 1 and (np.isnan(cf) == np.isnan(cr)).all()
+    np.testing.assert_array_equal(cf[0], cr[0])
+
+
 def test_midi_augmentations_fused_path_matches_torch_hooks():
     """MIDI augmentations (suite/variations.py) on the HIP task layer: per-env goal bank
     slots are regenerated on the host at every episode start; the fused launch must hand

@@ -90,6 +90,29 @@ def test_importer_rejects_dynamics_the_engine_does_not_model(field, value, what)
         imp.model_from_npz(bad)
 
 
+@pytest.mark.parametrize("mj_type,name", [(5, "cylinder"), (4, "ellipsoid"), (2, "sphere"), (0, "plane")])
+def test_importer_rejects_collision_geoms_the_narrow_phase_does_not_handle(mj_type, name):
+    """A real dump whose colliding geoms include a cylinder / ellipsoid / sphere / plane must raise and NAME the geoms
+    (the oracle's pair loop would otherwise skip those pairs silently); the same type on a visual geom (contype =
+    conaffinity = 0) imports."""
+    from robopianist_amd.model import scene
+    from robopianist_amd.tools import mjmodel_to_blob as imp
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=True)
+    d = imp.npz_from_model(si.model)
+    gn = [str(x) for x in d["names_geom"]]
+    g = next(i for i, n in enumerate(gn) if n.endswith("wrist_col"))
+    bad = dict(d)
+    t = np.array(d["model_geom_type"]); t[g] = mj_type; bad["model_geom_type"] = t
+    with pytest.raises(ValueError, match=r"unsupported collision geom types.*wrist_col \(%s\)" % name):
+        imp.model_from_npz(bad)
+    ok = dict(bad)
+    for k in ("model_geom_contype", "model_geom_conaffinity"):
+        v = np.array(d[k]); v[g] = 0; ok[k] = v
+    imp.model_from_npz(ok)   # a visual geom of that type never collides
+
+
 def test_oracle_steps_the_imported_model_like_the_compiled_one(tmp_path):
     from robopianist_amd import engine
     from robopianist_amd.tools import mjmodel_to_blob as imp
