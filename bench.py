@@ -414,7 +414,7 @@ def main():
                        "note": "same env loop with the actions in host numpy arrays and every TimeStep field "
                                "copied back to numpy (pageable memory, synchronous copies) each step"}
 
-        return dict(per_rank=per_rank, host_io=host_io, dt=dt, kms=kms, nl=nl, sms=sms, snl=snl, senvs=senvs, fused=fused, warn=warn_or, finite=finite, phys=phys,
+        return dict(per_rank=per_rank, host_io=host_io, dt=dt, kms=kms, nl=nl, sms=sms, snl=snl, senvs=senvs, fused=fused, split=bool(getattr(phys, 'split_position_stage', False)), warn=warn_or, finite=finite, phys=phys,
                     m=m, E=E, key_ids=base_env.task.scene.key_joint_ids, sim=sim_all, n_spread=n_spread, events=events,
                     graphed=bool(use_graph and env.graph_captured), stagger=stagger)
 
@@ -468,7 +468,8 @@ def main():
                           ("rp_lean_solver_kernel<%s> (mj_step2: constraint solver + Euler, one substep of all envs; the "
                            "probe brackets it together with the full-capacity rp_stage_kernel<%s, 1> that takes the envs "
                            "outside the light capacity class)" % (tname, tname)),
-                "schedule": "fused substeps" if r["fused"] else "one launch per stage",
+                "schedule": "fused substeps" if r["fused"] else ("three slices, split position stage (front part / pooled narrow phase / back part)"
+                                                                if r.get("split") else "one launch per stage"),
                 "valu": _valu_profile(args.precision),
                 "kernel_avg_ms": sms, "kernel_launches_sampled": snl,
                 "envs_per_launch": r["senvs"],

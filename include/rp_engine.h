@@ -127,6 +127,14 @@ int rp_set_solver_tolerance(rp_engine* e, double tolerance, double ls_tolerance)
  * rp_field_ptr views: a caller that writes state through a view must call rp_forward (or rp_set)
  * before the next rp_step.  Default: off.  Results are bit-identical either way. */
 int rp_set_lazy_position_stage(rp_engine* e, int on);
+/* dm_control's `legacy_step` (robopianist/suite/__init__.py:55,91 -> composer.Environment(legacy_step=...) ->
+ * mjcf.Physics.step).  on (the default, and dm_control's): every physics.step() is `mj_step2; mj_step1`, i.e. after
+ * rp_step the position-dependent outputs (RP_SITE_XPOS, RP_NCON / RP_CONTACT_GEOMS / RP_CONTACT_DIST, RP_ACT_VELOCITY)
+ * belong to the NEW state.  off: physics.step() is `mj_step` = `mj_step1; mj_step2` -- the state trajectory is the same,
+ * but those outputs are the ones of the state BEFORE the last integration of the call, exactly what MuJoCo's mjData
+ * holds after mj_step.  (The engine still runs the stage for the new state -- the next rp_step needs its hand-over --
+ * and only keeps its outputs back; the leading stage of the next rp_step publishes them, so the lazy mode is ignored.) */
+int rp_set_legacy_step(rp_engine* e, int on);
 /* Cost-ordered launch: every stage kernel processes the envs in descending order of what their last
  * solver stage needed (Newton iterations x coupled rows, contact count), re-sorted on the device after
  * every solver stage (longest-processing-time-first).  One wave steps one env and a SIMD runs its
@@ -155,19 +163,23 @@ int rp_set_lean_solver(rp_engine* e, int on);
 int rp_set_fused_substeps(rp_engine* e, int on);
 int rp_get_fused_substeps(rp_engine* e);
 
-/* Split position stage (fp64 default-depth builds; on by default there, RP_SPLIT_POS=0 in the environment turns the
- * default off).  on: in the per-stage schedules the position / velocity stage of every substep (mj_step1: kinematics,
+/* Split position stage (fp64 default-depth builds).  The position / velocity stage of a substep (mj_step1: kinematics,
  * CRB, collision, constraint rows) runs as three launches instead of one -- front part (kinematics, composite inertias,
- * broad phase, fp32 prefilters; one wave per env), POOLED narrow phase (one wave per 64 candidate pairs of one geom-type
- * pair, whatever envs they belong to: capsule-capsule, capsule-box, box-box, hull pairs through MPR), back part
- * (constraint rows, contact Jacobians, velocity stage; one wave per env).  Bit-identical results (the same routines on
- * the same inputs, contacts collected in the one-kernel stage's order); candidates beyond 256 per env and mj_step
- * are dropped and flagged RP_WARN_WORK_FULL.  What it replaces: mj_collision's narrow phase inside
- * physics.step() (robopianist/suite/tasks/base.py:28,31,68-70).  rp_get_split_position_stage: 1 when in use. */
+ * broad phase, fp32 prefilters; one wave per env, 13 KB of LDS / 155 registers: three waves per SIMD), POOLED narrow phase
+ * (one wave per 64 candidate pairs of one geom-type pair, whatever envs they belong to: capsule-capsule, capsule-box,
+ * box-box, hull pairs through MPR in buckets of equal vertex sets), back part (constraint rows, contact Jacobians,
+ * velocity stage; one wave per env).  Bit-identical results (the same routines on the same inputs, contacts collected
+ * in the one-kernel stage's order); candidates beyond 256 per env and mj_step are dropped and flagged
+ * RP_WARN_WORK_FULL.  on: 0 = never, 1 = in every per-stage schedule, 2 = automatic (the default where the builds
+ * exist; RP_SPLIT_POS=0/1/2 in the environment sets the default): with rp_set_stream_slices(e, 0) the schedule "three
+ * slices, split position stage, every slice's launches on one stream" is one more candidate of the engine's own
+ * timing-based choice (batches of >= 3072 envs).  What it replaces: mj_collision's narrow phase inside physics.step()
+ * (robopianist/suite/tasks/base.py:28,31,68-70).  rp_get_split_position_stage: 0 = not in use, 1 = the schedule rp_step
+ * currently runs, 2 = a candidate the automatic choice currently rejects. */
 int rp_set_split_position_stage(rp_engine* e, int on);
 int rp_get_split_position_stage(rp_engine* e);
 
-/* Stream slices (0, 1, 2 or 4; default 1): with n > 1, rp_step runs n slices of the batch as n
+/* Stream slices (0, 1, 2, 3 or 4; default 1): with n > 1, rp_step runs n slices of the batch as n
  * independent kernel chains (the caller's stream and internal ones, forked / joined with events
  * inside the call), so that the tail of one slice's launch overlaps another slice's next kernel:
  * faster for heterogeneous batches (two slices: +3 %; four: slower again), slower for uniform ones

@@ -18,6 +18,12 @@
 #include "rp_wave.hpp"
 #include "rp_narrow.hpp"
 
+// The scanned hulls' vertex table in LDS (hull_support_wave<.., LDSV>): one variable, named from the kernel (which fills
+// it) and from the hull routine (which reads it) through this accessor, so that both see an LDS address, not a generic one.
+template <typename T> __device__ __forceinline__ T* rp_lds_vert() {
+  __shared__ T v[3 * RPK_MAXMESHV];
+  return v;
+}
 // One pair type per routine, each a REAL call (noinline): the kernel then needs the registers of its hungriest routine,
 // not of all four inlined side by side (256 VGPRs + 96 AGPRs, one wave per SIMD -- a workgroup that has to wait for a
 // whole idle SIMD while the other slice's kernels hold the chip), and nothing of the caller lives across the call.
@@ -37,15 +43,32 @@ __device__ __noinline__ void rp_narrow_chunk(const RpModel<T>& M, const RpState<
   const bool key = gb >= RPK_KEYBASE;
   const int kk = key ? gb - RPK_KEYBASE : 0, gbi = key ? 0 : gb;
   // side A: a hand geom; side B: a hand geom, or the key's box (moving with the key's hinge angle)
+  // (a geom's world frame from its link's frame, RpStage::frames, with the one-kernel stage's expressions: the front
+  // part would pay 9 k cycles per wave to write world frames of all its geoms; this kernel's waves mostly wait anyway)
+  auto geom_frame = [&](const int g, T* pos, T* mat) {
+    const int gl = M.geom_link()[g];
+    const T* gp = M.geom_pos() + 3 * g;
+    const T* gm = M.geom_mat() + 9 * g;
+    if (gl >= 0) {
+      const T* fr = B.frames + (size_t)env * RPK_NFRAME * 64 + gl;
+      T xp[3], xm[9], t[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) xp[k] = fr[(size_t)k * 64];
+#pragma unroll
+      for (int k = 0; k < 9; k++) xm[k] = fr[(size_t)(3 + k) * 64];
+      mat_vec(t, xm, gp);
+      pos[0] = xp[0] + t[0]; pos[1] = xp[1] + t[1]; pos[2] = xp[2] + t[2];
+      mat_mul(mat, xm, gm);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; k++) pos[k] = gp[k];
+#pragma unroll
+      for (int k = 0; k < 9; k++) mat[k] = gm[k];
+    }
+  };
   T posA[3], mA[9], posB[3], mB[9];
   const T* sB;
-  {
-    const T* fa = B.gframe + ((size_t)env * 64 + ga) * 12;
-#pragma unroll
-    for (int k = 0; k < 3; k++) posA[k] = fa[k];
-#pragma unroll
-    for (int k = 0; k < 9; k++) mA[k] = fa[3 + k];
-  }
+  geom_frame(ga, posA, mA);
   T invw = M.geom_invw()[ga];
   const T* pB;
   if (key) {
@@ -58,11 +81,7 @@ __device__ __noinline__ void rp_narrow_chunk(const RpModel<T>& M, const RpState<
     pB = M.key_cparam();
     invw += M.key_invw_body()[kk];
   } else {
-    const T* fb = B.gframe + ((size_t)env * 64 + gbi) * 12;
-#pragma unroll
-    for (int k = 0; k < 3; k++) posB[k] = fb[k];
-#pragma unroll
-    for (int k = 0; k < 9; k++) mB[k] = fb[3 + k];
+    geom_frame(gbi, posB, mB);
     sB = M.geom_size() + 3 * gbi;
     pB = M.geom_cparam() + 8 * gbi;
     invw += M.geom_invw()[gbi];
@@ -103,7 +122,7 @@ __device__ __noinline__ void rp_narrow_chunk(const RpModel<T>& M, const RpState<
       for (int i = 0; i < 9; i++) { a_.mat[i] = mA[i]; b_.mat[i] = mB[i]; }
     }
     RawCon<T> rcm[1];
-    const int nm = convex_mpr_wave<T, (MESH > 1)>(rcm, &a_, &b_, M.mesh_vert(), M.hull_vert, M.hull_graph, in);
+    const int nm = convex_mpr_wave<T, (MESH > 1), true>(rcm, &a_, &b_, rp_lds_vert<T>(), M.hull_vert, M.hull_graph, in);
     if (in) {
       n = nm; rc[0] = rcm[0];
       if (key) { rc[0].n[0] = -rc[0].n[0]; rc[0].n[1] = -rc[0].n[1]; rc[0].n[2] = -rc[0].n[2]; }
@@ -150,6 +169,8 @@ template <typename T, int MESH>
 __global__ __launch_bounds__(64, RPK_NARROW_WAVES) void rp_narrow_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B) {
   const int lane = (int)threadIdx.x;
   const int* const tc = B.tcount + B.tcount_off;
+  // the scanned hulls' vertex table, staged in LDS by the waves that walk a hull list (hull_support_wave<.., LDSV>)
+  bool staged = false;
   // chunks of candidates of one list: the long routines first (hull buckets, box-box, capsule-box, capsule-capsule)
   int first = 0;   // (first chunk of the list under test)
 #define RP_NARROW_LIST(TYPE_, LANES_)                                                                  \
@@ -159,7 +180,17 @@ __global__ __launch_bounds__(64, RPK_NARROW_WAVES) void rp_narrow_kernel(RpModel
     if (ch < first) ch += (first - ch + (int)gridDim.x - 1) / (int)gridDim.x * (int)gridDim.x;         \
     for (; ch < first + nch_; ch += (int)gridDim.x) {                                                  \
       const int e = (ch - first) * (LANES_) + lane;                                                    \
+      const long long t0_ = S.prof ? (long long)__builtin_readcyclecounter() : 0;                      \
+      if (MESH != 0 && (TYPE_) >= 3 && !staged) {                                                      \
+        for (int i_ = lane; i_ < 3 * RPK_MAXMESHV; i_ += 64) rp_lds_vert<T>()[i_] = M.mesh_vert()[i_]; \
+        staged = true;                                                                                 \
+        __syncthreads();                                                                               \
+      }                                                                                                \
       rp_narrow_chunk<T, MESH, TYPE_>(M, S, B, st_, e, lane < (LANES_) && e < cnt_);                   \
+      if (S.prof && lane == 0) {   /* (debug aid: shader cycles and chunks per list) */                \
+        atomicAdd((unsigned long long*)&S.prof[48 + (TYPE_)], (unsigned long long)((long long)__builtin_readcyclecounter() - t0_)); \
+        atomicAdd((unsigned long long*)&S.prof[56 + (TYPE_)], 1ull);                                   \
+      }                                                                                                \
     }                                                                                                  \
     first += nch_;                                                                                     \
   }

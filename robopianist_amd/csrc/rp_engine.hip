@@ -178,7 +178,7 @@ struct EngineBase {
   // hysteresis) runs the rest.  Measured, config 2 with 4096 envs at staggered episode times: two
   // slices; the same in lockstep, or with <= 2048 envs: fused.
   int ev_trial[kRing] = {};           // 0 = not a trial step, else the schedule it ran with
-  double trial_ms[4] = {0, 0, 0, 0}, trial_n[4] = {0, 0, 0, 0};
+  double trial_ms[5] = {0, 0, 0, 0, 0}, trial_n[5] = {0, 0, 0, 0, 0};
   int auto_mode = 1; unsigned auto_pos = 0;
   void harvest(int i, bool wait) {
     if (!ev_pending[i]) return;
@@ -204,6 +204,7 @@ struct EngineBase {
   virtual void limits(int newton, int ls) = 0;
   virtual void tolerances(double tol, double ls_tol) = 0;
   bool lazy_position = false;
+  bool legacy_step = true;   // rp_set_legacy_step: false = dm_control's legacy_step=False output semantics
   bool cost_order = false;   // rp_set_cost_ordered_launch
   int n_slices = 1;          // rp_set_stream_slices (0 = automatic)
   static const int kMaxSlices = 4;
@@ -241,15 +242,18 @@ struct Engine : EngineBase {
   bool deep = false;    // a trunk of 5..8 links (more than two forearm dofs): the RPK_MAXD_DEEP builds
   bool lean = false;    // light envs are stepped by rp_lean_solver_kernel (rp_solver2.hpp), the others by the full build
   // the position stage of the substeps as three launches: front part, pooled narrow phase (rp_collide.hpp), back part
-  bool split_capable = false, split_stage = false;
-  bool fuse_lean_front = getenv("RP_FUSE_LF") && getenv("RP_FUSE_LF")[0] == '1';   // (lean solver stage + front part in one launch)
+  // split_mode: 0 = never, 1 = in every per-stage schedule, 2 = automatic: the schedule "three slices, split stage, no
+  // companion streams" is a candidate of the engine's own choice (with rp_set_stream_slices(e, 0))
+  bool split_capable = false;
+  int split_mode = 0;
+  bool split_now = false;   // (this rp_step)
   const int narrow_grid_env = getenv("RP_NARROW_GRID") ? atoi(getenv("RP_NARROW_GRID")) : 0;
   int split_position(int on) override {
     if (on && !split_capable) return fail("rp_set_split_position_stage: the split stage exists for the fp64 default-depth builds only");
-    split_stage = on != 0;
+    split_mode = on < 0 ? 2 : (on > 2 ? 2 : on);
     return 0;
   }
-  int split_position_on() const override { return split_stage ? 1 : 0; }
+  int split_position_on() const override { return split_mode == 1 ? 1 : (split_mode == 2 && n_slices == 0 ? (auto_mode == 4 ? 1 : 2) : 0); }
   int lean_solver(int on) override {
     if (on && (deep || sizeof(T) != 8)) return fail("rp_set_lean_solver: the lean solver stage exists for the fp64 default builds only");
     lean = on != 0; S.lean = on > 0 ? on : 0;   // (on > 1: the light class capped at that many Jacobian entries)
@@ -456,10 +460,9 @@ struct Engine : EngineBase {
     {
       const char* sp = getenv("RP_SPLIT_POS");
       split_capable = sizeof(T) == 8 && !deep;
-      split_stage = split_capable && !(sp && sp[0] == '0');
+      split_mode = !split_capable ? 0 : (sp ? (sp[0] == '0' ? 0 : (sp[0] == '1' ? 1 : 2)) : 2);
       if (split_capable) {
         B.frames = dalloc<T>(E * RPK_NFRAME * 64);
-        B.gframe = dalloc<T>(E * 64 * 12);
         B.cand = dalloc<int>(E * RPK_NCAND * 2);
         B.ncand = dalloc<int>(E);
         B.cres = dalloc<T>(E * RPK_NRES * 12);
@@ -470,7 +473,6 @@ struct Engine : EngineBase {
         B.tcount_off = 0;
         hipMemset(B.ncand, 0xFF, sizeof(int) * E);        // -1: no front part has run
         hipMemset(B.frames, 0xFF, sizeof(T) * E * RPK_NFRAME * 64);
-        hipMemset(B.gframe, 0xFF, sizeof(T) * E * 64 * 12);
       }
     }
     // hand-over buffers start as NaN / -1 patterns: a read of anything the position kernel
@@ -614,15 +616,15 @@ struct Engine : EngineBase {
   unsigned char* d_valid = nullptr; // hand-over of env e matches its state
   int profile(long long* out, int n, int enable) override {
     HIP_OK(hipSetDevice(device));
-    if (!d_prof) { d_prof = dalloc<long long>(RPK_NPROF); }
+    if (!d_prof) { d_prof = dalloc<long long>(RPK_NPROF_ALL); }
     HIP_OK(hipStreamSynchronize(stream));
     if (out) {
-      long long h[RPK_NPROF];
+      long long h[RPK_NPROF_ALL];
       HIP_OK(hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost));
-      for (int i = 0; i < n && i < RPK_NPROF; i++) out[i] = h[i];
+      for (int i = 0; i < n && i < RPK_NPROF_ALL; i++) out[i] = h[i];
     }
     HIP_OK(hipStreamSynchronize(stream));  // counters of launches still in flight
-    HIP_OK(hipMemset(d_prof, 0, sizeof(long long) * RPK_NPROF));
+    HIP_OK(hipMemset(d_prof, 0, sizeof(long long) * RPK_NPROF_ALL));
     HIP_OK(hipDeviceSynchronize());        // (null-stream fill vs the engine's non-blocking stream)
     S.prof = enable ? d_prof : nullptr;
     return 0;
@@ -773,11 +775,15 @@ struct Engine : EngineBase {
     int want = n_slices;
     const bool fused_capable = lean && !deep && !graph && sizeof(T) == 8;   // (no fused builds for scenes with graph hulls)
     bool fused_now = fused == 1 && fused_capable && mode == 0;
+    bool sched4 = false;
     if (n_slices == 0 && mode == 0 && !fused_now) {
-      int cand[3], nc = 0;
+      int cand[4], nc = 0;
       cand[nc++] = 1;
       if (nenv >= 1024 && !capturing) cand[nc++] = 2;
       if (fused == 2 && fused_capable) cand[nc++] = 3;
+      // 4: three slices, the position stage split (front part / pooled narrow phase / back part), every launch of a
+      // slice on its own stream (three streams: within the device's four hardware queues)
+      if (split_mode == 2 && split_capable && nenv >= 3072 && !capturing) cand[nc++] = 4;
       // (a schedule that is no candidate right now -- two slices inside a stream capture -- is replaced for THIS
       // step only: the measured choice survives the capture)
       bool have = false;
@@ -808,13 +814,16 @@ struct Engine : EngineBase {
               fprintf(stderr, " -> %d\n", auto_mode);
             }
           }
-          for (int k = 1; k <= 3; k++) { trial_ms[k] = 0; trial_n[k] = 0; }   // (the latest block decides: the workload drifts)
+          for (int k = 1; k <= 4; k++) { trial_ms[k] = 0; trial_n[k] = 0; }   // (the latest block decides: the workload drifts)
         }
       }
       fused_now = sched == 3;
-      want = sched == 2 ? 2 : 1;
+      want = sched == 2 ? 2 : (sched == 4 ? 3 : 1);
+      sched4 = sched == 4;
     }
-    int nsl = (mode == 0 && want > 1 && nenv >= 1024 && !capturing && !fused_now) ? (want >= 4 ? 4 : 2) : 1;
+    split_now = split_capable && mode == 0 && (split_mode == 1 || sched4);
+    const bool companion_now = companion && !sched4;
+    int nsl = (mode == 0 && want > 1 && nenv >= 1024 && !capturing && !fused_now) ? (want >= 4 ? 4 : want) : 1;
     if (nsl > 1 && !ev_fork && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev_fork = nullptr; nsl = 1; }
     for (int i = 1; i < nsl; i++) {
       if (xstream[i]) continue;
@@ -824,9 +833,13 @@ struct Engine : EngineBase {
     // slice sl covers the envs [bound(sl), bound(sl + 1)); bounds are multiples of 8 (XCD classes of the order)
     auto bound = [&](int sl) { return sl >= nsl ? nenv : (int)(((long long)nenv * sl / nsl + 7) / 8 * 8); };
     if (cost_order && mode == 0) s.order = d_order;   // (initialised to the identity; refreshed below)
-    const bool lead_masked = (lazy_position || reset_mask) && mode == 0;
+    // (legacy_step = False: the leading stage always runs -- it is what publishes the outputs of the incoming state,
+    // which the previous step's last position stage computed but kept to itself)
+    const bool lazy_now = lazy_position && legacy_step;
+    s.stale_outputs = (!legacy_step && mode == 0) ? 1 : 0;
+    const bool lead_masked = (lazy_now || reset_mask) && mode == 0;
     if (lead_masked)
-      hipLaunchKernelGGL(rp_lead_mask_kernel, dim3(hb), dim3(256), 0, stream, d_lead, s.active, d_valid, lazy_position ? 1 : 0, reset_mask, nenv);
+      hipLaunchKernelGGL(rp_lead_mask_kernel, dim3(hb), dim3(256), 0, stream, d_lead, s.active, d_valid, lazy_now ? 1 : 0, reset_mask, nenv);
     if (nsl > 1) {
       HIP_OK(hipEventRecord(ev_fork, stream));
       for (int i = 1; i < nsl; i++) HIP_OK(hipStreamWaitEvent(xstream[i], ev_fork, 0));
@@ -843,9 +856,7 @@ struct Engine : EngineBase {
         }
       };
       // the position / velocity stage of substep k as front part, pooled narrow phase, back part (same results, bit for bit)
-      // (front: 1 = the front part as a launch of its own, 2 = fused behind the lean solver stage (rp_lean_front_kernel:
-      // `q` then is that stage's state), 0 = already done; rest: the pooled narrow phase and the back part)
-      auto launch_pos_split = [&](const RpState<T>& q, int k, int front = 1, bool rest = true) {
+      auto launch_pos_split = [&](const RpState<T>& q, int k) {
         if constexpr (sizeof(T) == 8) {
           RpStage<T> Bs = B;
           Bs.tcount_off = sl * RPK_NSTRIPE * RPK_NTYPE_PAD;
@@ -853,19 +864,16 @@ struct Engine : EngineBase {
           ng = ng < 64 ? 64 : (ng > 2048 ? 2048 : ng);
 #define RP_SPLIT_LAUNCH(MESH_)                                                                                                     \
           {                                                                                                                        \
-            if (front == 1) hipLaunchKernelGGL((rp_pos_front_kernel<T, MESH_>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);     \
-            if (front == 2) hipLaunchKernelGGL((rp_lean_front_kernel<T, MESH_>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);    \
-            if (rest) {                                                                                                            \
-              hipLaunchKernelGGL((rp_narrow_kernel<T, MESH_>), dim3(ng), dim3(64), 0, st, M, q, Bs);                                \
-              hipLaunchKernelGGL((rp_pos_back_kernel<T, MESH_>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);                    \
-            }                                                                                                                      \
+            hipLaunchKernelGGL((rp_pos_front_kernel<T, MESH_>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);                     \
+            hipLaunchKernelGGL((rp_narrow_kernel<T, MESH_>), dim3(ng), dim3(64), 0, st, M, q, Bs);                                  \
+            hipLaunchKernelGGL((rp_pos_back_kernel<T, MESH_>), dim3(cnt), dim3(64), 0, st, M, q, Bs, k, nsub);                      \
           }
           if (mesh && graph) RP_SPLIT_LAUNCH(2) else if (mesh) RP_SPLIT_LAUNCH(1) else RP_SPLIT_LAUNCH(0)
 #undef RP_SPLIT_LAUNCH
         }
       };
       auto launch_pos_on = [&](const RpState<T>& q, int k) {
-        if (split_stage && !deep && sizeof(T) == 8) { launch_pos_split(q, k); return; }
+        if (split_now && !deep && sizeof(T) == 8) { launch_pos_split(q, k); return; }
         if (deep && mesh && graph) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP, 2>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
         else if (mesh && graph) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD, 2>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
         else if (deep && mesh) hipLaunchKernelGGL((rp_stage_kernel<T, 0, 0, RPK_MAXD_DEEP, 1>), dim3(cnt), dim3(64), 0, st, M, q, B, k, nsub);
@@ -919,7 +927,7 @@ struct Engine : EngineBase {
       // ... then n_sub x (mj_step2; mj_step1): dm_control's legacy order.  Two kernels per substep instead
       // of one fused launch: each half fits in registers, the hand-over (RpStage) stays in L2 / Infinity Cache.
       int hgrid_step = 0;   // (the full-capacity stage's grid: one choice per step and slice)
-      bool split_step = false, fuse_lf = false;
+      bool split_step = false;
       for (int k = 0; k < nsub; k++) {
         const bool probe = timeit && sl == 0 && k == (int)(step_calls % (unsigned)nsub) && !ev_trial[slot];
         const bool sense = sensors_on && k == nsub - 1;
@@ -941,10 +949,10 @@ struct Engine : EngineBase {
         // light envs on the lean build (two waves per SIMD), the others on the full-capacity build (it skips
         // the light ones) -- side by side: the full-capacity launch goes to the slice's companion stream
         hipStream_t hs = st;
-        if (lean && !capturing && companion) {
-          if (!hstream[sl] && (create_companion_stream(&hstream[sl]) != hipSuccess ||
-                               hipEventCreateWithFlags(&ev_hfork[sl], hipEventDisableTiming) != hipSuccess ||
-                               hipEventCreateWithFlags(&ev_hjoin[sl], hipEventDisableTiming) != hipSuccess)) {
+        if (lean && !capturing && companion_now) {
+          if (!hstream[sl] && create_companion_stream(&hstream[sl]) != hipSuccess) { (void)hipGetLastError(); hstream[sl] = nullptr; }
+          if (hstream[sl] && !ev_hfork[sl] && (hipEventCreateWithFlags(&ev_hfork[sl], hipEventDisableTiming) != hipSuccess ||
+                                               hipEventCreateWithFlags(&ev_hjoin[sl], hipEventDisableTiming) != hipSuccess)) {
             (void)hipGetLastError(); hstream[sl] = nullptr;
           }
           if (hstream[sl]) {
@@ -961,10 +969,7 @@ struct Engine : EngineBase {
           // (the split pays when the list is long: config 3 446 -> 455 k; on a batch whose lists are empty the extra
           // launch and the later join cost 1-4 %: config 2 657 -> 632 ... 651 k -- so it follows the same lagged estimate)
           hgrid = capturing ? (cnt < kHeavyGrid ? cnt : kHeavyGrid) : (k == 0 ? (hgrid_step = heavy_grid_for(sl, cnt)) : hgrid_step);
-          // (the lean solver stage fused with the front part of the split position stage: the listed envs then always
-          // take their position stage with them to the companion stream)
-          fuse_lf = fuse_lean_front && split_stage && lean && hs != st && !deep && !graph && sizeof(T) == 8;
-          split_step = (split_heavy_pos && hs != st && !deep && !graph && sizeof(T) == 8 && heavy_est[sl] >= 4.0) || fuse_lf;
+          split_step = split_heavy_pos && hs != st && !deep && !graph && sizeof(T) == 8 && heavy_est[sl] >= 4.0;
           sh.heavy_keep = (split_step && !sense) ? 1 : 0;
         }
         // (RP_X_NO_HEAVY=1: MEASUREMENT ONLY -- the full-capacity launch is suppressed, envs outside the light class are
@@ -978,9 +983,7 @@ struct Engine : EngineBase {
         // (config 3: 0.27 ms of every 0.81 ms substep); the streams join after it, in front of the next order pass
         const bool split_pos = split_step && listed && !sense;
         if (hs != st && !split_pos) HIP_OK(hipEventRecord(ev_hjoin[sl], hs));
-        const bool fuse_now = fuse_lf && split_pos && !sense;
-        if (fuse_now) { RpState<T> sf_ = ss; sf_.skip_heavy = 1; launch_pos_split(sf_, k, 2, false); }
-        else if (lean) hipLaunchKernelGGL((rp_lean_solver_kernel<T>), dim3(cnt), dim3(64), 0, st, M, ss, B);
+        if (lean) hipLaunchKernelGGL((rp_lean_solver_kernel<T>), dim3(cnt), dim3(64), 0, st, M, ss, B);
         if (hs != st && !split_pos) HIP_OK(hipStreamWaitEvent(st, ev_hjoin[sl], 0));
         if (probe) HIP_OK(hipEventRecord(sv1[slot], st));
         if (sense) {
@@ -1004,8 +1007,7 @@ struct Engine : EngineBase {
           HIP_OK(hipEventRecord(ev_hjoin[sl], hs));
           RpState<T> sm_ = ss;
           sm_.skip_heavy = 1;
-          if (fuse_now) launch_pos_split(sm_, k, 0, true);
-          else launch_pos_on(sm_, k);
+          launch_pos_on(sm_, k);
           HIP_OK(hipStreamWaitEvent(st, ev_hjoin[sl], 0));
         } else {
           launch_pos_on(ss, k);
@@ -1105,6 +1107,11 @@ int rp_set_lazy_position_stage(rp_engine* e, int on) {
   E(e)->lazy_position = on != 0;
   return 0;
 }
+int rp_set_legacy_step(rp_engine* e, int on) {
+  if (!e) return fail("null engine");
+  E(e)->legacy_step = on != 0;
+  return 0;
+}
 int rp_set_acc_sensors(rp_engine* e, int on) { return e ? E(e)->acc_sensors(on) : fail("null engine"); }
 int rp_set_lean_solver(rp_engine* e, int on) { return e ? E(e)->lean_solver(on) : fail("null engine"); }
 int rp_set_fused_substeps(rp_engine* e, int on) { return e ? E(e)->fused_substeps(on) : fail("null engine"); }
@@ -1113,7 +1120,7 @@ int rp_set_split_position_stage(rp_engine* e, int on) { return e ? E(e)->split_p
 int rp_get_split_position_stage(rp_engine* e) { return e ? E(e)->split_position_on() : fail("null engine"); }
 int rp_set_stream_slices(rp_engine* e, int n) {
   if (!e) return fail("null engine");
-  if (n != 0 && n != 1 && n != 2 && n != 4) return fail("rp_set_stream_slices: 0 (automatic), 1, 2 or 4");
+  if (n != 0 && n != 1 && n != 2 && n != 3 && n != 4) return fail("rp_set_stream_slices: 0 (automatic), 1, 2, 3 or 4");
   E(e)->n_slices = n;
   return 0;
 }

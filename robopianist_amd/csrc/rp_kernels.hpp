@@ -1395,7 +1395,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       }
       WSYNC();
     }
-    if (MODE == 0 && lane < M.nsite) {  // site positions of this state
+    if (MODE == 0 && lane < M.nsite && !(S.stale_outputs && substep == nsub - 1)) {  // site positions of this state
       int sl = M.site_link()[lane];
       T t[3];
       mat_vec(t, sm.xmat[sl], M.site_pos() + 3 * lane);
@@ -1482,18 +1482,6 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         gp[0] = sm.xpos[gl][0] + t[0]; gp[1] = sm.xpos[gl][1] + t[1]; gp[2] = sm.xpos[gl][2] + t[2];
       }
       sm.gpos[lane][0] = gp[0]; sm.gpos[lane][1] = gp[1]; sm.gpos[lane][2] = gp[2];
-      if constexpr (PART == 1) {   // the geom's world frame, for the pooled narrow phase (the whole stage forms it per candidate)
-        T mw_[9];
-        if (gl >= 0) mat_mul(mw_, sm.xmat[gl], M.geom_mat() + 9 * lane);
-        else {
-#pragma unroll
-          for (int k = 0; k < 9; k++) mw_[k] = M.geom_mat()[9 * lane + k];
-        }
-        T* gf_ = B.gframe + ((size_t)env * 64 + lane) * 12;
-        gf_[0] = gp[0]; gf_[1] = gp[1]; gf_[2] = gp[2];
-#pragma unroll
-        for (int k = 0; k < 9; k++) gf_[3 + k] = mw_[k];
-      }
       // capsule axis (third column of the world geom frame) for the segment prefilter
       const T* gm = M.geom_mat() + 9 * lane;
       T az[3] = {gm[2], gm[5], gm[8]};
@@ -1569,11 +1557,14 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     // register allocation spilled inside the CRB / RNE level loops -- 207 spilled VGPRs against 144 -- and the
     // step got 2.8 % slower although candidate generation itself went from 40 k to 26 k cycles.)
     int kcount = 0;
-    // (hull builds walk the key lanes over the near geoms: see above; RPK_MESH_KEYWALK = experiment: the window walk there too)
-#ifdef RPK_MESH_KEYWALK
-    constexpr bool KEYLANES = false;
-#else
+    // (ROUND 5: the window walk in every build.  The split stage's front part has no narrow phase to share registers
+    // with (160 VGPRs, no scratch) and takes the walk's 17 k cycles per mj_step; and since both ways of running the stage
+    // must emit the same candidates in the same ORDER to stay bit-identical, the one-kernel hull builds follow (round 4
+    // measured them 0.6 % slower with it).  RPK_MESH_KEYLANES = the old loop, for experiments.)
+#ifdef RPK_MESH_KEYLANES
     constexpr bool KEYLANES = MESH != 0;
+#else
+    constexpr bool KEYLANES = false;
 #endif
     unsigned long long remK0 = 0, remK1 = 0;   // hull builds: the capsules near this lane's two keys
     {
@@ -1829,6 +1820,60 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
                     const float rb = gb[9 + j1] * Qf[i][j2] + gb[9 + j2] * Qf[i][j1];
                     sp = sp || tl > ra + rb + 1e-4f;   // (unnormalised axis: both sides scale alike; the
                   }                                    //  allowance only makes the test more conservative)
+                }
+                has = has && !sp;
+              }
+            }
+          } else if constexpr (MESH != 0) {
+            // (ROUND 5) hull against key: the hull's bounding box (the box of its vertices in the geom frame: it contains
+            // the hull) against the key's box, all fifteen separating axes in fp32 with the 0.1 mm allowance of the other
+            // culls.  Until now such a pair went on with the window walk's world-axis test only, and a fingertip hovering
+            // a few millimetres over the keyboard was a candidate for every key under it: measured 21 hull pairs per env
+            // and mj_step on the replay against ~2 hull contacts -- each of them two or three trips of the portal
+            // refinement for the whole wave, and 1300 of the pooled narrow phase's 1900 waves per launch.
+            const int bi = bit - ncap;
+            const bool hb = has && bit >= ncap && bi < RPK_NBOXF && !((boxmask >> bit) & 1);
+            if (__builtin_amdgcn_ballot_w64(hb) != 0ull) {
+              const int src = a & 63;
+              const float c0 = (float)__shfl(kcos[0], src, 64), c1 = (float)__shfl(kcos[1], src, 64);
+              const float s0 = (float)__shfl(ksin[0], src, 64), s1 = (float)__shfl(ksin[1], src, 64);
+              if (hb) {
+                const float kc = a >= 64 ? c1 : c0, ks = a >= 64 ? s1 : s0;
+                const T *kp_ = M.key_pos() + 3 * a, *kh_ = M.key_half() + 3 * a;
+                const float hx = (float)kh_[0], hy = (float)kh_[1], hz = (float)kh_[2];
+                // key box: centre = anchor + R_y(q) (hx, 0, 0); axes = the columns of R_y(q)
+                const float bcx = (float)kp_[0] - hx + hx * kc, bcy = (float)kp_[1], bcz = (float)kp_[2] - hx * ks;
+                const float kb[12] = {kc, 0.f, ks, 0.f, 1.f, 0.f, -ks, 0.f, kc, hx, hy, hz};
+                const float* ga_ = sm.gbox[bi];
+                const float rx = (float)sm.gpos[bit][0] - bcx, ry = (float)sm.gpos[bit][1] - bcy, rz = (float)sm.gpos[bit][2] - bcz;   // (A centre - B centre)
+                float Rf[3][3], Qf[3][3], tf[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                  tf[i] = -(ga_[i] * rx + ga_[3 + i] * ry + ga_[6 + i] * rz);   // (B centre - A centre) in A's frame
+#pragma unroll
+                  for (int j = 0; j < 3; j++) {
+                    Rf[i][j] = ga_[i] * kb[j] + ga_[3 + i] * kb[3 + j] + ga_[6 + i] * kb[6 + j];
+                    Qf[i][j] = fabsf(Rf[i][j]) + 1e-6f;
+                  }
+                }
+                bool sp = false;
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                  sp = sp || fabsf(tf[i]) > ga_[9 + i] + kb[9] * Qf[i][0] + kb[10] * Qf[i][1] + kb[11] * Qf[i][2] + 1e-4f;
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                  sp = sp || fabsf(tf[0] * Rf[0][j] + tf[1] * Rf[1][j] + tf[2] * Rf[2][j]) >
+                                 kb[9 + j] + ga_[9] * Qf[0][j] + ga_[10] * Qf[1][j] + ga_[11] * Qf[2][j] + 1e-4f;
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+#pragma unroll
+                  for (int j = 0; j < 3; j++) {
+                    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+                    const float tl = fabsf(tf[i2] * Rf[i1][j] - tf[i1] * Rf[i2][j]);
+                    const float ra = ga_[9 + i1] * Qf[i2][j] + ga_[9 + i2] * Qf[i1][j];
+                    const float rb = kb[9 + j1] * Qf[i][j2] + kb[9 + j2] * Qf[i][j1];
+                    sp = sp || tl > ra + rb + 1e-4f;
+                  }
                 }
                 has = has && !sp;
               }
@@ -2758,6 +2803,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
   PROF(17);
   // ------------------------------------------------------------------ outputs
   if constexpr (MODE == 0 && PART != 1) {
+  if (!(S.stale_outputs && substep == nsub - 1)) {   // (legacy_step = False: see RpState::stale_outputs)
 #pragma unroll
   for (int s = 0; s < 2; s++) if (isk[s]) {
     if (kact[s] >= 0) S.act_vel[(size_t)env * nu + kact[s]] = M.act_coef()[2 * kact[s]] * qd[1 + s];
@@ -2778,12 +2824,13 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     S.contact_dist[(size_t)env * RPK_NCOUT + lane] = v ? con_dist : (T)0;
   }
   }
+  }
   if constexpr (MODE != 2) {
     int w = warn;
     w = wave_or(w);
     if (lane == 0) {
       S.warn[env] |= w;
-      if constexpr (MODE == 0 && PART != 1) S.ncon[env] = ncon;
+      if constexpr (MODE == 0 && PART != 1) { if (!(S.stale_outputs && substep == nsub - 1)) S.ncon[env] = ncon; }
       if constexpr (MODE == 1) {
         S.solver_iter[env] = (niter_last & 255) | ((__popcll(dirty_mask) & 255) << 8) | ((nkt & 255) << 16);
         S.time[env] = time;
@@ -2841,27 +2888,6 @@ __global__ __launch_bounds__(64, 2) void rp_pos_back_kernel(RpModel<T> M, RpStat
   if (blockIdx.x == 0 && threadIdx.x < RPK_NSTRIPE * RPK_NTYPE_PAD) B.tcount[B.tcount_off + threadIdx.x] = 0;
   const int env = S.order ? S.order[S.env_base + blockIdx.x] : S.env_base + (int)blockIdx.x;
   rp_stage_body<T, 0, 0, RPK_MAXD, MESH, false, 2>(M, S, B, substep, nsub, env, nullptr, (int)threadIdx.x);
-}
-
-// Lean solver stage + front part of the position stage of the state it produces, one wave per env in ONE launch (the
-// per-stage schedules with the split position stage): one launch boundary -- one tail of waves waiting for the slowest
-// env -- less per substep, and the front part starts from an env's new state the moment its solve ends.  Envs outside
-// the light class are not touched: their full-capacity solve and their (one-kernel) position stage run on the
-// companion stream (RpState::listed is rp_order_kernel's snapshot of the list).
-template <typename T, int MESH>
-__global__ __launch_bounds__(64, 2) void rp_lean_front_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep, int nsub) {
-  using namespace rpk;
-  constexpr size_t NB = sizeof(SmemLean<T>) > sizeof(SmemFront<T, RPK_MAXD>) ? sizeof(SmemLean<T>) : sizeof(SmemFront<T, RPK_MAXD>);
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NB];
-  const int env = S.order ? S.order[S.env_base + blockIdx.x] : S.env_base + (int)blockIdx.x;
-  if (S.active && S.active[env] == 0) return;
-  if (S.listed[env]) return;
-  int lane = (int)threadIdx.x;
-  asm volatile("" : "+v"(lane));
-  rp_lean_solver_body<T, true>(M, S, B, env, smem, lane);
-  RPK_STAGE_FENCE();
-  asm volatile("" : "+v"(lane));
-  rp_stage_body<T, 0, 0, RPK_MAXD, MESH, true, 1>(M, S, B, substep, nsub, env, smem, lane);
 }
 
 // The position / velocity stage of the envs on the compacted list (the envs outside the light class), on the companion

@@ -217,6 +217,11 @@ struct RpState {
   // (skip_heavy tests this snapshot -- 1 = rp_order_kernel put the env on the list of the substep just solved -- not
   // hdr[6], which the list's own position stage rewrites on the companion stream while the slice's launch reads it)
   const unsigned char* listed;
+  // dm_control's legacy_step = False (physics.step() = mj_step = mj_step1; mj_step2: position-dependent data is NOT
+  // refreshed after the last integration): the position stage that follows the LAST substep's solve keeps its outputs
+  // to itself (site positions, contacts, actuator velocities stay those of the state before that integration; the
+  // hand-over for the next step is written as always)
+  int stale_outputs;
   // fused substeps (rp_fused_steps_kernel): may be null -- where the state before the last substep's solver
   // stage goes (the acceleration-stage sensors belong to that state)
   T *qpos_prev, *qvel_prev;
@@ -244,7 +249,8 @@ template <typename S_, bool EXT> __device__ __forceinline__ S_& rp_smem(void* ex
   if constexpr (EXT) return *reinterpret_cast<S_*>(ext);
   else { __shared__ S_ own; return own; }
 }
-#define RPK_NPROF 48        // counters the host reads (slots 32.. belong to the lean solver stage)
+#define RPK_NPROF 48        // counters the stage kernels keep (slots 32.. belong to the lean solver stage)
+#define RPK_NPROF_ALL 64    // ... and the host reads: 48 + t / 56 + t = shader cycles / chunks of pooled list t (rp_narrow_kernel)
 #define RPK_NPROF_STAGE 32  // ... of which the stage kernels use the first 32 (their LDS is full: 20480 B at two waves per SIMD)
 // Per-phase shader-clock counters of env 0 (debug aid), accumulated in LDS so a probe
 // costs about one LDS round trip; flushed to global memory once at kernel exit.
@@ -285,7 +291,6 @@ struct RpStage {
   // narrow phase (lane = candidate, whatever env it belongs to, one routine per wave) fills the result records; the
   // back part (constraint rows, Jacobians, velocity stage) collects them in the one-kernel stage's emission order.
   T* frames;      // [E][RPK_NFRAME][64]   lane = link
-  T* gframe;      // [E][64][12]           geom world frame: pos[3], mat[9]
   int* cand;      // [E][RPK_NCAND][2]     ga | gb << 16 ; first result record | type << 16
   int* ncand;     // [E]                   candidates of this mj_step; -1: the front part did not run for this env
   T* cres;        // [E][RPK_NRES][12]     pos[3], normal[3], dist, mu, kterm, B, D (as covf)

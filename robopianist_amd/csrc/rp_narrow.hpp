@@ -473,7 +473,10 @@ __device__ __forceinline__ void prim_support(const CGeom<T>& g, const T* d, T* o
 // walk (geom_support), vertex for vertex.  Per-lane loads; the wave loops until its last walker has arrived.
 // (GRAPH = false: the builds for scenes without such hulls -- the benchmark's -- carry none of this: with the walk
 // compiled in, the position stage of the stand-in scene lost 4 %)
-template <typename T, bool GRAPH>
+// (LDSV: `mv` is a copy of the vertex table in LDS -- the pooled narrow phase, whose waves own no other LDS: the scan
+// reads it with uniform addresses (broadcast reads) and the winner's coordinates come back in ~130 cycles instead of
+// a dependent global round trip per support; the one-kernel stage's LDS is full and keeps the scalar-cache scan)
+template <typename T, bool GRAPH, bool LDSV = false>
 __device__ __forceinline__ void hull_support_wave(const T* mv, const T* hv, const int* hg, const CGeom<T>& g, const T* d, const bool need_any, T* out) {
   T dl[3];
   matT_vec(dl, g.mat, d);
@@ -509,9 +512,22 @@ __device__ __forceinline__ void hull_support_wave(const T* mv, const T* hv, cons
     const int base = bcast(g.vadr, L0), nv = bcast(g.nvert, L0);
     const bool mine = need && g.vadr == base;
     todo &= ~__ballot(mine);
-    const T RPK_CONST_AS* vb = uniform_const(mv + 3 * base);
     // (eight vertices per trip, so that their scalar loads are in flight together; the table pads every set to a
     // multiple of eight with copies of its last vertex, which cannot win a strict comparison against itself)
+    if constexpr (LDSV) {
+      const T* vb = mv + 3 * base;
+      for (int i = 0; i < nv; i += 8) {
+        T x[8], y[8], z[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { x[u] = vb[3 * (i + u)]; y[u] = vb[3 * (i + u) + 1]; z[u] = vb[3 * (i + u) + 2]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const T v = dl[0] * x[u] + dl[1] * y[u] + dl[2] * z[u];
+          if (mine && v > bv) { bv = v; bi = i + u; }
+        }
+      }
+    } else {
+    const T RPK_CONST_AS* vb = uniform_const(mv + 3 * base);
 #ifdef RPK_X_MPR_SHORTSCAN   // timing experiment only (wrong results): what the vertex scan costs
     for (int i = 0; i < 8; i += 8) {
 #else
@@ -525,6 +541,7 @@ __device__ __forceinline__ void hull_support_wave(const T* mv, const T* hv, cons
         const T v = dl[0] * x[u] + dl[1] * y[u] + dl[2] * z[u];
         if (mine && v > bv) { bv = v; bi = i + u; }
       }
+    }
     }
   }
   const int a = need_any ? 3 * (g.vadr + bi) : 0;
@@ -553,7 +570,7 @@ template <typename T> __device__ __forceinline__ void portal_dir(T* dir, const M
 #ifndef RPK_MPR_INLINE
 #define RPK_MPR_INLINE __forceinline__   // (inlined: as a real call it cost the position stage 290 more scratch operations, 19 of them in the drain loop)
 #endif
-template <typename T, bool GRAPH>
+template <typename T, bool GRAPH, bool LDSV = false>
 __device__ RPK_MPR_INLINE int convex_mpr_wave(RawCon<T>* __restrict__ out, const CGeom<T>* __restrict__ Ap,
                                             const CGeom<T>* __restrict__ Bp, const T* __restrict__ mv, const T* __restrict__ hv,
                                             const int* __restrict__ hg, const bool active) {
@@ -588,8 +605,8 @@ __device__ RPK_MPR_INLINE int convex_mpr_wave(RawCon<T>* __restrict__ out, const
       const T nd[3] = {-dir[0], -dir[1], -dir[2]};
       T p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
       const bool hA = run && A.type == GEOM_MESH_, hB = run && B.type == GEOM_MESH_;
-      if (__ballot(hA) != 0ull) hull_support_wave<T, GRAPH>(mv, hv, hg, A, nd, hA, p1);
-      if (__ballot(hB) != 0ull) hull_support_wave<T, GRAPH>(mv, hv, hg, B, dir, hB, p2);
+      if (__ballot(hA) != 0ull) hull_support_wave<T, GRAPH, LDSV>(mv, hv, hg, A, nd, hA, p1);
+      if (__ballot(hB) != 0ull) hull_support_wave<T, GRAPH, LDSV>(mv, hv, hg, B, dir, hB, p2);
       if (run && A.type != GEOM_MESH_) prim_support(A, nd, p1);
       if (run && B.type != GEOM_MESH_) prim_support(B, dir, p2);
 #pragma unroll

@@ -37,7 +37,7 @@ WARN_DENSE_FULL = 32
 
 EXPORTED_SYMBOLS = (
     "rp_create", "rp_destroy", "rp_reset", "rp_set", "rp_get", "rp_step", "rp_forward", "rp_step_masked",
-    "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_set_lazy_position_stage", "rp_set_cost_ordered_launch", "rp_set_stream_slices", "rp_set_lean_solver", "rp_set_fused_substeps", "rp_get_fused_substeps", "rp_set_split_position_stage", "rp_get_split_position_stage", "rp_set_acc_sensors", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
+    "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_set_lazy_position_stage", "rp_set_legacy_step", "rp_set_cost_ordered_launch", "rp_set_stream_slices", "rp_set_lean_solver", "rp_set_fused_substeps", "rp_get_fused_substeps", "rp_set_split_position_stage", "rp_get_split_position_stage", "rp_set_acc_sensors", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
     "rp_n_envs", "rp_dim",
     "rp_kernel_time", "rp_solver_kernel_time", "rp_solver_kernel_envs", "rp_solver_kernel_fused", "rp_profile", "rp_last_error",
 )
@@ -87,6 +87,7 @@ def load_library(path: str = LIB_PATH):
     L.rp_set_acc_sensors.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.rp_set_stream_slices.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.rp_set_lean_solver.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.rp_set_legacy_step.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.rp_set_fused_substeps.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.rp_get_fused_substeps.argtypes = [ctypes.c_void_p]
     L.rp_set_split_position_stage.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -270,6 +271,11 @@ class BatchedPhysics:
         """rp_step steps the batch as `n` (1 or 2; 0 = the engine picks) kernel chains (include/rp_engine.h)."""
         self._check(self._L.rp_set_stream_slices(self._h, int(n)))
 
+    def set_legacy_step(self, on: bool = True):
+        """dm_control's legacy_step (include/rp_engine.h: rp_set_legacy_step): False = the position-dependent outputs
+        after step() are those of the state before the last integration (mj_step order)."""
+        self._check(self._L.rp_set_legacy_step(self._h, int(bool(on))))
+
     def set_lean_solver(self, on=True):
         """Capacity classes of the solver stage (include/rp_engine.h: rp_set_lean_solver); an int > 1 caps the
         light class at that many contact Jacobian entries (tests: both classes in one small scene)."""
@@ -285,13 +291,15 @@ class BatchedPhysics:
         """True if rp_step currently runs the fused schedule."""
         return self._L.rp_get_fused_substeps(self._h) == 1
 
-    def set_split_position_stage(self, on: bool = True):
+    def set_split_position_stage(self, on=True):
         """Position stage of the substeps as front part / pooled narrow phase / back part (include/rp_engine.h:
-        rp_set_split_position_stage); bit-identical results."""
-        self._check(self._L.rp_set_split_position_stage(self._h, int(bool(on))))
+        rp_set_split_position_stage): False / True, or "auto" (2): a candidate of the engine's own schedule choice.
+        Bit-identical results."""
+        self._check(self._L.rp_set_split_position_stage(self._h, 2 if on == "auto" else int(on)))
 
     @property
     def split_position_stage(self) -> bool:
+        """True if rp_step currently runs the split position stage."""
         return self._L.rp_get_split_position_stage(self._h) == 1
 
     def set_cost_ordered_launch(self, on: bool = True):
@@ -325,8 +333,8 @@ class BatchedPhysics:
 
     def profile(self, enable=True):
         """Reads+clears the per-phase cycle counters of env 0, then (dis)enables them."""
-        out = np.zeros(48, np.int64)
-        self._check(self._L.rp_profile(self._h, out.ctypes.data, 48, int(bool(enable))))
+        out = np.zeros(64, np.int64)   # (RPK_NPROF_ALL: 0 .. 47 per-phase cycles of env 0, 48 .. 63 the pooled narrow phase's lists)
+        self._check(self._L.rp_profile(self._h, out.ctypes.data, 64, int(bool(enable))))
         return out
 
     @property

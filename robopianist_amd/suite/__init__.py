@@ -41,8 +41,6 @@ def load(
 ) -> environment.Environment:
     """Loads a (batched) RoboPianist environment; raises ValueError for unknown names."""
     del recompile_physics  # the model is compiled once and uploaded to the GPU
-    if not legacy_step:
-        raise ValueError("Only dm_control's legacy step order (mj_step2; mj_step1) is implemented.")
     if midi_file is not None:
         midi = music.load(midi_file, stretch=stretch, shift=shift)
     else:
@@ -53,7 +51,7 @@ def load(
     task_kwargs = dict(task_kwargs or {})
     task = piano_with_shadow_hands.PianoWithShadowHands(midi=midi, **task_kwargs)
     return environment.Environment(task, n_envs=n_envs, random_state=seed, device_id=device_id,
-                                   precision=precision)
+                                   precision=precision, legacy_step=legacy_step)
 
 
 __all__ = ["ALL", "DEBUG", "ETUDE_12", "REPERTOIRE_150", "load"]

@@ -26,7 +26,7 @@ from robopianist_amd.suite.specs import StepType, TimeStep
 class Environment:
     def __init__(self, task, n_envs: int = 1, random_state=None, device_id: int = 0,
                  precision: int = 64, physics=None, record_key_trace: bool = False,
-                 copy_outputs: bool = True):
+                 copy_outputs: bool = True, legacy_step: bool = True):
         self._task = task
         self._n_envs = int(n_envs)
         if isinstance(random_state, np.random.RandomState):
@@ -37,6 +37,14 @@ class Environment:
             from robopianist_amd.suite.physics import TorchPhysics
             physics = TorchPhysics(task.scene, self._n_envs, device_id=device_id, precision=precision)
         self._physics = physics
+        # composer.Environment(legacy_step=...) (robopianist/suite/__init__.py:91): False = every physics.step() is
+        # mj_step (mj_step1; mj_step2) -- same state trajectory; sites, contacts and velocity sensors are then the
+        # ones of the state before the last integration (include/rp_engine.h: rp_set_legacy_step)
+        self._legacy_step = bool(legacy_step)
+        if not self._legacy_step:
+            if not hasattr(getattr(physics, "engine", None), "set_legacy_step"):
+                raise ValueError("legacy_step=False needs the HIP engine (this physics object has no step-order switch)")
+            physics.engine.set_legacy_step(False)
         self._n_sub_steps = task.physics_steps_per_control_step
         task.bind(physics, self._n_envs, self._random_state)
         self._needs_reset = torch.ones(self._n_envs, dtype=torch.bool, device=physics.device)

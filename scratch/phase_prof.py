@@ -24,8 +24,13 @@ cand, passes = p[30], p[31]; p[30]=0; p[31]=0
 print('drain rounds/mj_step %.2f' % (p[26]/n/10)); p[26]=0
 print('capsule-box cands after prefilter/mj_step %.1f' % (p[27]/n/10)); p[27]=0
 print('geom-geom cands/mj_step %.1f key cands %.1f' % (p[28]/n/10, p[29]/n/10)); p[28]=0; p[29]=0
+pk = p[48:64].copy(); p[48:64] = 0
 tot = p.sum()
 print('candidates/mj_step %.1f  narrow passes/mj_step %.2f' % (cand/n/10, passes/n/10))
 print('total cycles/env-step (env0): %.0f  -> per mj_step %.0f' % (tot/n, tot/n/10), 'mean newton iters', np.mean([int(v)&255 for v in np.array(its).ravel()]) if False else '', 'ncon mean', phys.get(engine.NCON).mean())
 for i in sorted(names, key=lambda i:-p[i]):
     print('%-16s %10.0f cyc/mj_step  %5.1f%%' % (names[i], p[i]/n/10, 100*p[i]/tot))
+if pk[8:15].sum() > 0:
+    print('pooled narrow phase, per list (cc, cb, bb, hull buckets 3..6): chunks per launch / avg cycles per chunk')
+    for t in range(7):
+        if pk[8 + t]: print('  list %d: %8.1f chunks/launch  %9.0f cycles/chunk' % (t, pk[8 + t] / n / 10, pk[t] / pk[8 + t]))

@@ -462,6 +462,103 @@ def test_stream_slices_and_cost_order_are_bit_identical(two_hand_scene):
     assert ref.get(engine.NCON).max() > 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("primitive", [False, True])
+def test_split_position_stage_is_bit_identical(primitive):
+    """Round 5: the position / velocity stage as front part -> POOLED narrow phase (one wave per 64 candidate pairs of one
+    geom-type pair, whatever envs they belong to; csrc/rp_collide.hpp) -> back part, against the one-kernel stage: same
+    bits in qpos / qvel / contacts (order included) / sensors -- with one slice, with three slices on three streams (the
+    schedule the engine's own choice may pick), with masked resets and envs sitting out, and under the automatic choice
+    over enough steps to run every candidate schedule (3072 envs: the split schedule is a candidate from there)."""
+    import warnings
+    from robopianist_amd import engine
+    from robopianist_amd.model import scene
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=primitive)
+    m = si.model
+    E = 3080
+    ctrl = _replay_ctrl(si)
+    rng = np.random.default_rng(2)
+    gain = 1 + 0.1 * rng.standard_normal((E, 1))
+    phase = rng.integers(0, 40, E)
+    ref = engine.BatchedPhysics(m, si.key_joint_ids, n_envs=E, precision=64)
+    ref.set_split_position_stage(False); ref.set_stream_slices(1); ref.set_fused_substeps(False); ref.set_acc_sensors(True)
+    modes = []
+    for slices, split in ((1, True), (3, True), (2, True), (0, "auto")):
+        p = engine.BatchedPhysics(m, si.key_joint_ids, n_envs=E, precision=64)
+        p.set_stream_slices(slices); p.set_split_position_stage(split); p.set_acc_sensors(True)
+        if slices: p.set_fused_substeps(False)
+        modes.append(p)
+    assert modes[0].split_position_stage and not ref.split_position_stage
+    seen_split_auto = False
+    for t in range(72):
+        c = ctrl[(10 * (t + 20) + 10 * phase) % len(ctrl)] * gain
+        mask = None
+        if t == 8:
+            mask = np.zeros(E, np.uint8); mask[::7] = 1
+        for p in [ref] + modes:
+            p.set(engine.CTRL, c)
+            if mask is not None:
+                p.reset(mask)
+            if t == 12:
+                act = np.ones(E, np.int32); act[5::11] = 0
+                p.sync(); p.view(engine.ACTIVE).copy_(torch_i32(act)); torch_sync()
+            if t == 13:
+                p.sync(); p.view(engine.ACTIVE).fill_(1); torch_sync()
+            p.step(10)
+        seen_split_auto = seen_split_auto or modes[3].split_position_stage
+        for i, p in enumerate(modes):
+            assert np.array_equal(ref.qpos, p.qpos) and np.array_equal(ref.qvel, p.qvel), (t, i)
+            assert np.array_equal(ref.get(engine.NCON), p.get(engine.NCON)), (t, i)
+            assert np.array_equal(ref.get(engine.CONTACT_GEOMS), p.get(engine.CONTACT_GEOMS)), (t, i)
+            assert np.array_equal(ref.get(engine.CONTACT_DIST), p.get(engine.CONTACT_DIST)), (t, i)
+            assert np.array_equal(ref.get(engine.SENSOR_TORQUE), p.get(engine.SENSOR_TORQUE)), (t, i)
+            assert np.array_equal(ref.get(engine.SENSOR_TOUCH), p.get(engine.SENSOR_TOUCH)), (t, i)
+            assert p.warn_flags.max() == 0
+    assert ref.get(engine.NCON).max() >= 6
+
+
+def legacy_step_off(si, nsteps=24):
+    """dm_control's legacy_step=False on the engine (rp_set_legacy_step(e, 0); reference:
+    robopianist/suite/__init__.py:55,91): physics.step() = mj_step = mj_step1; mj_step2.  Two engines on the same
+    controls: A in the legacy order, B not.  After B.step(n) the state equals A's after n substeps, bit for bit, and B's
+    position-dependent outputs (sites, contacts, actuator velocities) are A's after n - 1 substeps -- what mjData holds
+    after mj_step.  Returns (max contacts seen, checks made)."""
+    from robopianist_amd import engine
+    m = si.model
+    A = engine.BatchedPhysics(m, si.key_joint_ids, n_envs=2, precision=64)
+    B = engine.BatchedPhysics(m, si.key_joint_ids, n_envs=2, precision=64)
+    B.set_legacy_step(False); B.set_lazy_position_stage(True)   # (the lazy mode must not hide the published outputs)
+    ctrl = wrist_press_sequence(si, nsteps)
+    A.forward(); B.forward()   # (physics.forward() after reset, as the env layer does: the outputs of the first state)
+    outs = (engine.SITE_XPOS, engine.NCON, engine.CONTACT_GEOMS, engine.CONTACT_DIST, engine.ACT_VELOCITY)
+    maxcon, checks = 0, 0
+    for t, c in enumerate(ctrl):
+        n = 1 + t % 3
+        for p in (A, B):
+            p.set(engine.CTRL, np.tile(c[None, :], (2, 1)))
+        B.step(n)
+        if n > 1:
+            A.step(n - 1)
+        before = [np.array(A.get(f)) for f in outs]        # A's outputs: the state before the last integration
+        A.step(1)
+        assert np.array_equal(A.qpos, B.qpos) and np.array_equal(A.qvel, B.qvel), t
+        for f, v in zip(outs, before):
+            assert np.array_equal(v, np.array(B.get(f))), (t, f)
+            checks += 1
+        assert not np.array_equal(np.array(A.get(engine.SITE_XPOS)), before[0])   # (the test can tell the two apart)
+        assert np.array_equal(np.array(A.get(engine.ACT_FORCE)), np.array(B.get(engine.ACT_FORCE)))   # (mj_step2's: same either way)
+        maxcon = max(maxcon, int(before[1].max()))
+    return maxcon, checks
+
+
+@pytest.mark.gpu
+def test_legacy_step_false_publishes_the_outputs_of_mj_step(two_hand_scene):
+    maxcon, checks = legacy_step_off(two_hand_scene, 90)
+    assert maxcon >= 2 and checks == 90 * 5
+
+
 def test_teacher_forced_fp64_hull_fingertips_with_four_forearm_dofs():
     """The reference's default fingertips (meshes -> hulls through MPR) on a hand with more than two forearm dofs
     (shadow_hand.py:41-69 allows any subset): the deep builds of the position / sensor stages with the hull narrow

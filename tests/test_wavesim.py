@@ -72,6 +72,23 @@ def test_pile_up_beyond_32_contacts_on_the_wave_emulator(wavesim_lib):
     assert worst < 1e-9, worst
 
 
+def test_legacy_step_false_on_the_wave_emulator(wavesim_lib):
+    """rp_set_legacy_step(e, 0) (dm_control's legacy_step=False: mj_step order) without a GPU: same state, outputs of the
+    state before the last integration (the GPU twin: test_legacy_step_false_publishes_the_outputs_of_mj_step)."""
+    maxcon, checks = _run_parity_fn(wavesim_lib, "legacy_step_off", 70)
+    assert checks == 350 and maxcon >= 2, (maxcon, checks)
+
+
+def test_split_position_stage_on_the_wave_emulator(wavesim_lib):
+    """The split position stage (front part / pooled narrow phase / back part, csrc/rp_collide.hpp) against the one-kernel
+    stage on the emulator, bit for bit, hull fingertips along the replay (the GPU twin:
+    test_split_position_stage_is_bit_identical)."""
+    env = dict(os.environ, RP_ENGINE_LIB=wavesim_lib, WAVESIM_SITE="0", RP_SKIP_SELF_CHECK="1")
+    out = subprocess.run([sys.executable, os.path.join(WS, "compare_split.py"), "60", "hull", "replay", "400"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "bit for bit" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_box_box_face_contacts_on_the_wave_emulator(wavesim_lib):
     """Box-box pairs with four to eight points (the palm flat on the keys) on the emulator."""
     worst, maxcon, pairs, most = _run_parity_fn(wavesim_lib, "palm_flat", 12)
