@@ -619,6 +619,13 @@ static int sphere_box_local(rawcon* c, const double* p, double r, const double* 
  * minimiser t* of the segment-box distance (root of the piecewise-linear derivative), second contact
  * at the segment END that lies deeper in / closer to the box (skipped when it coincides with t*).
  * The way MuJoCo picks its second point in edge / corner configurations is NOT reproduced. */
+/* Bisection knob (rpo_debug_set_capsule_box; oracle/bisect_golden.py): which points of the capsule's axis get a
+ * sphere-box contact.  0 (default, what the engine computes) = the point closest to the box, then the deeper END;
+ * 1 = the closest point only; 2 = the two ends only (no interior point); 3 = closest point + BOTH ends (up to three).
+ * The choice among these is what DESIGN section 8 lists as "not reproducible from memory" of mjc_CapsuleBox: a first real
+ * recording that disagrees with the default can be replayed under each variant to see which rule MuJoCo follows. */
+static int g_capbox_variant = 0;
+void rpo_debug_set_capsule_box(int variant) { g_capbox_variant = variant; }
 static int capsule_box(rawcon* out, const double* cp, const double* cm, const double* cs,
                        const double* bp, const double* bm, const double* bs, double margin) {
   double r = cs[0], l = cs[1];
@@ -661,10 +668,15 @@ static int capsule_box(rawcon* out, const double* cp, const double* cm, const do
   }
   double tend = dend[0] <= dend[1] ? -1.0 : 1.0;
   if (fabs(tend - tstar) < 1e-9) tend = -tend;
-  double cand[2] = {tstar, tend};
+  double cand[3] = {tstar, tend, -tend};
+  int ncand = 2;
+  if (g_capbox_variant == 1) ncand = 1;
+  else if (g_capbox_variant == 2) { cand[0] = -1.0; cand[1] = 1.0; }
+  else if (g_capbox_variant == 3) ncand = 3;
   int n = 0;
-  for (int i = 0; i < 2; i++) {
-    if (i > 0 && fabs(cand[i] - tstar) < 1e-9) continue;
+  for (int i = 0; i < ncand; i++) {
+    if (i > 0 && fabs(cand[i] - cand[0]) < 1e-9) continue;
+    if (i > 1 && fabs(cand[i] - cand[1]) < 1e-9) continue;
     double p[3] = {c[0]+cand[i]*a[0], c[1]+cand[i]*a[1], c[2]+cand[i]*a[2]};
     rawcon rc;
     if (sphere_box_local(&rc, p, r, bs, margin)) {

@@ -62,6 +62,8 @@ def lib():
         L.rpo_bench_seq.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                     ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.rpo_debug_set_mpr.argtypes = [ctypes.c_double, ctypes.c_int]
+        L.rpo_debug_set_capsule_box.argtypes = [ctypes.c_int]
+        L.rpo_debug_set_boxbox_max.argtypes = [ctypes.c_int]
         _lib = L
     return _lib
 
@@ -70,6 +72,28 @@ def set_mpr_experiment(tolerance: float = 1e-6, discrete: bool = False) -> None:
     """Experiment knob of the hull narrow phase (process-wide): the refinement's stopping tolerance, and `discrete`
     = polytope pairs stop when the support vertex already is a portal vertex (a tolerance-free rule)."""
     lib().rpo_debug_set_mpr(float(tolerance), int(bool(discrete)))
+
+
+# The narrow-phase choices this restatement could not pin from memory (DESIGN section 8), as process-wide switches, so
+# that the first real-MuJoCo recording that disagrees with the defaults can be bisected (oracle/bisect_golden.py).
+# Defaults = what the HIP engine computes; any other value is an ORACLE-ONLY experiment.
+NARROW_PHASE_VARIANTS = {
+    "capsule_box": {0: "closest axis point + the deeper end (default)", 1: "closest axis point only",
+                    2: "the two ends only", 3: "closest axis point + both ends"},
+    "boxbox_max": {8: "all clipped points, up to eight (default)", 4: "the first four", 3: "the first three", 1: "one point"},
+    "mpr": {"tolerance": "refinement stops at 1e-6 (default)", "discrete": "polytope pairs stop at a repeated support vertex",
+            "tight": "refinement stops at 1e-10"},
+}
+
+
+def set_narrow_phase_variant(capsule_box: int = 0, boxbox_max: int = 8, mpr: str = "tolerance") -> None:
+    """Selects one combination of NARROW_PHASE_VARIANTS (no arguments = the defaults)."""
+    if capsule_box not in NARROW_PHASE_VARIANTS["capsule_box"] or mpr not in NARROW_PHASE_VARIANTS["mpr"] or not 1 <= boxbox_max <= 8:
+        raise ValueError("unknown narrow-phase variant")
+    L = lib()
+    L.rpo_debug_set_capsule_box(int(capsule_box))
+    L.rpo_debug_set_boxbox_max(int(boxbox_max))
+    L.rpo_debug_set_mpr(1e-10 if mpr == "tight" else 1e-6, int(mpr == "discrete"))
 
 
 def chaos_control(model, blob, ctrl_seq, nstep=1000, hold=10, seeds=(0, 1, 2), eps0=1e-15, eps_step=0.0,

@@ -353,6 +353,30 @@ def test_subclass_before_step_is_not_bypassed_and_nan_actions_propagate():
     np.testing.assert_array_equal(cf[0], cr[0])
 
 
+def test_suite_load_legacy_step_false_runs_mj_step_order():
+    """suite.load(legacy_step=False) (robopianist/suite/__init__.py:55,91): physics.step() = mj_step.  Same state
+    trajectory as the legacy order on the same actions; the fingertip sites the task reads lag the state by one mj_step
+    (what mjData holds after mj_step); TimeSteps stay finite and episodes end at the same step."""
+    import os
+    from robopianist_amd import suite
+    from robopianist_amd.wrappers import CanonicalSpecWrapper
+    actions = np.load(os.path.join(os.path.dirname(__file__), "golden", "twinkle_twinkle_actions.npy"))
+    name = "RoboPianist-debug-TwinkleTwinkleRousseau-v0"
+    kw = dict(seed=3, n_envs=4, precision=64, task_kwargs=dict(trim_silence=True, control_timestep=0.05, gravity_compensation=True,
+                                                                primitive_fingertip_collisions=True))
+    a_env = CanonicalSpecWrapper(suite.load(name, **kw))
+    b_env = CanonicalSpecWrapper(suite.load(name, legacy_step=False, **kw))
+    a_env.reset(); b_env.reset()
+    lag = 0.0
+    for t in range(40):
+        at = torch.as_tensor(np.tile(actions[t], (4, 1)), device=a_env.physics.device, dtype=torch.float64)
+        ta, tb = a_env.step(at), b_env.step(at)
+        assert torch.equal(a_env.physics.qpos, b_env.physics.qpos) and torch.equal(a_env.physics.qvel, b_env.physics.qvel), t
+        assert torch.equal(ta.step_type, tb.step_type) and bool(torch.isfinite(tb.reward).all())
+        lag = max(lag, float((a_env.physics.site_xpos_eng - b_env.physics.site_xpos_eng).abs().max()))
+    assert 1e-6 < lag < 5e-3, lag   # (one 5 ms mj_step of fingertip motion)
+
+
 def test_midi_augmentations_fused_path_matches_torch_hooks():
     """MIDI augmentations (suite/variations.py) on the HIP task layer: per-env goal bank
     slots are regenerated on the host at every episode start; the fused launch must hand

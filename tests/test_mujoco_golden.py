@@ -10,6 +10,7 @@ them usable: mjModel dump -> compile.Model -> blob (robopianist_amd/tools/mjmode
 """
 import glob
 import os
+import sys
 import warnings
 
 import numpy as np
@@ -238,6 +239,41 @@ def synthetic_golden(tmp_path_factory):
     np.savez_compressed(path, ctrl=ctrl, qpos=np.asarray(qpos), qvel=np.asarray(qvel), qacc_warmstart=np.asarray(warm),
                         ncon=np.asarray(ncon), n_substeps=np.asarray(nsub), **imp.npz_from_model(si.model))
     return path
+
+
+def test_narrow_phase_variants_can_be_bisected_on_a_recording(tmp_path):
+    """oracle/bisect_golden.py: the choices DESIGN section 8 lists as not reproducible from memory (capsule-box second
+    point, box-box point count, MPR stopping rule) are switches of the oracle; a recording replayed under each tells
+    which rule its author followed.  Here the recorder is the oracle itself along the replay (capsule-box pairs with
+    two points): the default combination reproduces it exactly, the other capsule-box rules show up as
+    contact-count mismatches -- i.e. the switches are live and the tool ranks them."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_gpu_parity as tgp
+    from oracle import bisect_golden, rp_oracle
+    from oracle.rp_oracle import Oracle
+    from robopianist_amd import engine
+    from robopianist_amd.tools import mjmodel_to_blob as imp
+    si = _standin(primitive_fingertip_collisions=True)
+    orc = Oracle(si.model, engine.make_blob(si.model, si.key_joint_ids))
+    ctrl = tgp._replay_ctrl(si)[300:420]   # (one row per mj_step: proximal links lying on palm boxes, fingers on keys)
+    rec = dict(qpos=[orc.qpos.copy()], qvel=[orc.qvel.copy()], qacc_warmstart=[orc.qacc_warmstart.copy()], ncon=[])
+    for c in ctrl:
+        orc.ctrl[:] = c
+        orc.step(1)
+        rec["qpos"].append(orc.qpos.copy()); rec["qvel"].append(orc.qvel.copy())
+        rec["qacc_warmstart"].append(orc.qacc_warmstart.copy()); rec["ncon"].append(orc.ncon)
+    assert max(rec["ncon"]) >= 6
+    d = dict(ctrl=ctrl, n_substeps=np.asarray(1), **{k: np.asarray(v) for k, v in rec.items()}, **imp.npz_from_model(si.model))
+    rows = bisect_golden.bisect(d, grid=[(0, 8, "tolerance"), (1, 8, "tolerance"), (2, 8, "tolerance"), (0, 3, "tolerance")])
+    by = {(r["capsule_box"], r["boxbox_max"]): r for r in rows}
+    assert by[(0, 8)]["first_count_mismatch"] == -1 and by[(0, 8)]["worst_rel_dv"] == 0.0
+    assert by[(1, 8)]["first_count_mismatch"] >= 0   # (one point per pair: not the recorder's rule)
+    assert by[(2, 8)]["first_count_mismatch"] >= 0   # (the two ends only: neither)
+    # the switches are process-wide: the tool must leave the defaults behind
+    orc2 = Oracle(si.model, engine.make_blob(si.model, si.key_joint_ids))
+    orc2.qpos[:] = d["qpos"][60]; orc2.qvel[:] = d["qvel"][60]; orc2.qacc_warmstart[:] = d["qacc_warmstart"][60]
+    orc2.ctrl[:] = ctrl[60]; orc2.step(1)
+    assert orc2.ncon == int(d["ncon"][60]) and np.array_equal(orc2.qvel, d["qvel"][61])
 
 
 def test_golden_pathway_with_the_oracle_as_recorder(synthetic_golden):
