@@ -45,6 +45,7 @@ def bisect(path_or_dict, max_steps=None, grid=None):
             for i in range(n):
                 orc.qpos[:] = d["qpos"][i]; orc.qvel[:] = d["qvel"][i]; orc.qacc_warmstart[:] = d["qacc_warmstart"][i]
                 orc.ctrl[:] = d["ctrl"][i // nsub]
+                orc.step1()   # (the recorded state was written from outside: its position / velocity stage first)
                 orc.step(1)
                 if orc.ncon != int(d["ncon"][i]):   # (ncon[i]: the contacts of the state step i produced, as make_golden records it)
                     if first_bad < 0:

@@ -1682,6 +1682,10 @@ static void euler(const rpo_model* m, rpo_data* d) {
 }
 
 void rpo_forward(const rpo_model* m, rpo_data* d) { step1(m, d); acceleration_stage(m, d); }
+/* mj_step1 alone: the position / velocity stage of the CURRENT qpos / qvel, nothing else touched (in particular not
+ * qacc_warmstart, which rpo_forward's acceleration stage overwrites).  What a teacher-forced replay of a recording
+ * needs between writing a recorded state and rpo_step (= mj_step2 on the stage data in place; mj_step1 of the result). */
+void rpo_step1(const rpo_model* m, rpo_data* d) { step1(m, d); }
 
 void rpo_reset(const rpo_model* m, rpo_data* d) {
   int nv = m->nv;

@@ -79,6 +79,7 @@ double rpo_bench_seq(const rpo_model* m, int nenv, int nstep, const double* ctrl
  * hand-made one-dimensional problem  phi(alpha) = q0 + q1 alpha + q2 alpha^2 + sum_i row_i(jar_i + alpha jv_i)
  * with n rows of type[i] (0 friction-loss: D, floss, R used; 1 / 2 limit / contact: quadratic D x^2 / 2 on
  * x < 0).  Returns alpha; *evals = number of evaluations of phi it used. */
+void rpo_step1(const rpo_model* m, rpo_data* d);   /* mj_step1 of the current state only (teacher-forced replays) */
 /* bisection knobs of the narrow phase (oracle/rp_oracle.py: set_narrow_phase_variant; process-wide, defaults = the engine's rules) */
 void rpo_debug_set_capsule_box(int variant);
 void rpo_debug_set_boxbox_max(int n);

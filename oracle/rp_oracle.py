@@ -48,7 +48,7 @@ def lib():
         L.rpo_data_new.restype = ctypes.c_void_p
         L.rpo_data_new.argtypes = [ctypes.c_void_p]
         L.rpo_data_free.argtypes = [ctypes.c_void_p]
-        for f in ("rpo_reset", "rpo_forward", "rpo_step"):
+        for f in ("rpo_reset", "rpo_forward", "rpo_step", "rpo_step1"):
             getattr(L, f).argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.rpo_get_ptr.restype = ctypes.POINTER(ctypes.c_double)
         L.rpo_get_ptr.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
@@ -201,6 +201,12 @@ class Oracle:
 
     def forward(self):
         self._L.rpo_forward(self._model, self._data)
+
+    def step1(self):
+        """mj_step1 of the CURRENT qpos / qvel (position / velocity stage only; qacc_warmstart untouched): call it after
+        writing a state from outside -- `step` runs mj_step2 on the stage data in place, i.e. on the data of whatever
+        state the previous call left."""
+        self._L.rpo_step1(self._model, self._data)
 
     def step(self, n: int = 1):
         for _ in range(n):

@@ -165,6 +165,9 @@ def _check_oracle(path, free_tol=1e-4):
 
     def step(q, v, w, c):
         orc.qpos[:] = q; orc.qvel[:] = v; orc.qacc_warmstart[:] = w; orc.ctrl[:] = c
+        # (round 5: the stage data of the WRITTEN state first -- `step` is mj_step2; mj_step1 and would otherwise solve
+        # on the data of the oracle's own previous state, which only a recording made by this oracle reproduces)
+        orc.step1()
         orc.step(1)
         return orc.qpos.copy(), orc.qvel.copy(), orc.ncon
     assert _teacher_forced(step, d, nsub) < 1e-9
@@ -272,7 +275,7 @@ def test_narrow_phase_variants_can_be_bisected_on_a_recording(tmp_path):
     # the switches are process-wide: the tool must leave the defaults behind
     orc2 = Oracle(si.model, engine.make_blob(si.model, si.key_joint_ids))
     orc2.qpos[:] = d["qpos"][60]; orc2.qvel[:] = d["qvel"][60]; orc2.qacc_warmstart[:] = d["qacc_warmstart"][60]
-    orc2.ctrl[:] = ctrl[60]; orc2.step(1)
+    orc2.ctrl[:] = ctrl[60]; orc2.step1(); orc2.step(1)
     assert orc2.ncon == int(d["ncon"][60]) and np.array_equal(orc2.qvel, d["qvel"][61])
 
 
