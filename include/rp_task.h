@@ -129,6 +129,13 @@ typedef struct rp_task_advance_args {
    * suite/tasks/piano_with_shadow_hands.py:212-220) */
   int warn_count_mask;
   long long* warn_count;             /* [E] or NULL */
+  /* optional (traj_record == NULL: off): the compact per-env trajectory record of the multi-GPU gather (SURVEY 8e,
+   * robopianist_amd/distributed.py: pack_trajectory_record), written by this launch straight into the buffer the
+   * all-gather sends -- no allocation and no extra launch per step on the N > 1 path.  One row per env, in the engine's
+   * precision T:  qpos[nv] | reward | discount | step_type | the 88 activation bits as raw bytes (little-endian, key k
+   * = bit k % 8 of byte k / 8) in the last 16 / sizeof(T) + (T == float) words, i.e. 2 (double) or 3 (float).
+   * Row length = nv + 3 + (T == double ? 2 : 3). */
+  void* traj_record;
 } rp_task_advance_args;
 
 int rp_task_advance(const rp_task_advance_args* args, void* hip_stream);

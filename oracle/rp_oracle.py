@@ -96,8 +96,14 @@ def set_narrow_phase_variant(capsule_box: int = 0, boxbox_max: int = 8, mpr: str
     L.rpo_debug_set_mpr(1e-10 if mpr == "tight" else 1e-6, int(mpr == "discrete"))
 
 
+def first_crossing(rel, level=1e-6):
+    """First mj_step (1-based) at which the per-step relative error curve `rel` exceeds `level`; 0 = never."""
+    idx = np.nonzero(np.asarray(rel) > level)[0]
+    return int(idx[0]) + 1 if len(idx) else 0
+
+
 def chaos_control(model, blob, ctrl_seq, nstep=1000, hold=10, seeds=(0, 1, 2), eps0=1e-15, eps_step=0.0,
-                  marks=(1, 10, 100, 300, 1000)):
+                  marks=(1, 10, 100, 300, 1000), cross_level=1e-6):
     """The CONTROL of the free-running parity figure: the oracle against ITSELF with a rounding-sized perturbation,
     on the action stream `ctrl_seq` [T, nu] (one row per `hold` mj_steps) from the reset state.
       eps0     one-time perturbation of qpos after the reset: qpos += eps0 * N(0, 1)
@@ -119,16 +125,19 @@ def chaos_control(model, blob, ctrl_seq, nstep=1000, hold=10, seeds=(0, 1, 2), e
         o = Oracle(model, blob)
         o.reset()
         o.qpos[:] += eps0 * rng.standard_normal(model.nv)
-        worst, curve = 0.0, {}
+        worst, curve, cross = 0.0, {}, 0
         for i in range(nstep):
             o.ctrl[:] = ctrl_seq[(i // hold) % ctrl_seq.shape[0]]
             o.step(1)
             if eps_step:
                 o.qvel[:] *= 1.0 + eps_step * rng.standard_normal(model.nv)
             worst = max(worst, float((np.abs(o.qpos - ref[i]) / np.maximum(np.abs(ref[i]), 1e-2)).max()))
+            if not cross and worst > cross_level:
+                cross = i + 1   # (the mj_step at which this control leaves the reference trajectory: the chaotic event)
             if i + 1 in marks:
                 curve[str(i + 1)] = worst
-        out.append({"seed": int(seed), "max_rel_qpos_error": worst, "running_max_at_mj_step": curve})
+        out.append({"seed": int(seed), "max_rel_qpos_error": worst, "running_max_at_mj_step": curve,
+                    "first_mj_step_above_%g" % cross_level: cross})
     return out
 
 

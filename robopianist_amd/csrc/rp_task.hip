@@ -284,6 +284,16 @@ __global__ __launch_bounds__(64) void rp_task_advance_kernel(rp_task_advance_arg
       if (pressed && g == (T)0) fail = 1;
     }
   }
+  if (p.traj_record) {
+    T* rec = (T*)p.traj_record + (size_t)env * (a.nv + 3 + (sizeof(T) == 8 ? 2 : 3));
+    for (int i = lane; i < a.nv; i += 64) rec[i] = qpos[i];
+    const unsigned long long b0 = __ballot(kv.pressed[0]), b1 = __ballot(kv.pressed[1]);
+    if (lane == 0) {
+      unsigned* w = (unsigned*)(rec + a.nv + 3);
+      w[0] = (unsigned)b0; w[1] = (unsigned)(b0 >> 32); w[2] = (unsigned)b1;
+      if (sizeof(T) == 8) w[3] = 0u;
+    }
+  }
   const T gsus = gstate[88];
   const bool sus_on = ((const T*)p.sustain_state)[env] >= (T)p.sustain_threshold;
   kv.goal_sustain = gsus; kv.sustain_on = sus_on;
@@ -360,6 +370,10 @@ __global__ __launch_bounds__(64) void rp_task_advance_kernel(rp_task_advance_arg
     ((T*)a.total)[env] = reward;
     ((T*)p.discount)[env] = disc;
     p.step_type[env] = st;
+    if (p.traj_record) {   // (the multi-GPU gather's record: reward | discount | step_type; qpos and the bits below)
+      T* rec = (T*)p.traj_record + (size_t)env * (a.nv + 3 + (sizeof(T) == 8 ? 2 : 3)) + a.nv;
+      rec[0] = reward; rec[1] = disc; rec[2] = (T)st;
+    }
     p.t_idx[env] = t;
     p.should_terminate[env] = t == slen;
     p.failure_termination[env] = failure;

@@ -93,6 +93,7 @@ def build_scene(
     disable_hand_collisions: bool = False,
     root_sites: bool = False,
     mesh_colliders: int = 0,
+    standin_wrist_clearance: bool = False,
 ) -> SceneInfo:
     """`mesh_colliders` = n > 0 (extension, for tests and the large-hull bench figure): every collider of the hands
     becomes a convex hull of ~n vertices inscribed in its stand-in primitive -- what the reference's default hand looks
@@ -121,6 +122,7 @@ def build_scene(
             side=side, forearm_dofs=forearm_dofs,
             reduced_action_space=reduced_action_space,
             primitive_fingertip_collisions=primitive_fingertip_collisions,
+            standin_wrist_clearance=standin_wrist_clearance,
         )
         position = RIGHT_HAND_POSITION if side == "right" else LEFT_HAND_POSITION
         quaternion = RIGHT_HAND_QUATERNION if side == "right" else LEFT_HAND_QUATERNION

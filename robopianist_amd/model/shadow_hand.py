@@ -127,8 +127,16 @@ class HandBuilder:
         restrict_wrist_yaw_range: bool = False,
         reduced_action_space: bool = False,
         primitive_fingertip_collisions: bool = True,
+        standin_wrist_clearance: bool = False,
     ):
         assert side in ("right", "left")
+        # DIAGNOSTIC VARIANT (off by default; oracle/standin_report.py, bench.py `aux.standin_wrist_clearance`): with the
+        # from-memory numbers the forearm's wrist box and the palm boxes -- two rigid links, two joints apart --
+        # interpenetrate by up to 7.6 mm when WRJ2 alone is driven to the negative end of its range, and that pair is in
+        # contact on 43 % / 61 % of the replay's mj_steps.  On: the box sits 12 mm lower (no rigid-link overlap left in
+        # the single-joint sweep apart from neighbouring fingers abducted into each other).  The default stays what
+        # memory says the menagerie XML holds: the six-digit box numbers are not this repo's to tune.
+        self.standin_wrist_clearance = bool(standin_wrist_clearance)
         self.primitive_fingertips = bool(primitive_fingertip_collisions)
         for d in forearm_dofs:
             if d not in FOREARM_DOFS:
@@ -254,7 +262,7 @@ class HandBuilder:
         # menagerie's box near the wrist.
         fa.geoms.append(self._capsule("forearm_col", 0.04, 0.07, (0, 0, 0.08)))
         fa.geoms.append(self._box("forearm_box", (0.035, 0.035, 0.035),
-                                  (0.01, 0, 0.181), (0.380188, 0.924909, 0, 0)))
+                                  (0.01, 0, 0.169 if self.standin_wrist_clearance else 0.181), (0.380188, 0.924909, 0, 0)))
         wr = fa.add(self._body("wrist", (0.01, 0, 0.21301), 0.1, (0, 0, 0.029),
                                (0.5, 0.5, 0.5, 0.5), (6.4e-05, 4.38e-05, 3.5e-05)))
         wr.joints.append(self._joint("WRJ2", "wrist_y"))

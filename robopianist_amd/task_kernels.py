@@ -57,6 +57,7 @@ class AdvanceArgs(ctypes.Structure):
         ("next_ready", ctypes.c_void_p), ("consumed", ctypes.c_void_p),
         ("warn_fatal_mask", ctypes.c_int), ("fatal_count", ctypes.c_void_p),
         ("warn_count_mask", ctypes.c_int), ("warn_count", ctypes.c_void_p),
+        ("traj_record", ctypes.c_void_p),
     ]
 
 
@@ -204,6 +205,20 @@ class FusedAdvance:
         self._p = p
         self._L_lookahead = int(n_lookahead)
 
+    def enable_trajectory_record(self, n_buffers: int = 2):
+        """The multi-GPU gather's per-env record (include/rp_task.h `traj_record`; distributed.pack_trajectory_record's
+        layout) written by every launch from now on, into `n_buffers` preallocated buffers in turn (two: the
+        asynchronous all-gather of step t may still read its buffer while step t + 1 writes the other).
+        `trajectory_record` is the buffer the last launch filled."""
+        E, dt, dev = self._E, self._dt, self._rw._phys.device
+        width = int(self._rw._args.nv) + 3 + (2 if dt == torch.float64 else 3)
+        self._traj = [torch.zeros((E, width), device=dev, dtype=dt) for _ in range(max(1, int(n_buffers)))]
+        self._traj_i = -1
+
+    @property
+    def trajectory_record(self):
+        return None if getattr(self, "_traj", None) is None or self._traj_i < 0 else self._traj[self._traj_i % len(self._traj)]
+
     def set_prefetch_buffers(self, next_ready, consumed):
         """Double-buffered goal bank (include/rp_task.h `next_ready` / `consumed`); None: off."""
         p, E = self._p, self._E
@@ -254,6 +269,11 @@ class FusedAdvance:
         p.finger_next = _chk(finger_next, torch.int64, (E, 88))
         p.fingering_state = _chk(fingering_state, dt, (E, 5 if a.hand_filter else 10))
         p.needs_reset = _chk(needs_reset, torch.bool, (E,))
+        if getattr(self, "_traj", None) is not None:
+            self._traj_i += 1
+            p.traj_record = self._traj[self._traj_i % len(self._traj)].data_ptr()
+        else:
+            p.traj_record = None
         with torch.cuda.device(self._rw._phys.device):
             stream = torch.cuda.current_stream(self._rw._phys.device).cuda_stream
             rc = self._L.rp_task_advance(ctypes.byref(p), ctypes.c_void_p(stream))

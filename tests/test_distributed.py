@@ -89,3 +89,46 @@ def test_two_rank_gloo_gather():
     for _, ids, _ in res:
         assert ids == list(map(float, range(total)))
     assert res[0][2] == pytest.approx(res[1][2])
+
+
+def _nccl_worker(rank, world, port, total_envs, out_q):
+    """One rank per GPU over RCCL (backend "nccl" IS RCCL on ROCm): the same gather as the gloo test, device tensors."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r, w, local_rank = rpd.init_from_env(backend="nccl")
+    dev = torch.device("cuda", local_rank)
+    start, stop = rpd.shard_envs(total_envs, r, w)
+    local = torch.zeros((stop - start, 145), dtype=torch.float64, device=dev)   # (the fp64 record's width: 140 + 5)
+    local[:, 0] = torch.arange(start, stop, device=dev)
+    local[:, 1] = float(rpd.rank_seed(12345, r))
+    out = torch.empty((total_envs, 145), dtype=torch.float64, device=dev)
+    full, work = rpd.gather_trajectories(local, async_op=True, out=out)   # (the enqueue-only form bench.py uses)
+    work.wait()
+    torch.cuda.synchronize(dev)
+    full2 = rpd.gather_trajectories(local)
+    assert torch.equal(full, full2) and full.data_ptr() == out.data_ptr()
+    dist.barrier()
+    out_q.put((r, full[:, 0].cpu().tolist(), full[:, 1].cpu().tolist()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2,
+                    reason="the RCCL gather needs two GPUs (one rank per device); the gloo twin above runs everywhere")
+def test_two_rank_rccl_gather():
+    """Round 5: the first multi-GPU driver run must not also be RCCL's first run -- wherever two devices are
+    visible, two ranks all-gather the trajectory record over the nccl (= RCCL) backend, blocks in global env order."""
+    world, total = 2, 4096
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for _, ids, seeds in res:
+        assert ids == list(map(float, range(total)))
+        assert seeds[:total // 2] == [12345.0] * (total // 2) and seeds[total // 2:] == [13345.0] * (total // 2)

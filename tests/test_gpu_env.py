@@ -377,6 +377,32 @@ def test_suite_load_legacy_step_false_runs_mj_step_order():
     assert 1e-6 < lag < 5e-3, lag   # (one 5 ms mj_step of fingertip motion)
 
 
+@pytest.mark.parametrize("precision", [64, 32])
+def test_fused_launch_writes_the_trajectory_record_of_the_gather(precision):
+    """Round 5: the multi-GPU gather's per-env record (qpos | reward | discount | step type | 88
+    activation bits) comes out of the rp_task_advance launch, into two preallocated buffers in turn -- byte for byte what
+    distributed.pack_trajectory_record builds from the TimeStep with half a dozen torch launches and two allocations."""
+    import os
+    from robopianist_amd import distributed as rpd
+    actions = np.load(os.path.join(os.path.dirname(__file__), "golden", "twinkle_twinkle_actions.npy"))
+    fused, _ = _load_pair(3, precision)
+    fused.reset()
+    fa = fused.task.fused_advance_for(fused.physics)
+    fa.enable_trajectory_record(2)
+    nv = fused.physics.qpos.shape[1]
+    seen, ptrs = 0, set()
+    for t in range(45):
+        a = np.tile(actions[t], (3, 1)); a[1] = actions[(t + 30) % len(actions)]
+        ts = fused.step(torch.as_tensor(a, device=fused.physics.device, dtype=fused.physics.dtype))
+        rec = fa.trajectory_record
+        ref = rpd.pack_trajectory_record(fused.physics.qpos, ts.reward, ts.discount, ts.step_type, fused.task.piano.activation)
+        assert rec.dtype == ref.dtype and rec.shape == ref.shape == (3, nv + (5 if precision == 64 else 6))
+        assert torch.equal(rec.view(torch.uint8), ref.view(torch.uint8)), t
+        assert torch.equal(rpd.unpack_key_activation(rec, nv), fused.task.piano.activation)
+        seen += int(fused.task.piano.activation.sum()); ptrs.add(rec.data_ptr())
+    assert seen > 0 and len(ptrs) == 2   # keys were pressed; exactly the two preallocated buffers were used
+
+
 def test_midi_augmentations_fused_path_matches_torch_hooks():
     """MIDI augmentations (suite/variations.py) on the HIP task layer: per-env goal bank
     slots are regenerated on the host at every episode start; the fused launch must hand

@@ -227,9 +227,13 @@ def test_replay_fp64_1000_steps_hull():
     through MPR; /root/reference/robopianist/models/hands/shadow_hand.py:105-107), the configuration bench.py's
     `value` is quoted on.  This trajectory is more sensitive than the capsule one (the stand-in hand's ring / little
     finger bounce on each other around step 430), so the free-running engine-vs-oracle figure is judged against its
-    CONTROL: the oracle against itself started qpos0 + 1e-14 N(0, 1) away (oracle.rp_oracle.chaos_control, eight
-    seeds).  Asserted: (a) while the trajectory is still smooth (300 mj_steps) engine and oracle agree to 1e-8;
-    (b) over 1000 mj_steps the engine separates from the oracle no further than 2x the worst control does."""
+    CONTROL: the oracle against itself started qpos0 + 1e-14 N(0, 1) away (oracle.rp_oracle.chaos_control, sixteen
+    seeds).  Asserted (round 5: tightened from "<= 2 x the worst of eight"):
+      (a) while the trajectory is still smooth (300 mj_steps) engine and oracle agree to 1e-8;
+      (b) over 1000 mj_steps the engine's error is at most 3 x the MEDIAN control's (a typical second trajectory, not
+          the luckiest-worst one);
+      (c) the engine leaves the oracle (error above 1e-6) no earlier than the EARLIEST control does: the separation
+          happens at the trajectory's own chaotic event, not at an engine-specific one."""
     from robopianist_amd.model import scene
     from oracle.rp_oracle import chaos_control
     with warnings.catch_warnings():
@@ -239,13 +243,20 @@ def test_replay_fp64_1000_steps_hull():
     rel, maxcon = free_running(si, 64, ctrl)
     from robopianist_amd import engine
     blob = engine.make_blob(si.model, si.key_joint_ids)
-    control = chaos_control(si.model, blob, ctrl[::10], nstep=1000, hold=10, seeds=range(8), eps0=1e-14)
-    cworst = max(r["max_rel_qpos_error"] for r in control)
+    from oracle.rp_oracle import first_crossing
+    control = chaos_control(si.model, blob, ctrl[::10], nstep=1000, hold=10, seeds=range(16), eps0=1e-14)
+    cerr = sorted(r["max_rel_qpos_error"] for r in control)
+    ccross = sorted(r["first_mj_step_above_1e-06"] for r in control)
+    ecross = first_crossing(np.maximum.accumulate(rel), 1e-6)
     print("fp64 hull replay rel err @[1,10,100,300,1000]:", rel[[0, 9, 99, 299, 999]], "max", rel.max(), "max contacts", maxcon)
-    print("control (oracle vs oracle + 1e-14):", sorted(r["max_rel_qpos_error"] for r in control))
+    print("control (oracle vs oracle + 1e-14), max rel err:", cerr)
+    print("first mj_step above 1e-6: engine", ecross, "controls", ccross)
     assert maxcon >= 8
     assert rel[:300].max() < 1e-8
-    assert rel.max() <= 2.0 * cworst, (rel.max(), cworst)
+    cmed = float(np.median(cerr))
+    assert rel.max() <= 3.0 * cmed, (rel.max(), cmed)
+    assert all(c > 0 for c in ccross), ccross   # (every control does separate: the trajectory is chaotic, not the engine)
+    assert ecross == 0 or ecross >= ccross[0], (ecross, ccross)
 
 
 def test_replay_fp32_curve_is_reported(two_hand_scene):
@@ -557,6 +568,24 @@ def legacy_step_off(si, nsteps=24):
 def test_legacy_step_false_publishes_the_outputs_of_mj_step(two_hand_scene):
     maxcon, checks = legacy_step_off(two_hand_scene, 90)
     assert maxcon >= 2 and checks == 90 * 5
+
+
+@pytest.mark.gpu
+def test_replay_teacher_forced_fp64_hull_full_episode():
+    """Round 5: THE CONTRACT on the configuration `value` is quoted on -- every one of the 1580 mj_steps of
+    the scripted Twinkle replay with the reference's default fingertip collider (hulls through MPR), restarted from the
+    oracle's state: 1e-9 of the step's velocity change, equal contact counts, through the region (mj_steps 420-440 and
+    on) where the free-running trajectory goes chaotic.  Until round 5 this was evidenced for 300 steps, in bench.py only."""
+    from robopianist_amd.model import scene
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=False)
+    ctrl = _replay_ctrl(si)
+    assert len(ctrl) == 1580
+    worst, maxcon = teacher_forced(si, 64, ctrl)
+    print("teacher-forced fp64, hull replay, 1580 mj_steps: worst rel dv", worst, "max contacts", maxcon)
+    assert maxcon >= 10
+    assert worst < 1e-9
 
 
 def test_teacher_forced_fp64_hull_fingertips_with_four_forearm_dofs():
