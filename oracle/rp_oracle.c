@@ -874,9 +874,18 @@ static int box_box(rawcon* out, const double* p1, const double* m1, const double
  * (1e-6, 50). */
 #define CCD_TOL 1e-6
 #define CCD_ITER 50
+/* Round 5: POLYTOPE pairs (neither side a capsule) refine until the support point is within CCD_TOL_POLY of the portal.
+ * For two polytopes the refinement ends on a face of B - A after finitely many steps (reach = 0 to rounding); with the
+ * 1e-6 rule it may ALSO end one step earlier, on a portal up to 1e-6 short of that face -- and whether it does depends
+ * on rounding-sized differences of the search direction (which of several tied support vertices comes first).  Two
+ * implementations then return depths up to 1e-6 apart: at mj_step 1058 of the hull replay the engine stopped 1.7e-7
+ * short of the oracle, 1.6 % of that step's velocity change (1579 of 1580 mj_steps agree to 1e-11).  Converged, the
+ * result no longer depends on the path.  Pairs with a capsule (a smooth support) keep MuJoCo's 1e-6. */
+#define CCD_TOL_POLY 1e-10
 static double g_mpr_tol = CCD_TOL;   /* experiment knobs (rpo_debug_set_mpr) */
 static int g_mpr_discrete = 0;
-void rpo_debug_set_mpr(double tol, int discrete) { g_mpr_tol = tol; g_mpr_discrete = discrete; }
+static int g_mpr_uniform = 0;        /* 1: CCD_TOL for polytope pairs too (MuJoCo's uniform rule; bisect variant "uniform") */
+void rpo_debug_set_mpr(double tol, int discrete) { g_mpr_tol = tol < 0 ? CCD_TOL : tol; g_mpr_uniform = tol < 0; g_mpr_discrete = discrete; }
 #define HULL_GRAPH_ROW 24   /* ints per vertex of mesh_graph: degree + neighbours (model/hull.py: GRAPH_ROW) */
 typedef struct { int type; const double *pos, *mat, *size; const double* vert; int nvert; const int32_t* graph; } cgeom;
 typedef struct { double v[3], p1[3], p2[3]; int id; } mpoint;   /* point of B - A, its witnesses on A and B; id = (vertex of A, vertex of B) for polytopes */
@@ -979,7 +988,8 @@ static int mpr_penetration(const cgeom* A, const cgeom* B, rawcon* out) {
     mpr_support(A, B, dir, &v4);
     double reach = dot3(v4.v, dir) - dot3(v1.v, dir);
     if (!hit && dot3(v4.v, dir) < 0) return 0;             /* the origin lies beyond the support plane */
-    int stop = reach <= g_mpr_tol;
+    const int poly = A->type != GEOM_CAPSULE && B->type != GEOM_CAPSULE;
+    int stop = reach <= ((poly && !g_mpr_uniform && g_mpr_tol > CCD_TOL_POLY) ? CCD_TOL_POLY : g_mpr_tol);
     if (g_mpr_discrete && A->type != GEOM_CAPSULE && B->type != GEOM_CAPSULE)
       stop = v4.id == v1.id || v4.id == v2.id || v4.id == v3.id || reach <= 1e-10;
     if (stop || it == CCD_ITER) {

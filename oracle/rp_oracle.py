@@ -81,8 +81,8 @@ NARROW_PHASE_VARIANTS = {
     "capsule_box": {0: "closest axis point + the deeper end (default)", 1: "closest axis point only",
                     2: "the two ends only", 3: "closest axis point + both ends"},
     "boxbox_max": {8: "all clipped points, up to eight (default)", 4: "the first four", 3: "the first three", 1: "one point"},
-    "mpr": {"tolerance": "refinement stops at 1e-6 (default)", "discrete": "polytope pairs stop at a repeated support vertex",
-            "tight": "refinement stops at 1e-10"},
+    "mpr": {"tolerance": "refinement stops at 1e-6, polytope pairs at 1e-10 (default)", "uniform": "1e-6 for every pair (MuJoCo's rule)",
+            "discrete": "polytope pairs stop at a repeated support vertex", "tight": "refinement stops at 1e-10"},
 }
 
 
@@ -93,7 +93,7 @@ def set_narrow_phase_variant(capsule_box: int = 0, boxbox_max: int = 8, mpr: str
     L = lib()
     L.rpo_debug_set_capsule_box(int(capsule_box))
     L.rpo_debug_set_boxbox_max(int(boxbox_max))
-    L.rpo_debug_set_mpr(1e-10 if mpr == "tight" else 1e-6, int(mpr == "discrete"))
+    L.rpo_debug_set_mpr(1e-10 if mpr == "tight" else (-1.0 if mpr == "uniform" else 1e-6), int(mpr == "discrete"))
 
 
 def first_crossing(rel, level=1e-6):

@@ -564,6 +564,7 @@ struct Engine : EngineBase {
 #else
   static constexpr bool x_no_heavy = false, x_order_twice = false;
 #endif
+  bool heavy_after_lean = !(getenv("RP_HEAVY_AFTER") && getenv("RP_HEAVY_AFTER")[0] == '0');   // (experiment switch)
   bool companion = !(getenv("RP_COMPANION") && getenv("RP_COMPANION")[0] == '0');   // (experiment: the full-capacity launch on the slice's own stream)
   // (Experiment, RP_HEAVY_PRIORITY=1: the companion stream at the highest priority the device offers.  The idea: the
   // full-capacity launch and the lean one become ready together, and whichever is dispatched first takes the machine
@@ -974,6 +975,11 @@ struct Engine : EngineBase {
         }
         // (RP_X_NO_HEAVY=1: MEASUREMENT ONLY -- the full-capacity launch is suppressed, envs outside the light class are
         // not stepped at all: what the launch costs a batch whose lists are empty)
+        // (without a companion stream -- the three-slice schedule -- the lean launch goes FIRST: the full-capacity stage's
+        // workgroups each need a whole idle SIMD, and in front of the lean launch they would hold it back until the
+        // other slices' kernels have drained that much; behind it they start as the lean waves retire)
+        const bool heavy_after = heavy_after_lean && hs == st && lean && listed;
+        if (heavy_after) hipLaunchKernelGGL((rp_lean_solver_kernel<T>), dim3(cnt), dim3(64), 0, st, M, ss, B);
         if (x_no_heavy && listed) { /* nothing */ }
         else if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 0, RPK_MAXD_DEEP>), dim3(hgrid), dim3(64), 0, hs, M, sh, B, k, nsub);
         else if (trunk4) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 4>), dim3(hgrid), dim3(64), 0, hs, M, sh, B, k, nsub);
@@ -983,7 +989,7 @@ struct Engine : EngineBase {
         // (config 3: 0.27 ms of every 0.81 ms substep); the streams join after it, in front of the next order pass
         const bool split_pos = split_step && listed && !sense;
         if (hs != st && !split_pos) HIP_OK(hipEventRecord(ev_hjoin[sl], hs));
-        if (lean) hipLaunchKernelGGL((rp_lean_solver_kernel<T>), dim3(cnt), dim3(64), 0, st, M, ss, B);
+        if (lean && !heavy_after) hipLaunchKernelGGL((rp_lean_solver_kernel<T>), dim3(cnt), dim3(64), 0, st, M, ss, B);
         if (hs != st && !split_pos) HIP_OK(hipStreamWaitEvent(st, ev_hjoin[sl], 0));
         if (probe) HIP_OK(hipEventRecord(sv1[slot], st));
         if (sense) {

@@ -374,7 +374,7 @@ def test_suite_load_legacy_step_false_runs_mj_step_order():
         assert torch.equal(a_env.physics.qpos, b_env.physics.qpos) and torch.equal(a_env.physics.qvel, b_env.physics.qvel), t
         assert torch.equal(ta.step_type, tb.step_type) and bool(torch.isfinite(tb.reward).all())
         lag = max(lag, float((a_env.physics.site_xpos_eng - b_env.physics.site_xpos_eng).abs().max()))
-    assert 1e-6 < lag < 5e-3, lag   # (one 5 ms mj_step of fingertip motion)
+    assert 1e-6 < lag < 5e-2, lag   # (one 5 ms mj_step of fingertip motion: centimetres at most, the replay flails at metres per second)
 
 
 @pytest.mark.parametrize("precision", [64, 32])
