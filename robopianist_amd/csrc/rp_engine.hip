@@ -564,7 +564,10 @@ struct Engine : EngineBase {
 #else
   static constexpr bool x_no_heavy = false, x_order_twice = false;
 #endif
-  bool heavy_after_lean = !(getenv("RP_HEAVY_AFTER") && getenv("RP_HEAVY_AFTER")[0] == '0');   // (experiment switch)
+  // (experiment, off: without a companion stream, the lean launch in FRONT of the full-capacity one.  Measured on config
+  // 2, three-slice split schedule, one box, two runs each: 660 k against 668 k env-steps/s with the full-capacity launch
+  // first; config 3: 429 against 442 k)
+  bool heavy_after_lean = getenv("RP_HEAVY_AFTER") && getenv("RP_HEAVY_AFTER")[0] == '1';
   bool companion = !(getenv("RP_COMPANION") && getenv("RP_COMPANION")[0] == '0');   // (experiment: the full-capacity launch on the slice's own stream)
   // (Experiment, RP_HEAVY_PRIORITY=1: the companion stream at the highest priority the device offers.  The idea: the
   // full-capacity launch and the lean one become ready together, and whichever is dispatched first takes the machine
@@ -975,9 +978,7 @@ struct Engine : EngineBase {
         }
         // (RP_X_NO_HEAVY=1: MEASUREMENT ONLY -- the full-capacity launch is suppressed, envs outside the light class are
         // not stepped at all: what the launch costs a batch whose lists are empty)
-        // (without a companion stream -- the three-slice schedule -- the lean launch goes FIRST: the full-capacity stage's
-        // workgroups each need a whole idle SIMD, and in front of the lean launch they would hold it back until the
-        // other slices' kernels have drained that much; behind it they start as the lean waves retire)
+        // (RP_HEAVY_AFTER=1, experiment: without a companion stream the lean launch first)
         const bool heavy_after = heavy_after_lean && hs == st && lean && listed;
         if (heavy_after) hipLaunchKernelGGL((rp_lean_solver_kernel<T>), dim3(cnt), dim3(64), 0, st, M, ss, B);
         if (x_no_heavy && listed) { /* nothing */ }

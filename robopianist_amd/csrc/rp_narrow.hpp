@@ -612,50 +612,31 @@ __device__ RPK_MPR_INLINE int convex_mpr_wave(RawCon<T>* __restrict__ out, const
 #pragma unroll
       for (int k = 0; k < 3; k++) { S.v[k] = p2[k] - p1[k]; S.m[k] = (T)0.5 * (p1[k] + p2[k]); }
     }
+    // Every branch below that needs a new search direction only FORMS it (unnormalised) and names what has to happen
+    // once it is a unit vector (`post`); the normalisation -- an fp64 square root and a division, ~400 cycles of
+    // dependent chain -- then runs ONCE per trip for the whole wave instead of once per branch (a pooled chunk holds
+    // lanes in every phase, so every branch's code is walked on every trip: up to six normalisations).  A lane's own
+    // arithmetic is what it was, operation for operation.
+    int post = 0;
     if (phase == 0) {
       v1 = S;
       if (dot3(v1.v, dir) <= 0) phase = 4;
-      else {
-        cross3(dir, v0.v, v1.v);
-        if (!normalize3(dir)) {   // the origin lies on the ray v0 -> v1
-          T n[3] = {v1.v[0] - v0.v[0], v1.v[1] - v0.v[1], v1.v[2] - v0.v[2]};
-          normalize3(n);
-          res.dist = -dot3(v1.v, n);
-#pragma unroll
-          for (int k = 0; k < 3; k++) { res.n[k] = -n[k]; res.pos[k] = v1.m[k]; }
-          result = res.dist <= 0 ? 1 : 0;
-          phase = 4;
-        } else phase = 1;
-      }
+      else { cross3(dir, v0.v, v1.v); post = 1; }
     } else if (phase == 1) {
       v2 = S;
       if (dot3(v2.v, dir) <= 0) phase = 4;
-      else {
-        portal_dir(dir, v1, v2, v0);
-        normalize3(dir);
-        if (dot3(dir, v0.v) > 0) {
-          const MPoint<T> tmp = v1; v1 = v2; v2 = tmp;
-          dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2];
-        }
-        phase = 2; it = 0;
-      }
+      else { portal_dir(dir, v1, v2, v0); post = 2; }
     } else if (phase == 2) {
       // ---- portal discovery
       v3 = S;
       if (dot3(v3.v, dir) <= 0) phase = 4;
       else {
         cross3(t1, v1.v, v3.v);
-        if (dot3(t1, v0.v) < 0) { v2 = v3; portal_dir(dir, v1, v3, v0); normalize3(dir); if (++it > 50) phase = 4; }
+        if (dot3(t1, v0.v) < 0) { v2 = v3; portal_dir(dir, v1, v3, v0); post = 3; }
         else {
           cross3(t1, v3.v, v2.v);
-          if (dot3(t1, v0.v) < 0) { v1 = v3; portal_dir(dir, v3, v2, v0); normalize3(dir); if (++it > 50) phase = 4; }
-          else {
-            // ---- refinement starts: direction of the first portal
-            it = 0; hit = false;
-            portal_dir(dir, v2, v3, v1);
-            if (!normalize3(dir)) phase = 4;
-            else { if (dot3(dir, v1.v) >= 0) hit = true; phase = 3; }
-          }
+          if (dot3(t1, v0.v) < 0) { v1 = v3; portal_dir(dir, v3, v2, v0); post = 3; }
+          else { it = 0; hit = false; portal_dir(dir, v2, v3, v1); post = 4; }   // (refinement starts: direction of the first portal)
         }
       }
     } else if (phase == 3) {
@@ -698,9 +679,36 @@ __device__ RPK_MPR_INLINE int convex_mpr_wave(RawCon<T>* __restrict__ out, const
         else { if (dot3(v3.v, t1) > 0) v2 = S; else v1 = S; }
         it++;
         portal_dir(dir, v2, v3, v1);
-        if (!normalize3(dir)) phase = 4;
-        else if (dot3(dir, v1.v) >= 0) hit = true;
+        post = 5;
       }
+    }
+    // ---- the one normalisation of the trip, then what each branch had to do with its unit direction
+    bool ok = true;
+    if (post != 0) ok = normalize3(dir);
+    if (post == 1) {
+      if (!ok) {   // the origin lies on the ray v0 -> v1
+        T n[3] = {v1.v[0] - v0.v[0], v1.v[1] - v0.v[1], v1.v[2] - v0.v[2]};
+        normalize3(n);
+        res.dist = -dot3(v1.v, n);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { res.n[k] = -n[k]; res.pos[k] = v1.m[k]; }
+        result = res.dist <= 0 ? 1 : 0;
+        phase = 4;
+      } else phase = 1;
+    } else if (post == 2) {
+      if (dot3(dir, v0.v) > 0) {
+        const MPoint<T> tmp = v1; v1 = v2; v2 = tmp;
+        dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2];
+      }
+      phase = 2; it = 0;
+    } else if (post == 3) {
+      if (++it > 50) phase = 4;
+    } else if (post == 4) {
+      if (!ok) phase = 4;
+      else { if (dot3(dir, v1.v) >= 0) hit = true; phase = 3; }
+    } else if (post == 5) {
+      if (!ok) phase = 4;
+      else if (dot3(dir, v1.v) >= 0) hit = true;
     }
   }
   *out = res;
