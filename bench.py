@@ -83,7 +83,7 @@ def _valu_profile(precision):
     """What actually bounds the solver stage (instruction issue + latency), from the committed
     rocprofv3 --pmc passes and the compiler's resource report of the shipped build: waves per SIMD, the share of
     VALU instructions that are fp64 arithmetic, the share of wave cycles that issue an instruction."""
-    for name in ("r04_sq_instruction_mix.json", "r03_sq_instruction_mix.json", "r02_sq_instruction_mix.json"):
+    for name in ("r05_sq_instruction_mix.json", "r04_sq_instruction_mix.json", "r03_sq_instruction_mix.json", "r02_sq_instruction_mix.json"):
         d = _profile_json(name)
         k = d and d.get("solver_stage_fp%d" % precision) or (d and d.get("solver_stage"))
         if k:
@@ -532,7 +532,9 @@ def main():
         if args.aux_fingertips and args.config == 2 and world == 1 and r["stagger"] and not args.engine_only:
             # config 2 is run with both fingertip colliders
             other = "hull" if args.fingertips == "primitive" else "primitive"
-            rh = measure(args.precision, 158, 10, fingertips=other)
+            # (warm-up past the engine's first schedule decision at step 64: a 158-step leg that starts cold spends
+            # half of itself on one slice)
+            rh = measure(args.precision, 158, 70, fingertips=other)
             out["value_" + other + "_fingertips"] = rh["sim"] / rh["dt"]
             out["value_" + args.fingertips + "_fingertips"] = value
             out.setdefault("aux", {})[other + "_fingertips"] = {
@@ -547,7 +549,7 @@ def main():
             # how much of the workload is an artefact of the stand-in hand -- the one rigid-link
             # overlap the single-joint sweep finds beyond neighbouring fingers (forearm wrist box vs palm boxes, 7.6 mm at
             # the end of WRJ2's range, in contact on 43 % / 61 % of the replay's mj_steps) removed: REPORTED, not adopted
-            rw = measure(args.precision, 158, 10, extra_kw={"standin_wrist_clearance": True})
+            rw = measure(args.precision, 158, 70, extra_kw={"standin_wrist_clearance": True})
             out.setdefault("aux", {})["standin_wrist_clearance"] = {
                 "value": rw["sim"] / rw["dt"], "unit": "env-steps/s", "steps": 158, "solve_stats": rw["solve_stats"],
                 "sanity": {"warn_flags_or": rw["warn"], "finite": rw["finite"], **(rw["events"] or {})},
@@ -556,7 +558,7 @@ def main():
                         "geometry: its box numbers are what memory says the menagerie XML holds, not this repo's to tune"}
             del rw
         if args.aux_large_hulls and args.config == 2 and world == 1 and r["stagger"] and not args.engine_only:
-            rm = measure(args.precision, 60, 10, fingertips="hull", mesh_colliders=args.aux_large_hulls)
+            rm = measure(args.precision, 60, 70, fingertips="hull", mesh_colliders=args.aux_large_hulls)
             out.setdefault("aux", {})["large_hulls"] = {
                 "value": rm["sim"] / rm["dt"], "unit": "env-steps/s", "steps": 60, "vertices_per_hull": args.aux_large_hulls,
                 "kernel_avg_ms": rm["sms"], "step_sequence_avg_ms": rm["kms"],
