@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -149,6 +151,32 @@ struct Blob {
   double f1(const char* name) const { return f(name).at(0); }
 };
 
+// The internal streams (slices 1.., companion streams) are PROCESS-WIDE, one set per device, shared by every engine and
+// never destroyed.  HIP maps a stream to one of the device's hardware queues (four) when it is created; streams that
+// share a queue serialise.  With a set of streams per ENGINE, the second engine of a process -- bench.py's auxiliary
+// legs, a training script's evaluation env -- got streams that shared queues with each other: its two- and three-slice
+// schedules measured 7.2-9.1 ms per step where the first engine's took 5.9-6.1 (round 5).  Engines that share streams
+// only order their launches among each other, which independent engines never relied on.
+struct StreamPool {
+  static const int kSlots = 8;   // [0 .. 3] slice streams (slot 0 unused), [4 .. 7] companion streams
+  hipStream_t s[kSlots] = {};
+};
+static std::mutex g_pool_mutex;
+static std::map<int, StreamPool> g_pools;
+static hipStream_t pooled_stream(int device, int slot, bool high_priority) {
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  StreamPool& p = g_pools[device];
+  if (!p.s[slot]) {
+    int least = 0, greatest = 0;
+    hipError_t e;
+    if (high_priority && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+      e = hipStreamCreateWithPriority(&p.s[slot], hipStreamNonBlocking, greatest);
+    else { (void)hipGetLastError(); e = hipStreamCreateWithFlags(&p.s[slot], hipStreamNonBlocking); }
+    if (e != hipSuccess) { (void)hipGetLastError(); p.s[slot] = nullptr; }
+  }
+  return p.s[slot];
+}
+
 struct EngineBase {
   virtual ~EngineBase() {}
   int nenv = 0, device = 0, precision = 32;
@@ -275,11 +303,10 @@ struct Engine : EngineBase {
     }
     if (stream && own_stream) hipStreamDestroy(stream);
     for (int i = 1; i < kMaxSlices; i++) {
-      if (xstream[i]) hipStreamDestroy(xstream[i]);
+      // (xstream / hstream: the process-wide pool's, never destroyed)
       if (ev_join[i]) hipEventDestroy(ev_join[i]);
     }
     for (int i = 0; i < kMaxSlices; i++) {
-      if (hstream[i]) hipStreamDestroy(hstream[i]);
       if (ev_hfork[i]) hipEventDestroy(ev_hfork[i]);
       if (ev_hjoin[i]) hipEventDestroy(ev_hjoin[i]);
     }
@@ -574,14 +601,7 @@ struct Engine : EngineBase {
   // -- 2048 lean workgroups fill every SIMD, and a full-capacity workgroup, a whole SIMD's registers, then waits for
   // both waves of some SIMD to retire, so the heavy envs START when the lean launch ends.  Measured: no effect on the
   // dispatch order -- configs 3 / 4 447 / 580 k env-steps/s either way, config 2 -0.6 %.  Off.)
-  hipError_t create_companion_stream(hipStream_t* s) {
-    int least = 0, greatest = 0;
-    const bool prio = getenv("RP_HEAVY_PRIORITY") && getenv("RP_HEAVY_PRIORITY")[0] == '1';
-    if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
-      return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
-    (void)hipGetLastError();
-    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
-  }
+  // (the stream itself: pooled_stream(device, 4 + slice, priority))
   // Threads per residue class of rp_order_kernel: two envs per thread.  (A 512-thread workgroup needs a whole
   // idle CU -- with both stage kernels at two waves per SIMD it waited ~60 us for one on every substep of a
   // 2048-env slice -- while a single wave takes too long over 512 envs.  Measured: 2048-env slices 64 / 128 /
@@ -831,8 +851,8 @@ struct Engine : EngineBase {
     if (nsl > 1 && !ev_fork && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev_fork = nullptr; nsl = 1; }
     for (int i = 1; i < nsl; i++) {
       if (xstream[i]) continue;
-      if (hipStreamCreateWithFlags(&xstream[i], hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); xstream[i] = nullptr; nsl = 1; break; }
+      xstream[i] = pooled_stream(device, i, false);
+      if (!xstream[i] || hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); xstream[i] = nullptr; nsl = 1; break; }
     }
     // slice sl covers the envs [bound(sl), bound(sl + 1)); bounds are multiples of 8 (XCD classes of the order)
     auto bound = [&](int sl) { return sl >= nsl ? nenv : (int)(((long long)nenv * sl / nsl + 7) / 8 * 8); };
@@ -954,7 +974,7 @@ struct Engine : EngineBase {
         // the light ones) -- side by side: the full-capacity launch goes to the slice's companion stream
         hipStream_t hs = st;
         if (lean && !capturing && companion_now) {
-          if (!hstream[sl] && create_companion_stream(&hstream[sl]) != hipSuccess) { (void)hipGetLastError(); hstream[sl] = nullptr; }
+          if (!hstream[sl]) hstream[sl] = pooled_stream(device, 4 + sl, getenv("RP_HEAVY_PRIORITY") && getenv("RP_HEAVY_PRIORITY")[0] == '1');
           if (hstream[sl] && !ev_hfork[sl] && (hipEventCreateWithFlags(&ev_hfork[sl], hipEventDisableTiming) != hipSuccess ||
                                                hipEventCreateWithFlags(&ev_hjoin[sl], hipEventDisableTiming) != hipSuccess)) {
             (void)hipGetLastError(); hstream[sl] = nullptr;
