@@ -164,6 +164,12 @@ struct StreamPool {
 static std::mutex g_pool_mutex;
 static std::map<int, StreamPool> g_pools;
 static hipStream_t pooled_stream(int device, int slot, bool high_priority) {
+  // Four hardware queues, one of them the caller's stream: the schedules the engine picks from use {caller, slice 1,
+  // companion 0, companion 1} (two slices) or {caller, slice 1, slice 2} (three slices, no companions) -- never both
+  // sets at once.  Slice 2 therefore IS companion 0's stream and slice 3 companion 1's: four streams in all, so that the
+  // five a process would otherwise own after the schedule trials do not share a queue.
+  if (slot == 2) slot = 4;
+  if (slot == 3) slot = 5;
   std::lock_guard<std::mutex> lock(g_pool_mutex);
   StreamPool& p = g_pools[device];
   if (!p.s[slot]) {
@@ -207,7 +213,7 @@ struct EngineBase {
   // slices; the same in lockstep, or with <= 2048 envs: fused.
   int ev_trial[kRing] = {};           // 0 = not a trial step, else the schedule it ran with
   double trial_ms[5] = {0, 0, 0, 0, 0}, trial_n[5] = {0, 0, 0, 0, 0};
-  int auto_mode = 1; unsigned auto_pos = 0;
+  int auto_mode = 1; unsigned auto_pos = 0, auto_period = 128;
   void harvest(int i, bool wait) {
     if (!ev_pending[i]) return;
     if (wait) hipEventSynchronize(ev1[i]);
@@ -815,7 +821,12 @@ struct Engine : EngineBase {
       int sched = have ? auto_mode : cand[0];
       if (!have && !capturing) auto_mode = cand[0];
       if (nc > 1 && !capturing) {
-        const unsigned pos = auto_pos++ % 128u;
+        // (the trial block costs: four candidates x four steps, three of them in slower schedules -- 1.8 % of a run at
+        // one block per 128 steps.  The period doubles, up to 1024 steps, every time a block confirms the schedule in
+        // use, and falls back to 128 when one overturns it: a steady workload pays 0.2 %, a drifting one is re-examined
+        // as before.)
+        if (auto_pos >= auto_period) auto_pos = 0;
+        const unsigned pos = auto_pos++;
         if (pos >= 16u && pos < 16u + 4u * nc) {   // (short runs -- tests, smoke -- never reach the trials)
           const int idx = (int)((pos - 16u) % (2u * nc));
           sched = cand[idx < nc ? idx : 2 * nc - 1 - idx];
@@ -831,6 +842,8 @@ struct Engine : EngineBase {
               const double m = trial_ms[cand[j]] / trial_n[cand[j]];
               if (m < 0.99 * trial_ms[auto_mode] / trial_n[auto_mode] && m < mb) { best = cand[j]; mb = m; }
             }
+            if (best == auto_mode) auto_period = auto_period < 1024u ? auto_period * 2u : 1024u;
+            else auto_period = 128u;
             auto_mode = best;
             if (getenv("RP_SCHED_DEBUG")) {
               fprintf(stderr, "rp schedule choice:");
