@@ -98,7 +98,7 @@ def _pmc_traffic(E, precision, envs_per_launch=None):
     """HBM-side bytes per solver-kernel launch from the committed rocprofv3 --pmc passes
     (newest profiles/traffic_rNN.json, see DESIGN.md 6), scaled to the envs one launch covers;
     null if not collected for this env count / precision."""
-    for name in ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
+    for name in ("traffic_r05.json", "traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
         d = _profile_json(name)
         if d and int(d.get("envs", -1)) == int(E) and int(d.get("precision", -1)) == int(precision):
             b = d.get("solver_kernel_bytes_per_launch")
