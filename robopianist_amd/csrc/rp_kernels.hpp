@@ -1773,11 +1773,29 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
             if (bbox) {
               const float reach2 = frr + 1e-4f;
               bool sep = false;
+              float akv[3];
 #pragma unroll
               for (int k = 0; k < 3; k++) {
                 const float ck = gb[k] * rx + gb[3 + k] * ry + gb[6 + k] * rz;
                 const float ak = gb[k] * fax + gb[3 + k] * fay + gb[6 + k] * faz;
+                akv[k] = fabsf(ak);
                 sep = sep || (fabsf(ck) - fhl * fabsf(ak) > gb[9 + k] + reach2);
+              }
+              // (round 5) ... the segment's own axis and the three cross axes d x b_k: with them the test is the complete
+              // separating-axis test of a segment against the box, inflated by the radius (a superset still: rounded
+              // corners only make the true shape smaller).  A fingertip hull's bounding box against the NEIGHBOURING
+              // finger's capsule passed the three box axes most of the time: 13 hull candidates per env and mj_step.
+              {
+                const float cd = fax * rx + fay * ry + faz * rz;
+                sep = sep || (fabsf(cd) - fhl > gb[9] * akv[0] + gb[10] * akv[1] + gb[11] * akv[2] + reach2 + 1e-6f);
+                const float wx = ry * faz - rz * fay, wy = rz * fax - rx * faz, wz = rx * fay - ry * fax;   // r x d
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                  const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+                  const float tk = gb[k] * wx + gb[3 + k] * wy + gb[6 + k] * wz;   // r . (d x b_k)
+                  const float ln = sqrtf(fmaxf(1.f - akv[k] * akv[k], 0.f));       // |d x b_k|
+                  sep = sep || (fabsf(tk) > gb[9 + k1] * akv[k2] + gb[9 + k2] * akv[k1] + reach2 * ln + 1e-5f);
+                }
               }
               has = has && !sep;
             }
