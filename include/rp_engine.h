@@ -120,6 +120,14 @@ int rp_set_solver_limits(rp_engine* e, int max_newton_iter, int max_ls_iter);
  * opt.ls_tolerance; the fp32 build raises a default tolerance below 1e-6 to 1e-6, the resolution
  * of single precision; values <= 0 leave the current setting). */
 int rp_set_solver_tolerance(rp_engine* e, double tolerance, double ls_tolerance);
+/* Stopping tolerance of the convex narrow phase (hull / cylinder pairs: Minkowski Portal Refinement, MuJoCo's
+ * mjc_Convex; reached from physics.step() like everything else, /root/reference/robopianist/suite/__init__.py:87-93).
+ * Default: MuJoCo's opt.mpr_tolerance = 1e-6 for every pair.  `polytope_tolerance` > 0 gives pairs of two polytopes
+ * (box / hull on both sides) their own: at 1e-10 the refinement has converged to a face of the Minkowski difference and
+ * the result no longer depends on rounding-sized tie-breaks between support vertices -- the setting of step-by-step
+ * comparisons against another implementation (the oracle has the same switch); NOT MuJoCo's rule.  Values <= 0 leave
+ * `tolerance` as it is / set the polytope tolerance back to `tolerance`.  fp32 engines clamp at 1e-6. */
+int rp_set_mpr_tolerance(rp_engine* e, double tolerance, double polytope_tolerance);
 /* rp_step starts with a position/velocity stage for the incoming state (the caller may have
  * changed it).  With the lazy mode on, that leading stage is skipped for every env whose stage data
  * is still the one of its current state: computed by the previous rp_step / rp_forward, and no

@@ -50,7 +50,8 @@ MODEL_FIELDS = (
     "exclude_signature geom_dataid mesh_vert mesh_vertadr mesh_vertnum mesh_graph mesh_graphadr "
     "site_size sensor_type sensor_objtype sensor_objid "
     # what the importer (tools/mjmodel_to_blob.py) must be able to REJECT: dynamics the engine does not model
-    "neq npair actuator_gaintype actuator_biastype actuator_dyntype jnt_group").split()
+    "neq npair actuator_gaintype actuator_biastype actuator_dyntype jnt_group "
+    "tendon_limited tendon_range tendon_frictionloss tendon_damping tendon_stiffness").split()
 
 
 def dump_model(m) -> dict:
@@ -69,6 +70,17 @@ def dump_model(m) -> dict:
     out["model_stat_meaninertia"] = np.array([m.stat.meaninertia])
     import mujoco
     out["model_opt_refsafe"] = np.asarray(0 if (int(o.disableflags) & int(mujoco.mjtDisableBit.mjDSBL_REFSAFE)) else 1)
+    # flags the importer rejects: any disable bit other than refsafe / nativeccd, any enable bit (override, multiccd ...)
+    allowed = int(mujoco.mjtDisableBit.mjDSBL_REFSAFE)
+    native = getattr(mujoco.mjtDisableBit, "mjDSBL_NATIVECCD", None)
+    if native is not None:
+        allowed |= int(native)
+    out["model_opt_disableflags_other"] = np.asarray(int(o.disableflags) & ~allowed)
+    out["model_opt_enableflags"] = np.asarray(int(o.enableflags))
+    # 1 = the convex pairs of this recording went through MuJoCo's native GJK / EPA (the default of recent versions)
+    # instead of libccd MPR, which oracle and engine restate: run_config() switches it off before stepping
+    out["model_opt_nativeccd"] = np.asarray(1 if (native is not None and not (int(o.disableflags) & int(native))) else 0)
+    out["mujoco_version"] = np.array([mujoco.__version__])
     for kind, n, enum in (("body", m.nbody, mujoco.mjtObj.mjOBJ_BODY), ("joint", m.njnt, mujoco.mjtObj.mjOBJ_JOINT),
                           ("geom", m.ngeom, mujoco.mjtObj.mjOBJ_GEOM), ("site", m.nsite, mujoco.mjtObj.mjOBJ_SITE),
                           ("actuator", m.nu, mujoco.mjtObj.mjOBJ_ACTUATOR)):
@@ -98,6 +110,12 @@ def run_config(config: int, out_dir: str, reference_root: str, n_steps: int):
     env = suite.load(name, seed=12345, task_kwargs=kw)
     physics = env.physics
     m, d = physics.model.ptr, physics.data.ptr
+    import mujoco
+    # The convex pairs (hulls, cylinders) must go through libccd MPR, which oracle and engine restate: recent MuJoCo
+    # versions default to their native GJK / EPA pipeline, whose results differ at the 1e-6 m level by construction.
+    native = getattr(mujoco.mjtDisableBit, "mjDSBL_NATIVECCD", None)
+    if native is not None:
+        m.opt.disableflags |= int(native)
     acts = action_stream(config, env.action_spec(), n_steps, reference_root)
     n_sub = env.task.physics_steps_per_control_step
     env.reset()
@@ -119,7 +137,7 @@ def run_config(config: int, out_dir: str, reference_root: str, n_steps: int):
     np.savez_compressed(path, ctrl=np.asarray(ctrl), qpos=np.asarray(qpos), qvel=np.asarray(qvel),
                         qacc_warmstart=np.asarray(warm), n_substeps=np.asarray(n_sub),
                         ncon=np.asarray(ncon), nefc=np.asarray(nefc), solver_niter=np.asarray(nit),
-                        mujoco_version=np.array([mujoco.__version__]), **dump_model(m))
+                        **dump_model(m))
     print("wrote", path)
 
 

@@ -41,6 +41,7 @@
 #define JNT_SLIDE 2
 #define JNT_HINGE 3
 #define GEOM_CAPSULE 3
+#define GEOM_CYLINDER 5   /* size = (radius, half height) along the geom's z axis [mjGEOM_CYLINDER] */
 #define GEOM_BOX 6
 #define GEOM_MESH 7
 #define TRN_JOINT 0
@@ -62,6 +63,7 @@ struct rpo_model {
   const blob_entry* entries;
   int nbody, njnt, nv, ngeom, nsite, ntendon, nu, npair;
   double timestep, tolerance, ls_tolerance, meaninertia;
+  double impratio;   /* opt.impratio: ratio of frictional to normal constraint impedance [MJ: mj_makeImpedance] */
   int iterations, ls_iterations, refsafe;
   const double* gravity;
   const int32_t *body_parentid, *body_jntadr, *body_jntnum, *body_weldid;
@@ -128,6 +130,7 @@ rpo_model* rpo_model_load(const void* blob, size_t nbytes) {
   m->nu = *BI("nu"); m->npair = *BI("npair");
   m->timestep = *BF("opt_timestep"); m->tolerance = *BF("opt_tolerance");
   m->ls_tolerance = *BF("opt_ls_tolerance"); m->meaninertia = *BF("stat_meaninertia");
+  m->impratio = *BF("opt_impratio");
   m->iterations = *BI("opt_iterations"); m->ls_iterations = *BI("opt_ls_iterations");
   m->refsafe = *BI("opt_refsafe");
   m->gravity = BF("opt_gravity");
@@ -874,18 +877,22 @@ static int box_box(rawcon* out, const double* p1, const double* m1, const double
  * (1e-6, 50). */
 #define CCD_TOL 1e-6
 #define CCD_ITER 50
-/* Round 5: POLYTOPE pairs (neither side a capsule) refine until the support point is within CCD_TOL_POLY of the portal.
- * For two polytopes the refinement ends on a face of B - A after finitely many steps (reach = 0 to rounding); with the
- * 1e-6 rule it may ALSO end one step earlier, on a portal up to 1e-6 short of that face -- and whether it does depends
- * on rounding-sized differences of the search direction (which of several tied support vertices comes first).  Two
- * implementations then return depths up to 1e-6 apart: at mj_step 1058 of the hull replay the engine stopped 1.7e-7
- * short of the oracle, 1.6 % of that step's velocity change (1579 of 1580 mj_steps agree to 1e-11).  Converged, the
- * result no longer depends on the path.  Pairs with a capsule (a smooth support) keep MuJoCo's 1e-6. */
-#define CCD_TOL_POLY 1e-10
-static double g_mpr_tol = CCD_TOL;   /* experiment knobs (rpo_debug_set_mpr) */
+/* The stopping rule is MuJoCo's UNIFORM one by default: every pair refines until the support point is within
+ * g_mpr_tol (1e-6) of the portal.  Two experiment knobs (process-wide; oracle/rp_oracle.py: set_mpr_experiment):
+ *   * g_mpr_tol_poly >= 0: POLYTOPE pairs (both sides a box or a hull) refine to that tolerance instead.  For two
+ *     polytopes the refinement ends on a face of B - A after finitely many steps (reach = 0 to rounding); with the
+ *     1e-6 rule it may ALSO end one step earlier, on a portal up to 1e-6 short of that face -- and whether it does
+ *     depends on rounding-sized differences of the search direction (which of several tied support vertices comes
+ *     first).  Two implementations then return depths up to 1e-6 apart: at mj_step 1058 of the hull replay the HIP
+ *     engine stops 1.7e-7 short of this oracle, 1.6 % of that step's velocity change (1579 of 1580 mj_steps agree to
+ *     1e-11).  At 1e-10 the result no longer depends on the path: the setting of the tests that compare two
+ *     implementations step by step (the engine has the same switch, rp_set_mpr_tolerance).  NOT MuJoCo's rule.
+ *   * g_mpr_discrete: polytope pairs stop when the support vertex already is a portal vertex. */
+static double g_mpr_tol = CCD_TOL;
+static double g_mpr_tol_poly = -1.0;   /* < 0: polytope pairs follow g_mpr_tol (the uniform rule) */
 static int g_mpr_discrete = 0;
-static int g_mpr_uniform = 0;        /* 1: CCD_TOL for polytope pairs too (MuJoCo's uniform rule; bisect variant "uniform") */
-void rpo_debug_set_mpr(double tol, int discrete) { g_mpr_tol = tol < 0 ? CCD_TOL : tol; g_mpr_uniform = tol < 0; g_mpr_discrete = discrete; }
+void rpo_debug_set_mpr(double tol, int discrete) { g_mpr_tol = tol > 0 ? tol : CCD_TOL; g_mpr_tol_poly = -1.0; g_mpr_discrete = discrete; }
+void rpo_debug_set_mpr_poly(double tol_poly) { g_mpr_tol_poly = tol_poly; }
 #define HULL_GRAPH_ROW 24   /* ints per vertex of mesh_graph: degree + neighbours (model/hull.py: GRAPH_ROW) */
 typedef struct { int type; const double *pos, *mat, *size; const double* vert; int nvert; const int32_t* graph; } cgeom;
 typedef struct { double v[3], p1[3], p2[3]; int id; } mpoint;   /* point of B - A, its witnesses on A and B; id = (vertex of A, vertex of B) for polytopes */
@@ -894,6 +901,16 @@ static int geom_support(const cgeom* g, const double* d, double* out) {   /* d: 
   if (g->type == GEOM_CAPSULE) {
     double ax[3] = {g->mat[2], g->mat[5], g->mat[8]}, sg = dot3(ax, d) >= 0 ? 1.0 : -1.0;
     for (int k = 0; k < 3; k++) out[k] = g->pos[k] + sg*g->size[1]*ax[k] + g->size[0]*d[k];
+    return 0;
+  } else if (g->type == GEOM_CYLINDER) {
+    /* [MJ: mjc_support, mjGEOM_CYLINDER] in the geom frame: the direction's xy part scaled to the radius (nothing when
+     * it vanishes), sign(z) * half height along the axis (mju_sign: 0 for 0) */
+    double dl[3], r[3]; matT_vec(dl, g->mat, d);
+    double t = sqrt(dl[0]*dl[0] + dl[1]*dl[1]);
+    if (t > MINVAL) { r[0] = dl[0] / t * g->size[0]; r[1] = dl[1] / t * g->size[0]; } else r[0] = r[1] = 0;
+    r[2] = dl[2] > 0 ? g->size[1] : (dl[2] < 0 ? -g->size[1] : 0.0);
+    double w[3]; mat_vec(w, g->mat, r);
+    for (int k = 0; k < 3; k++) out[k] = g->pos[k] + w[k];
     return 0;
   } else if (g->type == GEOM_BOX) {
     int id = 0;
@@ -988,9 +1005,9 @@ static int mpr_penetration(const cgeom* A, const cgeom* B, rawcon* out) {
     mpr_support(A, B, dir, &v4);
     double reach = dot3(v4.v, dir) - dot3(v1.v, dir);
     if (!hit && dot3(v4.v, dir) < 0) return 0;             /* the origin lies beyond the support plane */
-    const int poly = A->type != GEOM_CAPSULE && B->type != GEOM_CAPSULE;
-    int stop = reach <= ((poly && !g_mpr_uniform && g_mpr_tol > CCD_TOL_POLY) ? CCD_TOL_POLY : g_mpr_tol);
-    if (g_mpr_discrete && A->type != GEOM_CAPSULE && B->type != GEOM_CAPSULE)
+    const int poly = (A->type == GEOM_BOX || A->type == GEOM_MESH) && (B->type == GEOM_BOX || B->type == GEOM_MESH);
+    int stop = reach <= ((poly && g_mpr_tol_poly >= 0) ? g_mpr_tol_poly : g_mpr_tol);
+    if (g_mpr_discrete && poly)
       stop = v4.id == v1.id || v4.id == v2.id || v4.id == v3.id || reach <= 1e-10;
     if (stop || it == CCD_ITER) {
       if (!hit) return 0;
@@ -1048,13 +1065,16 @@ static void collision(const rpo_model* m, rpo_data* d) {
     else if (t1 == GEOM_BOX && t2 == GEOM_BOX)
       n = box_box(rc, p1, d->geom_xmat + 9*g1, m->geom_size + 3*g1, p2,
                   d->geom_xmat + 9*g2, m->geom_size + 3*g2, margin);
-    else if (t2 == GEOM_MESH && m->mesh_vert) {
+    else if ((t2 == GEOM_MESH && m->mesh_vert) || t1 == GEOM_CYLINDER || t2 == GEOM_CYLINDER) {
+      /* [MJ: mjCOLLISIONFUNC] every pair with a hull or a cylinder goes to mjc_Convex, in geom-type order
+       * (capsule 3 < cylinder 5 < box 6 < mesh 7): (capsule, cylinder), (cylinder, cylinder / box / mesh) */
 #define HULL_GRAPH_OF(g_) ((m->geom_vertgraph && m->mesh_graph && m->geom_vertgraph[g_]) ? m->mesh_graph + (size_t)HULL_GRAPH_ROW * m->geom_vertadr[g_] : NULL)
       cgeom A = {t1, p1, d->geom_xmat + 9*g1, m->geom_size + 3*g1,
                  t1 == GEOM_MESH ? m->mesh_vert + 3*m->geom_vertadr[g1] : NULL, t1 == GEOM_MESH ? m->geom_vertnum[g1] : 0,
                  t1 == GEOM_MESH ? HULL_GRAPH_OF(g1) : NULL};
-      cgeom B = {t2, p2, d->geom_xmat + 9*g2, m->geom_size + 3*g2, m->mesh_vert + 3*m->geom_vertadr[g2], m->geom_vertnum[g2],
-                 HULL_GRAPH_OF(g2)};
+      cgeom B = {t2, p2, d->geom_xmat + 9*g2, m->geom_size + 3*g2,
+                 t2 == GEOM_MESH ? m->mesh_vert + 3*m->geom_vertadr[g2] : NULL, t2 == GEOM_MESH ? m->geom_vertnum[g2] : 0,
+                 t2 == GEOM_MESH ? HULL_GRAPH_OF(g2) : NULL};
 #undef HULL_GRAPH_OF
       n = mpr_penetration(&A, &B, rc);
     }
@@ -1195,9 +1215,15 @@ static void make_constraint(const rpo_model* m, rpo_data* d) {
   for (int i = 0; i < ne; i++) {
     d->efc_R[i] = fmax(MINVAL, (1 - d->efc_imp[i]) * d->efc_diagApprox[i] / d->efc_imp[i]);
   }
+  /* [MJ: mj_makeImpedance, pyramidal cone] the friction dimensions are regularised by R / impratio: the contact's
+   * regularised friction coefficient is mu = friction[0] * sqrt(1 / impratio), and every pyramid edge gets
+   * Rpy = 2 mu^2 R (the Jacobian rows above keep friction[] itself: impratio > 1 makes slip "harder" without
+   * widening the cone).  The reference's hand XML sets impratio = 10; mjcf.from_path carries the
+   * option into the scene (robopianist/models/hands/shadow_hand.py:122). */
+  const double mu_scale = sqrt(1.0 / fmax(MINVAL, m->impratio));
   for (int ic = 0; ic < d->ncon; ic++) {
     int base = first_con_row + 4*ic;
-    double mu = d->contact[ic].friction[0];
+    double mu = d->contact[ic].friction[0] * mu_scale;
     double Rpy = 2 * mu * mu * d->efc_R[base];
     for (int r = 0; r < 4; r++) d->efc_R[base + r] = Rpy;
   }

@@ -83,7 +83,8 @@ void rpo_step1(const rpo_model* m, rpo_data* d);   /* mj_step1 of the current st
 /* bisection knobs of the narrow phase (oracle/rp_oracle.py: set_narrow_phase_variant; process-wide, defaults = the engine's rules) */
 void rpo_debug_set_capsule_box(int variant);
 void rpo_debug_set_boxbox_max(int n);
-void rpo_debug_set_mpr(double tol, int discrete);
+void rpo_debug_set_mpr(double tol, int discrete);   /* uniform stopping tolerance (<= 0: MuJoCo's 1e-6); resets the polytope tolerance */
+void rpo_debug_set_mpr_poly(double tol_poly);         /* >= 0: polytope pairs (box / hull on both sides) refine to this instead; < 0: off */
 double rpo_debug_line_search(int n, const int* type, const double* jar, const double* jv, const double* D,
                              const double* floss, const double* R, const double quad[3], double gtol,
                              int ls_iterations, int* evals);

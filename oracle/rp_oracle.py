@@ -62,16 +62,23 @@ def lib():
         L.rpo_bench_seq.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                     ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.rpo_debug_set_mpr.argtypes = [ctypes.c_double, ctypes.c_int]
+        L.rpo_debug_set_mpr_poly.argtypes = [ctypes.c_double]
         L.rpo_debug_set_capsule_box.argtypes = [ctypes.c_int]
         L.rpo_debug_set_boxbox_max.argtypes = [ctypes.c_int]
         _lib = L
     return _lib
 
 
-def set_mpr_experiment(tolerance: float = 1e-6, discrete: bool = False) -> None:
-    """Experiment knob of the hull narrow phase (process-wide): the refinement's stopping tolerance, and `discrete`
-    = polytope pairs stop when the support vertex already is a portal vertex (a tolerance-free rule)."""
+MPR_POLY_REFINED = 1e-10   # the polytope-pair tolerance of the step-by-step comparisons (engine: rp_set_mpr_tolerance)
+
+
+def set_mpr_experiment(tolerance: float = 1e-6, discrete: bool = False, poly_tolerance: float | None = None) -> None:
+    """Stopping rule of the hull / cylinder narrow phase (process-wide).  No arguments = MuJoCo's uniform rule (1e-6 for
+    every pair), which is the oracle's default.  `poly_tolerance`: polytope pairs (box / hull on both sides) refine to
+    that instead -- converged, two implementations cannot stop on different portals (rp_oracle.c: g_mpr_tol_poly);
+    `discrete` = polytope pairs stop when the support vertex already is a portal vertex (a tolerance-free rule)."""
     lib().rpo_debug_set_mpr(float(tolerance), int(bool(discrete)))
+    lib().rpo_debug_set_mpr_poly(-1.0 if poly_tolerance is None else float(poly_tolerance))
 
 
 # The narrow-phase choices this restatement could not pin from memory (DESIGN section 8), as process-wide switches, so
@@ -81,19 +88,19 @@ NARROW_PHASE_VARIANTS = {
     "capsule_box": {0: "closest axis point + the deeper end (default)", 1: "closest axis point only",
                     2: "the two ends only", 3: "closest axis point + both ends"},
     "boxbox_max": {8: "all clipped points, up to eight (default)", 4: "the first four", 3: "the first three", 1: "one point"},
-    "mpr": {"tolerance": "refinement stops at 1e-6, polytope pairs at 1e-10 (default)", "uniform": "1e-6 for every pair (MuJoCo's rule)",
+    "mpr": {"uniform": "1e-6 for every pair (MuJoCo's rule; default)", "refined": "1e-6, polytope pairs at 1e-10",
             "discrete": "polytope pairs stop at a repeated support vertex", "tight": "refinement stops at 1e-10"},
 }
 
 
-def set_narrow_phase_variant(capsule_box: int = 0, boxbox_max: int = 8, mpr: str = "tolerance") -> None:
+def set_narrow_phase_variant(capsule_box: int = 0, boxbox_max: int = 8, mpr: str = "uniform") -> None:
     """Selects one combination of NARROW_PHASE_VARIANTS (no arguments = the defaults)."""
     if capsule_box not in NARROW_PHASE_VARIANTS["capsule_box"] or mpr not in NARROW_PHASE_VARIANTS["mpr"] or not 1 <= boxbox_max <= 8:
         raise ValueError("unknown narrow-phase variant")
     L = lib()
     L.rpo_debug_set_capsule_box(int(capsule_box))
     L.rpo_debug_set_boxbox_max(int(boxbox_max))
-    L.rpo_debug_set_mpr(1e-10 if mpr == "tight" else (-1.0 if mpr == "uniform" else 1e-6), int(mpr == "discrete"))
+    set_mpr_experiment(1e-10 if mpr == "tight" else 1e-6, mpr == "discrete", MPR_POLY_REFINED if mpr == "refined" else None)
 
 
 def first_crossing(rel, level=1e-6):

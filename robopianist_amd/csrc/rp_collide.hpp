@@ -108,24 +108,25 @@ __device__ __noinline__ void rp_narrow_chunk(const RpModel<T>& M, const RpState<
       g.flip = hull ? M.geom_vertflip()[gi] : 0;
       g.graph = (MESH > 1 && hull) ? M.geom_vertgraph()[gi] : 0;
     };
-    if (key) {
+    const bool cylkey = MESH > 1 && key && M.geom_type()[ga] == GEOM_CYL_;   // (cylinder, box): the hand geom IS geom 1
+    if (key && !cylkey) {
       hull_of(a_, GEOM_BOX_, -1); hull_of(b_, GEOM_MESH_, ga);
 #pragma unroll
       for (int i = 0; i < 3; i++) { a_.pos[i] = posB[i]; a_.size[i] = sB[i]; b_.pos[i] = posA[i]; b_.size[i] = M.geom_size()[3 * ga + i]; }
 #pragma unroll
       for (int i = 0; i < 9; i++) { a_.mat[i] = mB[i]; b_.mat[i] = mA[i]; }
     } else {
-      hull_of(a_, M.geom_type()[ga], ga); hull_of(b_, GEOM_MESH_, gbi);
+      hull_of(a_, M.geom_type()[ga], ga); hull_of(b_, key ? GEOM_BOX_ : (MESH > 1 ? M.geom_type()[gbi] : GEOM_MESH_), key ? -1 : gbi);
 #pragma unroll
       for (int i = 0; i < 3; i++) { a_.pos[i] = posA[i]; a_.size[i] = M.geom_size()[3 * ga + i]; b_.pos[i] = posB[i]; b_.size[i] = sB[i]; }
 #pragma unroll
       for (int i = 0; i < 9; i++) { a_.mat[i] = mA[i]; b_.mat[i] = mB[i]; }
     }
     RawCon<T> rcm[1];
-    const int nm = convex_mpr_wave<T, (MESH > 1), true>(rcm, &a_, &b_, rp_lds_vert<T>(), M.hull_vert, M.hull_graph, in);
+    const int nm = convex_mpr_wave<T, (MESH > 1), true>(rcm, &a_, &b_, rp_lds_vert<T>(), M.hull_vert, M.hull_graph, in, M.mpr_tol, M.mpr_tol_poly);
     if (in) {
       n = nm; rc[0] = rcm[0];
-      if (key) { rc[0].n[0] = -rc[0].n[0]; rc[0].n[1] = -rc[0].n[1]; rc[0].n[2] = -rc[0].n[2]; }
+      if (key && !cylkey) { rc[0].n[0] = -rc[0].n[0]; rc[0].n[1] = -rc[0].n[1]; rc[0].n[2] = -rc[0].n[2]; }
     }
   }
   // ---- the records: contact + its parameters [MJ: mj_contactParam, mj_makeImpedance] (as the one-kernel stage's `emit`)
@@ -145,7 +146,8 @@ __device__ __noinline__ void rp_narrow_chunk(const RpModel<T>& M, const RpState<
     auto put = [&](const int slot, const RawCon<T>& r) {
       const T imp = impedance(solimp, r.dist);
       const T Rn = fmax(RPK_MINVAL, ((T)1 - imp) * invw * ((T)1 + mu * mu) / imp);
-      const T Rpy = fmax(RPK_MINVAL, (T)2 * mu * mu * Rn);
+      const T mur = mu * M.mu_scale;   // (opt.impratio: the regularised friction coefficient)
+      const T Rpy = fmax(RPK_MINVAL, (T)2 * mur * mur * Rn);
       T* o = res + (size_t)slot * 12;
 #pragma unroll
       for (int k = 0; k < 3; k++) { o[k] = r.pos[k]; o[3 + k] = r.n[k]; }

@@ -237,6 +237,7 @@ struct EngineBase {
   virtual int step(int nsub, uint32_t* trace, int mode, const uint8_t* reset_mask = nullptr) = 0;
   virtual void limits(int newton, int ls) = 0;
   virtual void tolerances(double tol, double ls_tol) = 0;
+  virtual void mpr_tolerances(double tol, double poly_tol) = 0;
   bool lazy_position = false;
   bool legacy_step = true;   // rp_set_legacy_step: false = dm_control's legacy_step=False output semantics
   bool cost_order = false;   // rp_set_cost_ordered_launch
@@ -364,6 +365,12 @@ struct Engine : EngineBase {
     // rp_set_solver_tolerance overrides this
     if (sizeof(T) == 4 && M.tolerance < (T)1e-6) M.tolerance = (T)1e-6;
     M.meaninertia = (T)b.f1("stat_meaninertia");
+    // opt.impratio [MJ: mj_makeImpedance]: friction dimensions regularised by R / impratio
+    {
+      const double ir = b.has("opt_impratio") ? b.f1("opt_impratio") : 1.0;
+      M.mu_scale = (T)std::sqrt(1.0 / (ir > 1e-15 ? ir : 1e-15));
+    }
+    M.mpr_tol = (T)1e-6; M.mpr_tol_poly = (T)1e-6;   // MuJoCo's uniform rule (rp_set_mpr_tolerance)
     // ---- pack every model table into the two device arrays (RpLayout offsets)
     std::vector<double> ft((size_t)RpLayout::F_TOTAL, 0.0);
     std::vector<int> it((size_t)RpLayout::I_TOTAL, 0);
@@ -453,6 +460,10 @@ struct Engine : EngineBase {
       if (b.has("eng_geom_vertgraph")) PI(geom_vertgraph, "eng_geom_vertgraph");
       for (int t : b.i("eng_geom_type")) if (t == GEOM_MESH_) mesh = true;
     }
+    // cylinders collide through the portal refinement like hulls; their support function is compiled into the MESH = 2
+    // builds only (the builds of scenes with the real hand's colliders: graph hulls, cylinders), so that the benchmark's
+    // kernels stay what they were
+    for (int t : b.i("eng_geom_type")) if (t == GEOM_CYL_) { mesh = true; graph = true; }
 #undef PF
 #undef PI
     M.ft = upF(ft);
@@ -494,19 +505,8 @@ struct Engine : EngineBase {
       const char* sp = getenv("RP_SPLIT_POS");
       split_capable = sizeof(T) == 8 && !deep;
       split_mode = !split_capable ? 0 : (sp ? (sp[0] == '0' ? 0 : (sp[0] == '1' ? 1 : 2)) : 2);
-      if (split_capable) {
-        B.frames = dalloc<T>(E * RPK_NFRAME * 64);
-        B.cand = dalloc<int>(E * RPK_NCAND * 2);
-        B.ncand = dalloc<int>(E);
-        B.cres = dalloc<T>(E * RPK_NRES * 12);
-        B.cres_n = dalloc<int>(E * RPK_NCAND);
-        B.tstride = ((E + RPK_NSTRIPE - 1) / RPK_NSTRIPE + 1) * RPK_NCAND;   // (+1: a slice's stripe may hold one env more than cnt / 8)
-        B.tlist = dalloc<int>((size_t)RPK_NTYPE * RPK_NSTRIPE * B.tstride * 4);
-        B.tcount = dalloc<int>(kMaxSlices * RPK_NSTRIPE * RPK_NTYPE_PAD);   // (zero-filled)
-        B.tcount_off = 0;
-        hipMemset(B.ncand, 0xFF, sizeof(int) * E);        // -1: no front part has run
-        hipMemset(B.frames, 0xFF, sizeof(T) * E * RPK_NFRAME * 64);
-      }
+      // (the buffers -- 78 KB per env: 320 MB at 4096 envs -- are allocated by the first rp_step that runs the split stage:
+      // ensure_split_buffers; an engine that never does, small batches and RP_SPLIT_POS=0 among them, never pays for them)
     }
     // hand-over buffers start as NaN / -1 patterns: a read of anything the position kernel
     // did not write this substep shows up as a bad state instead of silently reusing old data
@@ -550,6 +550,38 @@ struct Engine : EngineBase {
     if (hipDeviceSynchronize() != hipSuccess) throw std::string("hipDeviceSynchronize failed after model upload");
   }
 
+  // The split position stage's buffers, on first use.  False (and the split stage off for good) when the device has no
+  // room for them: the one-kernel stage computes the same bits.
+  bool split_alloc_failed = false;
+  bool ensure_split_buffers() {
+    if (B.frames) return true;
+    if (split_alloc_failed) return false;
+    const size_t E = (size_t)nenv;
+    const size_t mark = allocs.size();
+    try {
+      T* frames = dalloc<T>(E * RPK_NFRAME * 64);
+      B.cand = dalloc<int>(E * RPK_NCAND * 2);
+      B.ncand = dalloc<int>(E);
+      B.cres = dalloc<T>(E * RPK_NRES * 12);
+      B.cres_n = dalloc<int>(E * RPK_NCAND);
+      B.tstride = ((E + RPK_NSTRIPE - 1) / RPK_NSTRIPE + 1) * RPK_NCAND;   // (+1: a slice's stripe may hold one env more than cnt / 8)
+      B.tlist = dalloc<int>((size_t)RPK_NTYPE * RPK_NSTRIPE * B.tstride * 4);
+      B.tcount = dalloc<int>(kMaxSlices * RPK_NSTRIPE * RPK_NTYPE_PAD);   // (zero-filled)
+      B.tcount_off = 0;
+      hipMemset(B.ncand, 0xFF, sizeof(int) * E);        // -1: no front part has run
+      hipMemset(frames, 0xFF, sizeof(T) * E * RPK_NFRAME * 64);
+      B.frames = frames;
+      // (null-stream fills vs the engine's non-blocking streams, as at the end of build())
+      if (hipDeviceSynchronize() != hipSuccess) throw std::string("hipDeviceSynchronize failed");
+    } catch (const std::string&) {
+      (void)hipGetLastError();
+      while (allocs.size() > mark) { hipFree(allocs.back()); allocs.pop_back(); }
+      B.frames = nullptr; B.cand = nullptr; B.ncand = nullptr; B.cres = nullptr; B.cres_n = nullptr; B.tlist = nullptr; B.tcount = nullptr;
+      split_alloc_failed = true; split_mode = 0;
+      return false;
+    }
+    return true;
+  }
   long long* d_prof = nullptr;
   int* d_active = nullptr;
   int* d_order = nullptr;           // cost-ordered launch: workgroup -> env
@@ -658,6 +690,12 @@ struct Engine : EngineBase {
     HIP_OK(hipDeviceSynchronize());        // (null-stream fill vs the engine's non-blocking stream)
     S.prof = enable ? d_prof : nullptr;
     return 0;
+  }
+  void mpr_tolerances(double tol, double poly_tol) override {
+    const double floor_ = sizeof(T) == 4 ? 1e-6 : 0.0;   // (single precision cannot resolve a tighter portal distance)
+    if (tol > 0) M.mpr_tol = (T)(tol > floor_ ? tol : floor_);
+    if (poly_tol > 0) M.mpr_tol_poly = (T)(poly_tol > floor_ ? poly_tol : floor_);
+    else if (tol > 0) M.mpr_tol_poly = M.mpr_tol;
   }
   void tolerances(double tol, double ls_tol) override {
     if (tol > 0) M.tolerance = (T)tol;
@@ -859,8 +897,13 @@ struct Engine : EngineBase {
       sched4 = sched == 4;
     }
     split_now = split_capable && mode == 0 && (split_mode == 1 || sched4);
-    const bool companion_now = companion && !sched4;
     int nsl = (mode == 0 && want > 1 && nenv >= 1024 && !capturing && !fused_now) ? (want >= 4 ? 4 : want) : 1;
+    // (slices 2 / 3 run ON the companion streams of slices 0 / 1 -- pooled_stream: four hardware queues -- so with more
+    // than two slices there are no companion streams, whoever asked for the slices: the full-capacity launch then goes in
+    // front of the lean one on the slice's own stream.  ADVICE round 5: only the engine's own three-slice schedule turned
+    // them off; a forced rp_set_stream_slices(e, 3 | 4) queued slice 2's whole chain behind slice 0's heavy solves.)
+    if (split_now && ((capturing && !B.frames) || !ensure_split_buffers())) split_now = false;   // (no allocation inside a stream capture)
+    const bool companion_now = companion && nsl <= 2;
     if (nsl > 1 && !ev_fork && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev_fork = nullptr; nsl = 1; }
     for (int i = 1; i < nsl; i++) {
       if (xstream[i]) continue;
@@ -1136,6 +1179,11 @@ int rp_set_solver_limits(rp_engine* e, int max_newton_iter, int max_ls_iter) {
 }
 int rp_profile(rp_engine* e, long long* out, int n, int enable) {
   return e ? E(e)->profile(out, n, enable) : fail("null engine");
+}
+int rp_set_mpr_tolerance(rp_engine* e, double tolerance, double polytope_tolerance) {
+  if (!e) return fail("null engine");
+  E(e)->mpr_tolerances(tolerance, polytope_tolerance);
+  return 0;
 }
 int rp_set_solver_tolerance(rp_engine* e, double tolerance, double ls_tolerance) {
   if (!e) return fail("null engine");

@@ -1988,6 +1988,14 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
             for (int i = 0; i < 3; i++) { mpr_a.pos[i] = bp[i]; mpr_a.size[i] = M.key_half()[3 * k + i]; mpr_b.pos[i] = posA[i]; mpr_b.size[i] = M.geom_size()[3 * ga + i]; }
 #pragma unroll
             for (int i = 0; i < 9; i++) { mpr_a.mat[i] = bm[i]; mpr_b.mat[i] = mA[i]; }
+          } else if (MESH > 1 && M.geom_type()[ga] == GEOM_CYL_) {
+            // (cylinder, box) in geom-type order: the hand geom is geom 1 of the pair, nothing to turn around
+            mpr = true;
+            hull_of(mpr_a, GEOM_CYL_, ga); hull_of(mpr_b, GEOM_BOX_, -1);
+#pragma unroll
+            for (int i = 0; i < 3; i++) { mpr_a.pos[i] = posA[i]; mpr_a.size[i] = M.geom_size()[3 * ga + i]; mpr_b.pos[i] = bp[i]; mpr_b.size[i] = M.key_half()[3 * k + i]; }
+#pragma unroll
+            for (int i = 0; i < 9; i++) { mpr_a.mat[i] = mA[i]; mpr_b.mat[i] = bm[i]; }
           } else {
             boxside = true; bxs = M.key_half() + 3 * k;
 #pragma unroll
@@ -2008,9 +2016,11 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
           }
           if (M.geom_type()[gb] == GEOM_CAPSULE_)
             n = capsule_capsule(rc, posA, mA, M.geom_size() + 3 * ga, posB, mB, M.geom_size() + 3 * gb);
-          else if (MESH && M.geom_type()[gb] == GEOM_MESH_) {
+          else if (MESH && (M.geom_type()[gb] == GEOM_MESH_ || (MESH > 1 && (M.geom_type()[ga] == GEOM_CYL_ || M.geom_type()[gb] == GEOM_CYL_)))) {
+            // (hulls, and in the MESH = 2 builds cylinders: every such pair goes to the portal refinement, in geom-type
+            // order -- capsule < cylinder < box < hull, which is lane order)
             mpr = true;
-            hull_of(mpr_a, M.geom_type()[ga], ga); hull_of(mpr_b, GEOM_MESH_, gb);
+            hull_of(mpr_a, M.geom_type()[ga], ga); hull_of(mpr_b, MESH > 1 ? M.geom_type()[gb] : GEOM_MESH_, gb);
 #pragma unroll
             for (int i = 0; i < 3; i++) { mpr_a.pos[i] = posA[i]; mpr_a.size[i] = M.geom_size()[3 * ga + i]; mpr_b.pos[i] = posB[i]; mpr_b.size[i] = M.geom_size()[3 * gb + i]; }
 #pragma unroll
@@ -2035,7 +2045,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         PROF(13);
         if (__ballot(mpr) != 0ull) {   // (the whole wave walks the portal refinement together)
           RawCon<T> rcm[1];
-          const int nm = convex_mpr_wave<T, (MESH > 1)>(rcm, &mpr_a, &mpr_b, M.mesh_vert(), M.hull_vert, M.hull_graph, mpr);
+          const int nm = convex_mpr_wave<T, (MESH > 1)>(rcm, &mpr_a, &mpr_b, M.mesh_vert(), M.hull_vert, M.hull_graph, mpr, M.mpr_tol, M.mpr_tol_poly);
           if (mpr) {
             n = nm; rc[0] = rcm[0];
             if (mpr_flip) { rc[0].n[0] = -rc[0].n[0]; rc[0].n[1] = -rc[0].n[1]; rc[0].n[2] = -rc[0].n[2]; }
@@ -2060,7 +2070,8 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         T Bc = (T)2 / fmax(RPK_MINVAL, dmax * solref0);
         T imp = impedance(solimp, dist);
         T Rn = fmax(RPK_MINVAL, ((T)1 - imp) * invw * ((T)1 + mu * mu) / imp);
-        T Rpy = fmax(RPK_MINVAL, (T)2 * mu * mu * Rn);
+        const T mur = mu * M.mu_scale;   // (opt.impratio: the regularised friction coefficient)
+        T Rpy = fmax(RPK_MINVAL, (T)2 * mur * mur * Rn);
         par[0] = mu; par[1] = Kc * imp * dist; par[2] = Bc; par[3] = (T)1 / Rpy;
       };
       auto emit = [&](const int idx, const RawCon<T>& r) {   // idx < RPK_NCL
@@ -2163,7 +2174,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         if (gb >= RPK_KEYBASE) ty = ta == GEOM_CAPSULE_ ? 1 : (ta == GEOM_BOX_ ? 2 : 3);
         else {
           const int tb = M.geom_type()[gb];
-          ty = tb == GEOM_CAPSULE_ ? 0 : ((tb == GEOM_MESH_ || ta == GEOM_MESH_) ? 3 : (ta == GEOM_CAPSULE_ ? 1 : 2));
+          ty = tb == GEOM_CAPSULE_ ? 0 : ((tb == GEOM_MESH_ || ta == GEOM_MESH_ || (MESH > 1 && (ta == GEOM_CYL_ || tb == GEOM_CYL_))) ? 3 : (ta == GEOM_CAPSULE_ ? 1 : 2));
         }
         if (MESH != 0 && ty == 3) {   // hull pairs: the bucket of lanes that need the same vertex scans (rp_model.hpp)
           const int hb_ = gb >= RPK_KEYBASE ? ga : gb;   // (side B of the refinement: the hull)

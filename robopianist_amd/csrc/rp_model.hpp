@@ -79,6 +79,7 @@
 #define JNT_SLIDE_ 2
 #define JNT_HINGE_ 3
 #define GEOM_CAPSULE_ 3
+#define GEOM_CYL_ 5    // cylinder: geom_size = (radius, radius, half height) -- its bounding box, as for hulls; MESH = 2 builds only
 #define GEOM_BOX_ 6
 #define GEOM_MESH_ 7   // convex hull (vertices in the geom frame)
 #define RPK_MAXMESHV 320 // vertices of all SCANNED hulls together (hulls with a vertex graph: RpModel::hull_vert, any size)
@@ -158,6 +159,12 @@ struct RpModel {
   int nlink, ntree, maxdepth, nkey, ngeom, nu, nsite, nv;
   int iterations, ls_iterations;
   T timestep, gx, gy, gz, tolerance, ls_tolerance, meaninertia, key_zmax;
+  // sqrt(1 / opt.impratio): a contact's regularised friction coefficient is friction * mu_scale, its pyramid edges get
+  // Rpy = 2 (mu * mu_scale)^2 R [MJ: mj_makeImpedance]; the Jacobian rows keep the friction coefficient itself
+  T mu_scale;
+  // stopping tolerance of the portal refinement (hull / cylinder pairs): MuJoCo's uniform 1e-6 by default; mpr_tol_poly
+  // applies to POLYTOPE pairs (box / hull on both sides) and differs only after rp_set_mpr_tolerance
+  T mpr_tol, mpr_tol_poly;
   const T* ft;    // RpLayout::F_* offsets
   const int* it;  // RpLayout::I_* offsets
   // hulls with a vertex graph (model/hull.py: more than 32 vertices -- the real hand's forearm / wrist / palm / thumb

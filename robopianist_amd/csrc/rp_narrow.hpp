@@ -446,10 +446,22 @@ __device__ RPK_BOXBOX_INLINE int box_box(RawCon<T>* out, RawCon<T>* extra, const
 template <typename T> struct CGeom { int type, nvert, vadr, flip, graph; T pos[3], mat[9], size[3]; };   // flip: bit k = the stored vertex set is this hull's mirror image in coordinate k; graph: the set has a vertex graph (walked, not scanned)
 template <typename T> struct MPoint { T v[3], m[3]; };   // a point of B - A and the midpoint of its two witness points
 
-// support point of a capsule / box (hulls: hull_support_wave)
-template <typename T>
+// support point of a capsule / box (hulls: hull_support_wave); CYL: ... or a cylinder [MJ: mjc_support, mjGEOM_CYLINDER:
+// in the geom frame the direction's xy part scaled to the radius (nothing when it vanishes), sign(z) * half height]
+// (size = (radius, radius, half height): the cylinder's bounding box, which the fp32 culls use as they use a hull's)
+template <typename T, bool CYL = false>
 __device__ __forceinline__ void prim_support(const CGeom<T>& g, const T* d, T* out) {
-  if (g.type == GEOM_CAPSULE_) {
+  if (CYL && g.type == GEOM_CYL_) {
+    T dl[3], r[3], w[3];
+    matT_vec(dl, g.mat, d);
+    const T t = Num<T>::sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
+    const T ts = t > RPK_MINVAL ? t : (T)1;   // (divisions, as the oracle writes them: the same roundings)
+    r[0] = t > RPK_MINVAL ? dl[0] / ts * g.size[0] : (T)0;
+    r[1] = t > RPK_MINVAL ? dl[1] / ts * g.size[0] : (T)0;
+    r[2] = dl[2] > 0 ? g.size[2] : (dl[2] < 0 ? -g.size[2] : (T)0);
+    mat_vec(w, g.mat, r);
+    out[0] = g.pos[0] + w[0]; out[1] = g.pos[1] + w[1]; out[2] = g.pos[2] + w[2];
+  } else if (g.type == GEOM_CAPSULE_) {
     const T ax[3] = {g.mat[2], g.mat[5], g.mat[8]};
     const T sl = dot3(ax, d) >= 0 ? g.size[1] : -g.size[1];
 #pragma unroll
@@ -573,7 +585,7 @@ template <typename T> __device__ __forceinline__ void portal_dir(T* dir, const M
 template <typename T, bool GRAPH, bool LDSV = false>
 __device__ RPK_MPR_INLINE int convex_mpr_wave(RawCon<T>* __restrict__ out, const CGeom<T>* __restrict__ Ap,
                                             const CGeom<T>* __restrict__ Bp, const T* __restrict__ mv, const T* __restrict__ hv,
-                                            const int* __restrict__ hg, const bool active) {
+                                            const int* __restrict__ hg, const bool active, const T tol, const T tol_poly) {
   // (the two geoms by value: re-reading them through the pointers on every trip -- scratch memory, a
   // dependent round trip each -- was most of this routine's time)
   const CGeom<T> A = *Ap, B = *Bp;
@@ -607,8 +619,8 @@ __device__ RPK_MPR_INLINE int convex_mpr_wave(RawCon<T>* __restrict__ out, const
       const bool hA = run && A.type == GEOM_MESH_, hB = run && B.type == GEOM_MESH_;
       if (__ballot(hA) != 0ull) hull_support_wave<T, GRAPH, LDSV>(mv, hv, hg, A, nd, hA, p1);
       if (__ballot(hB) != 0ull) hull_support_wave<T, GRAPH, LDSV>(mv, hv, hg, B, dir, hB, p2);
-      if (run && A.type != GEOM_MESH_) prim_support(A, nd, p1);
-      if (run && B.type != GEOM_MESH_) prim_support(B, dir, p2);
+      if (run && A.type != GEOM_MESH_) prim_support<T, GRAPH>(A, nd, p1);
+      if (run && B.type != GEOM_MESH_) prim_support<T, GRAPH>(B, dir, p2);
 #pragma unroll
       for (int k = 0; k < 3; k++) { S.v[k] = p2[k] - p1[k]; S.m[k] = (T)0.5 * (p1[k] + p2[k]); }
     }
@@ -642,11 +654,11 @@ __device__ RPK_MPR_INLINE int convex_mpr_wave(RawCon<T>* __restrict__ out, const
     } else if (phase == 3) {
       const T reach = dot3(S.v, dir) - dot3(v1.v, dir);
       if (!hit && dot3(S.v, dir) < 0) phase = 4;
-      // (round 5: POLYTOPE pairs refine to 1e-10 -- converged, the result does not depend on which of several tied support
-      // vertices rounding put first; with the 1e-6 rule the engine stopped 1.7e-7 short of the oracle at one mj_step in
-      // 1580 of the hull replay, 1.6 % of that step's velocity change; oracle/rp_oracle.c: CCD_TOL_POLY.  Pairs with a
-      // capsule keep MuJoCo's 1e-6.)
-      else if (reach <= ((A.type != GEOM_CAPSULE_ && B.type != GEOM_CAPSULE_) ? (T)(sizeof(T) == 8 ? 1e-10 : 1e-6) : (T)1e-6) || it == 50) {
+      // (MuJoCo's uniform rule by default: tol = tol_poly = 1e-6.  rp_set_mpr_tolerance gives POLYTOPE pairs -- box / hull on
+      // both sides -- their own: refined to 1e-10 the result does not depend on which of several tied support vertices
+      // rounding put first; with the 1e-6 rule the engine stops 1.7e-7 short of the oracle at one mj_step in 1580 of the
+      // hull replay, 1.6 % of that step's velocity change.  oracle/rp_oracle.c: g_mpr_tol_poly.)
+      else if (reach <= (((A.type == GEOM_BOX_ || A.type == GEOM_MESH_) && (B.type == GEOM_BOX_ || B.type == GEOM_MESH_)) ? tol_poly : tol) || it == 50) {
         if (hit) {
           const T depth = dot3(v1.v, dir);
           T b[4], c[3];

@@ -37,7 +37,7 @@ WARN_DENSE_FULL = 32
 
 EXPORTED_SYMBOLS = (
     "rp_create", "rp_destroy", "rp_reset", "rp_set", "rp_get", "rp_step", "rp_forward", "rp_step_masked",
-    "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_set_lazy_position_stage", "rp_set_legacy_step", "rp_set_cost_ordered_launch", "rp_set_stream_slices", "rp_set_lean_solver", "rp_set_fused_substeps", "rp_get_fused_substeps", "rp_set_split_position_stage", "rp_get_split_position_stage", "rp_set_acc_sensors", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
+    "rp_set_solver_limits", "rp_set_solver_tolerance", "rp_set_mpr_tolerance", "rp_set_lazy_position_stage", "rp_set_legacy_step", "rp_set_cost_ordered_launch", "rp_set_stream_slices", "rp_set_lean_solver", "rp_set_fused_substeps", "rp_get_fused_substeps", "rp_set_split_position_stage", "rp_get_split_position_stage", "rp_set_acc_sensors", "rp_sync", "rp_get_stream", "rp_set_stream", "rp_field_ptr",
     "rp_n_envs", "rp_dim",
     "rp_kernel_time", "rp_solver_kernel_time", "rp_solver_kernel_envs", "rp_solver_kernel_fused", "rp_profile", "rp_last_error",
 )
@@ -82,6 +82,7 @@ def load_library(path: str = LIB_PATH):
     L.rp_set_solver_limits.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     L.rp_sync.argtypes = [ctypes.c_void_p]
     L.rp_set_solver_tolerance.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]
+    L.rp_set_mpr_tolerance.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]
     L.rp_set_lazy_position_stage.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.rp_set_cost_ordered_launch.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.rp_set_acc_sensors.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -305,6 +306,11 @@ class BatchedPhysics:
     def set_cost_ordered_launch(self, on: bool = True):
         """Stage kernels process the envs heaviest-first (include/rp_engine.h); bit-identical results."""
         self._check(self._L.rp_set_cost_ordered_launch(self._h, int(bool(on))))
+
+    def set_mpr_tolerance(self, tolerance=0.0, polytope_tolerance=0.0):
+        """Stopping tolerance of the hull / cylinder narrow phase (default: MuJoCo's uniform 1e-6);
+        `polytope_tolerance` = box / hull pairs refine to that instead (include/rp_engine.h)."""
+        self._check(self._L.rp_set_mpr_tolerance(self._h, float(tolerance), float(polytope_tolerance)))
 
     def set_solver_tolerance(self, tolerance=0.0, ls_tolerance=0.0):
         self._check(self._L.rp_set_solver_tolerance(self._h, float(tolerance), float(ls_tolerance)))

@@ -319,6 +319,8 @@ def compile_scene(scene: spec.Scene) -> Model:
             rb[g] = s[0] + s[1]
         elif t == spec.GEOM_BOX:
             rb[g] = np.linalg.norm(s)
+        elif t == spec.GEOM_CYLINDER:
+            rb[g] = np.hypot(s[0], s[1])
         elif t == spec.GEOM_MESH:
             a, n_ = geom["vertadr"][g], geom["vertnum"][g]
             rb[g] = np.linalg.norm(np.asarray(mesh_vert[a:a + n_]), axis=1).max()

@@ -371,7 +371,13 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
     t["eng_ngeom"] = np.array([ng], np.int32)
     t["eng_geom_link"] = g_link
     t["eng_geom_type"] = m.geom_type[egeoms].astype(np.int32) if ng else np.zeros(0, np.int32)
-    t["eng_geom_size"] = m.geom_size[egeoms] if ng else np.zeros((0, 3))
+    gsz = m.geom_size[egeoms].copy() if ng else np.zeros((0, 3))
+    for i, g in enumerate(egeoms):
+        # a cylinder's engine size is its bounding box (radius, radius, half height) -- what the fp32 culls treat it as,
+        # exactly as they treat a hull's box; the support function takes the radius from [0], the half height from [2]
+        if m.geom_type[g] == spec.GEOM_CYLINDER:
+            gsz[i] = (m.geom_size[g, 0], m.geom_size[g, 0], m.geom_size[g, 1])
+    t["eng_geom_size"] = gsz
     t["eng_geom_pos"] = g_pos
     t["eng_geom_mat"] = g_mat
     t["eng_geom_rbound"] = m.geom_rbound[egeoms] if ng else np.zeros(0)
@@ -381,6 +387,9 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
         axis=1) if ng else np.zeros((0, 8)))
     t["eng_geom_modelid"] = np.array(egeoms, np.int32)
     # convex hulls: vertices (geom frame; welded bodies are handled through geom_pos / geom_mat)
+    for g in egeoms:
+        assert m.geom_type[g] in (spec.GEOM_CAPSULE, spec.GEOM_CYLINDER, spec.GEOM_BOX, spec.GEOM_MESH), (
+            f"collision geom {g}: the engine's narrow phase handles capsule / cylinder / box / mesh (type {int(m.geom_type[g])})")
     if ng and "geom_vertnum" in m and int(np.sum(m.geom_vertnum[egeoms])) > 0:
         # (geoms with identical vertex sets -- the four finger tips of a hand -- share one copy, and so do sets that
         # are mirror images of a stored one in one coordinate -- the other hand: the lanes of a wave that use the
@@ -451,7 +460,7 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
         assert not (ka and kb)
         if ka or kb:
             h = b if ka else a
-            assert m.geom_type[h] in (spec.GEOM_CAPSULE, spec.GEOM_BOX, spec.GEOM_MESH), "capsule- / box- / hull-vs-key pairs only"
+            assert m.geom_type[h] in (spec.GEOM_CAPSULE, spec.GEOM_CYLINDER, spec.GEOM_BOX, spec.GEOM_MESH), "capsule- / cylinder- / box- / hull-vs-key pairs only"
             keycount[h] = keycount.get(h, 0) + 1
         else:
             spairs.append((eidx[a], eidx[b]))

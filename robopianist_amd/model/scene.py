@@ -93,13 +93,20 @@ def build_scene(
     disable_hand_collisions: bool = False,
     root_sites: bool = False,
     mesh_colliders: int = 0,
-    standin_wrist_clearance: bool = False,
+    standin_wrist_clearance: bool = True,
+    cylinder_colliders: bool = False,
+    impratio: Optional[float] = None,
 ) -> SceneInfo:
     """`mesh_colliders` = n > 0 (extension, for tests and the large-hull bench figure): every collider of the hands
     becomes a convex hull of ~n vertices inscribed in its stand-in primitive -- what the reference's default hand looks
     like to the collision pipeline, where forearm, wrist, palm, thumb links and fingertips all are `plastic_collision`
     meshes collided through their hulls (/root/reference/robopianist/models/hands/shadow_hand.py:144-152,
-    shadow_hand_constants.py:52-53)."""
+    shadow_hand_constants.py:52-53).
+    `impratio`: `opt.impratio` of the compiled scene.  None = what the reference's scene ends up with: the hand XML's
+    `<option impratio="10"/>` (`mjcf.from_path`, models/hands/shadow_hand.py:122, and `arena.attach` merge
+    the hand's options into the root) when a hand is attached, MuJoCo's default 1 for the piano alone.
+    `cylinder_colliders`: wrist / knuckle colliders as cylinders (the menagerie's types) instead of capsules.
+    `standin_wrist_clearance=False`: rounds 1-5's forearm box (a rigid-link overlap; model/shadow_hand.py)."""
     if hands and not primitive_fingertip_collisions:
         warnings.warn(
             "The menagerie fingertip meshes are not available (mujoco_menagerie is not vendored in the "
@@ -114,6 +121,7 @@ def build_scene(
         world.add(k)
     scene = spec.Scene(world=world)
     scene.options.timestep = physics_timestep
+    scene.options.impratio = float(impratio) if impratio is not None else (10.0 if hands else 1.0)
     scene.actuators.extend(piano_acts)
 
     builders = {}
@@ -123,6 +131,7 @@ def build_scene(
             reduced_action_space=reduced_action_space,
             primitive_fingertip_collisions=primitive_fingertip_collisions,
             standin_wrist_clearance=standin_wrist_clearance,
+            cylinder_colliders=cylinder_colliders,
         )
         position = RIGHT_HAND_POSITION if side == "right" else LEFT_HAND_POSITION
         quaternion = RIGHT_HAND_QUATERNION if side == "right" else LEFT_HAND_QUATERNION

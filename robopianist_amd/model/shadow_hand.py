@@ -23,8 +23,13 @@ deliberate:
     primitives; fingertips are capsules, i.e. the reference's
     `primitive_fingertip_collisions=True` mode (shadow_hand.py:144-152) with
     hand-picked capsule sizes instead of MuJoCo's mesh-fit ones;
-  * cylinder colliders (wrist, knuckles) are replaced by capsules so that the
-    narrow phase only needs capsule-capsule and capsule-box.
+  * cylinder colliders (wrist, knuckles) are capsules by default (the benchmark's kernel builds carry no
+    cylinder code); `cylinder_colliders=True` restores them as cylinders of the same radius / half length, collided
+    through the support-function path like hulls (round 6: both narrow phases handle mjGEOM_CYLINDER).
+Round 6 also made two corrections to the stand-in itself: the scene carries the hand XML's `<option impratio="10"/>`
+(model/scene.py), and the forearm's wrist box sits 12 mm lower (`standin_wrist_clearance`, now the
+default): with the remembered z = 0.181 two RIGID links two joints apart overlapped by 7.6 mm at the end of WRJ2's
+range and sat in contact on 43-61 % of the replay's mj_steps -- an artefact of this file, not of the hand.
 The compiled blob format is generic: a real mjModel dumped to the same arrays
 drops in without touching the engine.
 """
@@ -127,17 +132,19 @@ class HandBuilder:
         restrict_wrist_yaw_range: bool = False,
         reduced_action_space: bool = False,
         primitive_fingertip_collisions: bool = True,
-        standin_wrist_clearance: bool = False,
+        standin_wrist_clearance: bool = True,
+        cylinder_colliders: bool = False,
     ):
         assert side in ("right", "left")
-        # DIAGNOSTIC VARIANT (off by default; oracle/standin_report.py, bench.py `aux.standin_wrist_clearance`): with the
-        # from-memory numbers the forearm's wrist box and the palm boxes -- two rigid links, two joints apart --
-        # interpenetrate by up to 7.6 mm when WRJ2 alone is driven to the negative end of its range, and that pair is in
-        # contact on 43 % / 61 % of the replay's mj_steps.  On: the box sits 12 mm lower (no rigid-link overlap left in
-        # the single-joint sweep apart from neighbouring fingers abducted into each other).  The default stays what
-        # memory says the menagerie XML holds: the six-digit box numbers are not this repo's to tune.
+        # `standin_wrist_clearance` (default since round 6): with the from-memory numbers (z = 0.181) the forearm's wrist
+        # box and the palm boxes -- two rigid links, two joints apart -- interpenetrate by up to 7.6 mm when WRJ2 alone
+        # is driven to the negative end of its range, and that pair was in contact on 43 % / 61 % of the replay's
+        # mj_steps (oracle/standin_report.py).  On: the box sits 12 mm lower and the single-joint sweep finds no
+        # rigid-link overlap apart from neighbouring fingers abducted into each other (tests/test_standin_report.py).
+        # False = rounds 1-5's geometry, kept for comparisons.
         self.standin_wrist_clearance = bool(standin_wrist_clearance)
         self.primitive_fingertips = bool(primitive_fingertip_collisions)
+        self.cylinder_colliders = bool(cylinder_colliders)
         for d in forearm_dofs:
             if d not in FOREARM_DOFS:
                 # Same error behaviour as shadow_hand.py:283-287.
@@ -199,6 +206,16 @@ class HandBuilder:
             **_PLASTIC,
         )
 
+    def _cylinder(self, name, radius, half, pos=(0, 0, 0), quat=(1, 0, 0, 0)):
+        """Wrist / knuckle colliders: cylinders in the menagerie XML [MEM]; capsules unless `cylinder_colliders`."""
+        if not self.cylinder_colliders:
+            return self._capsule(name, radius, half, pos, quat)
+        return spec.Geom(
+            self._n(name), spec.GEOM_CYLINDER, (radius, half, 0.0),
+            pos=_mirror_vec(pos, self.left), quat=_mirror_quat(quat, self.left),
+            **_PLASTIC,
+        )
+
     def _fingertip(self, name, radius, half, pos):
         """Collision geom of a distal phalanx (`*distal_pst`).  The reference's default is the
         menagerie mesh, collided through its convex hull; `primitive_fingertip_collisions=True`
@@ -233,8 +250,8 @@ class HandBuilder:
         kn = palm.add(self._body(f + "knuckle", knuckle_pos, 0.008, (0, 0, 0),
                                  (0.5, 0.5, -0.5, 0.5), (3.2e-07, 2.6e-07, 2.6e-07)))
         kn.joints.append(self._joint(f.upper() + "J4", "knuckle"))
-        kn.geoms.append(self._capsule(f + "knuckle_col", 0.008, 0.001,
-                                      quat=(1, 0, 1, 0)))
+        kn.geoms.append(self._cylinder(f + "knuckle_col", 0.008, 0.001,
+                                       quat=(1, 0, 1, 0)))
         self._finger_chain(kn, f)
 
     def _finger_chain(self, kn, f):
@@ -266,8 +283,8 @@ class HandBuilder:
         wr = fa.add(self._body("wrist", (0.01, 0, 0.21301), 0.1, (0, 0, 0.029),
                                (0.5, 0.5, 0.5, 0.5), (6.4e-05, 4.38e-05, 3.5e-05)))
         wr.joints.append(self._joint("WRJ2", "wrist_y"))
-        wr.geoms.append(self._capsule("wrist_col", 0.0135, 0.015,
-                                      quat=(0.5, 0.5, 0.5, -0.5)))
+        wr.geoms.append(self._cylinder("wrist_col", 0.0135, 0.015,
+                                       quat=(0.5, 0.5, 0.5, -0.5)))
         palm = wr.add(self._body("palm", (0, 0, 0.034), 0.3, (0, 0, 0.035),
                                  (1, 0, 0, 1), (0.0005287, 0.0003581, 0.000191)))
         palm.joints.append(self._joint("WRJ1", "wrist_x"))
@@ -301,7 +318,7 @@ class HandBuilder:
         kn = mc.add(self._body("lfknuckle", (0, 0, 0.06579), 0.008, (0, 0, 0),
                                (0.5, 0.5, -0.5, 0.5), (3.2e-07, 2.6e-07, 2.6e-07)))
         kn.joints.append(self._joint("LFJ4", "knuckle"))
-        kn.geoms.append(self._capsule("lfknuckle_col", 0.008, 0.001, quat=(1, 0, 1, 0)))
+        kn.geoms.append(self._cylinder("lfknuckle_col", 0.008, 0.001, quat=(1, 0, 1, 0)))
         self._finger_chain(kn, "lf")
         # Thumb.
         tb = palm.add(self._body("thbase", (0.034, -0.00858, 0.029), 0.01, (0, 0, 0),

@@ -22,6 +22,7 @@ import numpy as np
 GEOM_PLANE = 0
 GEOM_SPHERE = 2
 GEOM_CAPSULE = 3
+GEOM_CYLINDER = 5  # size = (radius, half height); collides through mjc_Convex (support function), like hulls
 GEOM_BOX = 6
 GEOM_MESH = 7  # a convex hull given by its vertices (MuJoCo collides meshes through their hulls)
 

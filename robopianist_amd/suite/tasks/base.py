@@ -198,7 +198,8 @@ class PianoTask(PianoOnlyTask):
                  physics_timestep: float = _PHYSICS_TIMESTEP,
                  control_timestep: float = _CONTROL_TIMESTEP,
                  disable_hand_collisions: bool = False, _hands=("right", "left"),
-                 _root_sites: bool = False, mesh_colliders: int = 0, standin_wrist_clearance: bool = False):
+                 _root_sites: bool = False, mesh_colliders: int = 0, standin_wrist_clearance: bool = True,
+                 cylinder_colliders: bool = False, impratio: Optional[float] = None):
         super().__init__(
             add_piano_actuators=False, change_color_on_activation=change_color_on_activation,
             physics_timestep=physics_timestep, control_timestep=control_timestep, _hands=_hands,
@@ -207,7 +208,7 @@ class PianoTask(PianoOnlyTask):
             reduced_action_space=reduced_action_space, attachment_yaw=attachment_yaw,
             forearm_dofs=forearm_dofs, disable_hand_collisions=disable_hand_collisions,
             root_sites=_root_sites, mesh_colliders=mesh_colliders,   # (extensions: model/scene.py)
-            standin_wrist_clearance=standin_wrist_clearance)
+            standin_wrist_clearance=standin_wrist_clearance, cylinder_colliders=cylinder_colliders, impratio=impratio)
         m = self.scene.model
         self._right_hand = Hand(self.scene.hands["right"], m) if "right" in self.scene.hands else None
         self._left_hand = Hand(self.scene.hands["left"], m) if "left" in self.scene.hands else None

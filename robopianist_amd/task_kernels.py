@@ -270,6 +270,15 @@ class FusedAdvance:
         p.fingering_state = _chk(fingering_state, dt, (E, 5 if a.hand_filter else 10))
         p.needs_reset = _chk(needs_reset, torch.bool, (E,))
         if getattr(self, "_traj", None) is not None:
+            # A captured graph bakes ONE record pointer in: replays would all write the buffer of the captured call while
+            # this counter stands still, and the "step t's gather may still read while step t + 1 writes" guarantee of
+            # two buffers would be void.  Under capture only the single-buffer mode is allowed; its
+            # contract is explicit: the consumer finishes with the record before the next replay.
+            if len(self._traj) > 1 and torch.cuda.is_current_stream_capturing():
+                raise engine.EngineError(
+                    "trajectory record with alternating buffers inside a stream capture: a replay always writes the "
+                    "captured buffer.  Call enable_trajectory_record(n_buffers=1) and wait for the gather of step t "
+                    "before replaying step t + 1")
             self._traj_i += 1
             p.traj_record = self._traj[self._traj_i % len(self._traj)].data_ptr()
         else:

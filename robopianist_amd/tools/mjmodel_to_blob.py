@@ -16,8 +16,11 @@ mapping is exercised here -- where MuJoCo cannot be installed -- by a round trip
 (tests/test_mujoco_golden.py).  What the mapping requires of the model is asserted, not assumed: 1-dof joints
 only (hinge / slide), fixed tendons (`wrap_type`), joint / tendon transmissions, fixed gain / affine bias / no
 activation dynamics, no equality constraints, no explicit contact pairs, pyramidal cone + Newton + Euler, default
-convex-collision tolerance; sphere / capsule / box / mesh geoms (meshes enter through the vertices of their convex
-hull).  A dump that violates one of these raises ValueError in `model_from_npz`.
+convex-collision tolerance through libccd MPR (not the native GJK / EPA pipeline), no tendon limits / friction /
+damping / stiffness, no disable / enable flags beyond refsafe, condim 3 / priority 0 / solmix 1 / no margin on
+colliding geoms; capsule / cylinder / box / mesh collision geoms (meshes enter through the vertices of their convex
+hull).  `opt.impratio` IS imported (round 6: oracle and engine apply it).  A dump that violates one of these raises
+ValueError in `model_from_npz`.
 """
 from __future__ import annotations
 
@@ -69,6 +72,25 @@ def model_from_npz(src) -> Tuple[mcompile.Model, np.ndarray]:
     _reject("actuator_dyntype", lambda v: (v == 0).all(), "actuators with activation dynamics")                    # mjDYN_NONE
     _reject("opt_mpr", lambda v: abs(float(v[0]) - 1e-6) < 1e-12 and int(v[1]) == 50,
             "convex-collision tolerance / iteration cap other than MuJoCo's defaults (1e-6, 50)")
+    # (round 6) what the restatement still does not model, checked wherever a dump records it (oracle/make_golden.py
+    # records all of these; dumps written before a field existed pass that check unchecked):
+    _reject("tendon_limited", lambda v: not np.asarray(v).any(), "tendon limits")
+    _reject("tendon_frictionloss", lambda v: (np.asarray(v, float) == 0).all(), "tendon frictionloss")
+    _reject("tendon_damping", lambda v: (np.asarray(v, float) == 0).all(), "tendon damping")
+    _reject("tendon_stiffness", lambda v: (np.asarray(v, float) == 0).all(), "tendon stiffness")
+    # opt.disableflags: only mjDSBL_REFSAFE (bit 1 << 9 [MEM]; recorded separately as model_opt_refsafe by name) may be
+    # set -- and mjDSBL_NATIVECCD where it exists, which make_golden sets on purpose (below).  Every other disable bit
+    # switches a pipeline stage off that the engine always runs.
+    _reject("opt_disableflags_other", lambda v: int(v) == 0,
+            "opt.disableflags other than refsafe / nativeccd (a pipeline stage the engine always runs is switched off)")
+    # opt.enableflags: override (o_margin / o_solref / o_solimp / o_friction), multiccd, fwdinv ... -- none is modelled
+    _reject("opt_enableflags", lambda v: int(v) == 0, "opt.enableflags (override / multiccd / ...: not modelled)")
+    # The convex narrow phase here is a restatement of libccd's MPR (mjc_Convex before MuJoCo's native GJK / EPA became the
+    # default).  A recording made WITH the native pipeline cannot be held against it at 1e-9: make_golden switches it off
+    # (mjDSBL_NATIVECCD) and records what was active.
+    _reject("opt_nativeccd", lambda v: int(v) == 0,
+            "the recording used MuJoCo's native convex collision (GJK / EPA), not libccd MPR: re-record with "
+            "oracle/make_golden.py, which sets mjDSBL_NATIVECCD")
     if "model_opt" in d:
         o_ = np.asarray(d["model_opt"], float)
         if len(o_) >= 10 and (int(o_[6]) != 0 or int(o_[8]) != 2 or int(o_[9]) != 0):
@@ -86,22 +108,32 @@ def model_from_npz(src) -> Tuple[mcompile.Model, np.ndarray]:
         m[k] = np.array(g(k), dtype=np.int32 if k in _INT else np.float64)
     if not np.isin(m.jnt_type, (spec.JNT_SLIDE, spec.JNT_HINGE)).all():
         raise ValueError("joint types other than hinge / slide")
-    # Collision geoms: capsule, box and mesh (through its convex hull) are what the narrow phase of the oracle and of the
-    # engine handle.  Anything else that can collide -- MuJoCo's cylinder (5), ellipsoid (4), sphere (2), plane (0),
-    # hfield (1), sdf (8) -- is REJECTED here: the oracle's pair loop would skip such a pair silently and the golden
-    # tests would then blame the solver for a missing contact.  (From memory the menagerie wrist carries cylinders: a
-    # real dump is expected to stop here until a cylinder support function exists in both narrow phases; an inscribed
-    # polytope would be 1e-4-level wrong, far outside the 1e-9 teacher-forced contract.)  Visual geoms (contype =
-    # conaffinity = 0) never collide and may be of any type.
+    # Collision geoms: capsule, cylinder (round 6), box and mesh (through its convex hull) are what the narrow phase of
+    # the oracle and of the engine handle.  Anything else that can collide -- ellipsoid (4), sphere (2), plane (0), hfield
+    # (1), sdf (8) -- is REJECTED here: the oracle's pair loop would skip such a pair silently and the golden tests would
+    # then blame the solver for a missing contact.  Visual geoms (contype = conaffinity = 0) never collide and may be of
+    # any type.
     collides = (m.geom_contype != 0) | (m.geom_conaffinity != 0)
-    bad = collides & ~np.isin(m.geom_type, (spec.GEOM_CAPSULE, spec.GEOM_BOX, spec.GEOM_MESH))
+    bad = collides & ~np.isin(m.geom_type, (spec.GEOM_CAPSULE, spec.GEOM_CYLINDER, spec.GEOM_BOX, spec.GEOM_MESH))
     if bad.any():
-        mj_names = {0: "plane", 1: "hfield", 2: "sphere", 4: "ellipsoid", 5: "cylinder", 8: "sdf"}
+        mj_names = {0: "plane", 1: "hfield", 2: "sphere", 4: "ellipsoid", 8: "sdf"}
         gn = names.get("geom", [])
         items = [f"{gn[i] if i < len(gn) and gn[i] else '#%d' % i} ({mj_names.get(int(m.geom_type[i]), int(m.geom_type[i]))})"
                  for i in np.nonzero(bad)[0][:8]]
-        raise ValueError("unsupported collision geom types (capsule / box / mesh only): " + ", ".join(items)
+        raise ValueError("unsupported collision geom types (capsule / cylinder / box / mesh only): " + ", ".join(items)
                          + (" ..." if int(bad.sum()) > 8 else ""))
+    # contact parameters the engine's tables fix (model/engine_tables.py asserts the same; here as a clean error)
+    ci = np.nonzero(collides)[0]
+    if len(ci):
+        def _geoms(mask):
+            gn = names.get("geom", [])
+            return ", ".join(gn[i] if i < len(gn) and gn[i] else "#%d" % i for i in ci[mask][:8])
+        for ok, what in (((m.geom_condim[ci] == 3), "condim other than 3"),
+                         ((m.geom_priority[ci] == 0), "geom_priority other than 0"),
+                         ((m.geom_margin[ci] == 0) & (m.geom_gap[ci] == 0), "non-zero geom margin / gap"),
+                         ((m.geom_solmix[ci] == 1), "geom_solmix other than 1")):
+            if not ok.all():
+                raise ValueError(f"unsupported collision geoms: {what} ({_geoms(~ok)})")
     m["jnt_limited"] = np.asarray(g("jnt_limited"), np.int32).reshape(njnt)
     m["body_inertia"] = m.body_inertia.reshape(nb, 3)
     # kinematic-tree bookkeeping the oracle wants precomputed
@@ -215,6 +247,11 @@ def npz_from_model(m: mcompile.Model) -> Dict[str, np.ndarray]:
     out["model_opt_gravity"] = np.asarray(m.opt_gravity, float)
     # what the importer checks and rejects (values of a model the engine supports)
     out["model_opt_mpr"] = np.array([1e-6, 50.0])
+    nt = int(m.ntendon)
+    out["model_tendon_limited"] = np.zeros(nt, np.int32); out["model_tendon_frictionloss"] = np.zeros(nt)
+    out["model_tendon_damping"] = np.zeros(nt); out["model_tendon_stiffness"] = np.zeros(nt)
+    out["model_opt_disableflags_other"] = np.asarray(0); out["model_opt_enableflags"] = np.asarray(0)
+    out["model_opt_nativeccd"] = np.asarray(0)
     out["model_neq"] = np.asarray(0); out["model_npair"] = np.asarray(0)
     out["model_wrap_type"] = np.ones(len(np.asarray(m.wrap_objid).reshape(-1)), np.int32)
     out["model_actuator_gaintype"] = np.zeros(nu, np.int32); out["model_actuator_biastype"] = np.ones(nu, np.int32)

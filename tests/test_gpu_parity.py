@@ -213,50 +213,42 @@ def _replay_ctrl(si):
 
 
 def test_replay_fp64_1000_steps(two_hand_scene):
-    """The headline workload itself: scripted Twinkle replay, free running, 1000 mj_steps.
-    The policy was trained on the real hand, so on the stand-in it flails and
-    self-collides (chaotic); the fp64 engine still tracks the oracle within 1e-4."""
-    rel, maxcon = free_running(two_hand_scene, 64, _replay_ctrl(two_hand_scene)[:1000])
-    print("fp64 replay rel err @[1,10,100,300,1000]:", rel[[0, 9, 99, 299, 999]], "max contacts", maxcon)
+    """The headline workload itself with capsule fingertips: scripted Twinkle replay, free running, the whole
+    episode (1580 mj_steps; north_star asks for 1000): the fp64 engine tracks the oracle within 1e-4."""
+    rel, maxcon = free_running(two_hand_scene, 64, _replay_ctrl(two_hand_scene))
+    print("fp64 replay rel err @[1,10,100,300,1000,1580]:", rel[[0, 9, 99, 299, 999, 1579]], "max", rel.max(), "max contacts", maxcon)
     assert maxcon >= 8
     assert rel.max() < 1e-4
 
 
 def test_replay_fp64_1000_steps_hull():
-    """The same replay with the reference's DEFAULT fingertip collider (`primitive_fingertip_collisions=False`: hulls
-    through MPR; /root/reference/robopianist/models/hands/shadow_hand.py:105-107), the configuration bench.py's
-    `value` is quoted on.  This trajectory is more sensitive than the capsule one (the stand-in hand's ring / little
-    finger bounce on each other around step 430), so the free-running engine-vs-oracle figure is judged against its
-    CONTROL: the oracle against itself started qpos0 + 1e-14 N(0, 1) away (oracle.rp_oracle.chaos_control, sixteen
-    seeds).  Asserted (round 5: tightened from "<= 2 x the worst of eight"):
-      (a) while the trajectory is still smooth (300 mj_steps) engine and oracle agree to 1e-8;
-      (b) over 1000 mj_steps the engine's error is at most 3 x the MEDIAN control's (a typical second trajectory, not
-          the luckiest-worst one);
-      (c) the engine leaves the oracle (error above 1e-6) no earlier than the EARLIEST control does: the separation
-          happens at the trajectory's own chaotic event, not at an engine-specific one."""
+    """north_star's statement on the HEADLINE configuration: the same replay with the reference's DEFAULT fingertip
+    collider (`primitive_fingertip_collisions=False`: hulls through MPR; /root/reference/robopianist/models/hands/
+    shadow_hand.py:105-107), the configuration bench.py's `value` is quoted on -- free-running, identical actions, the
+    WHOLE episode (1580 mj_steps), |dq| / max(|q|, 1e-2) < 1e-4.
+    Rounds 3-5 could not assert this: on their stand-in hand (forearm box overlapping the palm, impratio 1) the replay
+    was chaotic -- the oracle started 1e-15 away from itself separated by 3e-3 -- and the test compared the engine with
+    that control instead.  On round 6's stand-in (model/shadow_hand.py) the control stays at 1e-11 and so does the
+    engine; the control is still run and printed, and must itself stay under the bar (otherwise the bar would again be
+    unattainable by ANY second implementation and the assertion below would be luck)."""
     from robopianist_amd.model import scene
     from oracle.rp_oracle import chaos_control
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=False)
-    ctrl = _replay_ctrl(si)[:1000]
+    ctrl = _replay_ctrl(si)
+    assert len(ctrl) == 1580
     rel, maxcon = free_running(si, 64, ctrl)
     from robopianist_amd import engine
     blob = engine.make_blob(si.model, si.key_joint_ids)
-    from oracle.rp_oracle import first_crossing
-    control = chaos_control(si.model, blob, ctrl[::10], nstep=1000, hold=10, seeds=range(16), eps0=1e-14)
+    control = chaos_control(si.model, blob, ctrl[::10], nstep=1580, hold=10, seeds=range(4), eps0=1e-14)
     cerr = sorted(r["max_rel_qpos_error"] for r in control)
-    ccross = sorted(r["first_mj_step_above_1e-06"] for r in control)
-    ecross = first_crossing(np.maximum.accumulate(rel), 1e-6)
-    print("fp64 hull replay rel err @[1,10,100,300,1000]:", rel[[0, 9, 99, 299, 999]], "max", rel.max(), "max contacts", maxcon)
+    print("fp64 hull replay rel err @[1,10,100,300,1000,1580]:", rel[[0, 9, 99, 299, 999, 1579]], "max", rel.max(), "max contacts", maxcon)
     print("control (oracle vs oracle + 1e-14), max rel err:", cerr)
-    print("first mj_step above 1e-6: engine", ecross, "controls", ccross)
     assert maxcon >= 8
+    assert max(cerr) < 1e-6, cerr
+    assert rel.max() < 1e-4, rel.max()
     assert rel[:300].max() < 1e-8
-    cmed = float(np.median(cerr))
-    assert rel.max() <= 3.0 * cmed, (rel.max(), cmed)
-    assert all(c > 0 for c in ccross), ccross   # (every control does separate: the trajectory is chaotic, not the engine)
-    assert ecross == 0 or ecross >= ccross[0], (ecross, ccross)
 
 
 def test_replay_fp32_curve_is_reported(two_hand_scene):
@@ -909,10 +901,16 @@ def test_teacher_forced_fp64_large_hull_colliders():
     assert worst < 1e-9
 
 
-def pile_up(si, nsteps=120, seed=3, lo_dx=0.083, hi_dx=0.098):
+def pile_up(si, nsteps=120, seed=3, lo_dx=0.083, hi_dx=0.098, stable_only=False, stats=None):
     """Teacher-forced steps from hand-IN-hand poses: both forearms shifted towards each other until the hands
     interpenetrate (30 ... 64 contacts, most of them hand-hand, i.e. ~14 Jacobian entries each and one large dense
-    block), fingers at random postures.  Returns (worst rel dv, max contacts, max entries, steps beyond 32 contacts)."""
+    block), fingers at random postures.  Returns (worst rel dv, max contacts, max entries, steps beyond 32 contacts).
+    `stable_only` (scenes with cylinders): a pose is compared only if the ORACLE's own contact distances survive a
+    1e-13 perturbation of qpos.  A cylinder's support point jumps by its whole height when the search direction crosses
+    the plane of its caps [MJ: mjc_support: sign(dir_z) * half height], so the portal refinement of a thin disc deep
+    inside a hull has rounding-decided branches: the oracle started 1e-13 away returns depths up to 4e-5 apart on ~12 %
+    of these poses -- as does the engine.  That is MuJoCo's algorithm, not a difference between implementations.
+    `stats` (dict): filled with the contact counts by geom-type pair and the number of poses skipped as unstable."""
     from robopianist_amd import engine
     from robopianist_amd.model import spec
     m = si.model
@@ -955,6 +953,21 @@ def pile_up(si, nsteps=120, seed=3, lo_dx=0.083, hi_dx=0.098):
                     return True
             return False
         degenerate = axis_in_box()
+        if stable_only:
+            if "orc2" not in locals():
+                from oracle.rp_oracle import Oracle
+                orc2 = Oracle(m, phys.blob)
+            d0 = sorted((int(x[13]), int(x[14]), float(x[0])) for x in orc.contact.reshape(-1, 16))
+            for _ in range(10):   # (a rounding-decided branch goes either way about half of the time)
+                orc2.reset()
+                orc2.qpos[:] = q + 1e-13 * rng.standard_normal(m.nv); orc2.qvel[:] = v; orc2.qacc_warmstart[:] = 0; orc2.ctrl[:] = c
+                orc2.forward()
+                d1 = sorted((int(x[13]), int(x[14]), float(x[0])) for x in orc2.contact.reshape(-1, 16))
+                if len(d0) != len(d1) or any(a[:2] != b[:2] or abs(a[2] - b[2]) > 1e-9 for a, b in zip(d0, d1)):
+                    if stats is not None:
+                        stats["unstable"] = stats.get("unstable", 0) + 1
+                    degenerate = True
+                    break
         phys.reset()   # (clears the sticky warn flags of an iteration that was beyond the capacity)
         phys.set(engine.QPOS, q[None, :]); phys.set(engine.QVEL, v[None, :])
         phys.set(engine.QACC_WARMSTART, w[None, :]); phys.set(engine.CTRL, c[None, :])
@@ -982,6 +995,11 @@ def pile_up(si, nsteps=120, seed=3, lo_dx=0.083, hi_dx=0.098):
             print(f"  pile-up step {it}: contacts {ncon0} -> {orc.ncon}, entries <= {ne0}, solver_iter {orc.solver_iter} / "
                   f"{int(phys.get(engine.SOLVER_ITER)[0]) & 255}, rel dv {dv / max(np.abs(orc.qvel - v0).max(), 1e-9):.2e}")
         maxcon = max(maxcon, ncon0, orc.ncon); maxent = max(maxent, ne0, ne); beyond += max(ncon0, orc.ncon) > 32
+        if stats is not None:
+            stats["compared"] = stats.get("compared", 0) + 1
+            for x in con:
+                k = (int(m.geom_type[int(x[13])]), int(m.geom_type[int(x[14])]))
+                stats[k] = stats.get(k, 0) + 1
     return worst, maxcon, maxent, beyond
 
 
@@ -1096,6 +1114,76 @@ def test_teacher_forced_fp64_palm_flat_on_the_keys(two_hand_scene):
     print(f"palm flat on the keys: worst rel dv {worst:.2e}, max contacts {maxcon}, {pairs} box-box pairs with > 3 points (most: {most})")
     assert pairs >= 50 and most >= 5
     assert worst < 1e-9
+
+
+@pytest.mark.parametrize("impratio", [1.0, 10.0])
+def test_teacher_forced_fp64_impratio(impratio):
+    """opt.impratio (round 6; VERDICT round 5, missing 2): the reference's hand comes in through mjcf.from_path with its
+    `<option impratio="10"/>` (models/hands/shadow_hand.py:122); oracle and engine regularise the friction
+    dimensions by R / impratio [MJ: mj_makeImpedance].  Teacher-forced along the replay at MuJoCo's default 1 and at
+    the hand's 10 (the stand-in's default since round 6)."""
+    from robopianist_amd.model import scene
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=True, impratio=impratio)
+    assert si.model.opt_impratio == impratio
+    worst, maxcon = teacher_forced(si, 64, _replay_ctrl(si)[500:700])
+    print(f"teacher-forced, impratio {impratio}: worst rel dv {worst:.2e}, max contacts {maxcon}")
+    assert maxcon >= 6 and worst < 1e-9, (worst, maxcon)
+
+
+def test_impratio_changes_the_step_and_both_sides_follow():
+    """... and the setting is live: from the same contact-rich state the step at impratio 10 differs from the step at 1
+    by far more than the parity bar, in the engine and in the oracle alike."""
+    from robopianist_amd import engine
+    from robopianist_amd.model import scene
+    out = {}
+    for ir in (1.0, 10.0):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=True, impratio=ir)
+        phys, orc = make_pair(si, 64)
+        for c in _replay_ctrl(si)[:560]:
+            orc.ctrl[:] = c; orc.step(1)
+            if ir == 10.0 and orc.ncon >= 8:
+                break
+        if ir == 10.0:
+            state = (orc.qpos.copy(), orc.qvel.copy(), orc.qacc_warmstart.copy(), c.copy())
+        out[ir] = (phys, orc)
+    for ir, (phys, orc) in out.items():
+        q, v, w, c = state
+        orc.qpos[:] = q; orc.qvel[:] = v; orc.qacc_warmstart[:] = w; orc.ctrl[:] = c
+        orc.step1(); orc.step(1)
+        phys.set(engine.QPOS, q[None, :]); phys.set(engine.QVEL, v[None, :]); phys.set(engine.QACC_WARMSTART, w[None, :])
+        phys.set(engine.CTRL, c[None, :]); phys.step(1)
+        assert np.abs(phys.qvel[0] - orc.qvel).max() < 1e-9 * max(np.abs(orc.qvel - v).max(), 1e-9) + 1e-12
+    d = np.abs(out[1.0][1].qvel - out[10.0][1].qvel).max()
+    assert d > 1e-4, d
+
+
+@pytest.mark.parametrize("fingertips", ["capsule", "hull"])
+def test_teacher_forced_fp64_cylinder_colliders(fingertips):
+    """mjGEOM_CYLINDER colliders (round 6; VERDICT round 5, missing 3): the reference retypes only the fingertip meshes
+    (models/hands/shadow_hand.py:144-152); the hand's wrist / knuckle colliders keep their XML type, cylinders.  Both
+    narrow phases now carry the cylinder support function [MJ: mjc_support] and send every cylinder pair through the
+    portal refinement in geom-type order: (capsule, cylinder), (cylinder, box / key), (cylinder, hull).  Hands pushed
+    into each other with the stand-in's wrist / knuckle colliders as cylinders and impratio = 10; poses whose cylinder
+    pairs are rounding-decided in the ORACLE ITSELF are skipped (pile_up: stable_only)."""
+    from robopianist_amd.model import scene, spec
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=fingertips == "capsule",
+                               cylinder_colliders=True, impratio=10.0)
+    assert int((si.model.geom_type == spec.GEOM_CYLINDER).sum()) == 10
+    st = {}
+    lo, hi = (0.07, 0.09) if fingertips == "capsule" else (0.06, 0.085)
+    worst, maxcon, maxent, beyond = pile_up(si, 80, lo_dx=lo, hi_dx=hi, stable_only=True, stats=st)
+    cyl = sum(v for k, v in st.items() if isinstance(k, tuple) and 5 in k)
+    print(f"cylinder colliders, {fingertips} fingertips: worst rel dv {worst:.2e}, max contacts {maxcon}, "
+          f"{st.get('compared', 0)} poses compared, {st.get('unstable', 0)} skipped as unstable in the oracle itself, "
+          f"contacts by geom-type pair { {k: v for k, v in st.items() if isinstance(k, tuple)} }")
+    assert st.get("compared", 0) >= 30 and cyl >= 12, st
+    assert worst < 1e-9, worst
 
 
 def test_teacher_forced_fp64_hull_fingertips():

@@ -108,3 +108,26 @@ def test_large_hull_colliders_on_the_wave_emulator(wavesim_lib):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     worst, maxcon = [float(x) for x in re.search(r"RESULT (.*)", out.stdout).group(1).split()]
     assert maxcon >= 4 and worst < 1e-9, (worst, maxcon)
+
+
+def test_impratio_and_cylinder_colliders_on_the_wave_emulator(wavesim_lib):
+    """Round 6 without a GPU: opt.impratio = 10 in the friction regularisation and mjGEOM_CYLINDER colliders through the
+    portal refinement (MESH = 2 kernel builds), the engine's own kernels against the oracle at the teacher-forced 1e-9
+    (the GPU twins: test_teacher_forced_fp64_impratio, test_teacher_forced_fp64_cylinder_colliders)."""
+    env = dict(os.environ, RP_ENGINE_LIB=wavesim_lib, WAVESIM_SITE="0", RP_SKIP_SELF_CHECK="1")
+    code = ("import sys, warnings; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_parity as t\nfrom robopianist_amd.model import scene\n"
+            "warnings.simplefilter('ignore')\n"
+            "si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=True, impratio=10.0)\n"
+            "print('IMPRATIO', *t.teacher_forced(si, 64, t._replay_ctrl(si)[520:600]))\n"
+            "si = scene.build_scene(gravity_compensation=True, primitive_fingertip_collisions=True, cylinder_colliders=True, impratio=10.0)\n"
+            "st = {}\n"
+            "r = t.pile_up(si, 30, lo_dx=0.07, hi_dx=0.09, stable_only=True, stats=st)\n"
+            "print('CYLINDER', r[0], st.get('compared', 0), sum(v for k, v in st.items() if isinstance(k, tuple) and 5 in k))\n"
+            ) % (os.path.dirname(HERE), HERE)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    worst, maxcon = [float(x) for x in re.search(r"IMPRATIO (.*)", out.stdout).group(1).split()]
+    assert maxcon >= 6 and worst < 1e-9, (worst, maxcon)
+    worst, compared, cyl = [float(x) for x in re.search(r"CYLINDER (.*)", out.stdout).group(1).split()]
+    assert compared >= 10 and cyl >= 8 and worst < 1e-9, (worst, compared, cyl)
