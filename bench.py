@@ -181,6 +181,28 @@ def spawn_ranks(args, argv):
     return subprocess.call(cmd, env=env)
 
 
+_REAL_STDOUT_FD = None
+
+
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries print there too (RCCL writes a version banner to the C-level
+    stdout when a communicator is created, flushed at exit, i.e. AFTER Python's own line): the process keeps a private
+    duplicate of the real stdout for the JSON line and points file descriptor 1 at stderr for everything else."""
+    global _REAL_STDOUT_FD
+    if _REAL_STDOUT_FD is None:
+        sys.stdout.flush()
+        _REAL_STDOUT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit_json_line(line):
+    sys.stdout.flush()
+    if _REAL_STDOUT_FD is None:
+        print(line, flush=True)
+    else:
+        os.write(_REAL_STDOUT_FD, (line + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,6 +219,7 @@ def main():
     ap.add_argument("--engine-only", action="store_true", help="config 2: time rp_step alone (no obs/reward epilogue)")
     ap.add_argument("--dist-backend", default="nccl", help="debug: 'gloo' lets several ranks share one GPU")
     ap.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0")
+    ap.add_argument("--aux-rccl", type=int, default=1, help="N = 1: run the gather's collective through a one-rank RCCL group (aux)")
     ap.add_argument("--host-io", type=int, default=1,
                     help="N=1, config 2: also time the loop with host-resident actions/TimeSteps (aux.host_io)")
     ap.add_argument("--graph", type=int, default=0, help="replay env.step from a captured hipGraph")
@@ -218,6 +241,7 @@ def main():
     in_torchrun = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if args.gpus > 1 and not in_torchrun:
         sys.exit(spawn_ranks(args, sys.argv[1:]))
+    _claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1")) if in_torchrun else 1
@@ -585,14 +609,62 @@ def main():
                 "warn_flags_or": r32["warn"],
                 "note": "same workload on the fp32 build; meets 1e-4 on smooth key-press scenarios only"}
             phys = r32["phys"]
+        if args.aux_rccl and world == 1 and dist is None:
+            out.setdefault("aux", {})["rccl_single_rank"] = rccl_selftest(E, int(m.nv), args.precision, dev)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out.update(cpu_leg(args, m, phys, base_key_ids, cfg))
             if "standin_contacts" in out:   # (the judge asked for the shares in `config`)
                 out["config"]["standin_contacts"] = out.pop("standin_contacts")
-        print(json.dumps(out))
+        _emit_json_line(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def rccl_selftest(E, nv, precision, dev):
+    """N = 1 only, after the timed region: a ONE-rank nccl (= RCCL) process group on this GPU runs the very collective of
+    the N > 1 gather (all_gather_into_tensor of the trajectory record, distributed.gather_trajectories) -- RCCL refuses
+    several ranks per device, so this is what a one-GPU box can execute of the multi-GPU path: library load, communicator,
+    the collective on the device.  Never part of `value`."""
+    import socket
+    import torch
+    import torch.distributed as dist_
+    from robopianist_amd import distributed as rpd
+    try:
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(dev))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        d = torch.device("cuda", dev)
+        dist_.init_process_group("nccl", device_id=d)
+        dt = torch.float64 if precision == 64 else torch.float32
+        width = nv + 3 + (2 if precision == 64 else 3)
+        rec = torch.rand((E, width), dtype=dt, device=d)
+        outb = torch.empty_like(rec)
+        for _ in range(3):
+            rpd.gather_trajectories(rec, out=outb, force_collective=True)
+        torch.cuda.synchronize(d)
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        n = 20
+        for _ in range(n):
+            rpd.gather_trajectories(rec, out=outb, force_collective=True)
+        ev[1].record(); torch.cuda.synchronize(d)
+        ok = bool(torch.equal(outb, rec))
+        ms = ev[0].elapsed_time(ev[1]) / n
+        dist_.barrier()
+        dist_.destroy_process_group()
+        return {"ok": ok, "backend": "nccl (RCCL)", "world_size": 1, "record_bytes": int(rec.numel() * rec.element_size()),
+                "all_gather_into_tensor_ms": ms,
+                "note": "one-rank RCCL group on this GPU running the N > 1 gather's collective on the trajectory record "
+                        "(RCCL refuses several ranks per device: this is the part of the multi-GPU path a one-GPU box can "
+                        "execute); not part of `value`"}
+    except Exception as e:   # (reported, never fatal: the headline line must not depend on it)
+        try:
+            if dist_.is_initialized():
+                dist_.destroy_process_group()
+        except Exception:
+            pass
+        return {"ok": False, "error": repr(e)[:300]}
 
 
 def cpu_leg(args, m, phys, key_ids, cfg):

@@ -205,15 +205,10 @@ struct EngineBase {
   int sv_envs[kRing] = {};            // envs the probed solver launch of that slot covered (a slice or the batch)
   double last_solver_envs = 0;
   int last_solver_kind = 0;
-  // schedule of an rp_step, automatic choice (n_slices == 0) among: 1 = one launch per stage, 2 = the same as
-  // two slices on two streams (>= 1024 envs), 3 = fused substeps (where they apply and are left on "auto").
-  // Steps 16 .. of every 128 run the candidates in the order a b c c b a a b c c b a (a linear drift of
-  // the workload cancels); the one with the lowest mean step time in that block (event ring; 1 %
-  // hysteresis) runs the rest.  Measured, config 2 with 4096 envs at staggered episode times: two
-  // slices; the same in lockstep, or with <= 2048 envs: fused.
-  int ev_trial[kRing] = {};           // 0 = not a trial step, else the schedule it ran with
-  double trial_ms[5] = {0, 0, 0, 0, 0}, trial_n[5] = {0, 0, 0, 0, 0};
-  int auto_mode = 1; unsigned auto_pos = 0, auto_period = 128;
+  // schedule of the last rp_step when the engine chooses (n_slices == 0): see step().  Rule-based since round 6.
+  int auto_mode = 1;
+  bool many_heavy = false;   // the lists of envs outside the light class have been long lately (hysteresis)
+  int last_nsl = 1;          // slices of the last rp_step
   void harvest(int i, bool wait) {
     if (!ev_pending[i]) return;
     if (wait) hipEventSynchronize(ev1[i]);
@@ -221,9 +216,7 @@ struct EngineBase {
     float ms = 0;
     if (hipEventElapsedTime(&ms, ev0[i], ev1[i]) == hipSuccess) {
       kernel_ms += ms; kernel_launches++;
-      if (ev_trial[i]) { trial_ms[ev_trial[i]] += ms; trial_n[ev_trial[i]]++; }
     }
-    ev_trial[i] = 0;
     if (sv_envs[i] > 0 && hipEventElapsedTime(&ms, sv0[i], sv1[i]) == hipSuccess) {
       const int kd = sv_kind[i] & 1;
       solver_ms_k[kd] += ms; solver_launches_k[kd]++; solver_envs_k[kd] += sv_envs[i];
@@ -282,7 +275,6 @@ struct Engine : EngineBase {
   bool split_capable = false;
   int split_mode = 0;
   bool split_now = false;   // (this rp_step)
-  const int narrow_grid_env = getenv("RP_NARROW_GRID") ? atoi(getenv("RP_NARROW_GRID")) : 0;
   int split_position(int on) override {
     if (on && !split_capable) return fail("rp_set_split_position_stage: the split stage exists for the fp64 default-depth builds only");
     split_mode = on < 0 ? 2 : (on > 2 ? 2 : on);
@@ -447,6 +439,7 @@ struct Engine : EngineBase {
     PI(geom_pairmask, "eng_geom_pairmask"); PI(geom_iskeycap, "eng_geom_iskeycap");
     PF(geom_size, "eng_geom_size"); PF(geom_pos, "eng_geom_pos"); PF(geom_mat, "eng_geom_mat");
     PF(geom_rbound, "eng_geom_rbound"); PF(geom_invw, "eng_geom_invw"); PF(geom_cparam, "eng_geom_cparam");
+    PF(geom_bcap, "eng_geom_bcap");
     PI(act_kind, "eng_act_kind"); PI(act_lane, "eng_act_lane"); PI(act_ctrllimited, "eng_act_ctrllimited");
     PI(act_forcelimited, "eng_act_forcelimited");
     PF(act_coef, "eng_act_coef"); PF(act_gain, "eng_act_gain"); PF(act_bias, "eng_act_bias");
@@ -595,14 +588,17 @@ struct Engine : EngineBase {
   // in rounds: slower for a step, never wrong).  Measured with the 55 KB stage, config 2 hull: fixed 128: 618 k
   // env-steps/s, following the list: 651 k (the 40 KB stage of round 3 at 128: 650 k).
   int *d_heavy_peak = nullptr, *h_heavy_peak = nullptr;
-  double heavy_est[kMaxSlices] = {64, 64, 64, 64};
+  double heavy_est[kMaxSlices] = {8, 8, 8, 8};
   int heavy_grid_for(int sl, int cnt) {
     int g = kHeavyGrid;
     if (!heavy_grid_fixed && h_heavy_peak) {
       const int seen = *(volatile int*)&h_heavy_peak[sl];
       if (seen >= 0) { heavy_est[sl] = seen > heavy_est[sl] ? seen : 0.9 * heavy_est[sl] + 0.1 * seen; *(volatile int*)&h_heavy_peak[sl] = -1; }
-      g = (int)(2.0 * heavy_est[sl]) + 8;   // (config 3, 4096 envs: fixed grids of 24 / 48 / 128: 409 / 436 / 445 k env-steps/s)
-      g = g < 8 ? 8 : (g > kHeavyGrid ? kHeavyGrid : g);
+      // (config 3, 4096 envs: fixed grids of 24 / 48 / 128: 409 / 436 / 445 k env-steps/s.  Round 6: the floor is 2
+      // workgroups, not 8 -- each needs a whole idle SIMD, and on the replay, whose lists are empty most of the time, a
+      // grid of one measured +0.7 %: 636.6 against 632.2 k, two runs each inside one call)
+      g = (int)(2.0 * heavy_est[sl]) + 2;
+      g = g < 2 ? 2 : (g > kHeavyGrid ? kHeavyGrid : g);
     }
     return cnt < g ? cnt : g;
   }
@@ -614,7 +610,6 @@ struct Engine : EngineBase {
     const bool capable = lean && !deep && !graph && sizeof(T) == 8;
     return !capable ? 0 : (fused == 1 ? 1 : (fused == 2 && n_slices == 0 ? (auto_mode == 3 ? 1 : 2) : 0));
   }
-  bool split_heavy_pos = !(getenv("RP_SPLIT_HEAVY_POS") && getenv("RP_SPLIT_HEAVY_POS")[0] == '0');   // (experiment switch)
   // MEASUREMENT-ONLY switches (they skip or repeat work: wrong physics / wasted time).  Compiled in only with
   // -DRP_EXPERIMENTS, and loud when set: a stray environment variable must not silently change a production step.
 #ifdef RP_EXPERIMENTS
@@ -629,25 +624,15 @@ struct Engine : EngineBase {
 #else
   static constexpr bool x_no_heavy = false, x_order_twice = false;
 #endif
-  // (experiment, off: without a companion stream, the lean launch in FRONT of the full-capacity one.  Measured on config
-  // 2, three-slice split schedule, one box, two runs each: 660 k against 668 k env-steps/s with the full-capacity launch
-  // first; config 3: 429 against 442 k)
-  bool heavy_after_lean = getenv("RP_HEAVY_AFTER") && getenv("RP_HEAVY_AFTER")[0] == '1';
-  bool companion = !(getenv("RP_COMPANION") && getenv("RP_COMPANION")[0] == '0');   // (experiment: the full-capacity launch on the slice's own stream)
-  // (Experiment, RP_HEAVY_PRIORITY=1: the companion stream at the highest priority the device offers.  The idea: the
-  // full-capacity launch and the lean one become ready together, and whichever is dispatched first takes the machine
-  // -- 2048 lean workgroups fill every SIMD, and a full-capacity workgroup, a whole SIMD's registers, then waits for
-  // both waves of some SIMD to retire, so the heavy envs START when the lean launch ends.  Measured: no effect on the
-  // dispatch order -- configs 3 / 4 447 / 580 k env-steps/s either way, config 2 -0.6 %.  Off.)
-  // (the stream itself: pooled_stream(device, 4 + slice, priority))
+  // (Measured and not kept, rounds 4-5: the lean launch in FRONT of the full-capacity one where there is no companion stream
+  // (660 against 668 k env-steps/s); a high-priority companion stream (no effect on the dispatch order); the full-capacity
+  // launch on the slice's own stream with two slices (-2.5 %).)
   // Threads per residue class of rp_order_kernel: two envs per thread.  (A 512-thread workgroup needs a whole
   // idle CU -- with both stage kernels at two waves per SIMD it waited ~60 us for one on every substep of a
   // 2048-env slice -- while a single wave takes too long over 512 envs.  Measured: 2048-env slices 64 / 128 /
   // 256 threads: 681 / 678 / 647 k env-steps/s; 4096-env slices 64 / 128 / 256 / 512: 540 / 547 / 561 / 562 k.)
-  int order_threads_env = getenv("RP_ORDER_THREADS") ? atoi(getenv("RP_ORDER_THREADS")) : 0;
   int order_threads_for(int cnt) const {
     // (the kernel's scan needs a full first wave and its launch bound is 512: multiples of 64 in 64 .. 512)
-    if (order_threads_env > 0) { const int t = (order_threads_env + 63) / 64 * 64; return t > 512 ? 512 : t; }
     const int t = ((cnt / 16 + 63) / 64) * 64;
     return t < 64 ? 64 : (t > 512 ? 512 : t);
   }
@@ -845,53 +830,30 @@ struct Engine : EngineBase {
     bool fused_now = fused == 1 && fused_capable && mode == 0;
     bool sched4 = false;
     if (n_slices == 0 && mode == 0 && !fused_now) {
-      int cand[4], nc = 0;
-      cand[nc++] = 1;
-      if (nenv >= 1024 && !capturing) cand[nc++] = 2;
-      if (fused == 2 && fused_capable) cand[nc++] = 3;
-      // 4: three slices, the position stage split (front part / pooled narrow phase / back part), every launch of a
-      // slice on its own stream (three streams: within the device's four hardware queues)
-      if (split_mode == 2 && split_capable && nenv >= 3072 && !capturing) cand[nc++] = 4;
-      // (a schedule that is no candidate right now -- two slices inside a stream capture -- is replaced for THIS
-      // step only: the measured choice survives the capture)
-      bool have = false;
-      for (int j = 0; j < nc; j++) have = have || cand[j] == auto_mode;
-      int sched = have ? auto_mode : cand[0];
-      if (!have && !capturing) auto_mode = cand[0];
-      if (nc > 1 && !capturing) {
-        // (the trial block costs: four candidates x four steps, three of them in slower schedules -- 1.8 % of a run at
-        // one block per 128 steps.  The period doubles, up to 1024 steps, every time a block confirms the schedule in
-        // use, and falls back to 128 when one overturns it: a steady workload pays 0.2 %, a drifting one is re-examined
-        // as before.)
-        if (auto_pos >= auto_period) auto_pos = 0;
-        const unsigned pos = auto_pos++;
-        if (pos >= 16u && pos < 16u + 4u * nc) {   // (short runs -- tests, smoke -- never reach the trials)
-          const int idx = (int)((pos - 16u) % (2u * nc));
-          sched = cand[idx < nc ? idx : 2 * nc - 1 - idx];
-          ev_trial[slot] = sched;
-        } else if (pos == 64) {  // the trial steps finished long ago: read them without waiting
-          for (int i = 0; i < kRing; i++) if (ev_trial[i]) harvest(i, false);
-          bool all = true;
-          for (int j = 0; j < nc; j++) all = all && trial_n[cand[j]] >= 3;
-          if (all) {
-            int best = auto_mode;
-            double mb = trial_ms[auto_mode] / trial_n[auto_mode];
-            for (int j = 0; j < nc; j++) {
-              const double m = trial_ms[cand[j]] / trial_n[cand[j]];
-              if (m < 0.99 * trial_ms[auto_mode] / trial_n[auto_mode] && m < mb) { best = cand[j]; mb = m; }
-            }
-            if (best == auto_mode) auto_period = auto_period < 1024u ? auto_period * 2u : 1024u;
-            else auto_period = 128u;
-            auto_mode = best;
-            if (getenv("RP_SCHED_DEBUG")) {
-              fprintf(stderr, "rp schedule choice:");
-              for (int j = 0; j < nc; j++) fprintf(stderr, " mode %d %.3f ms (n %.1f)", cand[j], trial_ms[cand[j]] / trial_n[cand[j]], trial_n[cand[j]]);
-              fprintf(stderr, " -> %d\n", auto_mode);
-            }
-          }
-          for (int k = 1; k <= 4; k++) { trial_ms[k] = 0; trial_n[k] = 0; }   // (the latest block decides: the workload drifts)
-        }
-      }
+      // The schedule of an rp_step, chosen by RULE (round 6; rounds 3-5 ran timing trials of up to four candidates on
+      // some steps of every 128 .. 1024: 1 % of a run, and a choice that differed from run to run).  All schedules give
+      // bit-identical results (tests/test_gpu_parity.py), so the rule only has to be good, not exact:
+      //   1 = one launch per stage        2 = the same as two slices on two streams, full-capacity launches on companion streams
+      //   3 = fused substeps (one launch takes a light env through all substeps; the rest in a clean-up launch)
+      //   4 = three slices, the position stage split (front part / pooled narrow phase / back part), no companion streams
+      // Measured on MI355X: batches under 3072 envs fill at most one round and a half of the chip's 2048 wave
+      // slots -- every launch boundary there is a tail, and the fused schedule (no boundaries) wins by 6-16 %; from 3072
+      // envs on, three slices with the split stage win on the replay (lists of envs outside the light class short or
+      // empty), two slices with companion streams when those lists are long (random policies: the full-capacity
+      // launches then need the chip to themselves beside the lean ones); 6144 envs and more are three rounds per launch
+      // and need no slices at all.  `many_heavy` follows the list lengths the device reports one step late (with
+      // hysteresis), never a timer.
+      double hl = 0;
+      for (int i = 0; i < last_nsl && i < kMaxSlices; i++) hl = heavy_est[i] > hl ? heavy_est[i] : hl;   // (the slices the last step used: the others' estimates are stale)
+      many_heavy = many_heavy ? hl >= 2.0 : hl >= 4.0;
+      const bool fused_ok = fused == 2 && fused_capable;
+      const bool split_ok = split_mode == 2 && split_capable && !capturing;
+      int sched;
+      if (capturing) sched = fused_ok ? 3 : 1;
+      else if (nenv < 3072) sched = (fused_ok && !many_heavy) ? 3 : (nenv >= 1024 ? 2 : 1);   // (config 5, 2048 envs, long lists: fused 245 k, two slices 286 k)
+      else if (split_ok && !many_heavy) sched = 4;
+      else sched = nenv >= 6144 ? 1 : 2;
+      if (!capturing) auto_mode = sched;
       fused_now = sched == 3;
       want = sched == 2 ? 2 : (sched == 4 ? 3 : 1);
       sched4 = sched == 4;
@@ -903,7 +865,8 @@ struct Engine : EngineBase {
     // front of the lean one on the slice's own stream.  ADVICE round 5: only the engine's own three-slice schedule turned
     // them off; a forced rp_set_stream_slices(e, 3 | 4) queued slice 2's whole chain behind slice 0's heavy solves.)
     if (split_now && ((capturing && !B.frames) || !ensure_split_buffers())) split_now = false;   // (no allocation inside a stream capture)
-    const bool companion_now = companion && nsl <= 2;
+    if (mode == 0 && !capturing) last_nsl = nsl;
+    const bool companion_now = nsl <= 2;
     if (nsl > 1 && !ev_fork && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev_fork = nullptr; nsl = 1; }
     for (int i = 1; i < nsl; i++) {
       if (xstream[i]) continue;
@@ -940,7 +903,7 @@ struct Engine : EngineBase {
         if constexpr (sizeof(T) == 8) {
           RpStage<T> Bs = B;
           Bs.tcount_off = sl * RPK_NSTRIPE * RPK_NTYPE_PAD;
-          int ng = narrow_grid_env > 0 ? narrow_grid_env : cnt / 2;
+          int ng = cnt / 2;
           ng = ng < 64 ? 64 : (ng > 2048 ? 2048 : ng);
 #define RP_SPLIT_LAUNCH(MESH_)                                                                                                     \
           {                                                                                                                        \
@@ -978,7 +941,7 @@ struct Engine : EngineBase {
           sf.heavy_list = d_heavy + base; sf.heavy_cnt = d_heavy_cnt + 2 * sl; sf.heavy_done = d_heavy_cnt + 2 * sl + 1;
           sf.heavy_peak = capturing ? nullptr : d_heavy_peak + sl;
           if (sensors_on) { sf.qpos_prev = d_qpos_prev; sf.qvel_prev = d_qvel_prev; }
-          const bool probe = timeit && sl == 0 && !ev_trial[slot];   // (probes: the schedule in use only)
+          const bool probe = timeit && sl == 0;
           if (probe) { HIP_OK(hipEventRecord(sv0[slot], st)); sv_envs[slot] = cnt * nsub; sv_kind[slot] = 1; }
           const int cgrid = capturing ? (cnt < kHeavyGrid ? cnt : kHeavyGrid) : heavy_grid_for(sl, cnt);
           if (mesh) {
@@ -1009,7 +972,7 @@ struct Engine : EngineBase {
       int hgrid_step = 0;   // (the full-capacity stage's grid: one choice per step and slice)
       bool split_step = false;
       for (int k = 0; k < nsub; k++) {
-        const bool probe = timeit && sl == 0 && k == (int)(step_calls % (unsigned)nsub) && !ev_trial[slot];
+        const bool probe = timeit && sl == 0 && k == (int)(step_calls % (unsigned)nsub);
         const bool sense = sensors_on && k == nsub - 1;
         // cost-ordered launch: heaviest envs first, from the hand-over the position stage just wrote
         // (the same pass compacts the envs outside the light class for the full-capacity solver stage)
@@ -1030,7 +993,7 @@ struct Engine : EngineBase {
         // the light ones) -- side by side: the full-capacity launch goes to the slice's companion stream
         hipStream_t hs = st;
         if (lean && !capturing && companion_now) {
-          if (!hstream[sl]) hstream[sl] = pooled_stream(device, 4 + sl, getenv("RP_HEAVY_PRIORITY") && getenv("RP_HEAVY_PRIORITY")[0] == '1');
+          if (!hstream[sl]) hstream[sl] = pooled_stream(device, 4 + sl, false);
           if (hstream[sl] && !ev_hfork[sl] && (hipEventCreateWithFlags(&ev_hfork[sl], hipEventDisableTiming) != hipSuccess ||
                                                hipEventCreateWithFlags(&ev_hjoin[sl], hipEventDisableTiming) != hipSuccess)) {
             (void)hipGetLastError(); hstream[sl] = nullptr;
@@ -1049,14 +1012,11 @@ struct Engine : EngineBase {
           // (the split pays when the list is long: config 3 446 -> 455 k; on a batch whose lists are empty the extra
           // launch and the later join cost 1-4 %: config 2 657 -> 632 ... 651 k -- so it follows the same lagged estimate)
           hgrid = capturing ? (cnt < kHeavyGrid ? cnt : kHeavyGrid) : (k == 0 ? (hgrid_step = heavy_grid_for(sl, cnt)) : hgrid_step);
-          split_step = split_heavy_pos && hs != st && !deep && !graph && sizeof(T) == 8 && heavy_est[sl] >= 4.0;
+          split_step = hs != st && !deep && !graph && sizeof(T) == 8 && heavy_est[sl] >= 4.0;
           sh.heavy_keep = (split_step && !sense) ? 1 : 0;
         }
         // (RP_X_NO_HEAVY=1: MEASUREMENT ONLY -- the full-capacity launch is suppressed, envs outside the light class are
         // not stepped at all: what the launch costs a batch whose lists are empty)
-        // (RP_HEAVY_AFTER=1, experiment: without a companion stream the lean launch first)
-        const bool heavy_after = heavy_after_lean && hs == st && lean && listed;
-        if (heavy_after) hipLaunchKernelGGL((rp_lean_solver_kernel<T>), dim3(cnt), dim3(64), 0, st, M, ss, B);
         if (x_no_heavy && listed) { /* nothing */ }
         else if (deep) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 0, RPK_MAXD_DEEP>), dim3(hgrid), dim3(64), 0, hs, M, sh, B, k, nsub);
         else if (trunk4) hipLaunchKernelGGL((rp_stage_kernel<T, 1, 4>), dim3(hgrid), dim3(64), 0, hs, M, sh, B, k, nsub);
@@ -1066,7 +1026,7 @@ struct Engine : EngineBase {
         // (config 3: 0.27 ms of every 0.81 ms substep); the streams join after it, in front of the next order pass
         const bool split_pos = split_step && listed && !sense;
         if (hs != st && !split_pos) HIP_OK(hipEventRecord(ev_hjoin[sl], hs));
-        if (lean && !heavy_after) hipLaunchKernelGGL((rp_lean_solver_kernel<T>), dim3(cnt), dim3(64), 0, st, M, ss, B);
+        if (lean) hipLaunchKernelGGL((rp_lean_solver_kernel<T>), dim3(cnt), dim3(64), 0, st, M, ss, B);
         if (hs != st && !split_pos) HIP_OK(hipStreamWaitEvent(st, ev_hjoin[sl], 0));
         if (probe) HIP_OK(hipEventRecord(sv1[slot], st));
         if (sense) {

@@ -1486,10 +1486,14 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       const T* gm = M.geom_mat() + 9 * lane;
       T az[3] = {gm[2], gm[5], gm[8]};
       if (gl >= 0) { T t[3]; mat_vec(t, sm.xmat[gl], az); az[0] = t[0]; az[1] = t[1]; az[2] = t[2]; }
-      const bool cap = M.geom_type()[lane] == GEOM_CAPSULE_;
+      // (round 6) ... for EVERY geom: its bounding capsule about the geom's z axis (model/engine_tables.py: a capsule's own
+      // half length and radius; the tightest capsule around a hull's vertices / a cylinder; a box keeps (0, bounding
+      // radius), its culls are the separating-axis tests below).  Until now a hull entered the segment test as its bounding
+      // SPHERE, and a fingertip hull next to the neighbouring finger's capsule passed it most of the time: 13 of the 17
+      // hull candidates per env and mj_step on the replay, each of them two or three trips of the portal refinement.
       sm.gax[lane][0] = (float)az[0]; sm.gax[lane][1] = (float)az[1]; sm.gax[lane][2] = (float)az[2];
-      sm.gax[lane][3] = cap ? (float)M.geom_size()[3 * lane + 1] : 0.f;
-      sm.grr[lane] = cap ? (float)M.geom_size()[3 * lane] : (float)M.geom_rbound()[lane];
+      sm.gax[lane][3] = (float)M.geom_bcap()[2 * lane];
+      sm.grr[lane] = (float)M.geom_bcap()[2 * lane + 1];
     }
     // geoms are sorted capsules first: box b is geom ncap + b; `boxmask`: the geoms that are boxes (not hulls)
     const unsigned long long boxmask = __ballot(lane < M.ngeom && M.geom_type()[lane < M.ngeom ? lane : 0] == GEOM_BOX_);

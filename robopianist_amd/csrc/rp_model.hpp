@@ -112,7 +112,7 @@
   X(geom_rbound,      RPK_WAVE,    1) X(geom_invw,       RPK_WAVE,    1) X(geom_cparam,    RPK_WAVE,  8) \
   X(act_coef,         RPK_MAXACT,  2) X(act_gain,        RPK_MAXACT,  1) X(act_bias,       RPK_MAXACT, 3) \
   X(act_ctrlrange,    RPK_MAXACT,  2) X(act_forcerange,  RPK_MAXACT,  2) X(site_pos,       RPK_WAVE,  3) \
-  X(site_touch_radius, RPK_WAVE,   1) X(mesh_vert, RPK_MAXMESHV, 3)
+  X(site_touch_radius, RPK_WAVE,   1) X(mesh_vert, RPK_MAXMESHV, 3) X(geom_bcap, RPK_WAVE, 2)
 #define RPK_ITABLES(X) \
   X(lane_topo,    RPK_NL_DEEP, 16) \
   X(link_parent,  RPK_NL_DEEP, 1) X(link_depth,   RPK_NL_DEEP, 1) X(link_tree,    RPK_NL_DEEP, 1) X(link_jtype,  RPK_NL_DEEP, 1) \

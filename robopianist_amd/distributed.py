@@ -73,12 +73,14 @@ def unpack_key_activation(record: torch.Tensor, nv: int, n_keys: int = 88) -> to
     return bits[:, :n_keys].bool()
 
 
-def gather_trajectories(local: torch.Tensor, async_op: bool = False, out: torch.Tensor | None = None):
+def gather_trajectories(local: torch.Tensor, async_op: bool = False, out: torch.Tensor | None = None,
+                        force_collective: bool = False):
     """All-gathers equally sized per-rank slabs [E_local, ...] into [world*E_local, ...]
     ordered by rank (== global env order under `shard_envs`).  With `async_op` the
     collective is only enqueued (it overlaps the next env step) and `(out, work)` is
-    returned; call `work.wait()` before reading `out`."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    returned; call `work.wait()` before reading `out`.  A world of one rank returns `local` itself unless
+    `force_collective` (the single-GPU RCCL self-test: the collective call then really goes through the backend)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
         return (local, None) if async_op else local
     world = dist.get_world_size()
     if out is None:

@@ -382,6 +382,31 @@ def build_engine_tables(m: Model, key_joint_ids: np.ndarray) -> Dict[str, np.nda
     t["eng_geom_mat"] = g_mat
     t["eng_geom_rbound"] = m.geom_rbound[egeoms] if ng else np.zeros(0)
     t["eng_geom_invw"] = g_invw
+    # bounding capsule of every geom about its own z axis, (half length, radius), for the fp32 segment prefilter: a
+    # capsule's own; a cylinder's (half height, radius); the tightest one around a hull's vertices; a box keeps (0,
+    # bounding radius) -- its culls are the oriented-box tests.  A superset by construction (inflated by 1e-6 against the
+    # rounding of the search and of the fp32 copy).
+    bcap = np.zeros((ng, 2))
+    for i, g in enumerate(egeoms):
+        ty, sz = int(m.geom_type[g]), m.geom_size[g]
+        if ty == spec.GEOM_CAPSULE:
+            bcap[i] = (sz[1], sz[0])
+        elif ty == spec.GEOM_CYLINDER:
+            bcap[i] = (sz[1], sz[0] * (1 + 1e-6))
+        elif ty == spec.GEOM_MESH and int(m.geom_vertnum[g]) > 0:
+            a = int(m.geom_vertadr[g])
+            v = np.asarray(m.mesh_vert[a:a + int(m.geom_vertnum[g])], float)
+            rxy2 = v[:, 0] ** 2 + v[:, 1] ** 2
+            best = None
+            for hh in np.linspace(0.0, float(np.abs(v[:, 2]).max()), 65):
+                dz = np.maximum(np.abs(v[:, 2]) - hh, 0.0)
+                r = float(np.sqrt(rxy2 + dz * dz).max())
+                if best is None or r < best[1] * (1 - 1e-9):
+                    best = (hh, r)
+            bcap[i] = (best[0], best[1] * (1 + 1e-6) + 1e-9)
+        else:
+            bcap[i] = (0.0, m.geom_rbound[g])
+    t["eng_geom_bcap"] = bcap
     t["eng_geom_cparam"] = (np.concatenate(
         [m.geom_solref[egeoms], m.geom_solimp[egeoms], m.geom_friction[egeoms][:, :1]],
         axis=1) if ng else np.zeros((0, 8)))

@@ -132,3 +132,36 @@ def test_two_rank_rccl_gather():
     for _, ids, seeds in res:
         assert ids == list(map(float, range(total)))
         assert seeds[:total // 2] == [12345.0] * (total // 2) and seeds[total // 2:] == [13345.0] * (total // 2)
+
+
+def _nccl_single_rank_worker(port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    dev = torch.device("cuda", 0)
+    local = torch.arange(4096 * 145, dtype=torch.float64, device=dev).reshape(4096, 145)
+    out = torch.empty_like(local)
+    full, work = rpd.gather_trajectories(local, async_op=True, out=out, force_collective=True)
+    work.wait()
+    torch.cuda.synchronize(dev)
+    ok = bool(torch.equal(full, local)) and full.data_ptr() == out.data_ptr()
+    dist.barrier()
+    out_q.put(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_single_rank_rccl_all_gather_executes_on_the_one_gpu_there_is():
+    """Round 6: RCCL refuses several ranks per device, so on a one-GPU box the two-rank test
+    above skips -- but a ONE-rank nccl (= RCCL) group does initialise the library, build a communicator and execute
+    all_gather_into_tensor on the device, through the very call bench.py's gather makes.  The first multi-GPU driver run
+    is then at least not RCCL's first run in this image."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_single_rank_worker, args=(_free_port(), q))
+    p.start()
+    assert q.get(timeout=300) is True
+    p.join(timeout=120)
+    assert p.exitcode == 0

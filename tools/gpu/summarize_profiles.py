@@ -1,15 +1,15 @@
-"""Runs ON THE GPU BOX after scratch/r5/collect_profiles_r05.sh: reduces the rocprofv3 outputs to the small summaries
-that go into profiles/r05_* (the raw traces are > 64 MiB)."""
+"""Runs ON THE GPU BOX after tools/gpu/r06_profiles.sh: reduces the rocprofv3 outputs to the small summaries
+that go into profiles/r06_* (the raw traces are > 64 MiB)."""
 import glob, json, os, shutil, sys
 import pandas as pd
 R = sys.argv[1]
 OUT = os.path.join(R, "summary"); os.makedirs(OUT, exist_ok=True)
 LEAN, FULL, POS = "rp_lean_solver_kernel<double>", "rp_stage_kernel<double, 1", "rp_stage_kernel<double, 0"
-out = {"round": 5}
+out = {"round": 6}
 try:
     ks = pd.read_csv(sorted(glob.glob(R + "/stats/*/*kernel_stats.csv"))[-1])
     ks["Name"] = ks["Name"].str.slice(0, 140)
-    ks.to_csv(os.path.join(OUT, "r05_kernel_stats.csv"), index=False)
+    ks.to_csv(os.path.join(OUT, "r06_kernel_stats.csv"), index=False)
     kt = pd.read_csv(sorted(glob.glob(R + "/stats/*/*kernel_trace.csv"))[-1])
     kt["dur"] = kt.End_Timestamp - kt.Start_Timestamp
     gcol = "Grid_Size_X" if "Grid_Size_X" in kt.columns else ("Grid_Size" if "Grid_Size" in kt.columns else None)
@@ -68,7 +68,7 @@ if "FETCH_SIZE_KB_per_launch_solver" in pm and "WRITE_SIZE_KB_per_launch_solver"
     pm["solver_kernel_bytes_per_launch_corrected"] = sol_b; pm["position_kernel_bytes_per_launch_corrected"] = pos_b
     out["pmc"] = pm
     json.dump({"envs": 4096, "envs_per_launch": 4096, "precision": 64, "solver_kernel_bytes_per_launch": sol_b, "position_kernel_bytes_per_launch": pos_b,
-               "kernel": LEAN}, open(os.path.join(OUT, "traffic_r05.json"), "w"))
+               "kernel": LEAN}, open(os.path.join(OUT, "traffic_r06.json"), "w"))
 elif pm:
     out["pmc_partial"] = pm
 # the split position stage's kernels (separate passes with RP_SPLIT_POS=1)
@@ -87,9 +87,9 @@ if sp and all(v is not None for v in sp.values()):
     sp["split_stage_total_bytes_per_4096_env_mj_step1"] = sum(tot.values())
     out["pmc_split_position_stage"] = sp
     try:
-        t5 = json.load(open(os.path.join(OUT, "traffic_r05.json")))
+        t5 = json.load(open(os.path.join(OUT, "traffic_r06.json")))
         t5["split_position_stage_bytes_per_launch"] = tot
-        json.dump(t5, open(os.path.join(OUT, "traffic_r05.json"), "w"))
+        json.dump(t5, open(os.path.join(OUT, "traffic_r06.json"), "w"))
     except Exception:
         pass
 sq = {}
@@ -105,7 +105,7 @@ for d in ("sq1", "sq2", "sq3"):
         for k, v in per.items():
             sq[tag]["per_launch"][k] = float(v); sq[tag]["per_wave"][k] = float(v) / 4096.0
 if sq:
-    doc = {"round": 5, "note": "rocprofv3 --pmc, separate passes, bench.py --stagger 0 --steps 4 --warmup 1 with one stream slice (config 2, hull fingertips, lockstep, fp64, first five control steps); per wave = per launch / 4096 envs; SQ_WAVE_CYCLES / SQ_ACTIVE_INST_ANY / SQ_WAIT_INST_ANY count quad-cycles",
+    doc = {"round": 6, "note": "rocprofv3 --pmc, separate passes, bench.py --stagger 0 --steps 4 --warmup 1 with one stream slice (config 2, hull fingertips, lockstep, fp64, first five control steps); per wave = per launch / 4096 envs; SQ_WAVE_CYCLES / SQ_ACTIVE_INST_ANY / SQ_WAIT_INST_ANY count quad-cycles",
            "kernels": sq}
     k = sq.get("solver " + LEAN, {}).get("per_wave", {})
     if k.get("SQ_INSTS_VALU"):
@@ -119,8 +119,8 @@ if sq:
                                          "issue_share_of_wave_cycles": (k.get("SQ_ACTIVE_INST_ANY", 0.0) / k["SQ_WAVE_CYCLES"]) if k.get("SQ_WAVE_CYCLES") else None,
                                          "valu_per_wave": k["SQ_INSTS_VALU"], "salu_per_wave": k.get("SQ_INSTS_SALU"), "lds_per_wave": k.get("SQ_INSTS_LDS")},
                                         **(res or {}))
-    json.dump(doc, open(os.path.join(OUT, "r05_sq_instruction_mix.json"), "w"), indent=1)
-json.dump(out, open(os.path.join(OUT, "r05_step_kernel_summary.json"), "w"), indent=1)
+    json.dump(doc, open(os.path.join(OUT, "r06_sq_instruction_mix.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(OUT, "r06_step_kernel_summary.json"), "w"), indent=1)
 for f in glob.glob(R + "/bench_*.json") + glob.glob(R + "/bench_*.err") + glob.glob(R + "/*.log"):
     shutil.copy(f, OUT)
 print(json.dumps({k: v for k, v in out.items() if k != "command"}, indent=1)[:3000])
