@@ -83,7 +83,7 @@ def _valu_profile(precision):
     """What actually bounds the solver stage (instruction issue + latency), from the committed
     rocprofv3 --pmc passes and the compiler's resource report of the shipped build: waves per SIMD, the share of
     VALU instructions that are fp64 arithmetic, the share of wave cycles that issue an instruction."""
-    for name in ("r05_sq_instruction_mix.json", "r04_sq_instruction_mix.json", "r03_sq_instruction_mix.json", "r02_sq_instruction_mix.json"):
+    for name in ("r06_sq_instruction_mix.json", "r05_sq_instruction_mix.json", "r04_sq_instruction_mix.json", "r03_sq_instruction_mix.json", "r02_sq_instruction_mix.json"):
         d = _profile_json(name)
         k = d and d.get("solver_stage_fp%d" % precision) or (d and d.get("solver_stage"))
         if k:
@@ -98,7 +98,7 @@ def _pmc_traffic(E, precision, envs_per_launch=None):
     """HBM-side bytes per solver-kernel launch from the committed rocprofv3 --pmc passes
     (newest profiles/traffic_rNN.json, see DESIGN.md 6), scaled to the envs one launch covers;
     null if not collected for this env count / precision."""
-    for name in ("traffic_r05.json", "traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
+    for name in ("traffic_r06.json", "traffic_r05.json", "traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
         d = _profile_json(name)
         if d and int(d.get("envs", -1)) == int(E) and int(d.get("precision", -1)) == int(precision):
             b = d.get("solver_kernel_bytes_per_launch")
@@ -289,12 +289,19 @@ def main():
         A = env.action_spec().shape[0]
         replay = cfg["policy"] == "replay"
         stagger = bool(args.stagger if stagger_on is None else stagger_on) and replay and not args.engine_only
-        state = {"t": 0, "sim": torch.zeros((), dtype=torch.long, device=device)}
+        # simulated env-steps = steps x envs - FIRST steps (dm_env: the step after LAST resets and returns FIRST without
+        # simulating); the FIRST steps are counted per env on the device, read once after the timed region
+        state = {"t": 0, "nstep": 0, "first": torch.zeros((E,), dtype=torch.long, device=device)}
         if replay:
             actions = np.load(os.path.join(ROOT, "tests", "golden", "twinkle_twinkle_actions.npy"))
             T = actions.shape[0]
             act_dev = torch.as_tensor(actions, dtype=tdt, device=device)
             idx = torch.zeros(E, dtype=torch.long, device=device)  # replay row of every env
+            # (round 6: the action table is replayed INSIDE the pre-step launch -- every env reads its own row and the launch
+            # advances the row index; the harness used to gather the rows and do the index arithmetic with six torch
+            # launches between two steps)
+            from robopianist_amd.suite.scripted import ScriptedActions
+            script = ScriptedActions(act_dev, idx)
         else:
             # a ~ U(spec.min, spec.max) i.i.d. per env and step (canonical: U(-1, 1)), sustain ~ U(0, 1);
             # np.random.default_rng(12345 + 1000 rank).  Slabs are drawn on the host before the
@@ -323,22 +330,22 @@ def main():
                 c = lo + (act_dev[t % T, :-1] + 1) * 0.5 * (hi - lo)
                 base_env.physics.set_ctrl(c.expand(E, -1))
                 phys.step(args.substeps)
-                state["sim"] += E
+                state["nstep"] += 1
                 state["t"] = t + 1
                 if (t + 1) % T == 0:
                     phys.sync(); phys.reset()
                 return
             if use_graph and state.get("gather") is not None:
                 state["gather"][1].wait()   # (single record buffer under graph replay: the gather must be done with it)
-            if replay:
+            if replay and not use_graph:
+                ts = env.step(script)
+            elif replay:   # (a captured graph takes a tensor: the rows are gathered here)
                 ts = env.step(act_dev.index_select(0, idx))
-                first = ts.step_type == 0
-                # dm_env: the step after LAST resets the env and returns FIRST without simulating
-                idx.add_(1).clamp_(max=T - 1).masked_fill_(first, 0)
+                idx.add_(1).clamp_(max=T - 1).masked_fill_(ts.step_type == 0, 0)
             else:
                 ts = env.step(act_dev[t % act_dev.shape[0]])
-                first = ts.step_type == 0
-            state["sim"] += (~first).sum()
+            state["first"].add_(ts.step_type == 0)
+            state["nstep"] += 1
             if world > 1 and args.gather:
                 # (record dtype = the engine's precision: fp64 state survives the gather.  The fused task launch writes
                 # it straight into one of two preallocated buffers; the torch packer is the fallback for custom reward sets)
@@ -383,7 +390,7 @@ def main():
             one_step(t)
         barrier()
         phys.solver_kernel_time(); phys.kernel_time()  # reset the event-timer statistics
-        state["sim"].zero_()
+        state["first"].zero_(); state["nstep"] = 0
         state["gwait"] = []
         if base_env.physics.warn is not None:
             base_env.physics.warn.zero_()
@@ -392,7 +399,7 @@ def main():
             one_step(warmup + t)
         barrier()
         dt = time.perf_counter() - t0
-        sim = int(state["sim"].item())
+        sim = E * state["nstep"] - int(state["first"].sum().item())
         gather_wait_ms = sum(a.elapsed_time(b) for a, b in state.get("gwait", []))
         per_rank = None
         if dist is not None:

@@ -163,6 +163,14 @@ typedef struct rp_task_prestep_args {
   void* sustain_state;               /* [E] */
   int* active;                       /* [E] out */
   unsigned char* reset_mask;         /* [E] out */
+  /* Scripted replay (optional; round 6).  The reference's example replays a recorded action table, one row per control
+   * step of every episode (/root/reference/examples/piano_with_shadow_hands_env.py:110-141: `for t: env.step(actions[t])`).
+   * With `action_table` set, env e takes row action_index[e] of the table instead of `action` (which may then be NULL),
+   * and the launch advances the index itself: 0 for an env that is being reset (its step returns FIRST and consumes no
+   * row), min(index + 1, action_table_len - 1) otherwise -- no host-side gather or index arithmetic between two steps. */
+  const void* action_table;          /* [action_table_len][n_action] or NULL */
+  long long* action_index;           /* [E] in / out (with action_table) */
+  int action_table_len;
 } rp_task_prestep_args;
 
 int rp_task_prestep(const rp_task_prestep_args* args, void* hip_stream);

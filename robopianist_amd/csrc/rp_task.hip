@@ -485,7 +485,11 @@ __global__ __launch_bounds__(64) void rp_task_prestep_kernel(rp_task_prestep_arg
   if (env >= a.n_envs) return;
   const bool resetting = a.needs_reset[env] != 0;
   if (l == 0) { a.active[env] = resetting ? 0 : 1; a.reset_mask[env] = resetting ? 1 : 0; }
-  const T* act = (const T*)a.action + (size_t)env * a.n_action;
+  // (scripted replay: the env's own row of the action table; every lane of the env reads the index before lane 0
+  // stores the next one -- same wave, same instruction)
+  const long long ti = a.action_table ? a.action_index[env] : 0;
+  const T* act = a.action_table ? (const T*)a.action_table + (size_t)(ti < 0 ? 0 : (ti >= a.action_table_len ? a.action_table_len - 1 : ti)) * a.n_action
+                                : (const T*)a.action + (size_t)env * a.n_action;
   const T *lo = (const T*)a.act_lo, *rng = (const T*)a.act_range;
   for (int i = l; i < a.n_action; i += 16) {
 #pragma clang fp contract(off)   // (the wrapper's torch expression rounds after every operation)
@@ -497,6 +501,7 @@ __global__ __launch_bounds__(64) void rp_task_prestep_kernel(rp_task_prestep_arg
     if (i == a.n_action - 1) ((T*)a.sustain_state)[env] = resetting ? (T)0 : v;
     else if (!resetting) ((T*)a.ctrl)[(size_t)env * a.nu + a.hand_act[i]] = v;
   }
+  if (a.action_table && l == 0) a.action_index[env] = resetting ? 0 : (ti + 1 < a.action_table_len ? ti + 1 : a.action_table_len - 1);
 }
 
 }  // namespace
@@ -509,8 +514,8 @@ int rp_task_prestep(const rp_task_prestep_args* a, void* hip_stream) {
   if (!a) { g_task_err = "rp_task_prestep: null args"; return -1; }
   if (a->precision != 32 && a->precision != 64) { g_task_err = "rp_task_prestep: precision must be 32 or 64"; return -1; }
   if (a->n_envs <= 0 || a->n_action < 1 || a->nu < a->n_action - 1) { g_task_err = "rp_task_prestep: bad sizes"; return -1; }
-  if (!a->action || !a->needs_reset || !a->hand_act || !a->ctrl || !a->sustain_state || !a->active || !a->reset_mask ||
-      (a->act_lo && !a->act_range)) {
+  if ((!a->action && !a->action_table) || (a->action_table && (!a->action_index || a->action_table_len <= 0)) || !a->needs_reset ||
+      !a->hand_act || !a->ctrl || !a->sustain_state || !a->active || !a->reset_mask || (a->act_lo && !a->act_range)) {
     g_task_err = "rp_task_prestep: null array pointer";
     return -1;
   }

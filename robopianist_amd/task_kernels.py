@@ -11,6 +11,8 @@ import ctypes
 
 import torch
 
+from robopianist_amd.suite.scripted import ScriptedActions  # noqa: F401  (the pre-step launch's table source)
+
 from robopianist_amd import engine
 
 EXPORTED_SYMBOLS = ("rp_task_rewards", "rp_task_advance", "rp_task_prestep", "rp_task_rasterize", "rp_task_last_error")
@@ -69,6 +71,7 @@ class PrestepArgs(ctypes.Structure):
         ("needs_reset", ctypes.c_void_p), ("hand_act", ctypes.c_void_p),
         ("ctrl", ctypes.c_void_p), ("sustain_state", ctypes.c_void_p),
         ("active", ctypes.c_void_p), ("reset_mask", ctypes.c_void_p),
+        ("action_table", ctypes.c_void_p), ("action_index", ctypes.c_void_p), ("action_table_len", ctypes.c_int),
     ]
 
 
@@ -319,7 +322,16 @@ class FusedPrestep:
         """action [E, n_action] (device, the engine's dtype); bounds = (lo, hi - lo) device tensors for a canonical
         action in [-1, 1], None for an action in the spec's units.  Returns the reset mask for step_masked."""
         a, E = self._args, self._E
-        a.action = _chk(action, self._dt, (E, a.n_action))
+        if isinstance(action, ScriptedActions):
+            # (include/rp_task.h: the launch takes every env's own row of the table and advances the index itself)
+            a.action = None
+            a.action_table = _chk(action.table, self._dt, (int(action.table.shape[0]), a.n_action))
+            a.action_index = _chk(action.index, torch.int64, (E,))
+            a.action_table_len = int(action.table.shape[0])
+        else:
+            a.action = _chk(action, self._dt, (E, a.n_action))
+            a.action_table = a.action_index = None
+            a.action_table_len = 0
         a.needs_reset = _chk(needs_reset, torch.bool, (E,))
         if bounds is None:
             a.act_lo = a.act_range = None

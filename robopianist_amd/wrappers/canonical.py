@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from robopianist_amd.suite import specs
+from robopianist_amd.suite.scripted import ScriptedActions
 
 
 class CanonicalSpecWrapper:
@@ -45,9 +46,16 @@ class CanonicalSpecWrapper:
             # directly around the batched environment: the mapping runs inside its pre-step launch
             dev, dt = env.physics.device, env.physics.dtype
             if getattr(dev, "type", None) == "cuda":
+                if isinstance(action, ScriptedActions):   # (a canonical action TABLE: mapped row by row inside the launch)
+                    self._convert(action.table[:0])
+                    return env.step_canonical(action, (self._bounds[2], self._bounds[3]), self._clip)
                 a = torch.as_tensor(action, device=dev, dtype=dt)
                 self._convert(a[:0])   # (fills the bounds cache)
                 return env.step_canonical(a, (self._bounds[2], self._bounds[3]), self._clip)
+        if isinstance(action, ScriptedActions):
+            ts = env.step(self._convert(action.take()))
+            action.advance(ts.step_type == 0)   # (a FIRST step consumed no row)
+            return ts
         return env.step(self._convert(action))
 
     def reset(self):

@@ -180,6 +180,47 @@ def test_scripted_twinkle_replay_through_canonical_wrapper():
     assert 0.0 <= metrics["f1"] <= 1.0
 
 
+def test_scripted_actions_replay_inside_the_prestep_launch_is_bitwise_the_host_loop():
+    """Round 6: `ScriptedActions` -- the reference example's `for t: env.step(actions[t])`
+    (/root/reference/examples/piano_with_shadow_hands_env.py:110-141) as an action source: the pre-step launch reads
+    every env's own row of the table and advances the row index (0 at a FIRST step).  Against the host loop that gathers
+    the rows and does the index arithmetic with torch ops: same TimeSteps, same state, same indices, bit for bit, across
+    staggered episode ends (envs at different episode times) and through the torch fallback of the wrapper."""
+    from robopianist_amd import suite
+    from robopianist_amd.suite.scripted import ScriptedActions
+    from robopianist_amd.wrappers import CanonicalSpecWrapper
+    actions = np.load("tests/golden/twinkle_twinkle_actions.npy")
+    T, E = actions.shape[0], 12
+    def make():
+        return CanonicalSpecWrapper(suite.load(
+            "RoboPianist-debug-TwinkleTwinkleRousseau-v0", n_envs=E, seed=1,
+            task_kwargs=dict(trim_silence=True, control_timestep=0.05, gravity_compensation=True,
+                             primitive_fingertip_collisions=True, n_steps_lookahead=1)))
+    a, b = make(), make()
+    dev, dt = a.physics.device, a.physics.dtype
+    table = torch.as_tensor(actions, device=dev, dtype=dt)
+    start = (torch.arange(E, device=dev) * 13) % T
+    ia, ib = start.clone(), start.clone()
+    script = ScriptedActions(table, ib)
+    a.reset(); b.reset()
+    for t in range(T + 40):
+        ta = a.step(table.index_select(0, ia))
+        ia.add_(1).clamp_(max=T - 1).masked_fill_(ta.step_type == 0, 0)
+        tb = b.step(script)
+        assert torch.equal(ta.step_type, tb.step_type) and torch.equal(ia, ib), t
+        assert torch.equal(ta.reward, tb.reward) and torch.equal(ta.discount, tb.discount), t
+        assert torch.equal(a.physics.qpos, b.physics.qpos) and torch.equal(a.physics.ctrl, b.physics.ctrl), t
+        for k in ta.observation:
+            assert torch.equal(ta.observation[k], tb.observation[k]), (t, k)
+    assert int((ia == 0).sum()) < E   # (the envs are at different episode times)
+    # the helper's own torch form (what every non-HIP path uses) against the launch's index arithmetic
+    ic = start.clone()
+    sc = ScriptedActions(table, ic)
+    assert torch.equal(sc.take(), table.index_select(0, start))
+    sc.advance(torch.zeros(E, dtype=torch.bool, device=dev))
+    assert torch.equal(ic, (start + 1).clamp(max=T - 1))
+
+
 def test_graphed_step_matches_eager():
     """wrappers.GraphedStepWrapper: a whole env.step replayed from one captured hipGraph
     gives the same TimeSteps and the same physics state as the eager path, across an
