@@ -29,16 +29,15 @@ template <typename T> __device__ __forceinline__ T* rp_lds_vert() {
 // whole idle SIMD while the other slice's kernels hold the chip), and nothing of the caller lives across the call.
 // TYPE: 0 capsule-capsule, 1 capsule-box, 2 box-box, 3 .. 6 hull pairs (MPR; MESH builds; the buckets of rp_model.hpp).  `e` = this lane's entry on the
 // type's pooled list, `in` = it exists.
-template <typename T, int MESH, int TYPE>
-__device__ __noinline__ void rp_narrow_chunk(const RpModel<T>& M, const RpState<T>& S, const RpStage<T>& B, const int stripe, const int e, const bool in) {
+// (LDSV: the scanned hulls' vertex table is the copy in LDS, rp_lds_vert -- the pooled kernel; false: the model's table
+// through the scalar cache, as in the one-kernel stage -- the fused schedule, whose LDS belongs to the stage bodies)
+template <typename T, int MESH, int TYPE, bool LDSV = true>
+__device__ __noinline__ void rp_narrow_pair(const RpModel<T>& M, const RpState<T>& S, const RpStage<T>& B, const int env_, const int pair_, const int rb_,
+                                            const int ci_, const bool in) {
   using namespace rpk;
   using N = Num<T>;
   const T h = M.timestep;
-  int env = 0, pair = 0, rb = 0, ci = 0;
-  if (in) {
-    const int4 rec = *(const int4*)(B.tlist + (((size_t)TYPE * RPK_NSTRIPE + stripe) * B.tstride + (size_t)(S.env_base / RPK_NSTRIPE) * RPK_NCAND + e) * 4);
-    env = rec.x; pair = rec.y; rb = rec.z; ci = rec.w;
-  }
+  const int env = in ? env_ : 0, pair = in ? pair_ : 0, rb = in ? rb_ : 0, ci = in ? ci_ : 0;
   const int ga = pair & 0xffff, gb = (pair >> 16) & 0xffff;
   const bool key = gb >= RPK_KEYBASE;
   const int kk = key ? gb - RPK_KEYBASE : 0, gbi = key ? 0 : gb;
@@ -123,7 +122,9 @@ __device__ __noinline__ void rp_narrow_chunk(const RpModel<T>& M, const RpState<
       for (int i = 0; i < 9; i++) { a_.mat[i] = mA[i]; b_.mat[i] = mB[i]; }
     }
     RawCon<T> rcm[1];
-    const int nm = convex_mpr_wave<T, (MESH > 1), true>(rcm, &a_, &b_, rp_lds_vert<T>(), M.hull_vert, M.hull_graph, in, M.mpr_tol, M.mpr_tol_poly);
+    const T* vtab;
+    if constexpr (LDSV) vtab = rp_lds_vert<T>(); else vtab = M.mesh_vert();
+    const int nm = convex_mpr_wave<T, (MESH > 1), LDSV>(rcm, &a_, &b_, vtab, M.hull_vert, M.hull_graph, in, M.mpr_tol, M.mpr_tol_poly);
     if (in) {
       n = nm; rc[0] = rcm[0];
       if (key && !cylkey) { rc[0].n[0] = -rc[0].n[0]; rc[0].n[1] = -rc[0].n[1]; rc[0].n[2] = -rc[0].n[2]; }
@@ -161,6 +162,38 @@ __device__ __noinline__ void rp_narrow_chunk(const RpModel<T>& M, const RpState<
       }
     }
     B.cres_n[(size_t)env * RPK_NCAND + ci] = n;
+  }
+}
+
+// a chunk of one pooled list: lane's entry e of the type's list (its env, pair, result records, candidate index)
+template <typename T, int MESH, int TYPE>
+__device__ __forceinline__ void rp_narrow_chunk(const RpModel<T>& M, const RpState<T>& S, const RpStage<T>& B, const int stripe, const int e, const bool in) {
+  int env = 0, pair = 0, rb = 0, ci = 0;
+  if (in) {
+    const int4 rec = *(const int4*)(B.tlist + (((size_t)TYPE * RPK_NSTRIPE + stripe) * B.tstride + (size_t)(S.env_base / RPK_NSTRIPE) * RPK_NCAND + e) * 4);
+    env = rec.x; pair = rec.y; rb = rec.z; ci = rec.w;
+  }
+  rp_narrow_pair<T, MESH, TYPE, true>(M, S, B, env, pair, rb, ci, in);
+}
+// The narrow phase of ONE env inside its own wave (fused substeps with the split stage's bodies, rp_fused_split_kernel):
+// lane = candidate of this env, one real call per pair type present -- the same routines on the same inputs as the pooled
+// kernel's, so the same bits; the hull buckets 3 .. 6 exist for pooling only and share routine 3 here.
+template <typename T, int MESH>
+__device__ __forceinline__ void rp_narrow_env(const RpModel<T>& M, const RpState<T>& S, const RpStage<T>& B, const int env, const int lane) {
+  const int nc = B.ncand[env];
+  const int* const cl = B.cand + (size_t)env * RPK_NCAND * 2;
+  for (int c0 = 0; c0 < nc; c0 += 64) {
+    const int i = c0 + lane;
+    const bool in = i < nc;
+    const int pair = in ? cl[2 * i] : 0, meta = in ? cl[2 * i + 1] : 0;
+    const int rb = meta & 0xffff, ty = (meta >> 16) & 15;
+    const bool ok = in && ((meta >> 20) & 1);   // (its result records fit: RPK_NRES)
+    if constexpr (MESH != 0) {
+      if (__ballot(ok && ty >= 3) != 0ull) rp_narrow_pair<T, MESH, 3, false>(M, S, B, env, pair, rb, i, ok && ty >= 3);
+    }
+    if (__ballot(ok && ty == 2) != 0ull) rp_narrow_pair<T, MESH, 2, false>(M, S, B, env, pair, rb, i, ok && ty == 2);
+    if (__ballot(ok && ty == 1) != 0ull) rp_narrow_pair<T, MESH, 1, false>(M, S, B, env, pair, rb, i, ok && ty == 1);
+    if (__ballot(ok && ty == 0) != 0ull) rp_narrow_pair<T, MESH, 0, false>(M, S, B, env, pair, rb, i, ok && ty == 0);
   }
 }
 

@@ -605,6 +605,7 @@ struct Engine : EngineBase {
   // fused substeps (rp_fused_steps_kernel): one launch takes every light env through all substeps of an rp_step
   // 0 = off, 1 = on, 2 = automatic (a candidate of the schedule choice when the slice count is automatic too)
   int fused = getenv("RP_FUSED") ? atoi(getenv("RP_FUSED")) : 2;
+  const bool fused_split = !(getenv("RP_FUSED_SPLIT") && getenv("RP_FUSED_SPLIT")[0] == '0');
   int fused_substeps(int on) override { fused = on < 0 ? 2 : (on > 2 ? 2 : on); return 0; }
   int fused_substeps_on() const override {
     const bool capable = lean && !deep && !graph && sizeof(T) == 8;
@@ -944,7 +945,20 @@ struct Engine : EngineBase {
           const bool probe = timeit && sl == 0;
           if (probe) { HIP_OK(hipEventRecord(sv0[slot], st)); sv_envs[slot] = cnt * nsub; sv_kind[slot] = 1; }
           const int cgrid = capturing ? (cnt < kHeavyGrid ? cnt : kHeavyGrid) : heavy_grid_for(sl, cnt);
-          if (mesh) {
+          // (round 6: with the split stage's bodies where they exist -- the one-kernel position body spills 276 registers
+          // in the hull builds; RP_FUSED_SPLIT=0: the round-3 kernel)
+          const bool fsplit = fused_split && split_capable && !deep && (capturing ? B.frames != nullptr : ensure_split_buffers());
+          RpStage<T> Bf = B;
+          Bf.tlist = nullptr;   // (no pooled lists: every wave runs its own env's narrow phase)
+          if (fsplit && mesh) {
+            hipLaunchKernelGGL((rp_fused_split_kernel<T, 1>), dim3(cnt), dim3(64), 0, st, M, sf, Bf, nsub);
+            if (trunk4) hipLaunchKernelGGL((rp_cleanup_steps_kernel<T, 1, 4>), dim3(cgrid), dim3(64), 0, st, M, sf, B, nsub);
+            else hipLaunchKernelGGL((rp_cleanup_steps_kernel<T, 1, 0>), dim3(cgrid), dim3(64), 0, st, M, sf, B, nsub);
+          } else if (fsplit) {
+            hipLaunchKernelGGL((rp_fused_split_kernel<T, 0>), dim3(cnt), dim3(64), 0, st, M, sf, Bf, nsub);
+            if (trunk4) hipLaunchKernelGGL((rp_cleanup_steps_kernel<T, 0, 4>), dim3(cgrid), dim3(64), 0, st, M, sf, B, nsub);
+            else hipLaunchKernelGGL((rp_cleanup_steps_kernel<T, 0, 0>), dim3(cgrid), dim3(64), 0, st, M, sf, B, nsub);
+          } else if (mesh) {
             hipLaunchKernelGGL((rp_fused_steps_kernel<T, 1>), dim3(cnt), dim3(64), 0, st, M, sf, B, nsub);
             if (trunk4) hipLaunchKernelGGL((rp_cleanup_steps_kernel<T, 1, 4>), dim3(cgrid), dim3(64), 0, st, M, sf, B, nsub);
             else hipLaunchKernelGGL((rp_cleanup_steps_kernel<T, 1, 0>), dim3(cgrid), dim3(64), 0, st, M, sf, B, nsub);

@@ -2201,14 +2201,15 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
           if (ty == t) mine = mt;
           if (lane == t) cntT = __popcll(mt);
         }
+        // (B.tlist null: the fused schedule -- the env's own wave runs its narrow phase from the candidate list, no pooled lists)
         int tb_ = 0;
-        if (lane < RPK_NTYPE && cntT > 0) tb_ = atomicAdd(&tc_[lane], cntT);
+        if (B.tlist && lane < RPK_NTYPE && cntT > 0) tb_ = atomicAdd(&tc_[lane], cntT);
         const int tbase = __shfl(tb_, ty, 64);
         if (in) {
-          cl_[2 * i] = pair; cl_[2 * i + 1] = (ok ? myb : 0) | (ty << 16);
+          cl_[2 * i] = pair; cl_[2 * i + 1] = (ok ? myb : 0) | (ty << 16) | (ok ? 1 << 20 : 0);
           B.cres_n[(size_t)env * RPK_NCAND + i] = 0;
         }
-        if (ok) {
+        if (ok && B.tlist) {
           int4* e_ = (int4*)(B.tlist + (((size_t)ty * RPK_NSTRIPE + (env & (RPK_NSTRIPE - 1))) * B.tstride + (size_t)(S.env_base / RPK_NSTRIPE) * RPK_NCAND + tbase +
                                        __popcll(mine & lanemask_lt(lane))) * 4);
           int4 v_; v_.x = env; v_.y = pair; v_.z = myb; v_.w = i;
@@ -2992,6 +2993,48 @@ __global__ __launch_bounds__(64, 2) void rp_fused_steps_kernel(RpModel<T> M, RpS
     RPK_STAGE_FENCE();
     asm volatile("" : "+v"(lane));
     rp_stage_body<T, 0, 0, RPK_MAXD, MESH, true>(M, S, B, k, nsub, env, smem, lane);
+    RPK_STAGE_FENCE();
+  }
+}
+
+// Round 6: the same with the SPLIT position stage's bodies -- front part, the env's narrow phase in its own wave (one real
+// call per pair type: rp_narrow_env), back part.  rp_fused_steps_kernel runs the one-kernel position body, which in the
+// hull builds spills 276 registers (the inlined portal refinement); the front and back parts have no scratch at all
+// (155 / 194 VGPRs) and the narrow-phase routines are calls that nothing lives across.  Same bodies on the same inputs as
+// the per-stage split schedule: same bits.  (B.tlist is null in this schedule: the front part writes the env's candidate
+// list only.)
+template <typename T, int MESH>
+__global__ __launch_bounds__(64, 2) void rp_fused_split_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int nsub) {
+  using namespace rpk;
+  constexpr size_t NA = sizeof(SmemLean<T>) > sizeof(Smem<T, 0, RPK_MAXD>) ? sizeof(SmemLean<T>) : sizeof(Smem<T, 0, RPK_MAXD>);
+  constexpr size_t NB = NA > sizeof(SmemFront<T, RPK_MAXD>) ? NA : sizeof(SmemFront<T, RPK_MAXD>);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NB];
+  const int env = S.order ? S.order[S.env_base + blockIdx.x] : S.env_base + (int)blockIdx.x;
+  if (S.active && S.active[env] == 0) return;
+  for (int k = 0; k < nsub; k++) {
+    int lane = (int)threadIdx.x;
+    asm volatile("" : "+v"(lane));
+    if (*(volatile const int*)&B.hdr[env * 8 + 6] != 1) {
+      if (threadIdx.x == 0) { B.hdr[env * 8 + 7] = k; S.heavy_list[atomicAdd(S.heavy_cnt, 1)] = env; }
+      return;
+    }
+    if (S.qpos_prev && k == nsub - 1) rp_save_prev_state(M, S, env);
+    rp_lean_solver_body<T, true>(M, S, B, env, smem, lane);
+    RPK_STAGE_FENCE();
+    asm volatile("" : "+v"(lane));
+    rp_stage_body<T, 0, 0, RPK_MAXD, MESH, true, 1>(M, S, B, k, nsub, env, smem, lane);
+    RPK_STAGE_FENCE();
+    asm volatile("" : "+v"(lane));
+    {
+      // (the routines are real calls taking the three parameter blocks by reference: COPIES go there -- a kernel argument
+      // whose address escapes is moved to scratch for the whole kernel, and every table pointer of the stage bodies,
+      // which must stay in scalar registers (`fresh`), would be reloaded from there into vector registers)
+      const RpModel<T> Mn = M; const RpState<T> Sn = S; const RpStage<T> Bn = B;
+      rp_narrow_env<T, MESH>(Mn, Sn, Bn, env, lane);
+    }
+    RPK_STAGE_FENCE();
+    asm volatile("" : "+v"(lane));
+    rp_stage_body<T, 0, 0, RPK_MAXD, MESH, true, 2>(M, S, B, k, nsub, env, smem, lane);
     RPK_STAGE_FENCE();
   }
 }
