@@ -72,7 +72,10 @@ typedef enum {
                                   fp32 build: 32 / 240) in one env; the deepest contacts are kept */
 #define RP_WARN_HESSIAN 4      /* non-positive pivot in the Newton Hessian */
 #define RP_WARN_KEYSLOT_FULL 8 /* more simultaneously touched keys than solver slots */
-#define RP_WARN_WORK_FULL 16   /* candidate list overflow: more geom-key candidates than the key list holds; split position stage: more than 256 candidates / 384 result records in one env and mj_step (the excess is dropped) */
+#define RP_WARN_WORK_FULL 16   /* candidate list overflow: more geom-key candidates than the key list holds */
+#define RP_WARN_SPLIT_FULL 64  /* split position stage only: more than 256 candidates / 384 result records in one env and mj_step (the
+                                  excess is dropped for that mj_step; the engine's own schedule rule stops using the split stage from the
+                                  next step on -- the one-kernel stage never overflows) */
 #define RP_WARN_DENSE_FULL 32  /* more than 57 (fp32 build: 53; deep builds: 52 / 47) cross-coupled rows; cross terms dropped */
 
 /* Builds an engine for `n_envs` copies of the model in `model_blob`

@@ -275,12 +275,16 @@ struct Engine : EngineBase {
   bool split_capable = false;
   int split_mode = 0;
   bool split_now = false;   // (this rp_step)
+  bool split_dropped = false;   // the split stage has overflowed its candidate / record lists once: the rule no longer picks it
   int split_position(int on) override {
     if (on && !split_capable) return fail("rp_set_split_position_stage: the split stage exists for the fp64 default-depth builds only");
     split_mode = on < 0 ? 2 : (on > 2 ? 2 : on);
     return 0;
   }
-  int split_position_on() const override { return split_mode == 1 ? 1 : (split_mode == 2 && n_slices == 0 ? (auto_mode == 4 ? 1 : 2) : 0); }
+  // (0 = off, 1 = in use, 2 = the rule may pick it: batches of >= 3072 envs that have never overflowed its lists)
+  int split_position_on() const override {
+    return split_mode == 1 ? 1 : (split_mode == 2 && n_slices == 0 && nenv >= 3072 && !split_dropped ? (auto_mode == 4 ? 1 : 2) : 0);
+  }
   int lean_solver(int on) override {
     if (on && (deep || sizeof(T) != 8)) return fail("rp_set_lean_solver: the lean solver stage exists for the fp64 default builds only");
     lean = on != 0; S.lean = on > 0 ? on : 0;   // (on > 1: the light class capped at that many Jacobian entries)
@@ -525,9 +529,10 @@ struct Engine : EngineBase {
     S.cost_pos = dalloc<int>(E); S.cost_sol = dalloc<int>(E);
     d_heavy = dalloc<int>(E); d_heavy_cnt = dalloc<int>(2 * kMaxSlices);   // (zero-filled)
     d_listed = dalloc<unsigned char>(E); S.listed = d_listed;
-    d_heavy_peak = dalloc<int>(kMaxSlices);
-    if (hipHostMalloc((void**)&h_heavy_peak, sizeof(int) * kMaxSlices) != hipSuccess) { (void)hipGetLastError(); h_heavy_peak = nullptr; }
-    else for (int i = 0; i < kMaxSlices; i++) h_heavy_peak[i] = -1;
+    // ([kMaxSlices]: candidates the split position stage dropped this step, RP_WARN_SPLIT_FULL -- read back with the peaks)
+    d_heavy_peak = dalloc<int>(kMaxSlices + 1);
+    if (hipHostMalloc((void**)&h_heavy_peak, sizeof(int) * (kMaxSlices + 1)) != hipSuccess) { (void)hipGetLastError(); h_heavy_peak = nullptr; }
+    else { for (int i = 0; i < kMaxSlices; i++) h_heavy_peak[i] = -1; h_heavy_peak[kMaxSlices] = 0; }
     S.heavy_list = nullptr; S.heavy_cnt = nullptr; S.heavy_done = nullptr;
     S.qpos_prev = nullptr; S.qvel_prev = nullptr;
     d_valid = dalloc<unsigned char>(E);  // (zero-filled: nothing is valid yet)
@@ -848,7 +853,12 @@ struct Engine : EngineBase {
       for (int i = 0; i < last_nsl && i < kMaxSlices; i++) hl = heavy_est[i] > hl ? heavy_est[i] : hl;   // (the slices the last step used: the others' estimates are stale)
       many_heavy = many_heavy ? hl >= 2.0 : hl >= 4.0;
       const bool fused_ok = fused == 2 && fused_capable;
-      const bool split_ok = split_mode == 2 && split_capable && !capturing;
+      // (the split stage keeps at most 256 candidates / 384 result records per env where the one-kernel stage never
+      // overflows: once it has dropped any -- RP_WARN_SPLIT_FULL, counted on the device and read back with the list
+      // lengths -- the rule stops choosing it for this engine: identical inputs must not give different physics
+      // depending on the schedule.  ADVICE round 5.)
+      if (h_heavy_peak && *(volatile int*)&h_heavy_peak[kMaxSlices] > 0) split_dropped = true;
+      const bool split_ok = split_mode == 2 && split_capable && !capturing && !split_dropped;
       int sched;
       if (capturing) sched = fused_ok ? 3 : 1;
       else if (nenv < 3072) sched = (fused_ok && !many_heavy) ? 3 : (nenv >= 1024 ? 2 : 1);   // (config 5, 2048 envs, long lists: fused 245 k, two slices 286 k)
@@ -904,6 +914,7 @@ struct Engine : EngineBase {
         if constexpr (sizeof(T) == 8) {
           RpStage<T> Bs = B;
           Bs.tcount_off = sl * RPK_NSTRIPE * RPK_NTYPE_PAD;
+          Bs.split_dropped = capturing ? nullptr : d_heavy_peak + kMaxSlices;
           int ng = cnt / 2;
           ng = ng < 64 ? 64 : (ng > 2048 ? 2048 : ng);
 #define RP_SPLIT_LAUNCH(MESH_)                                                                                                     \
@@ -1075,8 +1086,8 @@ struct Engine : EngineBase {
     hipLaunchKernelGGL(rp_mark_valid_kernel, dim3(hb), dim3(256), 0, stream, d_valid, s.active, reset_mask, nenv);
     if (mode == 0 && lean && !capturing && h_heavy_peak && !heavy_grid_fixed) {
       // the longest lists of this step, for the grids of a later one (the host never waits for the copy)
-      HIP_OK(hipMemcpyAsync(h_heavy_peak, d_heavy_peak, sizeof(int) * kMaxSlices, hipMemcpyDeviceToHost, stream));
-      HIP_OK(hipMemsetAsync(d_heavy_peak, 0, sizeof(int) * kMaxSlices, stream));
+      HIP_OK(hipMemcpyAsync(h_heavy_peak, d_heavy_peak, sizeof(int) * (kMaxSlices + 1), hipMemcpyDeviceToHost, stream));
+      HIP_OK(hipMemsetAsync(d_heavy_peak, 0, sizeof(int) * (kMaxSlices + 1), stream));
     }
     HIP_OK(hipGetLastError());
     if (mode == 0) step_calls++;

@@ -2163,7 +2163,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       // with lane = candidate whatever env it came from.  (Where an entry lands on that list depends on the order
       // in which the waves of the launch arrive; the results do not: they return to the candidate's own records.)
       int nc_ = nwork;
-      if (nc_ > RPK_NCAND) { warn |= 16; nc_ = RPK_NCAND; }   // (RP_WARN_WORK_FULL)
+      if (nc_ > RPK_NCAND) { warn |= 64; nc_ = RPK_NCAND; }   // (RP_WARN_SPLIT_FULL)
       WSYNC();
       int rbase = 0;
       int* const cl_ = B.cand + (size_t)env * RPK_NCAND * 2;
@@ -2191,7 +2191,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
         const int myb = rbase + incl - (in ? wdt : 0);
         const bool ok = in && myb + wdt <= RPK_NRES;
-        if (__ballot(in && !ok) != 0ull) warn |= 16;   // (its records do not fit: the candidate is dropped, flagged)
+        if (__ballot(in && !ok) != 0ull) warn |= 64;   // (its records do not fit: the candidate is dropped, flagged: RP_WARN_SPLIT_FULL)
         rbase += bcast(incl, 63);
         unsigned long long mine = 0ull;
         int cntT = 0;
@@ -2216,7 +2216,10 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
           *e_ = v_;
         }
       }
-      if (lane == 0) B.ncand[env] = nc_;
+      if (lane == 0) {
+        B.ncand[env] = nc_;
+        if ((warn & 64) && B.split_dropped) atomicAdd(B.split_dropped, 1);   // (the host then stops choosing this schedule)
+      }
     }
     }
     }  // PART != 2

@@ -306,4 +306,5 @@ struct RpStage {
   int* tcount;    // [slices][RPK_NSTRIPE][RPK_NTYPE_PAD]   entries per list (the back part's first workgroup clears them)
   int tcount_off; // this launch's slice: tcount + tcount_off
   size_t tstride; // ceil(E / 8) * RPK_NCAND: one stripe of one type (a slice's entries start at (env_base / 8) * RPK_NCAND)
+  int* split_dropped;   // may be null: counts the envs whose candidate / record lists overflowed (RP_WARN_SPLIT_FULL)
 };

@@ -233,7 +233,10 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
     // column << 11 | cross << 15 and first entry | entries << 8 | rank << 16 -- a light env has < 32 contacts and
     // < 256 entries)
     const int h0 = B.entM[e * 2], h1 = B.entM[e * 2 + 1];
-    const int m0 = RPK_EM_LANE(h0) | (RPK_EM_CON(h0) << 6) | (RPK_EM_COL(h0) << 11) | (RPK_EM_CROSS(h0) << 15);
+    // (round 6: ... | the row of the entry's dof in the packed dense block << 16 -- its rank among the dirty rows, which the
+    // cross-contact pass used to recount, one 64-bit population count per visited entry and Newton iteration)
+    const int m0 = RPK_EM_LANE(h0) | (RPK_EM_CON(h0) << 6) | (RPK_EM_COL(h0) << 11) | (RPK_EM_CROSS(h0) << 15) |
+                   (__popcll(dirty_mask & lanemask_lt(RPK_EM_LANE(h0))) << 16);
     const int m1 = RPK_EM_BASE(h1) | (RPK_EM_CNT(h1) << 8) | (RPK_EM_RANK(h1) << 16);
     const T* fr = sm.R[(m0 >> 6) & 31];
     sm.entJ[i][0] = fr[0] * j0 + fr[1] * j1 + fr[2] * j2;
@@ -573,9 +576,14 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
   // y = J x for the rows owned by this lane (x in per-lane slot registers).  Every contact lane walks ITS
   // entries (no LDS adds: ten lanes adding into one contact's cell cost ~400 cycles per instruction).
   auto mulJ = [&](const T* x, RowsL& out) {
+    // (round 6: a touched key's value goes to its SLOT LANE's cell of sm.vec -- entry lanes nl + slot -- so that an entry
+    // reads sm.vec[its lane] whatever kind of dof it is.  Every lane writes its own cell first (unpredicated: `if (isl)`
+    // around this store cost 2 % of the step, 631 against 644 k env-steps/s), then, behind a wave-level fence, the key lanes
+    // overwrite their slots' cells)
     sm.vec[lane] = x[0];
+    WSYNC();
 #pragma unroll
-    for (int s = 0; s < 2; s++) { const int ks = myks(s); if (ks >= 0) sm.slotv[0][ks] = x[1 + s]; }
+    for (int s = 0; s < 2; s++) { const int ks = myks(s); if (ks >= 0) sm.vec[nl + ks] = x[1 + s]; }
     WSYNC();
     out.fr = x[0];
 #pragma unroll
@@ -588,12 +596,10 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
       for (int k0 = 0; k0 < maxm; k0 += 4) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          const int e = base + k0 + u < nent ? base + k0 + u : nent - 1;
+          const int e = min(base + k0 + u, nent - 1);   // (clamped: an entry past the list's end may hold NaN, and NaN x 0 is NaN)
           const int ln = sm.entM[e][0] & 63;
           const T j0 = sm.entJ[e][0], j1 = sm.entJ[e][1], j2 = sm.entJ[e][2];
-          const T xl = sm.vec[ln];
-          const T xk = sm.slotv[0][ln >= nl ? ln - nl : 0];
-          const T xv = ln < nl ? xl : xk;
+          const T xv = sm.vec[ln];
           const T xm = k0 + u < cnt ? xv : (T)0;   // (selected, not branched: the loads of the four entries batch)
           vc[0] += j0 * xm; vc[1] += j1 * xm; vc[2] += j2 * xm;
         }
@@ -849,6 +855,13 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
         unsigned cm = call;
         asm volatile("" : "+v"(cm));
         cm &= ~crossm;   // (cross-chain contacts: below)
+        // (round 6) which local columns exist for this LINK lane, as one bit mask (bit k: column k): the per-column
+        // predicate used to be rebuilt from depth / trunk length / chain position for every column of every contact
+        // (six instructions per column, more than the column's arithmetic)
+        unsigned hcol = 0;
+#pragma unroll
+        for (int k = 0; k < MD; k++)
+          if (isl && (k < TC ? (k < tp.TL && k <= tp.depth) : (pos >= 0 && k - TC <= pos))) hcol |= 1u << k;
         int inf_n = sm.cinf[cm ? __ffs(cm) - 1 : 0];
         while (__ballot(cm != 0u) != 0ull) {
           const bool mem = cm != 0u;
@@ -866,26 +879,31 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
           const T u1 = a1 * ja0 + b1 * ja1;
           const T u2 = a2 * ja0 + b2 * ja2;
           const int npath = cnt - 1;   // slot lanes: the links of this contact
+          // columns of this lane for this contact: a link's own columns, a slot lane's first npath columns
+          const unsigned vm = mem ? (isl ? hcol : ((1u << npath) - 1u)) : 0u;
           // (branch-free: the reads of a group of columns go out together and the products are selected -- a
           // predicated block per column made every column wait for its own two LDS round trips: 2.2 k cycles per
-          // contact, the largest single phase of the stage)
+          // contact, the largest single phase of the stage.  The ADDRESS is not selected any more (round 6): entry
+          // base + depth-of-column of a column this lane does not have is some other entry of the list, or at worst a
+          // few hundred bytes further inside this stage's own LDS block (base + 12 < LeanCaps::NE + 13); its product is
+          // selected away.  base + k is then an immediate offset of the read for the trunk columns and base + shift + k
+          // for the chain columns: no address arithmetic per column.)
+          const T* const eT = &sm.entJ[base][0];            // trunk columns k < TC: entry base + k
+          const T* const eC = &sm.entJ[base + shift][0];    // chain columns k >= TC: entry base + k + shift
 #pragma unroll
           for (int k0 = 0; k0 < MD; k0 += 5) {
             T jb[5][3];
-            bool valid[5];
 #pragma unroll
             for (int u = 0; u < 5; u++) {
               const int k = k0 + u < MD ? k0 + u : MD - 1;
-              const int dk = k < TC ? k : k + shift;   // depth of local column k
-              valid[u] = k0 + u < MD && mem && (isl ? (k < TC ? (k < tp.TL && k <= tp.depth) : (pos >= 0 && k - TC <= pos)) : k < npath);
-              const int eb = valid[u] ? base + dk : 0;
-              jb[u][0] = sm.entJ[eb][0]; jb[u][1] = sm.entJ[eb][1]; jb[u][2] = sm.entJ[eb][2];
+              const T* e = (k < TC ? eT : eC) + 3 * k;
+              jb[u][0] = e[0]; jb[u][1] = e[1]; jb[u][2] = e[2];
             }
 #pragma unroll
             for (int u = 0; u < 5; u++) {
               if (k0 + u < MD) {
                 const T v = u0 * jb[u][0] + u1 * jb[u][1] + u2 * jb[u][2];
-                Rr[k0 + u] += valid[u] ? v : (T)0;
+                Rr[k0 + u] += ((vm >> (k0 + u)) & 1u) ? v : (T)0;
               }
             }
           }
@@ -911,7 +929,11 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
           const T u0 = sn * ja0 + a1 * ja1 + a2 * ja2;
           const T u1 = a1 * ja0 + b1 * ja1;
           const T u2 = a2 * ja0 + b2 * ja2;
+#ifdef RPK_NO_T7
           const int cia = cross ? cidx(ln) : 0;
+#else
+          const int cia = cross ? ((m0 >> 16) & 63) : 0;
+#endif
           for (int k0 = 0; k0 < maxm; k0 += 4) {
             int mb[4];
             T val[4];
@@ -923,7 +945,11 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
+#ifdef RPK_NO_T7
               if (valid && cross && k0 + u <= rank) lds_add(&sm.H[tri(cia, cidx(mb[u] & 63))], val[u]);
+#else
+              if (valid && cross && k0 + u <= rank) lds_add(&sm.H[tri(cia, (mb[u] >> 16) & 63)], val[u]);
+#endif
             }
           }
         }
@@ -981,25 +1007,28 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
         // limit rows (a weight each) and the four pyramid rows of my contact (one weight: applied once to the
         // sums of the active rows' products) -- the stage is VALU-issue bound and the line search is its largest
         // consumer, so an evaluation forms as few products per row as the algebra allows
+        // (round 6: a row's zone test is a 0 / 1 factor on ITS weighted row values, not a predicated block -- seven
+        // blocks per evaluation, each a compare, two exec-mask writes and a branch around three or four multiply-adds,
+        // were a quarter of this stage's instructions.  The factor multiplies ONE operand of every product, exactly
+        // (x * 1 = x), so an active row contributes the same bits as before and an inactive one +-0.)
         T h0_ = 0, h2_ = 0;   // twice the alpha^0 / alpha^2 coefficients
 #pragma unroll
         for (int s = 0; s < 3; s++) {
           const T xx = jar.lim[s] + alpha * jv.lim[s];
-          if (xx < 0) {
-            const T t = lim_D[s] * jar.lim[s], u = lim_D[s] * jv.lim[s];   // (weight 0 without a limit row)
-            s1 += t * jv.lim[s]; h2_ += u * jv.lim[s];
-            if (with_cost) h0_ += t * jar.lim[s];
-          }
+          const T m = xx < 0 ? (T)1 : (T)0;
+          const T t = (lim_D[s] * jar.lim[s]) * m, u = (lim_D[s] * jv.lim[s]) * m;   // (weight 0 without a limit row)
+          s1 += t * jv.lim[s]; h2_ += u * jv.lim[s];
+          if (with_cost) h0_ += t * jar.lim[s];
         }
         if (any_con) {
           T c0_ = 0, c1_ = 0, c2_ = 0;
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const T xx = jar.con[r] + alpha * jv.con[r];
-            if (xx < 0) {
-              c1_ += jar.con[r] * jv.con[r]; c2_ += jv.con[r] * jv.con[r];
-              if (with_cost) c0_ += jar.con[r] * jar.con[r];
-            }
+            const T m = xx < 0 ? (T)1 : (T)0;
+            const T ja = jar.con[r] * m, jb = jv.con[r] * m;
+            c1_ += ja * jv.con[r]; c2_ += jb * jv.con[r];
+            if (with_cost) c0_ += ja * jar.con[r];
           }
           const T Dp = hascon ? con_D : (T)0;
           s1 += Dp * c1_; h2_ += Dp * c2_;

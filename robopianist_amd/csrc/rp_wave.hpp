@@ -51,13 +51,20 @@ template <int CTRL> __device__ __forceinline__ double dpp_move(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+// (round 6: the four row sums are combined by two more DPP steps -- row_bcast:15 adds row r - 1's sum into row r, then
+// row_bcast:31 adds lane 31's (r0 + r1) into rows 2 and 3 -- and the total is read from lane 63: (r3 + r2) + (r1 + r0),
+// bit for bit the old (r0 + r1) + (r2 + r3) since every IEEE addition commutes; 20 instructions for a double instead of
+// 29 (eight v_readlane, the moves of the scalar operands back into vector registers and three adds): the lean solver stage
+// takes ~120 wave sums per mj_step and is instruction-issue bound.)
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
   v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
   v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
   v += dpp_move<0x141>(v);  // row_half_mirror
   v += dpp_move<0x140>(v);  // row_mirror
-  return (bcast(v, 0) + bcast(v, 16)) + (bcast(v, 32) + bcast(v, 48));
+  v += dpp_move<0x142>(v);  // row_bcast:15 (row 0 receives 0: bound_ctrl)
+  v += dpp_move<0x143>(v);  // row_bcast:31 (rows 0, 1 receive 0)
+  return bcast(v, 63);
 }
 template <int CTRL> __device__ __forceinline__ int dpp_move(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);

@@ -33,6 +33,7 @@ WARN_CONTACT_FULL = 2
 WARN_HESSIAN = 4
 WARN_KEYSLOT_FULL = 8
 WARN_WORK_FULL = 16
+WARN_SPLIT_FULL = 64
 WARN_DENSE_FULL = 32
 
 EXPORTED_SYMBOLS = (

@@ -86,7 +86,7 @@ class PianoWithShadowHands(base.PianoTask):
         # 2-3, when a third of a percent of such env-steps overflowed): the overflow ends the episode like a diverged
         # state does -- reward 0, discount 0.
         from robopianist_amd import engine as _eng
-        self.overflow_warn_mask = _eng.WARN_CONTACT_FULL | _eng.WARN_KEYSLOT_FULL | _eng.WARN_DENSE_FULL | _eng.WARN_WORK_FULL
+        self.overflow_warn_mask = _eng.WARN_CONTACT_FULL | _eng.WARN_KEYSLOT_FULL | _eng.WARN_DENSE_FULL | _eng.WARN_WORK_FULL | _eng.WARN_SPLIT_FULL
         self.fatal_warn_mask = _eng.WARN_BADSTATE | (self.overflow_warn_mask if overflow_termination else 0)
         self._fatal_count = None
         self._overflow_count = None
