@@ -35,7 +35,7 @@ timeout 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/fetch_split -- 
 timeout 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/write_split -- $SHORT > $R/write_split.log 2>&1
 unset RP_STREAM_SLICES RP_SPLIT_POS
 cd $GRAFT_REPO_ROOT
-python tools/gpu/timeline.py $R/stats > $R/timeline.txt 2>&1
+python tools/gpu/timeline.py $R/stats 260 > $R/timeline.txt 2>&1
 python tools/gpu/summarize_profiles.py $R 2>&1 | tail -40
 mkdir -p $R/summary; cp $R/timeline.txt $R/summary/r06_timeline.txt
 for d in stats fetch write sq1 sq2 sq3 fetch_split write_split; do rm -rf $R/$d; done
