@@ -547,13 +547,13 @@ def main():
                         "kernels, so its duration is not exclusive and achieved/frac drop when slices are on although the step "
                         "gets faster -- compare step_sequence_avg_ms); one rp_step = 1 + 2*substeps launches "
                         "per slice (rp_stage_kernel<T,0> position/velocity stage, solver stage), or 4 launches with the fused schedule "
-                        "(the engine times both on a few steps of every 128 and runs the faster: `schedule`; probes are taken on "
-                        "the steps of the schedule in use only).  The path is instruction-issue / latency bound "
+                        "(the engine picks the schedule by rule from the batch size and the heavy-env list lengths: `schedule`; probes are "
+                        "taken on the steps of the schedule in use only).  The path is instruction-issue / latency bound "
                         "(one wave per env, two waves per SIMD), not HBM bound: `valu` carries the figures that bound it, see DESIGN.md 6",
             },
             "sanity": {"warn_flags_or": r["warn"], "finite": r["finite"], **(r["events"] or {})},
             "parity": "fp64 engine vs the CPU oracle: see cpu_baseline_parity (measured live when the CPU leg runs) and "
-                      "tests/test_gpu_parity.py; the fp32 engine diverges on the chaotic replay and is aux only",
+                      "tests/test_gpu_parity.py; the fp32 engine is aux only",
         }
         if r.get("host_io"):
             out.setdefault("aux", {})["host_io"] = r["host_io"]
