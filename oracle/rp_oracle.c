@@ -1473,9 +1473,27 @@ static void mul_J(const rpo_model* m, const rpo_data* d, double* res, const doub
 /* search = -H^{-1} grad with H = M + J' diag(D_active) J.  H is block diagonal:
  * dofs without off-diagonal entries are scalars, the rest (the hand trees and
  * any key they touch) form one dense block. */
+/* Debug statistics (not thread safe; single-env experiments only): Newton directions computed, and how many of them had
+ * the SAME set of quadratic rows as the direction before in the same solve, i.e. an unchanged Hessian. */
+static long g_dbg_newton_dirs = 0, g_dbg_newton_same_hessian = 0;
+static int g_dbg_prev_quad[4096], g_dbg_prev_n = -1;
+void rpo_debug_newton_stats(long* out, int reset) {
+  out[0] = g_dbg_newton_dirs; out[1] = g_dbg_newton_same_hessian;
+  if (reset) g_dbg_newton_dirs = g_dbg_newton_same_hessian = 0;
+}
 static void newton_direction(const rpo_model* m, rpo_data* d) {
   int nv = m->nv, ne = d->nefc;
   double* H = d->H;
+  if (ne <= 4096) {
+    int same = g_dbg_prev_n == ne;
+    for (int i = 0; i < ne; i++) {
+      int q = d->efc_state[i] == 1;
+      if (same && g_dbg_prev_quad[i] != q) same = 0;
+      g_dbg_prev_quad[i] = q;
+    }
+    g_dbg_prev_n = ne;
+    g_dbg_newton_dirs++; g_dbg_newton_same_hessian += same;
+  }
   memcpy(H, d->qM, sizeof(double)*nv*nv);
   for (int i = 0; i < ne; i++) {
     if (d->efc_state[i] != 1) continue;
@@ -1553,6 +1571,7 @@ static void solve_newton(const rpo_model* m, rpo_data* d) {
   }
   for (int j = 0; j < nv; j++) d->grad[j] = d->Ma[j] - d->qfrc_smooth[j] - d->qfrc_constraint[j];
 
+  g_dbg_prev_n = -1;
   for (int iter = 0; iter < m->iterations; iter++) {
     newton_direction(m, d);
     double snorm = 0;

@@ -85,6 +85,7 @@ void rpo_debug_set_capsule_box(int variant);
 void rpo_debug_set_boxbox_max(int n);
 void rpo_debug_set_mpr(double tol, int discrete);   /* uniform stopping tolerance (<= 0: MuJoCo's 1e-6); resets the polytope tolerance */
 void rpo_debug_set_mpr_poly(double tol_poly);         /* >= 0: polytope pairs (box / hull on both sides) refine to this instead; < 0: off */
+void rpo_debug_newton_stats(long* out, int reset);     /* out[0] Newton directions computed, out[1] of them with the Hessian of the direction before (single-env runs only) */
 double rpo_debug_line_search(int n, const int* type, const double* jar, const double* jv, const double* D,
                              const double* floss, const double* R, const double quad[3], double gtol,
                              int ls_iterations, int* evals);
