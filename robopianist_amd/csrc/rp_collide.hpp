@@ -202,7 +202,6 @@ __device__ __forceinline__ void rp_narrow_env(const RpModel<T>& M, const RpState
 #endif
 template <typename T, int MESH>
 __global__ __launch_bounds__(64, RPK_NARROW_WAVES) void rp_narrow_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B) {
-  if (RPK_PRIO_POS > 0) RPK_SETPRIO(RPK_PRIO_POS);
   const int lane = (int)threadIdx.x;
   const int* const tc = B.tcount + B.tcount_off;
   // the scanned hulls' vertex table, staged in LDS by the waves that walk a hull list (hull_support_wave<.., LDSV>)

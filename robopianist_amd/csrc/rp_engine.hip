@@ -53,7 +53,6 @@ __global__ __launch_bounds__(512) void rp_order_kernel(int* order_all, const int
   // (sorts the envs base .. base + n - 1 into order_all[base .. base + n - 1]; base is a multiple of 8.
   // One workgroup per residue class: eight short kernels side by side instead of one 1024-thread block.)
   const int x = blockIdx.x;
-  if (RPK_PRIO_POS > 0) RPK_SETPRIO(RPK_PRIO_POS);   // (on the slice's critical path: rp_model.hpp)
   // the envs outside the light capacity class, compacted for the full-capacity solver stage (any order: envs
   // are independent); the counter is cleared by that stage's last workgroup
   if (heavy_list) {

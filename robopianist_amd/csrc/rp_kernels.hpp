@@ -2892,7 +2892,6 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
   // One env per workgroup -- or, for the full-capacity solver stage next to the lean one, a small grid walking
   // the compacted list of the envs outside the light class (RpState::heavy_list).
   const bool listed = MODE == 1 && S.heavy_list != nullptr;
-  if (RPK_PRIO_POS > 0 && (MODE == 0 || listed)) RPK_SETPRIO(RPK_PRIO_POS);   // (position stage; the full-capacity solver stage of the few envs outside the light class)
   const int n = listed ? *(volatile const int*)S.heavy_cnt : (int)gridDim.x;
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     const int env = listed ? S.heavy_list[i] : (S.order ? S.order[S.env_base + i] : S.env_base + i);
@@ -2918,13 +2917,11 @@ __global__ __launch_bounds__(64, (MODE != 1 || sizeof(T) == 4) ? 2 : RPK_SOL64_W
 // next front launch on this stream (the narrow-phase launch between them has finished reading them by then).
 template <typename T, int MESH>
 __global__ __launch_bounds__(64, 2) void rp_pos_front_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep, int nsub) {
-  if (RPK_PRIO_POS > 0) RPK_SETPRIO(RPK_PRIO_POS);
   const int env = S.order ? S.order[S.env_base + blockIdx.x] : S.env_base + (int)blockIdx.x;
   rp_stage_body<T, 0, 0, RPK_MAXD, MESH, false, 1>(M, S, B, substep, nsub, env, nullptr, (int)threadIdx.x);
 }
 template <typename T, int MESH>
 __global__ __launch_bounds__(64, 2) void rp_pos_back_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep, int nsub) {
-  if (RPK_PRIO_POS > 0) RPK_SETPRIO(RPK_PRIO_POS);
   if (blockIdx.x == 0 && threadIdx.x < RPK_NSTRIPE * RPK_NTYPE_PAD) B.tcount[B.tcount_off + threadIdx.x] = 0;
   const int env = S.order ? S.order[S.env_base + blockIdx.x] : S.env_base + (int)blockIdx.x;
   rp_stage_body<T, 0, 0, RPK_MAXD, MESH, false, 2>(M, S, B, substep, nsub, env, nullptr, (int)threadIdx.x);
@@ -2936,7 +2933,6 @@ __global__ __launch_bounds__(64, 2) void rp_pos_back_kernel(RpModel<T> M, RpStat
 // benchmark goes through -- spilled 500 registers instead of 340 (loop-invariant per-lane state hoisted out of the loop).
 template <typename T, int MESH>
 __global__ __launch_bounds__(64, 2) void rp_pos_list_kernel(RpModel<T> M, RpState<T> S, RpStage<T> B, int substep, int nsub) {
-  if (RPK_PRIO_POS > 0) RPK_SETPRIO(RPK_PRIO_POS);
   const int n = *(volatile const int*)S.heavy_cnt;
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     int lane = (int)threadIdx.x;

@@ -242,21 +242,6 @@ struct RpState {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
     __builtin_amdgcn_wave_barrier();                         \
   } while (0)
-// Wave priority at the SIMD's instruction arbiter (s_setprio, 0 lowest .. 3 highest; it decides which of the resident waves
-// issues when several are ready -- scheduling only, results are unchanged).  A launch ends with its slowest wave and the
-// next kernel of the slice's chain waits for it, so the waves on a slice's critical path go first: the short kernels of
-// the position stage (which share their SIMDs with the other slices' solver waves) and the solver waves that are late
-// (Newton iteration RPK_PRIO_LEAN_T1 / _T2 and beyond: the launch's tail).
-#ifndef RPK_PRIO_POS
-#define RPK_PRIO_POS 2
-#endif
-#ifndef RPK_PRIO_LEAN_T1
-#define RPK_PRIO_LEAN_T1 6
-#endif
-#ifndef RPK_PRIO_LEAN_T2
-#define RPK_PRIO_LEAN_T2 9
-#endif
-#define RPK_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 // ... and a hand-off through GLOBAL memory between lanes of one wave (the stages of the fused-substeps kernels; the
 // position stage's contact overflow records).  Workgroup scope: writer and reader sit behind the same vector L1,
 // which a CU's own stores keep coherent; an agent-scope fence writes the L2 back and invalidates it.

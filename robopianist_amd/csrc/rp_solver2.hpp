@@ -805,9 +805,6 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
     PROF(3);
     const int maxit = S.max_newton;
     for (int iter = 0; iter < maxit; iter++) {
-      // (a late wave is the tail its launch ends with: it goes first at the instruction arbiter, rp_model.hpp)
-      if (RPK_PRIO_LEAN_T1 > 0 && iter == RPK_PRIO_LEAN_T1) RPK_SETPRIO(1);
-      if (RPK_PRIO_LEAN_T2 > 0 && iter == RPK_PRIO_LEAN_T2) RPK_SETPRIO(2);
       // gradient of the cost: M qacc - qfrc_smooth - J^T f
       const T grad[3] = {r0 - qfc[0], kM[0] * dq[1] - qfc[1], kM[1] * dq[2] - qfc[2]};
       // ---- H = M + J^T D J on the coupled system (hand dofs + touched keys)

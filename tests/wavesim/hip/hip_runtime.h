@@ -77,7 +77,6 @@ __attribute__((noinline)) static int ws_permute(int byte_addr, int v) {
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_s_barrier() ws_syncthreads()
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
-#define __builtin_amdgcn_s_setprio(x) ((void)0)   /* issue-arbitration priority: scheduling only */
 #define __syncthreads() ws_syncthreads()
 template <typename V> static inline V ws_shfl(V v, int src) {
   static_assert(sizeof(V) == 4 || sizeof(V) == 8, "shuffle width");
