@@ -489,6 +489,7 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
     // local column k of a link lane: does it exist, and which lane is that ancestor
     auto col_valid = [&](int k) -> bool { return k < TC ? (k < TL && k <= depth) : (pos >= 0 && k - TC <= pos); };
     auto col_lane = [&](int k) -> int { return k < TC ? tbase + k : lane - (pos - (k - TC)); };
+    T xcur = 0;   // my row's x once its level has passed (dirty rows: from the dense block)
     // ---- dense block on the dirty rows (Schur complement + cross-contact terms)
     if (dm) {
       const int nD = __popcll(dm);
@@ -519,26 +520,50 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
       WSYNC();
       if (lane < nD) sm.vec[lane] = xr;
       WSYNC();
-      if (dirty) sm.xs[lane] = sm.vec[ci];
+      const T xd = sm.vec[dirty ? ci : 0];
+      if (dirty) xcur = xd;
       WSYNC();
     }
     PROF(25);
-    // ---- back-substitution, root to leaves: x_v = (b_v - sum_{a above v} H[v][a] x[a]) / d_v.  One level
-    // per local column (trunk 0 .. TC-1, then chain positions): the links whose diagonal it is publish x,
-    // every link below subtracts its term.
+    // ---- back-substitution, root to leaves: x_v = (b_v - sum_{a above v} H[v][a] x[a]) / d_v, one level per local
+    // column (trunk 0 .. TC-1, then chain positions 0 .. 4).  Round 6: the levels no longer cross LDS (nine dependent
+    // write -> read round trips per solve).  A trunk link's x goes to everything below it with v_readlane (one source
+    // lane per tree, selected by the lane's tree); the x of the link at chain position p goes down its chain on a
+    // wave_shr:1 DPP cascade -- after d shifts the lane at position p + d holds it (chain lanes are consecutive, and a
+    // lane takes the value only at the shift that equals its distance, so what crosses into the next chain is never
+    // used).  Same terms in the same order as the LDS version: bit-identical.
     T s_ = rhs;
+    {
+      const int tb0 = bcast(tbase, 0), tb1 = bcast(tbase, nl - 1);   // (trunk base lane of the first / last tree)
 #pragma unroll
-    for (int k = 0; k < MD; k++) {
-      if (isl && kd == k && !dirty) sm.xs[lane] = s_ * mydinv;
-      WSYNC();
-      const bool below = isl && col_valid(k) && kd != k;
-      const T xa = sm.xs[below ? col_lane(k) : lane];
-      if (below) s_ -= Rr[k] * xa;
+      for (int k = 0; k < TC; k++) {
+        if (isl && kd == k && !dirty) xcur = s_ * mydinv;
+        const T v0 = bcast(xcur, tb0 + k), v1 = bcast(xcur, tb1 + k);
+        const T xa = (ltree & 1) ? v1 : v0;
+        const bool below = isl && col_valid(k) && kd != k;
+        if (below) s_ -= Rr[k] * xa;
+      }
+#pragma unroll
+      for (int q = 0; q < MD - TC; q++) {
+        const int k = TC + q;
+        if (isl && kd == k && !dirty) xcur = s_ * mydinv;
+        if (q == MD - TC - 1) break;
+        T t = xcur, xa = 0;
+#pragma unroll
+        for (int d = 1; d < MD - TC - q; d++) {
+          t = dpp_move<0x138>(t);   // wave_shr:1
+          xa = (pos == q + d) ? t : xa;
+        }
+        const bool below = isl && col_valid(k) && kd != k;
+        if (below) s_ -= Rr[k] * xa;
+      }
     }
-    T x = isl ? sm.xs[lane] : (T)0;
-    if (isslot) {
-      x = sm.xs[lane];
-      if (!dirty) {
+    T x = (isl || (isslot && dirty)) ? xcur : (T)0;
+    if (nslots > 0) {
+      // the key leaves read their anchor path's x from LDS
+      if (isl) sm.xs[lane] = xcur;
+      WSYNC();
+      if (isslot && !dirty) {
         x = rhs / Dslot;
 #pragma unroll
         for (int e = 0; e < MD; e++)
