@@ -49,6 +49,9 @@ template <> __device__ __forceinline__ float rcp_nr<float>(float x) {
 //     the forward substitution for free; only the backward pass is a serial chain.
 // Measured on gfx950, one wave per SIMD, n = 20, fp64: 12 k cycles (the first version,
 // one column per step with sqrt/divide/readlane, took 34 k).
+#ifndef RPK_DENSE_PTRIP
+#define RPK_DENSE_PTRIP 4
+#endif
 template <typename T, bool WIDE = (sizeof(T) == 4)>
 __device__ T dense_factor_solve(T* H, int n, int lane, int* warn) {
   T invd_me = 0;
@@ -64,11 +67,16 @@ __device__ T dense_factor_solve(T* H, int n, int lane, int* warn) {
     const T* r2 = H + tri(j + 2, 0);
     const T* r3 = H + tri(j + 3, 0);
     T s0 = ri[j], s1 = ri[j + 1], s2 = ri[j + 2], s3 = ri[j + 3];
-    for (int p = 0; p < j; p += 2) {  // j is a multiple of 4 here; two p per trip keeps the
-#pragma unroll                       // live set small (the fp64 solver is at its register limit)
-      for (int u = 0; u < 2; u++) {
-        const T a = ri[p + u];
-        s0 -= a * r0[p + u]; s1 -= a * r1[p + u]; s2 -= a * r2[p + u]; s3 -= a * r3[p + u];
+    for (int p = 0; p < j; p += RPK_DENSE_PTRIP) {  // j is a multiple of 4 here; p per trip: LDS round trips against live registers
+      T a[RPK_DENSE_PTRIP], b0[RPK_DENSE_PTRIP], b1[RPK_DENSE_PTRIP], b2[RPK_DENSE_PTRIP], b3[RPK_DENSE_PTRIP];
+#pragma unroll
+      for (int u = 0; u < RPK_DENSE_PTRIP; u++) { a[u] = ri[p + u]; b0[u] = r0[p + u]; b1[u] = r1[p + u]; b2[u] = r2[p + u]; b3[u] = r3[p + u]; }
+#if RPK_DENSE_PTRIP > 2
+      __builtin_amdgcn_sched_barrier(0);   // (all reads of the trip in flight before the first multiply-add waits)
+#endif
+#pragma unroll
+      for (int u = 0; u < RPK_DENSE_PTRIP; u++) {
+        s0 -= a[u] * b0[u]; s1 -= a[u] * b1[u]; s2 -= a[u] * b2[u]; s3 -= a[u] * b3[u];
       }
     }
     T d0 = bcast(s0, j);
@@ -113,6 +121,9 @@ __device__ T dense_factor_solve(T* H, int n, int lane, int* warn) {
       T a0 = ri[p], a1 = ri[p + 1], a2 = ri[p + 2], a3 = ri[p + 3];
       T b0 = rj[p], b1 = rj[p + 1], b2 = rj[p + 2], b3 = rj[p + 3];
       T c0 = rk[p], c1 = rk[p + 1], c2 = rk[p + 2], c3 = rk[p + 3];
+#if RPK_DENSE_PTRIP > 2
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       s -= a0 * b0; t -= a0 * c0; s -= a1 * b1; t -= a1 * c1;
       s -= a2 * b2; t -= a2 * c2; s -= a3 * b3; t -= a3 * c3;
     }
@@ -138,7 +149,27 @@ __device__ T dense_factor_solve(T* H, int n, int lane, int* warn) {
     const T* ri = H + tri(act ? lane : 0, 0);
     const T* rj = H + tri(j, 0);
     T s = ri[j];
-    for (int p = 0; p < j; p++) s -= ri[p] * rj[p];
+    int p = 0;
+#if RPK_DENSE_PTRIP > 2
+    // (the reads of a trip in flight together: the plain loop waited for every pair of them, j / 2 LDS round trips)
+    for (; p + 8 <= j; p += 8) {
+      T a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { a[u] = ri[p + u]; b[u] = rj[p + u]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; u++) s -= a[u] * b[u];
+    }
+    for (; p + 4 <= j; p += 4) {
+      T a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { a[u] = ri[p + u]; b[u] = rj[p + u]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; u++) s -= a[u] * b[u];
+    }
+#endif
+    for (; p < j; p++) s -= ri[p] * rj[p];
     T dj = bcast(s, j);
     if (!(dj >= RPK_MINVAL)) { dj = RPK_MINVAL; *warn |= 4; }
     const T rs = rsqrt_nr(dj);

@@ -619,14 +619,25 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
       asm volatile("" : "+v"(ci_));
       const int base = ci_ & 255, cnt = (ci_ >> 8) & 255;
       for (int k0 = 0; k0 < maxm; k0 += 4) {
+        // (two LDS round trips per four entries: the entries' records and Jacobians together, then the values of their dofs.
+        // The scheduling barriers keep the reads of a phase in flight together -- left alone, the compiler waited for
+        // every entry's record and then for its value: eight dependent round trips per trip of this loop)
+        int ln[4];
+        T j0[4], j1[4], j2[4], xv[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const int e = min(base + k0 + u, nent - 1);   // (clamped: an entry past the list's end may hold NaN, and NaN x 0 is NaN)
-          const int ln = sm.entM[e][0] & 63;
-          const T j0 = sm.entJ[e][0], j1 = sm.entJ[e][1], j2 = sm.entJ[e][2];
-          const T xv = sm.vec[ln];
-          const T xm = k0 + u < cnt ? xv : (T)0;   // (selected, not branched: the loads of the four entries batch)
-          vc[0] += j0 * xm; vc[1] += j1 * xm; vc[2] += j2 * xm;
+          ln[u] = sm.entM[e][0];
+          j0[u] = sm.entJ[e][0]; j1[u] = sm.entJ[e][1]; j2[u] = sm.entJ[e][2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) xv[u] = sm.vec[ln[u] & 63];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const T xm = k0 + u < cnt ? xv[u] : (T)0;   // (selected, not branched)
+          vc[0] += j0[u] * xm; vc[1] += j1[u] * xm; vc[2] += j2[u] * xm;
         }
       }
     }
@@ -683,20 +694,36 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
     unsigned cm = call;
     asm volatile("" : "+v"(cm));
     while (__ballot(cm != 0u) != 0ull) {
-      int c[4], e[4];
+      // (two LDS round trips per four contacts, kept together by scheduling barriers: the contacts' headers and force
+      // vectors, then this lane's entry of each -- the compiler's own order waited for every header and every entry in turn,
+      // twelve dependent round trips per trip)
+      int c[4], e[4], inf[4];
       bool on[4];
+      unsigned long long sup[4];
+      T f[4][3], je[4][3];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         on[u] = cm != 0u;
         c[u] = on[u] ? __ffs((int)cm) - 1 : 0;
         cm &= cm - 1u;
-        const unsigned long long sup = sm.csup[c[u]];
-        const int e_ = (sm.cinf[c[u]] & 255) + __popcll(sup & lanemask_lt(lane));
-        e[u] = e_ < nent ? e_ : (nent > 0 ? nent - 1 : 0);
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const T v = sm.entJ[e[u]][0] * sm.cv[c[u]][0] + sm.entJ[e[u]][1] * sm.cv[c[u]][1] + sm.entJ[e[u]][2] * sm.cv[c[u]][2];
+        sup[u] = sm.csup[c[u]]; inf[u] = sm.cinf[c[u]];
+        f[u][0] = sm.cv[c[u]][0]; f[u][1] = sm.cv[c[u]][1]; f[u][2] = sm.cv[c[u]][2];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e_ = (inf[u] & 255) + __popcll(sup[u] & lanemask_lt(lane));
+        e[u] = e_ < nent ? e_ : (nent > 0 ? nent - 1 : 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) { je[u][0] = sm.entJ[e[u]][0]; je[u][1] = sm.entJ[e[u]][1]; je[u][2] = sm.entJ[e[u]][2]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const T v = je[u][0] * f[u][0] + je[u][1] * f[u][1] + je[u][2] * f[u][2];
         acc += on[u] ? v : (T)0;
       }
     }
@@ -727,8 +754,14 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
     WSYNC();
     T y = 0;
     if (isl) {
+      // (all reads of this part in flight together, then selected sums in the old order: a predicated read per ancestor was
+      // nine dependent LDS round trips)
+      T xa[MD];
 #pragma unroll
-      for (int e = 0; e < MD; e++) if (e <= tp.depth) y += Mr[e] * sm.vec[anc_at(tp, e)];
+      for (int e = 0; e < MD; e++) xa[e] = sm.vec[e <= tp.depth ? anc_at(tp, e) : lane];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < MD; e++) { const T t_ = y + Mr[e] * xa[e]; y = e <= tp.depth ? t_ : y; }
       // column part, in-chain: the links below me on my chain
       {
 #pragma unroll
@@ -755,17 +788,22 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
     }
     WSYNC();
     if (isl && pos < 0) {
-      // trunk links: the chains' sums and the trunk links below me
+      // trunk links: the chains' sums and the trunk links below me (reads together, then the sums in the old order)
+      T vc_[5], vq[TC - 1];
 #pragma unroll
-      for (int c = 0; c < 5; c++) {
-        const T v = sm.stage[(tp.ltree & 1) * 5 + c][tp.depth];
-        if ((tp.chainmask >> c) & 1) y += v;
-      }
+      for (int c = 0; c < 5; c++) vc_[c] = sm.stage[(tp.ltree & 1) * 5 + c][tp.depth];
 #pragma unroll
       for (int q = 1; q < TC; q++) {
         const bool on = tp.depth + q < tp.TL;
-        const T v = sm.R[on ? lane + q : lane][tp.depth];
-        y += on ? v : (T)0;
+        vq[q - 1] = sm.R[on ? lane + q : lane][tp.depth];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 5; c++) { const T t_ = y + vc_[c]; y = ((tp.chainmask >> c) & 1) ? t_ : y; }
+#pragma unroll
+      for (int q = 1; q < TC; q++) {
+        const bool on = tp.depth + q < tp.TL;
+        y += on ? vq[q - 1] : (T)0;
       }
     }
     WSYNC();
@@ -887,26 +925,27 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
 #pragma unroll
         for (int k = 0; k < MD; k++)
           if (isl && (k < TC ? (k < tp.TL && k <= tp.depth) : (pos >= 0 && k - TC <= pos))) hcol |= 1u << k;
-        int inf_n = sm.cinf[cm ? __ffs(cm) - 1 : 0];
+        // (one LDS round trip per contact, held together by a scheduling barrier: the header and weight of the lane's NEXT
+        // contact are fetched with the entries of this one -- the compiler's own order took four to five dependent round
+        // trips per contact: header, own entry, weight, two groups of columns)
+        int c_n = cm ? __ffs(cm) - 1 : 0;
+        int inf_n = sm.cinf[c_n];
+        T Cn[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) Cn[i] = sm.cC[c_n][i];
         while (__ballot(cm != 0u) != 0ull) {
           const bool mem = cm != 0u;
-          const int c = mem ? __ffs(cm) - 1 : 0;
           cm &= cm - 1u;   // (0 & 0xffffffff = 0)
           const int inf = inf_n;
-          inf_n = sm.cinf[cm ? __ffs(cm) - 1 : 0];
+          const T sn = Cn[0], a1 = Cn[1], a2 = Cn[2], b1 = Cn[3], b2 = Cn[4];
+          c_n = cm ? __ffs(cm) - 1 : 0;
           const int base = inf & 255, cnt = (inf >> 8) & 255;
           const int eo_ = base + (isl ? tp.depth : cnt - 1);
           const int eo = (mem && eo_ < nent) ? eo_ : 0;
-          const T ja0 = sm.entJ[eo][0], ja1 = sm.entJ[eo][1], ja2 = sm.entJ[eo][2];
-          const T* C = sm.cC[c];
-          const T sn = C[0], a1 = C[1], a2 = C[2], b1 = C[3], b2 = C[4];
-          const T u0 = sn * ja0 + a1 * ja1 + a2 * ja2;
-          const T u1 = a1 * ja0 + b1 * ja1;
-          const T u2 = a2 * ja0 + b2 * ja2;
-          const int npath = cnt - 1;   // slot lanes: the links of this contact
           // columns of this lane for this contact: a link's own columns, a slot lane's first npath columns
+          const int npath = cnt - 1;   // slot lanes: the links of this contact
           const unsigned vm = mem ? (isl ? hcol : ((1u << npath) - 1u)) : 0u;
-          // (branch-free: the reads of a group of columns go out together and the products are selected -- a
+          // (branch-free: the reads of the columns go out together and the products are selected -- a
           // predicated block per column made every column wait for its own two LDS round trips: 2.2 k cycles per
           // contact, the largest single phase of the stage.  The ADDRESS is not selected any more (round 6): entry
           // base + depth-of-column of a column this lane does not have is some other entry of the list, or at worst a
@@ -915,22 +954,24 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
           // for the chain columns: no address arithmetic per column.)
           const T* const eT = &sm.entJ[base][0];            // trunk columns k < TC: entry base + k
           const T* const eC = &sm.entJ[base + shift][0];    // chain columns k >= TC: entry base + k + shift
+          const T ja0 = sm.entJ[eo][0], ja1 = sm.entJ[eo][1], ja2 = sm.entJ[eo][2];
+          T jb[MD][3];
 #pragma unroll
-          for (int k0 = 0; k0 < MD; k0 += 5) {
-            T jb[5][3];
+          for (int k = 0; k < MD; k++) {
+            const T* e = (k < TC ? eT : eC) + 3 * k;
+            jb[k][0] = e[0]; jb[k][1] = e[1]; jb[k][2] = e[2];
+          }
+          inf_n = sm.cinf[c_n];
 #pragma unroll
-            for (int u = 0; u < 5; u++) {
-              const int k = k0 + u < MD ? k0 + u : MD - 1;
-              const T* e = (k < TC ? eT : eC) + 3 * k;
-              jb[u][0] = e[0]; jb[u][1] = e[1]; jb[u][2] = e[2];
-            }
+          for (int i = 0; i < 5; i++) Cn[i] = sm.cC[c_n][i];
+          __builtin_amdgcn_sched_barrier(0);
+          const T u0 = sn * ja0 + a1 * ja1 + a2 * ja2;
+          const T u1 = a1 * ja0 + b1 * ja1;
+          const T u2 = a2 * ja0 + b2 * ja2;
 #pragma unroll
-            for (int u = 0; u < 5; u++) {
-              if (k0 + u < MD) {
-                const T v = u0 * jb[u][0] + u1 * jb[u][1] + u2 * jb[u][2];
-                Rr[k0 + u] += ((vm >> (k0 + u)) & 1u) ? v : (T)0;
-              }
-            }
+          for (int k = 0; k < MD; k++) {
+            const T v = u0 * jb[k][0] + u1 * jb[k][1] + u2 * jb[k][2];
+            Rr[k] += ((vm >> k) & 1u) ? v : (T)0;
           }
           if (mem && !isl) sdiag += u0 * ja0 + u1 * ja1 + u2 * ja2;
         }
