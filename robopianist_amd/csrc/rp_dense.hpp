@@ -180,9 +180,20 @@ __device__ T dense_factor_solve(T* H, int n, int lane, int* warn) {
   // row n now holds y = L^-1 b; backward pass L^T x = y
   T x = lane < n ? H[tri(n, 0) + lane] : (T)0;
   int p = n - 1;
+  // (the rows of the NEXT group of four are requested before this group's serial chain starts: their LDS round trip runs
+  // under it instead of in front of the next one)
+  T nx0 = 0, nx1 = 0, nx2 = 0, nx3 = 0;
+  if (p - 3 >= 0) {
+    nx0 = H[tri(p, 0) + (lane < p ? lane : 0)]; nx1 = H[tri(p - 1, 0) + (lane < p - 1 ? lane : 0)];
+    nx2 = H[tri(p - 2, 0) + (lane < p - 2 ? lane : 0)]; nx3 = H[tri(p - 3, 0) + (lane < p - 3 ? lane : 0)];
+  }
   for (; p - 3 >= 0; p -= 4) {
-    T l0 = H[tri(p, 0) + (lane < p ? lane : 0)], l1 = H[tri(p - 1, 0) + (lane < p - 1 ? lane : 0)];
-    T l2 = H[tri(p - 2, 0) + (lane < p - 2 ? lane : 0)], l3 = H[tri(p - 3, 0) + (lane < p - 3 ? lane : 0)];
+    T l0 = nx0, l1 = nx1, l2 = nx2, l3 = nx3;
+    if (p - 7 >= 0) {
+      const int p4 = p - 4;
+      nx0 = H[tri(p4, 0) + (lane < p4 ? lane : 0)]; nx1 = H[tri(p4 - 1, 0) + (lane < p4 - 1 ? lane : 0)];
+      nx2 = H[tri(p4 - 2, 0) + (lane < p4 - 2 ? lane : 0)]; nx3 = H[tri(p4 - 3, 0) + (lane < p4 - 3 ? lane : 0)];
+    }
     l0 = lane < p ? l0 : (T)0; l1 = lane < p - 1 ? l1 : (T)0; l2 = lane < p - 2 ? l2 : (T)0; l3 = lane < p - 3 ? l3 : (T)0;
     if (lane == p) x *= invd_me;
     x -= l0 * bcast(x, p);

@@ -1473,9 +1473,20 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       }
     }
     WSYNC();
-    if (lane < M.ngeom) {
-      int gl = M.geom_link()[lane];
-      T gp[3] = {M.geom_pos()[3 * lane], M.geom_pos()[3 * lane + 1], M.geom_pos()[3 * lane + 2]};
+    // (the model's per-geom constants first, all reads in flight together: fetched where they were used they were a dozen
+    // dependent trips to L2, most of this phase's time)
+    const bool isg = lane < M.ngeom;
+    const int G_ = isg ? lane : 0;
+    const int ggl = M.geom_link()[G_], gty = M.geom_type()[G_];
+    T gp[3] = {M.geom_pos()[3 * G_], M.geom_pos()[3 * G_ + 1], M.geom_pos()[3 * G_ + 2]};
+    T gmat[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) gmat[k] = M.geom_mat()[9 * G_ + k];
+    const T gbc0 = M.geom_bcap()[2 * G_], gbc1 = M.geom_bcap()[2 * G_ + 1];
+    const T gsz[3] = {M.geom_size()[3 * G_], M.geom_size()[3 * G_ + 1], M.geom_size()[3 * G_ + 2]};
+    __builtin_amdgcn_sched_barrier(0);
+    if (isg) {
+      const int gl = ggl;
       if (gl >= 0) {
         T t[3];
         mat_vec(t, sm.xmat[gl], gp);
@@ -1483,8 +1494,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       }
       sm.gpos[lane][0] = gp[0]; sm.gpos[lane][1] = gp[1]; sm.gpos[lane][2] = gp[2];
       // capsule axis (third column of the world geom frame) for the segment prefilter
-      const T* gm = M.geom_mat() + 9 * lane;
-      T az[3] = {gm[2], gm[5], gm[8]};
+      T az[3] = {gmat[2], gmat[5], gmat[8]};
       if (gl >= 0) { T t[3]; mat_vec(t, sm.xmat[gl], az); az[0] = t[0]; az[1] = t[1]; az[2] = t[2]; }
       // (round 6) ... for EVERY geom: its bounding capsule about the geom's z axis (model/engine_tables.py: a capsule's own
       // half length and radius; the tightest capsule around a hull's vertices / a cylinder; a box keeps (0, bounding
@@ -1492,25 +1502,25 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       // SPHERE, and a fingertip hull next to the neighbouring finger's capsule passed it most of the time: 13 of the 17
       // hull candidates per env and mj_step on the replay, each of them two or three trips of the portal refinement.
       sm.gax[lane][0] = (float)az[0]; sm.gax[lane][1] = (float)az[1]; sm.gax[lane][2] = (float)az[2];
-      sm.gax[lane][3] = (float)M.geom_bcap()[2 * lane];
-      sm.grr[lane] = (float)M.geom_bcap()[2 * lane + 1];
+      sm.gax[lane][3] = (float)gbc0;
+      sm.grr[lane] = (float)gbc1;
     }
     // geoms are sorted capsules first: box b is geom ncap + b; `boxmask`: the geoms that are boxes (not hulls)
-    const unsigned long long boxmask = __ballot(lane < M.ngeom && M.geom_type()[lane < M.ngeom ? lane : 0] == GEOM_BOX_);
-    const int ncap = __popcll(__ballot(lane < M.ngeom && M.geom_type()[lane < M.ngeom ? lane : 0] == GEOM_CAPSULE_));
-    if (lane >= ncap && lane < M.ngeom && lane - ncap < RPK_NBOXF) {
-      const int gl = M.geom_link()[lane];
+    const unsigned long long boxmask = __ballot(isg && gty == GEOM_BOX_);
+    const int ncap = __popcll(__ballot(isg && gty == GEOM_CAPSULE_));
+    if (lane >= ncap && isg && lane - ncap < RPK_NBOXF) {
+      const int gl = ggl;
       T mw[9];
-      if (gl >= 0) mat_mul(mw, sm.xmat[gl], M.geom_mat() + 9 * lane);
+      if (gl >= 0) mat_mul(mw, sm.xmat[gl], gmat);
       else {
 #pragma unroll
-        for (int k = 0; k < 9; k++) mw[k] = M.geom_mat()[9 * lane + k];
+        for (int k = 0; k < 9; k++) mw[k] = gmat[k];
       }
       float* gb = sm.gbox[lane - ncap];
 #pragma unroll
       for (int k = 0; k < 9; k++) gb[k] = (float)mw[k];
 #pragma unroll
-      for (int k = 0; k < 3; k++) gb[9 + k] = (float)M.geom_size()[3 * lane + k];
+      for (int k = 0; k < 3; k++) gb[9 + k] = (float)gsz[k];
     }
     WSYNC();
 

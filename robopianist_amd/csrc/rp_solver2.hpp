@@ -68,8 +68,11 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
   using namespace rpk;
   using N = Num<T>;
   constexpr int MD = RPK_MAXD, TC = 4;
+  // (the env's header in two wide scalar loads; everything the prologue reads from the hand-over is requested further down
+  // in ONE batch before the first value is used: fetched where they were used, these were some twenty dependent trips to L2)
+  const int4 hq0 = *(const int4*)(B.hdr + (size_t)env * 8), hq1 = *(const int4*)(B.hdr + (size_t)env * 8 + 4);
   if (S.active && S.active[env] == 0) return;
-  if (B.hdr[env * 8 + 6] != 1) return;   // not a light env: the full-capacity build takes it
+  if (hq1.z != 1) return;   // not a light env: the full-capacity build takes it
   SmemLean<T>& sm = rp_smem<SmemLean<T>, EXT>(ext);
 #ifdef RP_LEAN_TRACE
   if (lane == 0) printf("lean kernel: env %d ncon %d\n", env, B.hdr[env * 8]);
@@ -98,12 +101,41 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
   //   spk: slot lanes: anchor link | its trunk length << 8 | its trunk base << 12 | its depth + 1 << 18; limit row signs + 1 << 22
   int tpk, kpk, spk;
   int ldof, lact;
+  const bool isk[2] = {lane < nk, lane + 64 < nk};
+  const int kid[2] = {lane, lane + 64};
+  const size_t lf = (size_t)env * RPK_NLF * 64 + lane, li = (size_t)env * RPK_NLI * 64 + lane;
+#define LF(i) B.lanef[lf + (size_t)(i) * 64]
+#define LI(i) B.lanei[li + (size_t)(i) * 64]
+  // ---- the prologue's reads: topology record, key tables, the hand-over's per-lane fields, the first round of entries
+  const int4* rec = (const int4*)(M.lane_topo() + 16 * L);
+  const int4 tr0 = rec[0], tr1 = rec[1], tr2 = rec[2], tr3 = rec[3];
+  int kdof[2], kact[2], kslot_raw[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const int K = isk[s] ? kid[s] : 0;
+    kdof[s] = M.key_dof()[K]; kact[s] = M.key_act()[K];
+    kslot_raw[s] = (int)((const signed char*)(B.keyslot + (size_t)env * (RPK_NKEYS / 4)))[K];
+  }
+  int pli[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) pli[i] = (i == 1 || i == 2) ? 0 : LI(i);
+  T plf[17];   // LF(8 .. 10), LF(14 .. 15), LF(16 .. 24): limit / contact D, friction, contact frame
+#pragma unroll
+  for (int i = 0; i < 3; i++) plf[i] = LF(8 + i);
+#pragma unroll
+  for (int i = 0; i < 11; i++) plf[3 + i] = LF(14 + i);
+  // this lane's first contact Jacobian entry (the list has room for RpCaps::NE entries per env: reading past its end is
+  // reading this env's own, unused, slots)
+  T pej[3]; int pem[2];
   {
-    const int4* rec = (const int4*)(M.lane_topo() + 16 * L);
-    const int4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-    ldof = isl ? r1.y : 0; lact = isl ? r2.z : -1;
-    const int4 r3 = rec[3];
-    tpk = isl ? ((r0.y + 1) | (r1.w << 4) | (r1.z << 7) | (r1.x << 13) | ((r2.w - r1.w) << 15) | ((r3.x & 7) << 18) | ((r3.y & 31) << 21)) : 0;
+    const size_t e = (size_t)env * RpCaps<T>::NE + lane;
+    pej[0] = B.entJ[e * 3]; pej[1] = B.entJ[e * 3 + 1]; pej[2] = B.entJ[e * 3 + 2];
+    pem[0] = B.entM[e * 2]; pem[1] = B.entM[e * 2 + 1];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    ldof = isl ? tr1.y : 0; lact = isl ? tr2.z : -1;
+    tpk = isl ? ((tr0.y + 1) | (tr1.w << 4) | (tr1.z << 7) | (tr1.x << 13) | ((tr2.w - tr1.w) << 15) | ((tr3.x & 7) << 18) | ((tr3.y & 31) << 21)) : 0;
   }
   struct Topo { int depth, TL, tbase, ltree, clen, mychain, chainmask; };
   auto topo = [&]() -> Topo {
@@ -117,16 +149,13 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
   // lane of my ancestor at depth e (lanes are in preorder: trunk chain, then the leaf chains)
   auto anc_at = [&](const Topo& tp, int e) -> int { return e < tp.TL ? tp.tbase + e : lane - (tp.depth - e); };
   auto anc_of = [](int lk, int dl, int tl, int tb, int e) -> int { return e < tl ? tb + e : lk - (dl - e); };
-  const bool isk[2] = {lane < nk, lane + 64 < nk};
-  const int kid[2] = {lane, lane + 64};
-  int kdof[2], kact[2];
   kpk = 0;
 #pragma unroll
   for (int s = 0; s < 2; s++) {
-    kdof[s] = isk[s] ? M.key_dof()[kid[s]] : 0;
-    kact[s] = isk[s] ? M.key_act()[kid[s]] : -1;
+    kdof[s] = isk[s] ? kdof[s] : 0;
+    kact[s] = isk[s] ? kact[s] : -1;
     // solver slot of my key (-1: not touched)
-    const int ks = isk[s] ? (int)((const signed char*)(B.keyslot + (size_t)env * (RPK_NKEYS / 4)))[kid[s]] : -1;
+    const int ks = isk[s] ? kslot_raw[s] : -1;
     kpk |= (ks + 1) << (5 * s);
   }
   auto myks = [&](int s) -> int {
@@ -135,13 +164,10 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
     return ((t >> (5 * s)) & 31) - 1;
   };
   const size_t eo = (size_t)env * nv;
-  const size_t lf = (size_t)env * RPK_NLF * 64 + lane, li = (size_t)env * RPK_NLI * 64 + lane;
-#define LF(i) B.lanef[lf + (size_t)(i) * 64]
-#define LI(i) B.lanei[li + (size_t)(i) * 64]
   // ---- what the position / velocity stage left behind
-  const int ncon = B.hdr[env * 8], nkt = B.hdr[env * 8 + 1];
-  const unsigned long long dirty_mask = ((unsigned long long)(unsigned)B.hdr[env * 8 + 3] << 32) | (unsigned)B.hdr[env * 8 + 2];
-  const int nent = B.hdr[env * 8 + 4], maxm = B.hdr[env * 8 + 5];
+  const int ncon = hq0.x, nkt = hq0.y;
+  const unsigned long long dirty_mask = ((unsigned long long)(unsigned)hq0.w << 32) | (unsigned)hq0.z;
+  const int nent = hq1.x, maxm = hq1.y;
   // my mass-matrix row over my ancestors (diag at [depth]); re-read from the (L2-resident) hand-over where it
   // is used instead of holding 20 registers through the Newton loop
   auto Mrow = [&]() -> const T* { return fresh(B.RM) + ((size_t)env * RPK_NLX(MD) + L) * (MD + 1); };
@@ -161,7 +187,7 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
 #pragma unroll
     for (int e = 0; e <= MD; e++) Mr[e] = isl ? row[e] : (T)0;
   };
-  spk = (LI(0) & 63) << 22;
+  spk = (pli[0] & 63) << 22;
   auto lim_sign = [&](int s) -> int {
     int t = spk;
     asm volatile("" : "+v"(t));
@@ -169,28 +195,28 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
   };
   T lim_D[3] = {0, 0, 0};
 #pragma unroll
-  for (int k = 0; k < 3; k++) if (lim_sign(k) != 0) lim_D[k] = LF(8 + k);
+  for (int k = 0; k < 3; k++) if (lim_sign(k) != 0) lim_D[k] = plf[k];
   T con_D = 0, con_mu = 0;
   int cinfo = 0;   // my contact: first entry | entries << 8 | cross-chain << 16
   if (lane < ncon) {
-    con_D = LF(14); con_mu = LF(15);
+    con_D = plf[3]; con_mu = plf[4];
     {
-      const int bc = LI(10);   // (hand-over layout: first entry | entries << 12; a light env's fit in 8 bits each)
-      cinfo = (bc & 255) | (((bc >> 12) & 63) << 8) | ((LI(4) & 1) << 16);
+      const int bc = pli[10];   // (hand-over layout: first entry | entries << 12; a light env's fit in 8 bits each)
+      cinfo = (bc & 255) | (((bc >> 12) & 63) << 8) | ((pli[4] & 1) << 16);
       unsigned long long sup = 0;
       if ((bc >> 12) & 63) {   // (a contact dropped for capacity keeps no entries)
-        sup = (((unsigned long long)(unsigned)LI(6) << 32) | (unsigned)LI(5)) | (((unsigned long long)(unsigned)LI(8) << 32) | (unsigned)LI(7));
-        const int slot = LI(3);
+        sup = (((unsigned long long)(unsigned)pli[6] << 32) | (unsigned)pli[5]) | (((unsigned long long)(unsigned)pli[8] << 32) | (unsigned)pli[7]);
+        const int slot = pli[3];
         if (slot >= 0) sup |= 1ull << (nl + slot);
       }
       sm.csup[lane] = sup; sm.cinf[lane] = cinfo;
     }
     // contact frame -> LDS (rows of sm.R are free until the first assembly), only to rotate the entries
 #pragma unroll
-    for (int k = 0; k < 9; k++) sm.R[lane][k] = LF(16 + k);
+    for (int k = 0; k < 9; k++) sm.R[lane][k] = plf[5 + k];
   }
   {
-    const int sl_ = LI(11), sd_ = LI(9);
+    const int sl_ = pli[11], sd_ = pli[9];
     spk |= (sl_ & 255) | (((sl_ >> 8) & 15) << 8) | (((sl_ >> 16) & 63) << 12) | (((sd_ + 1) & 15) << 18);
   }
   struct SlotI { int salink, sTL, sTB, sdepth; };
@@ -226,13 +252,10 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
   }
   crossm = (unsigned)uni((int)crossm);
   // contact Jacobian entries, rotated into the contact frame of their contact
-  for (int i = lane; i < nent; i += 64) {
-    const size_t e = (size_t)env * RpCaps<T>::NE + i;
-    const T j0 = B.entJ[e * 3], j1 = B.entJ[e * 3 + 1], j2 = B.entJ[e * 3 + 2];
+  auto put_entry = [&](const int i, const T j0, const T j1, const T j2, const int h0, const int h1) {
     // (the hand-over's records, rp_model.hpp, repacked into this stage's narrower fields: lane | contact << 6 |
     // column << 11 | cross << 15 and first entry | entries << 8 | rank << 16 -- a light env has < 32 contacts and
     // < 256 entries)
-    const int h0 = B.entM[e * 2], h1 = B.entM[e * 2 + 1];
     // (round 6: ... | the row of the entry's dof in the packed dense block << 16 -- its rank among the dirty rows, which the
     // cross-contact pass used to recount, one 64-bit population count per visited entry and Newton iteration)
     const int m0 = RPK_EM_LANE(h0) | (RPK_EM_CON(h0) << 6) | (RPK_EM_COL(h0) << 11) | (RPK_EM_CROSS(h0) << 15) |
@@ -243,61 +266,116 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
     sm.entJ[i][1] = fr[3] * j0 + fr[4] * j1 + fr[5] * j2;
     sm.entJ[i][2] = fr[6] * j0 + fr[7] * j1 + fr[8] * j2;
     sm.entM[i][0] = m0; sm.entM[i][1] = m1;
+  };
+  if (lane < nent) put_entry(lane, pej[0], pej[1], pej[2], pem[0], pem[1]);   // (fetched with the prologue's batch)
+  for (int i = lane + 64; i < nent; i += 64) {
+    const size_t e = (size_t)env * RpCaps<T>::NE + i;
+    put_entry(i, B.entJ[e * 3], B.entJ[e * 3 + 1], B.entJ[e * 3 + 2], B.entM[e * 2], B.entM[e * 2 + 1]);
   }
   WSYNC();
   PROF(0);
-  // ---- per-lane constants of the dynamics
-  const T lfloss = isl ? M.link_floss()[L] : (T)0;
-  const T lflR = isl ? M.link_fl_R()[L] : (T)1;
+  // ---- per-lane constants of the dynamics, actuator tables and state: every read of this phase requested in ONE batch
+  // (clamped indices, values selected afterwards) -- read where they were used, under their predicates, they were some
+  // fifteen dependent trips to L2
+  const int A = lane < nu ? lane : 0;
+  int KA[2], Kc[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) { Kc[s] = isk[s] ? kid[s] : 0; KA[s] = (isk[s] && kact[s] >= 0) ? kact[s] : 0; }
+  const T ld_floss = M.link_floss()[L], ld_flR = M.link_fl_R()[L], ld_stiff = M.link_stiffness()[L], ld_sref = M.link_springref()[L],
+          ld_actcoef = M.link_act_coef()[L], ld_damp = M.link_damping()[L];
+  T kd_M[2], kd_stiff[2], kd_sref[2], kd_mass[2], kd_hx[2], kd_damp[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    kd_M[s] = M.key_M()[Kc[s]]; kd_stiff[s] = M.key_stiffness()[Kc[s]]; kd_sref[s] = M.key_springref()[Kc[s]];
+    kd_mass[s] = M.key_mass()[Kc[s]]; kd_hx[s] = M.key_half()[3 * Kc[s]]; kd_damp[s] = M.key_damping()[Kc[s]];
+  }
+  const auto a_kind = M.act_kind()[A];
+  const auto a_climited = M.act_ctrllimited()[A];
+  const auto a_flimited = M.act_forcelimited()[A];
+  const T a_clo = M.act_ctrlrange()[2 * A], a_chi = M.act_ctrlrange()[2 * A + 1], a_gain = M.act_gain()[A],
+          a_b0 = M.act_bias()[3 * A], a_b1 = M.act_bias()[3 * A + 1], a_b2 = M.act_bias()[3 * A + 2],
+          a_flo = M.act_forcerange()[2 * A], a_fhi = M.act_forcerange()[2 * A + 1];
+  T k_clo[2], k_chi[2], k_gain[2], k_flo[2], k_fhi[2], k_coef[2], k_ctrl[2];
+  bool k_climited[2], k_flimited[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    k_climited[s] = M.act_ctrllimited()[KA[s]] != 0; k_flimited[s] = M.act_forcelimited()[KA[s]] != 0;
+    k_clo[s] = M.act_ctrlrange()[2 * KA[s]]; k_chi[s] = M.act_ctrlrange()[2 * KA[s] + 1]; k_gain[s] = M.act_gain()[KA[s]];
+    k_flo[s] = M.act_forcerange()[2 * KA[s]]; k_fhi[s] = M.act_forcerange()[2 * KA[s] + 1]; k_coef[s] = M.act_coef()[2 * KA[s]];
+    k_ctrl[s] = S.ctrl[(size_t)env * nu + KA[s]];
+  }
+  const T s_ctrl = S.ctrl[(size_t)env * nu + A];
+  const T s_q0 = S.qpos[eo + ldof], s_qd0 = S.qvel[eo + ldof];
+  T s_qk[2], s_qdk[2], s_qappk[2] = {0, 0};
+#pragma unroll
+  for (int s = 0; s < 2; s++) { s_qk[s] = S.qpos[eo + kdof[s]]; s_qdk[s] = S.qvel[eo + kdof[s]]; }
+  T s_qapp0 = 0;
+  if (S.qfrc_applied) {
+    s_qapp0 = S.qfrc_applied[eo + ldof];
+#pragma unroll
+    for (int s = 0; s < 2; s++) s_qappk[s] = S.qfrc_applied[eo + kdof[s]];
+  }
+  T hf[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) hf[i] = LF(i);
+  __builtin_amdgcn_sched_barrier(0);
+  const T lfloss = isl ? ld_floss : (T)0;
+  const T lflR = isl ? ld_flR : (T)1;
   const T lflD = (T)1 / lflR;
   T kM[2];
 #pragma unroll
-  for (int s = 0; s < 2; s++) kM[s] = isk[s] ? M.key_M()[isk[s] ? kid[s] : 0] : (T)1;
+  for (int s = 0; s < 2; s++) kM[s] = isk[s] ? kd_M[s] : (T)1;
   // ---- actuation, passive forces, bias [MJ: mj_fwdActuation, mj_passive] -> qfrc_smooth
   T qfs[3], qs[3];
   {
-    const bool isa = lane < nu && M.act_kind()[lane < nu ? lane : 0] == 0;
-    const int A = lane < nu ? lane : 0;
-    T ctrl = (lane < nu) ? S.ctrl[(size_t)env * nu + lane] : (T)0;
-    if (lane < nu && M.act_ctrllimited()[A])
-      ctrl = fmin(M.act_ctrlrange()[2 * A + 1], fmax(M.act_ctrlrange()[2 * A], ctrl));
+    const bool isa = lane < nu && a_kind == 0;
+    T ctrl = (lane < nu) ? s_ctrl : (T)0;
+    {
+      const T cl_ = fmin(a_chi, fmax(a_clo, ctrl));
+      ctrl = (lane < nu && a_climited) ? cl_ : ctrl;
+    }
     if (isa) {
-      const T alen = LF(1), avel = LF(2);
-      T aforce = M.act_gain()[A] * ctrl + M.act_bias()[3 * A] + M.act_bias()[3 * A + 1] * alen +
-                 M.act_bias()[3 * A + 2] * avel;
-      if (M.act_forcelimited()[A])
-        aforce = fmin(M.act_forcerange()[2 * A + 1], fmax(M.act_forcerange()[2 * A], aforce));
+      const T alen = hf[1], avel = hf[2];
+      T aforce = a_gain * ctrl + a_b0 + a_b1 * alen +
+                 a_b2 * avel;
+      if (a_flimited)
+        aforce = fmin(a_fhi, fmax(a_flo, aforce));
       sm.vec[lane] = aforce;
       S.act_force[(size_t)env * nu + lane] = aforce;
     }
     WSYNC();
-    const T qbias = LF(0);
-    const T q0 = isl ? S.qpos[eo + ldof] : (T)0, qd0 = isl ? S.qvel[eo + ldof] : (T)0;
-    const T qapp0 = (isl && S.qfrc_applied) ? S.qfrc_applied[eo + ldof] : (T)0;
-    const T lstiff = isl ? M.link_stiffness()[L] : (T)0, lsref = isl ? M.link_springref()[L] : (T)0;
-    const T lactcoef = isl ? M.link_act_coef()[L] : (T)0;
+    const T qbias = hf[0];
+    const T q0 = isl ? s_q0 : (T)0, qd0 = isl ? s_qd0 : (T)0;
+    const T qapp0 = isl ? s_qapp0 : (T)0;
+    const T lstiff = isl ? ld_stiff : (T)0, lsref = isl ? ld_sref : (T)0;
+    const T lactcoef = isl ? ld_actcoef : (T)0;
     const T qact = (isl && lact >= 0) ? lactcoef * sm.vec[lact >= 0 ? lact : 0] : (T)0;
-    const T qpas = -lstiff * (q0 - lsref) - (isl ? M.link_damping()[L] : (T)0) * qd0;
+    const T qpas = -lstiff * (q0 - lsref) - (isl ? ld_damp : (T)0) * qd0;
     qfs[0] = isl ? (qpas - qbias + qapp0 + qact) : (T)0;
-    const T ksin[2] = {LF(3), isk[1] ? LF(4) : (T)0}, kcos[2] = {LF(5), isk[1] ? LF(6) : (T)1};
+    const T ksin[2] = {hf[3], isk[1] ? hf[4] : (T)0}, kcos[2] = {hf[5], isk[1] ? hf[6] : (T)1};
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-      const int K = isk[s] ? kid[s] : 0;
-      const T kstiff = isk[s] ? M.key_stiffness()[K] : (T)0, ksref = isk[s] ? M.key_springref()[K] : (T)0;
-      const T kmass = isk[s] ? M.key_mass()[K] : (T)0, khx = isk[s] ? M.key_half()[3 * K] : (T)0;
-      const T qk = isk[s] ? S.qpos[eo + kdof[s]] : (T)0, qdk = isk[s] ? S.qvel[eo + kdof[s]] : (T)0;
-      const T qappk = (isk[s] && S.qfrc_applied) ? S.qfrc_applied[eo + kdof[s]] : (T)0;
+      const T kstiff = isk[s] ? kd_stiff[s] : (T)0, ksref = isk[s] ? kd_sref[s] : (T)0;
+      const T kmass = isk[s] ? kd_mass[s] : (T)0, khx = isk[s] ? kd_hx[s] : (T)0;
+      const T qk = isk[s] ? s_qk[s] : (T)0, qdk = isk[s] ? s_qdk[s] : (T)0;
+      const T qappk = isk[s] ? s_qappk[s] : (T)0;
       const T grav = -kmass * M.gz * khx * kcos[s] - kmass * M.gx * khx * ksin[s];
-      T f = -kstiff * (qk - ksref) - (isk[s] ? M.key_damping()[K] : (T)0) * qdk + grav + qappk;
-      if (isk[s] && kact[s] >= 0) {
-        T c = S.ctrl[(size_t)env * nu + kact[s]];
-        if (M.act_ctrllimited()[kact[s]])
-          c = fmin(M.act_ctrlrange()[2 * kact[s] + 1], fmax(M.act_ctrlrange()[2 * kact[s]], c));
-        T af = M.act_gain()[kact[s]] * c;
-        if (M.act_forcelimited()[kact[s]])
-          af = fmin(M.act_forcerange()[2 * kact[s] + 1], fmax(M.act_forcerange()[2 * kact[s]], af));
-        f += M.act_coef()[2 * kact[s]] * af;
-        S.act_force[(size_t)env * nu + kact[s]] = af;
+      T f = -kstiff * (qk - ksref) - (isk[s] ? kd_damp[s] : (T)0) * qdk + grav + qappk;
+      {
+        const bool on = isk[s] && kact[s] >= 0;
+        T c = k_ctrl[s];
+        {
+          const T cl_ = fmin(k_chi[s], fmax(k_clo[s], c));
+          c = k_climited[s] ? cl_ : c;
+        }
+        T af = k_gain[s] * c;
+        {
+          const T al_ = fmin(k_fhi[s], fmax(k_flo[s], af));
+          af = k_flimited[s] ? al_ : af;
+        }
+        const T f2 = f + k_coef[s] * af;
+        f = on ? f2 : f;
+        if (on) S.act_force[(size_t)env * nu + kact[s]] = af;
       }
       qfs[1 + s] = f;
       qs[1 + s] = f / kM[s];
@@ -437,19 +515,24 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
     PROF(33);
     WSYNC();
     if (isl && pos < 0) {
+      // (the five chains' records read together, then added in the old order: a predicated block per chain was five
+      // dependent round trips per solve)
       const int tro = depth * (depth + 1) / 2;
+      T dv[5][TC], dr[5];
 #pragma unroll
       for (int c = 0; c < 5; c++) {
         const T* st = sm.stage[(ltree & 1) * 5 + c];
-        T dv[TC];
 #pragma unroll
-        for (int e = 0; e < TC; e++) dv[e] = st[tro + e < 10 ? tro + e : 9];
-        const T dr = st[10 + depth];
-        if ((tp.chainmask >> c) & 1) {
+        for (int e = 0; e < TC; e++) dv[c][e] = st[tro + e < 10 ? tro + e : 9];
+        dr[c] = st[10 + depth];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int e = 0; e < TC; e++) if (e <= depth) Rr[e] += dv[e];
-          rhs += dr;
-        }
+      for (int c = 0; c < 5; c++) {
+        const bool on = (tp.chainmask >> c) & 1;
+#pragma unroll
+        for (int e = 0; e < TC; e++) { const T t_ = Rr[e] + dv[c][e]; Rr[e] = (on && e <= depth) ? t_ : Rr[e]; }
+        { const T t_ = rhs + dr[c]; rhs = on ? t_ : rhs; }
       }
     }
     PROF(34);
@@ -565,9 +648,16 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
       WSYNC();
       if (isslot && !dirty) {
         x = rhs / Dslot;
+        // (reads together, then the terms in the old order: a predicated pair of reads per ancestor was nine dependent round trips)
+        T rr_[MD], xx_[MD];
 #pragma unroll
-        for (int e = 0; e < MD; e++)
-          if (e <= sdepth) x -= sm.R[lane][e] * sm.xs[anc_of(salink, sdepth, sTL, sTB, e)];
+        for (int e = 0; e < MD; e++) {
+          const int ee = e <= sdepth ? e : 0;
+          rr_[e] = sm.R[lane][ee]; xx_[e] = sm.xs[anc_of(salink, sdepth, sTL, sTB, ee)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < MD; e++) { const T t_ = x - rr_[e] * xx_[e]; x = e <= sdepth ? t_ : x; }
       }
     }
     WSYNC();
