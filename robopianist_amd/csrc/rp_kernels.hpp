@@ -212,6 +212,9 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
   // one 64-byte topology record per link lane (engine_tables.py: eng_lane_topo), so that
   // the prologue is a single batch of independent loads instead of a chain of lookups
   int tp[16];
+  // (the key tables are requested with the topology record -- clamped indices, selected below -- and the state with
+  // one more batch: read under their predicates they were seven dependent trips to L2 in front of the first useful instruction)
+  int kdof_raw[2], kact_raw[2];
   {
     const int4* rec = (const int4*)(M.lane_topo() + 16 * L);
 #pragma unroll
@@ -219,6 +222,12 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       const int4 v = rec[q];
       tp[4 * q] = v.x; tp[4 * q + 1] = v.y; tp[4 * q + 2] = v.z; tp[4 * q + 3] = v.w;
     }
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const int K = (lane + 64 * s) < M.nkey ? lane + 64 * s : 0;
+      kdof_raw[s] = M.key_dof()[K]; kact_raw[s] = M.key_act()[K];
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
   // (not const: the position stage re-reads the record after the collision phase instead of carrying
   // fourteen integers through it -- it is register-bound there)
@@ -246,8 +255,8 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
   int kdof[2], kact[2];
 #pragma unroll
   for (int s = 0; s < 2; s++) {
-    kdof[s] = isk[s] ? M.key_dof()[kid[s]] : 0;
-    kact[s] = isk[s] ? M.key_act()[kid[s]] : -1;
+    kdof[s] = isk[s] ? kdof_raw[s] : 0;
+    kact[s] = isk[s] ? kact_raw[s] : -1;
   }
 // Per-lane model constants are re-read from the (L2-resident) tables inside the stage
 // that uses them instead of being pinned in registers for the whole kernel: the kernel
@@ -327,15 +336,24 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
   // ------------------------------------------------------------------- state
   const size_t eo = (size_t)env * nv;
   T q[3], qd[3], qw[3], qapp[3];
-  q[0] = isl ? S.qpos[eo + ldof] : (T)0; qd[0] = isl ? S.qvel[eo + ldof] : (T)0;
-  qw[0] = isl ? S.warm[eo + ldof] : (T)0;
-  qapp[0] = (isl && S.qfrc_applied) ? S.qfrc_applied[eo + ldof] : (T)0;
+  {
+    // (ldof / kdof are 0 for lanes without the dof: every address is the env's own state)
+    T q_[3], qd_[3], qw_[3], qa_[3] = {0, 0, 0};
+    q_[0] = S.qpos[eo + ldof]; qd_[0] = S.qvel[eo + ldof]; qw_[0] = S.warm[eo + ldof];
 #pragma unroll
-  for (int s = 0; s < 2; s++) {
-    q[1 + s] = isk[s] ? S.qpos[eo + kdof[s]] : (T)0;
-    qd[1 + s] = isk[s] ? S.qvel[eo + kdof[s]] : (T)0;
-    qw[1 + s] = isk[s] ? S.warm[eo + kdof[s]] : (T)0;
-    qapp[1 + s] = (isk[s] && S.qfrc_applied) ? S.qfrc_applied[eo + kdof[s]] : (T)0;
+    for (int s = 0; s < 2; s++) { q_[1 + s] = S.qpos[eo + kdof[s]]; qd_[1 + s] = S.qvel[eo + kdof[s]]; qw_[1 + s] = S.warm[eo + kdof[s]]; }
+    if (S.qfrc_applied) {
+      qa_[0] = S.qfrc_applied[eo + ldof];
+#pragma unroll
+      for (int s = 0; s < 2; s++) qa_[1 + s] = S.qfrc_applied[eo + kdof[s]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    q[0] = isl ? q_[0] : (T)0; qd[0] = isl ? qd_[0] : (T)0; qw[0] = isl ? qw_[0] : (T)0; qapp[0] = isl ? qa_[0] : (T)0;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      q[1 + s] = isk[s] ? q_[1 + s] : (T)0; qd[1 + s] = isk[s] ? qd_[1 + s] : (T)0;
+      qw[1 + s] = isk[s] ? qw_[1 + s] : (T)0; qapp[1 + s] = isk[s] ? qa_[1 + s] : (T)0;
+    }
   }
   T ctrl = (lane < nu) ? S.ctrl[(size_t)env * nu + lane] : (T)0;
   if (lane < nu && M.act_ctrllimited()[A])
@@ -2279,12 +2297,29 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
             oi[0] = iA; oi[1] = iB; oi[2] = igA; oi[3] = igB;
           }
         };
+        // (the first result record of every candidate is requested together with the geom tables above: one trip to L2
+        // instead of two)
+        T r0v[11];
+        {
+          const T* r0p = res_ + (size_t)rb * 12;
+#pragma unroll
+          for (int k = 0; k < 11; k++) r0v[k] = r0p[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         const int nslot = __ballot(n > 3) != 0ull ? 8 : 3;
         for (int slot = 0; slot < nslot; slot++) {
           const bool has = n > slot;
           const unsigned long long mk = __ballot(has);
           if (mk == 0ull) continue;
-          const T* r = res_ + (size_t)(rb + (has ? slot : 0)) * 12;
+          T r[11];
+          if (slot == 0) {
+#pragma unroll
+            for (int k = 0; k < 11; k++) r[k] = r0v[k];
+          } else {
+            const T* rg = res_ + (size_t)(rb + (has ? slot : 0)) * 12;
+#pragma unroll
+            for (int k = 0; k < 11; k++) r[k] = rg[k];
+          }
           const int idx = ncon + __popcll(mk & lanemask_lt(lane));
           if (has && idx < NCX) put(idx, r);
           if (ncon + __popcll(mk) > NCX) {
@@ -2372,10 +2407,16 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
 #pragma unroll
         for (int k = 0; k < 3; k++) con_n[k] = conf(3 + k);
         make_frame(con_n, con_t1, con_t2);
-        if (con_A >= 0 && con_A < RPK_KEYBASE)
-          con_maskA = ((unsigned long long)M.link_ancmask_u()[2 * con_A + 1] << 32) | M.link_ancmask_u()[2 * con_A];
-        if (con_B >= 0 && con_B < RPK_KEYBASE)
-          con_maskB = ((unsigned long long)M.link_ancmask_u()[2 * con_B + 1] << 32) | M.link_ancmask_u()[2 * con_B];
+        {
+          // (both bodies' ancestor masks requested together, clamped indices, selected afterwards)
+          const bool la_ = con_A >= 0 && con_A < RPK_KEYBASE, lb_ = con_B >= 0 && con_B < RPK_KEYBASE;
+          const int ia_ = la_ ? con_A : 0, ib_ = lb_ ? con_B : 0;
+          const unsigned a0_ = M.link_ancmask_u()[2 * ia_], a1_ = M.link_ancmask_u()[2 * ia_ + 1];
+          const unsigned b0_ = M.link_ancmask_u()[2 * ib_], b1_ = M.link_ancmask_u()[2 * ib_ + 1];
+          __builtin_amdgcn_sched_barrier(0);
+          if (la_) con_maskA = ((unsigned long long)a1_ << 32) | a0_;
+          if (lb_) con_maskB = ((unsigned long long)b1_ << 32) | b0_;
+        }
       }
     }
     // ======================================================================
@@ -2605,9 +2646,9 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     }
     // ---- bias forces: recursive Newton-Euler with gravity as base acceleration [MJ: mj_rne]
     T ca[6] = {0, 0, 0, 0, 0, 0};
+    const T gscale = fresh(M.link_gscale())[L];   // (once, in front of the level loop: inside it every level waited for its own trip to L2)
     for (int d = 0; d < M.maxdepth; d++) {
       if (isl && depth == d) {
-        const T gscale = fresh(M.link_gscale())[L];
         T pa[6] = {0, 0, 0, -M.gx * gscale, -M.gy * gscale, -M.gz * gscale};
         if (parent >= 0) {
 #pragma unroll
