@@ -832,9 +832,7 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
   auto gauss = [&]() -> T { return (T)0.5 * (r0 * dq[0] + kM[0] * dq[1] * dq[1] + kM[1] * dq[2] * dq[2]); };
   // (M x) of my hand dof with the tree-sparse rows: the row part from this lane's own row, the column part
   // (descendants) scattered by the descendants with LDS adds.  Keys: M is diagonal (kM).
-  auto mulM0 = [&](T x0) -> T {
-    T Mr[MD + 1];
-    load_Mr(Mr);
+  auto mulM0 = [&](T x0, const T* Mr) -> T {   // (Mr: my mass-matrix row, load_Mr -- requested by the caller ahead of time)
     const Topo tp = topo();
     const int pos = isl ? tp.depth - tp.TL : -2;
     // every link publishes its products M[me][a] x_me (a = my ancestors; sm.R is free outside the factorisation)
@@ -939,7 +937,9 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
       RowsL jtmp;
       mulJ(qs, jtmp); sub_aref(jtmp);
       const T cost_smooth = uni(wave_sum(update(jtmp)));
-      const T Mw = mulM0(qw[0]);
+      T Mrw[MD + 1];
+      load_Mr(Mrw);
+      const T Mw = mulM0(qw[0], Mrw);
       mulJ(qw, jar); sub_aref(jar);
       r0 = Mw - qfs[0];
 #pragma unroll
@@ -1113,6 +1113,9 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
       WSYNC();
       PROF(4);
       const T x = tree_solve(Rr, sdiag, rhs, nkt, dmx);
+      // (the mass-matrix row of M * search: its trip to L2 runs under the slot exchange and the two wave sums below)
+      T Mrs[MD + 1];
+      load_Mr(Mrs);
       T search[3];
       search[0] = isl ? -x : (T)0;
       if (isslot) sm.slotv[0][lane - nl] = -x;
@@ -1130,7 +1133,7 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
       if (!(snorm >= RPK_MINVAL)) break;
       // phi'(0) = grad . search (before grad goes out of use)
       const T f0g = uni(wave_sum(grad[0] * search[0] + grad[1] * search[1] + grad[2] * search[2]));
-      const T Mv0 = mulM0(search[0]);
+      const T Mv0 = mulM0(search[0], Mrs);
       PROF(35);
       RowsL jv;
       mulJ(search, jv);
