@@ -1502,6 +1502,10 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     for (int k = 0; k < 9; k++) gmat[k] = M.geom_mat()[9 * G_ + k];
     const T gbc0 = M.geom_bcap()[2 * G_], gbc1 = M.geom_bcap()[2 * G_ + 1];
     const T gsz[3] = {M.geom_size()[3 * G_], M.geom_size()[3 * G_ + 1], M.geom_size()[3 * G_ + 2]};
+    // (... and the broad phase's: bounding radius, pair mask, key-capable flag)
+    const T grb_ = M.geom_rbound()[G_];
+    const unsigned gpm0_ = (unsigned)M.geom_pairmask()[2 * G_], gpm1_ = (unsigned)M.geom_pairmask()[2 * G_ + 1];
+    const auto gkc_ = M.geom_iskeycap()[G_];
     __builtin_amdgcn_sched_barrier(0);
     if (isg) {
       const int gl = ggl;
@@ -1557,11 +1561,9 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     const bool isg = lane < M.ngeom;
     const float fcx = isg ? (float)sm.gpos[lane][0] : 0.f, fcy = isg ? (float)sm.gpos[lane][1] : 0.f,
                 fcz = isg ? (float)sm.gpos[lane][2] : 0.f;
-    const float frb = isg ? (float)M.geom_rbound()[lane] * 1.0001f + 1e-6f : 0.f;
-    const unsigned long long gpm =
-        isg ? (((unsigned long long)(unsigned)M.geom_pairmask()[2 * lane + 1] << 32) | (unsigned)M.geom_pairmask()[2 * lane])
-            : 0ull;
-    const bool gkc = isg && M.geom_iskeycap()[lane] != 0;
+    const float frb = isg ? (float)grb_ * 1.0001f + 1e-6f : 0.f;
+    const unsigned long long gpm = isg ? (((unsigned long long)gpm1_ << 32) | gpm0_) : 0ull;
+    const bool gkc = isg && gkc_ != 0;
     const float fax = isg ? sm.gax[lane][0] : 0.f, fay = isg ? sm.gax[lane][1] : 0.f, faz = isg ? sm.gax[lane][2] : 0.f;
     const float fhl = isg ? sm.gax[lane][3] : 0.f, frr = isg ? sm.grr[lane] : 0.f;
     unsigned hitlo = 0, hithi = 0;
@@ -1611,7 +1613,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
           gex = fabsf(gb_[0]) * gb_[9] + fabsf(gb_[1]) * gb_[10] + fabsf(gb_[2]) * gb_[11] + 1e-4f;
           gey = fabsf(gb_[3]) * gb_[9] + fabsf(gb_[4]) * gb_[10] + fabsf(gb_[5]) * gb_[11] + 1e-4f;
           gez = fabsf(gb_[6]) * gb_[9] + fabsf(gb_[7]) * gb_[10] + fabsf(gb_[8]) * gb_[11] + 1e-4f;
-        } else if (isg && lane < ncap && M.geom_type()[lane] == GEOM_CAPSULE_) {
+        } else if (isg && lane < ncap && gty == GEOM_CAPSULE_) {
           // (fp32 with an allowance of 0.1 mm + 1e-4 of the size: the cull only has to be a superset)
           gex = fminf(frb, (fabsf(fax) * fhl + frr) * 1.0001f + 1e-4f);
           gey = fminf(frb, (fabsf(fay) * fhl + frr) * 1.0001f + 1e-4f);
@@ -2376,6 +2378,8 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     }
     PROF(13);
     // ---- solver slots for touched keys
+    int dpA_ = -1, dpB_ = -1;   // depths of my contact's two links (read with their ancestor masks)
+    T khx_pre = 0, khz_pre = 0;  // slot lanes: hinge line of my key (read with the anchor's topology record)
     {
       int kb = -1;
       if (lane < ncon) {
@@ -2398,6 +2402,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       con_slot = kb >= 0 ? sm.keyslot[kb] : -1;
       // per-contact registers
       con_A = -1; con_B = -1; con_D = 0; con_mu = 0; con_maskA = 0; con_maskB = 0;
+      dpA_ = -1; dpB_ = -1;
       if (lane < ncon) {
         con_A = coni(0); con_B = coni(1);
         con_mu = conf(7);
@@ -2413,9 +2418,10 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
           const int ia_ = la_ ? con_A : 0, ib_ = lb_ ? con_B : 0;
           const unsigned a0_ = M.link_ancmask_u()[2 * ia_], a1_ = M.link_ancmask_u()[2 * ia_ + 1];
           const unsigned b0_ = M.link_ancmask_u()[2 * ib_], b1_ = M.link_ancmask_u()[2 * ib_ + 1];
+          const int da_ = M.link_depth()[ia_], db_ = M.link_depth()[ib_];   // (for the key anchors below)
           __builtin_amdgcn_sched_barrier(0);
-          if (la_) con_maskA = ((unsigned long long)a1_ << 32) | a0_;
-          if (lb_) con_maskB = ((unsigned long long)b1_ << 32) | b0_;
+          if (la_) { con_maskA = ((unsigned long long)a1_ << 32) | a0_; dpA_ = da_; }
+          if (lb_) { con_maskB = ((unsigned long long)b1_ << 32) | b0_; dpB_ = db_; }
         }
       }
     }
@@ -2450,7 +2456,7 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       // pressing the same key must lie on the anchor's chain
       const int mylink = (con_A >= 0 && con_A < RPK_KEYBASE) ? con_A : ((con_B >= 0 && con_B < RPK_KEYBASE) ? con_B : -1);
       const unsigned long long mymask = con_maskA | con_maskB;
-      const int mydepthc = (lane < ncon && mylink >= 0) ? M.link_depth()[mylink] : -1;
+      const int mydepthc = (lane < ncon && mylink >= 0) ? (mylink == bodyA ? dpA_ : dpB_) : -1;
       for (int sidx = 0; sidx < nkt; sidx++) {
         int cand = (lane < ncon && con_slot == sidx && mylink >= 0) ? ((mydepthc << 8) | lane) : -1;
         cand = wave_max(cand);
@@ -2483,11 +2489,18 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       WSYNC();
       sdepth = -1;
       if (!isl && lane < nl + nkt) {
-        int al = sm.slotlink[lane - nl];
+        // (the anchor's topology record and the key's hinge line in one trip to L2; the hinge line is used by the Jacobian
+        // pass below)
+        const int al = sm.slotlink[lane - nl];
+        const int k_ = sm.slotkey[lane - nl];
+        const int* rec = M.lane_topo() + 16 * (al >= 0 ? al : 0);
+        const int rc1 = rec[1], rc6 = rec[6], rc7 = rec[7];
+        const T kp0 = M.key_pos()[3 * k_], kh0 = M.key_half()[3 * k_], kp2 = M.key_pos()[3 * k_ + 2];
+        __builtin_amdgcn_sched_barrier(0);
+        khx_pre = kp0 - kh0; khz_pre = kp2;
         if (al >= 0) {
-          const int* rec = M.lane_topo() + 16 * al;
-          sdepth = rec[1];
-          salink = al; sTB = rec[6]; sTL = rec[7];
+          sdepth = rc1;
+          salink = al; sTB = rc6; sTL = rc7;
         }
       }
     }
@@ -2547,8 +2560,8 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
       } else if (lane < nl + nkt) {
         const int k = sm.slotkey[lane - nl];
         xv = sm.keyvec[0][k];
-        khx_ = M.key_pos()[3 * k] - M.key_half()[3 * k];  // hinge line x, z
-        khz_ = M.key_pos()[3 * k + 2];
+        khx_ = khx_pre;  // hinge line x, z
+        khz_ = khz_pre;
       }
       for (int c = 0; c < ncon; c++) {
         const unsigned long long sc = ((unsigned long long)(unsigned)bcast((int)(sup >> 32), c) << 32) |

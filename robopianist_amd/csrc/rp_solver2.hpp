@@ -172,16 +172,23 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
   // is used instead of holding 20 registers through the Newton loop
   auto Mrow = [&]() -> const T* { return fresh(B.RM) + ((size_t)env * RPK_NLX(MD) + L) * (MD + 1); };
   // ... in the local column layout of the tree solve (see there), plus `add` on my diagonal
-  auto load_Mlocal = [&](T* Rl, const T add) {
+  // (in two steps so that the Newton loop can request the row one phase ahead of its use)
+  auto fetch_Mlocal = [&](T* Rl) {
     const Topo tp = topo();
     const int pos = isl ? tp.depth - tp.TL : -2;
-    const int shift = (isl && pos >= 0) ? tp.TL - TC : 0, kd = pos >= 0 ? TC + pos : tp.depth;
+    const int shift = (isl && pos >= 0) ? tp.TL - TC : 0;
     const T* row = Mrow();
 #pragma unroll
     for (int k = 0; k <= MD; k++) Rl[k] = isl ? row[k < TC ? k : k + shift] : (T)0;
+  };
+  auto finish_Mlocal = [&](T* Rl, const T add) {
+    const Topo tp = topo();
+    const int pos = isl ? tp.depth - tp.TL : -2;
+    const int kd = pos >= 0 ? TC + pos : tp.depth;
 #pragma unroll
     for (int k = 0; k < MD; k++) if (isl && k == kd) Rl[k] += add;
   };
+  auto load_Mlocal = [&](T* Rl, const T add) { fetch_Mlocal(Rl); finish_Mlocal(Rl, add); };
   auto load_Mr = [&](T* Mr) {
     const T* row = fresh(B.RM) + ((size_t)env * RPK_NLX(MD) + L) * (MD + 1);
 #pragma unroll
@@ -318,6 +325,8 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
   T hf[7];
 #pragma unroll
   for (int i = 0; i < 7; i++) hf[i] = LF(i);
+  T Rr_s[MD + 1];   // (my mass-matrix row for the qacc_smooth solve that follows this phase)
+  fetch_Mlocal(Rr_s);
   __builtin_amdgcn_sched_barrier(0);
   const T lfloss = isl ? ld_floss : (T)0;
   const T lflR = isl ? ld_flR : (T)1;
@@ -666,9 +675,8 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
 
   // ---- qacc_smooth = M^-1 qfrc_smooth (M is always tree-sparse)
   {
-    T Rr[MD + 1];
-    load_Mlocal(Rr, (T)0);
-    qs[0] = tree_solve(Rr, (T)0, qfs[0], 0, 0ull);
+    finish_Mlocal(Rr_s, (T)0);
+    qs[0] = tree_solve(Rr_s, (T)0, qfs[0], 0, 0ull);
   }
   PROF(2);
 
@@ -1313,33 +1321,52 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
   }
   PROF(8);
   // ---- Euler with implicit joint damping [MJ: mj_Euler, eulerdamp]; qfrc_smooth comes back from its parking slots
+  // (the epilogue's reads in two batches IN FRONT of the last solve -- dof indices, parked forces, damping, my mass-matrix
+  // row; then the state at those indices -- so that their trips to L2 run under the solve: read where they were used they
+  // were nine dependent trips behind it)
   T qe[3];
+  const int e_ld = fresh(M.lane_topo())[16 * L + 5];   // my dof
+  int e_kd[2];
+  T e_fk[2], e_kdamp[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const int K = isk[s] ? kid[s] : 0;
+    e_kd[s] = M.key_dof()[K]; e_kdamp[s] = M.key_damping()[K];
+  }
+  e_fk[0] = LF(3); e_fk[1] = LF(4);
+  const T e_f0 = LF(0);
+  const T e_ldamp = M.link_damping()[L];
+  T Rr_e[MD + 1];
+  fetch_Mlocal(Rr_e);
+  __builtin_amdgcn_sched_barrier(0);
+  const T e_qv0 = S.qvel[eo + e_ld], e_qp0 = S.qpos[eo + e_ld], e_w0 = S.warm[eo + e_ld];
+  T e_qvk[2], e_qpk[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) { e_qvk[s] = S.qvel[eo + e_kd[s]]; e_qpk[s] = S.qpos[eo + e_kd[s]]; }
+  __builtin_amdgcn_sched_barrier(0);
   {
-    const T f0_ = LF(0);
-    const T ldamp = isl ? M.link_damping()[L] : (T)0;
-    T Rr[MD + 1];
-    load_Mlocal(Rr, h * ldamp);
-    qe[0] = tree_solve(Rr, (T)0, f0_ + qfc[0], 0, 0ull);
+    const T f0_ = e_f0;
+    const T ldamp = isl ? e_ldamp : (T)0;
+    finish_Mlocal(Rr_e, h * ldamp);
+    qe[0] = tree_solve(Rr_e, (T)0, f0_ + qfc[0], 0, 0ull);
   }
   PROF(9);
-  // ---- new state (qpos / qvel are re-read here: nothing above needed them after the passive forces;
-  // S.warm holds qacc_smooth of my hand dof, the keys' is qfrc_smooth / kM)
+  // ---- new state (S.warm holds qacc_smooth of my hand dof, the keys' is qfrc_smooth / kM)
   if (isl) {
-    const int ld = fresh(M.lane_topo())[16 * L + 5];   // my dof
-    const T qd0 = S.qvel[eo + ld] + h * qe[0];
+    const int ld = e_ld;
+    const T qd0 = e_qv0 + h * qe[0];
     S.qvel[eo + ld] = qd0;
-    S.qpos[eo + ld] += h * qd0;
-    S.warm[eo + ld] += dq[0];
+    S.qpos[eo + ld] = e_qp0 + h * qd0;
+    S.warm[eo + ld] = e_w0 + dq[0];
   }
 #pragma unroll
   for (int s = 0; s < 2; s++) if (isk[s]) {
-    const int K = kid[s];
-    const int kd = M.key_dof()[K];
-    const T fk = s == 0 ? LF(3) : LF(4);
-    const T qek = (fk + qfc[1 + s]) / (kM[s] + h * M.key_damping()[K]);
-    const T qdk = S.qvel[eo + kd] + h * qek;
+    const int kd = e_kd[s];
+    const T fk = e_fk[s];
+    const T qek = (fk + qfc[1 + s]) / (kM[s] + h * e_kdamp[s]);
+    const T qdk = e_qvk[s] + h * qek;
     S.qvel[eo + kd] = qdk;
-    S.qpos[eo + kd] += h * qdk;
+    S.qpos[eo + kd] = e_qpk[s] + h * qdk;
     S.warm[eo + kd] = fk / kM[s] + dq[1 + s];
   }
   {
