@@ -1100,13 +1100,16 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
 #endif
           for (int k0 = 0; k0 < maxm; k0 += 4) {
             int mb[4];
-            T val[4];
+            T val[4], jq[4][3];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
               const int b = base + k0 + u < nent ? base + k0 + u : nent - 1;
               mb[u] = sm.entM[b][0];
-              val[u] = u0 * sm.entJ[b][0] + u1 * sm.entJ[b][1] + u2 * sm.entJ[b][2];
+              jq[u][0] = sm.entJ[b][0]; jq[u][1] = sm.entJ[b][1]; jq[u][2] = sm.entJ[b][2];
             }
+            __builtin_amdgcn_sched_barrier(0);   // (the four entries' reads in flight together)
+#pragma unroll
+            for (int u = 0; u < 4; u++) val[u] = u0 * jq[u][0] + u1 * jq[u][1] + u2 * jq[u][2];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
 #ifdef RPK_NO_T7
