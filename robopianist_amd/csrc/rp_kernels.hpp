@@ -1559,13 +1559,17 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
     ncon = 0;
     {
     const bool isg = lane < M.ngeom;
-    const float fcx = isg ? (float)sm.gpos[lane][0] : 0.f, fcy = isg ? (float)sm.gpos[lane][1] : 0.f,
-                fcz = isg ? (float)sm.gpos[lane][2] : 0.f;
+    // (read unconditionally and selected: a predicated LDS read per value was eight dependent round trips)
+    const T gq0_ = sm.gpos[lane][0], gq1_ = sm.gpos[lane][1], gq2_ = sm.gpos[lane][2];
+    const float ga0_ = sm.gax[lane][0], ga1_ = sm.gax[lane][1], ga2_ = sm.gax[lane][2], ga3_ = sm.gax[lane][3], grr_ = sm.grr[lane];
+    __builtin_amdgcn_sched_barrier(0);
+    const float fcx = isg ? (float)gq0_ : 0.f, fcy = isg ? (float)gq1_ : 0.f,
+                fcz = isg ? (float)gq2_ : 0.f;
     const float frb = isg ? (float)grb_ * 1.0001f + 1e-6f : 0.f;
     const unsigned long long gpm = isg ? (((unsigned long long)gpm1_ << 32) | gpm0_) : 0ull;
     const bool gkc = isg && gkc_ != 0;
-    const float fax = isg ? sm.gax[lane][0] : 0.f, fay = isg ? sm.gax[lane][1] : 0.f, faz = isg ? sm.gax[lane][2] : 0.f;
-    const float fhl = isg ? sm.gax[lane][3] : 0.f, frr = isg ? sm.grr[lane] : 0.f;
+    const float fax = isg ? ga0_ : 0.f, fay = isg ? ga1_ : 0.f, faz = isg ? ga2_ : 0.f;
+    const float fhl = isg ? ga3_ : 0.f, frr = isg ? grr_ : 0.f;
     unsigned hitlo = 0, hithi = 0;
 #pragma unroll
     for (int j0 = 0; j0 < 64; j0 += 8) {
@@ -1694,8 +1698,11 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         const float kx_ = s1 ? tx1 : tx0, kz_ = s1 ? tz1 : tz0;
         const int kk = k < nk ? k : 0;
         const T *kp_ = M.key_pos() + 3 * kk, *kh_ = M.key_half() + 3 * kk;
-        const float kpx_ = (float)kp_[0], kpy_ = (float)kp_[1], ktop_ = (float)(kp_[2] + kh_[2]) + 0.01f;
-        const float khx2 = (float)kh_[0] + 0.01f, khy2 = (float)kh_[1], krb2 = (float)M.key_rbound()[kk] * 1.0001f + 1e-6f;
+        // (the key's seven constants in one trip to L2: read where they were used they were three)
+        const T kp0_ = kp_[0], kp1_ = kp_[1], kp2_ = kp_[2], kh0_ = kh_[0], kh1_ = kh_[1], kh2_ = kh_[2], krbr_ = M.key_rbound()[kk];
+        __builtin_amdgcn_sched_barrier(0);
+        const float kpx_ = (float)kp0_, kpy_ = (float)kp1_, ktop_ = (float)(kp2_ + kh2_) + 0.01f;
+        const float khx2 = (float)kh0_ + 0.01f, khy2 = (float)kh1_, krb2 = (float)krbr_ * 1.0001f + 1e-6f;
         const float dx = kx_ - fcx, dy = kpy_ - fcy, dz = kz_ - fcz, rr = frb + krb2;
         // bounding spheres, then a conservative box test (the key only rotates about
         // y, so its y-extent is exact; x/z get a 1 cm allowance)
