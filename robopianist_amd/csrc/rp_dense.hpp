@@ -67,15 +67,16 @@ __device__ T dense_factor_solve(T* H, int n, int lane, int* warn) {
     const T* r2 = H + tri(j + 2, 0);
     const T* r3 = H + tri(j + 3, 0);
     T s0 = ri[j], s1 = ri[j + 1], s2 = ri[j + 2], s3 = ri[j + 3];
-    for (int p = 0; p < j; p += RPK_DENSE_PTRIP) {  // j is a multiple of 4 here; p per trip: LDS round trips against live registers
-      T a[RPK_DENSE_PTRIP], b0[RPK_DENSE_PTRIP], b1[RPK_DENSE_PTRIP], b2[RPK_DENSE_PTRIP], b3[RPK_DENSE_PTRIP];
+    // (fp64 -- the lean solver stage: four p per trip, all reads in flight before the first multiply-add waits; the fp32
+    // build's solver kernel is over its register budget already and keeps two)
+    constexpr int PT = sizeof(T) == 8 ? RPK_DENSE_PTRIP : 2;
+    for (int p = 0; p < j; p += PT) {  // j is a multiple of 4 here; p per trip: LDS round trips against live registers
+      T a[PT], b0[PT], b1[PT], b2[PT], b3[PT];
 #pragma unroll
-      for (int u = 0; u < RPK_DENSE_PTRIP; u++) { a[u] = ri[p + u]; b0[u] = r0[p + u]; b1[u] = r1[p + u]; b2[u] = r2[p + u]; b3[u] = r3[p + u]; }
-#if RPK_DENSE_PTRIP > 2
-      __builtin_amdgcn_sched_barrier(0);   // (all reads of the trip in flight before the first multiply-add waits)
-#endif
+      for (int u = 0; u < PT; u++) { a[u] = ri[p + u]; b0[u] = r0[p + u]; b1[u] = r1[p + u]; b2[u] = r2[p + u]; b3[u] = r3[p + u]; }
+      if constexpr (PT > 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int u = 0; u < RPK_DENSE_PTRIP; u++) {
+      for (int u = 0; u < PT; u++) {
         s0 -= a[u] * b0[u]; s1 -= a[u] * b1[u]; s2 -= a[u] * b2[u]; s3 -= a[u] * b3[u];
       }
     }

@@ -188,7 +188,17 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
 #pragma unroll
     for (int k = 0; k < MD; k++) if (isl && k == kd) Rl[k] += add;
   };
-  auto load_Mlocal = [&](T* Rl, const T add) { fetch_Mlocal(Rl); finish_Mlocal(Rl, add); };
+  // (one piece for the Newton loop's call: in two steps it cost the fused-substeps kernel 900 spilled registers)
+  auto load_Mlocal = [&](T* Rl, const T add) {
+    const Topo tp = topo();
+    const int pos = isl ? tp.depth - tp.TL : -2;
+    const int shift = (isl && pos >= 0) ? tp.TL - TC : 0, kd = pos >= 0 ? TC + pos : tp.depth;
+    const T* row = Mrow();
+#pragma unroll
+    for (int k = 0; k <= MD; k++) Rl[k] = isl ? row[k < TC ? k : k + shift] : (T)0;
+#pragma unroll
+    for (int k = 0; k < MD; k++) if (isl && k == kd) Rl[k] += add;
+  };
   auto load_Mr = [&](T* Mr) {
     const T* row = fresh(B.RM) + ((size_t)env * RPK_NLX(MD) + L) * (MD + 1);
 #pragma unroll
