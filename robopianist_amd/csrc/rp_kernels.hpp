@@ -336,7 +336,20 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
   // ------------------------------------------------------------------- state
   const size_t eo = (size_t)env * nv;
   T q[3], qd[3], qw[3], qapp[3];
-  {
+  if constexpr (MODE != 0) {
+    // (the solver builds keep the reads under their predicates: they are over their register budget, and the batch below
+    // cost the fp32 build 22 more spilled registers)
+    q[0] = isl ? S.qpos[eo + ldof] : (T)0; qd[0] = isl ? S.qvel[eo + ldof] : (T)0;
+    qw[0] = isl ? S.warm[eo + ldof] : (T)0;
+    qapp[0] = (isl && S.qfrc_applied) ? S.qfrc_applied[eo + ldof] : (T)0;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      q[1 + s] = isk[s] ? S.qpos[eo + kdof[s]] : (T)0;
+      qd[1 + s] = isk[s] ? S.qvel[eo + kdof[s]] : (T)0;
+      qw[1 + s] = isk[s] ? S.warm[eo + kdof[s]] : (T)0;
+      qapp[1 + s] = (isk[s] && S.qfrc_applied) ? S.qfrc_applied[eo + kdof[s]] : (T)0;
+    }
+  } else {
     // (ldof / kdof are 0 for lanes without the dof: every address is the env's own state)
     T q_[3], qd_[3], qw_[3], qa_[3] = {0, 0, 0};
     q_[0] = S.qpos[eo + ldof]; qd_[0] = S.qvel[eo + ldof]; qw_[0] = S.warm[eo + ldof];
