@@ -979,6 +979,11 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
       // gradient of the cost: M qacc - qfrc_smooth - J^T f
       const T grad[3] = {r0 - qfc[0], kM[0] * dq[1] - qfc[1], kM[1] * dq[2] - qfc[2]};
       // ---- H = M + J^T D J on the coupled system (hand dofs + touched keys)
+      // rows of H in registers: links in the local column layout of the tree solve, solver slots over the
+      // path of their anchor link (+ `sdiag`).  (My mass-matrix row is requested first: its trip to L2 runs under the
+      // slot / weight hand-over below)
+      T Rr[MD + 1];
+      load_Mlocal(Rr, ((act & 1) ? lflD : (T)0) + (((act >> 1) & 1) ? lim_D[0] : (T)0));
       // key diagonals and gradients to the solver slots
 #pragma unroll
       for (int s = 0; s < 2; s++) {
@@ -1001,11 +1006,7 @@ __device__ __forceinline__ void rp_lean_solver_body(const RpModel<T>& M, const R
       }
       const bool isslot = !isl && lane < nsys;
       WSYNC();
-      // rows of H in registers: links in the local column layout of the tree solve, solver slots over the
-      // path of their anchor link (+ `sdiag`)
-      T Rr[MD + 1];
       T sdiag = 0, rhs = isl ? grad[0] : (T)0;
-      load_Mlocal(Rr, ((act & 1) ? lflD : (T)0) + (((act >> 1) & 1) ? lim_D[0] : (T)0));
       if (isslot) { sdiag = sm.slotv[0][lane - nl]; rhs = sm.slotv[1][lane - nl]; }
       const unsigned long long dmx = dirty_mask;
       if (dmx) {
