@@ -930,9 +930,24 @@ __device__ __forceinline__ void rp_stage_body(const RpModel<T>& M, const RpState
         WSYNC();
         T y = 0;
         if (isl) {
+          // (reads in flight together, terms in the old order: a predicated read per ancestor and a read pair per
+          // descendant were up to 35 dependent LDS round trips for a trunk link)
+          T xa_[MD + 1];
 #pragma unroll
-          for (int e = 0; e <= MD; e++) if (e <= depth) y += Mr[e] * sm.xs[anc_at(e)];
-          for (int j = 1; j <= ndesc; j++) y += sm.RM[lane + j][depth] * sm.xs[lane + j];
+          for (int e = 0; e <= MD; e++) xa_[e] = sm.xs[e <= depth ? anc_at(e) : lane];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e <= MD; e++) { const T t_ = y + Mr[e] * xa_[e]; y = e <= depth ? t_ : y; }
+          int j = 1;
+          for (; j + 3 <= ndesc; j += 4) {
+            T m_[4], x_[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { m_[u] = sm.RM[lane + j + u][depth]; x_[u] = sm.xs[lane + j + u]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; u++) y += m_[u] * x_[u];
+          }
+          for (; j <= ndesc; j++) y += sm.RM[lane + j][depth] * sm.xs[lane + j];
         }
         out[0] = y;
         out[1] = kM[0] * x[1];
