@@ -3,7 +3,7 @@
 `load()` keeps the reference's signature and adds `n_envs`, `device_id`,
 `precision` (64 by default: the reference computes in float64, and only the fp64
 engine tracks the CPU path to the teacher-forced 1e-9; 32 selects the fp32 build, which is NOT faster -- it has
-no lean solver / split-stage schedule, measured 623 k against 667 k env-steps/s -- and exists for memory-bound batch
+no lean solver / split-stage schedule, measured 664 k against 705 k env-steps/s -- and exists for memory-bound batch
 sizes).  It returns a batched dm_env-style Environment whose physics is the HIP engine."""
 
 from pathlib import Path
